@@ -1,0 +1,73 @@
+"""Generate the known-answer fixtures under tests/golden/ from the reference's
+committed demo inputs and reports (run in the authoring container only; the
+GPU box has no /root/reference).
+
+Inputs copied verbatim (data files, not source):
+  data/dbat/pmexports/camcal-pmexport.txt, data/dbat/ref/camcal-fixed.txt
+Expected values parsed from the reference's committed reports:
+  data/dbat/dbatexports/camcal-dbatreport{,-model2..5}.txt
+"""
+import json
+import os
+import re
+import shutil
+
+REF = '/root/reference/data/dbat'
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def parse_report(path):
+    txt = open(path).read()
+    out = {}
+    g = lambda pat: re.search(pat, txt)
+    out['sigma0'] = float(g(r'Sigma0:\s+([-\d.eE+]+)').group(1))
+    out['redundancy'] = int(g(r'Redundancy\s+(\d+)').group(1))
+    m = g(r'Number of params:\s+(\d+) \((\d+) IO, (\d+) EO, (\d+) OP\)')
+    out['numParams'] = int(m.group(1))
+    out['nIO'], out['nEO'], out['nOP'] = int(m.group(2)), int(m.group(3)), int(m.group(4))
+    out['numObs'] = int(g(r'Number of observations:\s+(\d+)').group(1))
+    out['iterations'] = int(g(r'Number of iterations:\s+(\d+)').group(1))
+    out['lastError'] = float(g(r'Last error:\s+([-\d.eE+]+)').group(1))
+    io = {}
+    for key, pat in [('cc', r'Camera Constant:\s+Value:\s+([-\d.eE+]+)'),
+                     ('px', r'px - principal point x:\s+Value:\s+([-\d.eE+]+)'),
+                     ('py', r'py - principal point y:\s+Value:\s+([-\d.eE+]+)'),
+                     ('K1', r'K1 - radial distortion 1:\s+Value:\s+([-\d.eE+]+)'),
+                     ('K2', r'K2 - radial distortion 2:\s+Value:\s+([-\d.eE+]+)'),
+                     ('K3', r'K3 - radial distortion 3:\s+Value:\s+([-\d.eE+]+)'),
+                     ('P1', r'P1 - decentering distortion 1:\s+Value:\s+([-\d.eE+]+)'),
+                     ('P2', r'P2 - decentering distortion 2:\s+Value:\s+([-\d.eE+]+)'),
+                     ('as', r'as - off-unit aspect parameter:\s+Value:\s+([-\d.eE+]+)')]:
+        m = g(pat)
+        if m:
+            io[key] = float(m.group(1))
+    out['IO_report'] = io   # report sign convention: py, K, P flipped vs IO.val
+    photos = []
+    for m in re.finditer(
+            r'Photo \d+: \S+\s+Omega:\s+Value:\s+([-\d.]+) deg\s+Deviation:.*\s+'
+            r'Phi:\s+Value:\s+([-\d.]+) deg\s+Deviation:.*\s+'
+            r'Kappa:\s+Value:\s+([-\d.]+) deg\s+Deviation:.*\s+'
+            r'Xc:\s+Value:\s+([-\d.]+) ou\s+Deviation:.*\s+'
+            r'Yc:\s+Value:\s+([-\d.]+) ou\s+Deviation:.*\s+'
+            r'Zc:\s+Value:\s+([-\d.]+) ou', txt):
+        photos.append([float(v) for v in m.groups()])
+    out['EO_report_deg'] = photos   # omega, phi, kappa [deg], Xc, Yc, Zc
+    return out
+
+
+def main():
+    shutil.copy(os.path.join(REF, 'pmexports/camcal-pmexport.txt'),
+                os.path.join(HERE, 'camcal-pmexport.txt'))
+    shutil.copy(os.path.join(REF, 'ref/camcal-fixed.txt'),
+                os.path.join(HERE, 'camcal-fixed.txt'))
+    exp = {'model3': parse_report(os.path.join(REF, 'dbatexports/camcal-dbatreport.txt'))}
+    for m in (2, 4, 5):
+        exp['model%d' % m] = parse_report(
+            os.path.join(REF, 'dbatexports/camcal-dbatreport-model%d.txt' % m))
+    with open(os.path.join(HERE, 'camcal_expected.json'), 'w') as fh:
+        json.dump(exp, fh, indent=1)
+    print({k: (v['sigma0'], len(v['EO_report_deg'])) for k, v in exp.items()})
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,99 @@
+"""CPU tests that pin the oracle (oracle/dbat_oracle.py) to the reference:
+known answers from the reference's committed reports and the reference's own
+derivative self-test method."""
+import numpy as np
+import pytest
+
+import dbat_oracle as o
+from helpers import camcal_struct, camcal_expected, check_camcal_against_report
+
+
+@pytest.mark.parametrize('model', [2, 3, 4, 5])
+def test_camcal_known_answer_gna(model):
+    exp = camcal_expected()['model%d' % model]
+    res, ok, iters, s0, E = o.bundle(camcal_struct(model), 'gna')
+    assert ok and E.code == 0
+    check_camcal_against_report(res, s0, E, exp)
+    assert abs(E.res[-1] - exp['lastError']) < 5e-4 * 1.01
+
+
+@pytest.mark.parametrize('damping', ['lm', 'lmp', 'gm'])
+def test_camcal_known_answer_other_dampings(damping):
+    exp = camcal_expected()['model3']
+    res, ok, iters, s0, E = o.bundle(camcal_struct(3), damping)
+    assert ok
+    check_camcal_against_report(res, s0, E, exp)
+
+
+@pytest.mark.parametrize('model', [2, 3, 4, 5])
+def test_derivative_selftest(model):
+    """cameramodel/private/full_self_test.m:17-56 with seeded inputs
+    (res_euler_brown_1.m:182-196), thresholds 1e-8 abs or rel."""
+    rng = np.random.default_rng(100 + model)
+    m = 5
+    Q = 3 + rng.random((3, m)); ang = rng.random(3) * np.pi / 6; q0 = rng.random(3)
+    f = 1 + rng.random(); u = rng.random((2, m)); K = rng.random(4); P = rng.random(3)
+    sz = rng.random() / 10; u0 = rng.random(2); b = rng.random(2)
+    v, d = o.res_euler_brown(model, Q, q0, ang, f, u, sz, u0, K, P, b, jac=True)
+    v2 = o.res_euler_brown(model, Q, q0, ang, f, u, sz, u0, K, P, b)
+    assert np.abs(v - v2).max() < 1e-14
+    F = lambda **kw: o.res_euler_brown(model, **{**dict(Q=Q, q0=q0, ang=ang, f=f, u=u, sz=sz,
+                                                        u0=u0, K=K, P=P, b=b), **kw}).flatten('F')
+    cases = {'dQ0': ('q0', q0), 'dA': ('ang', ang), 'dU0': ('u0', u0), 'dK': ('K', K),
+             'dP': ('P', P), 'dB': ('b', b)}
+    for name, (arg, x0) in cases.items():
+        Jn = o.jacapprox(lambda x: F(**{arg: x}), x0)
+        Ja = d[name].reshape(-1, d[name].shape[2])
+        err = np.abs(Jn - Ja).max()
+        assert err < 1e-8 or err / np.abs(Jn).max() < 1e-8, (name, err)
+    Jn = o.jacapprox(lambda x: F(f=x[0]), np.array([f]))
+    assert np.abs(Jn - d['dF'].reshape(-1, 1)).max() < 1e-8
+    Jn = o.jacapprox(lambda x: F(Q=x.reshape(3, -1, order='F')), Q.flatten('F'))
+    Ja = np.zeros((2 * m, 3 * m))
+    for i in range(m):
+        Ja[2 * i:2 * i + 2, 3 * i:3 * i + 3] = d['dQ'][i]
+    assert np.abs(Jn - Ja).max() < 1e-7
+
+
+def test_eulerrotmat_all_sequences():
+    """eulerrotmat.m:127-146 self test: all axis sequences, fixed and moving."""
+    rng = np.random.default_rng(7)
+    for seq in [100 * a + 10 * b + c for a in (1, 2, 3) for b in (1, 2, 3) for c in (1, 2, 3)]:
+        for fixed in (False, True):
+            ang = rng.random(3)
+            M, dA = o.eulerrotmat(ang, seq, fixed, jac=True)
+            Jn = o.jacapprox(lambda a: o.eulerrotmat(a, seq, fixed).flatten('F'), ang)
+            assert np.abs(Jn - dA).max() < 1e-8
+            assert np.abs(M @ M.T - np.eye(3)).max() < 1e-14
+
+
+def test_whole_model_jacobian_numeric():
+    """brown_euler_cam4.m:24-28: analytic J vs jacapprox on the whole model,
+    with priors, fixed parameters and shared IO."""
+    s = camcal_struct(3)
+    # keep it small: first 3 images
+    keep = s.IP.cam < 3
+    import copy
+    s = copy.deepcopy(s)
+    s.IP.val, s.IP.std = s.IP.val[:, keep], s.IP.std[:, keep]
+    s.IP.cam, s.IP.pt = s.IP.cam[keep], s.IP.pt[keep]
+    for nm in ('IO', 'EO'):
+        a = getattr(s, nm)
+        a.val = a.val[:, :3]
+        a.struct.block = a.struct.block[:, :3]
+        est = getattr(s.bundle.est, nm); setattr(s.bundle.est, nm, est[:, :3])
+        pr = getattr(s.prior, nm)
+        pr.use, pr.val, pr.std = pr.use[:, :3], pr.val[:, :3], pr.std[:, :3]
+    s.IO.model.distModel = s.IO.model.distModel[:3]
+    s.IO.sensor.pxSize = s.IO.sensor.pxSize[:, :3]
+    s.prior.EO.use[0:3, 1] = True
+    s.prior.EO.val[0:3, 1] = s.EO.val[0:3, 1] + 0.01
+    s.prior.EO.std[0:3, 1] = 0.05
+    s = o.buildserialindices(s)
+    x = o.serialize(s)
+    f, J = o.brown_euler_cam4(x, s, jac=True)
+    Jn = o.jacapprox(lambda xx: o.brown_euler_cam4(xx, s), x)
+    Jd = J.toarray()
+    assert np.abs(f - o.brown_euler_cam4(x, s)).max() == 0
+    scale = np.maximum(1.0, np.abs(Jn))
+    assert (np.abs(Jd - Jn) / scale).max() < 1e-6
