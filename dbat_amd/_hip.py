@@ -1,0 +1,367 @@
+"""ctypes binding of the C ABI in include/dbat_hip.h (libdbat_hip.so).
+
+The library is the product: there is no Python or CPU fallback.  If the shared
+object is missing or cannot be loaded, importing callers get a loud
+`DbatHipUnavailable` with the build command.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdbat_hip.so')
+
+ABI_VERSION = 1
+DAMP = {'none': 0, 'gm': 0, 'gna': 1, 'lm': 2, 'lmp': 3}
+
+OK, EINVAL, EUNSUPPORTED, EDEVICE, ENOMEM = 0, -101, -102, -103, -104
+
+
+class DbatHipUnavailable(RuntimeError):
+    pass
+
+
+class DbatHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__('dbat_hip error %d: %s' % (code, msg))
+        self.code = code
+
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_bp = C.POINTER(C.c_uint8)
+
+
+class Problem(C.Structure):
+    _fields_ = [
+        ('abi_version', C.c_int32), ('n_images', C.c_int32), ('n_points', C.c_int32),
+        ('n_obs', C.c_int64), ('dist_model', C.c_int32), ('nK', C.c_int32), ('nP', C.c_int32),
+        ('ip_cam', _ip), ('ip_pt', _ip), ('ip_val', _dp), ('ip_std', _dp),
+        ('IO_val', _dp), ('px_size', _dp), ('EO_val', _dp), ('OP_val', _dp),
+        ('est_IO', _bp), ('est_EO', _bp), ('est_OP', _bp),
+        ('IO_block', _ip), ('EO_block', _ip),
+        ('prior_IO_use', _bp), ('prior_IO_val', _dp), ('prior_IO_std', _dp),
+        ('prior_EO_use', _bp), ('prior_EO_val', _dp), ('prior_EO_std', _dp),
+        ('prior_OP_use', _bp), ('prior_OP_val', _dp), ('prior_OP_std', _dp),
+        ('device', C.c_int32), ('shard_rank', C.c_int32), ('shard_count', C.c_int32),
+    ]
+
+
+class Options(C.Structure):
+    _fields_ = [
+        ('damping', C.c_int32), ('max_iter', C.c_int32), ('conv_tol', C.c_double),
+        ('abs_term', C.c_int32), ('singular_test', C.c_int32), ('store_trace', C.c_int32),
+        ('mu', C.c_double), ('alpha_min', C.c_double), ('lambda0', C.c_double),
+        ('lambda_min', C.c_double), ('rho_bad', C.c_double), ('rho_good', C.c_double),
+        ('delta0', C.c_double),
+    ]
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ('code', C.c_int32), ('iters', C.c_int32), ('n_res', C.c_int32), ('n_damp', C.c_int32),
+        ('n_trace', C.c_int32), ('sigma0', C.c_double), ('time_s', C.c_double),
+        ('n_residual_evals', C.c_int32), ('n_linearizations', C.c_int32), ('n_solves', C.c_int32),
+    ]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+
+# every symbol include/dbat_hip.h declares: name -> (restype, argtypes)
+_H = C.c_void_p
+SYMBOLS = {
+    'dbat_hip_last_error': (C.c_char_p, []),
+    'dbat_hip_abi_version': (C.c_int, []),
+    'dbat_hip_default_options': (C.c_int, [C.c_int32, C.POINTER(Options)]),
+    'dbat_hip_plan': (C.c_int, [C.POINTER(Problem)] + [C.POINTER(C.c_int64)] * 7),
+    'dbat_hip_plan_serialize': (C.c_int, [C.POINTER(Problem), _dp]),
+    'dbat_hip_create': (C.c_int, [C.POINTER(Problem), C.POINTER(_H)]),
+    'dbat_hip_destroy': (None, [_H]),
+    'dbat_hip_num_params': (C.c_int64, [_H]),
+    'dbat_hip_num_residuals': (C.c_int64, [_H]),
+    'dbat_hip_serialize': (C.c_int, [_H, _dp]),
+    'dbat_hip_deserialize': (C.c_int, [_H, _dp, _dp, _dp, _dp]),
+    'dbat_hip_structural_rank_ok': (C.c_int, [_H, C.POINTER(C.c_int32)]),
+    'dbat_hip_residual': (C.c_int, [_H, _dp, _dp, _dp]),
+    'dbat_hip_jacobian_blocks': (C.c_int, [_H, _dp, _dp, _dp, _dp]),
+    'dbat_hip_linearize_solve': (C.c_int, [_H, _dp, C.c_double, C.c_int32, _dp, _dp]),
+    'dbat_hip_gradient': (C.c_int, [_H, _dp]),
+    'dbat_hip_colnorms': (C.c_int, [_H, _dp]),
+    'dbat_hip_jtimes_sqnorm': (C.c_int, [_H, _dp, _dp]),
+    'dbat_hip_solve': (C.c_int, [_H, C.POINTER(Options), _dp, C.POINTER(Result), _dp, _dp, _dp, _dp]),
+    'dbat_hip_final_residuals': (C.c_int, [_H, _dp, _dp]),
+    'dbat_hip_set_allreduce': (C.c_int, [_H, ALLREDUCE_FN, C.c_void_p]),
+    'dbat_hip_owned_mask': (C.c_int, [_H, _bp]),
+    'dbat_hip_bench_step': (C.c_int, [_H, C.c_double, C.c_int32, _dp]),
+    'dbat_hip_set_x': (C.c_int, [_H, _dp]),
+    'dbat_hip_info': (C.c_int, [_H, C.POINTER(C.c_int64)]),
+}
+DEBUG_SYMBOLS = {
+    'dbat_hip_debug_model_eval_host': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, C.c_double,
+                                                 _dp, _dp, _dp, _dp, _dp, _dp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libdbat_hip.so and bind every declared symbol (fails loudly)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DbatHipUnavailable(
+            '%s not built: run `python -c "import __graft_entry__ as g; g.build()"` or '
+            '`make -C dbat_amd/csrc` (needs hipcc).  There is no CPU fallback.' % LIB_PATH)
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise DbatHipUnavailable('cannot load %s: %s' % (LIB_PATH, e)) from e
+    for name, (res, args) in {**SYMBOLS, **DEBUG_SYMBOLS}.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise DbatHipUnavailable('%s does not export %s' % (LIB_PATH, name)) from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.dbat_hip_abi_version() != ABI_VERSION:
+        raise DbatHipUnavailable('ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().dbat_hip_last_error().decode('utf-8', 'replace')
+
+
+def check(rc):
+    if rc != 0:
+        raise DbatHipError(rc, last_error())
+
+
+def dptr(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+def _f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64).flatten('F'))
+
+
+def _u8(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=bool).flatten('F').astype(np.uint8))
+
+
+def _i32(a):
+    return np.ascontiguousarray(np.asarray(a).flatten('F').astype(np.int32))
+
+
+def problem_from_struct(s, device=0, shard_rank=0, shard_count=1):
+    """Flatten a DBAT struct (dbat_amd.dbatstruct) into a `Problem`.
+
+    Returns (Problem, keepalive) -- keepalive holds the numpy buffers the
+    pointers refer to.
+    """
+    nc, npnt, no = s.EO.val.shape[1], s.OP.val.shape[1], s.IP.val.shape[1]
+    dm = np.unique(s.IO.model.distModel)
+    if dm.size != 1:
+        raise ValueError('Mixed lens distortion models not implemented.')   # brown_euler_cam4.m:31-33
+    if npnt >= 2 ** 31 or nc >= 2 ** 31:
+        raise ValueError('too many points/images for int32 indices')
+    keep = dict(
+        ip_cam=_i32(s.IP.cam), ip_pt=_i32(s.IP.pt), ip_val=_f64(s.IP.val), ip_std=_f64(s.IP.std),
+        IO_val=_f64(s.IO.val), px_size=_f64(s.IO.sensor.pxSize), EO_val=_f64(s.EO.val[:6]),
+        OP_val=_f64(s.OP.val),
+        est_IO=_u8(s.bundle.est.IO), est_EO=_u8(s.bundle.est.EO[:6]), est_OP=_u8(s.bundle.est.OP),
+        IO_block=_i32(s.IO.struct.block), EO_block=_i32(s.EO.struct.block[:6]),
+    )
+    for nm in ('IO', 'EO', 'OP'):
+        pr = getattr(s.prior, nm)
+        rows = slice(0, 6) if nm == 'EO' else slice(None)
+        keep['prior_%s_use' % nm] = _u8(np.asarray(pr.use)[rows])
+        keep['prior_%s_val' % nm] = _f64(np.nan_to_num(np.asarray(pr.val, float)[rows]))
+        keep['prior_%s_std' % nm] = _f64(np.nan_to_num(np.asarray(pr.std, float)[rows], nan=1.0))
+    p = Problem()
+    p.abi_version = ABI_VERSION
+    p.n_images, p.n_points, p.n_obs = nc, npnt, no
+    p.dist_model, p.nK, p.nP = int(dm[0]), int(s.IO.model.nK), int(s.IO.model.nP)
+    for k, v in keep.items():
+        ptr_t = dict(Problem._fields_)[k]
+        setattr(p, k, v.ctypes.data_as(ptr_t))
+    p.device, p.shard_rank, p.shard_count = int(device), int(shard_rank), int(shard_count)
+    return p, keep
+
+
+class Handle:
+    """RAII wrapper of dbat_hip_handle."""
+
+    def __init__(self, s, device=0, shard_rank=0, shard_count=1):
+        self.lib = load()
+        self.prob, self._keep = problem_from_struct(s, device, shard_rank, shard_count)
+        h = _H()
+        check(self.lib.dbat_hip_create(C.byref(self.prob), C.byref(h)))
+        self.h = h
+        self.n = int(self.lib.dbat_hip_num_params(h))
+        self.m = int(self.lib.dbat_hip_num_residuals(h))
+        self._cb = None
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.dbat_hip_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def serialize(self):
+        x = np.empty(self.n)
+        check(self.lib.dbat_hip_serialize(self.h, dptr(x)))
+        return x
+
+    def deserialize(self, x):
+        nc, npnt = self.prob.n_images, self.prob.n_points
+        R = 5 + self.prob.nK + self.prob.nP
+        IO, EO, OP = np.empty(R * nc), np.empty(6 * nc), np.empty(3 * npnt)
+        x = np.ascontiguousarray(x, float)
+        check(self.lib.dbat_hip_deserialize(self.h, dptr(x), dptr(IO), dptr(EO), dptr(OP)))
+        return (IO.reshape(R, nc, order='F'), EO.reshape(6, nc, order='F'),
+                OP.reshape(3, npnt, order='F'))
+
+    def structural_rank_ok(self):
+        ok = C.c_int32(0)
+        check(self.lib.dbat_hip_structural_rank_ok(self.h, C.byref(ok)))
+        return bool(ok.value)
+
+    def residual(self, x, want_r=True):
+        x = np.ascontiguousarray(x, float)
+        r = np.zeros(self.m) if want_r else None
+        f = C.c_double(0)
+        check(self.lib.dbat_hip_residual(self.h, dptr(x), dptr(r), C.byref(f)))
+        return (r, f.value) if want_r else f.value
+
+    def jacobian_blocks(self, x):
+        no, R = self.prob.n_obs, 5 + self.prob.nK + self.prob.nP
+        x = np.ascontiguousarray(x, float)
+        JEO, JOP, JIO = np.zeros(12 * no), np.zeros(6 * no), np.zeros(2 * R * no)
+        check(self.lib.dbat_hip_jacobian_blocks(self.h, dptr(x), dptr(JEO), dptr(JOP), dptr(JIO)))
+        return (JEO.reshape(no, 6, 2).transpose(0, 2, 1), JOP.reshape(no, 3, 2).transpose(0, 2, 1),
+                JIO.reshape(no, R, 2).transpose(0, 2, 1))
+
+    def linearize_solve(self, x, lam=0.0, scale=True):
+        x = np.ascontiguousarray(x, float)
+        p, st = np.empty(self.n), np.empty(8)
+        check(self.lib.dbat_hip_linearize_solve(self.h, dptr(x), float(lam), int(bool(scale)),
+                                                dptr(p), dptr(st)))
+        return p, dict(f=st[0], JpJp=st[1], rJp=st[2], pp=st[3], trace=st[4], singular=bool(st[5]))
+
+    def gradient(self):
+        g = np.empty(self.n)
+        check(self.lib.dbat_hip_gradient(self.h, dptr(g)))
+        return g
+
+    def colnorms(self):
+        g = np.empty(self.n)
+        check(self.lib.dbat_hip_colnorms(self.h, dptr(g)))
+        return g
+
+    def jtimes_sqnorm(self, v):
+        v = np.ascontiguousarray(v, float)
+        out = C.c_double(0)
+        check(self.lib.dbat_hip_jtimes_sqnorm(self.h, dptr(v), C.byref(out)))
+        return out.value
+
+    def solve(self, x0, opt):
+        x = np.ascontiguousarray(x0, float).copy()
+        res = Result()
+        mi = opt.max_iter
+        rr = np.full(mi + 3, np.nan)
+        damp = np.full(2 * mi + 4, np.nan)
+        aux = np.full(2 * mi + 4, np.nan)
+        trace = np.full(self.n * (mi + 2), np.nan) if opt.store_trace else None
+        check(self.lib.dbat_hip_solve(self.h, C.byref(opt), dptr(x), C.byref(res), dptr(rr),
+                                      dptr(damp), dptr(aux), dptr(trace)))
+        T = (trace[:self.n * res.n_trace].reshape(self.n, res.n_trace, order='F')
+             if trace is not None else None)
+        return x, res, rr[:res.n_res], damp[:res.n_damp], aux, T
+
+    def final_residuals(self):
+        ru, rw = np.zeros(self.m), np.zeros(self.m)
+        check(self.lib.dbat_hip_final_residuals(self.h, dptr(ru), dptr(rw)))
+        return ru, rw
+
+    def set_allreduce(self, pyfunc):
+        """pyfunc(ptr:int, count:int, stream:int) -> int (0 ok)."""
+        def tramp(user, buf, count, stream):
+            try:
+                return int(pyfunc(int(buf or 0), int(count), int(stream or 0)) or 0)
+            except Exception:   # noqa: BLE001 - must not unwind through C
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._cb = ALLREDUCE_FN(tramp)
+        check(self.lib.dbat_hip_set_allreduce(self.h, self._cb, None))
+
+    def owned_mask(self):
+        m = np.zeros(self.n, np.uint8)
+        check(self.lib.dbat_hip_owned_mask(self.h, m.ctypes.data_as(_bp)))
+        return m.astype(bool)
+
+    def index_maps(self):
+        """x index of every IO/EO/OP array entry (-1 = not an unknown); the
+        deserial maps of misc/buildserialindices.m:204-221."""
+        big = 1e15
+        IO, EO, OP = self.deserialize(big + np.arange(self.n, dtype=float))
+        f = lambda a: np.where(a >= big / 2, np.rint(a - big), -1).astype(np.int64)
+        return f(IO), f(EO), f(OP)
+
+    def set_x(self, x):
+        x = np.ascontiguousarray(x, float)
+        check(self.lib.dbat_hip_set_x(self.h, dptr(x)))
+
+    def bench_step(self, lam=0.0, scale=False):
+        ms = np.zeros(4)
+        check(self.lib.dbat_hip_bench_step(self.h, float(lam), int(bool(scale)), dptr(ms)))
+        return ms
+
+    def info(self):
+        a = (C.c_int64 * 8)()
+        check(self.lib.dbat_hip_info(self.h, a))
+        keys = ('NS', 'n_batches', 'max_k', 'n_obs_shard', 'n_pts_shard', 'BT', 'ncolmax', 'n')
+        return dict(zip(keys, [int(v) for v in a]))
+
+
+def default_options(damping='gna'):
+    o = Options()
+    check(load().dbat_hip_default_options(DAMP[damping.lower()], C.byref(o)))
+    return o
+
+
+def plan(s, shard_rank=0, shard_count=1):
+    """Host-only index plan (no GPU needed): sizes of x and r, shard range."""
+    lib = load()
+    p, keep = problem_from_struct(s, 0, shard_rank, shard_count)
+    v = [C.c_int64(0) for _ in range(7)]
+    check(lib.dbat_hip_plan(C.byref(p), *[C.byref(a) for a in v]))
+    keys = ('n', 'm', 'nIO', 'nEO', 'nOP', 'pt_lo', 'pt_hi')
+    return dict(zip(keys, [a.value for a in v]))
+
+
+def plan_serialize(s):
+    """Host-only x0 = serialize(s) (no GPU needed)."""
+    lib = load()
+    p, keep = problem_from_struct(s)
+    x0 = np.empty(plan(s)['n'])
+    check(lib.dbat_hip_plan_serialize(C.byref(p), dptr(x0)))
+    return x0
+
+
+def debug_model_eval_host(model, nK, nP, EO6, IO, px, Q, uv):
+    """Host evaluation of csrc/model.hpp for CPU unit tests of the closed form."""
+    lib = load()
+    R = 5 + nK + nP
+    r, A, B, Cc = np.zeros(2), np.zeros(12), np.zeros(6), np.zeros(2 * R)
+    a = [np.ascontiguousarray(v, float) for v in (EO6, IO, Q, uv)]
+    check(lib.dbat_hip_debug_model_eval_host(model, nK, nP, dptr(a[0]), dptr(a[1]), float(px),
+                                             dptr(a[2]), dptr(a[3]), dptr(r), dptr(A), dptr(B), dptr(Cc)))
+    return r, A.reshape(6, 2).T, B.reshape(3, 2).T, Cc.reshape(R, 2).T

@@ -1,0 +1,182 @@
+"""`bundle()` -- host-side mirror of DBAT's bundle driver over the HIP core.
+
+Mirrors `bundle/bundle.m:1-132` (argument conventions), `:156-192` (set-up),
+`:267-358` (dispatch on damping, result struct E, deserialise only if ok) and
+`:449-491` (residual scatter, sigma0).  All arithmetic of the path --
+residuals, Jacobian blocks, normal equations, Schur solve, damping loops --
+runs in libdbat_hip.so through the C ABI of include/dbat_hip.h; nothing here
+computes them on the CPU.
+"""
+from __future__ import annotations
+
+import copy
+import types
+
+import numpy as np
+
+from . import _hip
+
+NS = types.SimpleNamespace
+
+
+class BadInput(ValueError):
+    """error('DBAT:bundle:badInput', ...)  (bundle.m:124,130)."""
+
+
+def _parse_args(args):
+    """bundle.m:78-132: integer => maxIter, non-integer scalar => tol, string =>
+    damping / flags, logical => chirality veto."""
+    o = dict(maxIter=20, damping='gna', veto=False, singularTest=True, doTrace=False,
+             dofVerb=False, pmDof=False, absTerm=False, convTol=1e-6)
+    for a in args:
+        if isinstance(a, (bool, np.bool_)):
+            o['veto'] = bool(a)
+        elif isinstance(a, (int, float, np.integer, np.floating)):
+            if float(a) == round(float(a)):
+                o['maxIter'] = int(a)
+            else:
+                o['convTol'] = float(a)
+        elif isinstance(a, str):
+            la = a.lower()
+            if la in ('none', 'gm', 'gna', 'lm', 'lmp'):
+                o['damping'] = la
+            elif la == 'trace':
+                o['doTrace'] = True
+            elif la == 'singulartest':
+                o['singularTest'] = True
+            elif la == 'nosingulartest':
+                o['singularTest'] = False
+            elif la == 'pmdof':
+                o['pmDof'] = True
+            elif la == 'dofverb':
+                o['dofVerb'] = True
+            elif la == 'absterm':
+                o['absTerm'] = True
+            else:
+                raise BadInput('DBAT:bundle:badInput: Unknown damping')
+        else:
+            raise BadInput('DBAT:bundle:badInput: Unknown parameter')
+    return o
+
+
+def bundle(s, *args, device=0, comm=None, store_trace=True):
+    """[s,ok,iters,s0,E] = bundle(s[,maxIter][,damping][,'trace'][,tol]
+    [,'absterm'][,'singulartest'|'nosingulartest'][,veto][,'pmdof'][,'dofverb'])
+
+    `comm` (dbat_amd.parallel.Comm) shards the object points over the ranks of
+    a torch.distributed group, one GPU per rank; every rank returns the full
+    result.  `store_trace=False` drops E.trace (n x iterations) for very large
+    problems.
+    """
+    o = _parse_args(args)
+    if o['veto']:
+        # bundle.m:169 references an undefined function `chirality`
+        # (SURVEY Appendix B item 2): the reference errors at this point too.
+        raise BadInput("chirality veto is not defined in the reference (bundle.m:169)")
+    s = copy.deepcopy(s)
+    # bundle.m:137-154: a fixed parameter cannot be used as a prior observation
+    for nm in ('IO', 'EO', 'OP'):
+        pr = getattr(s.prior, nm)
+        est = np.asarray(getattr(s.bundle.est, nm), bool)
+        pr.use = np.asarray(pr.use, bool)
+        if np.any(pr.use & ~est):
+            print("Warning: Some %s parameters are set to both 'fixed' and 'observed'" % nm)
+            print('Setting %s parameters to fixed' % nm)
+            pr.use = pr.use & est
+    rank, world = (comm.rank, comm.world_size) if comm is not None else (0, 1)
+    h = _hip.Handle(s, device=device, shard_rank=rank, shard_count=world)
+    try:
+        if comm is not None and world > 1:
+            h.set_allreduce(comm.allreduce_ptr)
+        x0 = h.serialize()                                           # bundle.m:162
+        opt = _hip.default_options(o['damping'])
+        opt.max_iter = o['maxIter']
+        opt.conv_tol = o['convTol']
+        opt.abs_term = int(o['absTerm'])
+        opt.singular_test = int(o['singularTest'])
+        opt.store_trace = int(bool(store_trace))
+        x, res, rr, damp, aux, T = h.solve(x0, opt)
+        if comm is not None and world > 1:
+            mask = h.owned_mask()
+            x = comm.allreduce_numpy(np.where(mask, x, 0.0))
+            if T is not None:
+                T = comm.allreduce_numpy(np.where(mask[:, None], T, 0.0))
+        E = NS(maxIter=o['maxIter'], convTol=o['convTol'], absTerm=o['absTerm'],
+               singularTest=o['singularTest'], chirality=False)
+        name = 'gm' if o['damping'] in ('none', 'gm') else o['damping']
+        if name == 'gm':
+            E.damping = NS(name='gm')
+        elif name == 'gna':
+            E.damping = NS(name='gna', alpha=damp, mu=opt.mu, alphaMin=opt.alpha_min)
+        elif name == 'lm':
+            E.damping = NS(name='lm', **{'lambda': damp},
+                           lambda0=damp[0] if len(damp) else np.nan,
+                           lambdaMin=damp[0] if len(damp) else np.nan)
+        else:
+            mi = o['maxIter']
+            rho = aux[:mi + 2]
+            rho = rho[~np.isnan(rho)]
+            step = aux[mi + 2:]
+            step = step[~np.isnan(step)].astype(int)
+            E.damping = NS(name='lmp', delta=damp, rho=rho, delta0=float(np.linalg.norm(x0)),
+                           rhoBad=opt.rho_bad, rhoGood=opt.rho_good, step=step)
+        E.res, E.trace, E.time = rr, T, res.time_s
+        E.code, E.usedIters = int(res.code), int(res.iters)
+        E.counters = NS(residual_evals=res.n_residual_evals, linearizations=res.n_linearizations,
+                        solves=res.n_solves)
+        ok = E.code == 0
+        if ok:                                                       # bundle.m:356-358
+            IO, EO, OP = h.deserialize(x)
+            s.IO.val, s.OP.val = IO, OP
+            s.EO.val = np.vstack([EO, s.EO.val[6:]]) if s.EO.val.shape[0] > 6 else EO
+        # residuals at the last linearisation point (bundle.m:449-460)
+        if E.code == -4:
+            ru = np.full(h.m, np.nan)
+            rw = ru
+        else:
+            ru, rw = h.final_residuals()
+            if comm is not None and world > 1:
+                ru, rw = comm.allreduce_numpy(ru), comm.allreduce_numpy(rw)
+        no = s.IP.val.shape[1]
+        s.post = getattr(s, 'post', NS())
+        s.post.res = NS()
+        s.post.res.IP = ru[:2 * no].reshape(2, no, order='F') / s.IO.sensor.pxSize[:, s.IP.cam]
+        IOix, EOix, OPix = h.index_maps()
+        ofs = 2 * no
+        for nm, ixmap in (('IO', IOix), ('EO', EOix), ('OP', OPix)):
+            val = getattr(s, nm).val
+            rows = slice(0, 6) if nm == 'EO' else slice(None)
+            use = np.asarray(getattr(s.prior, nm).use, bool)[rows]
+            arr = np.full(val[rows].shape, np.nan)
+            # prior rows = column-major order of use & leading (buildserialindices.m:138-139,200)
+            flatmap = ixmap.flatten('F')
+            lead = np.zeros(flatmap.shape, bool)
+            valid = np.flatnonzero(flatmap >= 0)
+            _, first = np.unique(flatmap[valid], return_index=True)
+            lead[valid[first]] = True
+            pos = np.flatnonzero(use.flatten('F') & lead)
+            flat = arr.flatten('F')
+            flat[pos] = ru[ofs:ofs + len(pos)]
+            ofs += len(pos)
+            setattr(s.post.res, nm, flat.reshape(arr.shape, order='F'))
+        E.final = NS(unweighted=NS(r=ru), weighted=NS(r=rw))
+        p_extra = 0
+        if o['pmDof']:                                               # bundle.m:467-471
+            seen_pt = np.zeros(s.OP.val.shape[1], bool); seen_pt[s.IP.pt] = True
+            seen_cam = np.zeros(s.EO.val.shape[1], bool); seen_cam[s.IP.cam] = True
+            p_extra = int(np.count_nonzero(~np.asarray(s.bundle.est.OP, bool)[:, seen_pt])
+                          + np.count_nonzero(~np.asarray(s.bundle.est.EO, bool)[:6, seen_cam]))
+        dof = h.m + p_extra - h.n
+        s0 = float(res.sigma0) * np.sqrt((h.m - h.n) / dof) if dof > 0 else np.nan
+        if o['dofVerb']:
+            print('bundle: dof=%d+%d-%d=%d.' % (h.m, p_extra, h.n, dof))
+        s.post.sigmas = s0 * np.asarray(s.IP.sigmas)
+        E.numObs, E.numParams, E.redundancy, E.s0 = h.m, h.n, dof, s0
+        E.sigmas = s.post.sigmas
+        E.x = x
+        if o['doTrace']:
+            for k, v in enumerate(rr):
+                print('%s: iteration %d, residual norm=%.6g' % (name, k, v))
+        return s, ok, E.usedIters, s0, E
+    finally:
+        h.close()

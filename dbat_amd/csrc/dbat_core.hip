@@ -1,0 +1,910 @@
+// Device engine + host damping loops + C ABI of the MI355X bundle core.
+// See include/dbat_hip.h for the boundary and DESIGN.md for the data layout.
+#include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/dbat_hip.h"
+#include "kernels.hpp"
+#include "plan.hpp"
+
+namespace dbat {
+
+static thread_local std::string g_err;
+
+struct DeviceError { std::string msg; };
+
+#define HIPCHK(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            throw DeviceError{std::string(#expr) + ": " + hipGetErrorString(e_)};          \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    void alloc(size_t count) {
+        n = count;
+        if (count) HIPCHK(hipMalloc((void **)&p, count * sizeof(T)));
+    }
+    void upload(const std::vector<T> &v) {
+        alloc(v.size());
+        if (!v.empty()) HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+struct Core {
+    Plan P;
+    DevProblem d{};
+    hipStream_t stream = nullptr;
+    rocblas_handle blas = nullptr;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    // static problem data
+    DevBuf<int32_t> cam_ncol, cam_col, cam_iorow, io_src, o_cam, o_pt;
+    DevBuf<uint32_t> cam_eo_est, o_seg;
+    DevBuf<double> io_fixed, px, cam_w, z_prw, z_prv, o_uv, o_w;
+    DevBuf<uint8_t> z_est, z_mine;
+    DevBuf<int64_t> o_row, batch_start, x2z;
+    // state
+    DevBuf<CamRec> cams;
+    DevBuf<double> z, zt, dz, zlin, vtmp, vtmp2, xbuf;  // NZ each (xbuf: n)
+    DevBuf<double> red;      // [S | g_red | g_c | diagU | scal(8)]
+    DevBuf<double> jn2c, dscale, rhs, Vinv, gp, jn2p, r_w, partial, scal;
+    DevBuf<rocblas_int> info;
+    double *S = nullptr, *g_red = nullptr, *g_c = nullptr, *diagU = nullptr, *red_scal = nullptr;
+    int64_t red_count = 0;
+    int64_t nb = 0, nobs = 0;
+    int grid_obs = 1, grid_z = 1;
+    size_t lds_build = 0, lds_back = 0;
+    dbat_hip_allreduce_fn allreduce = nullptr;
+    void *allreduce_user = nullptr;
+    // linearisation state
+    double f_lin = 0, trace_jtj = 0, lambda_lin = 0;
+    int scale_lin = 0;
+    bool have_lin = false;
+    bool s_valid = false;      // S holds an unfactorised reduced system
+    // counters
+    int n_res_evals = 0, n_lin = 0, n_solves = 0;
+
+    ~Core() {
+        for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+        if (blas) rocblas_destroy_handle(blas);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+
+    void init(const dbat_hip_problem &pb) {
+        HIPCHK(hipSetDevice(pb.device));
+        HIPCHK(hipStreamCreate(&stream));
+        if (rocblas_create_handle(&blas) != rocblas_status_success) throw DeviceError{"rocblas_create_handle failed"};
+        rocblas_set_stream(blas, stream);
+        for (auto &e : ev) HIPCHK(hipEventCreate(&e));
+        nb = (int64_t)P.batch_start.size() - 1;
+        nobs = (int64_t)P.o_cam.size();
+        cam_ncol.upload(P.cam_ncol); cam_col.upload(P.cam_col); cam_iorow.upload(P.cam_iorow);
+        cam_eo_est.upload(P.cam_eo_est); io_src.upload(P.io_src); io_fixed.upload(P.io_fixed);
+        px.upload(P.px); cam_w.upload(P.cam_w);
+        z_est.upload(P.z_est); z_mine.upload(P.z_mine); z_prw.upload(P.z_prw); z_prv.upload(P.z_prv);
+        o_cam.upload(P.o_cam); o_pt.upload(P.o_pt); o_uv.upload(P.o_uv); o_w.upload(P.o_w);
+        o_seg.upload(P.o_seg); o_row.upload(P.o_row); batch_start.upload(P.batch_start);
+        x2z.upload(P.x2z);
+        d.nc = P.nc; d.np = P.np; d.nIOrows = P.nIOrows; d.nK = P.nK; d.nP = P.nP; d.nIOu = P.nIOu;
+        d.ncolmax = P.ncolmax; d.BT = P.BT; d.NS = P.NS; d.NZ = P.NZ; d.nobs = nobs; d.nb = nb;
+        d.cam_ncol = cam_ncol.p; d.cam_col = cam_col.p; d.cam_iorow = cam_iorow.p; d.cam_eo_est = cam_eo_est.p;
+        d.io_src = io_src.p; d.io_fixed = io_fixed.p; d.px = px.p; d.cam_w = cam_w.p;
+        d.z_est = z_est.p; d.z_mine = z_mine.p; d.z_prw = z_prw.p; d.z_prv = z_prv.p;
+        d.o_cam = o_cam.p; d.o_pt = o_pt.p; d.o_uv = o_uv.p; d.o_w = P.uniform_w ? nullptr : o_w.p;
+        d.o_seg = o_seg.p; d.o_row = o_row.p; d.batch_start = batch_start.p;
+        cams.alloc(P.nc);
+        z.alloc(P.NZ); zt.alloc(P.NZ); dz.alloc(P.NZ); zlin.alloc(P.NZ); vtmp.alloc(P.NZ); vtmp2.alloc(P.NZ);
+        xbuf.alloc(std::max<int64_t>(P.n, 1));
+        red_count = P.NS * P.NS + 3 * P.NS + 8;
+        red.alloc(red_count);
+        S = red.p; g_red = S + P.NS * P.NS; g_c = g_red + P.NS; diagU = g_c + P.NS; red_scal = diagU + P.NS;
+        jn2c.alloc(P.NS); dscale.alloc(P.NS); rhs.alloc(P.NS);
+        Vinv.alloc((size_t)6 * P.np); gp.alloc((size_t)3 * P.np); jn2p.alloc((size_t)3 * P.np);
+        HIPCHK(hipMemset(Vinv.p, 0, (size_t)6 * P.np * 8));
+        HIPCHK(hipMemset(gp.p, 0, (size_t)3 * P.np * 8));
+        HIPCHK(hipMemset(jn2p.p, 0, (size_t)3 * P.np * 8));
+        r_w.alloc(std::max<int64_t>(2 * nobs, 2));
+        grid_obs = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(nobs, 256), 2048));
+        grid_z = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(P.NZ, 256), 2048));
+        partial.alloc((size_t)4 * std::max<int64_t>(std::max<int64_t>(nb, 2048), 1));
+        scal.alloc(16);
+        info.alloc(1);
+        lds_build = ((size_t)P.BT * P.ncolmax * 3 + (size_t)P.BT * 18) * sizeof(double);
+        lds_back = (size_t)P.BT * 6 * sizeof(double);
+        HIPCHK(hipMemcpy(z.p, P.z0.data(), P.NZ * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemset(dz.p, 0, P.NZ * 8));
+        HIPCHK(hipDeviceSynchronize());
+    }
+
+    // ---- helpers
+    void sync() { HIPCHK(hipStreamSynchronize(stream)); }
+    void do_allreduce(double *buf, int64_t count) {
+        if (allreduce && P.nranks > 1) {
+            if (allreduce(allreduce_user, buf, count, (void *)stream) != 0) throw DeviceError{"all-reduce callback failed"};
+        }
+    }
+    void read_scal(double *host, int n) {
+        HIPCHK(hipMemcpyAsync(host, scal.p, n * sizeof(double), hipMemcpyDeviceToHost, stream));
+        sync();
+    }
+    void prep_cams(const double *zz) {
+        hipLaunchKernelGGL(k_cam_prep, dim3((unsigned)cdiv(P.nc, 64)), dim3(64), 0, stream, d, zz, cams.p);
+    }
+    void x_to_z(const double *x_host, double *z_dev) {
+        // z keeps fixed entries; estimated entries overwritten from x
+        HIPCHK(hipMemcpyAsync(z_dev, P.z0.data(), P.NZ * 8, hipMemcpyHostToDevice, stream));
+        if (P.n) {
+            HIPCHK(hipMemcpyAsync(xbuf.p, x_host, P.n * 8, hipMemcpyHostToDevice, stream));
+            hipLaunchKernelGGL(k_scatter_x, dim3((unsigned)cdiv(P.n, 256)), dim3(256), 0, stream, P.n, x2z.p, xbuf.p, z_dev);
+        }
+    }
+    void z_to_x(const double *z_dev, double *x_host) {
+        if (!P.n) return;
+        hipLaunchKernelGGL(k_gather_x, dim3((unsigned)cdiv(P.n, 256)), dim3(256), 0, stream, P.n, x2z.p, z_dev, xbuf.p);
+        HIPCHK(hipMemcpyAsync(x_host, xbuf.p, P.n * 8, hipMemcpyDeviceToHost, stream));
+        sync();
+    }
+
+#define DISPATCH_MODEL(KERNEL, ...)                                                          \
+    switch (P.model) {                                                                       \
+        case 2: KERNEL(2, __VA_ARGS__); break;                                               \
+        case 3: KERNEL(3, __VA_ARGS__); break;                                               \
+        case 4: KERNEL(4, __VA_ARGS__); break;                                               \
+        default: KERNEL(5, __VA_ARGS__); break;                                              \
+    }
+
+    // ---- K2: f = 0.5 r'r at zz (all ranks' sum).  Optionally store r.
+    double eval_f(const double *zz, double *r_w_out, double *r_unw_out) {
+        prep_cams(zz);
+#define L_RES(M, dummy) hipLaunchKernelGGL((k_residual<M>), dim3(grid_obs), dim3(256), 0, stream, d, zz, cams.p, partial.p, r_w_out, r_unw_out)
+        DISPATCH_MODEL(L_RES, 0)
+#undef L_RES
+        hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(256), 0, stream, partial.p, (int64_t)grid_obs, scal.p, 0);
+        hipLaunchKernelGGL(k_prior_sq, dim3(grid_z), dim3(256), 0, stream, d, zz, partial.p);
+        hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(256), 0, stream, partial.p, (int64_t)grid_z, scal.p, 1);
+        do_allreduce(scal.p, 1);
+        double s;
+        read_scal(&s, 1);
+        ++n_res_evals;
+        return 0.5 * s;
+    }
+
+    // ---- K1: linearise at zz with damping lambda; builds the reduced system.
+    void build_enqueue(const double *zz, double lambda) {
+        prep_cams(zz);
+        HIPCHK(hipMemsetAsync(red.p, 0, red_count * sizeof(double), stream));
+        if (nb > 0) {
+#define L_BUILD(M, IO) hipLaunchKernelGGL((k_build<M, IO>), dim3((unsigned)nb), dim3(P.BT), lds_build, stream, d, zz, cams.p, lambda, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p)
+            if (P.with_io) { DISPATCH_MODEL(L_BUILD, true) } else { DISPATCH_MODEL(L_BUILD, false) }
+#undef L_BUILD
+        }
+        hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(256), 0, stream, partial.p, nb, red_scal, 0);
+        hipLaunchKernelGGL(k_prior_sq, dim3(grid_z), dim3(256), 0, stream, d, zz, partial.p);
+        hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(256), 0, stream, partial.p, (int64_t)grid_z, red_scal, 1);
+        // owned squared column norms of the point columns -> red_scal[1]
+        hipLaunchKernelGGL(k_dot, dim3(grid_z), dim3(256), 0, stream, (int64_t)3 * P.np, z_mine.p + P.NS, jn2p.p, (const double *)nullptr, partial.p);
+        hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(256), 0, stream, partial.p, (int64_t)grid_z, red_scal + 1, 0);
+    }
+    void build(const double *zz, double lambda, int scale) {
+        build_enqueue(zz, lambda);
+        do_allreduce(red.p, red_count);
+        finish_enqueue(zz, lambda, scale);
+        if (zz != zlin.p) HIPCHK(hipMemcpyAsync(zlin.p, zz, P.NZ * 8, hipMemcpyDeviceToDevice, stream));
+        // trace(J'J): camera part from jn2c (estimated), point part from red_scal[1]
+        hipLaunchKernelGGL(k_dot, dim3(grid_z), dim3(256), 0, stream, P.NS, z_est.p, jn2c.p, (const double *)nullptr, partial.p);
+        hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(256), 0, stream, partial.p, (int64_t)grid_z, scal.p, 0);
+        double hs[2], hr[2];
+        HIPCHK(hipMemcpyAsync(hr, red_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
+        read_scal(hs, 1);
+        f_lin = 0.5 * hr[0];
+        trace_jtj = hs[0] + hr[1];
+        lambda_lin = lambda;
+        scale_lin = scale;
+        have_lin = true;
+        s_valid = true;
+        ++n_lin;
+    }
+    void finish_enqueue(const double *zz, double lambda, int scale) {
+        hipLaunchKernelGGL(k_finish, dim3((unsigned)cdiv(P.NS, 256)), dim3(256), 0, stream, d, zz, lambda, scale, S, g_c, g_red, diagU, jn2c.p, dscale.p, rhs.p);
+        if (scale)
+            hipLaunchKernelGGL(k_scale_S, dim3((unsigned)cdiv(P.NS, 256), (unsigned)P.NS), dim3(256), 0, stream, P.NS, S, dscale.p);
+    }
+
+    // ---- K6: Cholesky of the reduced system; returns 0 or the failing pivot
+    int factor_solve_enqueue() {
+        const rocblas_int n = (rocblas_int)P.NS;
+        if (rocsolver_dpotrf(blas, rocblas_fill_lower, n, S, n, info.p) != rocblas_status_success) throw DeviceError{"rocsolver_dpotrf failed"};
+        if (rocsolver_dpotrs(blas, rocblas_fill_lower, n, 1, S, n, rhs.p, n) != rocblas_status_success) throw DeviceError{"rocsolver_dpotrs failed"};
+        hipLaunchKernelGGL(k_unscale, dim3((unsigned)cdiv(P.NS, 256)), dim3(256), 0, stream, P.NS, rhs.p, dscale.p, dz.p);
+        ++n_solves;
+        return 0;
+    }
+    // ---- K7: back-substitution; sums {||Jp||^2, r'Jp, ||p||^2}
+    void backsub_enqueue() {
+        if (nb > 0) {
+#define L_BACK(M, IO) hipLaunchKernelGGL((k_backsub<M, IO>), dim3((unsigned)nb), dim3(P.BT), lds_back, stream, d, zlin.p, cams.p, Vinv.p, gp.p, r_w.p, dz.p, partial.p)
+            if (P.with_io) { DISPATCH_MODEL(L_BACK, true) } else { DISPATCH_MODEL(L_BACK, false) }
+#undef L_BACK
+        }
+        hipLaunchKernelGGL((k_sum_partials<2>), dim3(1), dim3(256), 0, stream, partial.p, nb, scal.p, 0);
+        hipLaunchKernelGGL(k_prior_jv, dim3(grid_z), dim3(256), 0, stream, d, zlin.p, dz.p, partial.p);
+        hipLaunchKernelGGL((k_sum_partials<3>), dim3(1), dim3(256), 0, stream, partial.p, (int64_t)grid_z, scal.p + 4, 0);
+    }
+    // solve at the current linearisation: p in dz, returns singular flag
+    bool solve(double &JpJp, double &rJp, double &pp) {
+        if (!s_valid) build(zlin.p, lambda_lin, scale_lin);   // the factorisation overwrote S
+        s_valid = false;
+        factor_solve_enqueue();
+        prep_cams(zlin.p);
+        backsub_enqueue();
+        rocblas_int hinfo = 0;
+        HIPCHK(hipMemcpyAsync(&hinfo, info.p, sizeof(hinfo), hipMemcpyDeviceToHost, stream));
+        do_allreduce(scal.p, 8);
+        double h[8];
+        read_scal(h, 8);
+        JpJp = h[0] + h[4]; rJp = h[1] + h[5]; pp = h[6];
+        bool singular = hinfo != 0 || !std::isfinite(pp) || !std::isfinite(JpJp);
+        return singular;
+    }
+    // ||J v||^2 and r'Jv at the linearisation point, ||v||^2 over owned entries
+    void jtimes(const double *v, double &JvJv, double &rJv, double &vv) {
+        prep_cams(zlin.p);
+#define L_JT(M, IO) hipLaunchKernelGGL((k_jtimes<M, IO>), dim3(grid_obs), dim3(256), 0, stream, d, zlin.p, cams.p, v, r_w.p, partial.p)
+        if (P.with_io) { DISPATCH_MODEL(L_JT, true) } else { DISPATCH_MODEL(L_JT, false) }
+#undef L_JT
+        hipLaunchKernelGGL((k_sum_partials<2>), dim3(1), dim3(256), 0, stream, partial.p, (int64_t)grid_obs, scal.p, 0);
+        hipLaunchKernelGGL(k_prior_jv, dim3(grid_z), dim3(256), 0, stream, d, zlin.p, v, partial.p);
+        hipLaunchKernelGGL((k_sum_partials<3>), dim3(1), dim3(256), 0, stream, partial.p, (int64_t)grid_z, scal.p + 4, 0);
+        do_allreduce(scal.p, 8);
+        double h[8];
+        read_scal(h, 8);
+        JvJv = h[0] + h[4]; rJv = h[1] + h[5]; vv = h[6];
+    }
+    double dot_owned(const double *a, const double *b) {
+        hipLaunchKernelGGL(k_dot, dim3(grid_z), dim3(256), 0, stream, P.NZ, z_mine.p, a, b, partial.p);
+        hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(256), 0, stream, partial.p, (int64_t)grid_z, scal.p, 0);
+        do_allreduce(scal.p, 1);
+        double s;
+        read_scal(&s, 1);
+        return s;
+    }
+    void axpby(double a, const double *x, double b, const double *y2, double *y) {
+        hipLaunchKernelGGL(k_axpby, dim3((unsigned)cdiv(P.NZ, 256)), dim3(256), 0, stream, P.NZ, a, x, b, y2, y);
+    }
+    void gradient(double *g) {
+        hipLaunchKernelGGL(k_gradient, dim3((unsigned)cdiv(P.NZ, 256)), dim3(256), 0, stream, d, g_c, gp.p, g);
+    }
+    void colnorm2(double *out) {
+        hipLaunchKernelGGL(k_jn2, dim3((unsigned)cdiv(P.NZ, 256)), dim3(256), 0, stream, d, jn2c.p, jn2p.p, out);
+    }
+    void copy(double *dst, const double *src) { HIPCHK(hipMemcpyAsync(dst, src, P.NZ * 8, hipMemcpyDeviceToDevice, stream)); }
+};
+
+// ============================================================================
+// Host damping loops (F12).  Device vectors: z (current), zt (trial), dz (step).
+// ============================================================================
+
+struct LoopOut {
+    std::vector<double> res, damp, aux;
+    std::vector<std::vector<double>> trace;
+    int code = 0, iters = 0;
+    double f_final = 0;
+};
+
+static bool term_fun(const dbat_hip_options &o, double JpJp, double f) {
+    // bundle.m:186-192: relative  norm(Jp)<=tol*norm(r) ; absolute norm(r)<=tol
+    const double nr = std::sqrt(2 * f);
+    if (o.abs_term) return nr <= o.conv_tol;
+    return std::sqrt(JpJp) <= o.conv_tol * nr;
+}
+
+static void push_trace(Core &c, const dbat_hip_options &o, LoopOut &out) {
+    if (!o.store_trace) return;
+    std::vector<double> x(c.P.n);
+    c.z_to_x(c.z.p, x.data());
+    out.trace.push_back(std::move(x));
+}
+
+// lsa/gauss_newton_armijo.m:86-245, linesearch :249-290
+static void loop_gna(Core &c, const dbat_hip_options &o, LoopOut &out) {
+    int n = 0;
+    push_trace(c, o, out);
+    double f = 0;
+    while (true) {
+        c.build(c.z.p, 0.0, 1);                                   // :112-116, :166-170
+        f = c.f_lin;
+        out.res.push_back(std::sqrt(2 * f));
+        if (n == 0 && !c.P.rank_ok) { out.code = -4; break; }     // :132-142
+        double JpJp, rJp, pp;
+        const bool singular = c.solve(JpJp, rJp, pp);             // :172-174
+        if (o.singular_test && singular) { out.code = -2; break; }  // :176-184
+        if (term_fun(o, JpJp, f)) break;                          // :191
+        ++n;
+        // linesearch
+        const double f0 = f, fp0 = rJp;
+        double alpha = 1.0;
+        bool found = false;
+        while (alpha >= o.alpha_min) {
+            c.axpby(1.0, c.z.p, alpha, c.dz.p, c.zt.p);
+            const double ft = c.eval_f(c.zt.p, nullptr, nullptr);
+            if (ft < f0 + o.mu * alpha * fp0) { found = true; f = ft; break; }
+            alpha /= 2;
+        }
+        if (!found) alpha = 0.0;
+        else c.copy(c.z.p, c.zt.p);
+        out.damp.push_back(alpha);
+        push_trace(c, o, out);
+        if (alpha == 0.0) { out.code = -3; out.res.push_back(out.res.back()); break; }
+        if (n > o.max_iter) { out.code = -1; out.res.push_back(std::sqrt(2 * f)); break; }
+    }
+    out.iters = n;
+    out.f_final = f;
+}
+
+// lsa/gauss_markov.m:52-129 with the documented semantics
+static void loop_gm(Core &c, const dbat_hip_options &o, LoopOut &out) {
+    int n = 0;
+    push_trace(c, o, out);
+    double f = 0;
+    while (true) {
+        c.build(c.z.p, 0.0, 0);
+        f = c.f_lin;
+        out.res.push_back(std::sqrt(2 * f));
+        double JpJp, rJp, pp;
+        const bool singular = c.solve(JpJp, rJp, pp);             // :79
+        if (o.singular_test && singular) { out.code = -2; break; }
+        if (term_fun(o, JpJp, f)) break;                          // :94
+        ++n;
+        c.axpby(1.0, c.z.p, 1.0, c.dz.p, c.z.p);
+        push_trace(c, o, out);
+        if (n > o.max_iter) { out.code = -1; break; }
+    }
+    out.iters = n;
+    out.f_final = f;
+}
+
+// lsa/levenberg_marquardt.m:52-250
+static void loop_lm(Core &c, const dbat_hip_options &o, LoopOut &out) {
+    int n = 0;
+    c.build(c.z.p, 0.0, 0);                                       // :76-82
+    double f = c.f_lin;
+    const double nx = (double)c.P.n;
+    double lambda0 = o.lambda0, lambdaMin = o.lambda_min;
+    if (lambda0 < 0) lambda0 = std::fabs(lambda0) * c.trace_jtj / nx;       // :88-90
+    if (lambdaMin < 0) lambdaMin = std::fabs(lambdaMin) * c.trace_jtj / nx; // :93-95
+    double lambda = lambda0;
+    if (lambda < lambdaMin) lambda = 0;
+    out.damp.push_back(lambda);
+    double prevLambda = NAN;
+    double JpJp = 0, rJp = 0, pp = 0;
+    std::vector<std::vector<double>> T;
+    while (true) {
+        while (n <= o.max_iter) {
+            if (c.lambda_lin != lambda) c.build(c.z.p, lambda, 0);            // (JTJ+lambda*I), :119
+            const bool singular = c.solve(JpJp, rJp, pp);
+            out.res.push_back(std::sqrt(2 * f));
+            if (n == 0 && !c.P.rank_ok) { out.code = -4; break; }             // :126-135
+            if (singular) { out.code = -2; break; }   // reference has no test here; MATLAB would return garbage
+            out.damp.push_back(lambda);
+            if (o.store_trace) { std::vector<double> x(c.P.n); c.z_to_x(c.z.p, x.data()); if ((int)T.size() <= n) T.resize(n + 1); T[n] = std::move(x); }
+            ++n;
+            c.axpby(1.0, c.z.p, 1.0, c.dz.p, c.zt.p);                         // t = x+p
+            const double fNew = c.eval_f(c.zt.p, nullptr, nullptr);
+            if (fNew < f) {
+                c.copy(c.z.p, c.zt.p);
+                lambda = lambda / 10;
+                if (lambda < lambdaMin) lambda = 0;
+                c.build(c.z.p, lambda, 0);                                    // :189-194
+                f = c.f_lin;
+                break;
+            } else {
+                if (lambda == 0) lambda = lambdaMin; else lambda = lambda * 10;
+            }
+        }
+        if (out.code != 0) break;
+        if (prevLambda == 0 && term_fun(o, JpJp, f)) break;                   // :217 (old Jp, new r)
+        prevLambda = lambda;
+        if (n > o.max_iter) { out.code = -1; break; }
+    }
+    if (o.store_trace) {
+        std::vector<double> x(c.P.n); c.z_to_x(c.z.p, x.data());
+        if ((int)T.size() <= n) T.resize(n + 1);
+        T[n] = std::move(x);
+        out.trace = std::move(T);
+    }
+    out.res.push_back(std::sqrt(2 * f));                                      // :242
+    out.iters = n;
+    out.f_final = f;
+}
+
+// lsa/levenberg_marquardt_powell.m:60-230, dogleg :232-335
+static void loop_lmp(Core &c, const dbat_hip_options &o, double delta0, LoopOut &out) {
+    int n = 0;
+    double delta = delta0;
+    std::vector<double> rhos, steps;
+    std::vector<std::vector<double>> T;
+    if (o.store_trace) { std::vector<double> x(c.P.n); c.z_to_x(c.z.p, x.data()); T.push_back(std::move(x)); }
+    c.build(c.z.p, 0.0, 1);
+    double f = c.f_lin;
+    bool have_gn = false;
+    double gnJpJp = 0, gnrJp = 0, gnpp = 0;
+    double *pGN = c.vtmp.p, *g = c.vtmp2.p;
+    while (true) {
+        out.res.push_back(std::sqrt(2 * f));
+        if (n == 0 && !c.P.rank_ok) { out.code = -4; break; }
+        // ---- dogleg(r,J,delta)
+        if (!have_gn) {
+            const bool singular = c.solve(gnJpJp, gnrJp, gnpp);   // :267-279 (scaled GN)
+            if (singular) { out.code = -2; break; }
+            c.copy(pGN, c.dz.p);
+            have_gn = true;
+        }
+        int step;
+        double JpJp, rJp;
+        const double npGN = std::sqrt(gnpp);
+        if (npGN <= delta) {                                       // :281-286
+            step = 0; c.copy(c.dz.p, pGN); JpJp = gnJpJp; rJp = gnrJp;
+        } else {
+            c.gradient(g);                                         // g = J'r
+            double gJJg, rJg, gg;
+            c.jtimes(g, gJJg, rJg, gg);                            // :304-311
+            const double lambdaStar = gg / gJJg;
+            const double nCP = lambdaStar * std::sqrt(gg);
+            if (nCP > delta) {                                     // :313-318
+                step = 2;
+                c.axpby(-delta / std::sqrt(gg), g, 0.0, g, c.dz.p);
+            } else {                                               // :324-335
+                step = 1;
+                // CP = -lambdaStar*g ; A=|CP-pGN|^2, B=2 CP.(pGN-CP), C=|CP|^2-delta^2
+                const double cp_pgn = -lambdaStar * c.dot_owned(g, pGN);
+                const double cp2 = nCP * nCP;
+                const double A = cp2 - 2 * cp_pgn + gnpp;
+                const double B = 2 * (cp_pgn - cp2);
+                const double Cc = cp2 - delta * delta;
+                const double k = (-B + std::sqrt(B * B - 4 * A * Cc)) / (2 * A);
+                // p = CP + k (pGN - CP) = (1-k)(-lambdaStar) g + k pGN
+                c.axpby(-(1 - k) * lambdaStar, g, k, pGN, c.dz.p);
+            }
+            double vv;
+            c.jtimes(c.dz.p, JpJp, rJp, vv);
+        }
+        out.damp.push_back(delta);
+        steps.push_back(step);
+        if (step == 0 && term_fun(o, gnJpJp, f)) break;            // :134-140
+        c.axpby(1.0, c.z.p, 1.0, c.dz.p, c.zt.p);
+        const double ft = c.eval_f(c.zt.p, nullptr, nullptr);
+        const double predicted = -rJp - 0.5 * JpJp;                // :153
+        const double actual = f - ft;
+        const double rho = actual / predicted;
+        rhos.push_back(rho);
+        if (rho <= o.rho_bad) {                                    // :166-179
+            delta = delta / 2;
+            if (delta > npGN) delta = delta / std::exp2(std::ceil(std::log2(delta / npGN)));
+        } else {
+            c.copy(c.z.p, c.zt.p);
+            c.build(c.z.p, 0.0, 1);
+            f = c.f_lin;
+            have_gn = false;
+            if (rho >= o.rho_good) delta = delta * 2;
+        }
+        if (o.store_trace) { std::vector<double> x(c.P.n); c.z_to_x(c.z.p, x.data()); if ((int)T.size() <= n) T.resize(n + 1); T[n] = std::move(x); }
+        ++n;
+        if (n > o.max_iter) { out.code = -1; break; }
+    }
+    if (o.store_trace) {
+        std::vector<double> x(c.P.n); c.z_to_x(c.z.p, x.data());
+        if ((int)T.size() <= n) T.resize(n + 1);
+        T[n] = std::move(x);
+        T.resize(std::max(n, 1));                                  // :229 trims to 1:n
+        out.trace = std::move(T);
+    }
+    out.aux = rhos;
+    out.aux.resize((size_t)o.max_iter + 2, NAN);
+    out.aux.insert(out.aux.end(), steps.begin(), steps.end());
+    out.iters = n;
+    out.f_final = f;
+}
+
+}  // namespace dbat
+
+// ============================================================================
+// C ABI
+// ============================================================================
+using namespace dbat;
+
+struct dbat_hip_handle {
+    std::unique_ptr<Core> core;
+};
+
+#define API_TRY try {
+#define API_CATCH                                                                       \
+    }                                                                                   \
+    catch (const DeviceError &e) { g_err = e.msg; return DBAT_HIP_EDEVICE; }            \
+    catch (const std::bad_alloc &) { g_err = "out of host memory"; return DBAT_HIP_ENOMEM; } \
+    catch (const std::exception &e) { g_err = e.what(); return DBAT_HIP_EINVAL; }
+
+extern "C" {
+
+const char *dbat_hip_last_error(void) { return g_err.c_str(); }
+int dbat_hip_abi_version(void) { return DBAT_HIP_ABI_VERSION; }
+
+int dbat_hip_default_options(int32_t damping, dbat_hip_options *opt) {
+    if (!opt || damping < 0 || damping > 3) { g_err = "bad damping"; return DBAT_HIP_EINVAL; }
+    opt->damping = damping; opt->max_iter = 20; opt->conv_tol = 1e-6; opt->abs_term = 0;
+    opt->singular_test = 1; opt->store_trace = 1; opt->mu = 0.1; opt->alpha_min = 1e-9;
+    opt->lambda0 = -1e-10; opt->lambda_min = -1e-10; opt->rho_bad = 0.25; opt->rho_good = 0.75;
+    opt->delta0 = -1.0;
+    return DBAT_HIP_OK;
+}
+
+int dbat_hip_plan(const dbat_hip_problem *prob, int64_t *n_params, int64_t *n_residuals,
+                  int64_t *n_io, int64_t *n_eo, int64_t *n_op, int64_t *shard_pt_lo, int64_t *shard_pt_hi) {
+    API_TRY
+    if (!prob) { g_err = "null problem"; return DBAT_HIP_EINVAL; }
+    Plan P;
+    if (!build_plan(*prob, P, false)) { g_err = P.err; return DBAT_HIP_EINVAL; }
+    if (n_params) *n_params = P.n;
+    if (n_residuals) *n_residuals = P.m;
+    if (n_io) *n_io = P.nIO;
+    if (n_eo) *n_eo = P.nEO;
+    if (n_op) *n_op = P.nOP;
+    if (shard_pt_lo) *shard_pt_lo = P.pt_lo;
+    if (shard_pt_hi) *shard_pt_hi = P.pt_hi;
+    return DBAT_HIP_OK;
+    API_CATCH
+}
+
+int dbat_hip_plan_serialize(const dbat_hip_problem *prob, double *x0) {
+    API_TRY
+    if (!prob || !x0) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
+    Plan P;
+    if (!build_plan(*prob, P, false)) { g_err = P.err; return DBAT_HIP_EINVAL; }
+    for (int64_t i = 0; i < P.n; ++i) x0[i] = P.z0[P.x2z[i]];
+    return DBAT_HIP_OK;
+    API_CATCH
+}
+
+int dbat_hip_create(const dbat_hip_problem *prob, dbat_hip_handle **out) {
+    API_TRY
+    if (!prob || !out) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        g_err = "no HIP device: the dbat_hip core has no CPU path";
+        return DBAT_HIP_EDEVICE;
+    }
+    auto h = std::make_unique<dbat_hip_handle>();
+    h->core = std::make_unique<Core>();
+    if (!build_plan(*prob, h->core->P, true)) {
+        g_err = h->core->P.err;
+        return g_err.find("not supported") != std::string::npos || g_err.find("more observations") != std::string::npos
+                   ? DBAT_HIP_EUNSUPPORTED : DBAT_HIP_EINVAL;
+    }
+    h->core->init(*prob);
+    *out = h.release();
+    return DBAT_HIP_OK;
+    API_CATCH
+}
+
+void dbat_hip_destroy(dbat_hip_handle *h) { delete h; }
+
+int64_t dbat_hip_num_params(const dbat_hip_handle *h) { return h ? h->core->P.n : -1; }
+int64_t dbat_hip_num_residuals(const dbat_hip_handle *h) { return h ? h->core->P.m : -1; }
+
+int dbat_hip_serialize(const dbat_hip_handle *h, double *x) {
+    if (!h || !x) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
+    const Plan &P = h->core->P;
+    for (int64_t i = 0; i < P.n; ++i) x[i] = P.z0[P.x2z[i]];
+    return DBAT_HIP_OK;
+}
+
+int dbat_hip_deserialize(const dbat_hip_handle *h, const double *x, double *IO, double *EO, double *OP) {
+    if (!h || !x) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
+    const Plan &P = h->core->P;
+    std::vector<double> z(P.z0);
+    for (int64_t i = 0; i < P.n; ++i) z[P.x2z[i]] = x[i];
+    if (EO) std::copy(z.begin(), z.begin() + 6 * (int64_t)P.nc, EO);
+    if (OP) std::copy(z.begin() + P.NS, z.end(), OP);
+    if (IO)
+        for (size_t e = 0; e < P.io_src.size(); ++e)
+            IO[e] = P.io_src[e] >= 0 ? z[6 * (int64_t)P.nc + P.io_src[e]] : P.io_fixed[e];
+    return DBAT_HIP_OK;
+}
+
+int dbat_hip_structural_rank_ok(const dbat_hip_handle *h, int32_t *ok) {
+    if (!h || !ok) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
+    *ok = h->core->P.rank_ok ? 1 : 0;
+    return DBAT_HIP_OK;
+}
+
+static void export_residuals(Core &c, const double *zdev, double *r_unw, double *r_wgt, double *f) {
+    // image rows via k_residual (reference row order), prior rows on the host
+    DevBuf<double> tmp;
+    double *dev_unw = nullptr;
+    if (r_unw || r_wgt) { tmp.alloc(2 * std::max<int64_t>(c.P.no, 1)); dev_unw = tmp.p; HIPCHK(hipMemsetAsync(dev_unw, 0, 2 * c.P.no * 8, c.stream)); }
+    const double ff = c.eval_f(zdev, nullptr, dev_unw);
+    if (f) *f = ff;
+    if (!(r_unw || r_wgt)) return;
+    std::vector<double> img(2 * c.P.no), zh(c.P.NZ);
+    HIPCHK(hipMemcpyAsync(img.data(), dev_unw, 2 * c.P.no * 8, hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipMemcpyAsync(zh.data(), zdev, c.P.NZ * 8, hipMemcpyDeviceToHost, c.stream));
+    c.sync();
+    const Plan &P = c.P;
+    // only this shard's rows are written; other rows keep the caller's content
+    for (size_t k = 0; k < P.o_row.size(); ++k) {
+        const int64_t row = P.o_row[k];
+        const int cam = P.o_cam[k];
+        for (int d = 0; d < 2; ++d) {
+            const double u = img[2 * row + d];
+            if (r_unw) r_unw[2 * row + d] = u;
+            if (r_wgt) {
+                const double w = P.uniform_w ? P.cam_w[2 * cam + d] : P.o_w[2 * k + d];
+                r_wgt[2 * row + d] = u * w;
+            }
+        }
+    }
+    int64_t row = 2 * P.no;
+    for (int64_t zi : P.prior_z) {
+        const double e = zh[zi] - P.z_prv[zi];
+        if (P.z_mine[zi] || P.nranks == 1) {
+            if (r_unw) r_unw[row] = e;
+            if (r_wgt) r_wgt[row] = e * std::sqrt(P.z_prw[zi]);
+        }
+        ++row;
+    }
+}
+
+int dbat_hip_residual(dbat_hip_handle *h, const double *x, double *r_unweighted, double *f) {
+    API_TRY
+    if (!h || !x) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
+    Core &c = *h->core;
+    c.x_to_z(x, c.zt.p);
+    export_residuals(c, c.zt.p, r_unweighted, nullptr, f);
+    return DBAT_HIP_OK;
+    API_CATCH
+}
+
+int dbat_hip_jacobian_blocks(dbat_hip_handle *h, const double *x, double *JEO, double *JOP, double *JIO) {
+    API_TRY
+    if (!h || !x) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
+    Core &c = *h->core;
+    const Plan &P = c.P;
+    c.x_to_z(x, c.zt.p);
+    c.prep_cams(c.zt.p);
+    DevBuf<double> a, b, cc;
+    const int64_t no = std::max<int64_t>(P.no, 1);
+    if (JEO) { a.alloc(12 * no); HIPCHK(hipMemsetAsync(a.p, 0, 12 * no * 8, c.stream)); }
+    if (JOP) { b.alloc(6 * no); HIPCHK(hipMemsetAsync(b.p, 0, 6 * no * 8, c.stream)); }
+    if (JIO) { cc.alloc(2 * (int64_t)P.nIOrows * no); HIPCHK(hipMemsetAsync(cc.p, 0, 2 * (int64_t)P.nIOrows * no * 8, c.stream)); }
+    if (c.nobs > 0) {
+#define L_JB(M, dummy) hipLaunchKernelGGL((k_jac_blocks<M>), dim3((unsigned)cdiv(c.nobs, 256)), dim3(256), 0, c.stream, c.d, c.zt.p, c.cams.p, a.p, b.p, cc.p)
+        switch (P.model) { case 2: L_JB(2, 0); break; case 3: L_JB(3, 0); break; case 4: L_JB(4, 0); break; default: L_JB(5, 0); break; }
+#undef L_JB
+    }
+    if (JEO) HIPCHK(hipMemcpyAsync(JEO, a.p, 12 * P.no * 8, hipMemcpyDeviceToHost, c.stream));
+    if (JOP) HIPCHK(hipMemcpyAsync(JOP, b.p, 6 * P.no * 8, hipMemcpyDeviceToHost, c.stream));
+    if (JIO) HIPCHK(hipMemcpyAsync(JIO, cc.p, 2 * (int64_t)P.nIOrows * P.no * 8, hipMemcpyDeviceToHost, c.stream));
+    c.sync();
+    return DBAT_HIP_OK;
+    API_CATCH
+}
+
+int dbat_hip_linearize_solve(dbat_hip_handle *h, const double *x, double lambda, int32_t scale_columns,
+                             double *p, double *stats) {
+    API_TRY
+    if (!h || !x) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
+    Core &c = *h->core;
+    c.x_to_z(x, c.z.p);
+    c.build(c.z.p, lambda, scale_columns);
+    double JpJp, rJp, pp;
+    const bool singular = c.solve(JpJp, rJp, pp);
+    if (p) c.z_to_x(c.dz.p, p);
+    if (stats) {
+        stats[0] = c.f_lin; stats[1] = JpJp; stats[2] = rJp; stats[3] = pp;
+        stats[4] = c.trace_jtj; stats[5] = singular ? 1.0 : 0.0; stats[6] = 0; stats[7] = 0;
+    }
+    return DBAT_HIP_OK;
+    API_CATCH
+}
+
+int dbat_hip_gradient(dbat_hip_handle *h, double *g) {
+    API_TRY
+    if (!h || !g || !h->core->have_lin) { g_err = "no linearisation"; return DBAT_HIP_EINVAL; }
+    Core &c = *h->core;
+    c.gradient(c.vtmp.p);
+    c.z_to_x(c.vtmp.p, g);
+    return DBAT_HIP_OK;
+    API_CATCH
+}
+
+int dbat_hip_colnorms(dbat_hip_handle *h, double *Jn) {
+    API_TRY
+    if (!h || !Jn || !h->core->have_lin) { g_err = "no linearisation"; return DBAT_HIP_EINVAL; }
+    Core &c = *h->core;
+    c.colnorm2(c.vtmp.p);
+    c.z_to_x(c.vtmp.p, Jn);
+    for (int64_t i = 0; i < c.P.n; ++i) Jn[i] = std::sqrt(Jn[i]);
+    return DBAT_HIP_OK;
+    API_CATCH
+}
+
+int dbat_hip_jtimes_sqnorm(dbat_hip_handle *h, const double *v, double *sqnorm) {
+    API_TRY
+    if (!h || !v || !sqnorm || !h->core->have_lin) { g_err = "no linearisation"; return DBAT_HIP_EINVAL; }
+    Core &c = *h->core;
+    HIPCHK(hipMemsetAsync(c.vtmp.p, 0, c.P.NZ * 8, c.stream));
+    if (c.P.n) {
+        HIPCHK(hipMemcpyAsync(c.xbuf.p, v, c.P.n * 8, hipMemcpyHostToDevice, c.stream));
+        hipLaunchKernelGGL(k_scatter_x, dim3((unsigned)cdiv(c.P.n, 256)), dim3(256), 0, c.stream, c.P.n, c.x2z.p, c.xbuf.p, c.vtmp.p);
+    }
+    double a, b, vv;
+    c.jtimes(c.vtmp.p, a, b, vv);
+    *sqnorm = a;
+    return DBAT_HIP_OK;
+    API_CATCH
+}
+
+int dbat_hip_solve(dbat_hip_handle *h, const dbat_hip_options *opt, double *x, dbat_hip_result *result,
+                   double *res, double *damp, double *aux, double *trace) {
+    API_TRY
+    if (!h || !opt || !x || !result) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
+    if (opt->damping < 0 || opt->damping > 3) { g_err = "Unknown damping"; return DBAT_HIP_EINVAL; }
+    if (opt->store_trace && !trace) { g_err = "store_trace without a trace buffer"; return DBAT_HIP_EINVAL; }
+    Core &c = *h->core;
+    c.n_res_evals = c.n_lin = c.n_solves = 0;
+    c.x_to_z(x, c.z.p);
+    c.lambda_lin = NAN;
+    LoopOut out;
+    const auto t0 = std::chrono::steady_clock::now();
+    switch (opt->damping) {
+        case DBAT_HIP_DAMP_GM: loop_gm(c, *opt, out); break;
+        case DBAT_HIP_DAMP_GNA: loop_gna(c, *opt, out); break;
+        case DBAT_HIP_DAMP_LM: loop_lm(c, *opt, out); break;
+        default: {
+            double delta0 = opt->delta0;
+            if (!(delta0 > 0)) {                                   // bundle.m:325 delta0 = norm(x0)
+                double s = 0;
+                for (int64_t i = 0; i < c.P.n; ++i) s += x[i] * x[i];
+                delta0 = std::sqrt(s);
+            }
+            loop_lmp(c, *opt, delta0, out);
+        }
+    }
+    c.sync();
+    result->time_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    result->code = out.code; result->iters = out.iters;
+    c.z_to_x(c.z.p, x);
+    const int cap_res = opt->max_iter + 3, cap_d = 2 * opt->max_iter + 4;
+    result->n_res = (int)std::min<size_t>(out.res.size(), cap_res);
+    if (res) for (int i = 0; i < result->n_res; ++i) res[i] = out.res[i];
+    result->n_damp = (int)std::min<size_t>(out.damp.size(), cap_d);
+    if (damp) for (int i = 0; i < result->n_damp; ++i) damp[i] = out.damp[i];
+    if (aux) for (int i = 0; i < cap_d; ++i) aux[i] = i < (int)out.aux.size() ? out.aux[i] : NAN;
+    result->n_trace = 0;
+    if (opt->store_trace && trace) {
+        const int cap_t = opt->max_iter + 2;
+        result->n_trace = (int)std::min<size_t>(out.trace.size(), cap_t);
+        for (int k = 0; k < result->n_trace; ++k)
+            for (int64_t i = 0; i < c.P.n; ++i)
+                trace[(int64_t)k * c.P.n + i] = out.trace[k].empty() ? NAN : out.trace[k][i];
+    }
+    const double dof = (double)(c.P.m - c.P.n);
+    result->sigma0 = std::sqrt(2 * out.f_final / dof);            // bundle.m:476-483
+    result->n_residual_evals = c.n_res_evals; result->n_linearizations = c.n_lin; result->n_solves = c.n_solves;
+    return DBAT_HIP_OK;
+    API_CATCH
+}
+
+int dbat_hip_final_residuals(dbat_hip_handle *h, double *r_unweighted, double *r_weighted) {
+    API_TRY
+    if (!h || !h->core->have_lin) { g_err = "no linearisation"; return DBAT_HIP_EINVAL; }
+    Core &c = *h->core;
+    export_residuals(c, c.zlin.p, r_unweighted, r_weighted, nullptr);
+    return DBAT_HIP_OK;
+    API_CATCH
+}
+
+int dbat_hip_set_allreduce(dbat_hip_handle *h, dbat_hip_allreduce_fn fn, void *user) {
+    if (!h) { g_err = "null handle"; return DBAT_HIP_EINVAL; }
+    h->core->allreduce = fn; h->core->allreduce_user = user;
+    return DBAT_HIP_OK;
+}
+
+int dbat_hip_owned_mask(const dbat_hip_handle *h, uint8_t *mask) {
+    if (!h || !mask) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
+    const Plan &P = h->core->P;
+    for (int64_t i = 0; i < P.n; ++i) mask[i] = P.z_mine[P.x2z[i]];
+    return DBAT_HIP_OK;
+}
+
+int dbat_hip_set_x(dbat_hip_handle *h, const double *x) {
+    API_TRY
+    if (!h || !x) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
+    Core &c = *h->core;
+    c.x_to_z(x, c.z.p);
+    c.sync();
+    return DBAT_HIP_OK;
+    API_CATCH
+}
+
+int dbat_hip_bench_step(dbat_hip_handle *h, double lambda, int32_t scale_columns, double *ms) {
+    API_TRY
+    if (!h) { g_err = "null handle"; return DBAT_HIP_EINVAL; }
+    Core &c = *h->core;
+    HIPCHK(hipEventRecord(c.ev[0], c.stream));
+    c.build_enqueue(c.z.p, lambda);
+    c.do_allreduce(c.red.p, c.red_count);
+    c.finish_enqueue(c.z.p, lambda, scale_columns);
+    HIPCHK(hipMemcpyAsync(c.zlin.p, c.z.p, c.P.NZ * 8, hipMemcpyDeviceToDevice, c.stream));
+    HIPCHK(hipEventRecord(c.ev[1], c.stream));
+    c.factor_solve_enqueue();
+    HIPCHK(hipEventRecord(c.ev[2], c.stream));
+    c.backsub_enqueue();
+    c.do_allreduce(c.scal.p, 8);
+    HIPCHK(hipEventRecord(c.ev[3], c.stream));
+    c.axpby(1.0, c.z.p, 1.0, c.dz.p, c.zt.p);
+    (void)c.eval_f(c.zt.p, nullptr, nullptr);                     // trial-point residual, syncs
+    HIPCHK(hipEventRecord(c.ev[4], c.stream));
+    c.sync();
+    c.have_lin = true; c.lambda_lin = lambda; c.scale_lin = scale_columns; c.s_valid = false;
+    if (ms)
+        for (int i = 0; i < 4; ++i) {
+            float t = 0;
+            HIPCHK(hipEventElapsedTime(&t, c.ev[i], c.ev[i + 1]));
+            ms[i] = t;
+        }
+    return DBAT_HIP_OK;
+    API_CATCH
+}
+
+int dbat_hip_info(const dbat_hip_handle *h, int64_t *info) {
+    if (!h || !info) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
+    const Core &c = *h->core;
+    info[0] = c.P.NS; info[1] = c.nb; info[2] = c.P.max_k; info[3] = c.nobs;
+    info[4] = c.P.pt_hi - c.P.pt_lo; info[5] = c.P.BT; info[6] = c.P.ncolmax; info[7] = c.P.n;
+    return DBAT_HIP_OK;
+}
+
+/* Host evaluation of the per-observation model (debug / CPU unit tests of
+ * model.hpp only; never used by the product path). */
+int dbat_hip_debug_model_eval_host(int32_t model, int32_t nK, int32_t nP, const double *EO6, const double *IO,
+                                   double px_size, const double *Q3, const double *uv, double *r2,
+                                   double *A12, double *B6, double *C /* 2 x nIOrows */) {
+    if (model < 2 || model > 5 || nK < 0 || nK > MAXK || nP < 0 || nP > MAXP) { g_err = "bad model"; return DBAT_HIP_EINVAL; }
+    CamRec c{};
+    c.c[0] = EO6[0]; c.c[1] = EO6[1]; c.c[2] = EO6[2];
+    cam_rotation(EO6 + 3, c.Mt, c.dMt);
+    c.f = IO[0]; c.pp[0] = IO[1]; c.pp[1] = IO[2]; c.b[0] = IO[3]; c.b[1] = IO[4];
+    for (int k = 0; k < nK; ++k) c.K[k] = IO[5 + k];
+    for (int k = 0; k < nP; ++k) c.P[k] = IO[5 + nK + k];
+    c.sz = px_size;
+    double r[2], A[2][6], B[2][3], Cf[2][MAXIO];
+    switch (model) {
+        case 2: obs_eval<2, true, true>(c, nK, nP, Q3, uv[0], uv[1], r, A, B, Cf); break;
+        case 3: obs_eval<3, true, true>(c, nK, nP, Q3, uv[0], uv[1], r, A, B, Cf); break;
+        case 4: obs_eval<4, true, true>(c, nK, nP, Q3, uv[0], uv[1], r, A, B, Cf); break;
+        default: obs_eval<5, true, true>(c, nK, nP, Q3, uv[0], uv[1], r, A, B, Cf); break;
+    }
+    r2[0] = r[0]; r2[1] = r[1];
+    for (int k = 0; k < 6; ++k) { A12[2 * k] = A[0][k]; A12[2 * k + 1] = A[1][k]; }
+    for (int k = 0; k < 3; ++k) { B6[2 * k] = B[0][k]; B6[2 * k + 1] = B[1][k]; }
+    for (int k = 0; k < 5 + nK + nP; ++k) { C[2 * k] = Cf[0][k]; C[2 * k + 1] = Cf[1][k]; }
+    return DBAT_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,614 @@
+// HIP kernels of the bundle hot path (gfx950, FP64, 64-lane wavefronts).
+//
+// Layout: observations are stored point-major ("processing order") in
+// batches of whole object points, at most BT observations per batch; one
+// workgroup (BT threads) handles one batch, one lane handles one observation.
+// The Jacobian is never materialised: every pass recomputes the 2x6 / 2x3 /
+// 2xnIO blocks of its observation from (u,v), the camera record and the
+// object point (F5-F9 of SURVEY.md 8(a)).
+//
+//   k_cam_prep   per camera: rotation, its derivatives, IO fan-out   (K0)
+//   k_residual   residual only, 0.5*r'r                               (K2)
+//   k_build      residual + Jacobian blocks + point blocks V, g_p,
+//                V^-1 and the Schur complement S -= (W V^-1) W'       (K1,K3,K4,K5)
+//   k_finish / k_scale_S   priors, damping, fixed rows, column scaling (F11)
+//   k_backsub    dp = -V^-1 (g_p + W' dc), J*p sums                   (K7,K8,K9)
+//   k_jtimes     ||J v||^2, r'Jv                                      (K8)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "model.hpp"
+
+namespace dbat {
+
+struct DevProblem {
+    // sizes
+    int nc, np, nIOrows, nK, nP, nIOu, ncolmax, BT;
+    int64_t NS, NZ, nobs, nb;
+    // camera static data
+    const int32_t *cam_ncol, *cam_col, *cam_iorow;
+    const uint32_t *cam_eo_est;
+    const int32_t *io_src;          // [nIOrows*nc]
+    const double *io_fixed;         // [nIOrows*nc]
+    const double *px;               // [2*nc]
+    const double *cam_w;            // [2*nc]
+    // z metadata
+    const uint8_t *z_est, *z_mine;
+    const double *z_prw, *z_prv;
+    // observations (processing order)
+    const int32_t *o_cam, *o_pt;
+    const double *o_uv;
+    const double *o_w;              // may be null (uniform)
+    const uint32_t *o_seg;
+    const int64_t *o_row;
+    const int64_t *batch_start;
+};
+
+__device__ __forceinline__ void atomic_add_f64(double *p, double v) {
+    unsafeAtomicAdd(p, v);          // global_atomic_add_f64 / ds_add_f64 on gfx950
+}
+
+// ---------------------------------------------------------------- K0 ----
+__global__ void k_cam_prep(DevProblem d, const double *__restrict__ z, CamRec *__restrict__ cams) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.nc) return;
+    CamRec r;
+    const double *eo = z + 6 * (int64_t)c;
+    r.c[0] = eo[0]; r.c[1] = eo[1]; r.c[2] = eo[2];
+    const double ang[3] = {eo[3], eo[4], eo[5]};
+    cam_rotation(ang, r.Mt, r.dMt);
+    double io[MAXIO];
+    for (int k = 0; k < MAXIO; ++k) {
+        io[k] = 0;
+        if (k < d.nIOrows) {
+            const int32_t s = d.io_src[(int64_t)c * d.nIOrows + k];
+            io[k] = s >= 0 ? z[6 * (int64_t)d.nc + s] : d.io_fixed[(int64_t)c * d.nIOrows + k];
+        }
+    }
+    r.f = io[0]; r.pp[0] = io[1]; r.pp[1] = io[2]; r.b[0] = io[3]; r.b[1] = io[4];
+    for (int k = 0; k < MAXK; ++k) r.K[k] = k < d.nK ? io[5 + k] : 0.0;
+    for (int k = 0; k < MAXP; ++k) r.P[k] = k < d.nP ? io[5 + d.nK + k] : 0.0;
+    r.sz = d.px[2 * c];
+    r.w[0] = d.cam_w[2 * c]; r.w[1] = d.cam_w[2 * c + 1];
+    r.ncol = d.cam_ncol[c];
+    for (int k = 0; k < MAXCOL; ++k) r.col[k] = d.cam_col[(int64_t)c * MAXCOL + k];
+    for (int k = 0; k < MAXIO; ++k) r.iorow[k] = d.cam_iorow[(int64_t)c * MAXIO + k];
+    r.eo_est = d.cam_eo_est[c];
+    cams[c] = r;
+}
+
+// block-wide sum of NV values per thread; result valid in thread 0
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double *sh /* >= NV*nwaves */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        double x = v[i];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if (lane == 0) sh[i * nw + wave] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            double s = 0;
+            for (int w = 0; w < nw; ++w) s += sh[i * nw + w];
+            v[i] = s;
+        }
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------- K2 ----
+// Residual only.  partial[blockIdx] = sum of squared weighted residuals.
+// r_w (weighted, processing order) and r_unw (mm, reference row order) optional.
+template <int MODEL>
+__global__ __launch_bounds__(256) void k_residual(DevProblem d, const double *__restrict__ z,
+                                                  const CamRec *__restrict__ cams,
+                                                  double *__restrict__ partial,
+                                                  double *__restrict__ r_w, double *__restrict__ r_unw) {
+    __shared__ double sh[8];
+    double acc[1] = {0.0};
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < d.nobs; o += stride) {
+        const int cam = d.o_cam[o], pt = d.o_pt[o];
+        const CamRec &C = cams[cam];
+        const double *q = z + d.NS + 3 * (int64_t)pt;
+        const double Q[3] = {q[0], q[1], q[2]};
+        double r[2];
+        double(*nil6)[6] = nullptr; double(*nil3)[3] = nullptr; double(*nilc)[MAXIO] = nullptr;
+        obs_eval<MODEL, false, false>(C, d.nK, d.nP, Q, d.o_uv[2 * o], d.o_uv[2 * o + 1], r, nil6, nil3, nilc);
+        if (r_unw) { const int64_t row = d.o_row[o]; r_unw[2 * row] = r[0]; r_unw[2 * row + 1] = r[1]; }
+        const double w0 = d.o_w ? d.o_w[2 * o] : C.w[0], w1 = d.o_w ? d.o_w[2 * o + 1] : C.w[1];
+        r[0] *= w0; r[1] *= w1;
+        if (r_w) { r_w[2 * o] = r[0]; r_w[2 * o + 1] = r[1]; }
+        acc[0] += r[0] * r[0] + r[1] * r[1];
+    }
+    block_sum<1>(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc[0];
+}
+
+// prior-observation rows (prior_obs.m:26-43): sum over owned z of w*(z-prior)^2
+__global__ __launch_bounds__(256) void k_prior_sq(DevProblem d, const double *__restrict__ z,
+                                                  double *__restrict__ partial) {
+    __shared__ double sh[8];
+    double acc[1] = {0.0};
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.NZ; i += stride) {
+        const double w = d.z_prw[i];
+        if (w > 0 && d.z_mine[i]) { const double e = z[i] - d.z_prv[i]; acc[0] += w * e * e; }
+    }
+    block_sum<1>(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc[0];
+}
+
+// sum npart partials (NV interleaved values each) into out[NV]; single block
+template <int NV>
+__global__ __launch_bounds__(256) void k_sum_partials(const double *__restrict__ partial, int64_t npart,
+                                                      double *__restrict__ out, int accumulate) {
+    __shared__ double sh[NV * 4];
+    double acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = 0;
+    for (int64_t k = threadIdx.x; k < npart; k += blockDim.x)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) acc[i] += partial[k * NV + i];
+    block_sum<NV>(acc, sh);
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) out[i] = accumulate ? out[i] + acc[i] : acc[i];
+}
+
+// 3x3 SPD inverse via the adjugate (symmetric storage a00 a01 a02 a11 a12 a22)
+__device__ __forceinline__ bool inv3_sym(const double a[6], double inv[6]) {
+    const double c00 = a[3] * a[5] - a[4] * a[4];
+    const double c01 = a[2] * a[4] - a[1] * a[5];
+    const double c02 = a[1] * a[4] - a[2] * a[3];
+    const double det = a[0] * c00 + a[1] * c01 + a[2] * c02;
+    const double id = 1.0 / det;
+    inv[0] = c00 * id; inv[1] = c01 * id; inv[2] = c02 * id;
+    inv[3] = (a[0] * a[5] - a[2] * a[2]) * id;
+    inv[4] = (a[1] * a[2] - a[0] * a[4]) * id;
+    inv[5] = (a[0] * a[3] - a[1] * a[1]) * id;
+    return det > 0 && c00 >= 0 && (a[0] > 0);
+}
+
+// Evaluate one observation, weight it, mask fixed parameters and gather the
+// camera-side columns E = [A | C(:,estimated IO rows)].
+template <int MODEL, bool WITH_IO>
+__device__ __forceinline__ void eval_obs_cols(const DevProblem &d, const CamRec &C, const double *z,
+                                              int64_t o, int pt, double r[2],
+                                              double E[2][WITH_IO ? MAXCOL : 6], double B[2][3]) {
+    const double *q = z + d.NS + 3 * (int64_t)pt;
+    const double Q[3] = {q[0], q[1], q[2]};
+    double A[2][6];
+    double Cf[2][MAXIO];                       // untouched (and optimised away) when !WITH_IO
+    obs_eval<MODEL, true, WITH_IO>(C, d.nK, d.nP, Q, d.o_uv[2 * o], d.o_uv[2 * o + 1], r, A, B, Cf);
+    const double w0 = d.o_w ? d.o_w[2 * o] : C.w[0], w1 = d.o_w ? d.o_w[2 * o + 1] : C.w[1];
+    r[0] *= w0; r[1] *= w1;
+    const uint8_t *pe = d.z_est + d.NS + 3 * (int64_t)pt;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double m = pe[k] ? 1.0 : 0.0;
+        B[0][k] *= w0 * m; B[1][k] *= w1 * m;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double m = ((C.eo_est >> k) & 1u) ? 1.0 : 0.0;
+        E[0][k] = A[0][k] * w0 * m; E[1][k] = A[1][k] * w1 * m;
+    }
+    if constexpr (WITH_IO) {
+#pragma unroll
+        for (int j = 0; j < MAXIO; ++j) {
+            double c0 = 0, c1 = 0;
+            if (6 + j < C.ncol) {
+                const int row = C.iorow[j];
+#pragma unroll
+                for (int rr = 0; rr < MAXIO; ++rr) if (rr == row) { c0 = Cf[0][rr]; c1 = Cf[1][rr]; }
+            }
+            E[0][6 + j] = c0 * w0; E[1][6 + j] = c1 * w1;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- K1 ----
+// One workgroup per batch; lane t <-> observation batch_start[b]+t.
+// Outputs: S (lower triangle, NS x NS column-major, atomically accumulated),
+// g_c (J_c' r), g_red (g_c - W V^-1 g_p), diagU (sum of squared camera-side
+// Jacobian columns), per point Vinv[6], gp[3], jn2[3] (squared column norms),
+// r_w (weighted residuals), partial sums of r'r.
+template <int MODEL, bool WITH_IO>
+__global__ __launch_bounds__(256) void k_build(DevProblem d, const double *__restrict__ z,
+                                               const CamRec *__restrict__ cams, double lambda,
+                                               double *__restrict__ S, double *__restrict__ g_c,
+                                               double *__restrict__ g_red, double *__restrict__ diagU,
+                                               double *__restrict__ Vinv, double *__restrict__ gp,
+                                               double *__restrict__ jn2p, double *__restrict__ r_w,
+                                               double *__restrict__ partial) {
+    constexpr int NCX = WITH_IO ? MAXCOL : 6;
+    extern __shared__ double smem[];
+    const int BT = blockDim.x;
+    const int strideW = d.ncolmax * 3;
+    double *Wl = smem;                               // [BT][strideW]
+    double *red = Wl + (size_t)BT * strideW;         // [BT][9]  B'B (6) | B'r (3)
+    double *pinfo = red + (size_t)BT * 9;            // [BT][9]  Vinv (6) | gp (3)
+    __shared__ double sh[8];
+
+    const int t = threadIdx.x;
+    const int64_t o0 = d.batch_start[blockIdx.x];
+    const int nobs = (int)(d.batch_start[blockIdx.x + 1] - o0);
+    const bool active = t < nobs;
+    const int64_t o = o0 + t;
+
+    double r[2] = {0, 0};
+    double E[2][NCX];
+    double B[2][3];
+    int cam = 0, pt = 0, seg_start = 0, seg_len = 0, ncol = 6;
+    const CamRec *C = cams;
+    if (active) {
+        cam = d.o_cam[o]; pt = d.o_pt[o];
+        const uint32_t sg = d.o_seg[o];
+        seg_start = sg & 0xFFFF; seg_len = sg >> 16;
+        C = cams + cam;
+        ncol = WITH_IO ? C->ncol : 6;
+        eval_obs_cols<MODEL, WITH_IO>(d, *C, z, o, pt, r, E, B);
+        r_w[2 * o] = r[0]; r_w[2 * o + 1] = r[1];
+        double *rd = red + (size_t)t * 9;
+        rd[0] = B[0][0] * B[0][0] + B[1][0] * B[1][0];
+        rd[1] = B[0][0] * B[0][1] + B[1][0] * B[1][1];
+        rd[2] = B[0][0] * B[0][2] + B[1][0] * B[1][2];
+        rd[3] = B[0][1] * B[0][1] + B[1][1] * B[1][1];
+        rd[4] = B[0][1] * B[0][2] + B[1][1] * B[1][2];
+        rd[5] = B[0][2] * B[0][2] + B[1][2] * B[1][2];
+        rd[6] = B[0][0] * r[0] + B[1][0] * r[1];
+        rd[7] = B[0][1] * r[0] + B[1][1] * r[1];
+        rd[8] = B[0][2] * r[0] + B[1][2] * r[1];
+    }
+    __syncthreads();
+    // ---- per point: V, g_p, damping, priors, V^-1 (K3,K4)
+    if (active && t == seg_start) {
+        double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+        for (int j = 0; j < seg_len; ++j) {
+            const double *rd = red + (size_t)(t + j) * 9;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) V[k] += rd[k];
+            g[0] += rd[6]; g[1] += rd[7]; g[2] += rd[8];
+        }
+        const int64_t zp = d.NS + 3 * (int64_t)pt;
+        const int dix[3] = {0, 3, 5};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double pw = d.z_prw[zp + k];
+            if (pw > 0) { V[dix[k]] += pw; g[k] += pw * (z[zp + k] - d.z_prv[zp + k]); }
+            jn2p[3 * (int64_t)pt + k] = V[dix[k]];
+            if (d.z_est[zp + k]) V[dix[k]] += lambda; else V[dix[k]] = 1.0;
+        }
+        double inv[6];
+        inv3_sym(V, inv);
+        double *pi = pinfo + (size_t)t * 9;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { pi[k] = inv[k]; Vinv[6 * (int64_t)pt + k] = inv[k]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { pi[6 + k] = g[k]; gp[3 * (int64_t)pt + k] = g[k]; }
+    }
+    __syncthreads();
+    // ---- W = E'B, Y = W V^-1, reduced right-hand side
+    double Vi[6] = {0, 0, 0, 0, 0, 0}, gpt[3] = {0, 0, 0};
+    double W[WITH_IO ? 1 : 6][3], Y[WITH_IO ? 1 : 6][3];
+    if (active) {
+        const double *pi = pinfo + (size_t)seg_start * 9;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Vi[k] = pi[k];
+        gpt[0] = pi[6]; gpt[1] = pi[7]; gpt[2] = pi[8];
+        double *wl = Wl + (size_t)t * strideW;
+#pragma unroll
+        for (int a = 0; a < NCX; ++a) {
+            if (a < ncol) {
+                const double w0 = E[0][a] * B[0][0] + E[1][a] * B[1][0];
+                const double w1 = E[0][a] * B[0][1] + E[1][a] * B[1][1];
+                const double w2 = E[0][a] * B[0][2] + E[1][a] * B[1][2];
+                wl[3 * a] = w0; wl[3 * a + 1] = w1; wl[3 * a + 2] = w2;
+                const double y0 = w0 * Vi[0] + w1 * Vi[1] + w2 * Vi[2];
+                const double y1 = w0 * Vi[1] + w1 * Vi[3] + w2 * Vi[4];
+                const double y2 = w0 * Vi[2] + w1 * Vi[4] + w2 * Vi[5];
+                if constexpr (!WITH_IO) { W[a][0] = w0; W[a][1] = w1; W[a][2] = w2; Y[a][0] = y0; Y[a][1] = y1; Y[a][2] = y2; }
+                const int col = C->col[a];
+                const double ga = E[0][a] * r[0] + E[1][a] * r[1];
+                atomic_add_f64(g_c + col, ga);
+                atomic_add_f64(g_red + col, ga - (y0 * gpt[0] + y1 * gpt[1] + y2 * gpt[2]));
+                atomic_add_f64(diagU + col, E[0][a] * E[0][a] + E[1][a] * E[1][a]);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- Schur complement (K5): S(rows of obs j, cols of obs i) += [i==j] E'E - Y_i W_j'
+    if (active) {
+        if constexpr (!WITH_IO) {
+            // cameras ascend inside a point, so partners j>=i give lower-triangle blocks
+            const int cbase = 6 * cam;
+            for (int jj = t; jj < seg_start + seg_len; ++jj) {
+                const double *wj = Wl + (size_t)jj * strideW;
+                const int rbase = 6 * d.o_cam[o0 + jj];
+#pragma unroll
+                for (int b = 0; b < 6; ++b) {
+                    const double wb0 = wj[3 * b], wb1 = wj[3 * b + 1], wb2 = wj[3 * b + 2];
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) {
+                        double val = -(Y[a][0] * wb0 + Y[a][1] * wb1 + Y[a][2] * wb2);
+                        if (jj == t) {
+                            if (b < a) continue;
+                            val += E[0][a] * E[0][b] + E[1][a] * E[1][b];
+                        }
+                        atomic_add_f64(S + (int64_t)(cbase + a) * d.NS + (rbase + b), val);
+                    }
+                }
+            }
+        } else {
+            const double *wi = Wl + (size_t)t * strideW;
+            for (int a = 0; a < NCX; ++a) {
+                if (a >= ncol) break;
+                const int gcol = C->col[a];
+                const double w0 = wi[3 * a], w1 = wi[3 * a + 1], w2 = wi[3 * a + 2];
+                const double y0 = w0 * Vi[0] + w1 * Vi[1] + w2 * Vi[2];
+                const double y1 = w0 * Vi[1] + w1 * Vi[3] + w2 * Vi[4];
+                const double y2 = w0 * Vi[2] + w1 * Vi[4] + w2 * Vi[5];
+                double ea0 = 0, ea1 = 0;
+#pragma unroll
+                for (int q = 0; q < NCX; ++q) if (q == a) { ea0 = E[0][q]; ea1 = E[1][q]; }
+                for (int jj = seg_start; jj < seg_start + seg_len; ++jj) {
+                    const CamRec *Cj = cams + d.o_cam[o0 + jj];
+                    const double *wj = Wl + (size_t)jj * strideW;
+                    const int ncj = Cj->ncol;
+                    for (int b = 0; b < ncj; ++b) {
+                        const int grow = Cj->col[b];
+                        if (grow < gcol) continue;
+                        double val = -(y0 * wj[3 * b] + y1 * wj[3 * b + 1] + y2 * wj[3 * b + 2]);
+                        if (jj == t) {
+                            double eb0 = 0, eb1 = 0;
+#pragma unroll
+                            for (int q = 0; q < NCX; ++q) if (q == b) { eb0 = E[0][q]; eb1 = E[1][q]; }
+                            val += ea0 * eb0 + ea1 * eb1;
+                        }
+                        atomic_add_f64(S + (int64_t)gcol * d.NS + grow, val);
+                    }
+                }
+            }
+        }
+    }
+    double acc[1] = {r[0] * r[0] + r[1] * r[1]};
+    block_sum<1>(acc, sh);
+    if (t == 0) partial[blockIdx.x] = acc[0];
+}
+
+// ---------------------------------------------------------------- F11 ---
+// Camera/IO side: priors, damping, fixed rows, column scaling factors.
+//   jn2c[i] = diagU[i] + prior weight  (squared column norm of J)
+//   dscale[i] = 1/sqrt(jn2c) if scaling, estimated and >0 ; else 1
+//   rhs[i]  = -dscale[i]*g_red[i]   (0 for fixed)
+__global__ void k_finish(DevProblem d, const double *__restrict__ z, double lambda, int scale,
+                         double *__restrict__ S, double *__restrict__ g_c, double *__restrict__ g_red,
+                         const double *__restrict__ diagU, double *__restrict__ jn2c,
+                         double *__restrict__ dscale, double *__restrict__ rhs) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.NS) return;
+    const double pw = d.z_prw[i];
+    double add = 0, g = g_red[i], jn2 = diagU[i];
+    if (pw > 0) {
+        const double e = pw * (z[i] - d.z_prv[i]);
+        add += pw; g += e; jn2 += pw; g_c[i] += e; g_red[i] = g;
+    }
+    jn2c[i] = jn2;
+    const bool est = d.z_est[i] != 0;
+    double ds = 1.0;
+    if (est) {
+        add += lambda;
+        if (scale && jn2 > 0) ds = 1.0 / sqrt(jn2);
+        S[i * d.NS + i] += add;
+        rhs[i] = -ds * g;
+    } else {
+        S[i * d.NS + i] = 1.0;
+        rhs[i] = 0.0;
+    }
+    dscale[i] = ds;
+}
+
+// S(i,j) *= d_i d_j on the lower triangle
+__global__ void k_scale_S(int64_t NS, double *__restrict__ S, const double *__restrict__ ds) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // row
+    const int64_t j = blockIdx.y;                                        // column
+    if (i >= NS || i < j) return;
+    S[j * NS + i] *= ds[i] * ds[j];
+}
+
+__global__ void k_unscale(int64_t NS, const double *__restrict__ q, const double *__restrict__ ds,
+                          double *__restrict__ dz) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < NS) dz[i] = ds[i] * q[i];
+}
+
+// ---------------------------------------------------------------- K7 ----
+// Back-substitution dp = -V^-1 (g_p + W' dc) and the sums ||Jp||^2, r'Jp over
+// the image rows.  dz[0..NS) holds dc on entry; dz[NS..) receives dp.
+template <int MODEL, bool WITH_IO>
+__global__ __launch_bounds__(256) void k_backsub(DevProblem d, const double *__restrict__ z,
+                                                 const CamRec *__restrict__ cams,
+                                                 const double *__restrict__ Vinv, const double *__restrict__ gp,
+                                                 const double *__restrict__ r_w, double *__restrict__ dz,
+                                                 double *__restrict__ partial /* [nb][2] */) {
+    constexpr int NCX = WITH_IO ? MAXCOL : 6;
+    extern __shared__ double smem[];
+    double *red = smem;                 // [BT][3]  B't
+    double *dpl = red + (size_t)blockDim.x * 3;   // [BT][3]  dp at leader slot
+    __shared__ double sh[16];
+    const int t = threadIdx.x;
+    const int64_t o0 = d.batch_start[blockIdx.x];
+    const int nobs = (int)(d.batch_start[blockIdx.x + 1] - o0);
+    const bool active = t < nobs;
+    const int64_t o = o0 + t;
+    double r[2] = {0, 0}, tt[2] = {0, 0};
+    double E[2][NCX];
+    double B[2][3] = {{0, 0, 0}, {0, 0, 0}};
+    int pt = 0, seg_start = 0, seg_len = 0;
+    if (active) {
+        const int cam = d.o_cam[o]; pt = d.o_pt[o];
+        const uint32_t sg = d.o_seg[o];
+        seg_start = sg & 0xFFFF; seg_len = sg >> 16;
+        const CamRec &C = cams[cam];
+        const int ncol = WITH_IO ? C.ncol : 6;
+        eval_obs_cols<MODEL, WITH_IO>(d, C, z, o, pt, r, E, B);
+#pragma unroll
+        for (int a = 0; a < NCX; ++a)
+            if (a < ncol) { const double dc = dz[C.col[a]]; tt[0] += E[0][a] * dc; tt[1] += E[1][a] * dc; }
+        red[3 * t] = B[0][0] * tt[0] + B[1][0] * tt[1];
+        red[3 * t + 1] = B[0][1] * tt[0] + B[1][1] * tt[1];
+        red[3 * t + 2] = B[0][2] * tt[0] + B[1][2] * tt[1];
+    }
+    __syncthreads();
+    if (active && t == seg_start) {
+        double s[3] = {gp[3 * (int64_t)pt], gp[3 * (int64_t)pt + 1], gp[3 * (int64_t)pt + 2]};
+        for (int j = 0; j < seg_len; ++j) { s[0] += red[3 * (t + j)]; s[1] += red[3 * (t + j) + 1]; s[2] += red[3 * (t + j) + 2]; }
+        const double *vi = Vinv + 6 * (int64_t)pt;
+        const double p0 = -(vi[0] * s[0] + vi[1] * s[1] + vi[2] * s[2]);
+        const double p1 = -(vi[1] * s[0] + vi[3] * s[1] + vi[4] * s[2]);
+        const double p2 = -(vi[2] * s[0] + vi[4] * s[1] + vi[5] * s[2]);
+        const int64_t zp = d.NS + 3 * (int64_t)pt;
+        const double q0 = d.z_est[zp] ? p0 : 0.0, q1 = d.z_est[zp + 1] ? p1 : 0.0, q2 = d.z_est[zp + 2] ? p2 : 0.0;
+        dz[zp] = q0; dz[zp + 1] = q1; dz[zp + 2] = q2;
+        dpl[3 * t] = q0; dpl[3 * t + 1] = q1; dpl[3 * t + 2] = q2;
+    }
+    __syncthreads();
+    double acc[2] = {0, 0};
+    if (active) {
+        const double *dp = dpl + 3 * seg_start;
+        const double j0 = tt[0] + B[0][0] * dp[0] + B[0][1] * dp[1] + B[0][2] * dp[2];
+        const double j1 = tt[1] + B[1][0] * dp[0] + B[1][1] * dp[1] + B[1][2] * dp[2];
+        acc[0] = j0 * j0 + j1 * j1;
+        acc[1] = r_w[2 * o] * j0 + r_w[2 * o + 1] * j1;
+    }
+    block_sum<2>(acc, sh);
+    if (t == 0) { partial[2 * blockIdx.x] = acc[0]; partial[2 * blockIdx.x + 1] = acc[1]; }
+}
+
+// ---------------------------------------------------------------- K8 ----
+// partial[2*blk] += ||J v||^2, partial[2*blk+1] += r'Jv over image rows
+// (grid-stride; v in z layout).
+template <int MODEL, bool WITH_IO>
+__global__ __launch_bounds__(256) void k_jtimes(DevProblem d, const double *__restrict__ z,
+                                                const CamRec *__restrict__ cams, const double *__restrict__ v,
+                                                const double *__restrict__ r_w, double *__restrict__ partial) {
+    constexpr int NCX = WITH_IO ? MAXCOL : 6;
+    __shared__ double sh[16];
+    double acc[2] = {0, 0};
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < d.nobs; o += stride) {
+        const int cam = d.o_cam[o], pt = d.o_pt[o];
+        const CamRec &C = cams[cam];
+        const int ncol = WITH_IO ? C.ncol : 6;
+        double r[2], E[2][NCX], B[2][3];
+        eval_obs_cols<MODEL, WITH_IO>(d, C, z, o, pt, r, E, B);
+        const double *vp = v + d.NS + 3 * (int64_t)pt;
+        double j0 = B[0][0] * vp[0] + B[0][1] * vp[1] + B[0][2] * vp[2];
+        double j1 = B[1][0] * vp[0] + B[1][1] * vp[1] + B[1][2] * vp[2];
+#pragma unroll
+        for (int a = 0; a < NCX; ++a)
+            if (a < ncol) { const double vc = v[C.col[a]]; j0 += E[0][a] * vc; j1 += E[1][a] * vc; }
+        acc[0] += j0 * j0 + j1 * j1;
+        acc[1] += r_w[2 * o] * j0 + r_w[2 * o + 1] * j1;
+    }
+    block_sum<2>(acc, sh);
+    if (threadIdx.x == 0) { partial[2 * blockIdx.x] = acc[0]; partial[2 * blockIdx.x + 1] = acc[1]; }
+}
+
+// prior rows' share of {||Jv||^2, r'Jv, ||v||^2(owned)}: out[3] per block
+__global__ __launch_bounds__(256) void k_prior_jv(DevProblem d, const double *__restrict__ z,
+                                                  const double *__restrict__ v, double *__restrict__ partial) {
+    __shared__ double sh[24];
+    double acc[3] = {0, 0, 0};
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.NZ; i += stride) {
+        if (!d.z_mine[i]) continue;
+        const double w = d.z_prw[i], vi = d.z_est[i] ? v[i] : 0.0;
+        if (w > 0) { acc[0] += w * vi * vi; acc[1] += w * (z[i] - d.z_prv[i]) * vi; }
+        acc[2] += vi * vi;
+    }
+    block_sum<3>(acc, sh);
+    if (threadIdx.x == 0) { partial[3 * blockIdx.x] = acc[0]; partial[3 * blockIdx.x + 1] = acc[1]; partial[3 * blockIdx.x + 2] = acc[2]; }
+}
+
+// ---------------------------------------------------------------- K9 ----
+// generic owned dot products: out = sum_{mine} a_i*b_i
+__global__ __launch_bounds__(256) void k_dot(int64_t n, const uint8_t *__restrict__ mine,
+                                             const double *__restrict__ a, const double *__restrict__ b /* null => 1 */,
+                                             double *__restrict__ partial) {
+    __shared__ double sh[8];
+    double acc[1] = {0};
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        if (!mine || mine[i]) acc[0] += a[i] * (b ? b[i] : 1.0);
+    block_sum<1>(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc[0];
+}
+
+// y = a*x + b*y2   (any of the pointers may alias y)
+__global__ void k_axpby(int64_t n, double a, const double *__restrict__ x, double b,
+                        const double *__restrict__ y2, double *__restrict__ y) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = a * x[i] + b * y2[i];
+}
+
+// gradient in z layout: g[0..NS) = g_c, g[NS..) = g_p (0 for fixed / unowned)
+__global__ void k_gradient(DevProblem d, const double *__restrict__ g_c, const double *__restrict__ gp,
+                           double *__restrict__ g) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.NZ) return;
+    double v = 0;
+    if (d.z_est[i]) v = i < d.NS ? g_c[i] : (d.z_mine[i] ? gp[i - d.NS] : 0.0);
+    g[i] = v;
+}
+
+// squared column norms in z layout
+__global__ void k_jn2(DevProblem d, const double *__restrict__ jn2c, const double *__restrict__ jn2p,
+                      double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.NZ) return;
+    double v = 0;
+    if (d.z_est[i]) v = i < d.NS ? jn2c[i] : (d.z_mine[i] ? jn2p[i - d.NS] : 0.0);
+    out[i] = v;
+}
+
+// x (reference order) <-> z (internal order)
+__global__ void k_scatter_x(int64_t n, const int64_t *__restrict__ x2z, const double *__restrict__ x,
+                            double *__restrict__ z) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) z[x2z[i]] = x[i];
+}
+__global__ void k_gather_x(int64_t n, const int64_t *__restrict__ x2z, const double *__restrict__ z,
+                           double *__restrict__ x) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = z[x2z[i]];
+}
+
+// per-observation Jacobian blocks in reference order (dbat_hip_jacobian_blocks)
+template <int MODEL>
+__global__ __launch_bounds__(256) void k_jac_blocks(DevProblem d, const double *__restrict__ z,
+                                                    const CamRec *__restrict__ cams,
+                                                    double *__restrict__ JEO, double *__restrict__ JOP,
+                                                    double *__restrict__ JIO) {
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= d.nobs) return;
+    const int cam = d.o_cam[o], pt = d.o_pt[o];
+    const CamRec &C = cams[cam];
+    const double *q = z + d.NS + 3 * (int64_t)pt;
+    const double Q[3] = {q[0], q[1], q[2]};
+    double r[2], A[2][6], B[2][3], Cf[2][MAXIO];
+    obs_eval<MODEL, true, true>(C, d.nK, d.nP, Q, d.o_uv[2 * o], d.o_uv[2 * o + 1], r, A, B, Cf);
+    const int64_t k = d.o_row[o];
+    if (JEO) for (int c = 0; c < 6; ++c) { JEO[12 * k + 2 * c] = A[0][c]; JEO[12 * k + 2 * c + 1] = A[1][c]; }
+    if (JOP) for (int c = 0; c < 3; ++c) { JOP[6 * k + 2 * c] = B[0][c]; JOP[6 * k + 2 * c + 1] = B[1][c]; }
+    if (JIO) for (int c = 0; c < d.nIOrows; ++c) {
+        JIO[2 * (int64_t)d.nIOrows * k + 2 * c] = Cf[0][c];
+        JIO[2 * (int64_t)d.nIOrows * k + 2 * c + 1] = Cf[1][c];
+    }
+}
+
+}  // namespace dbat

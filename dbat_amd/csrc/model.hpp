@@ -1,0 +1,254 @@
+// Per-observation camera model for the bundle hot path (device + host).
+//
+// Closed-form, scalar restatement of the reference's chain of primitives for
+// one image observation (paths relative to /root/reference/code/):
+//   res_euler_brown_{0,1,2,3}.m   lens models 2..5 (brown_euler_cam4.m:127-130)
+//   eulerpinhole2.m:51-67,97-106  world2cam.m:46-49,76-82  pinhole.m:39,54-66
+//   eulerrotmat.m:81,109-124      scale2/aniscale2/aniscale2b/xlat2/affine2/skew
+//   brown_dist.m:52-57,83-89      brown_rad.m:48-52,73-94  brown_tang.m:58-70,91-137
+//   rad_scale.m:44-50,72-75       tang_scale.m:42-45,66-87
+//
+// v = lhs - rhs,  lhs = -f * pinhole(M'(Q-q0)),
+// rhs = T_post * brown(T_pre(x), -K, -P),  x = [sz*u1 ; -sz*u2] - u0.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dbat {
+
+constexpr int MAXK = 5;            // max radial coefficients
+constexpr int MAXP = 5;            // max tangential coefficients (P1,P2 + radial scaling terms)
+constexpr int MAXIO = 5 + MAXK + MAXP;
+constexpr int MAXCOL = 6 + MAXIO;  // camera-side columns of one observation
+
+// Per-camera record, rebuilt from the parameter vector before every pass.
+struct CamRec {
+    double Mt[9];        // world->camera rotation M' (row-major), M = R1(om)R2(ph)R3(ka)
+    double dMt[3][9];    // d(M')/d(omega,phi,kappa)
+    double c[3];         // camera centre
+    double f;            // camera constant cc
+    double pp[2];        // principal point
+    double b[2];         // aspect, skew
+    double K[MAXK];
+    double P[MAXP];
+    double sz;           // pixel size (pxSize(1,cam), multi_res.m:97,138)
+    double w[2];         // 1/sigma_mm for x,y rows when IP.std is uniform per camera
+    int32_t ncol;        // 6 + number of estimated IO rows of this camera
+    int32_t col[MAXCOL]; // reduced-system column of each camera-side column
+    int32_t iorow[MAXIO];// IO row behind column 6+j
+    uint32_t eo_est;     // bit k set: EO(k) estimated
+};
+
+#define DBAT_HD __host__ __device__ __forceinline__
+
+// eulerrotmat.m:81,109-124 (seq 123, moving axes) and the transposition of
+// eulerpinhole2.m:54-60.
+DBAT_HD void cam_rotation(const double ang[3], double Mt[9], double dMt[3][9]) {
+    const double so = sin(ang[0]), co = cos(ang[0]);
+    const double sp = sin(ang[1]), cp = cos(ang[1]);
+    const double sk = sin(ang[2]), ck = cos(ang[2]);
+    const double R1[9] = {1, 0, 0, 0, co, -so, 0, so, co};
+    const double R2[9] = {cp, 0, sp, 0, 1, 0, -sp, 0, cp};
+    const double R3[9] = {ck, -sk, 0, sk, ck, 0, 0, 0, 1};
+    const double G1[9] = {0, 0, 0, 0, 0, -1, 0, 1, 0};
+    const double G2[9] = {0, 0, 1, 0, 0, 0, -1, 0, 0};
+    const double G3[9] = {0, -1, 0, 1, 0, 0, 0, 0, 0};
+    auto mul = [](const double *a, const double *b, double *c) {
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double s = 0;
+                for (int k = 0; k < 3; ++k) s += a[3 * i + k] * b[3 * k + j];
+                c[3 * i + j] = s;
+            }
+    };
+    double R12[9], M[9], t[9], t2[9], d1[9], d2[9], d3[9];
+    mul(R1, R2, R12);
+    mul(R12, R3, M);
+    mul(G1, M, d1);            // dA1 = P1*M
+    mul(R12, G2, t);
+    mul(t, R3, d2);            // dA2 = M1*M2*P2*M3
+    mul(M, G3, d3);            // dA3 = M*P3
+    (void)t2;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            Mt[3 * i + j] = M[3 * j + i];
+            dMt[0][3 * i + j] = d1[3 * j + i];
+            dMt[1][3 * i + j] = d2[3 * j + i];
+            dMt[2][3 * i + j] = d3[3 * j + i];
+        }
+}
+
+// Image-side part: rhs and its derivatives.  a = pre-distortion coordinates.
+//   l    = brown_dist(a,-K,-P)
+//   dLU  = d l / d a (2x2)
+struct ImgSide {
+    double rhs[2];
+    double dU0[2][2];
+    double dB[2][2];
+    double dK[2][MAXK];
+    double dP[2][MAXP];
+};
+
+template <int MODEL, bool JAC>
+DBAT_HD void image_side(const CamRec &cam, int nK, int nP, double u, double v, ImgSide &o) {
+    // scale2, aniscale2([1;-1]), (aniscale2b for model 5), xlat2(-u0)
+    const double s0 = cam.sz * u, s1 = -cam.sz * v;
+    double x0, x1;
+    if (MODEL == 5) { x0 = (1.0 + cam.b[0]) * s0 - cam.pp[0]; x1 = s1 - cam.pp[1]; }
+    else            { x0 = s0 - cam.pp[0];                    x1 = s1 - cam.pp[1]; }
+    // T_pre: affine2 before distortion (model 3)
+    double a0 = x0, a1 = x1;
+    if (MODEL == 3) { a0 = (1.0 + cam.b[0]) * x0 + cam.b[1] * x1; }
+    // brown_dist(a, -K, -P)
+    const double rho = a0 * a0 + a1 * a1;
+    double rs = 0, drs = 0, pw = 1.0;            // rs = sum Kn_j rho^j ; drs = sum j Kn_j rho^(j-1)
+    double rpow[MAXK + 1];
+    rpow[0] = 1.0;
+    for (int j = 0; j < MAXK; ++j) {
+        if (j < nK) {
+            const double kn = -cam.K[j];
+            drs += (j + 1) * kn * pw;
+            pw *= rho;
+            rs += kn * pw;
+        }
+        rpow[j + 1] = pw;
+    }
+    double t0 = 0, t1 = 0, ts0 = 0, ts1 = 0, rs2 = 0, drs2 = 0, pTu = 0, pn0 = 0, pn1 = 0;
+    if (nP >= 2) {
+        pn0 = -cam.P[0]; pn1 = -cam.P[1];
+        pTu = pn0 * a0 + pn1 * a1;
+        ts0 = pn0 * rho + 2 * pTu * a0;
+        ts1 = pn1 * rho + 2 * pTu * a1;
+        double q = 1.0;
+        for (int j = 2; j < MAXP; ++j)
+            if (j < nP) {
+                const double pn = -cam.P[j];
+                drs2 += (j - 1) * pn * q;
+                q *= rho;
+                rs2 += pn * q;
+            }
+        t0 = ts0 * (1 + rs2);
+        t1 = ts1 * (1 + rs2);
+    }
+    const double l0 = a0 + a0 * rs + t0;
+    const double l1 = a1 + a1 * rs + t1;
+    // T_post
+    if (MODEL == 4)      { o.rhs[0] = (1.0 + cam.b[0]) * l0 + cam.b[1] * l1; o.rhs[1] = l1; }
+    else if (MODEL == 5) { o.rhs[0] = l0 + cam.b[1] * l1;                    o.rhs[1] = l1; }
+    else                 { o.rhs[0] = l0;                                    o.rhs[1] = l1; }
+    if (!JAC) return;
+    // dL/dU = I + (a*(2 drs a') + rs I) + d tang / dU
+    double L00 = 1 + rs + 2 * drs * a0 * a0, L01 = 2 * drs * a0 * a1;
+    double L10 = 2 * drs * a1 * a0,          L11 = 1 + rs + 2 * drs * a1 * a1;
+    if (nP >= 2) {
+        const double m = 1 + rs2;
+        const double d00 = 2 * (2 * pn0 * a0 + pTu), d01 = 2 * (pn0 * a1 + pn1 * a0);
+        const double d11 = 2 * (2 * pn1 * a1 + pTu);
+        L00 += d00 * m + ts0 * drs2 * 2 * a0;  L01 += d01 * m + ts0 * drs2 * 2 * a1;
+        L10 += d01 * m + ts1 * drs2 * 2 * a0;  L11 += d11 * m + ts1 * drs2 * 2 * a1;
+    }
+    // post transform matrix T (2x2, second row = [0 1])
+    double T00 = 1, T01 = 0;
+    if (MODEL == 4) { T00 = 1.0 + cam.b[0]; T01 = cam.b[1]; }
+    if (MODEL == 5) { T01 = cam.b[1]; }
+    const double TL00 = T00 * L00 + T01 * L10, TL01 = T00 * L01 + T01 * L11;
+    const double TL10 = L10, TL11 = L11;
+    // dv/du0 = +T*dL*Apre   (res_euler_brown_1.m:167-169)
+    if (MODEL == 3) {
+        const double A00 = 1.0 + cam.b[0], A01 = cam.b[1];
+        o.dU0[0][0] = TL00 * A00; o.dU0[0][1] = TL00 * A01 + TL01;
+        o.dU0[1][0] = TL10 * A00; o.dU0[1][1] = TL10 * A01 + TL11;
+    } else {
+        o.dU0[0][0] = TL00; o.dU0[0][1] = TL01;
+        o.dU0[1][0] = TL10; o.dU0[1][1] = TL11;
+    }
+    // dv/dK = T * a * rho^j   (brown_rad.m:76-79 ; sign: -K passed, v = lhs - l)
+    for (int j = 0; j < MAXK; ++j) {
+        if (j < nK) {
+            const double k0 = a0 * rpow[j + 1], k1 = a1 * rpow[j + 1];
+            o.dK[0][j] = T00 * k0 + T01 * k1;
+            o.dK[1][j] = k1;
+        } else { o.dK[0][j] = 0; o.dK[1][j] = 0; }
+    }
+    // dv/dP  (tang_scale.m:66-72, brown_tang.m:95-104)
+    for (int j = 0; j < MAXP; ++j) { o.dP[0][j] = 0; o.dP[1][j] = 0; }
+    if (nP >= 2) {
+        const double m = 1 + rs2;
+        const double p00 = m * (rho + 2 * a0 * a0), p01 = m * 2 * a0 * a1;
+        const double p11 = m * (rho + 2 * a1 * a1);
+        o.dP[0][0] = T00 * p00 + T01 * p01; o.dP[0][1] = T00 * p01 + T01 * p11;
+        o.dP[1][0] = p01;                   o.dP[1][1] = p11;
+        double q = 1.0;
+        for (int j = 2; j < MAXP; ++j)
+            if (j < nP) {
+                q *= rho;
+                o.dP[0][j] = T00 * ts0 * q + T01 * ts1 * q;
+                o.dP[1][j] = ts1 * q;
+            }
+    }
+    // dv/db
+    if (MODEL == 2) {
+        o.dB[0][0] = o.dB[0][1] = o.dB[1][0] = o.dB[1][1] = 0;
+    } else if (MODEL == 3) {      // -dL.dU*dA.dB, dA.dB = [x0 x1; 0 0]  (res_euler_brown_1.m:176-178)
+        o.dB[0][0] = -L00 * x0; o.dB[0][1] = -L00 * x1;
+        o.dB[1][0] = -L10 * x0; o.dB[1][1] = -L10 * x1;
+    } else if (MODEL == 4) {      // -dA.dB, rows [l0 l1; 0 0]
+        o.dB[0][0] = -l0; o.dB[0][1] = -l1;
+        o.dB[1][0] = 0;   o.dB[1][1] = 0;
+    } else {                      // model 5: -[SK*dL*[s0;0], [l1;0]]  (res_euler_brown_3.m:180)
+        o.dB[0][0] = -TL00 * s0; o.dB[0][1] = -l1;
+        o.dB[1][0] = -TL10 * s0; o.dB[1][1] = 0;
+    }
+}
+
+// Full observation: residual r[2] (unweighted, mm) and Jacobian blocks
+//   A[2][6]  wrt EO = [centre(3) angles(3)]   (dQ0, dA)
+//   B[2][3]  wrt OP                           (dQ)
+//   C[2][nIOrows] wrt IO rows [cc px py as sk K.. P..] (only if WITH_IO)
+template <int MODEL, bool JAC, bool WITH_IO>
+DBAT_HD void obs_eval(const CamRec &cam, int nK, int nP, const double Q[3], double u, double v,
+                      double r[2], double A[2][6], double B[2][3], double C[2][MAXIO]) {
+    const double d0 = Q[0] - cam.c[0], d1 = Q[1] - cam.c[1], d2 = Q[2] - cam.c[2];
+    const double X0 = cam.Mt[0] * d0 + cam.Mt[1] * d1 + cam.Mt[2] * d2;
+    const double X1 = cam.Mt[3] * d0 + cam.Mt[4] * d1 + cam.Mt[5] * d2;
+    const double X2 = cam.Mt[6] * d0 + cam.Mt[7] * d1 + cam.Mt[8] * d2;
+    const double iz = 1.0 / X2;
+    const double ph0 = X0 * iz, ph1 = X1 * iz;
+    ImgSide im;
+    image_side<MODEL, JAC && WITH_IO>(cam, nK, nP, u, v, im);
+    const double nf = -cam.f;
+    r[0] = nf * ph0 - im.rhs[0];
+    r[1] = nf * ph1 - im.rhs[1];
+    if (!JAC) return;
+    // Pi = (1/X2)[1 0 -ph0; 0 1 -ph1]  (pinhole.m:54-66); dv/dQ = -f*Pi*M'
+    const double s = nf * iz;
+    for (int k = 0; k < 3; ++k) {
+        const double m0 = cam.Mt[k], m1 = cam.Mt[3 + k], m2 = cam.Mt[6 + k];
+        const double b0 = s * (m0 - ph0 * m2), b1 = s * (m1 - ph1 * m2);
+        B[0][k] = b0;  B[1][k] = b1;
+        A[0][k] = -b0; A[1][k] = -b1;              // world2cam.m:82  dP0 = -M
+    }
+    for (int k = 0; k < 3; ++k) {                  // eulerpinhole2.m:100
+        const double *D = cam.dMt[k];
+        const double y0 = D[0] * d0 + D[1] * d1 + D[2] * d2;
+        const double y1 = D[3] * d0 + D[4] * d1 + D[5] * d2;
+        const double y2 = D[6] * d0 + D[7] * d1 + D[8] * d2;
+        A[0][3 + k] = s * (y0 - ph0 * y2);
+        A[1][3 + k] = s * (y1 - ph1 * y2);
+    }
+    if (WITH_IO) {
+        C[0][0] = -ph0; C[1][0] = -ph1;            // dv/df = -vec(PH)
+        C[0][1] = im.dU0[0][0]; C[0][2] = im.dU0[0][1];
+        C[1][1] = im.dU0[1][0]; C[1][2] = im.dU0[1][1];
+        C[0][3] = im.dB[0][0];  C[0][4] = im.dB[0][1];
+        C[1][3] = im.dB[1][0];  C[1][4] = im.dB[1][1];
+        for (int j = 0; j < MAXK; ++j)
+            if (j < nK) { C[0][5 + j] = im.dK[0][j]; C[1][5 + j] = im.dK[1][j]; }
+        for (int j = 0; j < MAXP; ++j)
+            if (j < nP && 5 + nK + j < MAXIO) {
+                C[0][5 + nK + j] = im.dP[0][j]; C[1][5 + nK + j] = im.dP[1][j];
+            }
+    }
+}
+
+}  // namespace dbat

@@ -1,0 +1,336 @@
+// Host-side plan: index maps and the point-major batch layout.
+//
+// Restates (on the host, once per problem) the reference's
+//   misc/buildserialindices.m:69-159,162-221   x order [IO;EO;OP], leading
+//                                              elements of parameter blocks
+//   misc/buildweightmatrix.m:13-43             sigma_mm = IP.std * pxSize
+//   bundle.m:137-154                           prior.use &= est
+// and builds the internal layout the kernels use:
+//   z = [ EO (6*nc) | IOu (nIOu leading IO unknowns) | OP (3*np) ]
+// The first NS = 6*nc+nIOu entries of z are the columns of the reduced
+// (camera + IO) system; the OP part is eliminated by the Schur complement.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/dbat_hip.h"
+#include "model.hpp"
+
+namespace dbat {
+
+struct Plan {
+    int nc = 0, np = 0, nIOrows = 0, nK = 0, nP = 0, model = 0;
+    int64_t no = 0;
+    int rank = 0, nranks = 1;
+    // unknown vector
+    int64_t n = 0, nIO = 0, nEO = 0, nOP = 0;      // sizes of the x sections
+    int64_t NS = 0, NZ = 0;
+    int nIOu = 0;
+    std::vector<int64_t> x2z;                      // [n] z index of every x entry
+    std::vector<int32_t> io_src;                   // [nIOrows*nc] IOu index or -1 (fixed)
+    std::vector<double> io_fixed;                  // [nIOrows*nc] IO.val (used where io_src<0)
+    std::vector<uint8_t> z_est;                    // [NZ]
+    std::vector<double> z_prw, z_prv;              // [NZ] prior weight 1/sigma^2 (0 = none), prior value
+    std::vector<uint8_t> z_mine;                   // [NZ] scalar sums over z counted by this rank
+    std::vector<double> z0;                        // [NZ] initial values
+    // prior residual rows in reference order (IO, EO, OP), buildserialindices.m:151-159
+    std::vector<int64_t> prior_z;                  // z index of every prior row
+    int64_t n_prior[3] = {0, 0, 0};
+    int64_t m = 0;                                 // total residual rows
+    // observations of this shard in processing (point-major) order
+    int64_t pt_lo = 0, pt_hi = 0;                  // range in processing order
+    std::vector<int32_t> porder;                   // processing order -> point
+    std::vector<int32_t> o_cam, o_pt;
+    std::vector<double> o_uv;                      // 2 per obs
+    std::vector<double> o_w;                       // 2 per obs (1/sigma_mm) or empty if uniform
+    std::vector<uint32_t> o_seg;                   // (seg_start | seg_len<<16) within batch
+    std::vector<int64_t> o_row;                    // IP column (reference order)
+    std::vector<int64_t> batch_start;              // [nb+1]
+    int BT = 256;
+    int ncolmax = 6;
+    bool with_io = false;
+    bool uniform_w = true;
+    std::vector<double> cam_w;                     // [2*nc] per-camera 1/sigma_mm when uniform
+    std::vector<int32_t> cam_ncol, cam_col, cam_iorow;   // per camera column lists (MAXCOL / MAXIO strides)
+    std::vector<uint32_t> cam_eo_est;
+    std::vector<double> px;                        // [2*nc]
+    int max_k = 0;                                 // max observations of one point
+    bool rank_ok = true;                           // structural rank test
+    std::string err;
+};
+
+inline bool fail(Plan &P, const std::string &msg) { P.err = msg; return false; }
+
+// serializeblock (buildserialindices.m:162-221) for one parameter array.
+// Returns for every entry (column-major rows x cols) the index of its leading
+// unknown inside the section (or -1 if fixed), and the list of leading entries.
+inline void serialize_block(int rows, int cols, const int32_t *block, const uint8_t *est,
+                            std::vector<int32_t> &dist, std::vector<int64_t> &lead_entries,
+                            bool &simple) {
+    dist.assign((size_t)rows * cols, -1);
+    std::vector<uint8_t> leading((size_t)rows * cols, 0);
+    simple = true;
+    for (int i = 0; i < rows; ++i) {
+        // first estimated occurrence of every non-zero block id in this row
+        std::unordered_map<int32_t, int> seen;
+        for (int j = 0; j < cols; ++j) {
+            const size_t e = (size_t)j * rows + i;
+            if (!est[e] || block[e] == 0) continue;
+            if (seen.emplace(block[e], j).second) leading[e] = 1;
+            else simple = false;
+        }
+    }
+    // leading entries in column-major order define the x order (find(leading))
+    lead_entries.clear();
+    for (size_t e = 0; e < leading.size(); ++e)
+        if (leading[e]) { dist[e] = (int32_t)lead_entries.size(); lead_entries.push_back((int64_t)e); }
+    if (!simple) {
+        for (int i = 0; i < rows; ++i) {
+            std::unordered_map<int32_t, int32_t> lead_of;   // block id -> x index of its leading element
+            for (int j = 0; j < cols; ++j) {
+                const size_t e = (size_t)j * rows + i;
+                if (leading[e]) lead_of[block[e]] = dist[e];
+            }
+            for (int j = 0; j < cols; ++j) {
+                const size_t e = (size_t)j * rows + i;
+                if (!est[e] || block[e] == 0 || leading[e]) continue;
+                dist[e] = lead_of[block[e]];
+            }
+        }
+    }
+}
+
+inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
+    if (pb.abi_version != DBAT_HIP_ABI_VERSION) return fail(P, "ABI version mismatch");
+    if (pb.n_images <= 0 || pb.n_points <= 0 || pb.n_obs < 0) return fail(P, "empty problem");
+    if (pb.dist_model < 2 || pb.dist_model > 5)
+        return fail(P, "lens distortion model must be 2..5 (brown_euler_cam4.m:122-130)");
+    if (pb.nK < 0 || pb.nK > MAXK || pb.nP < 0 || pb.nP > MAXP || pb.nP == 1)
+        return fail(P, "nK/nP out of supported range");
+    P.nc = pb.n_images; P.np = pb.n_points; P.no = pb.n_obs;
+    P.nK = pb.nK; P.nP = pb.nP; P.model = pb.dist_model;
+    P.nIOrows = 5 + pb.nK + pb.nP;
+    P.rank = pb.shard_rank; P.nranks = std::max(1, pb.shard_count);
+    if (P.rank < 0 || P.rank >= P.nranks) return fail(P, "bad shard rank");
+    const int nc = P.nc, np = P.np, R = P.nIOrows;
+
+    // ---- est / prior masks; bundle.m:137-154
+    std::vector<uint8_t> estIO(pb.est_IO, pb.est_IO + (size_t)R * nc);
+    std::vector<uint8_t> estEO(pb.est_EO, pb.est_EO + (size_t)6 * nc);
+    std::vector<uint8_t> estOP(pb.est_OP, pb.est_OP + (size_t)3 * np);
+    // K estimation mask must be a leading run; P1,P2 together (multi_res.m:179-186,202-209)
+    for (int c = 0; c < nc; ++c) {
+        const uint8_t *e = &estIO[(size_t)c * R];
+        bool gap = false;
+        for (int j = 0; j < P.nK; ++j) { if (!e[5 + j]) gap = true; else if (gap) return fail(P, "Illegal cK vector"); }
+        gap = false;
+        for (int j = 0; j < P.nP; ++j) { if (!e[5 + P.nK + j]) gap = true; else if (gap) return fail(P, "Illegal cP vector"); }
+        if (P.nP >= 2 && (e[5 + P.nK] != e[5 + P.nK + 1])) return fail(P, "Illegal cP vector");
+    }
+    // ---- serial indices
+    std::vector<int32_t> distIO, distEO;
+    std::vector<int64_t> leadIO, leadEO;
+    bool simpleIO, simpleEO;
+    serialize_block(R, nc, pb.IO_block, estIO.data(), distIO, leadIO, simpleIO);
+    serialize_block(6, nc, pb.EO_block, estEO.data(), distEO, leadEO, simpleEO);
+    if (!simpleEO) return fail(P, "shared EO blocks (EO.struct.block) are not supported by the HIP path");
+    for (size_t e = 0; e < estEO.size(); ++e)
+        if (estEO[e] && pb.EO_block[e] == 0) return fail(P, "estimated EO element with block id 0");
+    for (size_t e = 0; e < estIO.size(); ++e)
+        if (estIO[e] && pb.IO_block[e] == 0) return fail(P, "estimated IO element with block id 0");
+    P.nIOu = (int)leadIO.size();
+    P.nIO = P.nIOu; P.nEO = (int64_t)leadEO.size();
+    P.NS = (int64_t)6 * nc + P.nIOu;
+    P.NZ = P.NS + (int64_t)3 * np;
+    P.io_src = distIO;
+    P.io_fixed.assign(pb.IO_val, pb.IO_val + (size_t)R * nc);
+    P.z_est.assign(P.NZ, 0); P.z_prw.assign(P.NZ, 0.0); P.z_prv.assign(P.NZ, 0.0);
+    P.z0.assign(P.NZ, 0.0);
+    for (size_t e = 0; e < (size_t)6 * nc; ++e) { P.z0[e] = pb.EO_val[e]; P.z_est[e] = estEO[e]; }
+    for (int k = 0; k < P.nIOu; ++k) { P.z0[6 * (int64_t)nc + k] = pb.IO_val[leadIO[k]]; P.z_est[6 * (int64_t)nc + k] = 1; }
+    for (size_t e = 0; e < (size_t)3 * np; ++e) { P.z0[P.NS + e] = pb.OP_val[e]; P.z_est[P.NS + e] = estOP[e]; }
+    // x order: IO leading (column-major), EO est (column-major), OP est (column-major)
+    P.x2z.clear();
+    for (int k = 0; k < P.nIOu; ++k) P.x2z.push_back(6 * (int64_t)nc + k);
+    for (size_t e = 0; e < (size_t)6 * nc; ++e) if (estEO[e]) P.x2z.push_back((int64_t)e);
+    for (size_t e = 0; e < (size_t)3 * np; ++e) if (estOP[e]) P.x2z.push_back(P.NS + (int64_t)e);
+    P.n = (int64_t)P.x2z.size();
+    P.nOP = P.n - P.nIO - P.nEO;
+    // priors: use & est & leading (bundle.m:137-154, buildserialindices.m:138-139)
+    P.prior_z.clear();
+    auto add_prior = [&](int64_t z, double val, double std_) {
+        P.z_prw[z] = 1.0 / (std_ * std_); P.z_prv[z] = val; P.prior_z.push_back(z);
+    };
+    for (int k = 0; k < P.nIOu; ++k) {
+        const int64_t e = leadIO[k];
+        if (pb.prior_IO_use && pb.prior_IO_use[e]) { add_prior(6 * (int64_t)nc + k, pb.prior_IO_val[e], pb.prior_IO_std[e]); P.n_prior[0]++; }
+    }
+    for (size_t e = 0; e < (size_t)6 * nc; ++e)
+        if (estEO[e] && pb.prior_EO_use && pb.prior_EO_use[e]) { add_prior((int64_t)e, pb.prior_EO_val[e], pb.prior_EO_std[e]); P.n_prior[1]++; }
+    for (size_t e = 0; e < (size_t)3 * np; ++e)
+        if (estOP[e] && pb.prior_OP_use && pb.prior_OP_use[e]) { add_prior(P.NS + (int64_t)e, pb.prior_OP_val[e], pb.prior_OP_std[e]); P.n_prior[2]++; }
+    for (int64_t z : P.prior_z)
+        if (!(P.z_prw[z] > 0) || !std::isfinite(P.z_prw[z])) return fail(P, "prior observation with zero/invalid std");
+    P.m = 2 * P.no + P.n_prior[0] + P.n_prior[1] + P.n_prior[2];
+
+    // ---- per-camera column lists
+    P.px.assign(pb.px_size, pb.px_size + (size_t)2 * nc);
+    P.cam_ncol.assign(nc, 6); P.cam_col.assign((size_t)nc * MAXCOL, -1);
+    P.cam_iorow.assign((size_t)nc * MAXIO, 0); P.cam_eo_est.assign(nc, 0);
+    P.ncolmax = 6; P.with_io = P.nIOu > 0;
+    for (int c = 0; c < nc; ++c) {
+        uint32_t m = 0;
+        for (int k = 0; k < 6; ++k) {
+            P.cam_col[(size_t)c * MAXCOL + k] = 6 * c + k;
+            if (estEO[(size_t)c * 6 + k]) m |= 1u << k;
+        }
+        P.cam_eo_est[c] = m;
+        int ncol = 6;
+        for (int r = 0; r < R; ++r) {
+            const int32_t src = distIO[(size_t)c * R + r];
+            if (src >= 0) {
+                P.cam_col[(size_t)c * MAXCOL + ncol] = 6 * nc + src;
+                P.cam_iorow[(size_t)c * MAXIO + (ncol - 6)] = r;
+                ++ncol;
+            }
+        }
+        P.cam_ncol[c] = ncol;
+        P.ncolmax = std::max(P.ncolmax, ncol);
+    }
+
+    // ---- observations: validate order, weights
+    std::vector<int32_t> k_pt(np, 0), n_cam(nc, 0);
+    for (int64_t o = 0; o < P.no; ++o) {
+        const int32_t c = pb.ip_cam[o], p = pb.ip_pt[o];
+        if (c < 0 || c >= nc || p < 0 || p >= np) return fail(P, "IP.cam / IP.pt out of range");
+        if (o > 0) {
+            const int32_t c0 = pb.ip_cam[o - 1], p0 = pb.ip_pt[o - 1];
+            if (c < c0 || (c == c0 && p <= p0))
+                return fail(P, "IP columns must be image-major with ascending OP index (prob2dbatstruct.m:349-365)");
+        }
+        k_pt[p]++; n_cam[c]++;
+    }
+    P.max_k = 0;
+    for (int p = 0; p < np; ++p) P.max_k = std::max(P.max_k, k_pt[p]);
+    // uniform sigma per camera?  sigma_mm = IP.std .* pxSize(:,cam)  (buildweightmatrix.m:20)
+    P.uniform_w = true;
+    P.cam_w.assign((size_t)2 * nc, 0.0);
+    {
+        std::vector<uint8_t> have(nc, 0);
+        for (int64_t o = 0; o < P.no && P.uniform_w; ++o) {
+            const int32_t c = pb.ip_cam[o];
+            const double wu = 1.0 / (pb.ip_std[2 * o] * P.px[2 * c]);
+            const double wv = 1.0 / (pb.ip_std[2 * o + 1] * P.px[2 * c + 1]);
+            if (!have[c]) { have[c] = 1; P.cam_w[2 * c] = wu; P.cam_w[2 * c + 1] = wv; }
+            else if (P.cam_w[2 * c] != wu || P.cam_w[2 * c + 1] != wv) P.uniform_w = false;
+        }
+    }
+    for (int64_t o = 0; o < P.no; ++o)
+        if (!(pb.ip_std[2 * o] > 0) || !(pb.ip_std[2 * o + 1] > 0)) return fail(P, "IP.std must be positive");
+
+    // ---- structural rank test (subset of sprank(J), gauss_newton_armijo.m:132-142):
+    // Hall-type counting conditions on the natural parameter groups.
+    P.rank_ok = P.m >= P.n;
+    for (int p = 0; p < np && P.rank_ok; ++p) {
+        int e = 0, pr = 0;
+        for (int d = 0; d < 3; ++d) { e += estOP[(size_t)3 * p + d]; pr += P.z_prw[P.NS + 3 * (int64_t)p + d] > 0; }
+        if (e > 2 * k_pt[p] + pr) P.rank_ok = false;
+        if (e > 0 && k_pt[p] == 0 && pr < e) P.rank_ok = false;
+    }
+    for (int c = 0; c < nc && P.rank_ok; ++c) {
+        int e = 0, pr = 0;
+        for (int d = 0; d < 6; ++d) { e += estEO[(size_t)6 * c + d]; pr += P.z_prw[6 * (int64_t)c + d] > 0; }
+        if (e > 2 * n_cam[c] + pr) P.rank_ok = false;
+    }
+    {
+        std::vector<int64_t> rows(P.nIOu, 0);
+        for (int c = 0; c < nc; ++c)
+            for (int r = 0; r < R; ++r) { const int32_t s = distIO[(size_t)c * R + r]; if (s >= 0) rows[s] += 2 * (int64_t)n_cam[c]; }
+        for (int k = 0; k < P.nIOu && P.rank_ok; ++k)
+            if (rows[k] == 0 && !(P.z_prw[6 * (int64_t)nc + k] > 0)) P.rank_ok = false;
+    }
+
+    // ---- processing order: points sorted by their (ascending) camera lists so
+    // that neighbouring points touch the same blocks of the reduced system.
+    std::vector<int64_t> pstart(np + 1, 0);
+    for (int p = 0; p < np; ++p) pstart[p + 1] = pstart[p] + k_pt[p];
+    std::vector<int64_t> fill(pstart.begin(), pstart.end() - 1);
+    std::vector<int64_t> by_pt(P.no);
+    for (int64_t o = 0; o < P.no; ++o) by_pt[fill[pb.ip_pt[o]]++] = o;   // image-major scan => cams ascending per point
+    std::vector<uint64_t> key(np);
+    for (int p = 0; p < np; ++p) {
+        uint64_t k = 0;
+        for (int j = 0; j < 4; ++j) {
+            uint64_t c = 0xFFFF;
+            if (j < k_pt[p]) c = std::min<uint64_t>(0xFFFE, (uint64_t)pb.ip_cam[by_pt[pstart[p] + j]]);
+            k = (k << 16) | c;
+        }
+        key[p] = k;
+    }
+    P.porder.resize(np);
+    std::iota(P.porder.begin(), P.porder.end(), 0);
+    std::stable_sort(P.porder.begin(), P.porder.end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });
+    // shard = contiguous range of the processing order balanced by observation count
+    {
+        std::vector<int64_t> cum(np + 1, 0);
+        for (int i = 0; i < np; ++i) cum[i + 1] = cum[i] + k_pt[P.porder[i]];
+        auto cut = [&](int r) -> int64_t {
+            if (r <= 0) return 0;
+            if (r >= P.nranks) return np;
+            const int64_t target = (cum[np] * r) / P.nranks;
+            return std::lower_bound(cum.begin(), cum.end(), target) - cum.begin();
+        };
+        P.pt_lo = cut(P.rank); P.pt_hi = cut(P.rank + 1);
+        if (P.pt_hi < P.pt_lo) P.pt_hi = P.pt_lo;
+    }
+    // z_mine: EO/IO counted by rank 0, OP by the owning shard
+    P.z_mine.assign(P.NZ, 0);
+    if (P.rank == 0) for (int64_t z = 0; z < P.NS; ++z) P.z_mine[z] = 1;
+    for (int64_t i = P.pt_lo; i < P.pt_hi; ++i)
+        for (int d = 0; d < 3; ++d) P.z_mine[P.NS + 3 * (int64_t)P.porder[i] + d] = 1;
+    if (!with_obs) return true;
+
+    // ---- batches of whole points, at most BT observations each
+    const int strideW = P.ncolmax * 3;
+    P.BT = 256;
+    if ((size_t)P.BT * strideW * 8 + (size_t)P.BT * 18 * 8 > 150 * 1024) P.BT = 128;
+    if (P.max_k > P.BT)
+        return fail(P, "an object point has more observations than one batch holds (" +
+                       std::to_string(P.max_k) + " > " + std::to_string(P.BT) + ")");
+    P.batch_start.clear(); P.batch_start.push_back(0);
+    int64_t nobs_shard = 0;
+    for (int64_t i = P.pt_lo; i < P.pt_hi; ++i) nobs_shard += k_pt[P.porder[i]];
+    P.o_cam.resize(nobs_shard); P.o_pt.resize(nobs_shard); P.o_uv.resize(2 * nobs_shard);
+    P.o_seg.resize(nobs_shard); P.o_row.resize(nobs_shard);
+    if (!P.uniform_w) P.o_w.resize(2 * nobs_shard);
+    int64_t pos = 0, bstart = 0;
+    for (int64_t i = P.pt_lo; i < P.pt_hi; ++i) {
+        const int32_t p = P.porder[i];
+        const int k = k_pt[p];
+        if (k == 0) continue;
+        if (pos - bstart + k > P.BT) { P.batch_start.push_back(pos); bstart = pos; }
+        const uint32_t seg = (uint32_t)(pos - bstart) | ((uint32_t)k << 16);
+        for (int j = 0; j < k; ++j, ++pos) {
+            const int64_t o = by_pt[pstart[p] + j];
+            P.o_cam[pos] = pb.ip_cam[o]; P.o_pt[pos] = p;
+            P.o_uv[2 * pos] = pb.ip_val[2 * o]; P.o_uv[2 * pos + 1] = pb.ip_val[2 * o + 1];
+            P.o_seg[pos] = seg; P.o_row[pos] = o;
+            if (!P.uniform_w) {
+                const int32_t c = pb.ip_cam[o];
+                P.o_w[2 * pos] = 1.0 / (pb.ip_std[2 * o] * P.px[2 * c]);
+                P.o_w[2 * pos + 1] = 1.0 / (pb.ip_std[2 * o + 1] * P.px[2 * c + 1]);
+            }
+        }
+    }
+    if (pos > bstart || P.batch_start.size() == 1) P.batch_start.push_back(pos);
+    if (P.batch_start.back() != pos) P.batch_start.push_back(pos);
+    return true;
+}
+
+}  // namespace dbat

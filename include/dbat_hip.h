@@ -1,0 +1,255 @@
+/*
+ * dbat_hip.h -- C ABI of the MI355X-native damped bundle-adjustment core.
+ *
+ * Drop-in boundary for the hot path of niclasborlin/dbat (MATLAB):
+ *   bundle()  ->  lsa/{gauss_markov,gauss_newton_armijo,levenberg_marquardt,
+ *                      levenberg_marquardt_powell}.m
+ *             ->  resFun = brown_euler_cam4(x,s)  (residual + sparse Jacobian)
+ *             ->  (J'*J [+lambda*I]) \ (-J'*r)
+ *
+ * The reference has no FFI for this path; the seam it replaces is the MATLAB
+ * function-handle contract between bundle.m and lsa/ *.m plus the DBAT struct
+ * (SURVEY.md section 8(b)).  Every entry point cites the reference interface
+ * it stands in for (paths relative to /root/reference/code/).
+ *
+ * Conventions
+ *   - plain C types only; all arrays are caller-owned HOST memory unless a
+ *     name ends in _dev; double arrays are column-major like MATLAB's;
+ *     indices are 0-based int32 (int64 where a count can exceed 2^31).
+ *   - every function returns 0 on success or a negative DBAT_HIP_E* code;
+ *     dbat_hip_last_error() gives the message.  Numerical failure of an
+ *     adjustment is NOT an error return: it is reported through
+ *     dbat_hip_result.code (0,-1,-2,-3,-4) exactly as the reference's
+ *     solvers do (gauss_newton_armijo.m:38-46).
+ *   - one handle per calling thread; a handle owns its device memory and its
+ *     HIP stream.  No call is re-entrant on the same handle.
+ *   - all device arithmetic is IEEE double.
+ */
+#ifndef DBAT_HIP_H
+#define DBAT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DBAT_HIP_ABI_VERSION 1
+
+/* error returns */
+#define DBAT_HIP_OK            0
+#define DBAT_HIP_EINVAL       -101  /* bad argument / inconsistent struct (DBAT:bundle:badInput) */
+#define DBAT_HIP_EUNSUPPORTED -102  /* struct uses a feature outside the hot path */
+#define DBAT_HIP_EDEVICE      -103  /* HIP / rocSOLVER failure */
+#define DBAT_HIP_ENOMEM       -104
+
+/* damping names of bundle.m:98-101 */
+#define DBAT_HIP_DAMP_GM   0   /* 'none' / 'gm'  -> lsa/gauss_markov.m */
+#define DBAT_HIP_DAMP_GNA  1   /* 'gna'           -> lsa/gauss_newton_armijo.m */
+#define DBAT_HIP_DAMP_LM   2   /* 'lm'            -> lsa/levenberg_marquardt.m */
+#define DBAT_HIP_DAMP_LMP  3   /* 'lmp'           -> lsa/levenberg_marquardt_powell.m */
+
+typedef struct dbat_hip_handle dbat_hip_handle;
+
+/*
+ * The DBAT struct fields read by the hot path (misc/prob2dbatstruct.m:12-186;
+ * list in SURVEY.md 8(b)).  nIOrows = 5+nK+nP.
+ */
+typedef struct dbat_hip_problem {
+    int32_t abi_version;        /* DBAT_HIP_ABI_VERSION */
+    int32_t n_images;           /* size(s.EO.val,2) */
+    int32_t n_points;           /* size(s.OP.val,2) */
+    int64_t n_obs;              /* size(s.IP.val,2) */
+    int32_t dist_model;         /* unique(s.IO.model.distModel): 2,3,4 or 5 (brown_euler_cam4.m:122-130) */
+    int32_t nK, nP;             /* s.IO.model.nK, .nP */
+
+    /* image observations, image-major, ascending OP inside an image
+     * (prob2dbatstruct.m:343-365; multi_res.m:126-135) */
+    const int32_t *ip_cam;      /* s.IP.cam - 1          [n_obs] */
+    const int32_t *ip_pt;       /* OP column of each IP column (find(s.IP.vis)) [n_obs] */
+    const double  *ip_val;      /* s.IP.val  2 x n_obs, pixels */
+    const double  *ip_std;      /* s.IP.std  2 x n_obs, pixels (buildweightmatrix.m:16-20) */
+
+    const double  *IO_val;      /* s.IO.val  nIOrows x n_images */
+    const double  *px_size;     /* s.IO.sensor.pxSize 2 x n_images */
+    const double  *EO_val;      /* s.EO.val(1:6,:) 6 x n_images */
+    const double  *OP_val;      /* s.OP.val  3 x n_points */
+
+    const uint8_t *est_IO;      /* s.bundle.est.IO nIOrows x n_images */
+    const uint8_t *est_EO;      /* s.bundle.est.EO 6 x n_images */
+    const uint8_t *est_OP;      /* s.bundle.est.OP 3 x n_points */
+    const int32_t *IO_block;    /* s.IO.struct.block nIOrows x n_images */
+    const int32_t *EO_block;    /* s.EO.struct.block 6 x n_images (must be simple: distinct per image) */
+
+    /* prior observations (lsa/prior_obs.m:26-72; buildweightmatrix.m:25-29) */
+    const uint8_t *prior_IO_use; const double *prior_IO_val; const double *prior_IO_std;
+    const uint8_t *prior_EO_use; const double *prior_EO_val; const double *prior_EO_std;
+    const uint8_t *prior_OP_use; const double *prior_OP_val; const double *prior_OP_std;
+
+    int32_t device;             /* HIP device ordinal this handle runs on */
+    int32_t shard_rank;         /* object-point shard owned by this handle ... */
+    int32_t shard_count;        /* ... of shard_count (1 = whole problem) */
+} dbat_hip_problem;
+
+/* options = the varargin of bundle() (bundle.m:78-132) plus the constants
+ * bundle.m hard-codes for each damping scheme (:281-283, :301-304, :321-325). */
+typedef struct dbat_hip_options {
+    int32_t damping;        /* DBAT_HIP_DAMP_* ; default GNA (bundle.m:79) */
+    int32_t max_iter;       /* 20   (bundle.m:78) */
+    double  conv_tol;       /* 1e-6 (bundle.m:86) */
+    int32_t abs_term;       /* 'absterm' (bundle.m:185-192) */
+    int32_t singular_test;  /* 'singulartest' (bundle.m:81) */
+    int32_t store_trace;    /* keep every iterate (E.trace); costs n*(iters+1) doubles of host memory */
+    double  mu;             /* GNA Armijo constant 0.1 (bundle.m:281) */
+    double  alpha_min;      /* GNA shortest step 1e-9 (bundle.m:283) */
+    double  lambda0;        /* LM: -1e-10 => 1e-10*trace(J'J)/n (bundle.m:301; levenberg_marquardt.m:88-95) */
+    double  lambda_min;     /* LM: = lambda0 (bundle.m:304) */
+    double  rho_bad;        /* LMP 0.25 (bundle.m:321) */
+    double  rho_good;       /* LMP 0.75 (bundle.m:322) */
+    double  delta0;         /* LMP: <=0 => norm(x0) (bundle.m:325) */
+} dbat_hip_options;
+
+/* what the lsa solvers return: [x,code,n,final,T,rr,extra...]
+ * (gauss_newton_armijo.m:1-2, levenberg_marquardt.m:1-2,
+ *  levenberg_marquardt_powell.m:1-2, gauss_markov.m:1) */
+typedef struct dbat_hip_result {
+    int32_t code;           /* 0 ok, -1 too many iterations, -2 singular normal matrix,
+                               -3 no alpha found, -4 structurally rank deficient */
+    int32_t iters;          /* n */
+    int32_t n_res;          /* #entries written to res[]  (rr) */
+    int32_t n_damp;         /* #entries written to damp[] (alphas / lambdas / deltas) */
+    int32_t n_trace;        /* #columns written to trace (T) */
+    double  sigma0;         /* sqrt(r'*r/(m-n)) at the last linearisation point (bundle.m:476-483) */
+    double  time_s;         /* wall seconds inside the damping loop (E.time, bundle.m:287-294) */
+    int32_t n_residual_evals;   /* residual-only evaluations (line search / trial points) */
+    int32_t n_linearizations;   /* residual+Jacobian+normal-equation builds */
+    int32_t n_solves;           /* reduced-system factorisations */
+} dbat_hip_result;
+
+const char *dbat_hip_last_error(void);
+int  dbat_hip_abi_version(void);
+
+/* default options for a damping scheme (bundle.m:78-86,281-283,301-304,321-325) */
+int  dbat_hip_default_options(int32_t damping, dbat_hip_options *opt);
+
+/* ---- set-up: replaces buildserialindices / serialize / buildweightmatrix --- */
+
+/* Host-only part of create(): index maps and sizes, no GPU needed.
+ * misc/buildserialindices.m:69-159 (x order [IO;EO;OP], leading elements of
+ * parameter blocks, residual row ranges). */
+int  dbat_hip_plan(const dbat_hip_problem *prob, int64_t *n_params, int64_t *n_residuals,
+                   int64_t *n_io, int64_t *n_eo, int64_t *n_op,
+                   int64_t *shard_pt_lo, int64_t *shard_pt_hi);
+
+/* Host-only x0 = serialize(s) straight from the problem description
+ * (misc/serialize.m:14-18 over the indices of buildserialindices.m); x0 has
+ * n_params entries (see dbat_hip_plan).  No GPU needed. */
+int  dbat_hip_plan_serialize(const dbat_hip_problem *prob, double *x0);
+
+/* Build the device problem: uploads observations, builds the point-major
+ * batches, weights (buildweightmatrix.m:13-43) and index maps.
+ * Replaces bundle.m:156-175. */
+int  dbat_hip_create(const dbat_hip_problem *prob, dbat_hip_handle **out);
+void dbat_hip_destroy(dbat_hip_handle *h);
+
+int64_t dbat_hip_num_params(const dbat_hip_handle *h);      /* s.bundle.serial.n */
+int64_t dbat_hip_num_residuals(const dbat_hip_handle *h);   /* s.post.res.ix.n */
+
+/* x0 = serialize(s)  (misc/serialize.m:14-18) */
+int  dbat_hip_serialize(const dbat_hip_handle *h, double *x /*[n]*/);
+/* s = deserialize(s,x)  (misc/deserialize.m:28-30): full IO/EO/OP arrays */
+int  dbat_hip_deserialize(const dbat_hip_handle *h, const double *x,
+                          double *IO /*nIOrows x nc*/, double *EO /*6 x nc*/, double *OP /*3 x np*/);
+/* structural rank test done by the solvers at n==0 (gauss_newton_armijo.m:132-142):
+ * 1 = full structural rank, 0 = deficient (code -4). Host only. */
+int  dbat_hip_structural_rank_ok(const dbat_hip_handle *h, int32_t *ok);
+
+/* ---- resFun: r = resFun(x) and [r,J] = resFun(x) ------------------------ */
+
+/* r = brown_euler_cam4(x,s) (brown_euler_cam4.m:122-148; multi_res.m:20-55;
+ * prior_obs.m:26-43).  r_unweighted [n_residuals] in the reference row order
+ * [image rows; IO priors; EO priors; OP priors] (may be NULL);
+ * f = 0.5*r'*W*r (gauss_newton_armijo.m:253).  With shard_count>1 the image
+ * rows of other shards are left untouched and *f is this shard's share. */
+int  dbat_hip_residual(dbat_hip_handle *h, const double *x, double *r_unweighted, double *f);
+
+/* [r,J] = resFun(x), J returned as the per-observation blocks the sparse J is
+ * made of (multi_res.m:138-294): for IP column k (reference order)
+ *   JEO[12k..] = d r_k / d EO(1:6,cam)   2x6 column-major
+ *   JOP[6k..]  = d r_k / d OP(:,pt)      2x3
+ *   JIO[2*nIOrows*k..] = d r_k / d IO(:,cam)  2 x nIOrows
+ * unweighted, fixed parameters included (the caller applies est masks and
+ * block sharing).  Any output may be NULL.  For bundle_cov / parity tests. */
+int  dbat_hip_jacobian_blocks(dbat_hip_handle *h, const double *x,
+                              double *JEO, double *JOP, double *JIO);
+
+/* ---- normal equations + solve: (J'*J [+lambda*I]) \ (-J'*r) ------------- */
+
+/* One linearisation at x and one solve:
+ *   scale_columns=1 : p = D*((D*J'*J*D) \ -(D*J'*r)), D = diag(1/||J(:,j)||)
+ *                     (gauss_newton_armijo.m:166-174; levenberg_marquardt_powell.m:267-279)
+ *   scale_columns=0 : p = (J'*J + lambda*I) \ (-J'*r)   (levenberg_marquardt.m:119; gauss_markov.m:79)
+ * computed by Schur-complement elimination of the object-point blocks.
+ * p [n] in x order.  stats[8] = { f=0.5 r'r, ||J p||^2, r'Jp, ||p||^2,
+ * trace(J'J), singular flag, 0, 0 }.  Jp/stats may be NULL. */
+int  dbat_hip_linearize_solve(dbat_hip_handle *h, const double *x, double lambda,
+                              int32_t scale_columns, double *p, double *stats);
+
+/* g = J'*r at the last linearisation point, x order (levenberg_marquardt.m:82) */
+int  dbat_hip_gradient(dbat_hip_handle *h, double *g);
+/* Jn = sqrt(sum(J.^2,1)) at the last linearisation point (gauss_newton_armijo.m:166) */
+int  dbat_hip_colnorms(dbat_hip_handle *h, double *Jn);
+/* ||J*v||^2 at the last linearisation point (Jp, dog-leg g'J'Jg: lmp.m:304-311) */
+int  dbat_hip_jtimes_sqnorm(dbat_hip_handle *h, const double *v, double *sqnorm);
+
+/* ---- the damping loops (host control flow, device arithmetic) ----------- */
+
+/* [x,code,n,final,T,rr,extra] = <solver>(resFun,vetoFun,x0,W,maxIter,termFun,...)
+ * dispatched on opt->damping as bundle.m:267-338 does.
+ *   x      [n]  in: x0, out: final estimate
+ *   res    [max_iter+3]   rr
+ *   damp   [2*max_iter+4] alphas (GNA) / lambdas (LM) / deltas (LMP)
+ *   aux    [2*max_iter+4] LMP: rhos then (offset max_iter+2) step types; may be NULL
+ *   trace  [n*(max_iter+2)] iterates as columns if opt->store_trace, else may be NULL
+ */
+int  dbat_hip_solve(dbat_hip_handle *h, const dbat_hip_options *opt, double *x,
+                    dbat_hip_result *result, double *res, double *damp, double *aux,
+                    double *trace);
+
+/* Post-processing of bundle.m:449-460: unweighted residuals at the last
+ * linearisation point of dbat_hip_solve, reference row order. */
+int  dbat_hip_final_residuals(dbat_hip_handle *h, double *r_unweighted, double *r_weighted);
+
+/* ---- multi-GPU: one handle per rank, object points sharded -------------- */
+
+/* Sum-all-reduce of `count` doubles at device address `buf_dev` over all
+ * ranks, enqueued on `stream` (a hipStream_t).  Installed by the host
+ * language binding (torch.distributed / RCCL in this repo); the core calls it
+ * once per linearisation for [S | g | diag] and for scalar packs. */
+typedef int (*dbat_hip_allreduce_fn)(void *user, void *buf_dev, int64_t count, void *stream);
+int  dbat_hip_set_allreduce(dbat_hip_handle *h, dbat_hip_allreduce_fn fn, void *user);
+
+/* mask[n_params]: 1 where this handle's shard owns the x entry (its object
+ * points; rank 0 also owns IO and EO).  The final x of a sharded solve is the
+ * sum over ranks of mask.*x.  Host only. */
+int  dbat_hip_owned_mask(const dbat_hip_handle *h, uint8_t *mask);
+
+/* ---- measurement hooks -------------------------------------------------- */
+
+/* One benchmark step = one Levenberg-Marquardt iteration's device work at
+ * the current point: J'J build + Schur solve (+ back-substitution) and one
+ * residual-only evaluation at the trial point.  x is not advanced, so every
+ * step does identical work.  ms[4] = { linearize+Schur build, factor+solve,
+ * back-substitution, trial residual } from HIP events on the handle's stream. */
+int  dbat_hip_bench_step(dbat_hip_handle *h, double lambda, int32_t scale_columns, double *ms);
+/* load x into the handle (device resident) before bench steps */
+int  dbat_hip_set_x(dbat_hip_handle *h, const double *x);
+/* sizes of the internal layout, for roofline accounting:
+ * info[0]=NS (reduced system order) info[1]=#batches info[2]=max obs per point
+ * info[3]=obs in this shard info[4]=points in this shard */
+int  dbat_hip_info(const dbat_hip_handle *h, int64_t *info /*[8]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DBAT_HIP_H */

@@ -57,3 +57,52 @@ def check_camcal_against_report(res, s0, E, exp, sig=6):
     dang = (ang - eo[:, :3] + 180.0) % 360.0 - 180.0     # x0-dependent 2*pi wraps
     assert np.abs(dang).max() < 1e-6
     assert np.abs(res.EO.val[:3].T - eo[:, 3:]).max() < 1e-6
+
+
+# ---------------------------------------------------------------------------
+# seeded synthetic variants used by the parity tests
+# ---------------------------------------------------------------------------
+
+def synth_struct(name='tiny', variant='plain', seed=None):
+    """Synthetic scene (dbat_amd.synth) with optional complications:
+       'plain'    fixed IO, datum by dependency
+       'selfcal'  one shared IO block, cc px py K1-3 P1-2 estimated
+       'imagevar' image-variant principal point (one px,py block per image),
+                  cc,K shared  (demo/romabundledemo_imagevariant.m:42-48)
+       'priors'   EO position priors on every 3rd camera, OP priors on control
+                  points, a few fixed control points, non-uniform IP.std
+    """
+    from dbat_amd import synth
+    s, truth = synth.make_scene(name, seed=seed)
+    nc, npnt = s.EO.val.shape[1], s.OP.val.shape[1]
+    rng = np.random.default_rng(12345)
+    if variant == 'selfcal':
+        s.bundle.est.IO[[0, 1, 2, 5, 6, 7, 8, 9]] = True
+    elif variant == 'imagevar':
+        s.bundle.est.IO[[0, 1, 2, 5, 6]] = True
+        s.IO.struct.block[1:3] = np.arange(1, nc + 1)[None, :]
+    elif variant == 'priors':
+        s.bundle.est.EO[:] = True                       # datum from priors instead
+        cams = np.arange(0, nc, 3)
+        s.prior.EO.use[0:3, cams] = True
+        s.prior.EO.val[0:3, cams] = truth['EO'][0:3, cams] + rng.normal(0, 0.02, (3, len(cams)))
+        s.prior.EO.std[0:3, cams] = 0.02
+        cps = np.arange(0, npnt, 37)
+        s.prior.OP.use[:, cps] = True
+        s.prior.OP.val[:, cps] = truth['OP'][:, cps] + rng.normal(0, 0.01, (3, len(cps)))
+        s.prior.OP.std[:, cps] = np.array([[0.01], [0.01], [0.02]])
+        fixed = np.arange(5, npnt, 53)
+        s.OP.val[:, fixed] = truth['OP'][:, fixed]
+        s.bundle.est.OP[:, fixed] = False
+        s.IP.std = s.IP.std * (1 + (np.arange(s.IP.std.shape[1]) % 3)[None, :] * 0.5)
+        s.IP.sigmas = np.unique(s.IP.std)
+    elif variant != 'plain':
+        raise ValueError(variant)
+    return s, truth
+
+
+def relerr(a, b):
+    """misc/relerr.m: Frobenius relative error."""
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    d = np.linalg.norm(b.ravel())
+    return np.linalg.norm((a - b).ravel()) / (d if d > 0 else 1.0)

@@ -1,0 +1,120 @@
+"""CPU tests of the boundary: the C-ABI library loads, exports every symbol
+include/dbat_hip.h declares, and its host-only logic (index plan, serialise,
+closed-form camera model) agrees with the oracle.  No GPU compute calls."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import dbat_oracle as o
+from dbat_amd import _hip
+from helpers import camcal_struct, synth_struct
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, 'include', 'dbat_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = set(re.findall(r'\b(dbat_hip_[a-z0-9_]+)\s*\(', hdr))
+    declared -= {'dbat_hip_allreduce_fn'}
+    assert declared, 'no declarations parsed'
+    lib = _hip.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    assert declared <= set(_hip.SYMBOLS), sorted(declared - set(_hip.SYMBOLS))
+    assert lib.dbat_hip_abi_version() == _hip.ABI_VERSION
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    s, _ = synth_struct('tiny')
+    with pytest.raises(_hip.DbatHipError) as e:
+        _hip.Handle(s)
+    assert e.value.code == _hip.EDEVICE
+
+
+def test_default_options_match_bundle_m():
+    # bundle.m:78-86, 281-283, 301-304, 321-322
+    for d in ('gm', 'gna', 'lm', 'lmp'):
+        opt = _hip.default_options(d)
+        assert opt.max_iter == 20 and opt.conv_tol == 1e-6 and opt.singular_test == 1
+        assert opt.mu == 0.1 and opt.alpha_min == 1e-9
+        assert opt.lambda0 == -1e-10 and opt.lambda_min == -1e-10
+        assert opt.rho_bad == 0.25 and opt.rho_good == 0.75
+
+
+@pytest.mark.parametrize('case', ['camcal', 'plain', 'selfcal', 'imagevar', 'priors'])
+def test_plan_and_serialize_match_oracle(case):
+    s = camcal_struct(3) if case == 'camcal' else synth_struct('tiny', case)[0]
+    so = o.buildserialindices(__import__('copy').deepcopy(s))
+    pl = _hip.plan(s)
+    assert pl['n'] == so.bundle.serial.n
+    assert pl['m'] == so.post.res.ix.n
+    assert pl['nIO'] == len(so.bundle.serial.IO.dest)
+    assert pl['nEO'] == len(so.bundle.serial.EO.dest)
+    assert pl['nOP'] == len(so.bundle.serial.OP.dest)
+    x0 = _hip.plan_serialize(s)
+    assert np.array_equal(x0, o.serialize(so))
+
+
+def test_plan_shards_cover_all_points():
+    from dbat_amd.parallel import shard_ranges
+    s, _ = synth_struct('small')
+    for w in (1, 2, 3, 8):
+        r = shard_ranges(s, w)
+        assert r[0][0] == 0 and r[-1][1] == s.OP.val.shape[1]
+        assert all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+        if w > 1:
+            sizes = [b - a for a, b in r]
+            assert max(sizes) - min(sizes) <= 0.05 * s.OP.val.shape[1] + 2
+
+
+def test_plan_rejects_bad_input():
+    s, _ = synth_struct('tiny')
+    s.IP.cam = s.IP.cam[::-1].copy()           # not image-major
+    with pytest.raises(_hip.DbatHipError):
+        _hip.plan(s)
+    s, _ = synth_struct('tiny')
+    s.IO.model.distModel[:] = 1                # legacy model: outside the hot path
+    with pytest.raises(_hip.DbatHipError):
+        _hip.plan(s)
+    s, _ = synth_struct('tiny')
+    s.bundle.est.IO[[5, 7]] = True             # K1,K3 without K2 (multi_res.m:182-186)
+    with pytest.raises(_hip.DbatHipError):
+        _hip.plan(s)
+
+
+@pytest.mark.parametrize('model', [2, 3, 4, 5])
+def test_device_model_closed_form_matches_oracle(model):
+    """csrc/model.hpp evaluated on the host vs the oracle's primitive chain."""
+    rng = np.random.default_rng(40 + model)
+    for nK, nP in ((3, 2), (4, 3), (0, 0), (2, 0), (5, 5), (1, 2)):
+        Q = 3 + rng.random(3); ang = rng.random(3) * np.pi / 3 - 0.3; q0 = rng.random(3)
+        f = 1 + rng.random(); u = rng.random(2) * 20
+        K = rng.random(nK) * 1e-2; P = rng.random(nP) * 1e-2
+        sz = rng.random() / 10; u0 = rng.random(2); b = rng.random(2) * 0.1
+        IO = np.concatenate([[f], u0, b, K, P]); EO = np.concatenate([q0, ang])
+        r, A, B, Cc = _hip.debug_model_eval_host(model, nK, nP, EO, IO, sz, Q, u)
+        v, d = o.res_euler_brown(model, Q[:, None], q0, ang, f, u[:, None], sz, u0, K, P, b, jac=True)
+        Ao = np.concatenate([d['dQ0'][0], d['dA'][0]], 1)
+        Co = np.concatenate([d['dF'][0], d['dU0'][0], d['dB'][0], d['dK'][0], d['dP'][0]], 1)
+        scale = max(1.0, np.abs(Co).max())
+        assert np.abs(r - v[:, 0]).max() < 1e-13
+        assert np.abs(A - Ao).max() < 1e-12 and np.abs(B - d['dQ'][0]).max() < 1e-12
+        assert np.abs(Cc - Co).max() / scale < 1e-12
+
+
+def test_bundle_argument_parsing():
+    from dbat_amd.bundle import _parse_args, BadInput
+    o_ = _parse_args((30, 'lm', 'trace', 1e-8, 'absterm', 'nosingulartest', 'pmdof'))
+    assert o_['maxIter'] == 30 and o_['damping'] == 'lm' and o_['doTrace']
+    assert o_['convTol'] == 1e-8 and o_['absTerm'] and not o_['singularTest'] and o_['pmDof']
+    assert _parse_args(())['damping'] == 'gna' and _parse_args(())['maxIter'] == 20
+    with pytest.raises(BadInput):
+        _parse_args(('newton',))
+    with pytest.raises(BadInput):
+        _parse_args(([1, 2],))

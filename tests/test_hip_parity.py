@@ -1,0 +1,251 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on
+the same inputs, against the reference's committed known answers, and through
+size-independent properties at the benchmark's sizes.
+
+Tolerances (north_star: parameter updates and converged parameters within
+1e-6 relative of the reference's full-matrix solve):
+  residuals, Jacobian blocks, gradient, column norms : 1e-11 relative
+  update p of one linearise+solve                    : 1e-8 relative (bar 1e-6)
+  converged x                                        : 1e-8 relative (bar 1e-6)
+"""
+import copy
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import dbat_oracle as o
+from helpers import (camcal_struct, camcal_expected, check_camcal_against_report, synth_struct,
+                     relerr)
+
+pytestmark = pytest.mark.gpu
+
+TOL_BLOCK = 1e-11
+TOL_STEP = 1e-8
+TOL_X = 1e-8
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from dbat_amd import _hip
+    import torch
+    assert torch.cuda.is_available(), 'gpu tests need a GPU'
+    _hip.load()
+    return _hip
+
+
+def cases():
+    out = [('camcal3', lambda: camcal_struct(3)), ('camcal2', lambda: camcal_struct(2)),
+           ('camcal4', lambda: camcal_struct(4)), ('camcal5', lambda: camcal_struct(5))]
+    for v in ('plain', 'selfcal', 'imagevar', 'priors'):
+        out.append(('tiny-' + v, (lambda v=v: synth_struct('tiny', v)[0])))
+    out.append(('small-plain', lambda: synth_struct('small', 'plain')[0]))
+    out.append(('small-priors', lambda: synth_struct('small', 'priors')[0]))
+    return out
+
+
+def oracle_setup(s):
+    s = copy.deepcopy(s)
+    for nm in ('IO', 'EO', 'OP'):
+        pr = getattr(s.prior, nm)
+        pr.use = np.asarray(pr.use, bool) & np.asarray(getattr(s.bundle.est, nm), bool)
+    s = o.buildserialindices(s)
+    return s, o.serialize(s), o.buildweightvector(s)
+
+
+def assemble_J(h, s, JEO, JOP, JIO):
+    """Sparse J from the per-observation blocks + index maps (multi_res.m:300-313)."""
+    IOix, EOix, OPix = h.index_maps()
+    no = s.IP.val.shape[1]
+    rows, cols, vals = [], [], []
+    r0 = 2 * np.arange(no)
+    for blk, ix in ((JEO, EOix[:, s.IP.cam]), (JOP, OPix[:, s.IP.pt]), (JIO, IOix[:, s.IP.cam])):
+        k = blk.shape[2]
+        for c in range(k):
+            m = ix[c] >= 0
+            for rr in range(2):
+                rows.append(r0[m] + rr); cols.append(ix[c][m]); vals.append(blk[m, rr, c])
+    J = sp.csc_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))),
+                      shape=(2 * no, h.n))
+    return J
+
+
+@pytest.mark.parametrize('name,make', cases(), ids=[c[0] for c in cases()])
+def test_residual_jacobian_parity(hip, name, make):
+    s = make()
+    so, x0, w = oracle_setup(s)
+    h = hip.Handle(s)
+    try:
+        assert h.n == len(x0) and h.m == so.post.res.ix.n
+        assert np.array_equal(h.serialize(), x0)
+        rng = np.random.default_rng(5)
+        x = x0 + 1e-3 * rng.standard_normal(len(x0)) * np.maximum(1e-3, np.abs(x0)) * 1e-2
+        r_o, J_o = o.brown_euler_cam4(x, so, jac=True)
+        r_h, f_h = h.residual(x)
+        assert relerr(r_h, r_o) < TOL_BLOCK
+        assert abs(f_h - 0.5 * np.sum(w * r_o ** 2)) <= 1e-11 * abs(f_h)
+        JEO, JOP, JIO = h.jacobian_blocks(x)
+        J_h = assemble_J(h, s, JEO, JOP, JIO)
+        no2 = 2 * s.IP.val.shape[1]
+        Jd = (J_h - J_o[:no2]).tocsc()
+        assert abs(Jd).max() <= TOL_BLOCK * abs(J_o).max()
+    finally:
+        h.close()
+
+
+@pytest.mark.parametrize('name,make', cases(), ids=[c[0] for c in cases()])
+def test_step_parity(hip, name, make):
+    """One linearisation + solve: Schur-complement solve on the GPU vs the
+    oracle's full sparse normal-equation solve (F11)."""
+    s = make()
+    so, x0, w = oracle_setup(s)
+    R = np.sqrt(w)
+    r_o, K = o.brown_euler_cam4(x0, so, jac=True)
+    r = R * r_o
+    J = (sp.diags(R) @ K).tocsc()
+    h = hip.Handle(s)
+    try:
+        # scaled Gauss-Newton step (gauss_newton_armijo.m:166-174)
+        p_o, sing, Jn, Jn2, Hs, gs, Js = o._scaled_gn(J, r)
+        p_h, st = h.linearize_solve(x0, 0.0, True)
+        assert not st['singular']
+        assert relerr(p_h, p_o) < TOL_STEP
+        assert abs(st['f'] - 0.5 * r @ r) <= 1e-11 * st['f']
+        Jp = J @ p_o
+        assert abs(st['JpJp'] - Jp @ Jp) <= 1e-7 * (Jp @ Jp)
+        assert abs(st['rJp'] - r @ Jp) <= 1e-7 * abs(r @ Jp)
+        assert abs(st['pp'] - p_o @ p_o) <= 1e-7 * (p_o @ p_o)
+        assert relerr(h.gradient(), J.T @ r) < 1e-10
+        assert relerr(h.colnorms(), Jn) < 1e-10
+        v = np.random.default_rng(2).standard_normal(len(x0))
+        Jv = J @ v
+        assert abs(h.jtimes_sqnorm(v) - Jv @ Jv) <= 1e-10 * (Jv @ Jv)
+        # damped, unscaled step (levenberg_marquardt.m:119)
+        JTJ = (J.T @ J).tocsc()
+        lam = 1e-4 * JTJ.diagonal().sum() / J.shape[1]
+        q_o, _ = o.normal_solve((JTJ + lam * sp.identity(J.shape[1])).tocsc(), -(J.T @ r))
+        q_h, st2 = h.linearize_solve(x0, lam, False)
+        assert relerr(q_h, q_o) < TOL_STEP
+        assert abs(st2['trace'] - JTJ.diagonal().sum()) <= 1e-10 * st2['trace']
+    finally:
+        h.close()
+
+
+@pytest.mark.parametrize('damping', ['gna', 'lm', 'lmp', 'gm'])
+@pytest.mark.parametrize('model', [2, 3, 4, 5])
+def test_camcal_known_answer_hip(hip, model, damping):
+    """Reference's committed camcal reports (data/dbat/dbatexports/
+    camcal-dbatreport{,-model*}.txt) reproduced through bundle() on the GPU."""
+    from dbat_amd import bundle
+    exp = camcal_expected()['model%d' % model]
+    res, ok, iters, s0, E = bundle(camcal_struct(model), damping)
+    assert ok and E.code == 0
+    check_camcal_against_report(res, s0, E, exp)
+    ro, oko, ito, s0o, Eo = o.bundle(camcal_struct(model), damping)
+    assert iters == ito and len(E.res) == len(Eo.res)
+    assert relerr(E.x, Eo.x) < TOL_X
+    assert abs(s0 - s0o) < 1e-9 * s0o
+    assert relerr(E.res, Eo.res) < 1e-8
+    assert relerr(E.trace, Eo.trace) < 1e-7
+    assert relerr(res.post.res.IP, ro.post.res.IP) < 1e-6
+
+
+@pytest.mark.parametrize('damping', ['gna', 'lm', 'lmp', 'gm'])
+@pytest.mark.parametrize('variant', ['plain', 'selfcal', 'imagevar', 'priors'])
+def test_synthetic_bundle_parity(hip, variant, damping):
+    from dbat_amd import bundle
+    s, truth = synth_struct('tiny', variant)
+    res, ok, iters, s0, E = bundle(s, damping)
+    ro, oko, ito, s0o, Eo = o.bundle(s, damping)
+    assert ok == oko and E.code == Eo.code and iters == ito
+    assert relerr(E.x, Eo.x) < TOL_X
+    assert abs(s0 - s0o) < 1e-9 * s0o
+    assert len(E.res) == len(Eo.res) and relerr(E.res, Eo.res) < 1e-8
+    if damping == 'gna':
+        assert np.array_equal(E.damping.alpha, Eo.damping.alpha)
+    if damping == 'lmp':
+        assert np.array_equal(E.damping.step, Eo.damping.step)
+        assert relerr(E.damping.delta, Eo.damping.delta) < 1e-9
+        assert relerr(E.damping.rho, Eo.damping.rho) < 1e-5
+    if damping == 'lm':
+        assert relerr(E.damping.__dict__['lambda'], Eo.damping.__dict__['lambda']) < 1e-8
+    for nm in ('IP', 'EO', 'OP'):
+        a, b = getattr(res.post.res, nm), getattr(ro.post.res, nm)
+        assert np.array_equal(np.isnan(a), np.isnan(b))
+        m = ~np.isnan(b)
+        if m.any():
+            assert relerr(a[m], b[m]) < 1e-6
+    assert E.numParams == Eo.numParams and E.numObs == Eo.numObs and E.redundancy == Eo.redundancy
+
+
+def test_small_scene_all_dampings(hip):
+    from dbat_amd import bundle
+    s, truth = synth_struct('small', 'plain')
+    for damping in ('gna', 'lm', 'lmp'):
+        res, ok, iters, s0, E = bundle(s, damping)
+        ro, oko, ito, s0o, Eo = o.bundle(s, damping)
+        assert ok and oko and iters == ito
+        assert relerr(E.x, Eo.x) < TOL_X
+        assert 0.4 < s0 < 0.6           # noise 0.5 px, IP.std 1 px
+
+
+def test_failure_codes(hip):
+    """Structural rank deficiency (code -4, camcaldemo_1ray) and a missing
+    datum (code -2, camcaldemo_no_datum): same codes as the oracle."""
+    from dbat_amd import bundle
+    s, _ = synth_struct('tiny', 'plain')
+    # a point measured in one image only: 2 rows, 3 unknowns
+    p = s.IP.pt[0]
+    keep = ~((s.IP.pt == p) & (np.arange(len(s.IP.pt)) != 0))
+    s.IP.val, s.IP.std = s.IP.val[:, keep], s.IP.std[:, keep]
+    s.IP.cam, s.IP.pt = s.IP.cam[keep], s.IP.pt[keep]
+    res, ok, iters, s0, E = bundle(s, 'gna')
+    ro, oko, ito, s0o, Eo = o.bundle(s, 'gna')
+    assert E.code == Eo.code == -4 and not ok
+    s, _ = synth_struct('tiny', 'plain')
+    s.bundle.est.EO[:] = True            # no datum: 7-dimensional null space
+    res, ok, iters, s0, E = bundle(s, 'gna')
+    ro, oko, ito, s0o, Eo = o.bundle(s, 'gna')
+    assert Eo.code == -2
+    assert E.code == -2 and not ok
+    # too few iterations: code -1, s not updated (bundle.m:356-358)
+    s, _ = synth_struct('tiny', 'plain')
+    res, ok, iters, s0, E = bundle(s, 'gna', 1)
+    ro, oko, ito, s0o, Eo = o.bundle(s, 'gna', 1)
+    assert E.code == Eo.code == -1 and iters == ito
+    assert np.array_equal(res.EO.val, s.EO.val)
+
+
+def test_unsupported_and_bad_input(hip):
+    s, _ = synth_struct('tiny', 'plain')
+    s.EO.struct.block[:, 1] = s.EO.struct.block[:, 0]      # shared camera station
+    with pytest.raises(hip.DbatHipError) as e:
+        hip.Handle(s)
+    assert e.value.code == hip.EUNSUPPORTED
+    from dbat_amd import bundle
+    from dbat_amd.bundle import BadInput
+    s, _ = synth_struct('tiny', 'plain')
+    with pytest.raises(BadInput):
+        bundle(s, 'newton')
+
+
+def test_C1_full_size_properties(hip):
+    """BASELINE config 2 (100 cams / 10k pts / 100k obs, LM-Powell): the HIP
+    path against the oracle at full size, plus size-independent properties."""
+    from dbat_amd import bundle
+    s, truth = synth_struct('C1', 'plain')
+    res, ok, iters, s0, E = bundle(s, 'lmp')
+    assert ok and 0.45 < s0 < 0.55
+    assert np.all(np.diff(E.res) <= 1e-9 * E.res[0])             # monotone residual norm
+    # converged point is stationary: ||J'r|| tiny relative to ||J|| ||r||
+    from dbat_amd import _hip
+    h = _hip.Handle(res)
+    try:
+        p, st = h.linearize_solve(h.serialize(), 0.0, True)
+        assert np.sqrt(st['JpJp']) <= 1e-5 * np.sqrt(2 * st['f'])
+    finally:
+        h.close()
+    # recovers the truth to the noise level
+    assert np.abs(res.OP.val - truth['OP']).std() < 0.05
+    ro, oko, ito, s0o, Eo = o.bundle(s, 'lmp')
+    assert iters == ito and relerr(E.x, Eo.x) < 1e-7
