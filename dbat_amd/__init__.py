@@ -2,14 +2,10 @@
 
 Host-side mirror of the reference's interface for the bundle hot path:
     dbatstruct   the DBAT struct (prob2dbatstruct.m field layout)
-    bundle       bundle(s, ...) -> (s, ok, iters, sigma0, E)
+    driver       bundle(s, ...) -> (s, ok, iters, sigma0, E)
     loadpm       PhotoModeler export loader (known-answer fixtures)
     parallel     torch.distributed / RCCL plumbing for sharded object points
     _hip         ctypes binding of include/dbat_hip.h (libdbat_hip.so)
 """
 from .dbatstruct import make_struct, seteoest_depend, validate  # noqa: F401
-
-
-def bundle(*args, **kwargs):
-    from .bundle import bundle as _bundle
-    return _bundle(*args, **kwargs)
+from .driver import bundle, BadInput  # noqa: F401

@@ -320,7 +320,7 @@ class Handle:
         check(self.lib.dbat_hip_set_x(self.h, dptr(x)))
 
     def bench_step(self, lam=0.0, scale=False):
-        ms = np.zeros(4)
+        ms = np.zeros(8)
         check(self.lib.dbat_hip_bench_step(self.h, float(lam), int(bool(scale)), dptr(ms)))
         return ms
 

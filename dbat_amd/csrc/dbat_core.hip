@@ -52,6 +52,8 @@ struct Core {
     hipStream_t stream = nullptr;
     rocblas_handle blas = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t kev[8] = {};      // per-kernel brackets, recorded only while timing is on
+    bool timing = false;
     // static problem data
     DevBuf<int32_t> cam_ncol, cam_col, cam_iorow, io_src, o_cam, o_pt;
     DevBuf<uint32_t> cam_eo_est, o_seg;
@@ -64,6 +66,8 @@ struct Core {
     DevBuf<double> red;      // [S | g_red | g_c | diagU | scal(8)]
     DevBuf<double> jn2c, dscale, rhs, Vinv, gp, jn2p, r_w, partial, scal;
     DevBuf<rocblas_int> info;
+    DevBuf<unsigned long long> pivmm;   // [0..1] point pivots min/max, [2..3] reduced-system pivots
+    DevBuf<double> mmx;                 // [2*nranks] min/max exchange through the sum-all-reduce
     double *S = nullptr, *g_red = nullptr, *g_c = nullptr, *diagU = nullptr, *red_scal = nullptr;
     int64_t red_count = 0;
     int64_t nb = 0, nobs = 0;
@@ -81,6 +85,7 @@ struct Core {
 
     ~Core() {
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+        for (auto &e : kev) if (e) (void)hipEventDestroy(e);
         if (blas) rocblas_destroy_handle(blas);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -91,6 +96,7 @@ struct Core {
         if (rocblas_create_handle(&blas) != rocblas_status_success) throw DeviceError{"rocblas_create_handle failed"};
         rocblas_set_stream(blas, stream);
         for (auto &e : ev) HIPCHK(hipEventCreate(&e));
+        for (auto &e : kev) HIPCHK(hipEventCreate(&e));
         nb = (int64_t)P.batch_start.size() - 1;
         nobs = (int64_t)P.o_cam.size();
         cam_ncol.upload(P.cam_ncol); cam_col.upload(P.cam_col); cam_iorow.upload(P.cam_iorow);
@@ -124,6 +130,8 @@ struct Core {
         partial.alloc((size_t)4 * std::max<int64_t>(std::max<int64_t>(nb, 2048), 1));
         scal.alloc(16);
         info.alloc(1);
+        pivmm.alloc(4);
+        mmx.alloc((size_t)2 * P.nranks);
         lds_build = ((size_t)P.BT * P.ncolmax * 3 + (size_t)P.BT * 18) * sizeof(double);
         lds_back = (size_t)P.BT * 6 * sizeof(double);
         HIPCHK(hipMemcpy(z.p, P.z0.data(), P.NZ * 8, hipMemcpyHostToDevice));
@@ -133,6 +141,7 @@ struct Core {
 
     // ---- helpers
     void sync() { HIPCHK(hipStreamSynchronize(stream)); }
+    void mark(int i) { if (timing) HIPCHK(hipEventRecord(kev[i], stream)); }
     void do_allreduce(double *buf, int64_t count) {
         if (allreduce && P.nranks > 1) {
             if (allreduce(allreduce_user, buf, count, (void *)stream) != 0) throw DeviceError{"all-reduce callback failed"};
@@ -171,9 +180,11 @@ struct Core {
     // ---- K2: f = 0.5 r'r at zz (all ranks' sum).  Optionally store r.
     double eval_f(const double *zz, double *r_w_out, double *r_unw_out) {
         prep_cams(zz);
+        mark(6);
 #define L_RES(M, dummy) hipLaunchKernelGGL((k_residual<M>), dim3(grid_obs), dim3(256), 0, stream, d, zz, cams.p, partial.p, r_w_out, r_unw_out)
         DISPATCH_MODEL(L_RES, 0)
 #undef L_RES
+        mark(7);
         hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(256), 0, stream, partial.p, (int64_t)grid_obs, scal.p, 0);
         hipLaunchKernelGGL(k_prior_sq, dim3(grid_z), dim3(256), 0, stream, d, zz, partial.p);
         hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(256), 0, stream, partial.p, (int64_t)grid_z, scal.p, 1);
@@ -185,14 +196,22 @@ struct Core {
     }
 
     // ---- K1: linearise at zz with damping lambda; builds the reduced system.
-    void build_enqueue(const double *zz, double lambda) {
+    void build_enqueue(const double *zz, double lambda, int scale) {
         prep_cams(zz);
         HIPCHK(hipMemsetAsync(red.p, 0, red_count * sizeof(double), stream));
+        {
+            const double big = 1e300;
+            unsigned long long init[4];
+            memcpy(&init[0], &big, 8); init[1] = 0; init[2] = init[0]; init[3] = 0;
+            HIPCHK(hipMemcpyAsync(pivmm.p, init, sizeof(init), hipMemcpyHostToDevice, stream));
+        }
+        mark(0);
         if (nb > 0) {
-#define L_BUILD(M, IO) hipLaunchKernelGGL((k_build<M, IO>), dim3((unsigned)nb), dim3(P.BT), lds_build, stream, d, zz, cams.p, lambda, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p)
+#define L_BUILD(M, IO) hipLaunchKernelGGL((k_build<M, IO>), dim3((unsigned)nb), dim3(P.BT), lds_build, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p, pivmm.p)
             if (P.with_io) { DISPATCH_MODEL(L_BUILD, true) } else { DISPATCH_MODEL(L_BUILD, false) }
 #undef L_BUILD
         }
+        mark(1);
         hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(256), 0, stream, partial.p, nb, red_scal, 0);
         hipLaunchKernelGGL(k_prior_sq, dim3(grid_z), dim3(256), 0, stream, d, zz, partial.p);
         hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(256), 0, stream, partial.p, (int64_t)grid_z, red_scal, 1);
@@ -201,7 +220,7 @@ struct Core {
         hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(256), 0, stream, partial.p, (int64_t)grid_z, red_scal + 1, 0);
     }
     void build(const double *zz, double lambda, int scale) {
-        build_enqueue(zz, lambda);
+        build_enqueue(zz, lambda, scale);
         do_allreduce(red.p, red_count);
         finish_enqueue(zz, lambda, scale);
         if (zz != zlin.p) HIPCHK(hipMemcpyAsync(zlin.p, zz, P.NZ * 8, hipMemcpyDeviceToDevice, stream));
@@ -228,24 +247,34 @@ struct Core {
     // ---- K6: Cholesky of the reduced system; returns 0 or the failing pivot
     int factor_solve_enqueue() {
         const rocblas_int n = (rocblas_int)P.NS;
+        mark(2);
         if (rocsolver_dpotrf(blas, rocblas_fill_lower, n, S, n, info.p) != rocblas_status_success) throw DeviceError{"rocsolver_dpotrf failed"};
         if (rocsolver_dpotrs(blas, rocblas_fill_lower, n, 1, S, n, rhs.p, n) != rocblas_status_success) throw DeviceError{"rocsolver_dpotrs failed"};
+        mark(3);
+        hipLaunchKernelGGL(k_diag_minmax, dim3(1), dim3(256), 0, stream, d, S, pivmm.p + 2);
         hipLaunchKernelGGL(k_unscale, dim3((unsigned)cdiv(P.NS, 256)), dim3(256), 0, stream, P.NS, rhs.p, dscale.p, dz.p);
         ++n_solves;
         return 0;
     }
     // ---- K7: back-substitution; sums {||Jp||^2, r'Jp, ||p||^2}
     void backsub_enqueue() {
+        mark(4);
         if (nb > 0) {
 #define L_BACK(M, IO) hipLaunchKernelGGL((k_backsub<M, IO>), dim3((unsigned)nb), dim3(P.BT), lds_back, stream, d, zlin.p, cams.p, Vinv.p, gp.p, r_w.p, dz.p, partial.p)
             if (P.with_io) { DISPATCH_MODEL(L_BACK, true) } else { DISPATCH_MODEL(L_BACK, false) }
 #undef L_BACK
         }
+        mark(5);
         hipLaunchKernelGGL((k_sum_partials<2>), dim3(1), dim3(256), 0, stream, partial.p, nb, scal.p, 0);
         hipLaunchKernelGGL(k_prior_jv, dim3(grid_z), dim3(256), 0, stream, d, zlin.p, dz.p, partial.p);
         hipLaunchKernelGGL((k_sum_partials<3>), dim3(1), dim3(256), 0, stream, partial.p, (int64_t)grid_z, scal.p + 4, 0);
     }
-    // solve at the current linearisation: p in dz, returns singular flag
+    // solve at the current linearisation: p in dz.  Returns true if the
+    // factorisation failed outright (non-positive pivot / non-finite step);
+    // near_singular mimics MATLAB's 'nearlySingularMatrix' warning through
+    // CHOLMOD's estimate rcond = (min diag(L) / max diag(L))^2 < eps over the
+    // pivots of the point blocks and of the reduced system.
+    bool near_singular = false;
     bool solve(double &JpJp, double &rJp, double &pp) {
         if (!s_valid) build(zlin.p, lambda_lin, scale_lin);   // the factorisation overwrote S
         s_valid = false;
@@ -253,13 +282,29 @@ struct Core {
         prep_cams(zlin.p);
         backsub_enqueue();
         rocblas_int hinfo = 0;
+        unsigned long long hmm[4];
         HIPCHK(hipMemcpyAsync(&hinfo, info.p, sizeof(hinfo), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(hmm, pivmm.p, sizeof(hmm), hipMemcpyDeviceToHost, stream));
         do_allreduce(scal.p, 8);
         double h[8];
         read_scal(h, 8);
         JpJp = h[0] + h[4]; rJp = h[1] + h[5]; pp = h[6];
-        bool singular = hinfo != 0 || !std::isfinite(pp) || !std::isfinite(JpJp);
-        return singular;
+        double mm[4];
+        memcpy(mm, hmm, sizeof(mm));
+        double pmin = std::min(mm[0], mm[2]), pmax = std::max(mm[1], mm[3]);
+        if (P.nranks > 1 && allreduce) {              // min/max over ranks through the sum-all-reduce
+            std::vector<double> slots((size_t)2 * P.nranks, 0.0);
+            slots[2 * P.rank] = pmin; slots[2 * P.rank + 1] = pmax;
+            HIPCHK(hipMemcpyAsync(mmx.p, slots.data(), slots.size() * 8, hipMemcpyHostToDevice, stream));
+            do_allreduce(mmx.p, (int64_t)slots.size());
+            HIPCHK(hipMemcpyAsync(slots.data(), mmx.p, slots.size() * 8, hipMemcpyDeviceToHost, stream));
+            sync();
+            for (int r = 0; r < P.nranks; ++r) { pmin = std::min(pmin, slots[2 * r]); pmax = std::max(pmax, slots[2 * r + 1]); }
+        }
+        const bool failed = hinfo != 0 || !std::isfinite(pp) || !std::isfinite(JpJp);
+        const double ratio = pmax > 0 ? pmin / pmax : 0.0;
+        near_singular = failed || !(ratio * ratio >= 2.220446049250313e-16);
+        return failed;
     }
     // ||J v||^2 and r'Jv at the linearisation point, ||v||^2 over owned entries
     void jtimes(const double *v, double &JvJv, double &rJv, double &vv) {
@@ -320,19 +365,24 @@ static void push_trace(Core &c, const dbat_hip_options &o, LoopOut &out) {
     out.trace.push_back(std::move(x));
 }
 
+// Objective values: every f = 0.5*r'r the loops compare comes from the same
+// kernel and reduction order (Core::eval_f), so the same point always gives
+// the same bits -- as it does in the reference, where one resFun computes all
+// of them.  (k_build also sums r'r, in a different order; that value is only
+// reported through dbat_hip_linearize_solve.)
+
 // lsa/gauss_newton_armijo.m:86-245, linesearch :249-290
 static void loop_gna(Core &c, const dbat_hip_options &o, LoopOut &out) {
     int n = 0;
     push_trace(c, o, out);
-    double f = 0;
+    double f = c.eval_f(c.z.p, nullptr, nullptr);
     while (true) {
         c.build(c.z.p, 0.0, 1);                                   // :112-116, :166-170
-        f = c.f_lin;
         out.res.push_back(std::sqrt(2 * f));
         if (n == 0 && !c.P.rank_ok) { out.code = -4; break; }     // :132-142
         double JpJp, rJp, pp;
-        const bool singular = c.solve(JpJp, rJp, pp);             // :172-174
-        if (o.singular_test && singular) { out.code = -2; break; }  // :176-184
+        const bool failed = c.solve(JpJp, rJp, pp);               // :172-174
+        if (failed || (o.singular_test && c.near_singular)) { out.code = -2; break; }  // :176-184
         if (term_fun(o, JpJp, f)) break;                          // :191
         ++n;
         // linesearch
@@ -362,12 +412,12 @@ static void loop_gm(Core &c, const dbat_hip_options &o, LoopOut &out) {
     push_trace(c, o, out);
     double f = 0;
     while (true) {
+        f = c.eval_f(c.z.p, nullptr, nullptr);
         c.build(c.z.p, 0.0, 0);
-        f = c.f_lin;
         out.res.push_back(std::sqrt(2 * f));
         double JpJp, rJp, pp;
-        const bool singular = c.solve(JpJp, rJp, pp);             // :79
-        if (o.singular_test && singular) { out.code = -2; break; }
+        const bool failed = c.solve(JpJp, rJp, pp);               // :79
+        if (failed || (o.singular_test && c.near_singular)) { out.code = -2; break; }
         if (term_fun(o, JpJp, f)) break;                          // :94
         ++n;
         c.axpby(1.0, c.z.p, 1.0, c.dz.p, c.z.p);
@@ -381,8 +431,8 @@ static void loop_gm(Core &c, const dbat_hip_options &o, LoopOut &out) {
 // lsa/levenberg_marquardt.m:52-250
 static void loop_lm(Core &c, const dbat_hip_options &o, LoopOut &out) {
     int n = 0;
+    double f = c.eval_f(c.z.p, nullptr, nullptr);
     c.build(c.z.p, 0.0, 0);                                       // :76-82
-    double f = c.f_lin;
     const double nx = (double)c.P.n;
     double lambda0 = o.lambda0, lambdaMin = o.lambda_min;
     if (lambda0 < 0) lambda0 = std::fabs(lambda0) * c.trace_jtj / nx;       // :88-90
@@ -396,10 +446,10 @@ static void loop_lm(Core &c, const dbat_hip_options &o, LoopOut &out) {
     while (true) {
         while (n <= o.max_iter) {
             if (c.lambda_lin != lambda) c.build(c.z.p, lambda, 0);            // (JTJ+lambda*I), :119
-            const bool singular = c.solve(JpJp, rJp, pp);
+            const bool failed = c.solve(JpJp, rJp, pp);
             out.res.push_back(std::sqrt(2 * f));
             if (n == 0 && !c.P.rank_ok) { out.code = -4; break; }             // :126-135
-            if (singular) { out.code = -2; break; }   // reference has no test here; MATLAB would return garbage
+            if (failed) { out.code = -2; break; }   // the reference has no test here; MATLAB would continue on Inf/NaN
             out.damp.push_back(lambda);
             if (o.store_trace) { std::vector<double> x(c.P.n); c.z_to_x(c.z.p, x.data()); if ((int)T.size() <= n) T.resize(n + 1); T[n] = std::move(x); }
             ++n;
@@ -410,7 +460,7 @@ static void loop_lm(Core &c, const dbat_hip_options &o, LoopOut &out) {
                 lambda = lambda / 10;
                 if (lambda < lambdaMin) lambda = 0;
                 c.build(c.z.p, lambda, 0);                                    // :189-194
-                f = c.f_lin;
+                f = fNew;
                 break;
             } else {
                 if (lambda == 0) lambda = lambdaMin; else lambda = lambda * 10;
@@ -439,8 +489,8 @@ static void loop_lmp(Core &c, const dbat_hip_options &o, double delta0, LoopOut 
     std::vector<double> rhos, steps;
     std::vector<std::vector<double>> T;
     if (o.store_trace) { std::vector<double> x(c.P.n); c.z_to_x(c.z.p, x.data()); T.push_back(std::move(x)); }
+    double f = c.eval_f(c.z.p, nullptr, nullptr);
     c.build(c.z.p, 0.0, 1);
-    double f = c.f_lin;
     bool have_gn = false;
     double gnJpJp = 0, gnrJp = 0, gnpp = 0;
     double *pGN = c.vtmp.p, *g = c.vtmp2.p;
@@ -449,8 +499,8 @@ static void loop_lmp(Core &c, const dbat_hip_options &o, double delta0, LoopOut 
         if (n == 0 && !c.P.rank_ok) { out.code = -4; break; }
         // ---- dogleg(r,J,delta)
         if (!have_gn) {
-            const bool singular = c.solve(gnJpJp, gnrJp, gnpp);   // :267-279 (scaled GN)
-            if (singular) { out.code = -2; break; }
+            const bool failed = c.solve(gnJpJp, gnrJp, gnpp);     // :267-279 (scaled GN)
+            if (failed) { out.code = -2; break; }   // no singular test in the reference's LMP
             c.copy(pGN, c.dz.p);
             have_gn = true;
         }
@@ -498,7 +548,7 @@ static void loop_lmp(Core &c, const dbat_hip_options &o, double delta0, LoopOut 
         } else {
             c.copy(c.z.p, c.zt.p);
             c.build(c.z.p, 0.0, 1);
-            f = c.f_lin;
+            f = ft;
             have_gn = false;
             if (rho >= o.rho_good) delta = delta * 2;
         }
@@ -712,7 +762,8 @@ int dbat_hip_linearize_solve(dbat_hip_handle *h, const double *x, double lambda,
     c.x_to_z(x, c.z.p);
     c.build(c.z.p, lambda, scale_columns);
     double JpJp, rJp, pp;
-    const bool singular = c.solve(JpJp, rJp, pp);
+    c.solve(JpJp, rJp, pp);
+    const bool singular = c.near_singular;
     if (p) c.z_to_x(c.dz.p, p);
     if (stats) {
         stats[0] = c.f_lin; stats[1] = JpJp; stats[2] = rJp; stats[3] = pp;
@@ -846,8 +897,9 @@ int dbat_hip_bench_step(dbat_hip_handle *h, double lambda, int32_t scale_columns
     API_TRY
     if (!h) { g_err = "null handle"; return DBAT_HIP_EINVAL; }
     Core &c = *h->core;
+    c.timing = true;
     HIPCHK(hipEventRecord(c.ev[0], c.stream));
-    c.build_enqueue(c.z.p, lambda);
+    c.build_enqueue(c.z.p, lambda, scale_columns);
     c.do_allreduce(c.red.p, c.red_count);
     c.finish_enqueue(c.z.p, lambda, scale_columns);
     HIPCHK(hipMemcpyAsync(c.zlin.p, c.z.p, c.P.NZ * 8, hipMemcpyDeviceToDevice, c.stream));
@@ -861,13 +913,20 @@ int dbat_hip_bench_step(dbat_hip_handle *h, double lambda, int32_t scale_columns
     (void)c.eval_f(c.zt.p, nullptr, nullptr);                     // trial-point residual, syncs
     HIPCHK(hipEventRecord(c.ev[4], c.stream));
     c.sync();
+    c.timing = false;
     c.have_lin = true; c.lambda_lin = lambda; c.scale_lin = scale_columns; c.s_valid = false;
-    if (ms)
+    if (ms) {
         for (int i = 0; i < 4; ++i) {
             float t = 0;
             HIPCHK(hipEventElapsedTime(&t, c.ev[i], c.ev[i + 1]));
             ms[i] = t;
         }
+        for (int i = 0; i < 4; ++i) {      // k_build, potrf+potrs, k_backsub, k_residual
+            float t = 0;
+            HIPCHK(hipEventElapsedTime(&t, c.kev[2 * i], c.kev[2 * i + 1]));
+            ms[4 + i] = t;
+        }
+    }
     return DBAT_HIP_OK;
     API_CATCH
 }

@@ -219,12 +219,13 @@ __device__ __forceinline__ void eval_obs_cols(const DevProblem &d, const CamRec 
 // r_w (weighted residuals), partial sums of r'r.
 template <int MODEL, bool WITH_IO>
 __global__ __launch_bounds__(256) void k_build(DevProblem d, const double *__restrict__ z,
-                                               const CamRec *__restrict__ cams, double lambda,
+                                               const CamRec *__restrict__ cams, double lambda, int scale,
                                                double *__restrict__ S, double *__restrict__ g_c,
                                                double *__restrict__ g_red, double *__restrict__ diagU,
                                                double *__restrict__ Vinv, double *__restrict__ gp,
                                                double *__restrict__ jn2p, double *__restrict__ r_w,
-                                               double *__restrict__ partial) {
+                                               double *__restrict__ partial,
+                                               unsigned long long *__restrict__ pivmm) {
     constexpr int NCX = WITH_IO ? MAXCOL : 6;
     extern __shared__ double smem[];
     const int BT = blockDim.x;
@@ -266,6 +267,7 @@ __global__ __launch_bounds__(256) void k_build(DevProblem d, const double *__res
     }
     __syncthreads();
     // ---- per point: V, g_p, damping, priors, V^-1 (K3,K4)
+    double pmin = 1e300, pmax = 0.0;       // Cholesky pivots of the estimated point coordinates
     if (active && t == seg_start) {
         double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
         for (int j = 0; j < seg_len; ++j) {
@@ -285,6 +287,20 @@ __global__ __launch_bounds__(256) void k_build(DevProblem d, const double *__res
         }
         double inv[6];
         inv3_sym(V, inv);
+        {   // diag of chol(V): the leading pivots of the full normal-matrix factor
+            const double d0 = sqrt(V[0]), l10 = V[1] / d0, l20 = V[2] / d0;
+            const double d1 = sqrt(V[3] - l10 * l10), l21 = (V[4] - l20 * l10) / d1;
+            const double d2 = sqrt(V[5] - l20 * l20 - l21 * l21);
+            const double dd[3] = {d0, d1, d2};
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (d.z_est[zp + k]) {
+                    // column scaling D multiplies the pivots by 1/||J(:,k)||
+                    double v = scale ? dd[k] / sqrt(jn2p[3 * (int64_t)pt + k]) : dd[k];
+                    v = v == v ? v : 0.0;                            // NaN pivot => 0
+                    pmin = fmin(pmin, v); pmax = fmax(pmax, v);
+                }
+        }
         double *pi = pinfo + (size_t)t * 9;
 #pragma unroll
         for (int k = 0; k < 6; ++k) { pi[k] = inv[k]; Vinv[6 * (int64_t)pt + k] = inv[k]; }
@@ -378,6 +394,34 @@ __global__ __launch_bounds__(256) void k_build(DevProblem d, const double *__res
     double acc[1] = {r[0] * r[0] + r[1] * r[1]};
     block_sum<1>(acc, sh);
     if (t == 0) partial[blockIdx.x] = acc[0];
+    for (int off = 32; off > 0; off >>= 1) {
+        pmin = fmin(pmin, __shfl_down(pmin, off, 64));
+        pmax = fmax(pmax, __shfl_down(pmax, off, 64));
+    }
+    if ((t & 63) == 0 && pmax > 0.0) {      // positive doubles order like their bit patterns
+        atomicMin(pivmm, (unsigned long long)__double_as_longlong(pmin));
+        atomicMax(pivmm + 1, (unsigned long long)__double_as_longlong(pmax));
+    }
+}
+
+// min/max of the Cholesky pivots of the reduced system (estimated entries only)
+__global__ __launch_bounds__(256) void k_diag_minmax(DevProblem d, const double *__restrict__ S,
+                                                     unsigned long long *__restrict__ pivmm) {
+    double pmin = 1e300, pmax = 0.0;
+    for (int64_t i = threadIdx.x; i < d.NS; i += blockDim.x)
+        if (d.z_est[i]) {
+            double v = S[i * d.NS + i];
+            v = v == v ? v : 0.0;
+            pmin = fmin(pmin, v); pmax = fmax(pmax, v);
+        }
+    for (int off = 32; off > 0; off >>= 1) {
+        pmin = fmin(pmin, __shfl_down(pmin, off, 64));
+        pmax = fmax(pmax, __shfl_down(pmax, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0 && pmax > 0.0) {
+        atomicMin(pivmm, (unsigned long long)__double_as_longlong(fmax(pmin, 0.0)));
+        atomicMax(pivmm + 1, (unsigned long long)__double_as_longlong(pmax));
+    }
 }
 
 // ---------------------------------------------------------------- F11 ---

@@ -239,8 +239,10 @@ int  dbat_hip_owned_mask(const dbat_hip_handle *h, uint8_t *mask);
 /* One benchmark step = one Levenberg-Marquardt iteration's device work at
  * the current point: J'J build + Schur solve (+ back-substitution) and one
  * residual-only evaluation at the trial point.  x is not advanced, so every
- * step does identical work.  ms[4] = { linearize+Schur build, factor+solve,
- * back-substitution, trial residual } from HIP events on the handle's stream. */
+ * step does identical work.  ms[8], from HIP events on the handle's stream:
+ * phases { linearize+Schur build, factor+solve, back-substitution, trial
+ * residual } then single kernels { k_build, potrf+potrs, k_backsub,
+ * k_residual }. */
 int  dbat_hip_bench_step(dbat_hip_handle *h, double lambda, int32_t scale_columns, double *ms);
 /* load x into the handle (device resident) before bench steps */
 int  dbat_hip_set_x(dbat_hip_handle *h, const double *x);

@@ -676,21 +676,27 @@ def normal_solve(H, g):
     """
     n = H.shape[0]
     eps = np.finfo(float).eps
+    Hc = sp.csc_matrix(H)
+    # Fill-reducing order: CHOLMOD (AMD) eliminates the low-degree object-point
+    # columns first; a minimum-degree sort by column count restates that.
+    perm = np.argsort(np.diff(Hc.indptr), kind='stable')
     if n <= 3000:
-        Hd = H.toarray() if sp.issparse(H) else np.asarray(H)
+        Hd = Hc.toarray()[np.ix_(perm, perm)]
         try:
             L = np.linalg.cholesky(Hd)
-            q = np.linalg.solve(L.T, np.linalg.solve(L, g))
+            q = np.empty(n)
+            q[perm] = np.linalg.solve(L.T, np.linalg.solve(L, g[perm]))
             d = np.diag(L)
+            # cholmod_rcond: (min diag(L) / max diag(L))^2
             sing = bool((d.min() / d.max()) ** 2 < eps)
             return q, sing
         except np.linalg.LinAlgError:
-            q, *_ = np.linalg.lstsq(Hd, g, rcond=None)
+            q, *_ = np.linalg.lstsq(Hc.toarray(), g, rcond=None)
             return q, True
-    lu = spla.splu(sp.csc_matrix(H), permc_spec='MMD_AT_PLUS_A',
-                   diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+    lu = spla.splu(Hc, permc_spec='MMD_AT_PLUS_A', diag_pivot_thresh=0.0,
+                   options=dict(SymmetricMode=True))
     q = lu.solve(g)
-    d = np.abs(lu.U.diagonal())
+    d = np.abs(lu.U.diagonal())          # = diag(L)^2 of the Cholesky factor
     sing = bool(d.min() / d.max() < eps) or not np.all(np.isfinite(q))
     return q, sing
 

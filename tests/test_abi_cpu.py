@@ -109,7 +109,7 @@ def test_device_model_closed_form_matches_oracle(model):
 
 
 def test_bundle_argument_parsing():
-    from dbat_amd.bundle import _parse_args, BadInput
+    from dbat_amd.driver import _parse_args, BadInput
     o_ = _parse_args((30, 'lm', 'trace', 1e-8, 'absterm', 'nosingulartest', 'pmdof'))
     assert o_['maxIter'] == 30 and o_['damping'] == 'lm' and o_['doTrace']
     assert o_['convTol'] == 1e-8 and o_['absTerm'] and not o_['singularTest'] and o_['pmDof']
