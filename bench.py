@@ -157,7 +157,8 @@ def main():
                                    'solve + back-substitution + trial residual)'
                                    % (args.config, nc, npnt, no,
                                       'self-calibrating' if info['ncolmax'] > 6 else 'fixed IO'),
-                       'reduced_system_order': NS, 'n_params': h.n, 'parallelism': 'points/%d' % world},
+                       'reduced_system_order': NS, 'n_params': h.n, 'parallelism': 'points/%d' % world,
+                       'n_tiles': info['n_tiles'], 'n_batches': info['n_batches'], 'batch': info['BT']},
             'ms_build_schur': ms[0], 'ms_factor_solve': ms[1], 'ms_backsub': ms[2],
             'ms_trial_residual': ms[3], 'kernel_ms': k_ms,
             'roofline': roof,

@@ -327,7 +327,7 @@ class Handle:
     def info(self):
         a = (C.c_int64 * 8)()
         check(self.lib.dbat_hip_info(self.h, a))
-        keys = ('NS', 'n_batches', 'max_k', 'n_obs_shard', 'n_pts_shard', 'BT', 'ncolmax', 'n')
+        keys = ('NS', 'n_batches', 'max_k', 'n_obs_shard', 'n_pts_shard', 'BT', 'ncolmax', 'n_tiles')
         return dict(zip(keys, [int(v) for v in a]))
 
 

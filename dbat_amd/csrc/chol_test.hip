@@ -1,0 +1,96 @@
+// Standalone check + timing of chol.hpp against rocsolver_dpotrf/dpotrs.
+// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 chol_test.hip -o chol_test -lrocsolver -lrocblas
+#include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "chol.hpp"
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+int main(int argc, char **argv) {
+    const int n = argc > 1 ? atoi(argv[1]) : 6000;
+    const int reps = argc > 2 ? atoi(argv[2]) : 5;
+    const int64_t lda = n + 8 - (n % 8 == 0 ? 0 : n % 8) + 8;   // >= n+1, multiple of 8
+    rocblas_handle h; rocblas_create_handle(&h);
+    hipStream_t st; CK(hipStreamCreate(&st)); rocblas_set_stream(h, st);
+    std::vector<double> M((size_t)n * n), b(n);
+    srand(1);
+    for (auto &v : M) v = (rand() / (double)RAND_MAX) - 0.5;
+    for (auto &v : b) v = (rand() / (double)RAND_MAX) - 0.5;
+    double *dM, *dA0, *dA, *dB, *dq, *dy, *dlinv; int *dinfo;
+    CK(hipMalloc(&dlinv, dbat::BlockChol::linv_doubles(n) * 8));
+    CK(hipMalloc(&dM, (size_t)n * n * 8)); CK(hipMalloc(&dA0, (size_t)lda * (n + 1) * 8));
+    CK(hipMalloc(&dA, (size_t)lda * (n + 1) * 8)); CK(hipMalloc(&dB, n * 8)); CK(hipMalloc(&dq, n * 8));
+    CK(hipMalloc(&dy, n * 8)); CK(hipMalloc(&dinfo, 4));
+    CK(hipMemcpy(dM, M.data(), (size_t)n * n * 8, hipMemcpyHostToDevice));
+    CK(hipMemset(dA0, 0, (size_t)lda * (n + 1) * 8));
+    const double one = 1.0, zero = 0.0;
+    rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_transpose, n, n, n, &one, dM, n, dM, n, &zero, dA0, (int)lda);
+    std::vector<double> A((size_t)lda * (n + 1));
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(A.data(), dA0, A.size() * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) A[(size_t)i * lda + i] += n;        // well conditioned SPD
+    for (int i = 0; i < n; ++i) A[(size_t)i * lda + n] = b[i];      // rhs row
+    CK(hipMemcpy(dA0, A.data(), A.size() * 8, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    // ---- own
+    float best = 1e9;
+    for (int r = 0; r < reps; ++r) {
+        CK(hipMemcpyAsync(dA, dA0, A.size() * 8, hipMemcpyDeviceToDevice, st));
+        CK(hipEventRecord(e0, st));
+        dbat::BlockChol::solve(h, st, dA, lda, n, dq, dy, dlinv, dinfo);
+        CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+    }
+    std::vector<double> q(n); int info;
+    CK(hipMemcpy(q.data(), dq, n * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(&info, dinfo, 4, hipMemcpyDeviceToHost));
+    printf("own   blocked chol+solve n=%d: %.3f ms  (%.2f TFLOP/s)  info=%d\n", n, best, (double)n * n * n / 3 / best / 1e9, info);
+    {   // phase timing: each kernel type alone, same launch counts as one factorisation
+        using namespace dbat;
+        const int NB = CHOL_NB, OB = CHOL_OB; const double one1 = 1.0, mone = -1.0; float ms;
+        CK(hipMemcpyAsync(dA, dA0, A.size() * 8, hipMemcpyDeviceToDevice, st));
+        CK(hipEventRecord(e0, st));
+        for (int j0 = 0; j0 + NB <= n; j0 += NB) hipLaunchKernelGGL(k_potf2, dim3(1), dim3(320), 0, st, dA, lda, n, j0, dlinv + (size_t)(j0 / NB) * NB * NB, dinfo);
+        CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st)); CK(hipEventElapsedTime(&ms, e0, e1)); printf("  potf2 x%d: %.3f ms\n", n / NB, ms);
+        CK(hipEventRecord(e0, st));
+        for (int j0 = 0; j0 + NB <= n; j0 += NB) { int below = n + 1 - j0 - NB; hipLaunchKernelGGL(k_trsm64, dim3((below + 63) / 64), dim3(256), 0, st, dA, lda, n + 1, j0, dlinv + (size_t)(j0 / NB) * NB * NB); }
+        CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st)); CK(hipEventElapsedTime(&ms, e0, e1)); printf("  trsm64 x%d: %.3f ms\n", n / NB, ms);
+        CK(hipEventRecord(e0, st));
+        for (int J = 0; J < n; J += OB) for (int j0 = J; j0 < J + OB && j0 + NB <= n; j0 += NB) { int below = n + 1 - j0 - NB; int ncb = (J + OB - (j0 + NB)) / NB; if (ncb > 0) hipLaunchKernelGGL(k_update64, dim3((below + 63) / 64, ncb), dim3(256), 0, st, dA, lda, n + 1, j0); }
+        CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st)); CK(hipEventElapsedTime(&ms, e0, e1)); printf("  update64: %.3f ms\n", ms);
+        CK(hipEventRecord(e0, st));
+        for (int J = OB; J < n; J += OB) { int ob = n - J < OB ? n - J : OB; rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_transpose, n + 1 - J, ob, J, &mone, dA + J, (int)lda, dA + J, (int)lda, &one1, dA + (int64_t)J * lda + J, (int)lda); }
+        CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st)); CK(hipEventElapsedTime(&ms, e0, e1)); printf("  dgemm x%d: %.3f ms\n", n / OB, ms);
+        CK(hipEventRecord(e0, st));
+        for (int j0 = ((n - 1) / NB) * NB; j0 >= 0; j0 -= NB) hipLaunchKernelGGL(k_backsolve, dim3(j0 > 0 ? (j0 + 255) / 256 : 1), dim3(256), 0, st, dA, lda, n, j0, dlinv + (size_t)(j0 / NB) * NB * NB, dy, dq);
+        CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st)); CK(hipEventElapsedTime(&ms, e0, e1)); printf("  backsolve x%d: %.3f ms\n", n / NB, ms);
+    }
+    // ---- rocsolver
+    float best2 = 1e9;
+    for (int r = 0; r < reps; ++r) {
+        CK(hipMemcpyAsync(dA, dA0, A.size() * 8, hipMemcpyDeviceToDevice, st));
+        CK(hipMemcpyAsync(dB, b.data(), n * 8, hipMemcpyHostToDevice, st));
+        CK(hipEventRecord(e0, st));
+        rocsolver_dpotrf(h, rocblas_fill_lower, n, dA, (int)lda, dinfo);
+        rocsolver_dpotrs(h, rocblas_fill_lower, n, 1, dA, (int)lda, dB, n);
+        CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best2) best2 = ms;
+    }
+    std::vector<double> q2(n);
+    CK(hipMemcpy(q2.data(), dB, n * 8, hipMemcpyDeviceToHost));
+    printf("rocsolver potrf+potrs n=%d: %.3f ms  (%.2f TFLOP/s)\n", n, best2, (double)n * n * n / 3 / best2 / 1e9);
+    double num = 0, den = 0;
+    for (int i = 0; i < n; ++i) { num += (q[i] - q2[i]) * (q[i] - q2[i]); den += q2[i] * q2[i]; }
+    printf("rel |q_own - q_rocsolver| = %.3e\n", std::sqrt(num / den));
+    // residual check of own solution: ||A q - b|| / ||b||
+    double rn = 0, bn = 0;
+    for (int i = 0; i < n; ++i) {
+        double s = 0;
+        for (int j = 0; j < n; ++j) { const double a = i >= j ? A[(size_t)j * lda + i] : A[(size_t)i * lda + j]; s += a * q[j]; }
+        rn += (s - b[i]) * (s - b[i]); bn += b[i] * b[i];
+    }
+    printf("own residual ||Aq-b||/||b|| = %.3e\n", std::sqrt(rn / bn));
+    return 0;
+}

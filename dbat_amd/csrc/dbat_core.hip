@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/dbat_hip.h"
+#include "chol.hpp"
 #include "kernels.hpp"
 #include "plan.hpp"
 
@@ -58,14 +59,19 @@ struct Core {
     DevBuf<int32_t> cam_ncol, cam_col, cam_iorow, io_src, o_cam, o_pt;
     DevBuf<uint32_t> cam_eo_est, o_seg;
     DevBuf<double> io_fixed, px, cam_w, z_prw, z_prv, o_uv, o_w;
-    DevBuf<uint8_t> z_est, z_mine;
+    DevBuf<uint8_t> z_est, z_mine, o_lc;
+    DevBuf<int32_t> tile_batch, tile_cam_start, tile_cams;
+    int64_t ntiles = 0;
+    size_t lds_tile = 0;
     DevBuf<int64_t> o_row, batch_start, x2z;
     // state
     DevBuf<CamRec> cams;
     DevBuf<double> z, zt, dz, zlin, vtmp, vtmp2, xbuf;  // NZ each (xbuf: n)
     DevBuf<double> red;      // [S | g_red | g_c | diagU | scal(8)]
     DevBuf<double> jn2c, dscale, rhs, Vinv, gp, jn2p, r_w, partial, scal;
-    DevBuf<rocblas_int> info;
+    DevBuf<int> info;
+    DevBuf<double> ywork, linv;
+    int64_t ldS = 0;
     DevBuf<unsigned long long> pivmm;   // [0..1] point pivots min/max, [2..3] reduced-system pivots
     DevBuf<double> mmx;                 // [2*nranks] min/max exchange through the sum-all-reduce
     double *S = nullptr, *g_red = nullptr, *g_c = nullptr, *diagU = nullptr, *red_scal = nullptr;
@@ -106,6 +112,8 @@ struct Core {
         o_cam.upload(P.o_cam); o_pt.upload(P.o_pt); o_uv.upload(P.o_uv); o_w.upload(P.o_w);
         o_seg.upload(P.o_seg); o_row.upload(P.o_row); batch_start.upload(P.batch_start);
         x2z.upload(P.x2z);
+        o_lc.upload(P.o_lc); tile_batch.upload(P.tile_batch); tile_cam_start.upload(P.tile_cam_start); tile_cams.upload(P.tile_cams);
+        ntiles = P.CMAX ? (int64_t)P.tile_batch.size() - 1 : 0;
         d.nc = P.nc; d.np = P.np; d.nIOrows = P.nIOrows; d.nK = P.nK; d.nP = P.nP; d.nIOu = P.nIOu;
         d.ncolmax = P.ncolmax; d.BT = P.BT; d.NS = P.NS; d.NZ = P.NZ; d.nobs = nobs; d.nb = nb;
         d.cam_ncol = cam_ncol.p; d.cam_col = cam_col.p; d.cam_iorow = cam_iorow.p; d.cam_eo_est = cam_eo_est.p;
@@ -113,12 +121,18 @@ struct Core {
         d.z_est = z_est.p; d.z_mine = z_mine.p; d.z_prw = z_prw.p; d.z_prv = z_prv.p;
         d.o_cam = o_cam.p; d.o_pt = o_pt.p; d.o_uv = o_uv.p; d.o_w = P.uniform_w ? nullptr : o_w.p;
         d.o_seg = o_seg.p; d.o_row = o_row.p; d.batch_start = batch_start.p;
+        d.CMAX = P.CMAX; d.ntiles = (int)ntiles; d.o_lc = o_lc.p;
+        d.tile_batch = tile_batch.p; d.tile_cam_start = tile_cam_start.p; d.tile_cams = tile_cams.p;
         cams.alloc(P.nc);
         z.alloc(P.NZ); zt.alloc(P.NZ); dz.alloc(P.NZ); zlin.alloc(P.NZ); vtmp.alloc(P.NZ); vtmp2.alloc(P.NZ);
         xbuf.alloc(std::max<int64_t>(P.n, 1));
-        red_count = P.NS * P.NS + 3 * P.NS + 8;
+        ldS = ((P.NS + 1 + 7) / 8) * 8;
+        d.ldS = ldS;
+        const int64_t s_count = ldS * (P.NS + 1);
+        red_count = s_count + 3 * P.NS + 8;
         red.alloc(red_count);
-        S = red.p; g_red = S + P.NS * P.NS; g_c = g_red + P.NS; diagU = g_c + P.NS; red_scal = diagU + P.NS;
+        S = red.p; g_red = S + s_count; g_c = g_red + P.NS; diagU = g_c + P.NS; red_scal = diagU + P.NS;
+        ywork.alloc(P.NS); linv.alloc(BlockChol::linv_doubles((int)P.NS));
         jn2c.alloc(P.NS); dscale.alloc(P.NS); rhs.alloc(P.NS);
         Vinv.alloc((size_t)6 * P.np); gp.alloc((size_t)3 * P.np); jn2p.alloc((size_t)3 * P.np);
         HIPCHK(hipMemset(Vinv.p, 0, (size_t)6 * P.np * 8));
@@ -127,16 +141,30 @@ struct Core {
         r_w.alloc(std::max<int64_t>(2 * nobs, 2));
         grid_obs = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(nobs, 256), 2048));
         grid_z = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(P.NZ, 256), 2048));
-        partial.alloc((size_t)4 * std::max<int64_t>(std::max<int64_t>(nb, 2048), 1));
         scal.alloc(16);
         info.alloc(1);
         pivmm.alloc(4);
         mmx.alloc((size_t)2 * P.nranks);
         lds_build = ((size_t)P.BT * P.ncolmax * 3 + (size_t)P.BT * 18) * sizeof(double);
         lds_back = (size_t)P.BT * 6 * sizeof(double);
+        lds_tile = ((size_t)P.BT * 27 + (size_t)(P.CMAX * (P.CMAX + 1) / 2) * 36 + (size_t)18 * P.CMAX) * sizeof(double);
+        partial.alloc((size_t)4 * std::max<int64_t>(std::max<int64_t>(std::max<int64_t>(nb, ntiles), 2048), 1));
+        set_lds_limits();
         HIPCHK(hipMemcpy(z.p, P.z0.data(), P.NZ * 8, hipMemcpyHostToDevice));
         HIPCHK(hipMemset(dz.p, 0, P.NZ * 8));
         HIPCHK(hipDeviceSynchronize());
+    }
+
+    // kernels that use more than 64 KB of dynamic LDS must opt in
+    void set_lds_limits() {
+#define SET_LDS(K, BYTES) HIPCHK(hipFuncSetAttribute((const void *)(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)))
+        SET_LDS((k_build_tile<2>), lds_tile); SET_LDS((k_build_tile<3>), lds_tile);
+        SET_LDS((k_build_tile<4>), lds_tile); SET_LDS((k_build_tile<5>), lds_tile);
+        SET_LDS((k_build<2, false>), lds_build); SET_LDS((k_build<3, false>), lds_build);
+        SET_LDS((k_build<4, false>), lds_build); SET_LDS((k_build<5, false>), lds_build);
+        SET_LDS((k_build<2, true>), lds_build); SET_LDS((k_build<3, true>), lds_build);
+        SET_LDS((k_build<4, true>), lds_build); SET_LDS((k_build<5, true>), lds_build);
+#undef SET_LDS
     }
 
     // ---- helpers
@@ -206,13 +234,19 @@ struct Core {
             HIPCHK(hipMemcpyAsync(pivmm.p, init, sizeof(init), hipMemcpyHostToDevice, stream));
         }
         mark(0);
-        if (nb > 0) {
+        int64_t npart = nb;
+        if (ntiles > 0) {
+            npart = ntiles;
+#define L_TILE(M, dummy) hipLaunchKernelGGL((k_build_tile<M>), dim3((unsigned)ntiles), dim3(P.BT), lds_tile, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p, pivmm.p)
+            DISPATCH_MODEL(L_TILE, 0)
+#undef L_TILE
+        } else if (nb > 0) {
 #define L_BUILD(M, IO) hipLaunchKernelGGL((k_build<M, IO>), dim3((unsigned)nb), dim3(P.BT), lds_build, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p, pivmm.p)
             if (P.with_io) { DISPATCH_MODEL(L_BUILD, true) } else { DISPATCH_MODEL(L_BUILD, false) }
 #undef L_BUILD
         }
         mark(1);
-        hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(256), 0, stream, partial.p, nb, red_scal, 0);
+        hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(256), 0, stream, partial.p, npart, red_scal, 0);
         hipLaunchKernelGGL(k_prior_sq, dim3(grid_z), dim3(256), 0, stream, d, zz, partial.p);
         hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(256), 0, stream, partial.p, (int64_t)grid_z, red_scal, 1);
         // owned squared column norms of the point columns -> red_scal[1]
@@ -239,17 +273,16 @@ struct Core {
         ++n_lin;
     }
     void finish_enqueue(const double *zz, double lambda, int scale) {
-        hipLaunchKernelGGL(k_finish, dim3((unsigned)cdiv(P.NS, 256)), dim3(256), 0, stream, d, zz, lambda, scale, S, g_c, g_red, diagU, jn2c.p, dscale.p, rhs.p);
+        hipLaunchKernelGGL(k_finish, dim3((unsigned)cdiv(P.NS, 256)), dim3(256), 0, stream, d, zz, lambda, scale, S, g_c, g_red, diagU, jn2c.p, dscale.p);
         if (scale)
-            hipLaunchKernelGGL(k_scale_S, dim3((unsigned)cdiv(P.NS, 256), (unsigned)P.NS), dim3(256), 0, stream, P.NS, S, dscale.p);
+            hipLaunchKernelGGL(k_scale_S, dim3((unsigned)cdiv(P.NS, 256), (unsigned)P.NS), dim3(256), 0, stream, P.NS, ldS, S, dscale.p);
     }
 
     // ---- K6: Cholesky of the reduced system; returns 0 or the failing pivot
     int factor_solve_enqueue() {
-        const rocblas_int n = (rocblas_int)P.NS;
         mark(2);
-        if (rocsolver_dpotrf(blas, rocblas_fill_lower, n, S, n, info.p) != rocblas_status_success) throw DeviceError{"rocsolver_dpotrf failed"};
-        if (rocsolver_dpotrs(blas, rocblas_fill_lower, n, 1, S, n, rhs.p, n) != rocblas_status_success) throw DeviceError{"rocsolver_dpotrs failed"};
+        // blocked Cholesky + both substitutions (chol.hpp); q -> rhs
+        BlockChol::solve(blas, stream, S, ldS, (int)P.NS, rhs.p, ywork.p, linv.p, info.p);
         mark(3);
         hipLaunchKernelGGL(k_diag_minmax, dim3(1), dim3(256), 0, stream, d, S, pivmm.p + 2);
         hipLaunchKernelGGL(k_unscale, dim3((unsigned)cdiv(P.NS, 256)), dim3(256), 0, stream, P.NS, rhs.p, dscale.p, dz.p);
@@ -281,7 +314,7 @@ struct Core {
         factor_solve_enqueue();
         prep_cams(zlin.p);
         backsub_enqueue();
-        rocblas_int hinfo = 0;
+        int hinfo = 0;
         unsigned long long hmm[4];
         HIPCHK(hipMemcpyAsync(&hinfo, info.p, sizeof(hinfo), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipMemcpyAsync(hmm, pivmm.p, sizeof(hmm), hipMemcpyDeviceToHost, stream));
@@ -935,7 +968,7 @@ int dbat_hip_info(const dbat_hip_handle *h, int64_t *info) {
     if (!h || !info) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
     const Core &c = *h->core;
     info[0] = c.P.NS; info[1] = c.nb; info[2] = c.P.max_k; info[3] = c.nobs;
-    info[4] = c.P.pt_hi - c.P.pt_lo; info[5] = c.P.BT; info[6] = c.P.ncolmax; info[7] = c.P.n;
+    info[4] = c.P.pt_hi - c.P.pt_lo; info[5] = c.P.BT; info[6] = c.P.ncolmax; info[7] = c.ntiles;
     return DBAT_HIP_OK;
 }
 

@@ -25,6 +25,7 @@ struct DevProblem {
     // sizes
     int nc, np, nIOrows, nK, nP, nIOu, ncolmax, BT;
     int64_t NS, NZ, nobs, nb;
+    int64_t ldS;                    // leading dimension of S (>= NS+1: row NS holds the right-hand side)
     // camera static data
     const int32_t *cam_ncol, *cam_col, *cam_iorow;
     const uint32_t *cam_eo_est;
@@ -42,6 +43,10 @@ struct DevProblem {
     const uint32_t *o_seg;
     const int64_t *o_row;
     const int64_t *batch_start;
+    // tiles (fixed-IO path): runs of batches touching at most CMAX cameras
+    int CMAX, ntiles;
+    const uint8_t *o_lc;
+    const int32_t *tile_batch, *tile_cam_start, *tile_cams;
 };
 
 __device__ __forceinline__ void atomic_add_f64(double *p, double v) {
@@ -355,7 +360,7 @@ __global__ __launch_bounds__(256) void k_build(DevProblem d, const double *__res
                             if (b < a) continue;
                             val += E[0][a] * E[0][b] + E[1][a] * E[1][b];
                         }
-                        atomic_add_f64(S + (int64_t)(cbase + a) * d.NS + (rbase + b), val);
+                        atomic_add_f64(S + (int64_t)(cbase + a) * d.ldS + (rbase + b), val);
                     }
                 }
             }
@@ -385,7 +390,7 @@ __global__ __launch_bounds__(256) void k_build(DevProblem d, const double *__res
                             for (int q = 0; q < NCX; ++q) if (q == b) { eb0 = E[0][q]; eb1 = E[1][q]; }
                             val += ea0 * eb0 + ea1 * eb1;
                         }
-                        atomic_add_f64(S + (int64_t)gcol * d.NS + grow, val);
+                        atomic_add_f64(S + (int64_t)gcol * d.ldS + grow, val);
                     }
                 }
             }
@@ -404,13 +409,196 @@ __global__ __launch_bounds__(256) void k_build(DevProblem d, const double *__res
     }
 }
 
+// ---------------------------------------------------------------- K1t ---
+// Tiled variant of k_build for the fixed-IO path: one workgroup per TILE (a
+// run of batches whose observations touch at most CMAX cameras).  The tile's
+// share of the reduced system -- 6x6 blocks for every pair of its cameras,
+// lower triangle -- and of g_c, g_red, diagU is accumulated in LDS with
+// ds_add_f64 and flushed to HBM once per tile, instead of one global f64
+// atomic per Schur-complement entry.
+template <int MODEL>
+__global__ __launch_bounds__(256) void k_build_tile(DevProblem d, const double *__restrict__ z,
+                                                    const CamRec *__restrict__ cams, double lambda, int scale,
+                                                    double *__restrict__ S, double *__restrict__ g_c,
+                                                    double *__restrict__ g_red, double *__restrict__ diagU,
+                                                    double *__restrict__ Vinv, double *__restrict__ gp,
+                                                    double *__restrict__ jn2p, double *__restrict__ r_w,
+                                                    double *__restrict__ partial,
+                                                    unsigned long long *__restrict__ pivmm) {
+    extern __shared__ double smem[];
+    const int BT = blockDim.x;
+    const int CM = d.CMAX;
+    const int nblk = CM * (CM + 1) / 2;
+    double *Wl = smem;                               // [BT][18]
+    double *red = Wl + (size_t)BT * 18;              // [BT][9]  B'B | B'r, then V^-1 | g_p at the leader's row
+    double *St = red + (size_t)BT * 9;               // [nblk][36] block (lj>=li) at lj*(lj+1)/2+li, entry [a*6+b]: col a of cam i, row b of cam j
+    double *vt = St + (size_t)nblk * 36;             // [3][6*CM]  g_c | g_red | diagU
+    __shared__ double sh[8];
+    const int t = threadIdx.x;
+    const int tile = blockIdx.x;
+    const int b0 = d.tile_batch[tile], b1 = d.tile_batch[tile + 1];
+    const int c0 = d.tile_cam_start[tile];
+    const int ncam = d.tile_cam_start[tile + 1] - c0;
+    for (int i = t; i < nblk * 36 + 18 * CM; i += BT) St[i] = 0.0;
+    double pmin = 1e300, pmax = 0.0, rr = 0.0;
+    __syncthreads();
+    for (int b = b0; b < b1; ++b) {
+        const int64_t o0 = d.batch_start[b];
+        const int nobs = (int)(d.batch_start[b + 1] - o0);
+        const bool active = t < nobs;
+        const int64_t o = o0 + t;
+        double r[2] = {0, 0};
+        double E[2][6];
+        double B[2][3];
+        int pt = 0, seg_start = 0, seg_len = 0, lc = 0;
+        if (active) {
+            const int cam = d.o_cam[o];
+            pt = d.o_pt[o]; lc = d.o_lc[o];
+            const uint32_t sg = d.o_seg[o];
+            seg_start = sg & 0xFFFF; seg_len = sg >> 16;
+            eval_obs_cols<MODEL, false>(d, cams[cam], z, o, pt, r, E, B);
+            r_w[2 * o] = r[0]; r_w[2 * o + 1] = r[1];
+            rr += r[0] * r[0] + r[1] * r[1];
+            double *rd = red + (size_t)t * 9;
+            rd[0] = B[0][0] * B[0][0] + B[1][0] * B[1][0];
+            rd[1] = B[0][0] * B[0][1] + B[1][0] * B[1][1];
+            rd[2] = B[0][0] * B[0][2] + B[1][0] * B[1][2];
+            rd[3] = B[0][1] * B[0][1] + B[1][1] * B[1][1];
+            rd[4] = B[0][1] * B[0][2] + B[1][1] * B[1][2];
+            rd[5] = B[0][2] * B[0][2] + B[1][2] * B[1][2];
+            rd[6] = B[0][0] * r[0] + B[1][0] * r[1];
+            rd[7] = B[0][1] * r[0] + B[1][1] * r[1];
+            rd[8] = B[0][2] * r[0] + B[1][2] * r[1];
+        }
+        __syncthreads();
+        if (active && t == seg_start) {
+            double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+            for (int j = 0; j < seg_len; ++j) {
+                const double *rd = red + (size_t)(t + j) * 9;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) V[k] += rd[k];
+                g[0] += rd[6]; g[1] += rd[7]; g[2] += rd[8];
+            }
+            const int64_t zp = d.NS + 3 * (int64_t)pt;
+            const int dix[3] = {0, 3, 5};
+            double jn[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double pw = d.z_prw[zp + k];
+                if (pw > 0) { V[dix[k]] += pw; g[k] += pw * (z[zp + k] - d.z_prv[zp + k]); }
+                jn[k] = V[dix[k]];
+                jn2p[3 * (int64_t)pt + k] = jn[k];
+                if (d.z_est[zp + k]) V[dix[k]] += lambda; else V[dix[k]] = 1.0;
+            }
+            double inv[6];
+            inv3_sym(V, inv);
+            {
+                const double d0 = sqrt(V[0]), l10 = V[1] / d0, l20 = V[2] / d0;
+                const double d1 = sqrt(V[3] - l10 * l10), l21 = (V[4] - l20 * l10) / d1;
+                const double d2 = sqrt(V[5] - l20 * l20 - l21 * l21);
+                const double dd[3] = {d0, d1, d2};
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    if (d.z_est[zp + k]) {
+                        double v = scale ? dd[k] / sqrt(jn[k]) : dd[k];
+                        v = v == v ? v : 0.0;
+                        pmin = fmin(pmin, v); pmax = fmax(pmax, v);
+                    }
+            }
+            double *pi = red + (size_t)t * 9;         // the leader's own row: safe to overwrite
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { pi[k] = inv[k]; Vinv[6 * (int64_t)pt + k] = inv[k]; }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { pi[6 + k] = g[k]; gp[3 * (int64_t)pt + k] = g[k]; }
+        }
+        __syncthreads();
+        double Y[6][3];
+        if (active) {
+            const double *pi = red + (size_t)seg_start * 9;
+            const double v0 = pi[0], v1 = pi[1], v2 = pi[2], v3 = pi[3], v4 = pi[4], v5 = pi[5];
+            const double g0 = pi[6], g1 = pi[7], g2 = pi[8];
+            double *wl = Wl + (size_t)t * 18;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                const double w0 = E[0][a] * B[0][0] + E[1][a] * B[1][0];
+                const double w1 = E[0][a] * B[0][1] + E[1][a] * B[1][1];
+                const double w2 = E[0][a] * B[0][2] + E[1][a] * B[1][2];
+                wl[3 * a] = w0; wl[3 * a + 1] = w1; wl[3 * a + 2] = w2;
+                Y[a][0] = w0 * v0 + w1 * v1 + w2 * v2;
+                Y[a][1] = w0 * v1 + w1 * v3 + w2 * v4;
+                Y[a][2] = w0 * v2 + w1 * v4 + w2 * v5;
+                const double ga = E[0][a] * r[0] + E[1][a] * r[1];
+                atomic_add_f64(vt + 6 * lc + a, ga);
+                atomic_add_f64(vt + 6 * CM + 6 * lc + a, ga - (Y[a][0] * g0 + Y[a][1] * g1 + Y[a][2] * g2));
+                atomic_add_f64(vt + 12 * CM + 6 * lc + a, E[0][a] * E[0][a] + E[1][a] * E[1][a]);
+            }
+        }
+        __syncthreads();
+        if (active) {
+            // partners jj >= t of the same point have larger local camera indices
+            for (int jj = t; jj < seg_start + seg_len; ++jj) {
+                const double *wj = Wl + (size_t)jj * 18;
+                const int lj = d.o_lc[o0 + jj];
+                double *blk = St + (size_t)(lj * (lj + 1) / 2 + lc) * 36;
+#pragma unroll
+                for (int b2 = 0; b2 < 6; ++b2) {
+                    const double wb0 = wj[3 * b2], wb1 = wj[3 * b2 + 1], wb2 = wj[3 * b2 + 2];
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) {
+                        double val = -(Y[a][0] * wb0 + Y[a][1] * wb1 + Y[a][2] * wb2);
+                        if (jj == t) {
+                            if (b2 < a) continue;
+                            val += E[0][a] * E[0][b2] + E[1][a] * E[1][b2];
+                        }
+                        atomic_add_f64(blk + a * 6 + b2, val);
+                    }
+                }
+            }
+        }
+        __syncthreads();       // Wl / red are reused by the next batch
+    }
+    // ---- flush the tile to HBM
+    for (int i = t; i < nblk * 36; i += BT) {
+        const int blkid = i / 36, e = i - blkid * 36;
+        // blkid = lj*(lj+1)/2 + li  ->  lj, li
+        int lj = (int)((sqrt(8.0 * blkid + 1.0) - 1.0) * 0.5);
+        while ((lj + 1) * (lj + 2) / 2 <= blkid) ++lj;
+        while (lj * (lj + 1) / 2 > blkid) --lj;
+        const int li = blkid - lj * (lj + 1) / 2;
+        if (lj >= ncam) continue;
+        const double v = St[i];
+        if (v == 0.0) continue;
+        const int a = e / 6, b2 = e - a * 6;
+        const int64_t col = 6 * (int64_t)d.tile_cams[c0 + li] + a;
+        const int64_t row = 6 * (int64_t)d.tile_cams[c0 + lj] + b2;
+        atomic_add_f64(S + col * d.ldS + row, v);
+    }
+    for (int i = t; i < 6 * ncam; i += BT) {
+        const int64_t col = 6 * (int64_t)d.tile_cams[c0 + i / 6] + i % 6;
+        atomic_add_f64(g_c + col, vt[i]);
+        atomic_add_f64(g_red + col, vt[6 * CM + i]);
+        atomic_add_f64(diagU + col, vt[12 * CM + i]);
+    }
+    double acc[1] = {rr};
+    block_sum<1>(acc, sh);
+    if (t == 0) partial[blockIdx.x] = acc[0];
+    for (int off = 32; off > 0; off >>= 1) {
+        pmin = fmin(pmin, __shfl_down(pmin, off, 64));
+        pmax = fmax(pmax, __shfl_down(pmax, off, 64));
+    }
+    if ((t & 63) == 0 && pmax > 0.0) {
+        atomicMin(pivmm, (unsigned long long)__double_as_longlong(pmin));
+        atomicMax(pivmm + 1, (unsigned long long)__double_as_longlong(pmax));
+    }
+}
+
 // min/max of the Cholesky pivots of the reduced system (estimated entries only)
 __global__ __launch_bounds__(256) void k_diag_minmax(DevProblem d, const double *__restrict__ S,
                                                      unsigned long long *__restrict__ pivmm) {
     double pmin = 1e300, pmax = 0.0;
     for (int64_t i = threadIdx.x; i < d.NS; i += blockDim.x)
         if (d.z_est[i]) {
-            double v = S[i * d.NS + i];
+            double v = S[i * d.ldS + i];
             v = v == v ? v : 0.0;
             pmin = fmin(pmin, v); pmax = fmax(pmax, v);
         }
@@ -428,11 +616,12 @@ __global__ __launch_bounds__(256) void k_diag_minmax(DevProblem d, const double 
 // Camera/IO side: priors, damping, fixed rows, column scaling factors.
 //   jn2c[i] = diagU[i] + prior weight  (squared column norm of J)
 //   dscale[i] = 1/sqrt(jn2c) if scaling, estimated and >0 ; else 1
-//   rhs[i]  = -dscale[i]*g_red[i]   (0 for fixed)
+//   S(NS, i) = -dscale[i]*g_red[i]  (0 for fixed): the right-hand side, stored as
+//              the extra row below the matrix (see chol.hpp)
 __global__ void k_finish(DevProblem d, const double *__restrict__ z, double lambda, int scale,
                          double *__restrict__ S, double *__restrict__ g_c, double *__restrict__ g_red,
                          const double *__restrict__ diagU, double *__restrict__ jn2c,
-                         double *__restrict__ dscale, double *__restrict__ rhs) {
+                         double *__restrict__ dscale) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d.NS) return;
     const double pw = d.z_prw[i];
@@ -447,21 +636,21 @@ __global__ void k_finish(DevProblem d, const double *__restrict__ z, double lamb
     if (est) {
         add += lambda;
         if (scale && jn2 > 0) ds = 1.0 / sqrt(jn2);
-        S[i * d.NS + i] += add;
-        rhs[i] = -ds * g;
+        S[i * d.ldS + i] += add;
+        S[i * d.ldS + d.NS] = -ds * g;
     } else {
-        S[i * d.NS + i] = 1.0;
-        rhs[i] = 0.0;
+        S[i * d.ldS + i] = 1.0;
+        S[i * d.ldS + d.NS] = 0.0;
     }
     dscale[i] = ds;
 }
 
 // S(i,j) *= d_i d_j on the lower triangle
-__global__ void k_scale_S(int64_t NS, double *__restrict__ S, const double *__restrict__ ds) {
+__global__ void k_scale_S(int64_t NS, int64_t ldS, double *__restrict__ S, const double *__restrict__ ds) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // row
     const int64_t j = blockIdx.y;                                        // column
     if (i >= NS || i < j) return;
-    S[j * NS + i] *= ds[i] * ds[j];
+    S[j * ldS + i] *= ds[i] * ds[j];
 }
 
 __global__ void k_unscale(int64_t NS, const double *__restrict__ q, const double *__restrict__ ds,

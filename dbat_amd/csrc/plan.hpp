@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -52,6 +53,13 @@ struct Plan {
     std::vector<uint32_t> o_seg;                   // (seg_start | seg_len<<16) within batch
     std::vector<int64_t> o_row;                    // IP column (reference order)
     std::vector<int64_t> batch_start;              // [nb+1]
+    // tiles: runs of batches whose observations touch at most CMAX cameras; the
+    // Schur complement of a tile is accumulated in LDS and flushed once
+    std::vector<uint8_t> o_lc;                     // local camera index of every observation
+    std::vector<int32_t> tile_batch;               // [ntiles+1] first batch of every tile
+    std::vector<int32_t> tile_cam_start;           // [ntiles+1]
+    std::vector<int32_t> tile_cams;                // global camera ids, ascending inside a tile
+    int CMAX = 0;                                  // 0 = no tiling (global atomics)
     int BT = 256;
     int ncolmax = 6;
     bool with_io = false;
@@ -256,22 +264,46 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
             if (rows[k] == 0 && !(P.z_prw[6 * (int64_t)nc + k] > 0)) P.rank_ok = false;
     }
 
-    // ---- processing order: points sorted by their (ascending) camera lists so
-    // that neighbouring points touch the same blocks of the reduced system.
+    // ---- processing order of the object points
     std::vector<int64_t> pstart(np + 1, 0);
     for (int p = 0; p < np; ++p) pstart[p + 1] = pstart[p] + k_pt[p];
     std::vector<int64_t> fill(pstart.begin(), pstart.end() - 1);
     std::vector<int64_t> by_pt(P.no);
     for (int64_t o = 0; o < P.no; ++o) by_pt[fill[pb.ip_pt[o]]++] = o;   // image-major scan => cams ascending per point
+    // Key = 3-D Morton code of the point's initial coordinates: points that are
+    // close in object space are seen by the same cameras, so neighbouring
+    // points touch the same blocks of the reduced system (tiles below).
+    // Unobserved points sort last.
     std::vector<uint64_t> key(np);
-    for (int p = 0; p < np; ++p) {
-        uint64_t k = 0;
-        for (int j = 0; j < 4; ++j) {
-            uint64_t c = 0xFFFF;
-            if (j < k_pt[p]) c = std::min<uint64_t>(0xFFFE, (uint64_t)pb.ip_cam[by_pt[pstart[p] + j]]);
-            k = (k << 16) | c;
+    {
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        for (int p = 0; p < np; ++p)
+            for (int d = 0; d < 3; ++d) {
+                const double v = pb.OP_val[(size_t)3 * p + d];
+                if (std::isfinite(v)) { lo[d] = std::min(lo[d], v); hi[d] = std::max(hi[d], v); }
+            }
+        double ext = 0;
+        for (int d = 0; d < 3; ++d) ext = std::max(ext, hi[d] - lo[d]);
+        if (!(ext > 0)) ext = 1;
+        auto spread = [](uint64_t v) {      // 21 bits -> every third bit
+            v &= 0x1FFFFF;
+            v = (v | v << 32) & 0x1F00000000FFFFull;
+            v = (v | v << 16) & 0x1F0000FF0000FFull;
+            v = (v | v << 8) & 0x100F00F00F00F00Full;
+            v = (v | v << 4) & 0x10C30C30C30C30C3ull;
+            v = (v | v << 2) & 0x1249249249249249ull;
+            return v;
+        };
+        for (int p = 0; p < np; ++p) {
+            uint64_t k = 0;
+            for (int d = 0; d < 3; ++d) {
+                double v = (pb.OP_val[(size_t)3 * p + d] - lo[d]) / ext;
+                if (!(v >= 0)) v = 0;
+                if (v > 1) v = 1;
+                k |= spread((uint64_t)(v * 2097151.0)) << d;
+            }
+            key[p] = k_pt[p] ? k : ~0ull;
         }
-        key[p] = k;
     }
     P.porder.resize(np);
     std::iota(P.porder.begin(), P.porder.end(), 0);
@@ -296,40 +328,78 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         for (int d = 0; d < 3; ++d) P.z_mine[P.NS + 3 * (int64_t)P.porder[i] + d] = 1;
     if (!with_obs) return true;
 
-    // ---- batches of whole points, at most BT observations each
+    // ---- batches of whole points, at most BT observations each; tiles of
+    // batches touching at most CMAX cameras (fixed-IO path only)
     const int strideW = P.ncolmax * 3;
-    P.BT = 256;
+    auto env_int = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
+    P.BT = env_int("DBAT_HIP_BT", 256);
+    if (P.BT != 128 && P.BT != 256) P.BT = 256;
     if ((size_t)P.BT * strideW * 8 + (size_t)P.BT * 18 * 8 > 150 * 1024) P.BT = 128;
+    P.CMAX = P.with_io ? 0 : env_int("DBAT_HIP_CMAX", 20);
+    if (P.CMAX < 0 || P.CMAX > 40) P.CMAX = 20;
     if (P.max_k > P.BT)
         return fail(P, "an object point has more observations than one batch holds (" +
                        std::to_string(P.max_k) + " > " + std::to_string(P.BT) + ")");
+    if (P.CMAX && P.max_k > P.CMAX) P.CMAX = 0;      // a point alone overflows a tile: fall back
     P.batch_start.clear(); P.batch_start.push_back(0);
     int64_t nobs_shard = 0;
     for (int64_t i = P.pt_lo; i < P.pt_hi; ++i) nobs_shard += k_pt[P.porder[i]];
     P.o_cam.resize(nobs_shard); P.o_pt.resize(nobs_shard); P.o_uv.resize(2 * nobs_shard);
-    P.o_seg.resize(nobs_shard); P.o_row.resize(nobs_shard);
+    P.o_seg.resize(nobs_shard); P.o_row.resize(nobs_shard); P.o_lc.assign(nobs_shard, 0);
     if (!P.uniform_w) P.o_w.resize(2 * nobs_shard);
-    int64_t pos = 0, bstart = 0;
+    P.tile_batch.clear(); P.tile_cam_start.clear(); P.tile_cams.clear();
+    P.tile_batch.push_back(0); P.tile_cam_start.push_back(0);
+    std::vector<int32_t> stamp(nc, -1);              // tile id in which a camera was last seen
+    std::vector<int32_t> cur_cams;
+    int64_t pos = 0, bstart = 0, tile_first_obs = 0;
+    auto close_tile = [&](int64_t end_obs) {
+        // local indices in ascending global camera order
+        std::sort(cur_cams.begin(), cur_cams.end());
+        std::vector<int32_t> &loc = stamp;            // reuse as cam -> local index (restored below)
+        for (size_t l = 0; l < cur_cams.size(); ++l) loc[cur_cams[l]] = (int32_t)l;
+        for (int64_t o = tile_first_obs; o < end_obs; ++o) P.o_lc[o] = (uint8_t)loc[P.o_cam[o]];
+        for (int32_t c : cur_cams) { P.tile_cams.push_back(c); loc[c] = -1; }
+        P.tile_cam_start.push_back((int32_t)P.tile_cams.size());
+        P.tile_batch.push_back((int32_t)P.batch_start.size() - 1);   // = number of closed batches
+        cur_cams.clear();
+        tile_first_obs = end_obs;
+    };
+    int32_t tile_id = 0;
     for (int64_t i = P.pt_lo; i < P.pt_hi; ++i) {
         const int32_t p = P.porder[i];
         const int k = k_pt[p];
         if (k == 0) continue;
+        if (P.CMAX) {
+            int fresh = 0;
+            for (int j = 0; j < k; ++j) if (stamp[pb.ip_cam[by_pt[pstart[p] + j]]] != tile_id) ++fresh;
+            if ((int)cur_cams.size() + fresh > P.CMAX && pos > tile_first_obs) {
+                // close the current batch and tile before this point
+                P.batch_start.push_back(pos); bstart = pos;
+                for (int32_t c : cur_cams) stamp[c] = -1;
+                close_tile(pos);
+                ++tile_id;
+            }
+        }
         if (pos - bstart + k > P.BT) { P.batch_start.push_back(pos); bstart = pos; }
         const uint32_t seg = (uint32_t)(pos - bstart) | ((uint32_t)k << 16);
         for (int j = 0; j < k; ++j, ++pos) {
             const int64_t o = by_pt[pstart[p] + j];
-            P.o_cam[pos] = pb.ip_cam[o]; P.o_pt[pos] = p;
+            const int32_t c = pb.ip_cam[o];
+            P.o_cam[pos] = c; P.o_pt[pos] = p;
             P.o_uv[2 * pos] = pb.ip_val[2 * o]; P.o_uv[2 * pos + 1] = pb.ip_val[2 * o + 1];
             P.o_seg[pos] = seg; P.o_row[pos] = o;
             if (!P.uniform_w) {
-                const int32_t c = pb.ip_cam[o];
                 P.o_w[2 * pos] = 1.0 / (pb.ip_std[2 * o] * P.px[2 * c]);
                 P.o_w[2 * pos + 1] = 1.0 / (pb.ip_std[2 * o + 1] * P.px[2 * c + 1]);
             }
+            if (P.CMAX && stamp[c] != tile_id) { stamp[c] = tile_id; cur_cams.push_back(c); }
         }
     }
     if (pos > bstart || P.batch_start.size() == 1) P.batch_start.push_back(pos);
-    if (P.batch_start.back() != pos) P.batch_start.push_back(pos);
+    if (P.CMAX) {
+        for (int32_t c : cur_cams) stamp[c] = -1;
+        close_tile(pos);
+    }
     return true;
 }
 

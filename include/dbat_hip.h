@@ -248,7 +248,8 @@ int  dbat_hip_bench_step(dbat_hip_handle *h, double lambda, int32_t scale_column
 int  dbat_hip_set_x(dbat_hip_handle *h, const double *x);
 /* sizes of the internal layout, for roofline accounting:
  * info[0]=NS (reduced system order) info[1]=#batches info[2]=max obs per point
- * info[3]=obs in this shard info[4]=points in this shard */
+ * info[3]=obs in this shard info[4]=points in this shard info[5]=batch size
+ * info[6]=max camera-side columns per observation info[7]=#tiles */
 int  dbat_hip_info(const dbat_hip_handle *h, int64_t *info /*[8]*/);
 
 #ifdef __cplusplus
