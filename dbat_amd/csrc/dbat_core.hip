@@ -59,7 +59,7 @@ struct Core {
     DevBuf<int32_t> cam_ncol, cam_col, cam_iorow, io_src, o_cam, o_pt;
     DevBuf<uint32_t> cam_eo_est, o_seg;
     DevBuf<double> io_fixed, px, cam_w, z_prw, z_prv, o_uv, o_w;
-    DevBuf<uint8_t> z_est, z_mine, o_lc;
+    DevBuf<uint8_t> z_est, z_mine, o_lc, o_pidx;
     DevBuf<int32_t> tile_batch, tile_cam_start, tile_cams;
     int64_t ntiles = 0;
     size_t lds_tile = 0;
@@ -112,7 +112,7 @@ struct Core {
         o_cam.upload(P.o_cam); o_pt.upload(P.o_pt); o_uv.upload(P.o_uv); o_w.upload(P.o_w);
         o_seg.upload(P.o_seg); o_row.upload(P.o_row); batch_start.upload(P.batch_start);
         x2z.upload(P.x2z);
-        o_lc.upload(P.o_lc); tile_batch.upload(P.tile_batch); tile_cam_start.upload(P.tile_cam_start); tile_cams.upload(P.tile_cams);
+        o_lc.upload(P.o_lc); o_pidx.upload(P.o_pidx); tile_batch.upload(P.tile_batch); tile_cam_start.upload(P.tile_cam_start); tile_cams.upload(P.tile_cams);
         ntiles = P.CMAX ? (int64_t)P.tile_batch.size() - 1 : 0;
         d.nc = P.nc; d.np = P.np; d.nIOrows = P.nIOrows; d.nK = P.nK; d.nP = P.nP; d.nIOu = P.nIOu;
         d.ncolmax = P.ncolmax; d.BT = P.BT; d.NS = P.NS; d.NZ = P.NZ; d.nobs = nobs; d.nb = nb;
@@ -121,7 +121,8 @@ struct Core {
         d.z_est = z_est.p; d.z_mine = z_mine.p; d.z_prw = z_prw.p; d.z_prv = z_prv.p;
         d.o_cam = o_cam.p; d.o_pt = o_pt.p; d.o_uv = o_uv.p; d.o_w = P.uniform_w ? nullptr : o_w.p;
         d.o_seg = o_seg.p; d.o_row = o_row.p; d.batch_start = batch_start.p;
-        d.CMAX = P.CMAX; d.ntiles = (int)ntiles; d.o_lc = o_lc.p;
+        d.CMAX = P.CMAX; d.ablate = getenv("DBAT_HIP_ABLATE") ? atoi(getenv("DBAT_HIP_ABLATE")) : 0;
+        d.ntiles = (int)ntiles; d.o_lc = o_lc.p; d.o_pidx = o_pidx.p;
         d.tile_batch = tile_batch.p; d.tile_cam_start = tile_cam_start.p; d.tile_cams = tile_cams.p;
         cams.alloc(P.nc);
         z.alloc(P.NZ); zt.alloc(P.NZ); dz.alloc(P.NZ); zlin.alloc(P.NZ); vtmp.alloc(P.NZ); vtmp2.alloc(P.NZ);
@@ -147,7 +148,7 @@ struct Core {
         mmx.alloc((size_t)2 * P.nranks);
         lds_build = ((size_t)P.BT * P.ncolmax * 3 + (size_t)P.BT * 18) * sizeof(double);
         lds_back = (size_t)P.BT * 6 * sizeof(double);
-        lds_tile = ((size_t)P.BT * 27 + (size_t)(P.CMAX * (P.CMAX + 1) / 2) * 36 + (size_t)18 * P.CMAX) * sizeof(double);
+        lds_tile = ((size_t)2 * 24 * 128 + (size_t)P.BT * 9 + (size_t)54 * P.CMAX) * sizeof(double);
         partial.alloc((size_t)4 * std::max<int64_t>(std::max<int64_t>(std::max<int64_t>(nb, ntiles), 2048), 1));
         set_lds_limits();
         HIPCHK(hipMemcpy(z.p, P.z0.data(), P.NZ * 8, hipMemcpyHostToDevice));

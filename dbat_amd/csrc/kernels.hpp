@@ -45,7 +45,8 @@ struct DevProblem {
     const int64_t *batch_start;
     // tiles (fixed-IO path): runs of batches touching at most CMAX cameras
     int CMAX, ntiles;
-    const uint8_t *o_lc;
+    int ablate;                     // profiling only (DBAT_HIP_ABLATE): bit0 skip MFMA, bit1 skip P3 atomics, bit2 skip eval
+    const uint8_t *o_lc, *o_pidx;
     const int32_t *tile_batch, *tile_cam_start, *tile_cams;
 };
 
@@ -411,11 +412,26 @@ __global__ __launch_bounds__(256) void k_build(DevProblem d, const double *__res
 
 // ---------------------------------------------------------------- K1t ---
 // Tiled variant of k_build for the fixed-IO path: one workgroup per TILE (a
-// run of batches whose observations touch at most CMAX cameras).  The tile's
-// share of the reduced system -- 6x6 blocks for every pair of its cameras,
-// lower triangle -- and of g_c, g_red, diagU is accumulated in LDS with
-// ds_add_f64 and flushed to HBM once per tile, instead of one global f64
-// atomic per Schur-complement entry.
+// run of batches whose observations touch at most CMAX <= 21 cameras, i.e. at
+// most 126 rows of the reduced system).  The tile's share of the Schur
+// complement  sum_p (W_p V_p^-1) W_p'  is a dense 128 x 128 x 3*npoints
+// contraction:  per chunk of 8 points the 6x3 blocks Y = W V^-1 and W of every
+// observation are scattered into zero-filled LDS panels Yt, Wt [24][128] and the
+// lower-triangular 16x16 tiles are accumulated on the f64 matrix cores
+// (v_mfma_f64_16x16x4_f64) in REGISTERS for the whole tile, then flushed to
+// HBM once -- no atomics on the k^2 pair terms.  E'E (camera diagonal blocks)
+// and the gradient pieces go through a few LDS atomics per observation.
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+
+struct TileMap { int8_t rt[36], ct[36]; };
+__host__ __device__ constexpr TileMap make_tile_map() {
+    TileMap m{};
+    int n = 0;
+    for (int r = 0; r < 8; ++r)
+        for (int c = 0; c <= r; ++c) { m.rt[n] = (int8_t)r; m.ct[n] = (int8_t)c; ++n; }
+    return m;
+}
+
 template <int MODEL>
 __global__ __launch_bounds__(256) void k_build_tile(DevProblem d, const double *__restrict__ z,
                                                     const CamRec *__restrict__ cams, double lambda, int scale,
@@ -425,21 +441,41 @@ __global__ __launch_bounds__(256) void k_build_tile(DevProblem d, const double *
                                                     double *__restrict__ jn2p, double *__restrict__ r_w,
                                                     double *__restrict__ partial,
                                                     unsigned long long *__restrict__ pivmm) {
+    constexpr int PC = 8, KC = 3 * PC, LD = 128;
+    constexpr TileMap TM = make_tile_map();
     extern __shared__ double smem[];
     const int BT = blockDim.x;
     const int CM = d.CMAX;
-    const int nblk = CM * (CM + 1) / 2;
-    double *Wl = smem;                               // [BT][18]
-    double *red = Wl + (size_t)BT * 18;              // [BT][9]  B'B | B'r, then V^-1 | g_p at the leader's row
-    double *St = red + (size_t)BT * 9;               // [nblk][36] block (lj>=li) at lj*(lj+1)/2+li, entry [a*6+b]: col a of cam i, row b of cam j
-    double *vt = St + (size_t)nblk * 36;             // [3][6*CM]  g_c | g_red | diagU
+    double *Yt = smem;                               // [KC][LD]  Yt[k][row] = (W V^-1)(row, k)
+    double *Wt = Yt + KC * LD;                       // [KC][LD]
+    double *red = Wt + KC * LD;                      // [BT][9]   B'B | B'r, then V^-1 | g_p at the leader's row
+    double *Ud = red + (size_t)BT * 9;               // [CM][36]  E'E of every camera, entry [a*6+b], b>=a
+    double *vt = Ud + (size_t)CM * 36;               // [3][6*CM] g_c | g_red | diagU
     __shared__ double sh[8];
-    const int t = threadIdx.x;
+    __shared__ int npts_sh;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);        // scalar: keeps the tile choices out of EXEC
     const int tile = blockIdx.x;
     const int b0 = d.tile_batch[tile], b1 = d.tile_batch[tile + 1];
     const int c0 = d.tile_cam_start[tile];
     const int ncam = d.tile_cam_start[tile + 1] - c0;
-    for (int i = t; i < nblk * 36 + 18 * CM; i += BT) St[i] = 0.0;
+    const int nrows = 6 * ncam;
+    // this wave's nine 16x16 tiles (row tile, column tile) of the lower triangle,
+    // as LDS element offsets; tiles beyond the tile's rows are switched off
+    int yoff[9], woff[9];
+    bool ton[9];
+#pragma unroll
+    for (int s = 0; s < 9; ++s) {
+        const int n = wave + 4 * s;
+        const int rt = __builtin_amdgcn_readfirstlane((int)TM.rt[n]);
+        const int ct = __builtin_amdgcn_readfirstlane((int)TM.ct[n]);
+        yoff[s] = 16 * rt; woff[s] = 16 * ct; ton[s] = 16 * rt < nrows;
+    }
+    for (int i = t; i < 2 * KC * LD; i += BT) Yt[i] = 0.0;
+    for (int i = t; i < CM * 36 + 18 * CM; i += BT) Ud[i] = 0.0;
+    mfma_d4 acc[9];
+#pragma unroll
+    for (int s = 0; s < 9; ++s) acc[s] = mfma_d4{0, 0, 0, 0};
     double pmin = 1e300, pmax = 0.0, rr = 0.0;
     __syncthreads();
     for (int b = b0; b < b1; ++b) {
@@ -450,13 +486,15 @@ __global__ __launch_bounds__(256) void k_build_tile(DevProblem d, const double *
         double r[2] = {0, 0};
         double E[2][6];
         double B[2][3];
-        int pt = 0, seg_start = 0, seg_len = 0, lc = 0;
-        if (active) {
+        int pt = 0, seg_start = 0, seg_len = 0, lc = 0, pidx = 0;
+        if (t == 0) npts_sh = 0;
+        if (active) {                                // ---- P1: residual + Jacobian blocks
             const int cam = d.o_cam[o];
-            pt = d.o_pt[o]; lc = d.o_lc[o];
+            pt = d.o_pt[o]; lc = d.o_lc[o]; pidx = d.o_pidx[o];
             const uint32_t sg = d.o_seg[o];
             seg_start = sg & 0xFFFF; seg_len = sg >> 16;
-            eval_obs_cols<MODEL, false>(d, cams[cam], z, o, pt, r, E, B);
+            if (d.ablate & 4) { for (int q = 0; q < 6; ++q) { E[0][q] = 1e-3 * (q + lc); E[1][q] = 2e-3 * q; } for (int q = 0; q < 3; ++q) { B[0][q] = q + 1.0; B[1][q] = 0.5 * q; } }
+            else eval_obs_cols<MODEL, false>(d, cams[cam], z, o, pt, r, E, B);
             r_w[2 * o] = r[0]; r_w[2 * o + 1] = r[1];
             rr += r[0] * r[0] + r[1] * r[1];
             double *rd = red + (size_t)t * 9;
@@ -471,7 +509,8 @@ __global__ __launch_bounds__(256) void k_build_tile(DevProblem d, const double *
             rd[8] = B[0][2] * r[0] + B[1][2] * r[1];
         }
         __syncthreads();
-        if (active && t == seg_start) {
+        if (active && t == seg_start) {              // ---- P2: per point V, damping, priors, V^-1
+            atomicMax(&npts_sh, pidx + 1);
             double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
             for (int j = 0; j < seg_len; ++j) {
                 const double *rd = red + (size_t)(t + j) * 9;
@@ -512,66 +551,115 @@ __global__ __launch_bounds__(256) void k_build_tile(DevProblem d, const double *
             for (int k = 0; k < 3; ++k) { pi[6 + k] = g[k]; gp[3 * (int64_t)pt + k] = g[k]; }
         }
         __syncthreads();
-        double Y[6][3];
-        if (active) {
+        double W[6][3];
+        double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
+        if (active) {                                // ---- P3: W = E'B, E'E, gradient pieces
             const double *pi = red + (size_t)seg_start * 9;
-            const double v0 = pi[0], v1 = pi[1], v2 = pi[2], v3 = pi[3], v4 = pi[4], v5 = pi[5];
+            v0 = pi[0]; v1 = pi[1]; v2 = pi[2]; v3 = pi[3]; v4 = pi[4]; v5 = pi[5];
             const double g0 = pi[6], g1 = pi[7], g2 = pi[8];
-            double *wl = Wl + (size_t)t * 18;
+            double *ud = Ud + (size_t)lc * 36;
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
                 const double w0 = E[0][a] * B[0][0] + E[1][a] * B[1][0];
                 const double w1 = E[0][a] * B[0][1] + E[1][a] * B[1][1];
                 const double w2 = E[0][a] * B[0][2] + E[1][a] * B[1][2];
-                wl[3 * a] = w0; wl[3 * a + 1] = w1; wl[3 * a + 2] = w2;
-                Y[a][0] = w0 * v0 + w1 * v1 + w2 * v2;
-                Y[a][1] = w0 * v1 + w1 * v3 + w2 * v4;
-                Y[a][2] = w0 * v2 + w1 * v4 + w2 * v5;
+                W[a][0] = w0; W[a][1] = w1; W[a][2] = w2;
+                const double y0 = w0 * v0 + w1 * v1 + w2 * v2;
+                const double y1 = w0 * v1 + w1 * v3 + w2 * v4;
+                const double y2 = w0 * v2 + w1 * v4 + w2 * v5;
                 const double ga = E[0][a] * r[0] + E[1][a] * r[1];
+                if (d.ablate & 2) continue;
                 atomic_add_f64(vt + 6 * lc + a, ga);
-                atomic_add_f64(vt + 6 * CM + 6 * lc + a, ga - (Y[a][0] * g0 + Y[a][1] * g1 + Y[a][2] * g2));
+                atomic_add_f64(vt + 6 * CM + 6 * lc + a, ga - (y0 * g0 + y1 * g1 + y2 * g2));
                 atomic_add_f64(vt + 12 * CM + 6 * lc + a, E[0][a] * E[0][a] + E[1][a] * E[1][a]);
+#pragma unroll
+                for (int b2 = a; b2 < 6; ++b2)
+                    atomic_add_f64(ud + a * 6 + b2, E[0][a] * E[0][b2] + E[1][a] * E[1][b2]);
             }
         }
-        __syncthreads();
-        if (active) {
-            // partners jj >= t of the same point have larger local camera indices
-            for (int jj = t; jj < seg_start + seg_len; ++jj) {
-                const double *wj = Wl + (size_t)jj * 18;
-                const int lj = d.o_lc[o0 + jj];
-                double *blk = St + (size_t)(lj * (lj + 1) / 2 + lc) * 36;
+        const int npts = (d.ablate & 1) ? 0 : npts_sh;   // written before the barrier after P2
+        // ---- P4: chunks of PC points through the matrix cores
+        for (int p0 = 0; p0 < npts; p0 += PC) {
+            const bool mine = active && pidx >= p0 && pidx < p0 + PC;
+            if (mine) {
+                const int kb = 3 * (pidx - p0);
 #pragma unroll
-                for (int b2 = 0; b2 < 6; ++b2) {
-                    const double wb0 = wj[3 * b2], wb1 = wj[3 * b2 + 1], wb2 = wj[3 * b2 + 2];
+                for (int a = 0; a < 6; ++a) {
+                    const int row = 6 * lc + a;
+                    const double w0 = W[a][0], w1 = W[a][1], w2 = W[a][2];
+                    Wt[(kb + 0) * LD + row] = w0; Wt[(kb + 1) * LD + row] = w1; Wt[(kb + 2) * LD + row] = w2;
+                    Yt[(kb + 0) * LD + row] = w0 * v0 + w1 * v1 + w2 * v2;
+                    Yt[(kb + 1) * LD + row] = w0 * v1 + w1 * v3 + w2 * v4;
+                    Yt[(kb + 2) * LD + row] = w0 * v2 + w1 * v4 + w2 * v5;
+                }
+            }
+            __syncthreads();
+            const int ksteps = (3 * min(PC, npts - p0) + 3) >> 2;
+            // k outer, the wave's 9 tiles inner: nine independent accumulator chains
+            // keep the matrix pipe busy (a single chain waits for every result)
+            if (ton[8]) {
+                // full tile: all nine products unconditionally, operands fetched first so
+                // that the LDS latency overlaps the matrix pipe (rows past the tile's
+                // cameras are zero-filled and contribute nothing)
+                for (int kk = 0; kk < ksteps; ++kk) {
+                    const int krow = 4 * kk + (lane >> 4);
+                    const double *yr = Yt + krow * LD + (lane & 15);
+                    const double *wr = Wt + krow * LD + (lane & 15);
+                    double ya[9], wa[9];
 #pragma unroll
-                    for (int a = 0; a < 6; ++a) {
-                        double val = -(Y[a][0] * wb0 + Y[a][1] * wb1 + Y[a][2] * wb2);
-                        if (jj == t) {
-                            if (b2 < a) continue;
-                            val += E[0][a] * E[0][b2] + E[1][a] * E[1][b2];
-                        }
-                        atomic_add_f64(blk + a * 6 + b2, val);
-                    }
+                    for (int s = 0; s < 9; ++s) { ya[s] = yr[yoff[s]]; wa[s] = wr[woff[s]]; }
+#pragma unroll
+                    for (int s = 0; s < 9; ++s)
+                        acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[s], wa[s], acc[s], 0, 0, 0);
+                }
+            } else {
+                for (int kk = 0; kk < ksteps; ++kk) {
+                    const int krow = 4 * kk + (lane >> 4);
+                    const double *yr = Yt + krow * LD + (lane & 15);
+                    const double *wr = Wt + krow * LD + (lane & 15);
+#pragma unroll
+                    for (int s = 0; s < 9; ++s)
+                        if (ton[s])                  // wave-uniform (scalar branch)
+                            acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(yr[yoff[s]], wr[woff[s]], acc[s], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+            if (mine) {                              // restore the zero fill
+                const int kb = 3 * (pidx - p0);
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    const int row = 6 * lc + a;
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) { Wt[(kb + e) * LD + row] = 0.0; Yt[(kb + e) * LD + row] = 0.0; }
+                }
+            }
+            __syncthreads();
+        }
+        __syncthreads();       // red / npts_sh are reused by the next batch
+    }
+    // ---- flush the tile to HBM:  S -= sum_p Y W'  (lower triangle), S += E'E
+#pragma unroll
+    for (int s = 0; s < 9; ++s) {
+        if (ton[s]) {
+            const int lcol = woff[s] + (lane & 15);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int lrow = yoff[s] + (lane >> 4) + 4 * e;
+                const double v = acc[s][e];
+                if (lrow < nrows && lcol <= lrow && v != 0.0) {
+                    const int64_t row = 6 * (int64_t)d.tile_cams[c0 + lrow / 6] + lrow % 6;
+                    const int64_t col = 6 * (int64_t)d.tile_cams[c0 + lcol / 6] + lcol % 6;
+                    atomic_add_f64(S + col * d.ldS + row, -v);
                 }
             }
         }
-        __syncthreads();       // Wl / red are reused by the next batch
     }
-    // ---- flush the tile to HBM
-    for (int i = t; i < nblk * 36; i += BT) {
-        const int blkid = i / 36, e = i - blkid * 36;
-        // blkid = lj*(lj+1)/2 + li  ->  lj, li
-        int lj = (int)((sqrt(8.0 * blkid + 1.0) - 1.0) * 0.5);
-        while ((lj + 1) * (lj + 2) / 2 <= blkid) ++lj;
-        while (lj * (lj + 1) / 2 > blkid) --lj;
-        const int li = blkid - lj * (lj + 1) / 2;
-        if (lj >= ncam) continue;
-        const double v = St[i];
-        if (v == 0.0) continue;
+    for (int i = t; i < ncam * 36; i += BT) {
+        const int lcam = i / 36, e = i - lcam * 36;
         const int a = e / 6, b2 = e - a * 6;
-        const int64_t col = 6 * (int64_t)d.tile_cams[c0 + li] + a;
-        const int64_t row = 6 * (int64_t)d.tile_cams[c0 + lj] + b2;
-        atomic_add_f64(S + col * d.ldS + row, v);
+        if (b2 < a) continue;
+        const int64_t cb = 6 * (int64_t)d.tile_cams[c0 + lcam];
+        atomic_add_f64(S + (cb + a) * d.ldS + (cb + b2), Ud[i]);
     }
     for (int i = t; i < 6 * ncam; i += BT) {
         const int64_t col = 6 * (int64_t)d.tile_cams[c0 + i / 6] + i % 6;
@@ -579,9 +667,9 @@ __global__ __launch_bounds__(256) void k_build_tile(DevProblem d, const double *
         atomic_add_f64(g_red + col, vt[6 * CM + i]);
         atomic_add_f64(diagU + col, vt[12 * CM + i]);
     }
-    double acc[1] = {rr};
-    block_sum<1>(acc, sh);
-    if (t == 0) partial[blockIdx.x] = acc[0];
+    double accr[1] = {rr};
+    block_sum<1>(accr, sh);
+    if (t == 0) partial[blockIdx.x] = accr[0];
     for (int off = 32; off > 0; off >>= 1) {
         pmin = fmin(pmin, __shfl_down(pmin, off, 64));
         pmax = fmax(pmax, __shfl_down(pmax, off, 64));

@@ -56,6 +56,7 @@ struct Plan {
     // tiles: runs of batches whose observations touch at most CMAX cameras; the
     // Schur complement of a tile is accumulated in LDS and flushed once
     std::vector<uint8_t> o_lc;                     // local camera index of every observation
+    std::vector<uint8_t> o_pidx;                   // ordinal of the observation's point inside its batch
     std::vector<int32_t> tile_batch;               // [ntiles+1] first batch of every tile
     std::vector<int32_t> tile_cam_start;           // [ntiles+1]
     std::vector<int32_t> tile_cams;                // global camera ids, ascending inside a tile
@@ -335,8 +336,8 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     P.BT = env_int("DBAT_HIP_BT", 256);
     if (P.BT != 128 && P.BT != 256) P.BT = 256;
     if ((size_t)P.BT * strideW * 8 + (size_t)P.BT * 18 * 8 > 150 * 1024) P.BT = 128;
-    P.CMAX = P.with_io ? 0 : env_int("DBAT_HIP_CMAX", 20);
-    if (P.CMAX < 0 || P.CMAX > 40) P.CMAX = 20;
+    P.CMAX = P.with_io ? 0 : env_int("DBAT_HIP_CMAX", 21);
+    if (P.CMAX < 0 || P.CMAX > 21) P.CMAX = 21;     // 6*CMAX <= 128 rows of the MFMA tile
     if (P.max_k > P.BT)
         return fail(P, "an object point has more observations than one batch holds (" +
                        std::to_string(P.max_k) + " > " + std::to_string(P.BT) + ")");
@@ -346,6 +347,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     for (int64_t i = P.pt_lo; i < P.pt_hi; ++i) nobs_shard += k_pt[P.porder[i]];
     P.o_cam.resize(nobs_shard); P.o_pt.resize(nobs_shard); P.o_uv.resize(2 * nobs_shard);
     P.o_seg.resize(nobs_shard); P.o_row.resize(nobs_shard); P.o_lc.assign(nobs_shard, 0);
+    P.o_pidx.assign(nobs_shard, 0);
     if (!P.uniform_w) P.o_w.resize(2 * nobs_shard);
     P.tile_batch.clear(); P.tile_cam_start.clear(); P.tile_cams.clear();
     P.tile_batch.push_back(0); P.tile_cam_start.push_back(0);
@@ -365,6 +367,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         tile_first_obs = end_obs;
     };
     int32_t tile_id = 0;
+    int pidx = 0;
     for (int64_t i = P.pt_lo; i < P.pt_hi; ++i) {
         const int32_t p = P.porder[i];
         const int k = k_pt[p];
@@ -381,19 +384,21 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
             }
         }
         if (pos - bstart + k > P.BT) { P.batch_start.push_back(pos); bstart = pos; }
+        if (pos == bstart) pidx = 0;
         const uint32_t seg = (uint32_t)(pos - bstart) | ((uint32_t)k << 16);
         for (int j = 0; j < k; ++j, ++pos) {
             const int64_t o = by_pt[pstart[p] + j];
             const int32_t c = pb.ip_cam[o];
             P.o_cam[pos] = c; P.o_pt[pos] = p;
             P.o_uv[2 * pos] = pb.ip_val[2 * o]; P.o_uv[2 * pos + 1] = pb.ip_val[2 * o + 1];
-            P.o_seg[pos] = seg; P.o_row[pos] = o;
+            P.o_seg[pos] = seg; P.o_row[pos] = o; P.o_pidx[pos] = (uint8_t)pidx;
             if (!P.uniform_w) {
                 P.o_w[2 * pos] = 1.0 / (pb.ip_std[2 * o] * P.px[2 * c]);
                 P.o_w[2 * pos + 1] = 1.0 / (pb.ip_std[2 * o + 1] * P.px[2 * c + 1]);
             }
             if (P.CMAX && stamp[c] != tile_id) { stamp[c] = tile_id; cur_cams.push_back(c); }
         }
+        ++pidx;
     }
     if (pos > bstart || P.batch_start.size() == 1) P.batch_start.push_back(pos);
     if (P.CMAX) {
