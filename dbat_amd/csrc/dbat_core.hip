@@ -653,6 +653,21 @@ int dbat_hip_plan(const dbat_hip_problem *prob, int64_t *n_params, int64_t *n_re
     API_CATCH
 }
 
+int dbat_hip_plan_point_owner(const dbat_hip_problem *prob, int32_t *owner) {
+    API_TRY
+    if (!prob || !owner) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
+    const int nr = std::max(1, prob->shard_count);
+    for (int r = 0; r < nr; ++r) {
+        dbat_hip_problem pb = *prob;
+        pb.shard_rank = r;
+        Plan P;
+        if (!build_plan(pb, P, false)) { g_err = P.err; return DBAT_HIP_EINVAL; }
+        for (int64_t i = P.pt_lo; i < P.pt_hi; ++i) owner[P.porder[i]] = r;
+    }
+    return DBAT_HIP_OK;
+    API_CATCH
+}
+
 int dbat_hip_plan_serialize(const dbat_hip_problem *prob, double *x0) {
     API_TRY
     if (!prob || !x0) { g_err = "null argument"; return DBAT_HIP_EINVAL; }

@@ -141,6 +141,11 @@ int  dbat_hip_plan(const dbat_hip_problem *prob, int64_t *n_params, int64_t *n_r
                    int64_t *n_io, int64_t *n_eo, int64_t *n_op,
                    int64_t *shard_pt_lo, int64_t *shard_pt_hi);
 
+/* Host-only: owner[p] = rank (0..prob->shard_count-1) whose shard holds object
+ * point p (contiguous ranges of the spatially sorted processing order,
+ * balanced by observation count).  prob->shard_rank is ignored. */
+int  dbat_hip_plan_point_owner(const dbat_hip_problem *prob, int32_t *owner /*[n_points]*/);
+
 /* Host-only x0 = serialize(s) straight from the problem description
  * (misc/serialize.m:14-18 over the indices of buildserialindices.m); x0 has
  * n_params entries (see dbat_hip_plan).  No GPU needed. */

@@ -290,3 +290,93 @@ def test_C1_full_size_properties(hip):
     assert np.abs(res.OP.val - truth['OP']).std() < 0.1
     ro, oko, ito, s0o, Eo = o.bundle(s, 'lmp')
     assert iters == ito and relerr(E.x, Eo.x) < 1e-7
+
+
+class _ThreadComm:
+    """Two shards on ONE GPU: each rank is a thread with its own handle; the
+    all-reduce callback exchanges buffers through the host.  Exercises the
+    core's N>1 path (sharded plan, reduce hooks, min/max exchange, final
+    gather) where only one device is available."""
+
+    def __init__(self, rank, world, shared):
+        self.rank, self.world_size, self.sh = rank, world, shared
+
+    def _reduce(self, arr):
+        sh = self.sh
+        sh['buf'][self.rank] = arr
+        sh['bar'].wait()
+        total = sum(sh['buf'][r] for r in range(self.world_size))
+        sh['bar'].wait()
+        return total
+
+    def allreduce_ptr(self, ptr, count, stream):
+        import torch
+        from dbat_amd.parallel import _DevMem
+        t = torch.as_tensor(_DevMem(ptr, count), device='cuda')
+        torch.cuda.synchronize()
+        total = self._reduce(t.cpu().numpy().copy())
+        t.copy_(torch.from_numpy(total))
+        torch.cuda.synchronize()
+        return 0
+
+    def allreduce_numpy(self, a):
+        return self._reduce(np.array(a, dtype=float, copy=True))
+
+
+@pytest.mark.parametrize('damping', ['gna', 'lm', 'lmp'])
+def test_two_shards_one_gpu_match_single(hip, damping):
+    import threading
+    from dbat_amd import bundle
+    s, truth = synth_struct('small', 'priors')
+    ref = bundle(s, damping)
+    shared = {'buf': [None, None], 'bar': threading.Barrier(2)}
+    out = [None, None]
+    err = []
+
+    def run(rank):
+        try:
+            out[rank] = bundle(s, damping, comm=_ThreadComm(rank, 2, shared))
+        except Exception as e:   # noqa: BLE001
+            err.append(e)
+            shared['bar'].abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    [t.start() for t in th]
+    [t.join(300) for t in th]
+    assert not err, err
+    for rank in range(2):
+        res, ok, iters, s0, E = out[rank]
+        assert ok == ref[1] and E.code == ref[4].code
+        assert relerr(E.x, ref[4].x) < 1e-8
+        assert abs(s0 - ref[3]) < 1e-9 * ref[3]
+        if damping != 'lm':
+            assert iters == ref[2]
+        assert relerr(res.post.res.IP, ref[0].post.res.IP) < 1e-6
+
+
+def test_rccl_allreduce_on_raw_device_pointer(hip):
+    """parallel.Comm.allreduce_ptr (the callback the core invokes) on a raw
+    device pointer and a non-default HIP stream, over the nccl (= RCCL)
+    backend with a one-rank group."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from dbat_amd.parallel import Comm
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29581')
+    if not dist.is_initialized():
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        comm = Comm()
+        x = torch.arange(1000, dtype=torch.float64, device='cuda')
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            x.mul_(2.0)
+        rc = comm.allreduce_ptr(x.data_ptr(), x.numel(), st.cuda_stream)
+        torch.cuda.synchronize()
+        assert rc == 0 and comm.n_collectives == 1
+        assert torch.equal(x.cpu(), torch.arange(1000, dtype=torch.float64) * 2)
+        a = comm.allreduce_numpy(np.arange(5.0))
+        assert np.array_equal(a, np.arange(5.0))
+    finally:
+        dist.destroy_process_group()
