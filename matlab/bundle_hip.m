@@ -1,0 +1,88 @@
+function [s,ok,iters,s0,E]=bundle_hip(s,varargin)
+%BUNDLE_HIP Drop-in for BUNDLE that runs the adjustment on an MI355X.
+%
+%   [S,OK,N,S0,E]=BUNDLE_HIP(S[,N][,DAMP][,'trace'][,TOL][,'absterm']
+%   [,'singulartest'|'nosingulartest']) takes the same arguments as
+%   BUNDLE and returns the same values.  The residual/Jacobian model
+%   (BROWN_EULER_CAM4), the normal equations and the damping loops of
+%   BUNDLE/LSA run in libdbat_hip.so via DBAT_HIP_MEX.
+
+% --- argument conventions of bundle.m:78-132
+maxIter=20; damping='gna'; singularTest=true; absTerm=false; convTol=1e-6;
+while ~isempty(varargin)
+    a=varargin{1}; varargin(1)=[];
+    if isnumeric(a) && isscalar(a)
+        if a==round(a), maxIter=a; else, convTol=a; end
+    elseif ischar(a)
+        switch lower(a)
+          case {'none','gm','gna','lm','lmp'}, damping=lower(a);
+          case 'trace' % printing only
+          case 'singulartest', singularTest=true;
+          case 'nosingulartest', singularTest=false;
+          case 'absterm', absTerm=true;
+          case {'pmdof','dofverb'}
+          otherwise, error('DBAT:bundle:badInput','Unknown damping');
+        end
+    elseif islogical(a)
+        if a, error('DBAT:bundle:badInput','chirality veto is undefined (bundle.m:169)'); end
+    else
+        error('DBAT:bundle:badInput','Unknown parameter');
+    end
+end
+% --- bundle.m:137-154
+s.prior.IO.use(~s.bundle.est.IO)=false;
+s.prior.EO.use(~s.bundle.est.EO)=false;
+s.prior.OP.use(~s.bundle.est.OP)=false;
+% --- flatten the struct (0-based indices, column-major, IP columns are
+% image-major with ascending OP, prob2dbatstruct.m:343-365)
+[pt,cam]=find(s.IP.vis);
+z=@(a)zeroifnan(a);
+P=struct('nImages',size(s.EO.val,2),'nOP',size(s.OP.val,2),'nIP',size(s.IP.val,2),...
+         'distModel',unique(s.IO.model.distModel),'nK',s.IO.model.nK,'nP',s.IO.model.nP,...
+         'ipCam',int32(cam-1),'ipPt',int32(pt-1),...
+         'ipVal',s.IP.val(:,full(s.IP.ix(s.IP.vis))),'ipStd',s.IP.std(:,full(s.IP.ix(s.IP.vis))),...
+         'IO',s.IO.val,'pxSize',s.IO.sensor.pxSize,'EO',s.EO.val(1:6,:),'OP',s.OP.val,...
+         'estIO',uint8(s.bundle.est.IO),'estEO',uint8(s.bundle.est.EO(1:6,:)),...
+         'estOP',uint8(s.bundle.est.OP),...
+         'IOblock',int32(s.IO.struct.block),'EOblock',int32(s.EO.struct.block(1:6,:)),...
+         'useIO',uint8(s.prior.IO.use),'priorIO',z(s.prior.IO.val),'stdIO',z(s.prior.IO.std),...
+         'useEO',uint8(s.prior.EO.use(1:6,:)),'priorEO',z(s.prior.EO.val(1:6,:)),...
+         'stdEO',z(s.prior.EO.std(1:6,:)),...
+         'useOP',uint8(s.prior.OP.use),'priorOP',z(s.prior.OP.val),'stdOP',z(s.prior.OP.std));
+if ~isscalar(P.distModel), error('Mixed lens distortion models not implemented.'); end
+dampNo=find(strcmp(damping,{'gm','gna','lm','lmp'}))-1;
+if strcmp(damping,'none'), dampNo=0; end
+opt=struct('damping',dampNo,'maxIter',maxIter,'convTol',convTol,'absTerm',absTerm,...
+           'singularTest',singularTest,'trace',true);
+[x,code,iters,s0,res,damp,aux,T,ru,rw,time]=dbat_hip_mex(P,opt);
+% --- result packaging, bundle.m:341-358,449-491
+if isempty(s.bundle.serial) || isempty(s.bundle.deserial), s=buildserialindices(s); end
+E=struct('maxIter',maxIter,'convTol',convTol,'absTerm',absTerm,'singularTest',singularTest,...
+         'chirality',false,'res',res,'trace',T,'time',time,'code',code,'usedIters',iters);
+switch damping
+  case {'none','gm'}, E.damping=struct('name','gm');
+  case 'gna', E.damping=struct('name','gna','alpha',damp,'mu',0.1,'alphaMin',1e-9);
+  case 'lm',  E.damping=struct('name','lm','lambda',damp,'lambda0',damp(1),'lambdaMin',damp(1));
+  case 'lmp'
+    rho=aux(1:maxIter+2); step=aux(maxIter+3:end);
+    E.damping=struct('name','lmp','delta',damp,'rho',rho(~isnan(rho)),...
+                     'delta0',norm(serialize(s)),'rhoBad',0.25,'rhoGood',0.75,...
+                     'step',step(~isnan(step)));
+end
+E.final=struct('unweighted',struct('r',ru),'weighted',struct('r',rw),'factorized',[]);
+ok=code==0;
+if ok, s=deserialize(s,x); end
+s.post.res.IP=nan(size(s.IP.val)); s.post.res.IO=nan(size(s.IO.val));
+s.post.res.EO=nan(size(s.EO.val)); s.post.res.OP=nan(size(s.OP.val));
+s.post.res.IP(:)=ru(s.post.res.ix.IP);
+ptCols=s.IP.ix(s.IP.vis);
+s.post.res.IP=s.post.res.IP./s.IO.sensor.pxSize(:,s.IP.cam(ptCols));
+s.post.res.IO(s.prior.IO.use)=ru(s.post.res.ix.IO);
+s.post.res.EO(s.prior.EO.use)=ru(s.post.res.ix.EO);
+s.post.res.OP(s.prior.OP.use)=ru(s.post.res.ix.OP);
+s.post.sigmas=s0*s.IP.sigmas;
+E.numObs=length(ru); E.numParams=length(x); E.redundancy=length(ru)-length(x);
+E.s0=s0; E.sigmas=s.post.sigmas;
+
+function a=zeroifnan(a)
+a(isnan(a))=0;

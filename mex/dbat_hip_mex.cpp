@@ -1,0 +1,110 @@
+// MEX gateway: MATLAB <-> include/dbat_hip.h.
+//
+// Built only where MATLAB's mex.h exists (not in this repo's CI image):
+//   mex -R2018a CXXFLAGS='$CXXFLAGS -std=c++17' -I../include dbat_hip_mex.cpp ...
+//       -L../dbat_amd -ldbat_hip
+// Conventions follow the reference's own MEX file code/test/postcov/icpc_mex.c
+// (:495-611): argument validation with mexErrMsgIdAndTxt("DBAT:<fn>:<id>"),
+// interleaved-complex API, a same-named .m stub that errors when the MEX file
+// is missing (code/test/postcov/icpc_mex.m:14).
+//
+//   [x,code,iters,sigma0,res,damp,aux,T,ru,rw,time] = dbat_hip_mex(P, opt)
+//
+// P   struct with the flattened DBAT struct fields built by bundle_hip.m
+// opt struct: damping (0..3), maxIter, convTol, absTerm, singularTest, trace
+#include <cstring>
+#include <vector>
+
+#include "mex.h"
+#include "dbat_hip.h"
+
+static const mxArray *field(const mxArray *s, const char *name) {
+    const mxArray *f = mxGetField(s, 0, name);
+    if (!f) mexErrMsgIdAndTxt("DBAT:dbat_hip_mex:badInput", "missing field %s", name);
+    return f;
+}
+static double scalar(const mxArray *s, const char *name) { return mxGetScalar(field(s, name)); }
+
+void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
+    if (nrhs != 2 || !mxIsStruct(prhs[0]) || !mxIsStruct(prhs[1]))
+        mexErrMsgIdAndTxt("DBAT:dbat_hip_mex:badInput", "usage: dbat_hip_mex(P, opt)");
+    const mxArray *P = prhs[0], *O = prhs[1];
+    dbat_hip_problem pb;
+    std::memset(&pb, 0, sizeof(pb));
+    pb.abi_version = DBAT_HIP_ABI_VERSION;
+    pb.n_images = (int32_t)scalar(P, "nImages");
+    pb.n_points = (int32_t)scalar(P, "nOP");
+    pb.n_obs = (int64_t)scalar(P, "nIP");
+    pb.dist_model = (int32_t)scalar(P, "distModel");
+    pb.nK = (int32_t)scalar(P, "nK");
+    pb.nP = (int32_t)scalar(P, "nP");
+    // int32 / uint8 arrays are prepared (0-based, column-major) by bundle_hip.m
+    pb.ip_cam = (const int32_t *)mxGetData(field(P, "ipCam"));
+    pb.ip_pt = (const int32_t *)mxGetData(field(P, "ipPt"));
+    pb.ip_val = mxGetDoubles(field(P, "ipVal"));
+    pb.ip_std = mxGetDoubles(field(P, "ipStd"));
+    pb.IO_val = mxGetDoubles(field(P, "IO"));
+    pb.px_size = mxGetDoubles(field(P, "pxSize"));
+    pb.EO_val = mxGetDoubles(field(P, "EO"));
+    pb.OP_val = mxGetDoubles(field(P, "OP"));
+    pb.est_IO = (const uint8_t *)mxGetData(field(P, "estIO"));
+    pb.est_EO = (const uint8_t *)mxGetData(field(P, "estEO"));
+    pb.est_OP = (const uint8_t *)mxGetData(field(P, "estOP"));
+    pb.IO_block = (const int32_t *)mxGetData(field(P, "IOblock"));
+    pb.EO_block = (const int32_t *)mxGetData(field(P, "EOblock"));
+    pb.prior_IO_use = (const uint8_t *)mxGetData(field(P, "useIO"));
+    pb.prior_IO_val = mxGetDoubles(field(P, "priorIO"));
+    pb.prior_IO_std = mxGetDoubles(field(P, "stdIO"));
+    pb.prior_EO_use = (const uint8_t *)mxGetData(field(P, "useEO"));
+    pb.prior_EO_val = mxGetDoubles(field(P, "priorEO"));
+    pb.prior_EO_std = mxGetDoubles(field(P, "stdEO"));
+    pb.prior_OP_use = (const uint8_t *)mxGetData(field(P, "useOP"));
+    pb.prior_OP_val = mxGetDoubles(field(P, "priorOP"));
+    pb.prior_OP_std = mxGetDoubles(field(P, "stdOP"));
+    pb.device = 0; pb.shard_rank = 0; pb.shard_count = 1;
+
+    dbat_hip_handle *h = nullptr;
+    if (dbat_hip_create(&pb, &h) != DBAT_HIP_OK)
+        mexErrMsgIdAndTxt("DBAT:bundle:badInput", "%s", dbat_hip_last_error());
+    dbat_hip_options opt;
+    dbat_hip_default_options((int32_t)scalar(O, "damping"), &opt);
+    opt.max_iter = (int32_t)scalar(O, "maxIter");
+    opt.conv_tol = scalar(O, "convTol");
+    opt.abs_term = (int32_t)scalar(O, "absTerm");
+    opt.singular_test = (int32_t)scalar(O, "singularTest");
+    opt.store_trace = (int32_t)scalar(O, "trace");
+    const int64_t n = dbat_hip_num_params(h), m = dbat_hip_num_residuals(h);
+    const int mi = opt.max_iter;
+    plhs[0] = mxCreateDoubleMatrix(n, 1, mxREAL);
+    double *x = mxGetDoubles(plhs[0]);
+    dbat_hip_serialize(h, x);
+    std::vector<double> res(mi + 3), damp(2 * mi + 4), aux(2 * mi + 4);
+    mxArray *T = mxCreateDoubleMatrix(opt.store_trace ? n : 0, opt.store_trace ? mi + 2 : 0, mxREAL);
+    dbat_hip_result r;
+    const int rc = dbat_hip_solve(h, &opt, x, &r, res.data(), damp.data(), aux.data(),
+                                  opt.store_trace ? mxGetDoubles(T) : nullptr);
+    if (rc != DBAT_HIP_OK) {
+        dbat_hip_destroy(h);
+        mexErrMsgIdAndTxt("DBAT:bundle:internal", "%s", dbat_hip_last_error());
+    }
+    auto vec = [](const double *p, int k) {
+        mxArray *a = mxCreateDoubleMatrix(1, k, mxREAL);
+        std::memcpy(mxGetDoubles(a), p, sizeof(double) * k);
+        return a;
+    };
+    if (nlhs > 1) plhs[1] = mxCreateDoubleScalar(r.code);
+    if (nlhs > 2) plhs[2] = mxCreateDoubleScalar(r.iters);
+    if (nlhs > 3) plhs[3] = mxCreateDoubleScalar(r.sigma0);
+    if (nlhs > 4) plhs[4] = vec(res.data(), r.n_res);
+    if (nlhs > 5) plhs[5] = vec(damp.data(), r.n_damp);
+    if (nlhs > 6) plhs[6] = vec(aux.data(), 2 * mi + 4);
+    if (nlhs > 7) { mxSetN(T, r.n_trace); plhs[7] = T; } else mxDestroyArray(T);
+    if (nlhs > 8) {
+        plhs[8] = mxCreateDoubleMatrix(m, 1, mxREAL);
+        mxArray *rw = mxCreateDoubleMatrix(m, 1, mxREAL);
+        if (r.code != -4) dbat_hip_final_residuals(h, mxGetDoubles(plhs[8]), mxGetDoubles(rw));
+        if (nlhs > 9) plhs[9] = rw; else mxDestroyArray(rw);
+    }
+    if (nlhs > 10) plhs[10] = mxCreateDoubleScalar(r.time_s);
+    dbat_hip_destroy(h);
+}
