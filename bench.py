@@ -84,8 +84,13 @@ def main():
         raise SystemExit('bench.py needs a GPU (the dbat_hip core has no CPU path)')
     torch.cuda.set_device(local)
     comm = None
-    if world > 1:
+    if world > 1 or os.environ.get('DBAT_BENCH_FORCE_COMM') == '1':
+        # one rank per GPU over RCCL (a forced one-rank group exercises the same code path)
         import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29555')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
         from dbat_amd.parallel import Comm
         comm = Comm()

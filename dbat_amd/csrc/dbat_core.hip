@@ -172,7 +172,7 @@ struct Core {
     void sync() { HIPCHK(hipStreamSynchronize(stream)); }
     void mark(int i) { if (timing) HIPCHK(hipEventRecord(kev[i], stream)); }
     void do_allreduce(double *buf, int64_t count) {
-        if (allreduce && P.nranks > 1) {
+        if (allreduce) {     // installed only by multi-rank drivers (a one-rank group exercises the same path)
             if (allreduce(allreduce_user, buf, count, (void *)stream) != 0) throw DeviceError{"all-reduce callback failed"};
         }
     }
@@ -326,7 +326,7 @@ struct Core {
         double mm[4];
         memcpy(mm, hmm, sizeof(mm));
         double pmin = std::min(mm[0], mm[2]), pmax = std::max(mm[1], mm[3]);
-        if (P.nranks > 1 && allreduce) {              // min/max over ranks through the sum-all-reduce
+        if (allreduce) {                              // min/max over ranks through the sum-all-reduce
             std::vector<double> slots((size_t)2 * P.nranks, 0.0);
             slots[2 * P.rank] = pmin; slots[2 * P.rank + 1] = pmax;
             HIPCHK(hipMemcpyAsync(mmx.p, slots.data(), slots.size() * 8, hipMemcpyHostToDevice, stream));
