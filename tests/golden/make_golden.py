@@ -4,6 +4,8 @@ GPU box has no /root/reference).
 
 Inputs copied verbatim (data files, not source):
   data/dbat/pmexports/camcal-pmexport.txt, data/dbat/ref/camcal-fixed.txt
+  data/script/romabundledemo/measurements/markpts.txt (xz-compressed),
+  data/script/romabundledemo/prior/initial_eo.txt
 Expected values parsed from the reference's committed reports:
   data/dbat/dbatexports/camcal-dbatreport{,-model2..5}.txt
 """
@@ -43,14 +45,15 @@ def parse_report(path):
             io[key] = float(m.group(1))
     out['IO_report'] = io   # report sign convention: py, K, P flipped vs IO.val
     photos = []
-    for m in re.finditer(
-            r'Photo \d+: \S+\s+Omega:\s+Value:\s+([-\d.]+) deg\s+Deviation:.*\s+'
-            r'Phi:\s+Value:\s+([-\d.]+) deg\s+Deviation:.*\s+'
-            r'Kappa:\s+Value:\s+([-\d.]+) deg\s+Deviation:.*\s+'
-            r'Xc:\s+Value:\s+([-\d.]+) ou\s+Deviation:.*\s+'
-            r'Yc:\s+Value:\s+([-\d.]+) ou\s+Deviation:.*\s+'
-            r'Zc:\s+Value:\s+([-\d.]+) ou', txt):
-        photos.append([float(v) for v in m.groups()])
+    blocks = re.split(r'Photo (\d+): \S+', txt)
+    for i in range(1, len(blocks), 2):
+        b = blocks[i + 1]
+        vals = []
+        for key in ('Omega', 'Phi', 'Kappa', 'Xc', 'Yc', 'Zc'):
+            m = re.search(key + r':\s+Value:\s+([-\d.]+)', b)
+            vals.append(float(m.group(1)))
+        assert int(blocks[i]) == len(photos) + 1
+        photos.append(vals)
     out['EO_report_deg'] = photos   # omega, phi, kappa [deg], Xc, Yc, Zc
     return out
 
@@ -67,6 +70,37 @@ def main():
     with open(os.path.join(HERE, 'camcal_expected.json'), 'w') as fh:
         json.dump(exp, fh, indent=1)
     print({k: (v['sigma0'], len(v['EO_report_deg'])) for k, v in exp.items()})
+    roma()
+
+
+def roma():
+    """Script inputs of data/script/romabundledemo (60 images, 26 321 OP,
+    90 561 image points) and the known answers of its committed result."""
+    import lzma
+    R = '/root/reference/data/script/romabundledemo'
+    with open(os.path.join(R, 'measurements/markpts.txt'), 'rb') as fi, \
+            lzma.open(os.path.join(HERE, 'roma-markpts.txt.xz'), 'wb', preset=9) as fo:
+        fo.write(fi.read())
+    shutil.copy(os.path.join(R, 'prior/initial_eo.txt'), os.path.join(HERE, 'roma-initial_eo.txt'))
+    cam_in = open(os.path.join(R, 'cameras/EOS5DMarkII.xml')).read()
+    cam_out = open(os.path.join(R, 'result/EOS5DMarkII.xml')).read()
+    tag = lambda txt, t: re.search(r'<%s>([^<]*)</%s>' % (t, t), txt).group(1)
+    nums = lambda v: [float(x) for x in v.split(',')]
+    rep = parse_report(os.path.join(R, 'result/report.txt'))
+    rep['firstError'] = float(re.search(r'First error:\s+([-\d.eE+]+)',
+                                        open(os.path.join(R, 'result/report.txt')).read()).group(1))
+    exp = {
+        'camera_in': {'image': nums(tag(cam_in, 'image')), 'sensor_height': 24.0,
+                      'cc': float(tag(cam_in, 'cc')), 'pp': nums(tag(cam_in, 'pp')),
+                      'K': nums(tag(cam_in, 'K')), 'P': nums(tag(cam_in, 'P')),
+                      'model': int(tag(cam_in, 'model'))},
+        'camera_out': {'cc': float(tag(cam_out, 'cc')), 'pp': nums(tag(cam_out, 'pp')),
+                       'K': nums(tag(cam_out, 'K')), 'sensor': nums(tag(cam_out, 'sensor'))},
+        'report': rep,
+    }
+    with open(os.path.join(HERE, 'roma_expected.json'), 'w') as fh:
+        json.dump(exp, fh, indent=1)
+    print('roma', rep['sigma0'], rep['numParams'], rep['iterations'], rep['firstError'], rep['lastError'])
 
 
 if __name__ == '__main__':

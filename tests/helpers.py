@@ -106,3 +106,47 @@ def relerr(a, b):
     a, b = np.asarray(a, float), np.asarray(b, float)
     d = np.linalg.norm(b.ravel())
     return np.linalg.norm((a - b).ravel()) / (d if d > 0 else 1.0)
+
+
+def roma_struct():
+    """data/script/romabundledemo/romabundledemo.xml: loaded camera and EO,
+    OP by forward intersection, estimate cc, pp, K1, K2 (no aspect, skew, P,
+    K3), datum by dependency on camera 1."""
+    from dbat_amd import loadtables as T
+    from dbat_amd.dbatstruct import seteoest_depend
+    exp = roma_expected()
+    ci = exp['camera_in']
+    eo = T.load_table(os.path.join(GOLDEN, 'roma-initial_eo.txt'))
+    mk = T.load_table(os.path.join(GOLDEN, 'roma-markpts.txt.xz'))
+    h = ci['sensor_height']
+    sensor = (ci['image'][0] * h / ci['image'][1], h)          # sensor 'auto,24', aspect 1
+    io = T.camera_io(ci['cc'], ci['pp'], ci['K'], ci['P'])
+    s = T.struct_from_tables(io, sensor, ci['image'], eo, mk, 'im,id,x,y', 1.0, distModel=ci['model'])
+    s = T.forwintersect(s)
+    s.bundle.est.IO[[0, 1, 2, 5, 6]] = True
+    return seteoest_depend(s, 0)
+
+
+def roma_expected():
+    with open(os.path.join(GOLDEN, 'roma_expected.json')) as fh:
+        return json.load(fh)
+
+
+def check_roma_against_result(res, s0, E, iters, exp):
+    rep, cam = exp['report'], exp['camera_out']
+    assert E.numParams == rep['numParams'] and E.numObs == rep['numObs']
+    assert E.redundancy == rep['redundancy'] and iters == rep['iterations']
+    assert abs(s0 - rep['sigma0']) < 1.01e-6
+    assert abs(E.res[0] - rep['firstError']) < 0.0051 * 1.01       # printed with 6 significant digits
+    assert abs(E.res[-1] - rep['lastError']) < 0.00051 * 1.01
+    io = res.IO.val[:, 0]
+    # result/EOS5DMarkII.xml is written with %.18g; the reference stops at convTol=1e-6
+    assert abs(io[0] - cam['cc']) < 1e-7 * cam['cc']
+    assert abs(io[1] - cam['pp'][0]) < 1e-7 * cam['pp'][0]
+    assert abs(-io[2] - cam['pp'][1]) < 1e-7 * cam['pp'][1]
+    assert abs(-io[5] - cam['K'][0]) < 1e-6 * abs(cam['K'][0])
+    assert abs(-io[6] - cam['K'][1]) < 1e-6 * abs(cam['K'][1])
+    eo = np.array(rep['EO_report_deg'])
+    dang = (np.rad2deg(res.EO.val[3:6]).T - eo[:, :3] + 180.0) % 360.0 - 180.0
+    assert np.abs(dang).max() < 1.01e-6
+    assert np.abs(res.EO.val[:3].T - eo[:, 3:]).max() < 1.01e-6

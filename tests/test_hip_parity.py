@@ -16,7 +16,7 @@ import scipy.sparse as sp
 
 import dbat_oracle as o
 from helpers import (camcal_struct, camcal_expected, check_camcal_against_report, synth_struct,
-                     relerr)
+                     relerr, roma_struct, roma_expected, check_roma_against_result)
 
 pytestmark = pytest.mark.gpu
 
@@ -217,6 +217,21 @@ def test_synthetic_bundle_parity(hip, variant, damping):
         if m.any():
             assert relerr(a[m], b[m]) < 1e-6
     assert E.numParams == Eo.numParams and E.numObs == Eo.numObs and E.redundancy == Eo.redundancy
+
+
+def test_roma_script_known_answer_hip(hip):
+    """The reference's roma script result (79 321 unknowns, real data, 5 IO
+    estimated) reproduced by bundle() on the GPU: first/last error, iteration
+    count, sigma0, camera and EO values of data/script/romabundledemo/result."""
+    from dbat_amd import bundle
+    s = roma_struct()
+    res, ok, iters, s0, E = bundle(s, 'gna')
+    assert ok and E.code == 0
+    check_roma_against_result(res, s0, E, iters, roma_expected())
+    for damping in ('lm', 'lmp'):
+        r2, ok2, it2, s02, E2 = bundle(s, damping, store_trace=False)
+        assert ok2 and abs(s02 - s0) < 1e-8 * s0
+        assert relerr(E2.x, E.x) < 1e-7
 
 
 def test_small_scene_all_dampings(hip):

@@ -5,7 +5,8 @@ import numpy as np
 import pytest
 
 import dbat_oracle as o
-from helpers import camcal_struct, camcal_expected, check_camcal_against_report
+from helpers import (camcal_struct, camcal_expected, check_camcal_against_report, roma_struct,
+                     roma_expected, check_roma_against_result)
 
 
 @pytest.mark.parametrize('model', [2, 3, 4, 5])
@@ -15,6 +16,15 @@ def test_camcal_known_answer_gna(model):
     assert ok and E.code == 0
     check_camcal_against_report(res, s0, E, exp)
     assert abs(E.res[-1] - exp['lastError']) < 5e-4 * 1.01
+
+
+def test_roma_script_known_answer():
+    """data/script/romabundledemo: 60 images, 26 321 points, 90 561 image points,
+    5 estimated IO; first/last error, iteration count, sigma0, camera and all
+    EO values of the committed result (result/report.txt, result/EOS5DMarkII.xml)."""
+    res, ok, iters, s0, E = o.bundle(roma_struct(), 'gna')
+    assert ok and E.code == 0
+    check_roma_against_result(res, s0, E, iters, roma_expected())
 
 
 @pytest.mark.parametrize('damping', ['lm', 'lmp', 'gm'])
