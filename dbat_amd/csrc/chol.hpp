@@ -27,6 +27,9 @@
 #include <rocblas/rocblas.h>
 #include <stdint.h>
 
+#include <algorithm>
+#include <vector>
+
 namespace dbat {
 
 constexpr int CHOL_NB = 64;     // inner panel width
@@ -132,13 +135,26 @@ __device__ __forceinline__ void mfma_tile64(const double *Pm, const double *Qm, 
 
 // X = A21 * (L11^-1)' for 64 rows per workgroup (the right-hand-side row
 // included):  X(r, c) = sum_m A21(r, m) Linv(c, m).
+// Row tiles: the rows below a panel that can hold non-zeros are the BAND rows
+// [r_begin, band_end) -- the envelope of the reduced system, see CholEnvelope --
+// followed by the dense TAIL rows [tail_begin, nrows_total) (IO unknowns and
+// the right-hand-side row).  Tile t < nband is a band tile.
+__device__ __forceinline__ void row_tile(int t, int nband, int r_begin, int band_end, int tail_begin,
+                                         int nrows_total, int64_t &r0, int &rlimit) {
+    if (t < nband) { r0 = (int64_t)r_begin + 64 * (int64_t)t; rlimit = band_end; }
+    else { r0 = (int64_t)tail_begin + 64 * (int64_t)(t - nband); rlimit = nrows_total; }
+}
+
 __global__ __launch_bounds__(256) void k_trsm64(double *__restrict__ A, int64_t lda, int nrows_total, int j0,
-                                                const double *__restrict__ Linv) {
+                                                const double *__restrict__ Linv, int nband, int band_end,
+                                                int tail_begin) {
     constexpr int NB = 64, LD = 65;
     __shared__ double Pm[NB * LD];                      // Pm[m][c] = Linv(c, m)
     __shared__ double Qm[NB * LD];                      // Qm[m][r] = A21(r, m)
     const int t = threadIdx.x, tx = t & 63, ty = t >> 6;
-    const int64_t r0 = (int64_t)j0 + NB + (int64_t)blockIdx.x * 64;
+    int64_t r0; int rlimit;
+    row_tile(blockIdx.x, nband, j0 + NB, band_end, tail_begin, nrows_total, r0, rlimit);
+    nrows_total = rlimit;
     const bool ok = r0 + tx < nrows_total;
     double *rowp = A + (int64_t)j0 * lda + r0 + tx;
 #pragma unroll 4
@@ -166,17 +182,25 @@ __global__ __launch_bounds__(256) void k_trsm64(double *__restrict__ A, int64_t 
 //   A(r, cj + c) -= sum_m X(r, m) X(cj + c, m),   X = A[:, j0:j0+64]
 // gridDim.y indexes the column blocks to the right of the panel inside the
 // outer block; only rows r >= cj are touched.
-__global__ __launch_bounds__(256) void k_update64(double *__restrict__ A, int64_t lda, int nrows_total, int j0) {
+__global__ __launch_bounds__(256) void k_update64(double *__restrict__ A, int64_t lda, int nrows_total, int j0,
+                                                  int band_end, int tail_begin) {
     constexpr int NB = 64, LD = 65;
     __shared__ double Pm[NB * LD];                      // Pm[m][c] = X(cj + c, m)
     __shared__ double Qm[NB * LD];                      // Qm[m][r] = X(r0 + r, m)
     const int t = threadIdx.x, tx = t & 63, ty = t >> 6;
     const int cb = blockIdx.y;
     const int64_t cj = (int64_t)j0 + NB * (cb + 1);
-    const int64_t r0 = cj + (int64_t)blockIdx.x * 64;
+    const int ntot = nrows_total;
+    // rows of this column block: band [cj, band_end) then tail [max(tail_begin,cj), ntot)
+    const int bend = band_end > cj ? band_end : (int)cj;
+    const int nband = (bend - (int)cj + 63) / 64;
+    const int tb = tail_begin > cj ? tail_begin : (int)cj;
+    int64_t r0; int rlimit;
+    row_tile(blockIdx.x, nband, (int)cj, bend, tb > bend ? tb : bend, ntot, r0, rlimit);
+    nrows_total = rlimit;
     if (r0 >= nrows_total) return;
     const bool ok = r0 + tx < nrows_total;
-    const bool okc = cj + tx < nrows_total;
+    const bool okc = cj + tx < ntot;
     const double *Xc = A + (int64_t)j0 * lda + cj + tx;
     const double *Xr = A + (int64_t)j0 * lda + r0 + tx;
 #pragma unroll 4
@@ -199,6 +223,45 @@ __global__ __launch_bounds__(256) void k_update64(double *__restrict__ A, int64_
     }
 }
 
+// Left-looking update of the dense tail rows (IO unknowns, right-hand side) for
+// one outer block column:  C(tail+r, J+c) -= sum_{k<J} L(tail+r, k) L(J+c, k).
+// A skinny product (<= 64 rows per z-slice, <= 256 columns, k = J): workgroup
+// (x = 64-column tile, y = 128-wide k chunk, z = 64-row tile) runs two
+// 64x64x64 MFMA tiles and adds its piece with f64 atomics.
+__global__ __launch_bounds__(256) void k_tail_gemm(double *__restrict__ A, int64_t lda, int J, int ob,
+                                                   int tail_begin, int nrows_total) {
+    constexpr int NB = 64, LD = 65;
+    __shared__ double Pm[NB * LD];                      // Pm[m][c] = L(J + 64*ct + c, k0 + m)
+    __shared__ double Qm[NB * LD];                      // Qm[m][r] = L(tail_begin + 64*rt + r, k0 + m)
+    const int t = threadIdx.x, tx = t & 63, ty = t >> 6;
+    const int ct = blockIdx.x, rt = blockIdx.z;
+    const int64_t crow = (int64_t)J + 64 * ct + tx;     // row of L that belongs to column J+64ct+tx of C
+    const int64_t rrow = (int64_t)tail_begin + 64 * rt + tx;
+    const bool okc = 64 * ct + tx < ob, okr = rrow < nrows_total;
+    chol_d4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int k0 = blockIdx.y * 128; k0 < min(J, (int)(blockIdx.y + 1) * 128); k0 += 64) {
+        __syncthreads();
+#pragma unroll 4
+        for (int mm = ty; mm < NB; mm += 4) {
+            const bool okk = k0 + mm < J;
+            Pm[mm * LD + tx] = (okc && okk) ? A[(int64_t)(k0 + mm) * lda + crow] : 0.0;
+            Qm[mm * LD + tx] = (okr && okk) ? A[(int64_t)(k0 + mm) * lda + rrow] : 0.0;
+        }
+        __syncthreads();
+        mfma_tile64<LD>(Pm, Qm, ty, tx, acc);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t r = (int64_t)tail_begin + 64 * rt + 16 * q + (tx & 15);
+        if (r < nrows_total)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 64 * ct + 16 * ty + (tx >> 4) + 4 * e;
+                if (c < ob) unsafeAtomicAdd(A + (int64_t)(J + c) * lda + r, -acc[q][e]);
+            }
+    }
+}
+
 // Backward substitution L' q = y, one launch per 64-panel from the last to the
 // first.  y (n entries, work vector) holds the right-hand side already reduced
 // by the panels after j0; the solved panel goes to qout.  Every workgroup
@@ -207,7 +270,7 @@ __global__ __launch_bounds__(256) void k_update64(double *__restrict__ A, int64_
 //   y[0:j0] -= L[j0:j0+nb, 0:j0]' q_j.
 __global__ __launch_bounds__(256) void k_backsolve(const double *__restrict__ A, int64_t lda, int n, int j0,
                                                    const double *__restrict__ Linv,
-                                                   double *__restrict__ y, double *__restrict__ qout) {
+                                                   double *__restrict__ y, double *__restrict__ qout, int c_begin) {
     constexpr int NB = 64;
     __shared__ double q[NB];
     __shared__ double part[4][NB];
@@ -230,7 +293,7 @@ __global__ __launch_bounds__(256) void k_backsolve(const double *__restrict__ A,
         if (blockIdx.x == 0 && t < nb) qout[j0 + t] = s;
     }
     __syncthreads();
-    const int c = blockIdx.x * 256 + t;
+    const int c = c_begin + blockIdx.x * 256 + t;       // columns left of the panel's envelope hold zeros
     if (c < j0) {
         const double *col = A + (int64_t)c * lda + j0;
         double v[NB];
@@ -243,6 +306,37 @@ __global__ __launch_bounds__(256) void k_backsolve(const double *__restrict__ A,
     }
 }
 
+// Envelope (profile) of the reduced system.  Row r of S (and of its Cholesky
+// factor: no fill outside the envelope) has its first non-zero in column
+// rowfirst[r]; rows >= tail0 are dense (IO unknowns, right-hand side).  For
+// bundle adjustment rowfirst comes from the camera co-visibility graph: camera
+// c only couples to cameras that share an object point with it.  With image
+// sequences / flight strips in acquisition order the band is narrow and the
+// block-column updates shrink from (n-J) x J to band x band products; a fully
+// connected network degenerates to the dense case (band_end = tail0).
+struct CholEnvelope {
+    int n = 0, tail0 = 0;
+    std::vector<int> rowfirst;      // [n]
+    std::vector<int> band_end;      // per 64-column panel jb: rows [.., band_end) reach into columns <= 64*jb+63
+    std::vector<int> panel_first;   // per 64-row panel: first non-zero column of any of its rows
+    void build(int n_, int tail0_, const std::vector<int> &first) {
+        n = n_; tail0 = tail0_ < n_ ? tail0_ : n_; rowfirst = first;
+        const int nblk = (n + CHOL_NB - 1) / CHOL_NB;
+        std::vector<int> reach(nblk, 0);
+        for (int r = 0; r < tail0; ++r) { const int b = rowfirst[r] / CHOL_NB; if (r + 1 > reach[b]) reach[b] = r + 1; }
+        band_end.assign(nblk, 0);
+        int m = 0;
+        for (int b = 0; b < nblk; ++b) { if (reach[b] > m) m = reach[b]; band_end[b] = m; }
+        panel_first.assign(nblk, 0);
+        for (int b = 0; b < nblk; ++b) {
+            int f = n;
+            for (int r = b * CHOL_NB; r < (b + 1) * CHOL_NB && r < n; ++r) f = std::min(f, r < tail0 ? rowfirst[r] : 0);
+            panel_first[b] = f;
+        }
+    }
+    void build_dense(int n_) { std::vector<int> f(n_, 0); build(n_, n_, f); }
+};
+
 struct BlockChol {
     // linv_work: ceil(n/NB) * NB*NB doubles (inverse factors of the diagonal blocks)
     static size_t linv_doubles(int n) { return (size_t)((n + CHOL_NB - 1) / CHOL_NB) * CHOL_NB * CHOL_NB; }
@@ -251,18 +345,46 @@ struct BlockChol {
     // columns allocated) and solve A q = b where b' sits in row n of A.
     // q -> q_out (n entries).  info_dev: LAPACK-style failure index (0 = ok).
     static void solve(rocblas_handle blas, hipStream_t stream, double *A, int64_t lda, int n,
-                      double *q_out, double *y_work, double *linv_work, int *info_dev) {
+                      double *q_out, double *y_work, double *linv_work, int *info_dev,
+                      const CholEnvelope &env) {
         constexpr int NB = CHOL_NB, OB = CHOL_OB;
         (void)hipMemsetAsync(info_dev, 0, sizeof(int), stream);
         const double one = 1.0, mone = -1.0;
         const int ntot = n + 1;                         // matrix rows + the right-hand-side row
+        const int nblk = (n + NB - 1) / NB;
         for (int J = 0; J < n; J += OB) {
             const int ob = n - J < OB ? n - J : OB;
             if (J > 0) {
-                // left-looking update of the block column with everything factored so far
-                rocblas_dgemm(blas, rocblas_operation_none, rocblas_operation_transpose, ntot - J, ob, J, &mone,
-                              A + J, (rocblas_int)lda, A + J, (rocblas_int)lda, &one,
-                              A + (int64_t)J * lda + J, (rocblas_int)lda);
+                // left-looking update of the block column with everything factored so far,
+                // restricted to the envelope: band rows x the columns they can reach, then
+                // the dense tail rows over all columns
+                const int jb_last = std::min(nblk - 1, (J + ob - 1) / NB);
+                const int tail_begin = std::max(env.tail0, J);
+                const int bend = std::min(std::max(env.band_end[jb_last], J), tail_begin);
+                int kmin = J;
+                for (int r = J; r < bend; ++r) kmin = std::min(kmin, env.rowfirst[r]);
+                kmin = (kmin / NB) * NB;
+                const int ntail = ntot - tail_begin;
+                if (bend == tail_begin && kmin == 0 && bend > J) {
+                    // dense case: band and tail are one contiguous row range over all columns
+                    rocblas_dgemm(blas, rocblas_operation_none, rocblas_operation_transpose, ntot - J, ob, J, &mone,
+                                  A + J, (rocblas_int)lda, A + J, (rocblas_int)lda, &one,
+                                  A + (int64_t)J * lda + J, (rocblas_int)lda);
+                } else {
+                    if (bend > J && kmin < J)
+                        rocblas_dgemm(blas, rocblas_operation_none, rocblas_operation_transpose, bend - J, ob, J - kmin,
+                                      &mone, A + (int64_t)kmin * lda + J, (rocblas_int)lda,
+                                      A + (int64_t)kmin * lda + J, (rocblas_int)lda, &one,
+                                      A + (int64_t)J * lda + J, (rocblas_int)lda);
+                    if (ntail > 256) {
+                        rocblas_dgemm(blas, rocblas_operation_none, rocblas_operation_transpose, ntail, ob, J,
+                                      &mone, A + tail_begin, (rocblas_int)lda, A + J, (rocblas_int)lda, &one,
+                                      A + (int64_t)J * lda + tail_begin, (rocblas_int)lda);
+                    } else if (ntail > 0) {
+                        hipLaunchKernelGGL(k_tail_gemm, dim3((ob + 63) / 64, (J + 127) / 128, (ntail + 63) / 64),
+                                           dim3(256), 0, stream, A, lda, J, ob, tail_begin, ntot);
+                    }
+                }
             }
             for (int j0 = J; j0 < J + ob; j0 += NB) {
                 double *Linv = linv_work + (size_t)(j0 / NB) * NB * NB;
@@ -271,10 +393,17 @@ struct BlockChol {
                 const int below = ntot - (j0 + nb);
                 if (below <= 0) break;
                 if (nb == NB) {
-                    hipLaunchKernelGGL(k_trsm64, dim3((below + 63) / 64), dim3(256), 0, stream, A, lda, ntot, j0, Linv);
+                    const int r_begin = j0 + NB;
+                    const int tail_begin = std::max(env.tail0, r_begin);
+                    const int bend = std::min(std::max(env.band_end[j0 / NB], r_begin), tail_begin);
+                    const int nband = (bend - r_begin + 63) / 64;
+                    const int ntail = (ntot - tail_begin + 63) / 64;
+                    hipLaunchKernelGGL(k_trsm64, dim3(nband + ntail), dim3(256), 0, stream, A, lda, ntot, j0, Linv,
+                                       nband, bend, tail_begin);
                     const int ncb = (J + ob - (j0 + NB) + NB - 1) / NB;   // column blocks left in this outer block
                     if (ncb > 0)
-                        hipLaunchKernelGGL(k_update64, dim3((below + 63) / 64, ncb), dim3(256), 0, stream, A, lda, ntot, j0);
+                        hipLaunchKernelGGL(k_update64, dim3(nband + ntail, ncb), dim3(256), 0, stream, A, lda, ntot, j0,
+                                           bend, tail_begin);
                 } else {
                     // ragged last panel (nb < 64): it is the last one, only the rhs row is below
                     rocblas_dtrsm(blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_transpose,
@@ -288,9 +417,10 @@ struct BlockChol {
                                hipMemcpyDeviceToDevice, stream);
         const int last = ((n - 1) / NB) * NB;
         for (int j0 = last; j0 >= 0; j0 -= NB) {
-            const int grid = j0 > 0 ? (j0 + 255) / 256 : 1;
+            const int c_begin = std::min(j0, (env.panel_first[j0 / NB] / 256) * 256);
+            const int grid = j0 > c_begin ? (j0 - c_begin + 255) / 256 : 1;
             hipLaunchKernelGGL(k_backsolve, dim3(grid), dim3(256), 0, stream, A, lda, n, j0,
-                               linv_work + (size_t)(j0 / NB) * NB * NB, y_work, q_out);
+                               linv_work + (size_t)(j0 / NB) * NB * NB, y_work, q_out, c_begin);
         }
     }
 };

@@ -12,6 +12,8 @@
 int main(int argc, char **argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 6000;
     const int reps = argc > 2 ? atoi(argv[2]) : 5;
+    const int band = argc > 3 ? atoi(argv[3]) : 0;      // >0: banded test matrix with this half-bandwidth and a dense tail
+    const int tail = argc > 4 ? atoi(argv[4]) : 0;
     const int64_t lda = n + 8 - (n % 8 == 0 ? 0 : n % 8) + 8;   // >= n+1, multiple of 8
     rocblas_handle h; rocblas_create_handle(&h);
     hipStream_t st; CK(hipStreamCreate(&st)); rocblas_set_stream(h, st);
@@ -31,6 +33,17 @@ int main(int argc, char **argv) {
     std::vector<double> A((size_t)lda * (n + 1));
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(A.data(), dA0, A.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<int> rowfirst(n, 0);
+    const int tail0 = n - tail;
+    if (band > 0) {
+        // keep only |i-j| <= band (rounded to 6x6 blocks) outside the dense tail rows
+        for (int i = 0; i < n; ++i) rowfirst[i] = i < tail0 ? std::max(0, (i / 6) * 6 - band) : 0;
+        for (int j = 0; j < n; ++j)
+            for (int i = j; i < n; ++i)
+                if (i < tail0 && j < rowfirst[i]) A[(size_t)j * lda + i] = 0.0;
+    }
+    dbat::CholEnvelope env;
+    if (band > 0) env.build(n, tail0, rowfirst); else env.build_dense(n);
     for (int i = 0; i < n; ++i) A[(size_t)i * lda + i] += n;        // well conditioned SPD
     for (int i = 0; i < n; ++i) A[(size_t)i * lda + n] = b[i];      // rhs row
     CK(hipMemcpy(dA0, A.data(), A.size() * 8, hipMemcpyHostToDevice));
@@ -40,33 +53,13 @@ int main(int argc, char **argv) {
     for (int r = 0; r < reps; ++r) {
         CK(hipMemcpyAsync(dA, dA0, A.size() * 8, hipMemcpyDeviceToDevice, st));
         CK(hipEventRecord(e0, st));
-        dbat::BlockChol::solve(h, st, dA, lda, n, dq, dy, dlinv, dinfo);
+        dbat::BlockChol::solve(h, st, dA, lda, n, dq, dy, dlinv, dinfo, env);
         CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
     }
     std::vector<double> q(n); int info;
     CK(hipMemcpy(q.data(), dq, n * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(&info, dinfo, 4, hipMemcpyDeviceToHost));
     printf("own   blocked chol+solve n=%d: %.3f ms  (%.2f TFLOP/s)  info=%d\n", n, best, (double)n * n * n / 3 / best / 1e9, info);
-    {   // phase timing: each kernel type alone, same launch counts as one factorisation
-        using namespace dbat;
-        const int NB = CHOL_NB, OB = CHOL_OB; const double one1 = 1.0, mone = -1.0; float ms;
-        CK(hipMemcpyAsync(dA, dA0, A.size() * 8, hipMemcpyDeviceToDevice, st));
-        CK(hipEventRecord(e0, st));
-        for (int j0 = 0; j0 + NB <= n; j0 += NB) hipLaunchKernelGGL(k_potf2, dim3(1), dim3(320), 0, st, dA, lda, n, j0, dlinv + (size_t)(j0 / NB) * NB * NB, dinfo);
-        CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st)); CK(hipEventElapsedTime(&ms, e0, e1)); printf("  potf2 x%d: %.3f ms\n", n / NB, ms);
-        CK(hipEventRecord(e0, st));
-        for (int j0 = 0; j0 + NB <= n; j0 += NB) { int below = n + 1 - j0 - NB; hipLaunchKernelGGL(k_trsm64, dim3((below + 63) / 64), dim3(256), 0, st, dA, lda, n + 1, j0, dlinv + (size_t)(j0 / NB) * NB * NB); }
-        CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st)); CK(hipEventElapsedTime(&ms, e0, e1)); printf("  trsm64 x%d: %.3f ms\n", n / NB, ms);
-        CK(hipEventRecord(e0, st));
-        for (int J = 0; J < n; J += OB) for (int j0 = J; j0 < J + OB && j0 + NB <= n; j0 += NB) { int below = n + 1 - j0 - NB; int ncb = (J + OB - (j0 + NB)) / NB; if (ncb > 0) hipLaunchKernelGGL(k_update64, dim3((below + 63) / 64, ncb), dim3(256), 0, st, dA, lda, n + 1, j0); }
-        CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st)); CK(hipEventElapsedTime(&ms, e0, e1)); printf("  update64: %.3f ms\n", ms);
-        CK(hipEventRecord(e0, st));
-        for (int J = OB; J < n; J += OB) { int ob = n - J < OB ? n - J : OB; rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_transpose, n + 1 - J, ob, J, &mone, dA + J, (int)lda, dA + J, (int)lda, &one1, dA + (int64_t)J * lda + J, (int)lda); }
-        CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st)); CK(hipEventElapsedTime(&ms, e0, e1)); printf("  dgemm x%d: %.3f ms\n", n / OB, ms);
-        CK(hipEventRecord(e0, st));
-        for (int j0 = ((n - 1) / NB) * NB; j0 >= 0; j0 -= NB) hipLaunchKernelGGL(k_backsolve, dim3(j0 > 0 ? (j0 + 255) / 256 : 1), dim3(256), 0, st, dA, lda, n, j0, dlinv + (size_t)(j0 / NB) * NB * NB, dy, dq);
-        CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st)); CK(hipEventElapsedTime(&ms, e0, e1)); printf("  backsolve x%d: %.3f ms\n", n / NB, ms);
-    }
     // ---- rocsolver
     float best2 = 1e9;
     for (int r = 0; r < reps; ++r) {

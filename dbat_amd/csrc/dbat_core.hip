@@ -72,6 +72,7 @@ struct Core {
     DevBuf<int> info;
     DevBuf<double> ywork, linv;
     int64_t ldS = 0;
+    CholEnvelope env;
     DevBuf<unsigned long long> pivmm;   // [0..1] point pivots min/max, [2..3] reduced-system pivots
     DevBuf<double> mmx;                 // [2*nranks] min/max exchange through the sum-all-reduce
     double *S = nullptr, *g_red = nullptr, *g_c = nullptr, *diagU = nullptr, *red_scal = nullptr;
@@ -134,6 +135,13 @@ struct Core {
         red.alloc(red_count);
         S = red.p; g_red = S + s_count; g_c = g_red + P.NS; diagU = g_c + P.NS; red_scal = diagU + P.NS;
         ywork.alloc(P.NS); linv.alloc(BlockChol::linv_doubles((int)P.NS));
+        {   // envelope of the reduced system from the camera co-visibility graph; IO rows are dense
+            std::vector<int> first((size_t)P.NS, 0);
+            for (int c = 0; c < P.nc; ++c)
+                for (int k = 0; k < 6; ++k) first[(size_t)6 * c + k] = 6 * P.cam_first[c];
+            if (getenv("DBAT_HIP_DENSE_CHOL")) env.build_dense((int)P.NS);
+            else env.build((int)P.NS, 6 * P.nc, first);
+        }
         jn2c.alloc(P.NS); dscale.alloc(P.NS); rhs.alloc(P.NS);
         Vinv.alloc((size_t)6 * P.np); gp.alloc((size_t)3 * P.np); jn2p.alloc((size_t)3 * P.np);
         HIPCHK(hipMemset(Vinv.p, 0, (size_t)6 * P.np * 8));
@@ -283,7 +291,7 @@ struct Core {
     int factor_solve_enqueue() {
         mark(2);
         // blocked Cholesky + both substitutions (chol.hpp); q -> rhs
-        BlockChol::solve(blas, stream, S, ldS, (int)P.NS, rhs.p, ywork.p, linv.p, info.p);
+        BlockChol::solve(blas, stream, S, ldS, (int)P.NS, rhs.p, ywork.p, linv.p, info.p, env);
         mark(3);
         hipLaunchKernelGGL(k_diag_minmax, dim3(1), dim3(256), 0, stream, d, S, pivmm.p + 2);
         hipLaunchKernelGGL(k_unscale, dim3((unsigned)cdiv(P.NS, 256)), dim3(256), 0, stream, P.NS, rhs.p, dscale.p, dz.p);

@@ -69,6 +69,7 @@ struct Plan {
     std::vector<int32_t> cam_ncol, cam_col, cam_iorow;   // per camera column lists (MAXCOL / MAXIO strides)
     std::vector<uint32_t> cam_eo_est;
     std::vector<double> px;                        // [2*nc]
+    std::vector<int32_t> cam_first;                // lowest camera index sharing an object point with each camera
     int max_k = 0;                                 // max observations of one point
     bool rank_ok = true;                           // structural rank test
     std::string err;
@@ -271,6 +272,17 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     std::vector<int64_t> fill(pstart.begin(), pstart.end() - 1);
     std::vector<int64_t> by_pt(P.no);
     for (int64_t o = 0; o < P.no; ++o) by_pt[fill[pb.ip_pt[o]]++] = o;   // image-major scan => cams ascending per point
+    // camera co-visibility: the envelope of the reduced system (chol.hpp)
+    P.cam_first.resize(nc);
+    for (int c = 0; c < nc; ++c) P.cam_first[c] = c;
+    for (int p = 0; p < np; ++p) {
+        if (!k_pt[p]) continue;
+        const int32_t c0 = pb.ip_cam[by_pt[pstart[p]]];          // cameras ascend inside a point
+        for (int j = 1; j < k_pt[p]; ++j) {
+            const int32_t c = pb.ip_cam[by_pt[pstart[p] + j]];
+            if (c0 < P.cam_first[c]) P.cam_first[c] = c0;
+        }
+    }
     // Key = 3-D Morton code of the point's initial coordinates: points that are
     // close in object space are seen by the same cameras, so neighbouring
     // points touch the same blocks of the reduced system (tiles below).
