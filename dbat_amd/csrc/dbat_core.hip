@@ -60,7 +60,9 @@ struct Core {
     DevBuf<uint32_t> cam_eo_est, o_seg;
     DevBuf<double> io_fixed, px, cam_w, z_prw, z_prv, o_uv, o_w;
     DevBuf<uint8_t> z_est, z_mine, o_lc, o_pidx;
-    DevBuf<int32_t> tile_batch, tile_cam_start, tile_cams;
+    DevBuf<int32_t> tile_batch, tile_cam_start, tile_cams, tile_io_start, tile_iocols;
+    DevBuf<uint8_t> tile_cam_io;
+    int tile_ncx = 6;
     int64_t ntiles = 0;
     size_t lds_tile = 0;
     DevBuf<int64_t> o_row, batch_start, x2z;
@@ -114,6 +116,8 @@ struct Core {
         o_seg.upload(P.o_seg); o_row.upload(P.o_row); batch_start.upload(P.batch_start);
         x2z.upload(P.x2z);
         o_lc.upload(P.o_lc); o_pidx.upload(P.o_pidx); tile_batch.upload(P.tile_batch); tile_cam_start.upload(P.tile_cam_start); tile_cams.upload(P.tile_cams);
+        tile_io_start.upload(P.tile_io_start); tile_iocols.upload(P.tile_iocols); tile_cam_io.upload(P.tile_cam_io);
+        tile_ncx = P.ncolmax <= 6 ? 6 : (P.ncolmax <= 14 ? 14 : MAXCOL);
         ntiles = P.CMAX ? (int64_t)P.tile_batch.size() - 1 : 0;
         d.nc = P.nc; d.np = P.np; d.nIOrows = P.nIOrows; d.nK = P.nK; d.nP = P.nP; d.nIOu = P.nIOu;
         d.ncolmax = P.ncolmax; d.BT = P.BT; d.NS = P.NS; d.NZ = P.NZ; d.nobs = nobs; d.nb = nb;
@@ -125,6 +129,7 @@ struct Core {
         d.CMAX = P.CMAX; d.ablate = getenv("DBAT_HIP_ABLATE") ? atoi(getenv("DBAT_HIP_ABLATE")) : 0;
         d.ntiles = (int)ntiles; d.o_lc = o_lc.p; d.o_pidx = o_pidx.p;
         d.tile_batch = tile_batch.p; d.tile_cam_start = tile_cam_start.p; d.tile_cams = tile_cams.p;
+        d.tile_io_start = tile_io_start.p; d.tile_iocols = tile_iocols.p; d.tile_cam_io = tile_cam_io.p;
         cams.alloc(P.nc);
         z.alloc(P.NZ); zt.alloc(P.NZ); dz.alloc(P.NZ); zlin.alloc(P.NZ); vtmp.alloc(P.NZ); vtmp2.alloc(P.NZ);
         xbuf.alloc(std::max<int64_t>(P.n, 1));
@@ -156,7 +161,8 @@ struct Core {
         mmx.alloc((size_t)2 * P.nranks);
         lds_build = ((size_t)P.BT * P.ncolmax * 3 + (size_t)P.BT * 18) * sizeof(double);
         lds_back = (size_t)P.BT * 6 * sizeof(double);
-        lds_tile = ((size_t)2 * 24 * 128 + (size_t)P.BT * 9 + (size_t)54 * P.CMAX) * sizeof(double);
+        lds_tile = ((size_t)2 * 24 * 128 + (size_t)P.BT * 9 + (size_t)36 * P.CMAX + 3 * 128 +
+                    (P.with_io ? (size_t)P.CMAX * 6 * 16 + 256 : 0)) * sizeof(double);
         partial.alloc((size_t)4 * std::max<int64_t>(std::max<int64_t>(std::max<int64_t>(nb, ntiles), 2048), 1));
         set_lds_limits();
         HIPCHK(hipMemcpy(z.p, P.z0.data(), P.NZ * 8, hipMemcpyHostToDevice));
@@ -167,8 +173,12 @@ struct Core {
     // kernels that use more than 64 KB of dynamic LDS must opt in
     void set_lds_limits() {
 #define SET_LDS(K, BYTES) HIPCHK(hipFuncSetAttribute((const void *)(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)))
-        SET_LDS((k_build_tile<2>), lds_tile); SET_LDS((k_build_tile<3>), lds_tile);
-        SET_LDS((k_build_tile<4>), lds_tile); SET_LDS((k_build_tile<5>), lds_tile);
+        SET_LDS((k_build_tile<2, 6>), lds_tile); SET_LDS((k_build_tile<3, 6>), lds_tile);
+        SET_LDS((k_build_tile<4, 6>), lds_tile); SET_LDS((k_build_tile<5, 6>), lds_tile);
+        SET_LDS((k_build_tile<2, 14>), lds_tile); SET_LDS((k_build_tile<3, 14>), lds_tile);
+        SET_LDS((k_build_tile<4, 14>), lds_tile); SET_LDS((k_build_tile<5, 14>), lds_tile);
+        SET_LDS((k_build_tile<2, MAXCOL>), lds_tile); SET_LDS((k_build_tile<3, MAXCOL>), lds_tile);
+        SET_LDS((k_build_tile<4, MAXCOL>), lds_tile); SET_LDS((k_build_tile<5, MAXCOL>), lds_tile);
         SET_LDS((k_build<2, false>), lds_build); SET_LDS((k_build<3, false>), lds_build);
         SET_LDS((k_build<4, false>), lds_build); SET_LDS((k_build<5, false>), lds_build);
         SET_LDS((k_build<2, true>), lds_build); SET_LDS((k_build<3, true>), lds_build);
@@ -246,8 +256,10 @@ struct Core {
         int64_t npart = nb;
         if (ntiles > 0) {
             npart = ntiles;
-#define L_TILE(M, dummy) hipLaunchKernelGGL((k_build_tile<M>), dim3((unsigned)ntiles), dim3(P.BT), lds_tile, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p, pivmm.p)
-            DISPATCH_MODEL(L_TILE, 0)
+#define L_TILE(M, NCXV) hipLaunchKernelGGL((k_build_tile<M, NCXV>), dim3((unsigned)ntiles), dim3(P.BT), lds_tile, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p, pivmm.p)
+            if (tile_ncx == 6) { DISPATCH_MODEL(L_TILE, 6) }
+            else if (tile_ncx == 14) { DISPATCH_MODEL(L_TILE, 14) }
+            else { DISPATCH_MODEL(L_TILE, MAXCOL) }
 #undef L_TILE
         } else if (nb > 0) {
 #define L_BUILD(M, IO) hipLaunchKernelGGL((k_build<M, IO>), dim3((unsigned)nb), dim3(P.BT), lds_build, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p, pivmm.p)

@@ -48,6 +48,8 @@ struct DevProblem {
     int ablate;                     // profiling only (DBAT_HIP_ABLATE): bit0 skip MFMA, bit1 skip P3 atomics, bit2 skip eval
     const uint8_t *o_lc, *o_pidx;
     const int32_t *tile_batch, *tile_cam_start, *tile_cams;
+    const int32_t *tile_io_start, *tile_iocols;     // IO columns (IOu indices) of every tile
+    const uint8_t *tile_cam_io;                     // [#tile cams][16] local IO row of a camera's j-th IO column
 };
 
 __device__ __forceinline__ void atomic_add_f64(double *p, double v) {
@@ -180,11 +182,12 @@ __device__ __forceinline__ bool inv3_sym(const double a[6], double inv[6]) {
 }
 
 // Evaluate one observation, weight it, mask fixed parameters and gather the
-// camera-side columns E = [A | C(:,estimated IO rows)].
-template <int MODEL, bool WITH_IO>
-__device__ __forceinline__ void eval_obs_cols(const DevProblem &d, const CamRec &C, const double *z,
-                                              int64_t o, int pt, double r[2],
-                                              double E[2][WITH_IO ? MAXCOL : 6], double B[2][3]) {
+// camera-side columns E = [A | C(:,estimated IO rows)].  NCX = 6 (fixed IO) or
+// the capacity of E (6 + up to NCX-6 estimated IO rows).
+template <int MODEL, int NCX>
+__device__ __forceinline__ void eval_obs_cols_n(const DevProblem &d, const CamRec &C, const double *z,
+                                                int64_t o, int pt, double r[2], double E[2][NCX], double B[2][3]) {
+    constexpr bool WITH_IO = NCX > 6;
     const double *q = z + d.NS + 3 * (int64_t)pt;
     const double Q[3] = {q[0], q[1], q[2]};
     double A[2][6];
@@ -205,7 +208,7 @@ __device__ __forceinline__ void eval_obs_cols(const DevProblem &d, const CamRec 
     }
     if constexpr (WITH_IO) {
 #pragma unroll
-        for (int j = 0; j < MAXIO; ++j) {
+        for (int j = 0; j < NCX - 6; ++j) {
             double c0 = 0, c1 = 0;
             if (6 + j < C.ncol) {
                 const int row = C.iorow[j];
@@ -215,6 +218,13 @@ __device__ __forceinline__ void eval_obs_cols(const DevProblem &d, const CamRec 
             E[0][6 + j] = c0 * w0; E[1][6 + j] = c1 * w1;
         }
     }
+}
+
+template <int MODEL, bool WITH_IO>
+__device__ __forceinline__ void eval_obs_cols(const DevProblem &d, const CamRec &C, const double *z,
+                                              int64_t o, int pt, double r[2],
+                                              double E[2][WITH_IO ? MAXCOL : 6], double B[2][3]) {
+    eval_obs_cols_n<MODEL, (WITH_IO ? MAXCOL : 6)>(d, C, z, o, pt, r, E, B);
 }
 
 // ---------------------------------------------------------------- K1 ----
@@ -432,7 +442,12 @@ __host__ __device__ constexpr TileMap make_tile_map() {
     return m;
 }
 
-template <int MODEL>
+// NCX = 6: fixed IO.  NCX > 6: self-calibration -- the estimated IO columns of
+// the tile's cameras are extra rows (after the 6*ncam camera rows) of the same
+// tile-local system, so the camera-IO border and the IO-IO block come out of the
+// same contraction.  J_c'J_c (per camera 6x6, camera x IO, IO x IO) and the
+// gradient pieces are accumulated with LDS atomics.
+template <int MODEL, int NCX>
 __global__ __launch_bounds__(256) void k_build_tile(DevProblem d, const double *__restrict__ z,
                                                     const CamRec *__restrict__ cams, double lambda, int scale,
                                                     double *__restrict__ S, double *__restrict__ g_c,
@@ -442,6 +457,8 @@ __global__ __launch_bounds__(256) void k_build_tile(DevProblem d, const double *
                                                     double *__restrict__ partial,
                                                     unsigned long long *__restrict__ pivmm) {
     constexpr int PC = 8, KC = 3 * PC, LD = 128;
+    constexpr bool IO = NCX > 6;
+    constexpr int IOT = 16;                          // Plan::IOT
     constexpr TileMap TM = make_tile_map();
     extern __shared__ double smem[];
     const int BT = blockDim.x;
@@ -450,7 +467,9 @@ __global__ __launch_bounds__(256) void k_build_tile(DevProblem d, const double *
     double *Wt = Yt + KC * LD;                       // [KC][LD]
     double *red = Wt + KC * LD;                      // [BT][9]   B'B | B'r, then V^-1 | g_p at the leader's row
     double *Ud = red + (size_t)BT * 9;               // [CM][36]  E'E of every camera, entry [a*6+b], b>=a
-    double *vt = Ud + (size_t)CM * 36;               // [3][6*CM] g_c | g_red | diagU
+    double *vt = Ud + (size_t)CM * 36;               // [3][LD]   g_c | g_red | diagU by local row
+    double *Uci = vt + 3 * LD;                       // [CM][6][IOT] camera x IO part of J_c'J_c   (IO only)
+    double *Uii = Uci + (IO ? (size_t)CM * 6 * IOT : 0);   // [IOT][IOT] IO x IO part, lower       (IO only)
     __shared__ double sh[8];
     __shared__ int npts_sh;
     const int t = threadIdx.x, lane = t & 63;
@@ -459,7 +478,10 @@ __global__ __launch_bounds__(256) void k_build_tile(DevProblem d, const double *
     const int b0 = d.tile_batch[tile], b1 = d.tile_batch[tile + 1];
     const int c0 = d.tile_cam_start[tile];
     const int ncam = d.tile_cam_start[tile + 1] - c0;
-    const int nrows = 6 * ncam;
+    const int io0 = IO ? d.tile_io_start[tile] : 0;
+    const int nio = IO ? d.tile_io_start[tile + 1] - io0 : 0;
+    const int iobase = 6 * ncam;                     // first IO row of the tile-local system
+    const int nrows = iobase + nio;
     // this wave's nine 16x16 tiles (row tile, column tile) of the lower triangle,
     // as LDS element offsets; tiles beyond the tile's rows are switched off
     int yoff[9], woff[9];
@@ -472,7 +494,7 @@ __global__ __launch_bounds__(256) void k_build_tile(DevProblem d, const double *
         yoff[s] = 16 * rt; woff[s] = 16 * ct; ton[s] = 16 * rt < nrows;
     }
     for (int i = t; i < 2 * KC * LD; i += BT) Yt[i] = 0.0;
-    for (int i = t; i < CM * 36 + 18 * CM; i += BT) Ud[i] = 0.0;
+    for (int i = t; i < CM * 36 + 3 * LD + (IO ? CM * 6 * IOT + IOT * IOT : 0); i += BT) Ud[i] = 0.0;
     mfma_d4 acc[9];
 #pragma unroll
     for (int s = 0; s < 9; ++s) acc[s] = mfma_d4{0, 0, 0, 0};
@@ -484,17 +506,27 @@ __global__ __launch_bounds__(256) void k_build_tile(DevProblem d, const double *
         const bool active = t < nobs;
         const int64_t o = o0 + t;
         double r[2] = {0, 0};
-        double E[2][6];
+        double E[2][NCX];
         double B[2][3];
-        int pt = 0, seg_start = 0, seg_len = 0, lc = 0, pidx = 0;
+        int pt = 0, seg_start = 0, seg_len = 0, lc = 0, pidx = 0, ncol = 6;
+        uint32_t ciop[4] = {0, 0, 0, 0};             // local IO rows of this camera's IO columns (1 byte each)
+        auto lrow = [&](int a) -> int {              // tile-local row of camera-side column a
+            return a < 6 ? 6 * lc + a : iobase + (int)((ciop[(a - 6) >> 2] >> (8 * ((a - 6) & 3))) & 255u);
+        };
         if (t == 0) npts_sh = 0;
         if (active) {                                // ---- P1: residual + Jacobian blocks
             const int cam = d.o_cam[o];
             pt = d.o_pt[o]; lc = d.o_lc[o]; pidx = d.o_pidx[o];
             const uint32_t sg = d.o_seg[o];
             seg_start = sg & 0xFFFF; seg_len = sg >> 16;
-            if (d.ablate & 4) { for (int q = 0; q < 6; ++q) { E[0][q] = 1e-3 * (q + lc); E[1][q] = 2e-3 * q; } for (int q = 0; q < 3; ++q) { B[0][q] = q + 1.0; B[1][q] = 0.5 * q; } }
-            else eval_obs_cols<MODEL, false>(d, cams[cam], z, o, pt, r, E, B);
+            const CamRec &C = cams[cam];
+            if (IO) {
+                ncol = min(C.ncol, NCX);
+                const uint32_t *cp = (const uint32_t *)(d.tile_cam_io + (size_t)(c0 + lc) * 16);
+                ciop[0] = cp[0]; ciop[1] = cp[1]; ciop[2] = cp[2]; ciop[3] = cp[3];
+            }
+            if (d.ablate & 4) { for (int q = 0; q < NCX; ++q) { E[0][q] = 1e-3 * (q + lc); E[1][q] = 2e-3 * q; } for (int q = 0; q < 3; ++q) { B[0][q] = q + 1.0; B[1][q] = 0.5 * q; } }
+            else eval_obs_cols_n<MODEL, NCX>(d, C, z, o, pt, r, E, B);
             r_w[2 * o] = r[0]; r_w[2 * o + 1] = r[1];
             rr += r[0] * r[0] + r[1] * r[1];
             double *rd = red + (size_t)t * 9;
@@ -551,7 +583,7 @@ __global__ __launch_bounds__(256) void k_build_tile(DevProblem d, const double *
             for (int k = 0; k < 3; ++k) { pi[6 + k] = g[k]; gp[3 * (int64_t)pt + k] = g[k]; }
         }
         __syncthreads();
-        double W[6][3];
+        double W[NCX][3];
         double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
         if (active) {                                // ---- P3: W = E'B, E'E, gradient pieces
             const double *pi = red + (size_t)seg_start * 9;
@@ -559,22 +591,41 @@ __global__ __launch_bounds__(256) void k_build_tile(DevProblem d, const double *
             const double g0 = pi[6], g1 = pi[7], g2 = pi[8];
             double *ud = Ud + (size_t)lc * 36;
 #pragma unroll
-            for (int a = 0; a < 6; ++a) {
+            for (int a = 0; a < NCX; ++a) {
                 const double w0 = E[0][a] * B[0][0] + E[1][a] * B[1][0];
                 const double w1 = E[0][a] * B[0][1] + E[1][a] * B[1][1];
                 const double w2 = E[0][a] * B[0][2] + E[1][a] * B[1][2];
                 W[a][0] = w0; W[a][1] = w1; W[a][2] = w2;
+                if (a >= ncol || (d.ablate & 2)) continue;
                 const double y0 = w0 * v0 + w1 * v1 + w2 * v2;
                 const double y1 = w0 * v1 + w1 * v3 + w2 * v4;
                 const double y2 = w0 * v2 + w1 * v4 + w2 * v5;
                 const double ga = E[0][a] * r[0] + E[1][a] * r[1];
-                if (d.ablate & 2) continue;
-                atomic_add_f64(vt + 6 * lc + a, ga);
-                atomic_add_f64(vt + 6 * CM + 6 * lc + a, ga - (y0 * g0 + y1 * g1 + y2 * g2));
-                atomic_add_f64(vt + 12 * CM + 6 * lc + a, E[0][a] * E[0][a] + E[1][a] * E[1][a]);
+                const int ra = lrow(a);
+                atomic_add_f64(vt + ra, ga);
+                atomic_add_f64(vt + LD + ra, ga - (y0 * g0 + y1 * g1 + y2 * g2));
+                atomic_add_f64(vt + 2 * LD + ra, E[0][a] * E[0][a] + E[1][a] * E[1][a]);
+                if (a < 6) {
 #pragma unroll
-                for (int b2 = a; b2 < 6; ++b2)
-                    atomic_add_f64(ud + a * 6 + b2, E[0][a] * E[0][b2] + E[1][a] * E[1][b2]);
+                    for (int b2 = a; b2 < 6; ++b2)
+                        atomic_add_f64(ud + a * 6 + b2, E[0][a] * E[0][b2] + E[1][a] * E[1][b2]);
+                    if constexpr (IO) {
+#pragma unroll
+                        for (int b2 = 6; b2 < NCX; ++b2)
+                            if (b2 < ncol)
+                                atomic_add_f64(Uci + ((size_t)lc * 6 + a) * IOT + (lrow(b2) - iobase),
+                                               E[0][a] * E[0][b2] + E[1][a] * E[1][b2]);
+                    }
+                } else if constexpr (IO) {
+                    const int ia = ra - iobase;
+#pragma unroll
+                    for (int b2 = 6; b2 < NCX; ++b2)
+                        if (b2 < ncol) {
+                            const int ib = lrow(b2) - iobase;
+                            if (ib >= ia)            // lower triangle: row ib, column ia
+                                atomic_add_f64(Uii + (size_t)ia * IOT + ib, E[0][a] * E[0][b2] + E[1][a] * E[1][b2]);
+                        }
+                }
             }
         }
         const int npts = (d.ablate & 1) ? 0 : npts_sh;   // written before the barrier after P2
@@ -584,19 +635,26 @@ __global__ __launch_bounds__(256) void k_build_tile(DevProblem d, const double *
             if (mine) {
                 const int kb = 3 * (pidx - p0);
 #pragma unroll
-                for (int a = 0; a < 6; ++a) {
-                    const int row = 6 * lc + a;
+                for (int a = 0; a < NCX; ++a) {
+                    if (a >= ncol) continue;
+                    const int row = lrow(a);
                     const double w0 = W[a][0], w1 = W[a][1], w2 = W[a][2];
-                    Wt[(kb + 0) * LD + row] = w0; Wt[(kb + 1) * LD + row] = w1; Wt[(kb + 2) * LD + row] = w2;
-                    Yt[(kb + 0) * LD + row] = w0 * v0 + w1 * v1 + w2 * v2;
-                    Yt[(kb + 1) * LD + row] = w0 * v1 + w1 * v3 + w2 * v4;
-                    Yt[(kb + 2) * LD + row] = w0 * v2 + w1 * v4 + w2 * v5;
+                    const double y0 = w0 * v0 + w1 * v1 + w2 * v2;
+                    const double y1 = w0 * v1 + w1 * v3 + w2 * v4;
+                    const double y2 = w0 * v2 + w1 * v4 + w2 * v5;
+                    if (a < 6) {                     // a camera row belongs to one observation of the point
+                        Wt[(kb + 0) * LD + row] = w0; Wt[(kb + 1) * LD + row] = w1; Wt[(kb + 2) * LD + row] = w2;
+                        Yt[(kb + 0) * LD + row] = y0; Yt[(kb + 1) * LD + row] = y1; Yt[(kb + 2) * LD + row] = y2;
+                    } else {                         // an IO row is shared by the point's observations: sum
+                        atomic_add_f64(Wt + (kb + 0) * LD + row, w0); atomic_add_f64(Wt + (kb + 1) * LD + row, w1);
+                        atomic_add_f64(Wt + (kb + 2) * LD + row, w2);
+                        atomic_add_f64(Yt + (kb + 0) * LD + row, y0); atomic_add_f64(Yt + (kb + 1) * LD + row, y1);
+                        atomic_add_f64(Yt + (kb + 2) * LD + row, y2);
+                    }
                 }
             }
             __syncthreads();
             const int ksteps = (3 * min(PC, npts - p0) + 3) >> 2;
-            // k outer, the wave's 9 tiles inner: nine independent accumulator chains
-            // keep the matrix pipe busy (a single chain waits for every result)
             if (ton[8]) {
                 // full tile: all nine products unconditionally, operands fetched first so
                 // that the LDS latency overlaps the matrix pipe (rows past the tile's
@@ -627,8 +685,9 @@ __global__ __launch_bounds__(256) void k_build_tile(DevProblem d, const double *
             if (mine) {                              // restore the zero fill
                 const int kb = 3 * (pidx - p0);
 #pragma unroll
-                for (int a = 0; a < 6; ++a) {
-                    const int row = 6 * lc + a;
+                for (int a = 0; a < NCX; ++a) {
+                    if (a >= ncol) continue;
+                    const int row = lrow(a);
 #pragma unroll
                     for (int e = 0; e < 3; ++e) { Wt[(kb + e) * LD + row] = 0.0; Yt[(kb + e) * LD + row] = 0.0; }
                 }
@@ -637,20 +696,21 @@ __global__ __launch_bounds__(256) void k_build_tile(DevProblem d, const double *
         }
         __syncthreads();       // red / npts_sh are reused by the next batch
     }
-    // ---- flush the tile to HBM:  S -= sum_p Y W'  (lower triangle), S += E'E
+    // ---- flush the tile to HBM:  S -= sum_p Y W'  (lower triangle), S += J_c'J_c
+    auto grow = [&](int lr) -> int64_t {             // tile-local row -> row of the reduced system
+        if (lr < iobase) return 6 * (int64_t)d.tile_cams[c0 + lr / 6] + lr % 6;
+        return 6 * (int64_t)d.nc + d.tile_iocols[io0 + lr - iobase];
+    };
 #pragma unroll
     for (int s = 0; s < 9; ++s) {
         if (ton[s]) {
             const int lcol = woff[s] + (lane & 15);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int lrow = yoff[s] + (lane >> 4) + 4 * e;
+                const int lr = yoff[s] + (lane >> 4) + 4 * e;
                 const double v = acc[s][e];
-                if (lrow < nrows && lcol <= lrow && v != 0.0) {
-                    const int64_t row = 6 * (int64_t)d.tile_cams[c0 + lrow / 6] + lrow % 6;
-                    const int64_t col = 6 * (int64_t)d.tile_cams[c0 + lcol / 6] + lcol % 6;
-                    atomic_add_f64(S + col * d.ldS + row, -v);
-                }
+                if (lr < nrows && lcol <= lr && v != 0.0)
+                    atomic_add_f64(S + grow(lcol) * d.ldS + grow(lr), -v);
             }
         }
     }
@@ -661,11 +721,25 @@ __global__ __launch_bounds__(256) void k_build_tile(DevProblem d, const double *
         const int64_t cb = 6 * (int64_t)d.tile_cams[c0 + lcam];
         atomic_add_f64(S + (cb + a) * d.ldS + (cb + b2), Ud[i]);
     }
-    for (int i = t; i < 6 * ncam; i += BT) {
-        const int64_t col = 6 * (int64_t)d.tile_cams[c0 + i / 6] + i % 6;
+    if constexpr (IO) {
+        for (int i = t; i < ncam * 6 * IOT; i += BT) {
+            const int li = i % IOT, ca = i / IOT;    // ca = lcam*6 + a
+            if (li >= nio) continue;
+            const double v = Uci[i];
+            if (v != 0.0) atomic_add_f64(S + grow(ca) * d.ldS + grow(iobase + li), v);
+        }
+        for (int i = t; i < IOT * IOT; i += BT) {
+            const int ia = i / IOT, ib = i % IOT;
+            if (ia >= nio || ib >= nio || ib < ia) continue;
+            const double v = Uii[i];
+            if (v != 0.0) atomic_add_f64(S + grow(iobase + ia) * d.ldS + grow(iobase + ib), v);
+        }
+    }
+    for (int i = t; i < nrows; i += BT) {
+        const int64_t col = grow(i);
         atomic_add_f64(g_c + col, vt[i]);
-        atomic_add_f64(g_red + col, vt[6 * CM + i]);
-        atomic_add_f64(diagU + col, vt[12 * CM + i]);
+        atomic_add_f64(g_red + col, vt[LD + i]);
+        atomic_add_f64(diagU + col, vt[2 * LD + i]);
     }
     double accr[1] = {rr};
     block_sum<1>(accr, sh);

@@ -61,6 +61,12 @@ struct Plan {
     std::vector<int32_t> tile_cam_start;           // [ntiles+1]
     std::vector<int32_t> tile_cams;                // global camera ids, ascending inside a tile
     int CMAX = 0;                                  // 0 = no tiling (global atomics)
+    // self-calibration: the estimated IO columns of a tile's cameras are extra rows
+    // of the tile-local system (at most IOT of them), after the 6*ncam camera rows
+    static constexpr int IOT = 16;
+    std::vector<int32_t> tile_io_start;            // [ntiles+1]
+    std::vector<int32_t> tile_iocols;              // IOu indices, ascending inside a tile
+    std::vector<uint8_t> tile_cam_io;              // [#tile cams][16]: local IO row of the camera's j-th IO column
     int BT = 256;
     int ncolmax = 6;
     bool with_io = false;
@@ -348,12 +354,29 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     P.BT = env_int("DBAT_HIP_BT", 256);
     if (P.BT != 128 && P.BT != 256) P.BT = 256;
     if ((size_t)P.BT * strideW * 8 + (size_t)P.BT * 18 * 8 > 150 * 1024) P.BT = 128;
-    P.CMAX = P.with_io ? 0 : env_int("DBAT_HIP_CMAX", 21);
-    if (P.CMAX < 0 || P.CMAX > 21) P.CMAX = 21;     // 6*CMAX <= 128 rows of the MFMA tile
+    P.CMAX = env_int("DBAT_HIP_CMAX", P.with_io ? 18 : 21);
+    if (P.CMAX < 0 || P.CMAX > (P.with_io ? 18 : 21)) P.CMAX = P.with_io ? 18 : 21;   // 6*CMAX (+IOT) <= 128 rows of the MFMA tile
+    if (P.ncolmax - 6 > Plan::IOT) P.CMAX = 0;
     if (P.max_k > P.BT)
         return fail(P, "an object point has more observations than one batch holds (" +
                        std::to_string(P.max_k) + " > " + std::to_string(P.BT) + ")");
-    if (P.CMAX && P.max_k > P.CMAX) P.CMAX = 0;      // a point alone overflows a tile: fall back
+    // a point whose cameras (and their IO columns) alone overflow a tile: fall back to k_build
+    for (int p = 0; p < np && P.CMAX; ++p) {
+        if (k_pt[p] > P.CMAX) { P.CMAX = 0; break; }
+        if (P.with_io) {
+            int32_t seen[Plan::IOT + 1]; int ns = 0;
+            for (int j = 0; j < k_pt[p] && ns <= Plan::IOT; ++j) {
+                const int32_t c = pb.ip_cam[by_pt[pstart[p] + j]];
+                for (int q = 6; q < P.cam_ncol[c] && ns <= Plan::IOT; ++q) {
+                    const int32_t io = P.cam_col[(size_t)c * MAXCOL + q];
+                    bool f = false;
+                    for (int t = 0; t < ns; ++t) if (seen[t] == io) { f = true; break; }
+                    if (!f) seen[ns++] = io;
+                }
+            }
+            if (ns > Plan::IOT) P.CMAX = 0;
+        }
+    }
     P.batch_start.clear(); P.batch_start.push_back(0);
     int64_t nobs_shard = 0;
     for (int64_t i = P.pt_lo; i < P.pt_hi; ++i) nobs_shard += k_pt[P.porder[i]];
@@ -364,7 +387,10 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     P.tile_batch.clear(); P.tile_cam_start.clear(); P.tile_cams.clear();
     P.tile_batch.push_back(0); P.tile_cam_start.push_back(0);
     std::vector<int32_t> stamp(nc, -1);              // tile id in which a camera was last seen
-    std::vector<int32_t> cur_cams;
+    std::vector<int32_t> io_stamp(std::max(1, P.nIOu), -1);
+    std::vector<int32_t> cur_cams, cur_io;
+    P.tile_io_start.clear(); P.tile_iocols.clear(); P.tile_cam_io.clear();
+    P.tile_io_start.push_back(0);
     int64_t pos = 0, bstart = 0, tile_first_obs = 0;
     auto close_tile = [&](int64_t end_obs) {
         // local indices in ascending global camera order
@@ -372,6 +398,19 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         std::vector<int32_t> &loc = stamp;            // reuse as cam -> local index (restored below)
         for (size_t l = 0; l < cur_cams.size(); ++l) loc[cur_cams[l]] = (int32_t)l;
         for (int64_t o = tile_first_obs; o < end_obs; ++o) P.o_lc[o] = (uint8_t)loc[P.o_cam[o]];
+        // IO columns of the tile, ascending; every camera's IO columns -> local IO rows
+        std::sort(cur_io.begin(), cur_io.end());
+        for (int32_t c : cur_cams) {
+            uint8_t rows16[16] = {0};
+            for (int q = 6; q < P.cam_ncol[c]; ++q) {
+                const int32_t io = P.cam_col[(size_t)c * MAXCOL + q] - 6 * nc;
+                rows16[q - 6] = (uint8_t)(std::lower_bound(cur_io.begin(), cur_io.end(), io) - cur_io.begin());
+            }
+            P.tile_cam_io.insert(P.tile_cam_io.end(), rows16, rows16 + 16);
+        }
+        for (int32_t io : cur_io) { P.tile_iocols.push_back(io); io_stamp[io] = -1; }
+        P.tile_io_start.push_back((int32_t)P.tile_iocols.size());
+        cur_io.clear();
         for (int32_t c : cur_cams) { P.tile_cams.push_back(c); loc[c] = -1; }
         P.tile_cam_start.push_back((int32_t)P.tile_cams.size());
         P.tile_batch.push_back((int32_t)P.batch_start.size() - 1);   // = number of closed batches
@@ -385,9 +424,23 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         const int k = k_pt[p];
         if (k == 0) continue;
         if (P.CMAX) {
-            int fresh = 0;
-            for (int j = 0; j < k; ++j) if (stamp[pb.ip_cam[by_pt[pstart[p] + j]]] != tile_id) ++fresh;
-            if ((int)cur_cams.size() + fresh > P.CMAX && pos > tile_first_obs) {
+            int fresh = 0, fresh_io = 0;
+            int32_t fio[Plan::IOT + 1];
+            for (int j = 0; j < k; ++j) {
+                const int32_t c = pb.ip_cam[by_pt[pstart[p] + j]];
+                if (stamp[c] == tile_id) continue;
+                ++fresh;
+                for (int q = 6; q < P.cam_ncol[c]; ++q) {
+                    const int32_t io = P.cam_col[(size_t)c * MAXCOL + q] - 6 * nc;
+                    if (io_stamp[io] == tile_id) continue;
+                    bool f = false;
+                    for (int t = 0; t < fresh_io; ++t) if (fio[t] == io) { f = true; break; }
+                    if (!f && fresh_io <= Plan::IOT) fio[fresh_io++] = io;
+                }
+            }
+            const bool over = (int)cur_cams.size() + fresh > P.CMAX ||
+                              (int)cur_io.size() + fresh_io > Plan::IOT;
+            if (over && pos > tile_first_obs) {
                 // close the current batch and tile before this point
                 P.batch_start.push_back(pos); bstart = pos;
                 for (int32_t c : cur_cams) stamp[c] = -1;
@@ -408,7 +461,13 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
                 P.o_w[2 * pos] = 1.0 / (pb.ip_std[2 * o] * P.px[2 * c]);
                 P.o_w[2 * pos + 1] = 1.0 / (pb.ip_std[2 * o + 1] * P.px[2 * c + 1]);
             }
-            if (P.CMAX && stamp[c] != tile_id) { stamp[c] = tile_id; cur_cams.push_back(c); }
+            if (P.CMAX && stamp[c] != tile_id) {
+                stamp[c] = tile_id; cur_cams.push_back(c);
+                for (int q = 6; q < P.cam_ncol[c]; ++q) {
+                    const int32_t io = P.cam_col[(size_t)c * MAXCOL + q] - 6 * nc;
+                    if (io_stamp[io] != tile_id) { io_stamp[io] = tile_id; cur_io.push_back(io); }
+                }
+            }
         }
         ++pidx;
     }
