@@ -118,7 +118,7 @@ struct Core {
         o_lc.upload(P.o_lc); o_pidx.upload(P.o_pidx); tile_batch.upload(P.tile_batch); tile_cam_start.upload(P.tile_cam_start); tile_cams.upload(P.tile_cams);
         tile_io_start.upload(P.tile_io_start); tile_iocols.upload(P.tile_iocols); tile_cam_io.upload(P.tile_cam_io);
         tile_ncx = P.ncolmax <= 6 ? 6 : (P.ncolmax <= 14 ? 14 : MAXCOL);
-        ntiles = P.CMAX ? (int64_t)P.tile_batch.size() - 1 : 0;
+        ntiles = (P.CMAX && P.nb_tiled > 0) ? (int64_t)P.tile_batch.size() - 1 : 0;
         d.nc = P.nc; d.np = P.np; d.nIOrows = P.nIOrows; d.nK = P.nK; d.nP = P.nP; d.nIOu = P.nIOu;
         d.ncolmax = P.ncolmax; d.BT = P.BT; d.NS = P.NS; d.NZ = P.NZ; d.nobs = nobs; d.nb = nb;
         d.cam_ncol = cam_ncol.p; d.cam_col = cam_col.p; d.cam_iorow = cam_iorow.p; d.cam_eo_est = cam_eo_est.p;
@@ -163,7 +163,7 @@ struct Core {
         lds_back = (size_t)P.BT * 6 * sizeof(double);
         lds_tile = ((size_t)2 * 24 * 128 + (size_t)P.BT * 9 + (size_t)36 * P.CMAX + 3 * 128 +
                     (P.with_io ? (size_t)P.CMAX * 6 * 16 + 256 : 0)) * sizeof(double);
-        partial.alloc((size_t)4 * std::max<int64_t>(std::max<int64_t>(std::max<int64_t>(nb, ntiles), 2048), 1));
+        partial.alloc((size_t)4 * std::max<int64_t>(std::max<int64_t>(nb + ntiles, 2048), 1));
         set_lds_limits();
         HIPCHK(hipMemcpy(z.p, P.z0.data(), P.NZ * 8, hipMemcpyHostToDevice));
         HIPCHK(hipMemset(dz.p, 0, P.NZ * 8));
@@ -253,18 +253,23 @@ struct Core {
             HIPCHK(hipMemcpyAsync(pivmm.p, init, sizeof(init), hipMemcpyHostToDevice, stream));
         }
         mark(0);
-        int64_t npart = nb;
-        if (ntiles > 0) {
+        // tiled batches through the MFMA kernel, the remaining ("heavy point") batches
+        // -- or all of them when tiling is off -- through k_build
+        int64_t npart = 0;
+        const int64_t nb_tiled = P.nb_tiled;
+        if (ntiles > 0 && nb_tiled > 0) {
             npart = ntiles;
 #define L_TILE(M, NCXV) hipLaunchKernelGGL((k_build_tile<M, NCXV>), dim3((unsigned)ntiles), dim3(P.BT), lds_tile, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p, pivmm.p)
             if (tile_ncx == 6) { DISPATCH_MODEL(L_TILE, 6) }
             else if (tile_ncx == 14) { DISPATCH_MODEL(L_TILE, 14) }
             else { DISPATCH_MODEL(L_TILE, MAXCOL) }
 #undef L_TILE
-        } else if (nb > 0) {
-#define L_BUILD(M, IO) hipLaunchKernelGGL((k_build<M, IO>), dim3((unsigned)nb), dim3(P.BT), lds_build, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p, pivmm.p)
+        }
+        if (nb > nb_tiled) {
+#define L_BUILD(M, IO) hipLaunchKernelGGL((k_build<M, IO>), dim3((unsigned)(nb - nb_tiled)), dim3(P.BT), lds_build, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p + npart, pivmm.p, (int)nb_tiled)
             if (P.with_io) { DISPATCH_MODEL(L_BUILD, true) } else { DISPATCH_MODEL(L_BUILD, false) }
 #undef L_BUILD
+            npart += nb - nb_tiled;
         }
         mark(1);
         hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(256), 0, stream, partial.p, npart, red_scal, 0);

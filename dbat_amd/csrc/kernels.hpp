@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void k_build(DevProblem d, const double *__res
                                                double *__restrict__ Vinv, double *__restrict__ gp,
                                                double *__restrict__ jn2p, double *__restrict__ r_w,
                                                double *__restrict__ partial,
-                                               unsigned long long *__restrict__ pivmm) {
+                                               unsigned long long *__restrict__ pivmm, int batch0) {
     constexpr int NCX = WITH_IO ? MAXCOL : 6;
     extern __shared__ double smem[];
     const int BT = blockDim.x;
@@ -252,8 +252,8 @@ __global__ __launch_bounds__(256) void k_build(DevProblem d, const double *__res
     __shared__ double sh[8];
 
     const int t = threadIdx.x;
-    const int64_t o0 = d.batch_start[blockIdx.x];
-    const int nobs = (int)(d.batch_start[blockIdx.x + 1] - o0);
+    const int64_t o0 = d.batch_start[batch0 + blockIdx.x];
+    const int nobs = (int)(d.batch_start[batch0 + blockIdx.x + 1] - o0);
     const bool active = t < nobs;
     const int64_t o = o0 + t;
 

@@ -61,6 +61,7 @@ struct Plan {
     std::vector<int32_t> tile_cam_start;           // [ntiles+1]
     std::vector<int32_t> tile_cams;                // global camera ids, ascending inside a tile
     int CMAX = 0;                                  // 0 = no tiling (global atomics)
+    int64_t nb_tiled = 0;                          // batches [0,nb_tiled) belong to tiles; the rest hold heavy points
     // self-calibration: the estimated IO columns of a tile's cameras are extra rows
     // of the tile-local system (at most IOT of them), after the 6*ncam camera rows
     static constexpr int IOT = 16;
@@ -289,6 +290,30 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
             if (c0 < P.cam_first[c]) P.cam_first[c] = c0;
         }
     }
+    // Points that fit a tile of the MFMA Schur kernel (at most CMAX cameras and
+    // IOT estimated IO columns) are processed first; "heavy" points (e.g. control
+    // points seen in very many images) follow and go through k_build.
+    auto env_int0 = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
+    P.CMAX = env_int0("DBAT_HIP_CMAX", P.with_io ? 18 : 21);
+    if (P.CMAX < 0 || P.CMAX > (P.with_io ? 18 : 21)) P.CMAX = P.with_io ? 18 : 21;   // 6*CMAX (+IOT) <= 128 rows of the MFMA tile
+    if (P.ncolmax - 6 > Plan::IOT) P.CMAX = 0;
+    std::vector<uint8_t> heavy(np, 0);
+    for (int p = 0; p < np && P.CMAX; ++p) {
+        if (k_pt[p] > P.CMAX) { heavy[p] = 1; continue; }
+        if (P.with_io) {
+            int32_t seen[Plan::IOT + 1]; int ns = 0;
+            for (int j = 0; j < k_pt[p] && ns <= Plan::IOT; ++j) {
+                const int32_t c = pb.ip_cam[by_pt[pstart[p] + j]];
+                for (int q = 6; q < P.cam_ncol[c] && ns <= Plan::IOT; ++q) {
+                    const int32_t io = P.cam_col[(size_t)c * MAXCOL + q];
+                    bool f = false;
+                    for (int t = 0; t < ns; ++t) if (seen[t] == io) { f = true; break; }
+                    if (!f) seen[ns++] = io;
+                }
+            }
+            if (ns > Plan::IOT) heavy[p] = 1;
+        }
+    }
     // Key = 3-D Morton code of the point's initial coordinates: points that are
     // close in object space are seen by the same cameras, so neighbouring
     // points touch the same blocks of the reduced system (tiles below).
@@ -321,7 +346,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
                 if (v > 1) v = 1;
                 k |= spread((uint64_t)(v * 2097151.0)) << d;
             }
-            key[p] = k_pt[p] ? k : ~0ull;
+            key[p] = k_pt[p] ? ((k >> 1) | (heavy[p] ? (1ull << 63) : 0)) : ~0ull;   // heavy points after the others
         }
     }
     P.porder.resize(np);
@@ -354,29 +379,9 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     P.BT = env_int("DBAT_HIP_BT", 256);
     if (P.BT != 128 && P.BT != 256) P.BT = 256;
     if ((size_t)P.BT * strideW * 8 + (size_t)P.BT * 18 * 8 > 150 * 1024) P.BT = 128;
-    P.CMAX = env_int("DBAT_HIP_CMAX", P.with_io ? 18 : 21);
-    if (P.CMAX < 0 || P.CMAX > (P.with_io ? 18 : 21)) P.CMAX = P.with_io ? 18 : 21;   // 6*CMAX (+IOT) <= 128 rows of the MFMA tile
-    if (P.ncolmax - 6 > Plan::IOT) P.CMAX = 0;
     if (P.max_k > P.BT)
         return fail(P, "an object point has more observations than one batch holds (" +
                        std::to_string(P.max_k) + " > " + std::to_string(P.BT) + ")");
-    // a point whose cameras (and their IO columns) alone overflow a tile: fall back to k_build
-    for (int p = 0; p < np && P.CMAX; ++p) {
-        if (k_pt[p] > P.CMAX) { P.CMAX = 0; break; }
-        if (P.with_io) {
-            int32_t seen[Plan::IOT + 1]; int ns = 0;
-            for (int j = 0; j < k_pt[p] && ns <= Plan::IOT; ++j) {
-                const int32_t c = pb.ip_cam[by_pt[pstart[p] + j]];
-                for (int q = 6; q < P.cam_ncol[c] && ns <= Plan::IOT; ++q) {
-                    const int32_t io = P.cam_col[(size_t)c * MAXCOL + q];
-                    bool f = false;
-                    for (int t = 0; t < ns; ++t) if (seen[t] == io) { f = true; break; }
-                    if (!f) seen[ns++] = io;
-                }
-            }
-            if (ns > Plan::IOT) P.CMAX = 0;
-        }
-    }
     P.batch_start.clear(); P.batch_start.push_back(0);
     int64_t nobs_shard = 0;
     for (int64_t i = P.pt_lo; i < P.pt_hi; ++i) nobs_shard += k_pt[P.porder[i]];
@@ -419,11 +424,20 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     };
     int32_t tile_id = 0;
     int pidx = 0;
+    bool in_heavy = false;
     for (int64_t i = P.pt_lo; i < P.pt_hi; ++i) {
         const int32_t p = P.porder[i];
         const int k = k_pt[p];
         if (k == 0) continue;
-        if (P.CMAX) {
+        if (P.CMAX && heavy[p] && !in_heavy) {
+            // first heavy point: close the last tile; the remaining batches are not tiled
+            if (pos > bstart) { P.batch_start.push_back(pos); bstart = pos; }
+            for (int32_t c : cur_cams) stamp[c] = -1;
+            close_tile(pos);
+            in_heavy = true;
+            P.nb_tiled = (int64_t)P.batch_start.size() - 1;
+        }
+        if (P.CMAX && !in_heavy) {
             int fresh = 0, fresh_io = 0;
             int32_t fio[Plan::IOT + 1];
             for (int j = 0; j < k; ++j) {
@@ -461,7 +475,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
                 P.o_w[2 * pos] = 1.0 / (pb.ip_std[2 * o] * P.px[2 * c]);
                 P.o_w[2 * pos + 1] = 1.0 / (pb.ip_std[2 * o + 1] * P.px[2 * c + 1]);
             }
-            if (P.CMAX && stamp[c] != tile_id) {
+            if (P.CMAX && !in_heavy && stamp[c] != tile_id) {
                 stamp[c] = tile_id; cur_cams.push_back(c);
                 for (int q = 6; q < P.cam_ncol[c]; ++q) {
                     const int32_t io = P.cam_col[(size_t)c * MAXCOL + q] - 6 * nc;
@@ -472,10 +486,12 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         ++pidx;
     }
     if (pos > bstart || P.batch_start.size() == 1) P.batch_start.push_back(pos);
-    if (P.CMAX) {
+    if (P.CMAX && !in_heavy) {
         for (int32_t c : cur_cams) stamp[c] = -1;
         close_tile(pos);
+        P.nb_tiled = (int64_t)P.batch_start.size() - 1;
     }
+    if (!P.CMAX) P.nb_tiled = 0;
     return true;
 }
 

@@ -446,3 +446,40 @@ def test_C4_full_size_properties(hip):
     res, ok, iters, s0, E = bundle(s, 'lm', store_trace=False)
     assert ok and 0.49 < s0 < 0.52
     assert E.numParams == 30000 - 7 + 32 + 15_000_000
+
+
+@pytest.mark.parametrize('variant', ['plain', 'selfcal'])
+def test_mixed_tiled_and_heavy_points(hip, variant, monkeypatch):
+    """Points with more cameras than a tile holds ("heavy", through k_build)
+    next to tiled points (MFMA kernel) in one problem: step parity with the
+    oracle and an identical bundle result."""
+    from dbat_amd import bundle
+    s, truth = synth_struct('small', variant)
+    # thin out every second point to 4 rays; with CMAX=6 the 8-ray points are heavy
+    pt, cam = s.IP.pt, s.IP.cam
+    rank = np.zeros(len(pt), int)
+    order = np.lexsort((cam, pt))
+    first = np.r_[True, pt[order][1:] != pt[order][:-1]]
+    idx = np.arange(len(pt)) - np.maximum.accumulate(np.where(first, np.arange(len(pt)), 0))
+    rank[order] = idx
+    keep = ~((pt % 2 == 0) & (rank >= 4))
+    s.IP.val, s.IP.std = s.IP.val[:, keep], s.IP.std[:, keep]
+    s.IP.cam, s.IP.pt = s.IP.cam[keep], s.IP.pt[keep]
+    monkeypatch.setenv('DBAT_HIP_CMAX', '6')
+    so, x0, w = oracle_setup(s)
+    R = np.sqrt(w)
+    r_o, K = o.brown_euler_cam4(x0, so, jac=True)
+    J = (sp.diags(R) @ K).tocsc()
+    p_o, *_ = o._scaled_gn(J, R * r_o)
+    h = hip.Handle(s)
+    try:
+        info = h.info()
+        assert 0 < info['n_tiles'] and info['n_batches'] > 0
+        p_h, st = h.linearize_solve(x0, 0.0, True)
+        assert relerr(p_h, p_o) < TOL_STEP
+    finally:
+        h.close()
+    res, ok, iters, s0, E = bundle(s, 'gna')
+    monkeypatch.delenv('DBAT_HIP_CMAX')
+    ro, oko, ito, s0o, Eo = o.bundle(s, 'gna')
+    assert ok and oko and iters == ito and relerr(E.x, Eo.x) < TOL_X
