@@ -161,7 +161,7 @@ struct Core {
         mmx.alloc((size_t)2 * P.nranks);
         lds_build = ((size_t)P.BT * P.ncolmax * 3 + (size_t)P.BT * 18) * sizeof(double);
         lds_back = (size_t)P.BT * 6 * sizeof(double);
-        lds_tile = ((size_t)2 * 24 * 128 + (size_t)P.BT * 9 + (size_t)36 * P.CMAX + 3 * 128 +
+        lds_tile = ((size_t)2 * 3 * TILE_PC * TILE_LD + (size_t)P.BT * 9 + (size_t)36 * P.CMAX + 3 * TILE_LD +
                     (P.with_io ? (size_t)P.CMAX * 6 * 16 + 256 : 0)) * sizeof(double);
         partial.alloc((size_t)4 * std::max<int64_t>(std::max<int64_t>(nb + ntiles, 2048), 1));
         set_lds_limits();

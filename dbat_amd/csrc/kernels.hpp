@@ -432,14 +432,49 @@ __global__ __launch_bounds__(256) void k_build(DevProblem d, const double *__res
 // HBM once -- no atomics on the k^2 pair terms.  E'E (camera diagonal blocks)
 // and the gradient pieces go through a few LDS atomics per observation.
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+#ifndef DBAT_TILE_PC
+#define DBAT_TILE_PC 8
+#endif
+constexpr int TILE_PC = DBAT_TILE_PC;           // object points per MFMA chunk (K = 3*TILE_PC)
+// Row stride of the LDS operand panels: 144 doubles = 288 dwords == 32 (mod 64
+// banks), so the four k-rows one ds_read_b64 wave-instruction touches fall on
+// disjoint bank halves (128 would make lanes l and l+16 collide).
+constexpr int TILE_LD = 144;
 
-struct TileMap { int8_t rt[36], ct[36]; };
-__host__ __device__ constexpr TileMap make_tile_map() {
-    TileMap m{};
-    int n = 0;
-    for (int r = 0; r < 8; ++r)
-        for (int c = 0; c <= r; ++c) { m.rt[n] = (int8_t)r; m.ct[n] = (int8_t)c; ++n; }
-    return m;
+// Tile -> wave assignment of the 8x8 lower-triangular grid of 16x16 tiles:
+// wave w owns row tiles w and 7-w (w+1 and 8-w tiles: nine each), so that it
+// needs only two Y fragments and at most eight W fragments per k-step.
+template <int WV>
+__device__ __forceinline__ void tile_mfma_steps(const double *Yt, const double *Wt, int lane, int ksteps,
+                                                mfma_d4 (&acc)[9]) {
+    constexpr int LD = TILE_LD, RA = WV, RB = 7 - WV;      // RA <= RB
+    if (ksteps <= 0) return;
+    // software pipeline: the fragments of k-step kk+1 are fetched while the
+    // matrix pipe works on k-step kk
+    const double *yr = Yt + (lane >> 4) * LD + (lane & 15);
+    const double *wr = Wt + (lane >> 4) * LD + (lane & 15);
+    double ya = yr[16 * RA], yb = yr[16 * RB];
+    double wa[RB + 1];
+#pragma unroll
+    for (int c = 0; c <= RB; ++c) wa[c] = wr[16 * c];
+    for (int kk = 0; kk < ksteps; ++kk) {
+        const int kn = kk + 1 < ksteps ? kk + 1 : kk;      // last step re-reads itself (harmless)
+        const double *yn = yr + 4 * kn * LD;
+        const double *wn = wr + 4 * kn * LD;
+        const double nya = yn[16 * RA], nyb = yn[16 * RB];
+        double nwa[RB + 1];
+#pragma unroll
+        for (int c = 0; c <= RB; ++c) nwa[c] = wn[16 * c];
+#pragma unroll
+        for (int c = 0; c <= RA; ++c)
+            acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ya, wa[c], acc[c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c <= RB; ++c)
+            acc[RA + 1 + c] = __builtin_amdgcn_mfma_f64_16x16x4f64(yb, wa[c], acc[RA + 1 + c], 0, 0, 0);
+        ya = nya; yb = nyb;
+#pragma unroll
+        for (int c = 0; c <= RB; ++c) wa[c] = nwa[c];
+    }
 }
 
 // NCX = 6: fixed IO.  NCX > 6: self-calibration -- the estimated IO columns of
@@ -456,10 +491,9 @@ __global__ __launch_bounds__(256) void k_build_tile(DevProblem d, const double *
                                                     double *__restrict__ jn2p, double *__restrict__ r_w,
                                                     double *__restrict__ partial,
                                                     unsigned long long *__restrict__ pivmm) {
-    constexpr int PC = 8, KC = 3 * PC, LD = 128;
+    constexpr int PC = TILE_PC, KC = 3 * PC, LD = TILE_LD;
     constexpr bool IO = NCX > 6;
     constexpr int IOT = 16;                          // Plan::IOT
-    constexpr TileMap TM = make_tile_map();
     extern __shared__ double smem[];
     const int BT = blockDim.x;
     const int CM = d.CMAX;
@@ -482,15 +516,14 @@ __global__ __launch_bounds__(256) void k_build_tile(DevProblem d, const double *
     const int nio = IO ? d.tile_io_start[tile + 1] - io0 : 0;
     const int iobase = 6 * ncam;                     // first IO row of the tile-local system
     const int nrows = iobase + nio;
-    // this wave's nine 16x16 tiles (row tile, column tile) of the lower triangle,
-    // as LDS element offsets; tiles beyond the tile's rows are switched off
+    // this wave's nine 16x16 tiles of the lower triangle: row tile `wave` with
+    // column tiles 0..wave, then row tile 7-wave with column tiles 0..7-wave
     int yoff[9], woff[9];
     bool ton[9];
 #pragma unroll
     for (int s = 0; s < 9; ++s) {
-        const int n = wave + 4 * s;
-        const int rt = __builtin_amdgcn_readfirstlane((int)TM.rt[n]);
-        const int ct = __builtin_amdgcn_readfirstlane((int)TM.ct[n]);
+        const int rt = s <= wave ? wave : 7 - wave;
+        const int ct = s <= wave ? s : s - wave - 1;
         yoff[s] = 16 * rt; woff[s] = 16 * ct; ton[s] = 16 * rt < nrows;
     }
     for (int i = t; i < 2 * KC * LD; i += BT) Yt[i] = 0.0;
@@ -631,7 +664,7 @@ __global__ __launch_bounds__(256) void k_build_tile(DevProblem d, const double *
         const int npts = (d.ablate & 1) ? 0 : npts_sh;   // written before the barrier after P2
         // ---- P4: chunks of PC points through the matrix cores
         for (int p0 = 0; p0 < npts; p0 += PC) {
-            const bool mine = active && pidx >= p0 && pidx < p0 + PC;
+            const bool mine = active && pidx >= p0 && pidx < p0 + PC && !(d.ablate & 16);
             if (mine) {
                 const int kb = 3 * (pidx - p0);
 #pragma unroll
@@ -654,21 +687,16 @@ __global__ __launch_bounds__(256) void k_build_tile(DevProblem d, const double *
                 }
             }
             __syncthreads();
-            const int ksteps = (3 * min(PC, npts - p0) + 3) >> 2;
+            const int ksteps = (d.ablate & 8) ? 0 : (3 * min(PC, npts - p0) + 3) >> 2;
             if (ton[8]) {
-                // full tile: all nine products unconditionally, operands fetched first so
-                // that the LDS latency overlaps the matrix pipe (rows past the tile's
-                // cameras are zero-filled and contribute nothing)
-                for (int kk = 0; kk < ksteps; ++kk) {
-                    const int krow = 4 * kk + (lane >> 4);
-                    const double *yr = Yt + krow * LD + (lane & 15);
-                    const double *wr = Wt + krow * LD + (lane & 15);
-                    double ya[9], wa[9];
-#pragma unroll
-                    for (int s = 0; s < 9; ++s) { ya[s] = yr[yoff[s]]; wa[s] = wr[woff[s]]; }
-#pragma unroll
-                    for (int s = 0; s < 9; ++s)
-                        acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[s], wa[s], acc[s], 0, 0, 0);
+                // full tile (the wave's larger row tile is populated): all nine products
+                // unconditionally, operands fetched first so that the LDS latency
+                // overlaps the matrix pipe (rows past the tile's cameras are zero)
+                switch (wave) {
+                    case 0: tile_mfma_steps<0>(Yt, Wt, lane, ksteps, acc); break;
+                    case 1: tile_mfma_steps<1>(Yt, Wt, lane, ksteps, acc); break;
+                    case 2: tile_mfma_steps<2>(Yt, Wt, lane, ksteps, acc); break;
+                    default: tile_mfma_steps<3>(Yt, Wt, lane, ksteps, acc); break;
                 }
             } else {
                 for (int kk = 0; kk < ksteps; ++kk) {
