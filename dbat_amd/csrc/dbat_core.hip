@@ -13,7 +13,7 @@
 #include <vector>
 
 #include "../../include/dbat_hip.h"
-#include "chol.hpp"
+#include "chol_df.hpp"
 #include "kernels.hpp"
 #include "plan.hpp"
 
@@ -73,6 +73,8 @@ struct Core {
     DevBuf<double> jn2c, dscale, rhs, Vinv, gp, jn2p, r_w, partial, scal;
     DevBuf<int> info;
     DevBuf<double> ywork, linv;
+    DataflowChol dfchol;                // persistent task-graph Cholesky (chol_df.hpp)
+    bool use_df = true;
     int64_t ldS = 0;
     CholEnvelope env;
     DevBuf<unsigned long long> pivmm;   // [0..1] point pivots min/max, [2..3] reduced-system pivots
@@ -95,6 +97,7 @@ struct Core {
     ~Core() {
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         for (auto &e : kev) if (e) (void)hipEventDestroy(e);
+        dfchol.release();
         if (blas) rocblas_destroy_handle(blas);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -146,6 +149,8 @@ struct Core {
                 for (int k = 0; k < 6; ++k) first[(size_t)6 * c + k] = 6 * P.cam_first[c];
             if (getenv("DBAT_HIP_DENSE_CHOL")) env.build_dense((int)P.NS);
             else env.build((int)P.NS, 6 * P.nc, first);
+            use_df = getenv("DBAT_HIP_BLOCKCHOL") == nullptr;       // the multi-launch BlockChol stays for A/B runs
+            if (use_df && !dfchol.setup(env)) throw DeviceError{"out of device memory (Cholesky schedule)"};
         }
         jn2c.alloc(P.NS); dscale.alloc(P.NS); rhs.alloc(P.NS);
         Vinv.alloc((size_t)6 * P.np); gp.alloc((size_t)3 * P.np); jn2p.alloc((size_t)3 * P.np);
@@ -307,8 +312,9 @@ struct Core {
     // ---- K6: Cholesky of the reduced system; returns 0 or the failing pivot
     int factor_solve_enqueue() {
         mark(2);
-        // blocked Cholesky + both substitutions (chol.hpp); q -> rhs
-        BlockChol::solve(blas, stream, S, ldS, (int)P.NS, rhs.p, ywork.p, linv.p, info.p, env);
+        // Cholesky + both substitutions; q -> rhs.  One persistent dataflow kernel (chol_df.hpp)
+        if (use_df) dfchol.solve(stream, S, ldS, rhs.p, linv.p, info.p);
+        else BlockChol::solve(blas, stream, S, ldS, (int)P.NS, rhs.p, ywork.p, linv.p, info.p, env);
         mark(3);
         hipLaunchKernelGGL(k_diag_minmax, dim3(1), dim3(256), 0, stream, d, S, pivmm.p + 2);
         hipLaunchKernelGGL(k_unscale, dim3((unsigned)cdiv(P.NS, 256)), dim3(256), 0, stream, P.NS, rhs.p, dscale.p, dz.p);
