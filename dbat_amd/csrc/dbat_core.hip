@@ -64,7 +64,8 @@ struct Core {
     DevBuf<uint8_t> tile_cam_io;
     int tile_ncx = 6;
     int64_t ntiles = 0;
-    size_t lds_tile = 0;
+    size_t lds_tile = 0, lds_tile2 = 0;
+    bool use_tile2 = true;
     DevBuf<int64_t> o_row, batch_start, x2z;
     // state
     DevBuf<CamRec> cams;
@@ -168,6 +169,10 @@ struct Core {
         lds_back = (size_t)P.BT * 6 * sizeof(double);
         lds_tile = ((size_t)2 * 3 * TILE_PC * TILE_LD + (size_t)P.BT * 9 + (size_t)36 * P.CMAX + 3 * TILE_LD +
                     (P.with_io ? (size_t)P.CMAX * 6 * 16 + 256 : 0)) * sizeof(double);
+        lds_tile2 = ((size_t)2 * 2 * 3 * TILE2_PC * TILE_LD + (size_t)256 * 9 + (size_t)128 * 9 + (size_t)36 * P.CMAX +
+                     3 * TILE_LD) * sizeof(double);
+        // the wave-specialised tile kernel covers the fixed-IO case with 256-observation batches
+        use_tile2 = P.BT == 256 && !P.with_io && getenv("DBAT_HIP_TILE_V1") == nullptr;
         partial.alloc((size_t)4 * std::max<int64_t>(std::max<int64_t>(nb + ntiles, 2048), 1));
         set_lds_limits();
         HIPCHK(hipMemcpy(z.p, P.z0.data(), P.NZ * 8, hipMemcpyHostToDevice));
@@ -184,6 +189,10 @@ struct Core {
         SET_LDS((k_build_tile<4, 14>), lds_tile); SET_LDS((k_build_tile<5, 14>), lds_tile);
         SET_LDS((k_build_tile<2, MAXCOL>), lds_tile); SET_LDS((k_build_tile<3, MAXCOL>), lds_tile);
         SET_LDS((k_build_tile<4, MAXCOL>), lds_tile); SET_LDS((k_build_tile<5, MAXCOL>), lds_tile);
+        if (use_tile2) {
+            SET_LDS((k_build_tile2<2>), lds_tile2); SET_LDS((k_build_tile2<3>), lds_tile2);
+            SET_LDS((k_build_tile2<4>), lds_tile2); SET_LDS((k_build_tile2<5>), lds_tile2);
+        }
         SET_LDS((k_build<2, false>), lds_build); SET_LDS((k_build<3, false>), lds_build);
         SET_LDS((k_build<4, false>), lds_build); SET_LDS((k_build<5, false>), lds_build);
         SET_LDS((k_build<2, true>), lds_build); SET_LDS((k_build<3, true>), lds_build);
@@ -265,10 +274,13 @@ struct Core {
         if (ntiles > 0 && nb_tiled > 0) {
             npart = ntiles;
 #define L_TILE(M, NCXV) hipLaunchKernelGGL((k_build_tile<M, NCXV>), dim3((unsigned)ntiles), dim3(P.BT), lds_tile, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p, pivmm.p)
-            if (tile_ncx == 6) { DISPATCH_MODEL(L_TILE, 6) }
+#define L_TILE2(M, NCXV) hipLaunchKernelGGL((k_build_tile2<M>), dim3((unsigned)ntiles), dim3(512), lds_tile2, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p, pivmm.p)
+            if (use_tile2 && tile_ncx == 6) { DISPATCH_MODEL(L_TILE2, 6) }
+            else if (tile_ncx == 6) { DISPATCH_MODEL(L_TILE, 6) }
             else if (tile_ncx == 14) { DISPATCH_MODEL(L_TILE, 14) }
             else { DISPATCH_MODEL(L_TILE, MAXCOL) }
 #undef L_TILE
+#undef L_TILE2
         }
         if (nb > nb_tiled) {
 #define L_BUILD(M, IO) hipLaunchKernelGGL((k_build<M, IO>), dim3((unsigned)(nb - nb_tiled)), dim3(P.BT), lds_build, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p + npart, pivmm.p, (int)nb_tiled)
@@ -277,6 +289,17 @@ struct Core {
             npart += nb - nb_tiled;
         }
         mark(1);
+        if ((d.ablate & 32) && use_tile2) {          // phase profile of the wave-specialised tile kernel
+            unsigned long long h[16];
+            HIPCHK(hipStreamSynchronize(stream));
+            HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tile2_prof), sizeof(h)));
+            static const char *nm[10] = {"stage(wait freed+restore)", "P1", "pbarrier", "P2", "P3", "drain", "cons wait full", "cons mfma", "tail/flush", "loop head"};
+            fprintf(stderr, "[tile2 prof, us per tile avg over %d tiles]", (int)ntiles);
+            for (int i = 0; i < 10; ++i) fprintf(stderr, " %s=%.2f", nm[i], h[i] * 0.01 / (double)std::max<int64_t>(ntiles, 1));
+            fprintf(stderr, "\n");
+            memset(h, 0, sizeof(h));
+            HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_tile2_prof), h, sizeof(h)));
+        }
         hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(256), 0, stream, partial.p, npart, red_scal, 0);
         hipLaunchKernelGGL(k_prior_sq, dim3(grid_z), dim3(256), 0, stream, d, zz, partial.p);
         hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(256), 0, stream, partial.p, (int64_t)grid_z, red_scal, 1);
@@ -672,7 +695,7 @@ int dbat_hip_plan(const dbat_hip_problem *prob, int64_t *n_params, int64_t *n_re
     API_TRY
     if (!prob) { g_err = "null problem"; return DBAT_HIP_EINVAL; }
     Plan P;
-    if (!build_plan(*prob, P, false)) { g_err = P.err; return DBAT_HIP_EINVAL; }
+    if (!build_plan(*prob, P, getenv("DBAT_HIP_PLAN_STATS") != nullptr)) { g_err = P.err; return DBAT_HIP_EINVAL; }
     if (n_params) *n_params = P.n;
     if (n_residuals) *n_residuals = P.m;
     if (n_io) *n_io = P.nIO;

@@ -220,6 +220,36 @@ __device__ __forceinline__ void eval_obs_cols_n(const DevProblem &d, const CamRe
     }
 }
 
+// Fixed-IO variant with the operands already in registers (prefetched one batch
+// ahead by k_build_tile2): Q = object point, (u,v), weights, est = bit k set if
+// point coordinate k is estimated.
+template <int MODEL>
+__device__ __forceinline__ void eval_obs_pre(const DevProblem &d, const CamRec &C, const double Q[3], double u,
+                                             double v, double w0, double w1, unsigned est, double r[2],
+                                             double E[2][6], double B[2][3]) {
+    double A[2][6];
+    double Cf[2][MAXIO];
+    obs_eval<MODEL, true, false>(C, d.nK, d.nP, Q, u, v, r, A, B, Cf);
+    r[0] *= w0; r[1] *= w1;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double m = ((est >> k) & 1u) ? 1.0 : 0.0;
+        B[0][k] *= w0 * m; B[1][k] *= w1 * m;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double m = ((C.eo_est >> k) & 1u) ? 1.0 : 0.0;
+        E[0][k] = A[0][k] * w0 * m; E[1][k] = A[1][k] * w1 * m;
+    }
+}
+
+// 1/x by v_rcp_f64 and two Newton steps (no division sequence on the path)
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = r * (2.0 - x * r);
+    return r * (2.0 - x * r);
+}
+
 template <int MODEL, bool WITH_IO>
 __device__ __forceinline__ void eval_obs_cols(const DevProblem &d, const CamRec &C, const double *z,
                                               int64_t o, int pt, double r[2],
@@ -772,6 +802,415 @@ __global__ __launch_bounds__(256) void k_build_tile(DevProblem d, const double *
     double accr[1] = {rr};
     block_sum<1>(accr, sh);
     if (t == 0) partial[blockIdx.x] = accr[0];
+    for (int off = 32; off > 0; off >>= 1) {
+        pmin = fmin(pmin, __shfl_down(pmin, off, 64));
+        pmax = fmax(pmax, __shfl_down(pmax, off, 64));
+    }
+    if ((t & 63) == 0 && pmax > 0.0) {
+        atomicMin(pivmm, (unsigned long long)__double_as_longlong(pmin));
+        atomicMax(pivmm + 1, (unsigned long long)__double_as_longlong(pmax));
+    }
+}
+
+// ---------------------------------------------------------------- K1t2 --
+// Wave-specialised tile kernel for the fixed-IO path: 512 threads.  Waves 0-3
+// ("producers") evaluate the observations of the tile's batches exactly as
+// k_build_tile does (P1-P3) and scatter the Y / W fragments of chunks of
+// TILE2_PC points into one of TWO operand panels in LDS; waves 4-7
+// ("consumers") run the 128 x 128 x 3*PC contraction of a filled panel on the
+// f64 matrix cores and hand the panel back.  Producer w and consumer w+4 share
+// a SIMD, and the hand-over of batch b-1's chunks is interleaved with P1, P2
+// and P3 of batch b (its W and V^-1 stay in registers meanwhile), so the matrix
+// pipe works under the residual/Jacobian arithmetic, the global-load latencies
+// and the LDS atomics instead of after them.
+// Hand-over is by LDS counters (full/freed per panel).  A panel slot is zeroed
+// again by the thread that filled it ("stage") and refilled ("commit") only
+// after a producer barrier, because the slot's next writer is in general a
+// different thread.  The producers synchronise among themselves with a counter
+// barrier; the hardware s_barrier is only used where all eight waves take part.
+// Every spin has a cap that poisons the objective value instead of hanging.
+constexpr int TILE2_PC = 8;
+constexpr int TILE2_SPIN_CAP = 1 << 24;
+
+__device__ unsigned long long g_tile2_prof[16];    // DBAT_HIP_ABLATE & 32: phase times (10 ns ticks), summed over tiles
+
+struct Tile2Sync { int full[2], freed[2], ks[2], pbar, abort_, npts[2]; };
+
+__device__ __forceinline__ void lds_fence() {           // all LDS traffic of this wave has completed
+    __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0)
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ bool lds_wait_ge(int *cnt, int target, int *abort_) {
+    int spins = 0;
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+        __builtin_amdgcn_s_sleep(0);
+        if ((++spins & 1023) == 0) {
+            if (spins > TILE2_SPIN_CAP) __hip_atomic_store(abort_, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (__hip_atomic_load(abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return false;
+        }
+    }
+    asm volatile("" ::: "memory");
+    return true;
+}
+__device__ __forceinline__ void lds_signal(int *cnt) {   // one count per wave
+    lds_fence();
+    if ((threadIdx.x & 63) == 0) atomicAdd(cnt, 1);
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double *__restrict__ z,
+                                                     const CamRec *__restrict__ cams, double lambda, int scale,
+                                                     double *__restrict__ S, double *__restrict__ g_c,
+                                                     double *__restrict__ g_red, double *__restrict__ diagU,
+                                                     double *__restrict__ Vinv, double *__restrict__ gp,
+                                                     double *__restrict__ jn2p, double *__restrict__ r_w,
+                                                     double *__restrict__ partial,
+                                                     unsigned long long *__restrict__ pivmm) {
+    constexpr int PC = TILE2_PC, KC = 3 * PC, LD = TILE_LD, PANEL = 2 * KC * LD;
+    constexpr int NPROD = 256;                       // producer threads = batch size
+    extern __shared__ double smem[];
+    const int CM = d.CMAX;
+    double *pan = smem;                              // [2][Yt KC*LD | Wt KC*LD]
+    double *red = pan + 2 * PANEL;                   // [NPROD][9]  B'B | B'r per observation
+    double *pinv = red + (size_t)NPROD * 9;          // [NPROD/2][9] V^-1 | g_p per point of the batch
+    double *Ud = pinv + (size_t)(NPROD / 2) * 9;     // [CM][36]
+    double *vt = Ud + (size_t)CM * 36;               // [3][LD]
+    __shared__ double sh[16];
+    __shared__ Tile2Sync sy;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(t >> 6);
+    const bool producer = wave8 < 4;
+    const int wave = wave8 & 3;
+    const int tile = blockIdx.x;
+    const int b0 = d.tile_batch[tile], b1 = d.tile_batch[tile + 1];
+    const int c0 = d.tile_cam_start[tile];
+    const int ncam = d.tile_cam_start[tile + 1] - c0;
+    const int nrows = 6 * ncam;
+    for (int i = t; i < 2 * PANEL; i += 512) pan[i] = 0.0;
+    for (int i = t; i < CM * 36 + 3 * LD; i += 512) Ud[i] = 0.0;
+    if (t == 0) { sy.full[0] = sy.full[1] = sy.freed[0] = sy.freed[1] = 0; sy.ks[0] = sy.ks[1] = 0; sy.pbar = 0; sy.abort_ = 0; sy.npts[0] = sy.npts[1] = 0; }
+    mfma_d4 acc[9];
+#pragma unroll
+    for (int s = 0; s < 9; ++s) acc[s] = mfma_d4{0, 0, 0, 0};
+    double pmin = 1e300, pmax = 0.0, rr = 0.0;
+    __syncthreads();
+    const bool prof = (d.ablate & 32) && lane == 0 && wave == 0;
+    long long tp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = prof ? wall_clock64() : 0;
+    auto lap = [&](int i) { if (prof) { const long long now = wall_clock64(); tp[i] += now - tlast; tlast = now; } };
+    if (producer) {
+        int nchunk = 0;                              // chunks handed over so far (panel = nchunk & 1)
+        int pbar_gen = 0;
+        int prev_kb[2] = {-1, -1}, prev_lc[2] = {0, 0};   // what this thread last wrote into each panel
+        bool ok = true;
+        // the batch whose chunks are being handed over (one behind the batch being evaluated)
+        double qW[6][3], qv0 = 0, qv1 = 0, qv2 = 0, qv3 = 0, qv4 = 0, qv5 = 0;
+        int q_pidx = 0, q_lc = 0, q_npts = 0, q_p0 = 0;
+        bool q_active = false, staged = false;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) qW[a][0] = qW[a][1] = qW[a][2] = 0.0;
+        auto pbarrier = [&]() -> bool {
+            lds_signal(&sy.pbar); ++pbar_gen;
+            return lds_wait_ge(&sy.pbar, 4 * pbar_gen, &sy.abort_);
+        };
+        // stage: wait until the consumers have released the panel of the next chunk and zero
+        // what this thread wrote there before
+        auto stage = [&]() {
+            if (!(q_p0 < q_npts) || !ok) return;
+            const int s = nchunk & 1, u = nchunk >> 1;
+            if (u > 0 && !lds_wait_ge(&sy.freed[s], 4 * u, &sy.abort_)) { ok = false; return; }
+            if (prev_kb[s] >= 0) {
+                double *Yt = pan + s * PANEL, *Wt = Yt + KC * LD;
+                const int kb = prev_kb[s], row0 = 6 * prev_lc[s];
+#pragma unroll
+                for (int a = 0; a < 6; ++a)
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) { Wt[(kb + e) * LD + row0 + a] = 0.0; Yt[(kb + e) * LD + row0 + a] = 0.0; }
+                prev_kb[s] = -1;
+            }
+            staged = true;
+        };
+        // commit (after a producer barrier): scatter the chunk and hand it to the consumers
+        auto commit = [&]() {
+            if (!staged || !ok) return;
+            staged = false;
+            const int s = nchunk & 1;
+            double *Yt = pan + s * PANEL, *Wt = Yt + KC * LD;
+            if (q_active && q_pidx >= q_p0 && q_pidx < q_p0 + PC) {
+                const int kb = 3 * (q_pidx - q_p0), row0 = 6 * q_lc;
+                prev_kb[s] = kb; prev_lc[s] = q_lc;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    const double w0 = qW[a][0], w1 = qW[a][1], w2 = qW[a][2];
+                    Wt[(kb + 0) * LD + row0 + a] = w0; Wt[(kb + 1) * LD + row0 + a] = w1; Wt[(kb + 2) * LD + row0 + a] = w2;
+                    Yt[(kb + 0) * LD + row0 + a] = w0 * qv0 + w1 * qv1 + w2 * qv2;
+                    Yt[(kb + 1) * LD + row0 + a] = w0 * qv1 + w1 * qv3 + w2 * qv4;
+                    Yt[(kb + 2) * LD + row0 + a] = w0 * qv2 + w1 * qv4 + w2 * qv5;
+                }
+            }
+            if (t == 0) sy.ks[s] = (3 * min(PC, q_npts - q_p0) + 3) >> 2;
+            lds_signal(&sy.full[s]);
+            ++nchunk; q_p0 += PC;
+        };
+        // observation header of the next batch and the object point of its observations are
+        // fetched one batch ahead, so their HBM latency hides behind the current batch
+        int hn_cam = 0, hn_pt = 0, hn_lc = 0, hn_pidx = 0; uint32_t hn_sg = 0; double hn_u = 0, hn_v = 0;
+        double qn[3] = {0, 0, 0}, pwn[3] = {0, 0, 0}; unsigned estn = 0;
+        auto fetch_header = [&](int bb) {
+            if (bb >= b1) return;
+            const int64_t oo0 = d.batch_start[bb];
+            if (t < (int)(d.batch_start[bb + 1] - oo0)) {
+                const int64_t oo = oo0 + t;
+                hn_cam = d.o_cam[oo]; hn_pt = d.o_pt[oo]; hn_lc = d.o_lc[oo]; hn_pidx = d.o_pidx[oo];
+                hn_sg = d.o_seg[oo]; hn_u = d.o_uv[2 * oo]; hn_v = d.o_uv[2 * oo + 1];
+            }
+        };
+        auto fetch_point = [&](int bb) {
+            if (bb >= b1) return;
+            if (t < (int)(d.batch_start[bb + 1] - d.batch_start[bb])) {
+                const int64_t zp = d.NS + 3 * (int64_t)hn_pt;
+                qn[0] = z[zp]; qn[1] = z[zp + 1]; qn[2] = z[zp + 2];
+                estn = (d.z_est[zp] ? 1u : 0u) | (d.z_est[zp + 1] ? 2u : 0u) | (d.z_est[zp + 2] ? 4u : 0u);
+                if (t == (int)(hn_sg & 0xFFFF)) { pwn[0] = d.z_prw[zp]; pwn[1] = d.z_prw[zp + 1]; pwn[2] = d.z_prw[zp + 2]; }
+            }
+        };
+        fetch_header(b0);
+        fetch_point(b0);
+        for (int b = b0; b < b1 && ok; ++b) {
+            const int64_t o0 = d.batch_start[b];
+            const int nobs = (int)(d.batch_start[b + 1] - o0);
+            const bool active = t < nobs;
+            const int64_t o = o0 + t;
+            int *npts_sh = &sy.npts[b & 1];
+            double r[2] = {0, 0};
+            double E[2][6];
+            double B[2][3];
+            const int cam = hn_cam, pt = hn_pt, lc = hn_lc, pidx = hn_pidx;
+            const int seg_start = hn_sg & 0xFFFF, seg_len = hn_sg >> 16;
+            const double uu = hn_u, vv = hn_v;
+            const double Q[3] = {qn[0], qn[1], qn[2]};
+            const double pw3[3] = {pwn[0], pwn[1], pwn[2]};
+            const unsigned est = estn;
+            if (t == 0) *npts_sh = 0;
+            fetch_header(b + 1);
+            lap(9);
+            stage();
+            lap(0);
+            if (active) {                            // ---- P1
+                const CamRec &C = cams[cam];
+                const double w0 = d.o_w ? d.o_w[2 * o] : C.w[0], w1 = d.o_w ? d.o_w[2 * o + 1] : C.w[1];
+                eval_obs_pre<MODEL>(d, C, Q, uu, vv, w0, w1, est, r, E, B);
+                r_w[2 * o] = r[0]; r_w[2 * o + 1] = r[1];
+                rr += r[0] * r[0] + r[1] * r[1];
+                double *rd = red + (size_t)t * 9;
+                rd[0] = B[0][0] * B[0][0] + B[1][0] * B[1][0];
+                rd[1] = B[0][0] * B[0][1] + B[1][0] * B[1][1];
+                rd[2] = B[0][0] * B[0][2] + B[1][0] * B[1][2];
+                rd[3] = B[0][1] * B[0][1] + B[1][1] * B[1][1];
+                rd[4] = B[0][1] * B[0][2] + B[1][1] * B[1][2];
+                rd[5] = B[0][2] * B[0][2] + B[1][2] * B[1][2];
+                rd[6] = B[0][0] * r[0] + B[1][0] * r[1];
+                rd[7] = B[0][1] * r[0] + B[1][1] * r[1];
+                rd[8] = B[0][2] * r[0] + B[1][2] * r[1];
+            }
+            fetch_point(b + 1);
+            lap(1);
+            if (!pbarrier()) { ok = false; break; }
+            lap(2);
+            commit();
+            stage();
+            lap(0);
+            if (active && t == seg_start) {          // ---- P2
+                atomicMax(npts_sh, pidx + 1);
+                double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+                for (int j = 0; j < seg_len; ++j) {
+                    const double *rd = red + (size_t)(t + j) * 9;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) V[k] += rd[k];
+                    g[0] += rd[6]; g[1] += rd[7]; g[2] += rd[8];
+                }
+                const int64_t zp = d.NS + 3 * (int64_t)pt;
+                const int dix[3] = {0, 3, 5};
+                double jn[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const double pw = pw3[k];
+                    if (pw > 0) { V[dix[k]] += pw; g[k] += pw * (Q[k] - d.z_prv[zp + k]); }
+                    jn[k] = V[dix[k]];
+                    jn2p[3 * (int64_t)pt + k] = jn[k];
+                    if ((est >> k) & 1u) V[dix[k]] += lambda; else V[dix[k]] = 1.0;
+                }
+                double inv[6];
+                {   // adjugate inverse and the SQUARED pivots of chol(V) (the square roots are taken
+                    // once per wave at the end of the kernel)
+                    const double c00 = V[3] * V[5] - V[4] * V[4];
+                    const double c01 = V[2] * V[4] - V[1] * V[5];
+                    const double c02 = V[1] * V[4] - V[2] * V[3];
+                    const double det = V[0] * c00 + V[1] * c01 + V[2] * c02;
+                    const double id = fast_rcp(det);
+                    inv[0] = c00 * id; inv[1] = c01 * id; inv[2] = c02 * id;
+                    inv[3] = (V[0] * V[5] - V[2] * V[2]) * id;
+                    inv[4] = (V[1] * V[2] - V[0] * V[4]) * id;
+                    inv[5] = (V[0] * V[3] - V[1] * V[1]) * id;
+                    const double r0 = fast_rcp(V[0]);
+                    const double d1s = V[3] - V[1] * V[1] * r0;
+                    const double tt = V[4] - V[2] * V[1] * r0;
+                    const double d2s = V[5] - V[2] * V[2] * r0 - tt * tt * fast_rcp(d1s);
+                    const double dd[3] = {V[0], d1s, d2s};
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        if ((est >> k) & 1u) {
+                            double v = scale ? dd[k] * fast_rcp(jn[k]) : dd[k];
+                            v = v > 0.0 ? v : 0.0;                  // NaN or negative pivot => 0
+                            pmin = fmin(pmin, v); pmax = fmax(pmax, v);
+                        }
+                }
+                double *pi = pinv + (size_t)pidx * 9;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { pi[k] = inv[k]; Vinv[6 * (int64_t)pt + k] = inv[k]; }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { pi[6 + k] = g[k]; gp[3 * (int64_t)pt + k] = g[k]; }
+            }
+            lap(3);
+            if (!pbarrier()) { ok = false; break; }
+            lap(2);
+            commit();
+            stage();
+            lap(0);
+            const int npts = *npts_sh;
+            double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
+            if (active) {                            // ---- P3: E'E, gradient pieces
+                const double *pi = pinv + (size_t)pidx * 9;
+                v0 = pi[0]; v1 = pi[1]; v2 = pi[2]; v3 = pi[3]; v4 = pi[4]; v5 = pi[5];
+                const double g0 = pi[6], g1 = pi[7], g2 = pi[8];
+                double *ud = Ud + (size_t)lc * 36;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    const double w0 = E[0][a] * B[0][0] + E[1][a] * B[1][0];
+                    const double w1 = E[0][a] * B[0][1] + E[1][a] * B[1][1];
+                    const double w2 = E[0][a] * B[0][2] + E[1][a] * B[1][2];
+                    const double y0 = w0 * v0 + w1 * v1 + w2 * v2;
+                    const double y1 = w0 * v1 + w1 * v3 + w2 * v4;
+                    const double y2 = w0 * v2 + w1 * v4 + w2 * v5;
+                    const double ga = E[0][a] * r[0] + E[1][a] * r[1];
+                    const int ra = 6 * lc + a;
+                    atomic_add_f64(vt + ra, ga);
+                    atomic_add_f64(vt + LD + ra, ga - (y0 * g0 + y1 * g1 + y2 * g2));
+                    atomic_add_f64(vt + 2 * LD + ra, E[0][a] * E[0][a] + E[1][a] * E[1][a]);
+#pragma unroll
+                    for (int b2 = a; b2 < 6; ++b2)
+                        atomic_add_f64(ud + a * 6 + b2, E[0][a] * E[0][b2] + E[1][a] * E[1][b2]);
+                }
+            }
+            lap(4);
+            // drain what is left of the previous batch, then queue this one
+            while (ok && (staged || q_p0 < q_npts)) {
+                if (!staged) stage();
+                if (!pbarrier()) { ok = false; break; }
+                commit();
+            }
+            lap(5);
+            if (!ok) break;
+            q_active = active; q_pidx = pidx; q_lc = lc; q_npts = npts; q_p0 = 0;
+            qv0 = v0; qv1 = v1; qv2 = v2; qv3 = v3; qv4 = v4; qv5 = v5;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                qW[a][0] = E[0][a] * B[0][0] + E[1][a] * B[1][0];
+                qW[a][1] = E[0][a] * B[0][1] + E[1][a] * B[1][1];
+                qW[a][2] = E[0][a] * B[0][2] + E[1][a] * B[1][2];
+            }
+        }
+        while (ok && (staged || q_p0 < q_npts)) {    // the last batch
+            if (!staged) stage();
+            if (!pbarrier()) { ok = false; break; }
+            commit();
+        }
+        {   // terminating chunk
+            const int s = nchunk & 1, u = nchunk >> 1;
+            if (ok && u > 0) ok = lds_wait_ge(&sy.freed[s], 4 * u, &sy.abort_);
+            if (t == 0) sy.ks[s] = -1;
+            lds_signal(&sy.full[s]);
+        }
+        if (!ok) rr = __longlong_as_double(0x7ff8000000000000ll);      // poison the objective value
+    } else {
+        // ---- consumers: this wave's nine 16x16 tiles of the lower triangle
+        const bool full_tile = 16 * (7 - wave) < nrows;
+        int yoff[9], woff[9];
+        bool ton[9];
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            const int rt = s <= wave ? wave : 7 - wave;
+            const int ct = s <= wave ? s : s - wave - 1;
+            yoff[s] = 16 * rt; woff[s] = 16 * ct; ton[s] = 16 * rt < nrows;
+        }
+        for (int n = 0;; ++n) {
+            const int s = n & 1, u = n >> 1;
+            if (!lds_wait_ge(&sy.full[s], 4 * (u + 1), &sy.abort_)) break;
+            lap(6);
+            const int ksteps = __hip_atomic_load(&sy.ks[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (ksteps < 0) break;
+            const double *Yt = pan + s * PANEL, *Wt = Yt + KC * LD;
+            if (full_tile) {
+                switch (wave) {
+                    case 0: tile_mfma_steps<0>(Yt, Wt, lane, ksteps, acc); break;
+                    case 1: tile_mfma_steps<1>(Yt, Wt, lane, ksteps, acc); break;
+                    case 2: tile_mfma_steps<2>(Yt, Wt, lane, ksteps, acc); break;
+                    default: tile_mfma_steps<3>(Yt, Wt, lane, ksteps, acc); break;
+                }
+            } else {
+                for (int kk = 0; kk < ksteps; ++kk) {
+                    const int krow = 4 * kk + (lane >> 4);
+                    const double *yr = Yt + krow * LD + (lane & 15);
+                    const double *wr = Wt + krow * LD + (lane & 15);
+#pragma unroll
+                    for (int q = 0; q < 9; ++q)
+                        if (ton[q])
+                            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(yr[yoff[q]], wr[woff[q]], acc[q], 0, 0, 0);
+                }
+            }
+            lds_signal(&sy.freed[s]);
+            lap(7);
+        }
+        // ---- flush this wave's part of the tile:  S -= sum_p Y W'
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            if (ton[s]) {
+                const int lcol = woff[s] + (lane & 15);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int lr = yoff[s] + (lane >> 4) + 4 * e;
+                    const double v = acc[s][e];
+                    if (lr < nrows && lcol <= lr && v != 0.0)
+                        atomic_add_f64(S + (6 * (int64_t)d.tile_cams[c0 + lcol / 6] + lcol % 6) * d.ldS +
+                                           6 * (int64_t)d.tile_cams[c0 + lr / 6] + lr % 6, -v);
+                }
+            }
+        }
+    }
+    lap(8);
+    __syncthreads();
+    if (prof) {
+        const int base = producer ? 0 : 0;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) if (tp[i]) atomicAdd(&g_tile2_prof[base + i], (unsigned long long)tp[i]);
+    }
+    // ---- J_c'J_c, gradient pieces (all 512 threads)
+    for (int i = t; i < ncam * 36; i += 512) {
+        const int lcam = i / 36, e = i - lcam * 36;
+        const int a = e / 6, b2 = e - a * 6;
+        if (b2 < a) continue;
+        const int64_t cb = 6 * (int64_t)d.tile_cams[c0 + lcam];
+        atomic_add_f64(S + (cb + a) * d.ldS + (cb + b2), Ud[i]);
+    }
+    for (int i = t; i < nrows; i += 512) {
+        const int64_t col = 6 * (int64_t)d.tile_cams[c0 + i / 6] + i % 6;
+        atomic_add_f64(g_c + col, vt[i]);
+        atomic_add_f64(g_red + col, vt[LD + i]);
+        atomic_add_f64(diagU + col, vt[2 * LD + i]);
+    }
+    double accr[1] = {rr};
+    block_sum<1>(accr, sh);
+    if (t == 0) partial[blockIdx.x] = accr[0];
+    pmin = pmin < 1e300 ? sqrt(pmin) : pmin; pmax = sqrt(pmax);   // squared pivots were tracked
     for (int off = 32; off > 0; off >>= 1) {
         pmin = fmin(pmin, __shfl_down(pmin, off, 64));
         pmax = fmax(pmax, __shfl_down(pmax, off, 64));

@@ -425,6 +425,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     int32_t tile_id = 0;
     int pidx = 0;
     bool in_heavy = false;
+    const int tile_bmax = std::max(1, env_int0("DBAT_HIP_TILE_BMAX", 16));   // batches per tile
     for (int64_t i = P.pt_lo; i < P.pt_hi; ++i) {
         const int32_t p = P.porder[i];
         const int k = k_pt[p];
@@ -452,8 +453,12 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
                     if (!f && fresh_io <= Plan::IOT) fio[fresh_io++] = io;
                 }
             }
+            // a tile is one workgroup's work: cap its length, otherwise a long run of points seen
+            // by the same few cameras becomes the tail of the whole launch
+            const int64_t tile_nb = (int64_t)P.batch_start.size() - 1 - P.tile_batch.back();   // closed batches
+            const bool too_long = pos - bstart + k > P.BT && tile_nb + 1 >= tile_bmax;
             const bool over = (int)cur_cams.size() + fresh > P.CMAX ||
-                              (int)cur_io.size() + fresh_io > Plan::IOT;
+                              (int)cur_io.size() + fresh_io > Plan::IOT || too_long;
             if (over && pos > tile_first_obs) {
                 // close the current batch and tile before this point
                 P.batch_start.push_back(pos); bstart = pos;
@@ -492,6 +497,15 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         P.nb_tiled = (int64_t)P.batch_start.size() - 1;
     }
     if (!P.CMAX) P.nb_tiled = 0;
+    if (getenv("DBAT_HIP_PLAN_STATS") && P.tile_batch.size() > 1) {      // tile size distribution
+        std::vector<int> nbt;
+        for (size_t i = 0; i + 1 < P.tile_batch.size(); ++i) nbt.push_back(P.tile_batch[i + 1] - P.tile_batch[i]);
+        std::sort(nbt.begin(), nbt.end());
+        double s = 0; for (int v : nbt) s += v;
+        fprintf(stderr, "[plan] %zu tiles, batches/tile min %d median %d mean %.1f p90 %d p99 %d max %d; cams/tile mean %.1f\n",
+                nbt.size(), nbt.front(), nbt[nbt.size() / 2], s / nbt.size(), nbt[nbt.size() * 9 / 10],
+                nbt[nbt.size() * 99 / 100], nbt.back(), (double)P.tile_cams.size() / nbt.size());
+    }
     return true;
 }
 
