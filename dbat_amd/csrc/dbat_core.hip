@@ -82,6 +82,12 @@ struct Core {
     DevBuf<double> mmx;                 // [2*nranks] min/max exchange through the sum-all-reduce
     double *S = nullptr, *g_red = nullptr, *g_c = nullptr, *diagU = nullptr, *red_scal = nullptr;
     int64_t red_count = 0;
+    // multi-GPU: envelope of S + the vectors, contiguous (what the all-reduce carries)
+    DevBuf<double> pk;
+    DevBuf<int> col_bend;
+    DevBuf<int64_t> col_off;
+    int64_t pk_s_count = 0;
+    int env_tail0 = 0;
     int64_t nb = 0, nobs = 0;
     int grid_obs = 1, grid_z = 1;
     size_t lds_build = 0, lds_back = 0;
@@ -150,6 +156,19 @@ struct Core {
                 for (int k = 0; k < 6; ++k) first[(size_t)6 * c + k] = 6 * P.cam_first[c];
             if (getenv("DBAT_HIP_DENSE_CHOL")) env.build_dense((int)P.NS);
             else env.build((int)P.NS, 6 * P.nc, first);
+            {   // packed layout of the envelope for the all-reduce
+                const int NSi = (int)P.NS;
+                std::vector<int> cb((size_t)NSi);
+                std::vector<int64_t> co((size_t)NSi + 1, 0);
+                env_tail0 = env.tail0;
+                for (int c = 0; c < NSi; ++c) {
+                    const int be = c >= env.tail0 ? c : std::min(std::max(env.band_end[c / CHOL_NB], c + 1), env.tail0);
+                    cb[c] = be;
+                    co[c + 1] = co[c] + (be - c) + (NSi - std::max(env.tail0, be));
+                }
+                pk_s_count = co[NSi];
+                col_bend.upload(cb); col_off.upload(co);
+            }
             use_df = getenv("DBAT_HIP_BLOCKCHOL") == nullptr;       // the multi-launch BlockChol stays for A/B runs
             if (use_df && !dfchol.setup(env)) throw DeviceError{"out of device memory (Cholesky schedule)"};
         }
@@ -203,6 +222,21 @@ struct Core {
     // ---- helpers
     void sync() { HIPCHK(hipStreamSynchronize(stream)); }
     void mark(int i) { if (timing) HIPCHK(hipEventRecord(kev[i], stream)); }
+    // sum of [S | g_red | g_c | diagU | scalars] over the ranks: the envelope of S is packed
+    // next to the vectors, one all-reduce, unpacked again
+    void allreduce_system() {
+        if (!allreduce) return;
+        if (getenv("DBAT_HIP_DENSE_ALLREDUCE")) { do_allreduce(red.p, red_count); return; }
+        const int64_t nvec = 3 * P.NS + 8;
+        if (!pk.p) pk.alloc((size_t)(pk_s_count + nvec));
+        hipLaunchKernelGGL(k_pack_envelope, dim3((unsigned)P.NS), dim3(256), 0, stream, S, ldS, (int)P.NS, env_tail0,
+                           col_bend.p, col_off.p, pk.p, 1);
+        HIPCHK(hipMemcpyAsync(pk.p + pk_s_count, g_red, nvec * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        do_allreduce(pk.p, pk_s_count + nvec);
+        hipLaunchKernelGGL(k_pack_envelope, dim3((unsigned)P.NS), dim3(256), 0, stream, S, ldS, (int)P.NS, env_tail0,
+                           col_bend.p, col_off.p, pk.p, 0);
+        HIPCHK(hipMemcpyAsync(g_red, pk.p + pk_s_count, nvec * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    }
     void do_allreduce(double *buf, int64_t count) {
         if (allreduce) {     // installed only by multi-rank drivers (a one-rank group exercises the same path)
             if (allreduce(allreduce_user, buf, count, (void *)stream) != 0) throw DeviceError{"all-reduce callback failed"};
@@ -309,7 +343,7 @@ struct Core {
     }
     void build(const double *zz, double lambda, int scale) {
         build_enqueue(zz, lambda, scale);
-        do_allreduce(red.p, red_count);
+        allreduce_system();
         finish_enqueue(zz, lambda, scale);
         if (zz != zlin.p) HIPCHK(hipMemcpyAsync(zlin.p, zz, P.NZ * 8, hipMemcpyDeviceToDevice, stream));
         // trace(J'J): camera part from jn2c (estimated), point part from red_scal[1]
@@ -1003,7 +1037,7 @@ int dbat_hip_bench_step(dbat_hip_handle *h, double lambda, int32_t scale_columns
     c.timing = true;
     HIPCHK(hipEventRecord(c.ev[0], c.stream));
     c.build_enqueue(c.z.p, lambda, scale_columns);
-    c.do_allreduce(c.red.p, c.red_count);
+    c.allreduce_system();
     c.finish_enqueue(c.z.p, lambda, scale_columns);
     HIPCHK(hipMemcpyAsync(c.zlin.p, c.z.p, c.P.NZ * 8, hipMemcpyDeviceToDevice, c.stream));
     HIPCHK(hipEventRecord(c.ev[1], c.stream));

@@ -1221,6 +1221,28 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
     }
 }
 
+// Envelope of S <-> contiguous buffer (multi-GPU: only the envelope of the
+// reduced system travels through the all-reduce).  Column c owns the rows
+// [c, col_bend[c]) of the co-visibility band and the dense tail rows
+// [max(tail0, col_bend[c]), NS); its packed run starts at col_off[c].
+// to_packed = 1: S -> buf, 0: buf -> S.
+__global__ __launch_bounds__(256) void k_pack_envelope(double *__restrict__ S, int64_t ldS, int NS, int tail0,
+                                                       const int *__restrict__ col_bend,
+                                                       const int64_t *__restrict__ col_off,
+                                                       double *__restrict__ buf, int to_packed) {
+    const int c = blockIdx.x;
+    const int be = col_bend[c];
+    const int nband = be - c;
+    const int t0 = max(tail0, be);
+    const int ntot = nband + (NS - t0);
+    double *col = S + (int64_t)c * ldS;
+    double *pk = buf + col_off[c];
+    for (int i = threadIdx.x; i < ntot; i += 256) {
+        const int r = i < nband ? c + i : t0 + (i - nband);
+        if (to_packed) pk[i] = col[r]; else col[r] = pk[i];
+    }
+}
+
 // min/max of the Cholesky pivots of the reduced system (estimated entries only)
 __global__ __launch_bounds__(256) void k_diag_minmax(DevProblem d, const double *__restrict__ S,
                                                      unsigned long long *__restrict__ pivmm) {
