@@ -1146,8 +1146,9 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
             const int s = n & 1, u = n >> 1;
             if (!lds_wait_ge(&sy.full[s], 4 * (u + 1), &sy.abort_)) break;
             lap(6);
-            const int ksteps = __hip_atomic_load(&sy.ks[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            int ksteps = __hip_atomic_load(&sy.ks[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (ksteps < 0) break;
+            if (d.ablate & 8) ksteps = 0;                // profiling: hand-over without the matrix work
             const double *Yt = pan + s * PANEL, *Wt = Yt + KC * LD;
             if (full_tile) {
                 switch (wave) {
