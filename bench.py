@@ -151,7 +151,7 @@ def main():
             traffic = json.load(open(tpath)).get('traffic_bytes_per_launch')   # PMC, see profiles/
         t_build = ms[4] * 1e-3
         mfma_binds = flops_schur / (FP64_PEAK_TFLOPS * 1e12) > bytes_build / (HBM_PEAK_GBS * 1e9)
-        kname = 'k_build_tile' if info['n_tiles'] > 0 else 'k_build'
+        kname = ('k_build_tile2' if info['ncolmax'] <= 6 else 'k_build_tile') if info['n_tiles'] > 0 else 'k_build'
         if mfma_binds:
             ach = flops_schur / t_build / 1e12
             roof = {'kernel': kname, 'bound': 'mfma', 'achieved': ach, 'peak': FP64_PEAK_TFLOPS,
