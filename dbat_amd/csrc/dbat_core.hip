@@ -66,7 +66,10 @@ struct Core {
     int64_t ntiles = 0;
     size_t lds_tile = 0, lds_tile2 = 0;
     bool use_tile2 = true;
-    DevBuf<int64_t> o_row, batch_start, x2z;
+    DevBuf<int64_t> o_row, batch_start, x2z, giant_start;
+    DevBuf<double> giant_W;
+    int64_t ngiant = 0;
+    int giant_threads = 256;            // DBAT_HIP_GIANT_THREADS (64/128/256): tests force several chunks per point
     // state
     DevBuf<CamRec> cams;
     DevBuf<double> z, zt, dz, zlin, vtmp, vtmp2, xbuf;  // NZ each (xbuf: n)
@@ -138,6 +141,13 @@ struct Core {
         d.o_seg = o_seg.p; d.o_row = o_row.p; d.batch_start = batch_start.p;
         d.CMAX = P.CMAX; d.ablate = getenv("DBAT_HIP_ABLATE") ? atoi(getenv("DBAT_HIP_ABLATE")) : 0;
         d.ntiles = (int)ntiles; d.o_lc = o_lc.p; d.o_pidx = o_pidx.p;
+        ngiant = P.giant_start.empty() ? 0 : (int64_t)P.giant_start.size() - 1;
+        if (ngiant > 0) {
+            giant_start.upload(P.giant_start);
+            giant_W.alloc((size_t)(P.giant_start.back() - P.giant_start.front()) * P.ncolmax * 3);
+        }
+        d.ngiant = (int)ngiant; d.giant_start = giant_start.p; d.giant_W = giant_W.p;
+        if (const char *e = getenv("DBAT_HIP_GIANT_THREADS")) { const int v = atoi(e); if (v == 64 || v == 128) giant_threads = v; }
         d.tile_batch = tile_batch.p; d.tile_cam_start = tile_cam_start.p; d.tile_cams = tile_cams.p;
         d.tile_io_start = tile_io_start.p; d.tile_iocols = tile_iocols.p; d.tile_cam_io = tile_cam_io.p;
         cams.alloc(P.nc);
@@ -192,7 +202,7 @@ struct Core {
                      3 * TILE_LD) * sizeof(double);
         // the wave-specialised tile kernel covers the fixed-IO case with 256-observation batches
         use_tile2 = P.BT == 256 && !P.with_io && getenv("DBAT_HIP_TILE_V1") == nullptr;
-        partial.alloc((size_t)4 * std::max<int64_t>(std::max<int64_t>(nb + ntiles, 2048), 1));
+        partial.alloc((size_t)4 * std::max<int64_t>(std::max<int64_t>(nb + ntiles + ngiant, 2048), 1));
         set_lds_limits();
         HIPCHK(hipMemcpy(z.p, P.z0.data(), P.NZ * 8, hipMemcpyHostToDevice));
         HIPCHK(hipMemset(dz.p, 0, P.NZ * 8));
@@ -322,6 +332,12 @@ struct Core {
 #undef L_BUILD
             npart += nb - nb_tiled;
         }
+        if (ngiant > 0) {                            // points with more observations than a batch holds
+#define L_GIANT(M, IO) hipLaunchKernelGGL((k_build_giant<M, IO>), dim3((unsigned)ngiant), dim3(giant_threads), 0, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p + npart, pivmm.p)
+            if (P.with_io) { DISPATCH_MODEL(L_GIANT, true) } else { DISPATCH_MODEL(L_GIANT, false) }
+#undef L_GIANT
+            npart += ngiant;
+        }
         mark(1);
         if ((d.ablate & 32) && use_tile2) {          // phase profile of the wave-specialised tile kernel
             unsigned long long h[16];
@@ -386,8 +402,13 @@ struct Core {
             if (P.with_io) { DISPATCH_MODEL(L_BACK, true) } else { DISPATCH_MODEL(L_BACK, false) }
 #undef L_BACK
         }
+        if (ngiant > 0) {
+#define L_BACKG(M, IO) hipLaunchKernelGGL((k_backsub_giant<M, IO>), dim3((unsigned)ngiant), dim3(giant_threads), 0, stream, d, zlin.p, cams.p, Vinv.p, gp.p, r_w.p, dz.p, partial.p + 2 * nb)
+            if (P.with_io) { DISPATCH_MODEL(L_BACKG, true) } else { DISPATCH_MODEL(L_BACKG, false) }
+#undef L_BACKG
+        }
         mark(5);
-        hipLaunchKernelGGL((k_sum_partials<2>), dim3(1), dim3(256), 0, stream, partial.p, nb, scal.p, 0);
+        hipLaunchKernelGGL((k_sum_partials<2>), dim3(1), dim3(256), 0, stream, partial.p, nb + ngiant, scal.p, 0);
         hipLaunchKernelGGL(k_prior_jv, dim3(grid_z), dim3(256), 0, stream, d, zlin.p, dz.p, partial.p);
         hipLaunchKernelGGL((k_sum_partials<3>), dim3(1), dim3(256), 0, stream, partial.p, (int64_t)grid_z, scal.p + 4, 0);
     }

@@ -50,6 +50,10 @@ struct DevProblem {
     const int32_t *tile_batch, *tile_cam_start, *tile_cams;
     const int32_t *tile_io_start, *tile_iocols;     // IO columns (IOu indices) of every tile
     const uint8_t *tile_cam_io;                     // [#tile cams][16] local IO row of a camera's j-th IO column
+    // "giant" points: more observations than a batch holds; one workgroup per point
+    int ngiant;
+    const int64_t *giant_start;                     // [ngiant+1] first observation (processing order)
+    double *giant_W;                                // scratch [n giant observations][3*ncolmax]  W = E'B
 };
 
 __device__ __forceinline__ void atomic_add_f64(double *p, double v) {
@@ -448,6 +452,202 @@ __global__ __launch_bounds__(256) void k_build(DevProblem d, const double *__res
         atomicMin(pivmm, (unsigned long long)__double_as_longlong(pmin));
         atomicMax(pivmm + 1, (unsigned long long)__double_as_longlong(pmax));
     }
+}
+
+// ---------------------------------------------------------------- K1g ---
+// k_build for an object point with more observations than one batch holds
+// (a control point seen in hundreds of images): one workgroup per point, the
+// observations in chunks of blockDim.  Pass 1 evaluates every observation
+// (residual, E'E, gradient pieces, W = E'B to scratch) and sums V = B'B, B'r
+// over the whole point; then V^-1; pass 2 removes (W V^-1) g_p from the reduced
+// right-hand side and adds the k^2 pair terms  -Y_i W_j'  with global atomics.
+// Same outputs as k_build.
+template <int MODEL, bool WITH_IO>
+__global__ __launch_bounds__(256) void k_build_giant(DevProblem d, const double *__restrict__ z,
+                                                     const CamRec *__restrict__ cams, double lambda, int scale,
+                                                     double *__restrict__ S, double *__restrict__ g_c,
+                                                     double *__restrict__ g_red, double *__restrict__ diagU,
+                                                     double *__restrict__ Vinv, double *__restrict__ gp,
+                                                     double *__restrict__ jn2p, double *__restrict__ r_w,
+                                                     double *__restrict__ partial,
+                                                     unsigned long long *__restrict__ pivmm) {
+    constexpr int NCX = WITH_IO ? MAXCOL : 6;
+    __shared__ double sh[9 * 4];
+    __shared__ double pin[9];
+    const int t = threadIdx.x, BT = blockDim.x;
+    const int64_t o0 = d.giant_start[blockIdx.x], o1 = d.giant_start[blockIdx.x + 1];
+    const int k = (int)(o1 - o0);
+    const int strideW = d.ncolmax * 3;
+    double *Wg = d.giant_W + (o0 - d.giant_start[0]) * strideW;
+    const int pt = d.o_pt[o0];
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, rr = 0.0;
+    for (int i = t; i < k; i += BT) {                // ---- pass 1
+        const int64_t o = o0 + i;
+        const CamRec &C = cams[d.o_cam[o]];
+        const int ncol = WITH_IO ? C.ncol : 6;
+        double r[2], E[2][NCX], B[2][3];
+        eval_obs_cols<MODEL, WITH_IO>(d, C, z, o, pt, r, E, B);
+        r_w[2 * o] = r[0]; r_w[2 * o + 1] = r[1];
+        rr += r[0] * r[0] + r[1] * r[1];
+        acc[0] += B[0][0] * B[0][0] + B[1][0] * B[1][0];
+        acc[1] += B[0][0] * B[0][1] + B[1][0] * B[1][1];
+        acc[2] += B[0][0] * B[0][2] + B[1][0] * B[1][2];
+        acc[3] += B[0][1] * B[0][1] + B[1][1] * B[1][1];
+        acc[4] += B[0][1] * B[0][2] + B[1][1] * B[1][2];
+        acc[5] += B[0][2] * B[0][2] + B[1][2] * B[1][2];
+        acc[6] += B[0][0] * r[0] + B[1][0] * r[1];
+        acc[7] += B[0][1] * r[0] + B[1][1] * r[1];
+        acc[8] += B[0][2] * r[0] + B[1][2] * r[1];
+        double *wl = Wg + (size_t)i * strideW;
+        for (int a = 0; a < NCX; ++a) {
+            if (a >= ncol) break;
+            double ea0 = 0, ea1 = 0;
+#pragma unroll
+            for (int q = 0; q < NCX; ++q) if (q == a) { ea0 = E[0][q]; ea1 = E[1][q]; }
+            wl[3 * a] = ea0 * B[0][0] + ea1 * B[1][0];
+            wl[3 * a + 1] = ea0 * B[0][1] + ea1 * B[1][1];
+            wl[3 * a + 2] = ea0 * B[0][2] + ea1 * B[1][2];
+            const int gcol = C.col[a];
+            const double ga = ea0 * r[0] + ea1 * r[1];
+            atomic_add_f64(g_c + gcol, ga);
+            atomic_add_f64(g_red + gcol, ga);
+            atomic_add_f64(diagU + gcol, ea0 * ea0 + ea1 * ea1);
+            for (int b = 0; b < ncol; ++b) {         // E'E of this observation, lower triangle
+                const int grow = C.col[b];
+                if (grow < gcol) continue;
+                double eb0 = 0, eb1 = 0;
+#pragma unroll
+                for (int q = 0; q < NCX; ++q) if (q == b) { eb0 = E[0][q]; eb1 = E[1][q]; }
+                atomic_add_f64(S + (int64_t)gcol * d.ldS + grow, ea0 * eb0 + ea1 * eb1);
+            }
+        }
+    }
+    block_sum<9>(acc, sh);
+    double pmin = 1e300, pmax = 0.0;
+    if (t == 0) {                                    // ---- V, damping, priors, V^-1 (as k_build P2)
+        double V[6] = {acc[0], acc[1], acc[2], acc[3], acc[4], acc[5]}, g[3] = {acc[6], acc[7], acc[8]};
+        const int64_t zp = d.NS + 3 * (int64_t)pt;
+        const int dix[3] = {0, 3, 5};
+        double jn[3];
+        for (int q = 0; q < 3; ++q) {
+            const double pw = d.z_prw[zp + q];
+            if (pw > 0) { V[dix[q]] += pw; g[q] += pw * (z[zp + q] - d.z_prv[zp + q]); }
+            jn[q] = V[dix[q]];
+            jn2p[3 * (int64_t)pt + q] = jn[q];
+            if (d.z_est[zp + q]) V[dix[q]] += lambda; else V[dix[q]] = 1.0;
+        }
+        double inv[6];
+        inv3_sym(V, inv);
+        const double d0 = sqrt(V[0]), l10 = V[1] / d0, l20 = V[2] / d0;
+        const double d1 = sqrt(V[3] - l10 * l10), l21 = (V[4] - l20 * l10) / d1;
+        const double d2 = sqrt(V[5] - l20 * l20 - l21 * l21);
+        const double dd[3] = {d0, d1, d2};
+        for (int q = 0; q < 3; ++q)
+            if (d.z_est[zp + q]) {
+                double v = scale ? dd[q] / sqrt(jn[q]) : dd[q];
+                v = v == v ? v : 0.0;
+                pmin = fmin(pmin, v); pmax = fmax(pmax, v);
+            }
+        for (int q = 0; q < 6; ++q) { pin[q] = inv[q]; Vinv[6 * (int64_t)pt + q] = inv[q]; }
+        for (int q = 0; q < 3; ++q) { pin[6 + q] = g[q]; gp[3 * (int64_t)pt + q] = g[q]; }
+        if (pmax > 0.0) {
+            atomicMin(pivmm, (unsigned long long)__double_as_longlong(pmin));
+            atomicMax(pivmm + 1, (unsigned long long)__double_as_longlong(pmax));
+        }
+    }
+    __threadfence_block();
+    __syncthreads();                                 // pin and the W scratch of the whole point are visible
+    const double v0 = pin[0], v1 = pin[1], v2 = pin[2], v3 = pin[3], v4 = pin[4], v5 = pin[5];
+    const double g0 = pin[6], g1 = pin[7], g2 = pin[8];
+    for (int i = t; i < k; i += BT) {                // ---- pass 2
+        const CamRec &Ci = cams[d.o_cam[o0 + i]];
+        const int nci = WITH_IO ? Ci.ncol : 6;
+        const double *wi = Wg + (size_t)i * strideW;
+        for (int a = 0; a < nci; ++a) {
+            const int gcol = Ci.col[a];
+            const double w0 = wi[3 * a], w1 = wi[3 * a + 1], w2 = wi[3 * a + 2];
+            const double y0 = w0 * v0 + w1 * v1 + w2 * v2;
+            const double y1 = w0 * v1 + w1 * v3 + w2 * v4;
+            const double y2 = w0 * v2 + w1 * v4 + w2 * v5;
+            atomic_add_f64(g_red + gcol, -(y0 * g0 + y1 * g1 + y2 * g2));
+            // partners: fixed IO -> cameras ascend inside a point, j >= i covers the lower triangle;
+            // with IO columns every ordered pair whose row is not above the column
+            for (int j = WITH_IO ? 0 : i; j < k; ++j) {
+                const CamRec &Cj = cams[d.o_cam[o0 + j]];
+                const int ncj = WITH_IO ? Cj.ncol : 6;
+                const double *wj = Wg + (size_t)j * strideW;
+                for (int b = 0; b < ncj; ++b) {
+                    const int grow = Cj.col[b];
+                    if (grow < gcol) continue;
+                    if (!WITH_IO && j == i && b < a) continue;
+                    atomic_add_f64(S + (int64_t)gcol * d.ldS + grow,
+                                   -(y0 * wj[3 * b] + y1 * wj[3 * b + 1] + y2 * wj[3 * b + 2]));
+                }
+            }
+        }
+    }
+    double accr[1] = {rr};
+    block_sum<1>(accr, sh);
+    if (t == 0) partial[blockIdx.x] = accr[0];
+}
+
+// Back-substitution for a giant point (k_backsub for one point per workgroup).
+template <int MODEL, bool WITH_IO>
+__global__ __launch_bounds__(256) void k_backsub_giant(DevProblem d, const double *__restrict__ z,
+                                                       const CamRec *__restrict__ cams,
+                                                       const double *__restrict__ Vinv, const double *__restrict__ gp,
+                                                       const double *__restrict__ r_w, double *__restrict__ dz,
+                                                       double *__restrict__ partial /* [ngiant][2] */) {
+    constexpr int NCX = WITH_IO ? MAXCOL : 6;
+    __shared__ double sh[3 * 4];
+    __shared__ double dps[3];
+    const int t = threadIdx.x, BT = blockDim.x;
+    const int64_t o0 = d.giant_start[blockIdx.x], o1 = d.giant_start[blockIdx.x + 1];
+    const int k = (int)(o1 - o0);
+    const int pt = d.o_pt[o0];
+    double s[3] = {0, 0, 0};
+    for (int i = t; i < k; i += BT) {
+        const int64_t o = o0 + i;
+        const CamRec &C = cams[d.o_cam[o]];
+        const int ncol = WITH_IO ? C.ncol : 6;
+        double r[2], E[2][NCX], B[2][3], tt[2] = {0, 0};
+        eval_obs_cols<MODEL, WITH_IO>(d, C, z, o, pt, r, E, B);
+#pragma unroll
+        for (int a = 0; a < NCX; ++a)
+            if (a < ncol) { const double dc = dz[C.col[a]]; tt[0] += E[0][a] * dc; tt[1] += E[1][a] * dc; }
+        s[0] += B[0][0] * tt[0] + B[1][0] * tt[1];
+        s[1] += B[0][1] * tt[0] + B[1][1] * tt[1];
+        s[2] += B[0][2] * tt[0] + B[1][2] * tt[1];
+    }
+    block_sum<3>(s, sh);
+    if (t == 0) {
+        for (int q = 0; q < 3; ++q) s[q] += gp[3 * (int64_t)pt + q];
+        const double *vi = Vinv + 6 * (int64_t)pt;
+        const double p0 = -(vi[0] * s[0] + vi[1] * s[1] + vi[2] * s[2]);
+        const double p1 = -(vi[1] * s[0] + vi[3] * s[1] + vi[4] * s[2]);
+        const double p2 = -(vi[2] * s[0] + vi[4] * s[1] + vi[5] * s[2]);
+        const int64_t zp = d.NS + 3 * (int64_t)pt;
+        dps[0] = d.z_est[zp] ? p0 : 0.0; dps[1] = d.z_est[zp + 1] ? p1 : 0.0; dps[2] = d.z_est[zp + 2] ? p2 : 0.0;
+        dz[zp] = dps[0]; dz[zp + 1] = dps[1]; dz[zp + 2] = dps[2];
+    }
+    __syncthreads();
+    double acc[2] = {0, 0};
+    for (int i = t; i < k; i += BT) {
+        const int64_t o = o0 + i;
+        const CamRec &C = cams[d.o_cam[o]];
+        const int ncol = WITH_IO ? C.ncol : 6;
+        double r[2], E[2][NCX], B[2][3], tt[2] = {0, 0};
+        eval_obs_cols<MODEL, WITH_IO>(d, C, z, o, pt, r, E, B);
+#pragma unroll
+        for (int a = 0; a < NCX; ++a)
+            if (a < ncol) { const double dc = dz[C.col[a]]; tt[0] += E[0][a] * dc; tt[1] += E[1][a] * dc; }
+        const double j0 = tt[0] + B[0][0] * dps[0] + B[0][1] * dps[1] + B[0][2] * dps[2];
+        const double j1 = tt[1] + B[1][0] * dps[0] + B[1][1] * dps[1] + B[1][2] * dps[2];
+        acc[0] += j0 * j0 + j1 * j1;
+        acc[1] += r_w[2 * o] * j0 + r_w[2 * o + 1] * j1;
+    }
+    block_sum<2>(acc, sh);
+    if (t == 0) { partial[2 * blockIdx.x] = acc[0]; partial[2 * blockIdx.x + 1] = acc[1]; }
 }
 
 // ---------------------------------------------------------------- K1t ---

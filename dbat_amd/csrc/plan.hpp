@@ -62,6 +62,8 @@ struct Plan {
     std::vector<int32_t> tile_cams;                // global camera ids, ascending inside a tile
     int CMAX = 0;                                  // 0 = no tiling (global atomics)
     int64_t nb_tiled = 0;                          // batches [0,nb_tiled) belong to tiles; the rest hold heavy points
+    // "giant" points (more observations than a batch holds) come last, outside the batches
+    std::vector<int64_t> giant_start;              // [ngiant+1] first observation of every giant point
     // self-calibration: the estimated IO columns of a tile's cameras are extra rows
     // of the tile-local system (at most IOT of them), after the 6*ncam camera rows
     static constexpr int IOT = 16;
@@ -297,7 +299,15 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     P.CMAX = env_int0("DBAT_HIP_CMAX", P.with_io ? 18 : 21);
     if (P.CMAX < 0 || P.CMAX > (P.with_io ? 18 : 21)) P.CMAX = P.with_io ? 18 : 21;   // 6*CMAX (+IOT) <= 128 rows of the MFMA tile
     if (P.ncolmax - 6 > Plan::IOT) P.CMAX = 0;
-    std::vector<uint8_t> heavy(np, 0);
+    {   // batch size: whole points, at most BT observations
+        auto env_int = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
+        P.BT = env_int("DBAT_HIP_BT", 256);
+        if (P.BT != 128 && P.BT != 256) P.BT = 256;
+        if ((size_t)P.BT * P.ncolmax * 3 * 8 + (size_t)P.BT * 18 * 8 > 150 * 1024) P.BT = 128;
+        if (P.BT != 256) P.CMAX = 0;                // the tile kernels are written for four waves of observations
+    }
+    std::vector<uint8_t> heavy(np, 0), giant(np, 0);
+    for (int p = 0; p < np; ++p) giant[p] = k_pt[p] > P.BT;
     for (int p = 0; p < np && P.CMAX; ++p) {
         if (k_pt[p] > P.CMAX) { heavy[p] = 1; continue; }
         if (P.with_io) {
@@ -346,7 +356,10 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
                 if (v > 1) v = 1;
                 k |= spread((uint64_t)(v * 2097151.0)) << d;
             }
-            key[p] = k_pt[p] ? ((k >> 1) | (heavy[p] ? (1ull << 63) : 0)) : ~0ull;   // heavy points after the others
+            // tiled points, then heavy points, then giant points; unobserved points last
+            key[p] = !k_pt[p] ? ~0ull
+                     : giant[p] ? ((k >> 2) | (3ull << 62))
+                     : heavy[p] ? ((k >> 2) | (1ull << 63)) : (k >> 1);
         }
     }
     P.porder.resize(np);
@@ -374,15 +387,8 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
 
     // ---- batches of whole points, at most BT observations each; tiles of
     // batches touching at most CMAX cameras (fixed-IO path only)
-    const int strideW = P.ncolmax * 3;
-    auto env_int = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
-    P.BT = env_int("DBAT_HIP_BT", 256);
-    if (P.BT != 128 && P.BT != 256) P.BT = 256;
-    if ((size_t)P.BT * strideW * 8 + (size_t)P.BT * 18 * 8 > 150 * 1024) P.BT = 128;
-    if (P.max_k > P.BT)
-        return fail(P, "an object point has more observations than one batch holds (" +
-                       std::to_string(P.max_k) + " > " + std::to_string(P.BT) + ")");
     P.batch_start.clear(); P.batch_start.push_back(0);
+    P.giant_start.clear();
     int64_t nobs_shard = 0;
     for (int64_t i = P.pt_lo; i < P.pt_hi; ++i) nobs_shard += k_pt[P.porder[i]];
     P.o_cam.resize(nobs_shard); P.o_pt.resize(nobs_shard); P.o_uv.resize(2 * nobs_shard);
@@ -430,6 +436,32 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         const int32_t p = P.porder[i];
         const int k = k_pt[p];
         if (k == 0) continue;
+        if (giant[p]) {
+            if (P.giant_start.empty()) {
+                // first giant point: close the last batch (and tile); what follows is outside the batches
+                if (pos > bstart) { P.batch_start.push_back(pos); bstart = pos; }
+                if (P.CMAX && !in_heavy) {
+                    for (int32_t c : cur_cams) stamp[c] = -1;
+                    close_tile(pos);
+                    in_heavy = true;
+                    P.nb_tiled = (int64_t)P.batch_start.size() - 1;
+                }
+            }
+            P.giant_start.push_back(pos);
+            for (int j = 0; j < k; ++j, ++pos) {
+                const int64_t o = by_pt[pstart[p] + j];
+                const int32_t c = pb.ip_cam[o];
+                P.o_cam[pos] = c; P.o_pt[pos] = p;
+                P.o_uv[2 * pos] = pb.ip_val[2 * o]; P.o_uv[2 * pos + 1] = pb.ip_val[2 * o + 1];
+                P.o_seg[pos] = 0; P.o_row[pos] = o;
+                if (!P.uniform_w) {
+                    P.o_w[2 * pos] = 1.0 / (pb.ip_std[2 * o] * P.px[2 * c]);
+                    P.o_w[2 * pos + 1] = 1.0 / (pb.ip_std[2 * o + 1] * P.px[2 * c + 1]);
+                }
+            }
+            bstart = pos;
+            continue;
+        }
         if (P.CMAX && heavy[p] && !in_heavy) {
             // first heavy point: close the last tile; the remaining batches are not tiled
             if (pos > bstart) { P.batch_start.push_back(pos); bstart = pos; }
@@ -490,7 +522,8 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         }
         ++pidx;
     }
-    if (pos > bstart || P.batch_start.size() == 1) P.batch_start.push_back(pos);
+    if (!P.giant_start.empty()) P.giant_start.push_back(pos);
+    if (pos > bstart || (P.batch_start.size() == 1 && P.giant_start.empty())) P.batch_start.push_back(pos);
     if (P.CMAX && !in_heavy) {
         for (int32_t c : cur_cams) stamp[c] = -1;
         close_tile(pos);

@@ -22,7 +22,8 @@ pytestmark = pytest.mark.gpu
 
 TOL_BLOCK = 1e-11
 TOL_STEP = 1e-8
-TOL_X = 1e-8
+TOL_X = 1e-7          # converged parameters (stated bar 1e-6; LM stops on a 1e-6 relative step, so the
+                      # last digits depend on the summation order of the atomics)
 
 
 @pytest.fixture(scope='module')
@@ -481,5 +482,59 @@ def test_mixed_tiled_and_heavy_points(hip, variant, monkeypatch):
         h.close()
     res, ok, iters, s0, E = bundle(s, 'gna')
     monkeypatch.delenv('DBAT_HIP_CMAX')
+    ro, oko, ito, s0o, Eo = o.bundle(s, 'gna')
+    assert ok and oko and iters == ito and relerr(E.x, Eo.x) < TOL_X
+
+
+@pytest.mark.parametrize('variant', ['plain', 'selfcal'])
+def test_giant_points(hip, variant, monkeypatch):
+    """Object points with more observations than one batch holds (control points
+    seen in every image; here 140 images, 128-observation batches, 64-thread
+    workgroups so that every point takes three chunks) go through
+    k_build_giant / k_backsub_giant: step parity with the oracle and an
+    identical bundle result.  Distortion-free camera, so that the projections
+    far outside the image format stay well defined."""
+    from dbat_amd import bundle, synth
+    s, truth = synth.make_scene('small', cams=140, points=500, rays=6)
+    s.IO.val[5:10] = 0.0
+    truth['IO'][5:10] = 0.0
+    if variant == 'selfcal':
+        s.bundle.est.IO[[0, 1, 2, 5, 6]] = True
+    nc = s.EO.val.shape[1]
+    px = float(np.ravel(s.IO.sensor.pxSize)[0])
+    rng = np.random.default_rng(5)
+    add_cam, add_pt = [], []
+    for p in (3, 77, 250):
+        have = set(s.IP.cam[s.IP.pt == p].tolist())
+        for c in range(nc):
+            if c not in have:
+                add_cam.append(c); add_pt.append(p)
+    cam = np.r_[s.IP.cam, np.array(add_cam)]; pt = np.r_[s.IP.pt, np.array(add_pt)]
+    order = np.lexsort((pt, cam))                       # image-major, ascending OP
+    cam, pt = cam[order], pt[order]
+    uv, depth = synth.project(truth['IO'], truth['EO'], truth['OP'], cam, pt, px, nK=3, nP=2)
+    assert np.all(depth < 0)
+    s.IP.val = uv + rng.normal(0, 0.5, uv.shape)
+    s.IP.std = np.ones_like(uv)
+    s.IP.cam, s.IP.pt = cam, pt
+    assert np.bincount(s.IP.pt).max() == nc
+    monkeypatch.setenv('DBAT_HIP_BT', '128')
+    monkeypatch.setenv('DBAT_HIP_GIANT_THREADS', '64')
+    so, x0, w = oracle_setup(s)
+    R = np.sqrt(w)
+    r_o, K = o.brown_euler_cam4(x0, so, jac=True)
+    J = (sp.diags(R) @ K).tocsc()
+    p_o, *_ = o._scaled_gn(J, R * r_o)
+    h = hip.Handle(s)
+    try:
+        p_h, st = h.linearize_solve(x0, 0.0, True)
+        assert not st['singular']
+        assert relerr(p_h, p_o) < TOL_STEP
+        Jp = J @ p_o
+        assert abs(st['JpJp'] - Jp @ Jp) <= 1e-7 * (Jp @ Jp)
+        assert relerr(h.gradient(), J.T @ (R * r_o)) < 1e-10
+    finally:
+        h.close()
+    res, ok, iters, s0, E = bundle(s, 'gna')
     ro, oko, ito, s0o, Eo = o.bundle(s, 'gna')
     assert ok and oko and iters == ito and relerr(E.x, Eo.x) < TOL_X
