@@ -2,10 +2,10 @@
 
 Host-side mirror of the reference's interface for the bundle hot path:
     dbatstruct   the DBAT struct (prob2dbatstruct.m field layout)
-    driver       bundle(s, ...) -> (s, ok, iters, sigma0, E)
+    driver       bundle(s, ...) -> (s, ok, iters, sigma0, E); bundle_cov(s, E, 'CIO','CEO','COP')
     loadpm       PhotoModeler export loader (known-answer fixtures)
     parallel     torch.distributed / RCCL plumbing for sharded object points
     _hip         ctypes binding of include/dbat_hip.h (libdbat_hip.so)
 """
 from .dbatstruct import make_struct, seteoest_depend, validate  # noqa: F401
-from .driver import bundle, BadInput  # noqa: F401
+from .driver import bundle, bundle_cov, BadInput  # noqa: F401

@@ -99,6 +99,7 @@ SYMBOLS = {
     'dbat_hip_bench_step': (C.c_int, [_H, C.c_double, C.c_int32, _dp]),
     'dbat_hip_set_x': (C.c_int, [_H, _dp]),
     'dbat_hip_info': (C.c_int, [_H, C.POINTER(C.c_int64)]),
+    'dbat_hip_posterior_cov': (C.c_int, [_H, _dp, C.c_double, _dp, _dp, _dp, _dp]),
 }
 DEBUG_SYMBOLS = {
     'dbat_hip_debug_model_eval_host': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, C.c_double,
@@ -315,6 +316,27 @@ class Handle:
         IO, EO, OP = self.deserialize(big + np.arange(self.n, dtype=float))
         f = lambda a: np.where(a >= big / 2, np.rint(a - big), -1).astype(np.int64)
         return f(IO), f(EO), f(OP)
+
+    def posterior_cov(self, x, sigma0, want_sinv=False):
+        """sigma0^2 * blocks of inv(J'J) at x (bundle_cov.m): CEO (nc,6,6), CIOu
+        (nIOu,nIOu; IO unknowns in z order, see x2z), COP (np,3,3) and, if asked
+        for, inv(S) (NS,NS; symmetrised, not scaled by sigma0^2)."""
+        x = np.ascontiguousarray(x, float)
+        NS = self.info()['NS']
+        nc, npnt = int(self.prob.n_images), int(self.prob.n_points)
+        nIOu = NS - 6 * nc
+        CEO = np.zeros(36 * nc)
+        CIO = np.zeros(max(nIOu * nIOu, 1))
+        COP = np.zeros(9 * npnt)
+        Sinv = np.zeros(NS * NS) if want_sinv else None
+        check(self.lib.dbat_hip_posterior_cov(self.h, dptr(x), float(sigma0), dptr(CEO), dptr(CIO), dptr(COP),
+                                              dptr(Sinv) if want_sinv else None))
+        out = [CEO.reshape(nc, 6, 6).transpose(0, 2, 1), CIO[:nIOu * nIOu].reshape(nIOu, nIOu).T,
+               COP.reshape(npnt, 3, 3).transpose(0, 2, 1)]
+        if want_sinv:
+            L = np.tril(Sinv.reshape(NS, NS).T)
+            out.append(L + np.tril(L, -1).T)
+        return tuple(out)
 
     def set_x(self, x):
         x = np.ascontiguousarray(x, float)

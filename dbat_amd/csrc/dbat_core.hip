@@ -222,6 +222,13 @@ struct Core {
             SET_LDS((k_build_tile2<2>), lds_tile2); SET_LDS((k_build_tile2<3>), lds_tile2);
             SET_LDS((k_build_tile2<4>), lds_tile2); SET_LDS((k_build_tile2<5>), lds_tile2);
         }
+        {
+            const size_t lds_cov = ((size_t)P.BT * P.ncolmax * 3 + (size_t)P.BT * 6) * sizeof(double);
+            SET_LDS((k_cov_points<2, false>), lds_cov); SET_LDS((k_cov_points<3, false>), lds_cov);
+            SET_LDS((k_cov_points<4, false>), lds_cov); SET_LDS((k_cov_points<5, false>), lds_cov);
+            SET_LDS((k_cov_points<2, true>), lds_cov); SET_LDS((k_cov_points<3, true>), lds_cov);
+            SET_LDS((k_cov_points<4, true>), lds_cov); SET_LDS((k_cov_points<5, true>), lds_cov);
+        }
         SET_LDS((k_build<2, false>), lds_build); SET_LDS((k_build<3, false>), lds_build);
         SET_LDS((k_build<4, false>), lds_build); SET_LDS((k_build<5, false>), lds_build);
         SET_LDS((k_build<2, true>), lds_build); SET_LDS((k_build<3, true>), lds_build);
@@ -448,6 +455,50 @@ struct Core {
         const double ratio = pmax > 0 ? pmin / pmax : 0.0;
         near_singular = failed || !(ratio * ratio >= 2.220446049250313e-16);
         return failed;
+    }
+    // ---- posterior covariance blocks at z (bundle_cov.m): s0^2 * blocks of inv(J'J)
+    void posterior_cov(double s0, double *hCEO, double *hCIO, double *hCOP, double *hSinv) {
+        build(z.p, 0.0, 0);                          // unscaled, undamped reduced system + V^-1 per point
+        s_valid = false;
+        factor_solve_enqueue();                      // L in the lower triangle of S
+        int hinfo = 0;
+        HIPCHK(hipMemcpyAsync(&hinfo, info.p, sizeof(hinfo), hipMemcpyDeviceToHost, stream));
+        sync();
+        if (hinfo != 0) throw DeviceError{"posterior covariance: the reduced normal matrix is not positive definite"};
+        if (rocsolver_dpotri(blas, rocblas_fill_lower, (rocblas_int)P.NS, S, (rocblas_int)ldS, info.p) != rocblas_status_success)
+            throw DeviceError{"rocsolver_dpotri failed"};
+        have_lin = false;
+        const double s02 = s0 * s0;
+        prep_cams(z.p);
+        DevBuf<double> dCEO, dCIO, dCOP;
+        if (hCEO) dCEO.alloc((size_t)36 * P.nc);
+        if (hCIO && P.nIOu > 0) dCIO.alloc((size_t)P.nIOu * P.nIOu);
+        if (hCEO || (hCIO && P.nIOu > 0)) {
+            const int64_t tot = 36 * (int64_t)P.nc + (int64_t)P.nIOu * P.nIOu;
+            hipLaunchKernelGGL(k_cov_cam, dim3((unsigned)cdiv(tot, 256)), dim3(256), 0, stream, d, S, s02, dCEO.p, dCIO.p);
+        }
+        if (hCOP) {
+            dCOP.alloc((size_t)9 * P.np);
+            HIPCHK(hipMemsetAsync(dCOP.p, 0, (size_t)9 * P.np * sizeof(double), stream));
+            const size_t lds_cov = ((size_t)P.BT * P.ncolmax * 3 + (size_t)P.BT * 6) * sizeof(double);
+            if (nb > 0) {
+#define L_COV(M, IO) hipLaunchKernelGGL((k_cov_points<M, IO>), dim3((unsigned)nb), dim3(P.BT), lds_cov, stream, d, z.p, cams.p, Vinv.p, S, s02, dCOP.p)
+                if (P.with_io) { DISPATCH_MODEL(L_COV, true) } else { DISPATCH_MODEL(L_COV, false) }
+#undef L_COV
+            }
+            if (ngiant > 0) {
+#define L_COVG(M, IO) hipLaunchKernelGGL((k_cov_giant<M, IO>), dim3((unsigned)ngiant), dim3(giant_threads), 0, stream, d, z.p, cams.p, Vinv.p, S, s02, dCOP.p)
+                if (P.with_io) { DISPATCH_MODEL(L_COVG, true) } else { DISPATCH_MODEL(L_COVG, false) }
+#undef L_COVG
+            }
+            HIPCHK(hipMemcpyAsync(hCOP, dCOP.p, (size_t)9 * P.np * sizeof(double), hipMemcpyDeviceToHost, stream));
+        }
+        if (hCEO) HIPCHK(hipMemcpyAsync(hCEO, dCEO.p, (size_t)36 * P.nc * sizeof(double), hipMemcpyDeviceToHost, stream));
+        if (hCIO && P.nIOu > 0) HIPCHK(hipMemcpyAsync(hCIO, dCIO.p, (size_t)P.nIOu * P.nIOu * sizeof(double), hipMemcpyDeviceToHost, stream));
+        if (hSinv)                                   // full inv(S) (lower triangle valid), NS x NS column-major, not scaled by s0^2
+            HIPCHK(hipMemcpy2DAsync(hSinv, (size_t)P.NS * sizeof(double), S, (size_t)ldS * sizeof(double),
+                                    (size_t)P.NS * sizeof(double), (size_t)P.NS, hipMemcpyDeviceToHost, stream));
+        sync();
     }
     // ||J v||^2 and r'Jv at the linearisation point, ||v||^2 over owned entries
     void jtimes(const double *v, double &JvJv, double &rJv, double &vv) {
@@ -1085,6 +1136,18 @@ int dbat_hip_bench_step(dbat_hip_handle *h, double lambda, int32_t scale_columns
             ms[4 + i] = t;
         }
     }
+    return DBAT_HIP_OK;
+    API_CATCH
+}
+
+int dbat_hip_posterior_cov(dbat_hip_handle *h, const double *x, double sigma0, double *CEO, double *CIO,
+                           double *COP, double *Sinv) {
+    API_TRY
+    if (!h || !x) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
+    Core &c = *h->core;
+    if (c.P.nranks > 1) { g_err = "posterior covariance is computed on one GPU (not supported on a sharded handle)"; return DBAT_HIP_EUNSUPPORTED; }
+    c.x_to_z(x, c.z.p);
+    c.posterior_cov(sigma0, CEO, CIO, COP, Sinv);
     return DBAT_HIP_OK;
     API_CATCH
 }

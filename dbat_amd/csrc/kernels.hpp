@@ -1422,6 +1422,196 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
     }
 }
 
+// ------------------------------------------------------- posterior cov ---
+// bundle_cov.m: blocks of C = s0^2 inv(J'J).  With the points eliminated,
+//   inv(J'J)[cams, cams] = inv(S)                         (CEO, CIO)
+//   inv(J'J)[p, p]       = V_p^-1 + Y_p' inv(S) Y_p,  Y_p = W_p V_p^-1  (COP)
+// Sinv holds the lower triangle of inv(S) (column-major, leading dimension ldS).
+__device__ __forceinline__ double sym_at(const double *Sinv, int64_t ldS, int r, int c) {
+    return r >= c ? Sinv[(int64_t)c * ldS + r] : Sinv[(int64_t)r * ldS + c];
+}
+
+// CEO: 6x6 block per image (zero rows/columns for fixed elements); CIO: the
+// nIOu x nIOu block of the IO unknowns.
+__global__ void k_cov_cam(DevProblem d, const double *__restrict__ Sinv, double s02, double *__restrict__ CEO,
+                          double *__restrict__ CIO) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t nE = 36 * (int64_t)d.nc, nI = (int64_t)d.nIOu * d.nIOu;
+    if (i < nE) {
+        if (!CEO) return;
+        const int c = (int)(i / 36), e = (int)(i % 36), a = e % 6, b = e / 6;
+        const int ra = 6 * c + a, rb = 6 * c + b;
+        CEO[i] = (d.z_est[ra] && d.z_est[rb]) ? s02 * sym_at(Sinv, d.ldS, ra, rb) : 0.0;
+    } else if (i < nE + nI) {
+        if (!CIO) return;
+        const int64_t q = i - nE;
+        const int a = (int)(q % d.nIOu), b = (int)(q / d.nIOu);
+        CIO[q] = s02 * sym_at(Sinv, d.ldS, 6 * d.nc + a, 6 * d.nc + b);
+    }
+}
+
+// COP for the points of one batch (same layout as k_build: lane t <-> observation).
+template <int MODEL, bool WITH_IO>
+__global__ __launch_bounds__(256) void k_cov_points(DevProblem d, const double *__restrict__ z,
+                                                    const CamRec *__restrict__ cams,
+                                                    const double *__restrict__ Vinv,
+                                                    const double *__restrict__ Sinv, double s02,
+                                                    double *__restrict__ COP) {
+    constexpr int NCX = WITH_IO ? MAXCOL : 6;
+    extern __shared__ double smem[];
+    const int BT = blockDim.x;
+    const int strideW = d.ncolmax * 3;
+    double *Yl = smem;                               // [BT][strideW]  Y = W V^-1
+    double *red = Yl + (size_t)BT * strideW;         // [BT][6]
+    const int t = threadIdx.x;
+    const int64_t o0 = d.batch_start[blockIdx.x];
+    const int nobs = (int)(d.batch_start[blockIdx.x + 1] - o0);
+    const bool active = t < nobs;
+    const int64_t o = o0 + t;
+    int pt = 0, seg_start = 0, seg_len = 0, ncol = 6;
+    const CamRec *C = cams;
+    double vi[6] = {0, 0, 0, 0, 0, 0};
+    if (active) {
+        pt = d.o_pt[o];
+        const uint32_t sg = d.o_seg[o];
+        seg_start = sg & 0xFFFF; seg_len = sg >> 16;
+        C = cams + d.o_cam[o];
+        ncol = WITH_IO ? C->ncol : 6;
+        double r[2], E[2][NCX], B[2][3];
+        eval_obs_cols<MODEL, WITH_IO>(d, *C, z, o, pt, r, E, B);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) vi[q] = Vinv[6 * (int64_t)pt + q];
+        double *yl = Yl + (size_t)t * strideW;
+#pragma unroll
+        for (int a = 0; a < NCX; ++a)
+            if (a < ncol) {
+                const double w0 = E[0][a] * B[0][0] + E[1][a] * B[1][0];
+                const double w1 = E[0][a] * B[0][1] + E[1][a] * B[1][1];
+                const double w2 = E[0][a] * B[0][2] + E[1][a] * B[1][2];
+                yl[3 * a] = w0 * vi[0] + w1 * vi[1] + w2 * vi[2];
+                yl[3 * a + 1] = w0 * vi[1] + w1 * vi[3] + w2 * vi[4];
+                yl[3 * a + 2] = w0 * vi[2] + w1 * vi[4] + w2 * vi[5];
+            }
+    }
+    __syncthreads();
+    if (active) {
+        // c = Y_i' (sum_j Sinv[cols_i, cols_j] Y_j), symmetric part xx xy xz yy yz zz
+        double c6[6] = {0, 0, 0, 0, 0, 0};
+        const double *yi = Yl + (size_t)t * strideW;
+        for (int a = 0; a < ncol; ++a) {
+            const int ra = C->col[a];
+            double r0 = 0, r1 = 0, r2 = 0;
+            for (int jj = seg_start; jj < seg_start + seg_len; ++jj) {
+                const CamRec *Cj = cams + d.o_cam[o0 + jj];
+                const int ncj = WITH_IO ? Cj->ncol : 6;
+                const double *yj = Yl + (size_t)jj * strideW;
+                for (int b = 0; b < ncj; ++b) {
+                    const double sv = sym_at(Sinv, d.ldS, ra, Cj->col[b]);
+                    r0 += sv * yj[3 * b]; r1 += sv * yj[3 * b + 1]; r2 += sv * yj[3 * b + 2];
+                }
+            }
+            const double y0 = yi[3 * a], y1 = yi[3 * a + 1], y2 = yi[3 * a + 2];
+            c6[0] += y0 * r0; c6[1] += 0.5 * (y0 * r1 + y1 * r0); c6[2] += 0.5 * (y0 * r2 + y2 * r0);
+            c6[3] += y1 * r1; c6[4] += 0.5 * (y1 * r2 + y2 * r1); c6[5] += y2 * r2;
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) red[6 * t + q] = c6[q];
+    }
+    __syncthreads();
+    if (active && t == seg_start) {
+        double c6[6] = {vi[0], vi[1], vi[2], vi[3], vi[4], vi[5]};
+        for (int j = 0; j < seg_len; ++j)
+#pragma unroll
+            for (int q = 0; q < 6; ++q) c6[q] += red[6 * (t + j) + q];
+        const int64_t zp = d.NS + 3 * (int64_t)pt;
+        const bool e0 = d.z_est[zp], e1 = d.z_est[zp + 1], e2 = d.z_est[zp + 2];
+        double *out = COP + 9 * (int64_t)pt;
+        out[0] = e0 ? s02 * c6[0] : 0.0;
+        out[1] = out[3] = (e0 && e1) ? s02 * c6[1] : 0.0;
+        out[2] = out[6] = (e0 && e2) ? s02 * c6[2] : 0.0;
+        out[4] = e1 ? s02 * c6[3] : 0.0;
+        out[5] = out[7] = (e1 && e2) ? s02 * c6[4] : 0.0;
+        out[8] = e2 ? s02 * c6[5] : 0.0;
+    }
+}
+
+// COP of a giant point: one workgroup per point, Y in the W scratch.
+template <int MODEL, bool WITH_IO>
+__global__ __launch_bounds__(256) void k_cov_giant(DevProblem d, const double *__restrict__ z,
+                                                   const CamRec *__restrict__ cams,
+                                                   const double *__restrict__ Vinv, const double *__restrict__ Sinv,
+                                                   double s02, double *__restrict__ COP) {
+    constexpr int NCX = WITH_IO ? MAXCOL : 6;
+    __shared__ double sh[6 * 4];
+    const int t = threadIdx.x, BT = blockDim.x;
+    const int64_t o0 = d.giant_start[blockIdx.x], o1 = d.giant_start[blockIdx.x + 1];
+    const int k = (int)(o1 - o0);
+    const int strideW = d.ncolmax * 3;
+    double *Yg = d.giant_W + (o0 - d.giant_start[0]) * strideW;
+    const int pt = d.o_pt[o0];
+    double vi[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) vi[q] = Vinv[6 * (int64_t)pt + q];
+    for (int i = t; i < k; i += BT) {
+        const int64_t o = o0 + i;
+        const CamRec &C = cams[d.o_cam[o]];
+        const int ncol = WITH_IO ? C.ncol : 6;
+        double r[2], E[2][NCX], B[2][3];
+        eval_obs_cols<MODEL, WITH_IO>(d, C, z, o, pt, r, E, B);
+        double *yl = Yg + (size_t)i * strideW;
+        for (int a = 0; a < NCX; ++a) {
+            if (a >= ncol) break;
+            double ea0 = 0, ea1 = 0;
+#pragma unroll
+            for (int q = 0; q < NCX; ++q) if (q == a) { ea0 = E[0][q]; ea1 = E[1][q]; }
+            const double w0 = ea0 * B[0][0] + ea1 * B[1][0];
+            const double w1 = ea0 * B[0][1] + ea1 * B[1][1];
+            const double w2 = ea0 * B[0][2] + ea1 * B[1][2];
+            yl[3 * a] = w0 * vi[0] + w1 * vi[1] + w2 * vi[2];
+            yl[3 * a + 1] = w0 * vi[1] + w1 * vi[3] + w2 * vi[4];
+            yl[3 * a + 2] = w0 * vi[2] + w1 * vi[4] + w2 * vi[5];
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    double c6[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = t; i < k; i += BT) {
+        const CamRec &Ci = cams[d.o_cam[o0 + i]];
+        const int nci = WITH_IO ? Ci.ncol : 6;
+        const double *yi = Yg + (size_t)i * strideW;
+        for (int a = 0; a < nci; ++a) {
+            const int ra = Ci.col[a];
+            double r0 = 0, r1 = 0, r2 = 0;
+            for (int j = 0; j < k; ++j) {
+                const CamRec &Cj = cams[d.o_cam[o0 + j]];
+                const int ncj = WITH_IO ? Cj.ncol : 6;
+                const double *yj = Yg + (size_t)j * strideW;
+                for (int b = 0; b < ncj; ++b) {
+                    const double sv = sym_at(Sinv, d.ldS, ra, Cj.col[b]);
+                    r0 += sv * yj[3 * b]; r1 += sv * yj[3 * b + 1]; r2 += sv * yj[3 * b + 2];
+                }
+            }
+            const double y0 = yi[3 * a], y1 = yi[3 * a + 1], y2 = yi[3 * a + 2];
+            c6[0] += y0 * r0; c6[1] += 0.5 * (y0 * r1 + y1 * r0); c6[2] += 0.5 * (y0 * r2 + y2 * r0);
+            c6[3] += y1 * r1; c6[4] += 0.5 * (y1 * r2 + y2 * r1); c6[5] += y2 * r2;
+        }
+    }
+    block_sum<6>(c6, sh);
+    if (t == 0) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) c6[q] += vi[q];
+        const int64_t zp = d.NS + 3 * (int64_t)pt;
+        const bool e0 = d.z_est[zp], e1 = d.z_est[zp + 1], e2 = d.z_est[zp + 2];
+        double *out = COP + 9 * (int64_t)pt;
+        out[0] = e0 ? s02 * c6[0] : 0.0;
+        out[1] = out[3] = (e0 && e1) ? s02 * c6[1] : 0.0;
+        out[2] = out[6] = (e0 && e2) ? s02 * c6[2] : 0.0;
+        out[4] = e1 ? s02 * c6[3] : 0.0;
+        out[5] = out[7] = (e1 && e2) ? s02 * c6[4] : 0.0;
+        out[8] = e2 ? s02 * c6[5] : 0.0;
+    }
+}
+
 // Envelope of S <-> contiguous buffer (multi-GPU: only the envelope of the
 // reduced system travels through the all-reduce).  Column c owns the rows
 // [c, col_bend[c]) of the co-visibility band and the dense tail rows

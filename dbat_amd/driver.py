@@ -180,3 +180,72 @@ def bundle(s, *args, device=0, comm=None, store_trace=True):
         return s, ok, E.usedIters, s0, E
     finally:
         h.close()
+
+
+def bundle_cov(s, E, *names, device=0):
+    """C = bundle_cov(s, E, 'CIO' | 'CEO' | 'COP' | 'CIOF' | 'CEOF', ...)
+    (bundle/bundle_cov.m:1-31): sigma0^2 times blocks of inv(J'J) at the
+    bundle result (s, E) as scipy sparse matrices of size numel(val) x
+    numel(val), zero-padded for elements that were not estimated; 'CIO',
+    'CEO', 'COP' keep the per-column diagonal blocks only (:9-16), 'CIOF' and
+    'CEOF' are the full component matrices.  'CXX' and 'COPF' (n x n resp.
+    3np x 3np dense results) are not offered by the GPU path.
+    Everything is computed on the device from the Schur blocks
+    (dbat_hip_posterior_cov); this function only scatters the blocks."""
+    import scipy.sparse as sp
+    names = [n.lower() for n in names]
+    for n in names:
+        if n in ('cxx', 'copf'):
+            raise BadInput("bundle_cov: '%s' is not offered by the GPU path" % n.upper())
+        if n not in ('cio', 'ceo', 'cop', 'ciof', 'ceof'):
+            raise BadInput("Bad covariance string '%s'" % n)          # bundle_cov.m:53-55
+    if not names:
+        return None
+    h = _hip.Handle(s, device=device)
+    try:
+        full = any(n.endswith('f') for n in names)
+        res = h.posterior_cov(np.asarray(E.x, float), float(E.s0), want_sinv=full)
+        CEOb, CIOu, COPb = res[:3]
+        ixIO, ixEO, ixOP = h.index_maps()                   # x index of every array entry, -1 = no unknown
+        nc = s.EO.val.shape[1]
+    finally:
+        h.close()
+    out = []
+    for n in names:
+        comp = n[1:3].upper()
+        val = getattr(s, comp).val
+        m, ncol = val.shape
+        if n == 'cop':
+            r = np.arange(3)
+            rows = (3 * np.arange(ncol)[:, None, None] + r[None, :, None]) + 0 * r[None, None, :]
+            cols = (3 * np.arange(ncol)[:, None, None] + r[None, None, :]) + 0 * r[None, :, None]
+            C = sp.csc_matrix((COPb.ravel(), (rows.ravel(), cols.ravel())), shape=(val.size, val.size))
+        elif n == 'ceo':
+            r = np.arange(6)
+            rows = (m * np.arange(ncol)[:, None, None] + r[None, :, None]) + 0 * r[None, None, :]
+            cols = (m * np.arange(ncol)[:, None, None] + r[None, None, :]) + 0 * r[None, :, None]
+            C = sp.csc_matrix((CEOb.ravel(), (rows.ravel(), cols.ravel())), shape=(val.size, val.size))
+        else:
+            # IO (shared blocks: several array entries map to one unknown) and the full matrices:
+            # entry (a, b) of the result = covariance of the unknowns behind array entries a and b
+            ix = (ixIO if comp == 'IO' else ixEO).flatten('F')
+            if comp == 'IO':
+                M, off = CIOu * 1.0, 0
+                src = ix                                     # x index == IO unknown index (IO comes first in x)
+            else:
+                Sinv = res[3]
+                M, off = float(E.s0) ** 2 * Sinv[:6 * nc, :6 * nc], 0
+                # EO entry e of the array <-> z index: row r of image c -> 6c + r (rows 0..5)
+                src = np.where(ix >= 0, (np.arange(val.size) % m) + 6 * (np.arange(val.size) // m), -1)
+                src = np.where((np.arange(val.size) % m) < 6, src, -1)
+            if n == 'ciof' and len(res) > 3:
+                M = float(E.s0) ** 2 * res[3][6 * nc:, 6 * nc:]
+            est = np.flatnonzero(src >= 0)
+            D = np.zeros((val.size, val.size))
+            if len(est):
+                D[np.ix_(est, est)] = M[np.ix_(src[est] - off, src[est] - off)]
+            if not n.endswith('f'):
+                D *= np.kron(np.eye(ncol), np.ones((m, m)))
+            C = sp.csc_matrix(D)
+        out.append(C)
+    return out[0] if len(out) == 1 else tuple(out)

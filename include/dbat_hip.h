@@ -257,6 +257,21 @@ int  dbat_hip_set_x(dbat_hip_handle *h, const double *x);
  * info[6]=max camera-side columns per observation info[7]=#tiles */
 int  dbat_hip_info(const dbat_hip_handle *h, int64_t *info /*[8]*/);
 
+/* Posterior covariance blocks at x: sigma0^2 * blocks of inv(J'J), J the
+ * weighted Jacobian incl. prior rows.  Replaces bundle/bundle_cov.m:63-214
+ * ('CIO','CEO','COP'; the native code it stands in for is
+ * test/postcov/icpc_mex.c) -- computed from the Schur blocks instead of a
+ * Cholesky factor of the full normal matrix:
+ *   inv(J'J)[cams,cams] = inv(S),  inv(J'J)[p,p] = V_p^-1 + (W_p V_p^-1)' inv(S) (W_p V_p^-1).
+ * CEO  [36*n_images]  6x6 block per image, column-major, rows/columns of fixed elements zero
+ * CIO  [nIOu*nIOu]    the IO unknowns in the order of the IO part of x (buildserialindices.m:11-17)
+ * COP  [9*n_points]   3x3 block per object point, rows/columns of fixed coordinates zero
+ * Sinv [NS*NS]        optional: inv(S) itself (lower triangle valid; NOT scaled by sigma0^2),
+ *                     order [EO of image 0..n-1 | IO unknowns], for 'CEOF'/'CIOF'
+ * Any output may be NULL.  One GPU only (DBAT_HIP_EUNSUPPORTED on a sharded handle). */
+int  dbat_hip_posterior_cov(dbat_hip_handle *h, const double *x, double sigma0, double *CEO, double *CIO,
+                            double *COP, double *Sinv);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,7 +54,7 @@ dampNo=find(strcmp(damping,{'gm','gna','lm','lmp'}))-1;
 if strcmp(damping,'none'), dampNo=0; end
 opt=struct('damping',dampNo,'maxIter',maxIter,'convTol',convTol,'absTerm',absTerm,...
            'singularTest',singularTest,'trace',true);
-[x,code,iters,s0,res,damp,aux,T,ru,rw,time]=dbat_hip_mex(P,opt);
+[x,code,iters,s0,res,damp,aux,T,ru,rw,time,CEOb,CIOu,COPb]=dbat_hip_mex(P,opt);
 % --- result packaging, bundle.m:341-358,449-491
 if isempty(s.bundle.serial) || isempty(s.bundle.deserial), s=buildserialindices(s); end
 E=struct('maxIter',maxIter,'convTol',convTol,'absTerm',absTerm,'singularTest',singularTest,...
@@ -83,6 +83,18 @@ s.post.res.OP(s.prior.OP.use)=ru(s.post.res.ix.OP);
 s.post.sigmas=s0*s.IP.sigmas;
 E.numObs=length(ru); E.numParams=length(x); E.redundancy=length(ru)-length(x);
 E.s0=s0; E.sigmas=s.post.sigmas;
+% --- posterior covariance blocks from the device (bundle_cov.m:193-210 reads
+% s.post.cov.CEO / COP when they are present; E.final.weighted.J is not shipped)
+if ok
+    m=size(s.EO.val,1); B=zeros(m,m,size(s.EO.val,2)); B(1:6,1:6,:)=CEOb;
+    c=squeeze(num2cell(B,[1,2])); s.post.cov.CEO=sparse(blkdiag(c{:}));
+    c=squeeze(num2cell(COPb,[1,2])); s.post.cov.COP=sparse(blkdiag(c{:}));
+    % IO: every array entry that maps to IO unknown k gets row/column k of CIOu,
+    % per-image diagonal blocks only
+    ix=zeros(size(s.IO.val)); ix(s.bundle.deserial.IO.dest)=s.bundle.deserial.IO.src;
+    C=zeros(numel(ix)); e=find(ix); C(e,e)=CIOu(ix(e),ix(e));
+    s.post.cov.CIO=sparse(C.*kron(eye(size(ix,2)),ones(size(ix,1))));
+end
 
 function a=zeroifnan(a)
 a(isnan(a))=0;

@@ -106,5 +106,21 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
         if (nlhs > 9) plhs[9] = rw; else mxDestroyArray(rw);
     }
     if (nlhs > 10) plhs[10] = mxCreateDoubleScalar(r.time_s);
+    if (nlhs > 11) {
+        // posterior covariance blocks (bundle_cov.m 'CEO','CIO','COP') at the result:
+        // plhs[11] 6 x 6 x nImages, plhs[12] nIOu x nIOu (IO unknowns in x order), plhs[13] 3 x 3 x nOP
+        const mwSize dE[3] = {6, 6, (mwSize)pb.n_images}, dP[3] = {3, 3, (mwSize)pb.n_points};
+        int64_t inf[8];
+        dbat_hip_info(h, inf);
+        const mwSize nIOu = (mwSize)(inf[0] - 6 * (int64_t)pb.n_images);
+        plhs[11] = mxCreateNumericArray(3, dE, mxDOUBLE_CLASS, mxREAL);
+        mxArray *cio = mxCreateDoubleMatrix(nIOu, nIOu, mxREAL), *cop = mxCreateNumericArray(3, dP, mxDOUBLE_CLASS, mxREAL);
+        if (r.code == 0 &&
+            dbat_hip_posterior_cov(h, x, r.sigma0, mxGetDoubles(plhs[11]), nIOu ? mxGetDoubles(cio) : nullptr,
+                                   mxGetDoubles(cop), nullptr) != DBAT_HIP_OK)
+            mexWarnMsgIdAndTxt("DBAT:bundle_cov:notPD", "%s", dbat_hip_last_error());
+        if (nlhs > 12) plhs[12] = cio; else mxDestroyArray(cio);
+        if (nlhs > 13) plhs[13] = cop; else mxDestroyArray(cop);
+    }
     dbat_hip_destroy(h);
 }

@@ -1093,6 +1093,52 @@ def bundle(s, *args):
 
 
 # ----------------------------------------------------------------------------
+# Posterior covariance: bundle/bundle_cov.m
+# ----------------------------------------------------------------------------
+
+def bundle_cov(s, E, *names):
+    """bundle/bundle_cov.m:1-214.  Returns, per requested name, s0^2 times a
+    block of inv(J'J) with J = E.final.weighted.J (bundle_cov.m:66,211):
+      'cxx'            the whole matrix in x order (:137-143)
+      'cio','ceo','cop' block-diagonal (one block per IO/EO/OP column: 'any
+                       correlations with other cameras/images/points are
+                       ignored', :9-16, BlockDiagonalC :219-311, VectorizedCOP),
+                       sized numel(val) x numel(val), zero-padded for elements
+                       that were not estimated
+      'ciof','ceof','copf' the full component matrices (:145-191).
+    The reference obtains the blocks from a Cholesky factor of the permuted
+    normal matrix (invblock.m "sqrt": B = W'W, W = inv(L) E); any exact method gives
+    the same numbers, here a dense inverse (test sizes only)."""
+    import scipy.sparse as sp
+    J = E.final.weighted.J
+    N = (J.T @ J).toarray()
+    n = N.shape[0]
+    try:                                                   # bundle_cov.m:92-112 (chol fails -> NaN)
+        np.linalg.cholesky(N)
+        Ninv = np.linalg.inv(N)
+        Ninv = 0.5 * (Ninv + Ninv.T)
+    except np.linalg.LinAlgError:
+        Ninv = np.full((n, n), np.nan)
+    out = []
+    for name in names:
+        name = name.lower()
+        if name == 'cxx':
+            out.append(E.s0 ** 2 * Ninv)
+            continue
+        comp = name[1:3].upper()
+        val = getattr(s, comp).val
+        des = getattr(s.bundle.deserial, comp)             # dest: element of val(:), src: index into x
+        C = np.zeros((val.size, val.size))
+        C[np.ix_(des.dest, des.dest)] = Ninv[np.ix_(des.src, des.src)]
+        if not name.endswith('f'):                         # keep the diagonal blocks only (mkblkdiag)
+            m = val.shape[0]
+            mask = np.kron(np.eye(val.shape[1]), np.ones((m, m)))
+            C = C * mask
+        out.append(sp.csc_matrix(E.s0 ** 2 * C))
+    return out[0] if len(out) == 1 else tuple(out)
+
+
+# ----------------------------------------------------------------------------
 # Test method: central-difference Jacobian (misc/jacapprox.m:35-61)
 # ----------------------------------------------------------------------------
 

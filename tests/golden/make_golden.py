@@ -44,17 +44,40 @@ def parse_report(path):
         if m:
             io[key] = float(m.group(1))
     out['IO_report'] = io   # report sign convention: py, K, P flipped vs IO.val
-    photos = []
+    # posterior standard deviations ("Deviation" lines; bundle_result_file.m:128-130 from bundle_cov)
+    iod = {}
+    for key, pat in [('cc', r'Camera Constant:\s+Value:[^\n]*\n\s+Deviation:\s+([-\d.eE+]+)'),
+                     ('px', r'px - principal point x:\s+Value:[^\n]*\n\s+Deviation:\s+([-\d.eE+]+)'),
+                     ('py', r'py - principal point y:\s+Value:[^\n]*\n\s+Deviation:\s+([-\d.eE+]+)'),
+                     ('K1', r'K1 - radial distortion 1:\s+Value:[^\n]*\n\s+Deviation:\s+([-\d.eE+]+)'),
+                     ('K2', r'K2 - radial distortion 2:\s+Value:[^\n]*\n\s+Deviation:\s+([-\d.eE+]+)'),
+                     ('K3', r'K3 - radial distortion 3:\s+Value:[^\n]*\n\s+Deviation:\s+([-\d.eE+]+)'),
+                     ('P1', r'P1 - decentering distortion 1:\s+Value:[^\n]*\n\s+Deviation:\s+([-\d.eE+]+)'),
+                     ('P2', r'P2 - decentering distortion 2:\s+Value:[^\n]*\n\s+Deviation:\s+([-\d.eE+]+)'),
+                     ('as', r'as - off-unit aspect parameter:\s+Value:[^\n]*\n\s+Deviation:\s+([-\d.eE+]+)')]:
+        m = g(pat)
+        if m:
+            iod[key] = float(m.group(1))
+    out['IO_deviation'] = iod
+    m = g(r'Total standard deviation \(RMS of X/Y/Z std\):\s+Minimum: ([-\d.eE+]+) \(OP (\d+)\)\s+Maximum: ([-\d.eE+]+) \(OP (\d+)\)')
+    if m:
+        out['OP_total_std'] = {'min': float(m.group(1)), 'min_id': int(m.group(2)),
+                               'max': float(m.group(3)), 'max_id': int(m.group(4))}
+        out['OP_max_std'] = [float(g(r'Maximum %s standard deviation: ([-\d.eE+]+)' % c).group(1)) for c in 'XYZ']
+    photos, pdev = [], []
     blocks = re.split(r'Photo (\d+): \S+', txt)
     for i in range(1, len(blocks), 2):
         b = blocks[i + 1]
-        vals = []
+        vals, devs = [], []
         for key in ('Omega', 'Phi', 'Kappa', 'Xc', 'Yc', 'Zc'):
             m = re.search(key + r':\s+Value:\s+([-\d.]+)', b)
             vals.append(float(m.group(1)))
+            m = re.search(key + r':\s+Value:[^\n]*\n\s+Deviation:\s+([-\d.eE+]+)', b)
+            devs.append(float(m.group(1)) if m else None)
         assert int(blocks[i]) == len(photos) + 1
-        photos.append(vals)
+        photos.append(vals); pdev.append(devs)
     out['EO_report_deg'] = photos   # omega, phi, kappa [deg], Xc, Yc, Zc
+    out['EO_deviation'] = pdev      # same order; angles in degrees
     return out
 
 

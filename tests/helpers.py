@@ -59,6 +59,34 @@ def check_camcal_against_report(res, s0, E, exp, sig=6):
     assert np.abs(res.EO.val[:3].T - eo[:, 3:]).max() < 1e-6
 
 
+def check_camcal_cov_against_report(s, CIO, CEO, COP, exp):
+    """Posterior standard deviations against the "Deviation" values of the
+    reference report (3 significant digits; angles printed in degrees) and its
+    point-precision summary (2 significant digits, bundle_result_file.m:674-700)."""
+    def close(a, b, digits):
+        return abs(a - b) <= 0.51 * 10.0 ** (np.floor(np.log10(abs(b))) - digits + 1) * 1.02
+    sd_io = np.sqrt(CIO.diagonal()).reshape(s.IO.val.shape, order='F')[:, 0]
+    got = {'cc': sd_io[0], 'px': sd_io[1], 'py': sd_io[2], 'as': sd_io[3], 'K1': sd_io[5],
+           'K2': sd_io[6], 'K3': sd_io[7], 'P1': sd_io[8], 'P2': sd_io[9]}
+    for k, v in exp['IO_deviation'].items():
+        assert close(got[k], v, 3), ('IO', k, got[k], v)
+    sd_eo = np.sqrt(CEO.diagonal()).reshape(s.EO.val.shape, order='F')[:6].T   # X Y Z om ph ka
+    dev = np.array(exp['EO_deviation'], float)                                # om ph ka [deg] X Y Z
+    for i in range(dev.shape[0]):
+        for j in range(3):
+            assert close(np.rad2deg(sd_eo[i, 3 + j]), dev[i, j], 3), ('EO angle', i, j)
+            assert close(sd_eo[i, j], dev[i, 3 + j], 3), ('EO pos', i, j)
+    var = COP.diagonal().reshape(s.OP.val.shape, order='F')
+    var = np.where(np.asarray(s.bundle.est.OP, bool), var, np.nan)
+    tstd = np.sqrt(var.sum(0))
+    ids = np.asarray(s.OP.id)
+    ts = exp['OP_total_std']
+    assert close(np.nanmin(tstd), ts['min'], 2) and close(np.nanmax(tstd), ts['max'], 2)
+    assert ids[np.nanargmax(tstd)] == ts['max_id']
+    for c in range(3):
+        assert close(np.sqrt(np.nanmax(var[c])), exp['OP_max_std'][c], 2), ('OP', c)
+
+
 # ---------------------------------------------------------------------------
 # seeded synthetic variants used by the parity tests
 # ---------------------------------------------------------------------------

@@ -538,3 +538,40 @@ def test_giant_points(hip, variant, monkeypatch):
     res, ok, iters, s0, E = bundle(s, 'gna')
     ro, oko, ito, s0o, Eo = o.bundle(s, 'gna')
     assert ok and oko and iters == ito and relerr(E.x, Eo.x) < TOL_X
+
+
+@pytest.mark.parametrize('model', [3, 5])
+def test_posterior_covariance_camcal_known_answer(hip, model):
+    """bundle_cov on the GPU (inv(S) and the per-point blocks from the Schur
+    pieces) against the standard deviations printed in the reference's camcal
+    reports, and against the oracle's dense inverse of the full normal matrix."""
+    from dbat_amd import bundle, bundle_cov
+    from helpers import check_camcal_cov_against_report
+    exp = camcal_expected()['model%d' % model]
+    res, ok, iters, s0, E = bundle(camcal_struct(model), 'gna')
+    assert ok
+    CIO, CEO, COP = bundle_cov(res, E, 'CIO', 'CEO', 'COP')
+    check_camcal_cov_against_report(res, CIO, CEO, COP, exp)
+    ro, oko, ito, s0o, Eo = o.bundle(camcal_struct(model), 'gna')
+    CIOo, CEOo, COPo = o.bundle_cov(ro, Eo, 'CIO', 'CEO', 'COP')
+    for A, B in ((CIO, CIOo), (CEO, CEOo), (COP, COPo)):
+        assert abs(A - B).max() <= 1e-6 * abs(B).max()
+    CEOF = bundle_cov(res, E, 'CEOF')
+    assert abs(CEOF - o.bundle_cov(ro, Eo, 'CEOF')).max() <= 1e-6 * abs(CEOo).max()
+
+
+@pytest.mark.parametrize('variant', ['plain', 'selfcal', 'imagevar', 'priors'])
+def test_posterior_covariance_synthetic(hip, variant):
+    from dbat_amd import bundle, bundle_cov
+    s, truth = synth_struct('tiny', variant)
+    res, ok, iters, s0, E = bundle(s, 'gna')
+    ro, oko, ito, s0o, Eo = o.bundle(s, 'gna')
+    assert ok and oko
+    got = bundle_cov(res, E, 'CIO', 'CEO', 'COP')
+    want = o.bundle_cov(ro, Eo, 'CIO', 'CEO', 'COP')
+    for A, B in zip(got, want):
+        assert A.shape == B.shape
+        if abs(B).max() > 0:
+            assert abs(A - B).max() <= 1e-6 * abs(B).max()
+        else:
+            assert abs(A).max() == 0

@@ -27,6 +27,22 @@ def test_roma_script_known_answer():
     check_roma_against_result(res, s0, E, iters, roma_expected())
 
 
+@pytest.mark.parametrize('model', [2, 3, 4, 5])
+def test_camcal_posterior_covariance_known_answer(model):
+    """bundle_cov.m: the standard deviations of all IO and EO parameters and the
+    point-precision summary of the reference's camcal reports."""
+    from helpers import check_camcal_cov_against_report
+    exp = camcal_expected()['model%d' % model]
+    res, ok, iters, s0, E = o.bundle(camcal_struct(model), 'gna')
+    assert ok
+    CIO, CEO, COP = o.bundle_cov(res, E, 'CIO', 'CEO', 'COP')
+    check_camcal_cov_against_report(res, CIO, CEO, COP, exp)
+    # block-diagonal pieces agree with the full matrix
+    CXX = o.bundle_cov(res, E, 'CXX')
+    src = res.bundle.deserial.EO.src
+    assert np.allclose(np.sqrt(np.diag(CXX)[src]), np.sqrt(CEO.diagonal()[res.bundle.deserial.EO.dest]))
+
+
 @pytest.mark.parametrize('damping', ['lm', 'lmp', 'gm'])
 def test_camcal_known_answer_other_dampings(damping):
     exp = camcal_expected()['model3']
