@@ -575,3 +575,38 @@ def test_posterior_covariance_synthetic(hip, variant):
             assert abs(A - B).max() <= 1e-6 * abs(B).max()
         else:
             assert abs(A).max() == 0
+
+
+def test_posterior_covariance_C1_sampled(hip):
+    """100 cams / 10k pts: blocks of inv(J'J) for a sample of points and images
+    from sparse direct solves with unit vectors (the oracle's dense inverse
+    would need 7.5 GB) against the device's Schur-block formulation."""
+    import scipy.sparse.linalg as spl
+    from dbat_amd import bundle, bundle_cov
+    s, truth = synth_struct('C1', 'plain')
+    res, ok, iters, s0, E = bundle(s, 'gna')
+    assert ok
+    CEO, COP = bundle_cov(res, E, 'CEO', 'COP')
+    so, x, w = oracle_setup(res)
+    r_o, K = o.brown_euler_cam4(x, so, jac=True)
+    J = (sp.diags(np.sqrt(w)) @ K).tocsc()
+    lu = spl.splu((J.T @ J).tocsc())
+    des = so.bundle.deserial
+    def block(src):
+        Eu = np.zeros((J.shape[1], len(src))); Eu[src, np.arange(len(src))] = 1.0
+        return E.s0 ** 2 * lu.solve(Eu)[src]
+    xOP = np.full(res.OP.val.size, -1); xOP[des.OP.dest] = des.OP.src
+    for p in (0, 1234, 5000, 9999):
+        src = xOP[3 * p:3 * p + 3]
+        assert np.all(src >= 0)
+        want = block(src)
+        got = COP[3 * p:3 * p + 3, 3 * p:3 * p + 3].toarray()
+        assert np.abs(got - want).max() <= 1e-6 * np.abs(want).max()
+    m = res.EO.val.shape[0]
+    xEO = np.full(res.EO.val.size, -1); xEO[des.EO.dest] = des.EO.src
+    for c in (5, 50, 99):
+        src = xEO[m * c:m * c + 6]
+        keep = src >= 0
+        want = block(src[keep])
+        got = CEO[m * c:m * c + 6, m * c:m * c + 6].toarray()[np.ix_(keep, keep)]
+        assert np.abs(got - want).max() <= 1e-6 * np.abs(want).max()
