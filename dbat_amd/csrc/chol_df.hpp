@@ -12,7 +12,15 @@
 //       i == k :  L(k,k) = chol(T), Linv_k = L(k,k)^-1      (df_potf2: 16-column panels in registers,
 //                                                           trailing updates on the matrix cores)
 //       i  > k :  L(i,k) = T Linv_k'                        f64 MFMA
-//   jlo = max(kfirst[i], kfirst[k]) -- the envelope is closed under fill.
+//   The sum runs over the columns j whose tiles exist in both tile rows (the
+//   pattern is closed under fill).
+//
+// Two layouts (DfView): IN PLACE -- S where it lies, natural order, pattern =
+// envelope of the camera co-visibility band; PERMUTED -- the cameras in
+// nested-dissection order, P S P' gathered into compact 64 x 64 tiles, pattern
+// from a symbolic tile factorisation.  With the permutation the independent
+// parts of the camera network factor concurrently and only the separators form
+// a dependent chain; in natural (acquisition) order all n/64 panels do.
 //
 // Workgroups take tasks from an atomic counter in column-major order, so every
 // dependency of a task has a smaller number and is already owned by a running
@@ -25,6 +33,9 @@
 // The right-hand side is tile row nT (one valid row, row n of the array): the
 // forward substitution rides along exactly as in chol.hpp.
 #pragma once
+#include <cstdio>
+#include <functional>
+
 #include "chol.hpp"
 
 namespace dbat {
@@ -162,17 +173,35 @@ __device__ __forceinline__ bool df_spin_wave(const int *flag, int epoch, int *ab
 
 constexpr unsigned long long DF_SENTINEL = 0xFFFFFFFFFFFFFFFFull;   // q entries not yet solved (a NaN no arithmetic produces)
 
+// Where the tiles live.  The kernel addresses tile (i,k) -- rows [64i, 64i+64)
+// x columns [64k, 64k+64) of the (possibly permuted) reduced system, i == nT:
+// the right-hand-side row -- as  base + toff[i*nT + k] + c*ld + r.
+//   in place : base = S, toff = 64k*ldS + 64i (i == nT: + n), ld = ldS
+//   tiles    : base = compact tile storage, toff = 4096 * tile number, ld = 64
+// rowbits[i] is the set of columns j <= i whose tile (i,j) is structurally
+// non-zero after fill (W 64-bit words per row); a task only multiplies tiles
+// that exist in both of its rows.
+struct DfView {
+    double *base;
+    const int64_t *toff;        // [(nT+1)*nT], -1 = structurally zero
+    int64_t ld;
+    const uint64_t *rowbits;    // [(nT+1)*W]
+    int W;
+    const int *iperm;           // permuted index -> natural index (nullptr: identity)
+};
+
 // Backward substitution task of panel j:  q_j = Linv_j' (y_j - sum_{i>j} L(i,j)' q_i).
 // Lane = row of the tile L(i,j), 16 of its columns per thread in registers; the
 // products with q_i accumulate lane-wise over all tiles of the block column and
 // are summed across lanes once at the end.  Tiles are fetched before their q_i
 // is polled, so when the last q (panel j+1) arrives only 16 FMAs, the reduction
-// and the 64 x 64 product with Linv_j' remain.  q entries double as their own
-// flags (DF_SENTINEL until solved).
-__device__ __forceinline__ bool df_backward(double *smem, const double *A, int64_t lda, int n, int nT, int j,
+// and the 64 x 64 product with Linv_j' remain.  q entries (in the order of the
+// factorised system) double as their own flags (DF_SENTINEL until solved); the
+// solution also goes to q_nat in natural order.
+__device__ __forceinline__ bool df_backward(double *smem, const DfView &V, int n, int nT, int j,
                                             const int *__restrict__ bk_ptr, const int *__restrict__ bk_idx,
                                             const int *flags, int epoch, int *abort_flag, const double *linv_all,
-                                            double *q_out) {
+                                            double *q_out, double *q_nat) {
     constexpr int NB = 64, LD = 65;
     const int t = threadIdx.x, tx = t & 63, ty = t >> 6;
     const int nc = min(NB, n - NB * j);
@@ -185,7 +214,7 @@ __device__ __forceinline__ bool df_backward(double *smem, const double *A, int64
     double lv[16];                                      // Linv(k = ty + 4q, c = tx)
 #pragma unroll
     for (int q = 0; q < 16; ++q) lv[q] = ld_coh(linv_all + (size_t)j * NB * NB + tx * NB + ty + 4 * q);
-    const double yv = tx < nc ? ld_coh(A + (col0 + tx) * lda + n) : 0.0;   // y_j(tx) (every wave)
+    const double yv = tx < nc ? ld_coh(V.base + V.toff[(int64_t)nT * nT + j] + (int64_t)tx * V.ld) : 0.0;   // y_j(tx)
     double acc[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.0;
@@ -194,9 +223,9 @@ __device__ __forceinline__ bool df_backward(double *smem, const double *A, int64
         const int nr = min(NB, n - NB * i);
         if (!df_spin_wave(flags + (int64_t)i * nT + j, epoch, abort_flag)) return false;
         double v[16];
-        const double *Lt = A + col0 * lda + (int64_t)NB * i + tx;
+        const double *Lt = V.base + V.toff[(int64_t)i * nT + j] + tx;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = (tx < nr && ty + 4 * q < nc) ? ld_coh(Lt + (int64_t)(ty + 4 * q) * lda) : 0.0;
+        for (int q = 0; q < 16; ++q) v[q] = (tx < nr && ty + 4 * q < nc) ? ld_coh(Lt + (int64_t)(ty + 4 * q) * V.ld) : 0.0;
         double qv = 0.0;
         int spins = 0;
         for (;;) {
@@ -231,17 +260,24 @@ __device__ __forceinline__ bool df_backward(double *smem, const double *A, int64
         red[ty * NB + tx] = s;
     }
     __syncthreads();
-    if (ty == 0 && tx < nc) st_coh(q_out + col0 + tx, (red[tx] + red[NB + tx]) + (red[2 * NB + tx] + red[3 * NB + tx]));
+    if (ty == 0 && tx < nc) {
+        const double qj = (red[tx] + red[NB + tx]) + (red[2 * NB + tx] + red[3 * NB + tx]);
+        st_coh(q_out + col0 + tx, qj);
+        if (q_nat != q_out) {
+            const int zn = V.iperm ? V.iperm[col0 + tx] : (int)(col0 + tx);
+            if (zn >= 0) q_nat[zn] = qj;                 // < 0: padding row of the permuted system
+        }
+    }
     __syncthreads();                                    // smem is reused by the next task
     return true;
 }
 
-__global__ __launch_bounds__(256) void k_chol_df(double *__restrict__ A, int64_t lda, int n, int nT,
-                                                 const int *__restrict__ kfirst, const DfTask *__restrict__ tasks,
+__global__ __launch_bounds__(256) void k_chol_df(DfView V, int n, int nT, const DfTask *__restrict__ tasks,
                                                  int ntasks, int *__restrict__ flags, int *__restrict__ ctl, int epoch,
                                                  double *__restrict__ linv_all, int *__restrict__ info,
                                                  long long *__restrict__ trace, const int *__restrict__ bk_ptr,
-                                                 const int *__restrict__ bk_idx, double *__restrict__ q_out) {
+                                                 const int *__restrict__ bk_idx, double *__restrict__ q_out,
+                                                 double *__restrict__ q_nat, double *__restrict__ ldiag) {
     constexpr int NB = 64, LD = DF_LD;
     __shared__ double smem[2 * NB * LD];                // Pm | Qm, or the augmented block of df_potf2
     double *Pm = smem, *Qm = smem + NB * LD;
@@ -256,8 +292,8 @@ __global__ __launch_bounds__(256) void k_chol_df(double *__restrict__ A, int64_t
             // backward substitution, panels last to first (q_out == nullptr: factor only)
             if (q_out == nullptr || task >= ntasks + nT) return;
             if (trace && t == 0) trace[task * 16 + 0] = wall_clock64();
-            if (!df_backward(smem, A, lda, n, nT, nT - 1 - (task - ntasks), bk_ptr, bk_idx, flags, epoch, abort_flag,
-                             linv_all, q_out)) {
+            if (!df_backward(smem, V, n, nT, nT - 1 - (task - ntasks), bk_ptr, bk_idx, flags, epoch, abort_flag,
+                             linv_all, q_out, q_nat)) {
                 if (t == 0) *info = -1;
                 return;
             }
@@ -265,11 +301,10 @@ __global__ __launch_bounds__(256) void k_chol_df(double *__restrict__ A, int64_t
             continue;
         }
         const int i = tasks[task].i, k = tasks[task].k;
-        const int64_t row0 = i == nT ? (int64_t)n : (int64_t)NB * i;
         const int nr = i == nT ? 1 : min(NB, n - NB * i);
         const int64_t col0 = (int64_t)NB * k;
         const int nc = min(NB, n - NB * k);
-        const int jlo = max(kfirst[i], kfirst[k]);
+        double *Tik = V.base + V.toff[(int64_t)i * nT + k];
         if (trace && t == 0) trace[task * 16 + 0] = wall_clock64();
         // original tile values in the accumulator layout: (c = 16*ty + (tx>>4) + 4e, r = 16*rt + (tx&15))
         chol_d4 orig[4];
@@ -279,33 +314,41 @@ __global__ __launch_bounds__(256) void k_chol_df(double *__restrict__ A, int64_t
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int c = 16 * ty + (tx >> 4) + 4 * e, r = 16 * rt + (tx & 15);
-                    orig[rt][e] = (r < nr && c < nc) ? A[(col0 + c) * lda + row0 + r] : 0.0;
+                    orig[rt][e] = (r < nr && c < nc) ? Tik[(int64_t)c * V.ld + r] : 0.0;
                 }
         }
         chol_d4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
         bool alive = true;
-        for (int j = jlo; j < k; ++j) {
-            if (t == 0) {
-                bool ok = df_spin(flags + (int64_t)k * nT + j, epoch, abort_flag);
-                if (ok && i != k) ok = df_spin(flags + (int64_t)i * nT + j, epoch, abort_flag);
-                s_ok = ok;
+        // T -= L(i,j) L(k,j)' over the columns j < k present in both tile rows
+        const uint64_t *bi = V.rowbits + (size_t)i * V.W, *bk = V.rowbits + (size_t)k * V.W;
+        for (int w = 0; w <= (k >> 6) && alive; ++w) {
+            uint64_t m = bi[w] & bk[w];
+            if (w == (k >> 6)) m &= (1ull << (k & 63)) - 1;     // j < k
+            while (m) {
+                const int j = 64 * w + __builtin_ctzll(m);
+                m &= m - 1;
+                if (t == 0) {
+                    bool ok = df_spin(flags + (int64_t)k * nT + j, epoch, abort_flag);
+                    if (ok && i != k) ok = df_spin(flags + (int64_t)i * nT + j, epoch, abort_flag);
+                    s_ok = ok;
+                }
+                __syncthreads();                        // also: the previous MFMA pass has read Pm/Qm
+                if (!s_ok) { alive = false; break; }
+                {
+                    const double *Lk = V.base + V.toff[(int64_t)k * nT + j] + tx;     // L(64k + tx, 64j + m)
+                    const double *Li = V.base + V.toff[(int64_t)i * nT + j] + tx;     // L(row0 + tx, 64j + m)
+                    const bool okc = tx < nc, okr = tx < nr && i != k;
+                    double vk[16], vi[16];              // all loads in flight before the first use
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) vk[q] = okc ? ld_coh(Lk + (int64_t)(ty + 4 * q) * V.ld) : 0.0;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) vi[q] = okr ? ld_coh(Li + (int64_t)(ty + 4 * q) * V.ld) : 0.0;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) { Pm[(ty + 4 * q) * LD + tx] = vk[q]; Qm[(ty + 4 * q) * LD + tx] = vi[q]; }
+                }
+                __syncthreads();
+                mfma_tile64<LD>(Pm, i == k ? Pm : Qm, ty, tx, acc);
             }
-            __syncthreads();                                // also: the previous MFMA pass has read Pm/Qm
-            if (!s_ok) { alive = false; break; }
-            {
-                const double *Lk = A + (int64_t)NB * j * lda + col0 + tx;     // L(64k + tx, 64j + m)
-                const double *Li = A + (int64_t)NB * j * lda + row0 + tx;     // L(row0 + tx, 64j + m)
-                const bool okc = tx < nc, okr = tx < nr && i != k;
-                double vk[16], vi[16];                      // all loads in flight before the first use
-#pragma unroll
-                for (int q = 0; q < 16; ++q) vk[q] = okc ? ld_coh(Lk + (int64_t)(ty + 4 * q) * lda) : 0.0;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) vi[q] = okr ? ld_coh(Li + (int64_t)(ty + 4 * q) * lda) : 0.0;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) { Pm[(ty + 4 * q) * LD + tx] = vk[q]; Qm[(ty + 4 * q) * LD + tx] = vi[q]; }
-            }
-            __syncthreads();
-            mfma_tile64<LD>(Pm, i == k ? Pm : Qm, ty, tx, acc);
         }
         if (!alive) { if (t == 0) *info = -1; return; }
         __syncthreads();
@@ -323,12 +366,15 @@ __global__ __launch_bounds__(256) void k_chol_df(double *__restrict__ A, int64_t
                 }
             if (trace && t == 0) trace[task * 16 + 2] = wall_clock64();
             df_potf2(smem, nc, (int)col0, info, trace ? trace + task * 16 : nullptr);
-            // L -> A (lower triangle), L^-1 -> Linv[c*64 + i] = Linv(i, c) = smem[i][64 + c]
-            double *A0 = A + col0 * lda + col0;
+            // L -> tile (lower triangle), L^-1 -> Linv[c*64 + i] = Linv(i, c) = smem[i][64 + c]
 #pragma unroll 4
             for (int c = ty; c < NB; c += 4) {
-                if (tx < nc && c < nc && tx >= c) st_coh(A0 + (int64_t)c * lda + tx, smem[c * DF_TLD + tx]);
+                if (tx < nc && c < nc && tx >= c) st_coh(Tik + (int64_t)c * V.ld + tx, smem[c * DF_TLD + tx]);
                 st_coh(Linv + c * NB + tx, (tx < nc && c < nc) ? smem[tx * DF_TLD + 64 + c] : 0.0);
+            }
+            if (ldiag && ty == 0 && tx < nc) {          // the pivots, by natural index (k_diag_minmax)
+                const int zn = V.iperm ? V.iperm[col0 + tx] : (int)(col0 + tx);
+                if (zn >= 0) ldiag[zn] = smem[tx * DF_TLD + tx];
             }
         } else {
             // T(r, c) = orig - acc  ->  Qm[c][r]
@@ -359,7 +405,7 @@ __global__ __launch_bounds__(256) void k_chol_df(double *__restrict__ A, int64_t
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int c = 16 * ty + (tx >> 4) + 4 * e, r = 16 * rt + (tx & 15);
-                        if (r < nr && c < nc) st_coh(A + (col0 + c) * lda + row0 + r, x[rt][e]);
+                        if (r < nr && c < nc) st_coh(Tik + (int64_t)c * V.ld + r, x[rt][e]);
                     }
             }
         }
@@ -371,67 +417,244 @@ __global__ __launch_bounds__(256) void k_chol_df(double *__restrict__ A, int64_t
     }
 }
 
+// S (natural order, dense column-major lower triangle + right-hand-side row n)
+// -> the non-zero tiles of P S P' in compact storage.  One workgroup per tile.
+__global__ __launch_bounds__(256) void k_gather_tiles(const double *__restrict__ S, int64_t ldS, int n_nat, int nT,
+                                                      const int *__restrict__ iperm, const DfTask *__restrict__ tile_ij,
+                                                      double *__restrict__ tiles) {
+    const DfTask tk = tile_ij[blockIdx.x];
+    double *T = tiles + (size_t)blockIdx.x * 4096;
+    for (int idx = threadIdx.x; idx < 4096; idx += 256) {
+        const int c = idx >> 6, r = idx & 63;
+        const int C = 64 * tk.k + c;
+        const int cn = iperm[C];                        // < 0: padding column (blocks start on tile boundaries)
+        double v = 0.0;
+        if (tk.i == nT) { if (r == 0 && cn >= 0) v = S[(int64_t)cn * ldS + n_nat]; }
+        else {
+            const int R = 64 * tk.i + r;
+            const int rn = iperm[R];
+            if (cn >= 0 && rn >= 0) v = rn >= cn ? S[(int64_t)cn * ldS + rn] : S[(int64_t)rn * ldS + cn];
+            else if (R == C) v = 1.0;
+        }
+        T[idx] = v;
+    }
+}
+
+// Host side: schedule (tile pattern, task list, tables) and launch.
+//   setup_inplace   factor S where it lies, natural order, envelope pattern
+//   setup_permuted  nested-dissection order of the cameras + symbolic tile
+//                   factorisation; the numeric phase gathers P S P' into compact
+//                   tiles first.  Independent sub-blocks of the camera network
+//                   then factor concurrently and only the separators form a chain,
+//                   instead of one chain over all n/64 panels.
 struct DataflowChol {
-    int n = 0, nT = 0, ntasks = 0, epoch = 0, grid = 512;
-    int *d_kfirst = nullptr, *d_flags = nullptr, *d_ctl = nullptr, *d_bk_ptr = nullptr, *d_bk_idx = nullptr;
-    DfTask *d_tasks = nullptr;
+    int n = 0, n_nat = 0, nT = 0, W = 0, ntasks = 0, ntiles = 0, epoch = 0, grid = 512;   // n: order of the factorised system (padded)
+    bool permuted = false;
+    int *d_flags = nullptr, *d_ctl = nullptr, *d_bk_ptr = nullptr, *d_bk_idx = nullptr, *d_iperm = nullptr;
+    int64_t *d_toff = nullptr;
+    uint64_t *d_rowbits = nullptr;
+    DfTask *d_tasks = nullptr, *d_tile_ij = nullptr;
+    double *d_tiles = nullptr, *d_qperm = nullptr;
     long long *d_trace = nullptr;                       // optional per-task timestamps (chol_test)
-    std::vector<int> panel_first;                       // for the backward pass (as CholEnvelope)
+    std::vector<int> perm;                              // natural -> permuted (empty: identity)
+    // doubles of the linv_work argument of solve(): one 64 x 64 inverse per tile row of the
+    // factorised (padded) system
+    size_t linv_doubles() const { return (size_t)std::max(nT, 1) * CHOL_NB * CHOL_NB; }
 
     void release() {
-        if (d_kfirst) (void)hipFree(d_kfirst);
-        if (d_flags) (void)hipFree(d_flags);
-        if (d_ctl) (void)hipFree(d_ctl);
-        if (d_tasks) (void)hipFree(d_tasks);
-        if (d_bk_ptr) (void)hipFree(d_bk_ptr);
-        if (d_bk_idx) (void)hipFree(d_bk_idx);
-        d_kfirst = d_flags = d_ctl = d_bk_ptr = d_bk_idx = nullptr; d_tasks = nullptr;
+        void *ps[] = {d_flags, d_ctl, d_bk_ptr, d_bk_idx, d_iperm, d_toff, d_rowbits, d_tasks, d_tile_ij, d_tiles, d_qperm};
+        for (void *p : ps) if (p) (void)hipFree(p);
+        d_flags = d_ctl = d_bk_ptr = d_bk_idx = d_iperm = nullptr; d_toff = nullptr; d_rowbits = nullptr;
+        d_tasks = d_tile_ij = nullptr; d_tiles = d_qperm = nullptr;
     }
-    bool setup(const CholEnvelope &env) {
-        release();
-        n = env.n; nT = (n + CHOL_NB - 1) / CHOL_NB; epoch = 0;
-        panel_first = env.panel_first;
-        std::vector<int> kf(nT + 1, 0);
-        for (int i = 0; i < nT; ++i) kf[i] = env.panel_first[i] / CHOL_NB;
+    template <class T>
+    static bool up(T *&dst, const std::vector<T> &v) {
+        if (hipMalloc((void **)&dst, std::max<size_t>(v.size(), 1) * sizeof(T)) != hipSuccess) return false;
+        if (!v.empty()) (void)hipMemcpy(dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+        return true;
+    }
+    // common part: nz[i] = bitset of columns k <= i with a structurally non-zero tile (i, k), i = 0..nT
+    // (row nT = right-hand side, all columns), fill included
+    bool finish_setup(const std::vector<uint64_t> &rowbits, const std::vector<int64_t> &toff) {
+        auto has = [&](int i, int k) { return (rowbits[(size_t)i * W + (k >> 6)] >> (k & 63)) & 1ull; };
         std::vector<DfTask> tasks;
         for (int k = 0; k < nT; ++k)
             for (int i = k; i <= nT; ++i)
-                if (kf[i] <= k) tasks.push_back(DfTask{i, k});
+                if (has(i, k)) tasks.push_back(DfTask{i, k});
         ntasks = (int)tasks.size();
-        // backward pass: per panel j the tile rows i > j (matrix rows only) that reach column j, last first
         std::vector<int> bptr(nT + 1, 0), bidx;
         for (int j = 0; j < nT; ++j) {
             for (int i = nT - 1; i > j; --i)
-                if (kf[i] <= j) bidx.push_back(i);
+                if (has(i, j)) bidx.push_back(i);
             bptr[j + 1] = (int)bidx.size();
         }
-        if (bidx.empty()) bidx.push_back(0);
-        if (hipMalloc(&d_bk_ptr, bptr.size() * sizeof(int)) != hipSuccess) return false;
-        if (hipMalloc(&d_bk_idx, bidx.size() * sizeof(int)) != hipSuccess) return false;
-        (void)hipMemcpy(d_bk_ptr, bptr.data(), bptr.size() * sizeof(int), hipMemcpyHostToDevice);
-        (void)hipMemcpy(d_bk_idx, bidx.data(), bidx.size() * sizeof(int), hipMemcpyHostToDevice);
-        if (hipMalloc(&d_kfirst, (nT + 1) * sizeof(int)) != hipSuccess) return false;
+        if (!up(d_tasks, tasks) || !up(d_bk_ptr, bptr) || !up(d_bk_idx, bidx) || !up(d_rowbits, rowbits) || !up(d_toff, toff))
+            return false;
         if (hipMalloc(&d_flags, (size_t)(nT + 1) * nT * sizeof(int)) != hipSuccess) return false;
         if (hipMalloc(&d_ctl, 2 * sizeof(int)) != hipSuccess) return false;
-        if (hipMalloc(&d_tasks, tasks.size() * sizeof(DfTask)) != hipSuccess) return false;
-        (void)hipMemcpy(d_kfirst, kf.data(), (nT + 1) * sizeof(int), hipMemcpyHostToDevice);
-        (void)hipMemcpy(d_tasks, tasks.data(), tasks.size() * sizeof(DfTask), hipMemcpyHostToDevice);
         (void)hipMemset(d_flags, 0, (size_t)(nT + 1) * nT * sizeof(int));
         if (const char *g = getenv("DBAT_HIP_DF_GRID")) grid = atoi(g);
+        epoch = 0;
         return true;
     }
-    // Factor the lower triangle of the n x n matrix in A (lda >= n+1, n+1 columns)
-    // and solve A q = b, b' in row n of A; q -> q_out.  linv_work as
-    // BlockChol::linv_doubles.  info_dev: > 0 first non-positive pivot (LAPACK
-    // potrf convention), -1 dataflow abort (spin cap).  One kernel launch.
-    void solve(hipStream_t stream, double *A, int64_t lda, double *q_out, double *linv_work, int *info_dev) {
+    bool setup_inplace(const CholEnvelope &env, int64_t lda) {
+        release();
+        permuted = false; perm.clear();
+        n = n_nat = env.n; nT = (n + CHOL_NB - 1) / CHOL_NB; W = (nT + 64) / 64;
+        std::vector<uint64_t> rb((size_t)(nT + 1) * W, 0);
+        std::vector<int64_t> toff((size_t)(nT + 1) * nT, -1);
+        for (int i = 0; i <= nT; ++i) {
+            const int kf = i < nT ? env.panel_first[i] / CHOL_NB : 0;
+            for (int k = kf; k <= std::min(i, nT - 1); ++k) {
+                rb[(size_t)i * W + (k >> 6)] |= 1ull << (k & 63);
+                toff[(size_t)i * nT + k] = (int64_t)CHOL_NB * k * lda + (i == nT ? (int64_t)n : (int64_t)CHOL_NB * i);
+            }
+        }
+        return finish_setup(rb, toff);
+    }
+    // adj: symmetric co-visibility bitsets of the nc cameras (adj_words 64-bit words per camera);
+    // xyz: 3 coordinates per camera (projection centres) for the geometric bisection;
+    // unknowns: 6 per camera, then nio dense IO unknowns.
+    bool setup_permuted(int nc, int nio, const uint64_t *adj, int adj_words, const double *xyz) {
+        release();
+        permuted = true;
+        n_nat = 6 * nc + nio;
+        auto adjacent = [&](int a, int b) { return (adj[(size_t)a * adj_words + (b >> 6)] >> (b & 63)) & 1ull; };
+        // ---- nested dissection by recursive coordinate bisection; separator = the cameras of the
+        // lower half that see a camera of the upper half
+        std::vector<int> order; order.reserve(nc);
+        std::vector<int> block_end;                     // order.size() after every leaf / separator block
+        const int leaf = std::max(8, getenv("DBAT_HIP_ND_LEAF") ? atoi(getenv("DBAT_HIP_ND_LEAF")) : 32);
+        std::function<void(std::vector<int> &)> nd = [&](std::vector<int> &cams) {
+            if ((int)cams.size() <= leaf) {
+                std::sort(cams.begin(), cams.end());
+                for (int c : cams) order.push_back(c);
+                block_end.push_back((int)order.size());
+                return;
+            }
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            for (int c : cams) for (int d = 0; d < 3; ++d) { lo[d] = std::min(lo[d], xyz[3 * c + d]); hi[d] = std::max(hi[d], xyz[3 * c + d]); }
+            int ax = 0;
+            for (int d = 1; d < 3; ++d) if (hi[d] - lo[d] > hi[ax] - lo[ax]) ax = d;
+            std::vector<int> s(cams);
+            std::stable_sort(s.begin(), s.end(), [&](int a, int b) { return xyz[3 * a + ax] < xyz[3 * b + ax]; });
+            const size_t half = s.size() / 2;
+            std::vector<int> A(s.begin(), s.begin() + half), B(s.begin() + half, s.end()), Sep, A2;
+            for (int a : A) {
+                bool touch = false;
+                for (int b : B) if (adjacent(a, b)) { touch = true; break; }
+                (touch ? Sep : A2).push_back(a);
+            }
+            if (Sep.size() * 2 >= cams.size() || A2.empty()) {     // no useful separator: one dense block
+                std::sort(cams.begin(), cams.end());
+                for (int c : cams) order.push_back(c);
+                block_end.push_back((int)order.size());
+                return;
+            }
+            nd(A2); nd(B);
+            std::sort(Sep.begin(), Sep.end());
+            for (int c : Sep) order.push_back(c);
+            block_end.push_back((int)order.size());
+        };
+        {
+            std::vector<int> all(nc);
+            for (int c = 0; c < nc; ++c) all[c] = c;
+            if (getenv("DBAT_HIP_ND_OFF")) { order = all; block_end.push_back(nc); } else nd(all);
+        }
+        // every block starts on a tile boundary (padding rows = identity): otherwise the tile that
+        // straddles two independent blocks chains them together
+        std::vector<int> rowpos(nc);                    // first row of every camera in the factorised order
+        int off = 0;
+        {
+            size_t b = 0; int q0 = 0;
+            for (int q = 0; q < nc; ++q) {
+                if (q == q0) off = (off + CHOL_NB - 1) / CHOL_NB * CHOL_NB;
+                rowpos[order[q]] = off; off += 6;
+                if (b < block_end.size() && q + 1 == block_end[b]) { q0 = q + 1; ++b; }
+            }
+        }
+        const int io0 = nio > 0 ? (off + CHOL_NB - 1) / CHOL_NB * CHOL_NB : off;
+        n = (io0 + nio + CHOL_NB - 1) / CHOL_NB * CHOL_NB;
+        nT = n / CHOL_NB; W = (nT + 64) / 64;
+        perm.assign(n_nat, 0);
+        std::vector<int> iperm((size_t)n, -1);
+        for (int c = 0; c < nc; ++c)
+            for (int a = 0; a < 6; ++a) perm[6 * c + a] = rowpos[c] + a;
+        for (int u = 0; u < nio; ++u) perm[6 * nc + u] = io0 + u;
+        for (int z = 0; z < n_nat; ++z) iperm[perm[z]] = z;
+        auto pos6 = [&](int c) { return rowpos[c]; };
+        // ---- tile pattern of P S P' (lower), IO rows and the right-hand side dense, then symbolic fill
+        std::vector<uint64_t> rb((size_t)(nT + 1) * W, 0);
+        auto setbit = [&](int i, int k) { rb[(size_t)i * W + (k >> 6)] |= 1ull << (k & 63); };
+        for (int a = 0; a < nc; ++a) {
+            const int ta0 = pos6(a) / CHOL_NB, ta1 = (pos6(a) + 5) / CHOL_NB;
+            for (int w = 0; w < adj_words; ++w) {
+                uint64_t m = adj[(size_t)a * adj_words + w];
+                while (m) {
+                    const int b = 64 * w + __builtin_ctzll(m);
+                    m &= m - 1;
+                    if (b >= nc) break;
+                    const int tb0 = pos6(b) / CHOL_NB, tb1 = (pos6(b) + 5) / CHOL_NB;
+                    for (int ti = ta0; ti <= ta1; ++ti)
+                        for (int tj = tb0; tj <= tb1; ++tj) setbit(std::max(ti, tj), std::min(ti, tj));
+                }
+            }
+            for (int ti = ta0; ti <= ta1; ++ti) for (int tj = ta0; tj <= ti; ++tj) setbit(ti, tj);
+        }
+        for (int i = 0; i < nT; ++i) setbit(i, i);
+        for (int i = io0 / CHOL_NB; i < nT && nio > 0; ++i) for (int k = 0; k <= i; ++k) setbit(i, k);
+        for (int k = 0; k < nT; ++k) setbit(nT, k);
+        {   // fill: eliminating column k couples all rows below it
+            std::vector<int> rows;
+            for (int k = 0; k < nT; ++k) {
+                rows.clear();
+                for (int i = k + 1; i <= nT; ++i) if ((rb[(size_t)i * W + (k >> 6)] >> (k & 63)) & 1ull) rows.push_back(i);
+                for (size_t a = 0; a < rows.size(); ++a)
+                    for (size_t b = 0; b <= a; ++b)
+                        if (rows[b] < nT) setbit(rows[a], rows[b]);
+            }
+        }
+        // ---- compact tile storage, column-major over the pattern
+        std::vector<int64_t> toff((size_t)(nT + 1) * nT, -1);
+        std::vector<DfTask> tile_ij;
+        for (int k = 0; k < nT; ++k)
+            for (int i = k; i <= nT; ++i)
+                if ((rb[(size_t)i * W + (k >> 6)] >> (k & 63)) & 1ull) {
+                    toff[(size_t)i * nT + k] = (int64_t)tile_ij.size() * 4096;
+                    tile_ij.push_back(DfTask{i, k});
+                }
+        ntiles = (int)tile_ij.size();
+        if (!up(d_tile_ij, tile_ij) || !up(d_iperm, iperm)) return false;
+        if (hipMalloc(&d_tiles, (size_t)ntiles * 4096 * sizeof(double)) != hipSuccess) return false;
+        if (hipMalloc(&d_qperm, (size_t)nT * CHOL_NB * sizeof(double)) != hipSuccess) return false;
+        if (getenv("DBAT_HIP_PLAN_STATS"))
+            fprintf(stderr, "[chol] order %d (%d with block padding, %zu blocks), %d tile rows, %d tiles (%.1f MB), dense lower triangle would be %d tiles\n",
+                    n_nat, n, block_end.size(), nT, ntiles, ntiles * 32768.0 / 1e6, nT * (nT + 1) / 2 + nT);
+        return finish_setup(rb, toff);
+    }
+    // Factor and solve S q = b (b' in row n of S, lower triangle of S, leading dimension lda).
+    // q -> q_out (natural order).  In-place mode leaves L in S; permuted mode leaves S untouched.
+    // ldiag (optional, n entries): the pivots diag(L) by natural index.  linv_work as
+    // BlockChol::linv_doubles.  info_dev: > 0 first non-positive pivot (index in the factorised
+    // order), -1 dataflow abort (spin cap).
+    void solve(hipStream_t stream, double *A, int64_t lda, double *q_out, double *linv_work, int *info_dev,
+               double *ldiag = nullptr) {
         (void)hipMemsetAsync(info_dev, 0, sizeof(int), stream);
         (void)hipMemsetAsync(d_ctl, 0, 2 * sizeof(int), stream);
-        (void)hipMemsetAsync(q_out, 0xFF, (size_t)n * sizeof(double), stream);      // DF_SENTINEL
         ++epoch;
-        hipLaunchKernelGGL(k_chol_df, dim3(std::min(grid, ntasks + nT)), dim3(256), 0, stream, A, lda, n, nT, d_kfirst,
-                           d_tasks, ntasks, d_flags, d_ctl, epoch, linv_work, info_dev, d_trace, d_bk_ptr, d_bk_idx,
-                           q_out);
+        DfView V;
+        V.toff = d_toff; V.rowbits = d_rowbits; V.W = W;
+        double *qflag;
+        if (permuted) {
+            hipLaunchKernelGGL(k_gather_tiles, dim3(ntiles), dim3(256), 0, stream, A, lda, n_nat, nT, d_iperm, d_tile_ij, d_tiles);
+            V.base = d_tiles; V.ld = 64; V.iperm = d_iperm; qflag = d_qperm;
+            (void)hipMemsetAsync(d_qperm, 0xFF, (size_t)nT * CHOL_NB * sizeof(double), stream);   // DF_SENTINEL
+        } else {
+            V.base = A; V.ld = lda; V.iperm = nullptr; qflag = q_out;
+            (void)hipMemsetAsync(q_out, 0xFF, (size_t)n * sizeof(double), stream);
+        }
+        hipLaunchKernelGGL(k_chol_df, dim3(std::min(grid, ntasks + nT)), dim3(256), 0, stream, V, n, nT, d_tasks, ntasks,
+                           d_flags, d_ctl, epoch, linv_work, info_dev, d_trace, d_bk_ptr, d_bk_idx, qflag, q_out, ldiag);
     }
 };
 

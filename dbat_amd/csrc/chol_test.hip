@@ -60,9 +60,9 @@ int main(int argc, char **argv) {
     std::vector<double> q(n); int info;
     CK(hipMemcpy(q.data(), dq, n * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(&info, dinfo, 4, hipMemcpyDeviceToHost));
     printf("own   blocked chol+solve n=%d: %.3f ms  (%.2f TFLOP/s)  info=%d\n", n, best, (double)n * n * n / 3 / best / 1e9, info);
-    // ---- dataflow
+    // ---- dataflow, in place
     {
-        dbat::DataflowChol df; df.setup(env);
+        dbat::DataflowChol df; df.setup_inplace(env, lda);
         float bdf = 1e9;
         for (int r = 0; r < reps; ++r) {
             CK(hipMemcpyAsync(dA, dA0, A.size() * 8, hipMemcpyDeviceToDevice, st));
@@ -76,47 +76,8 @@ int main(int argc, char **argv) {
         CK(hipMemcpy(qd.data(), dq, n * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(&infod, dinfo, 4, hipMemcpyDeviceToHost));
         double num = 0, den = 0;
         for (int i = 0; i < n; ++i) { num += (qd[i] - q[i]) * (qd[i] - q[i]); den += q[i] * q[i]; }
-        printf("dataflow chol+solve n=%d: %.3f ms  tasks=%d grid=%d info=%d  rel |q_df - q_own| = %.3e\n", n, bdf, df.ntasks,
-               df.grid, infod, std::sqrt(num / den));
-        // factor only timing
-        float bf = 1e9;
-        for (int r = 0; r < reps; ++r) {
-            CK(hipMemcpyAsync(dA, dA0, A.size() * 8, hipMemcpyDeviceToDevice, st));
-            CK(hipMemsetAsync(df.d_ctl, 0, 8, st)); ++df.epoch;
-            CK(hipEventRecord(e0, st));
-            hipLaunchKernelGGL(dbat::k_chol_df, dim3(std::min(df.grid, df.ntasks)), dim3(256), 0, st, dA, lda, n, df.nT,
-                               df.d_kfirst, df.d_tasks, df.ntasks, df.d_flags, df.d_ctl, df.epoch, dlinv, dinfo, (long long *)nullptr, df.d_bk_ptr, df.d_bk_idx, (double *)nullptr);
-            CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
-            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < bf) bf = ms;
-        }
-        printf("dataflow factor kernel only: %.3f ms\n", bf);
-        if (getenv("DF_TRACE")) {
-            CK(hipMalloc(&df.d_trace, (size_t)(df.ntasks + df.nT) * 16 * 8));
-            CK(hipMemcpyAsync(dA, dA0, A.size() * 8, hipMemcpyDeviceToDevice, st));
-            df.solve(st, dA, lda, dq, dlinv, dinfo); CK(hipStreamSynchronize(st));
-            std::vector<long long> tr((size_t)(df.ntasks + df.nT) * 16);
-            CK(hipMemcpy(tr.data(), df.d_trace, tr.size() * 8, hipMemcpyDeviceToHost));
-            std::vector<dbat::DfTask> tk(df.ntasks);
-            CK(hipMemcpy(tk.data(), df.d_tasks, tk.size() * sizeof(dbat::DfTask), hipMemcpyDeviceToHost));
-            const long long t0 = tr[0];
-            // 100 MHz clock: ticks of 10 ns
-            printf("task (i,k): start deps_ready diag_ready/potf2_start compute_done published [us]\n");
-            for (int q = 0; q < df.ntasks; ++q)
-                if (tk[q].k >= 40 && tk[q].k < 43 && tk[q].i <= tk[q].k + 2)
-                    printf("(%d,%d): %.2f %.2f %.2f %.2f %.2f\n", tk[q].i, tk[q].k, (tr[q * 16] - t0) * 0.01, (tr[q * 16 + 1] - t0) * 0.01,
-                           (tr[q * 16 + 2] - t0) * 0.01, (tr[q * 16 + 3] - t0) * 0.01, (tr[q * 16 + 4] - t0) * 0.01);
-            for (int q = 0; q < df.ntasks; ++q)
-                if (tk[q].k == 40 && tk[q].i == 40) {
-                    printf("potf2 phases (us from potf2 start):");
-                    for (int s = 6; s < 13; ++s) printf(" %.2f", (tr[q * 16 + s] - tr[q * 16 + 2]) * 0.01);
-                    printf("\n");
-                }
-            printf("backward tasks (start, done) us:");
-            for (int q = df.ntasks; q < df.ntasks + df.nT; ++q)
-                if ((q - df.ntasks) < 6 || q >= df.ntasks + df.nT - 3) printf(" [%.2f %.2f]", (tr[q * 16] - t0) * 0.01, (tr[q * 16 + 4] - t0) * 0.01);
-            printf("\n");
-            (void)hipFree(df.d_trace); df.d_trace = nullptr;
-        }
+        printf("dataflow (in place) chol+solve n=%d: %.3f ms  tasks=%d grid=%d info=%d  rel |q_df - q_own| = %.3e\n", n, bdf,
+               df.ntasks, df.grid, infod, std::sqrt(num / den));
         df.release();
     }
     // ---- rocsolver

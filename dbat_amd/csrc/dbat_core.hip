@@ -76,9 +76,11 @@ struct Core {
     DevBuf<double> red;      // [S | g_red | g_c | diagU | scal(8)]
     DevBuf<double> jn2c, dscale, rhs, Vinv, gp, jn2p, r_w, partial, scal;
     DevBuf<int> info;
-    DevBuf<double> ywork, linv;
-    DataflowChol dfchol;                // persistent task-graph Cholesky (chol_df.hpp)
-    bool use_df = true;
+    DevBuf<double> ywork, linv, ldiag;
+    DataflowChol dfchol;                // persistent task-graph Cholesky, cameras in nested-dissection order (chol_df.hpp)
+    DataflowChol dfchol_ip;             // the same in place, natural order (posterior covariance: L must end up in S)
+    bool use_df = true, use_perm = true;
+    bool chol_in_place = false;         // next factorisation must leave L in S
     int64_t ldS = 0;
     CholEnvelope env;
     DevBuf<unsigned long long> pivmm;   // [0..1] point pivots min/max, [2..3] reduced-system pivots
@@ -107,7 +109,7 @@ struct Core {
     ~Core() {
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         for (auto &e : kev) if (e) (void)hipEventDestroy(e);
-        dfchol.release();
+        dfchol.release(); dfchol_ip.release();
         if (blas) rocblas_destroy_handle(blas);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -159,7 +161,7 @@ struct Core {
         red_count = s_count + 3 * P.NS + 8;
         red.alloc(red_count);
         S = red.p; g_red = S + s_count; g_c = g_red + P.NS; diagU = g_c + P.NS; red_scal = diagU + P.NS;
-        ywork.alloc(P.NS); linv.alloc(BlockChol::linv_doubles((int)P.NS));
+        ywork.alloc(P.NS); ldiag.alloc(P.NS);
         {   // envelope of the reduced system from the camera co-visibility graph; IO rows are dense
             std::vector<int> first((size_t)P.NS, 0);
             for (int c = 0; c < P.nc; ++c)
@@ -180,7 +182,17 @@ struct Core {
                 col_bend.upload(cb); col_off.upload(co);
             }
             use_df = getenv("DBAT_HIP_BLOCKCHOL") == nullptr;       // the multi-launch BlockChol stays for A/B runs
-            if (use_df && !dfchol.setup(env)) throw DeviceError{"out of device memory (Cholesky schedule)"};
+            use_perm = use_df && getenv("DBAT_HIP_DF_NOPERM") == nullptr;
+            if (!dfchol_ip.setup_inplace(env, ldS)) throw DeviceError{"out of device memory (Cholesky schedule)"};
+            if (use_perm) {
+                std::vector<double> xyz((size_t)3 * P.nc);
+                for (int c = 0; c < P.nc; ++c)
+                    for (int k = 0; k < 3; ++k) xyz[(size_t)3 * c + k] = P.z0[(size_t)6 * c + k];
+                if (!dfchol.setup_permuted(P.nc, P.nIOu, P.cam_adj.data(), P.cam_adj_words, xyz.data()))
+                    throw DeviceError{"out of device memory (Cholesky schedule)"};
+            }
+            linv.alloc(std::max({BlockChol::linv_doubles((int)P.NS), dfchol_ip.linv_doubles(),
+                                 use_perm ? dfchol.linv_doubles() : (size_t)0}));
         }
         jn2c.alloc(P.NS); dscale.alloc(P.NS); rhs.alloc(P.NS);
         Vinv.alloc((size_t)6 * P.np); gp.alloc((size_t)3 * P.np); jn2p.alloc((size_t)3 * P.np);
@@ -393,10 +405,15 @@ struct Core {
     int factor_solve_enqueue() {
         mark(2);
         // Cholesky + both substitutions; q -> rhs.  One persistent dataflow kernel (chol_df.hpp)
-        if (use_df) dfchol.solve(stream, S, ldS, rhs.p, linv.p, info.p);
-        else BlockChol::solve(blas, stream, S, ldS, (int)P.NS, rhs.p, ywork.p, linv.p, info.p, env);
+        if (use_perm && !chol_in_place) dfchol.solve(stream, S, ldS, rhs.p, linv.p, info.p, ldiag.p);
+        else if (use_df) dfchol_ip.solve(stream, S, ldS, rhs.p, linv.p, info.p, ldiag.p);
+        else {
+            BlockChol::solve(blas, stream, S, ldS, (int)P.NS, rhs.p, ywork.p, linv.p, info.p, env);
+            HIPCHK(hipMemcpy2DAsync(ldiag.p, sizeof(double), S, (ldS + 1) * sizeof(double), sizeof(double), (size_t)P.NS,
+                                    hipMemcpyDeviceToDevice, stream));
+        }
         mark(3);
-        hipLaunchKernelGGL(k_diag_minmax, dim3(1), dim3(256), 0, stream, d, S, pivmm.p + 2);
+        hipLaunchKernelGGL(k_diag_minmax, dim3(1), dim3(256), 0, stream, d, ldiag.p, pivmm.p + 2);
         hipLaunchKernelGGL(k_unscale, dim3((unsigned)cdiv(P.NS, 256)), dim3(256), 0, stream, P.NS, rhs.p, dscale.p, dz.p);
         ++n_solves;
         return 0;
@@ -460,7 +477,9 @@ struct Core {
     void posterior_cov(double s0, double *hCEO, double *hCIO, double *hCOP, double *hSinv) {
         build(z.p, 0.0, 0);                          // unscaled, undamped reduced system + V^-1 per point
         s_valid = false;
+        chol_in_place = true;
         factor_solve_enqueue();                      // L in the lower triangle of S
+        chol_in_place = false;
         int hinfo = 0;
         HIPCHK(hipMemcpyAsync(&hinfo, info.p, sizeof(hinfo), hipMemcpyDeviceToHost, stream));
         sync();

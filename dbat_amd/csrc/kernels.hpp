@@ -1635,12 +1635,12 @@ __global__ __launch_bounds__(256) void k_pack_envelope(double *__restrict__ S, i
 }
 
 // min/max of the Cholesky pivots of the reduced system (estimated entries only)
-__global__ __launch_bounds__(256) void k_diag_minmax(DevProblem d, const double *__restrict__ S,
+__global__ __launch_bounds__(256) void k_diag_minmax(DevProblem d, const double *__restrict__ ldiag,
                                                      unsigned long long *__restrict__ pivmm) {
     double pmin = 1e300, pmax = 0.0;
     for (int64_t i = threadIdx.x; i < d.NS; i += blockDim.x)
         if (d.z_est[i]) {
-            double v = S[i * d.ldS + i];
+            double v = ldiag[i];                     // diag(L) by natural index (the factorisation may be permuted)
             v = v == v ? v : 0.0;
             pmin = fmin(pmin, v); pmax = fmax(pmax, v);
         }

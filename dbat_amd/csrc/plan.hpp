@@ -79,6 +79,8 @@ struct Plan {
     std::vector<uint32_t> cam_eo_est;
     std::vector<double> px;                        // [2*nc]
     std::vector<int32_t> cam_first;                // lowest camera index sharing an object point with each camera
+    std::vector<uint64_t> cam_adj;                 // [nc][cam_adj_words] co-visibility graph (bit c2 of row c1), symmetric
+    int cam_adj_words = 0;
     int max_k = 0;                                 // max observations of one point
     bool rank_ok = true;                           // structural rank test
     std::string err;
@@ -290,6 +292,21 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         for (int j = 1; j < k_pt[p]; ++j) {
             const int32_t c = pb.ip_cam[by_pt[pstart[p] + j]];
             if (c0 < P.cam_first[c]) P.cam_first[c] = c0;
+        }
+    }
+    // full co-visibility graph of the cameras: the pattern of the reduced system
+    // (ordering + symbolic factorisation of the tile Cholesky, chol_df.hpp)
+    P.cam_adj_words = (nc + 63) / 64;
+    P.cam_adj.assign((size_t)nc * P.cam_adj_words, 0);
+    for (int p = 0; p < np; ++p) {
+        const int k = k_pt[p];
+        for (int a = 0; a < k; ++a) {
+            const int32_t ca = pb.ip_cam[by_pt[pstart[p] + a]];
+            uint64_t *row = P.cam_adj.data() + (size_t)ca * P.cam_adj_words;
+            for (int b = 0; b < k; ++b) {
+                const int32_t cb = pb.ip_cam[by_pt[pstart[p] + b]];
+                row[cb >> 6] |= 1ull << (cb & 63);
+            }
         }
     }
     // Points that fit a tile of the MFMA Schur kernel (at most CMAX cameras and
