@@ -99,6 +99,7 @@ SYMBOLS = {
     'dbat_hip_bench_step': (C.c_int, [_H, C.c_double, C.c_int32, _dp]),
     'dbat_hip_set_x': (C.c_int, [_H, _dp]),
     'dbat_hip_info': (C.c_int, [_H, C.POINTER(C.c_int64)]),
+    'dbat_hip_chol_stats': (C.c_int, [_H, C.POINTER(C.c_int64)]),
     'dbat_hip_posterior_cov': (C.c_int, [_H, _dp, C.c_double, _dp, _dp, _dp, _dp]),
 }
 DEBUG_SYMBOLS = {
@@ -346,6 +347,12 @@ class Handle:
         ms = np.zeros(8)
         check(self.lib.dbat_hip_bench_step(self.h, float(lam), int(bool(scale)), dptr(ms)))
         return ms
+
+    def chol_stats(self):
+        a = (C.c_int64 * 6)()
+        check(self.lib.dbat_hip_chol_stats(self.h, a))
+        keys = ('order_padded', 'tile_tasks', 'tile_products', 'tile_rows', 'nested_dissection', 'dataflow')
+        return dict(zip(keys, [int(v) for v in a]))
 
     def info(self):
         a = (C.c_int64 * 8)()

@@ -450,6 +450,7 @@ __global__ __launch_bounds__(256) void k_gather_tiles(const double *__restrict__
 struct DataflowChol {
     int n = 0, n_nat = 0, nT = 0, W = 0, ntasks = 0, ntiles = 0, epoch = 0, grid = 512;   // n: order of the factorised system (padded)
     bool permuted = false;
+    long long n_products = 0;                           // 64x64x64 tile products of the update phase (schedule statistic)
     int *d_flags = nullptr, *d_ctl = nullptr, *d_bk_ptr = nullptr, *d_bk_idx = nullptr, *d_iperm = nullptr;
     int64_t *d_toff = nullptr;
     uint64_t *d_rowbits = nullptr;
@@ -482,6 +483,13 @@ struct DataflowChol {
             for (int i = k; i <= nT; ++i)
                 if (has(i, k)) tasks.push_back(DfTask{i, k});
         ntasks = (int)tasks.size();
+        n_products = 0;
+        for (const DfTask &tk : tasks)
+            for (int w = 0; w <= (tk.k >> 6); ++w) {
+                uint64_t m = rowbits[(size_t)tk.i * W + w] & rowbits[(size_t)tk.k * W + w];
+                if (w == (tk.k >> 6)) m &= (1ull << (tk.k & 63)) - 1;
+                n_products += __builtin_popcountll(m);
+            }
         std::vector<int> bptr(nT + 1, 0), bidx;
         for (int j = 0; j < nT; ++j) {
             for (int i = nT - 1; i > j; --i)

@@ -1171,6 +1171,14 @@ int dbat_hip_posterior_cov(dbat_hip_handle *h, const double *x, double sigma0, d
     API_CATCH
 }
 
+int dbat_hip_chol_stats(const dbat_hip_handle *h, int64_t *st) {
+    if (!h || !st) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
+    const Core &c = *h->core;
+    const DataflowChol &f = c.use_perm ? c.dfchol : c.dfchol_ip;
+    st[0] = f.n; st[1] = f.ntasks; st[2] = f.n_products; st[3] = f.nT; st[4] = c.use_perm ? 1 : 0; st[5] = c.use_df ? 1 : 0;
+    return DBAT_HIP_OK;
+}
+
 int dbat_hip_info(const dbat_hip_handle *h, int64_t *info) {
     if (!h || !info) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
     const Core &c = *h->core;

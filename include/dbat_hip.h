@@ -257,6 +257,11 @@ int  dbat_hip_set_x(dbat_hip_handle *h, const double *x);
  * info[6]=max camera-side columns per observation info[7]=#tiles */
 int  dbat_hip_info(const dbat_hip_handle *h, int64_t *info /*[8]*/);
 
+/* Schedule of the Cholesky of the reduced system (measurement only): st[0] order of the
+ * factorised system incl. block padding, st[1] tile tasks, st[2] 64x64x64 tile products of
+ * the update phase, st[3] tile rows, st[4] 1 = nested-dissection order, st[5] 1 = dataflow kernel. */
+int  dbat_hip_chol_stats(const dbat_hip_handle *h, int64_t *st /*[6]*/);
+
 /* Posterior covariance blocks at x: sigma0^2 * blocks of inv(J'J), J the
  * weighted Jacobian incl. prior rows.  Replaces bundle/bundle_cov.m:63-214
  * ('CIO','CEO','COP'; the native code it stands in for is
