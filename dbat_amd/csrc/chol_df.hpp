@@ -562,7 +562,7 @@ struct DataflowChol {
             nd(A2); nd(B);
             std::sort(Sep.begin(), Sep.end());
             for (int c : Sep) order.push_back(c);
-            block_end.push_back((int)order.size());
+            if (!Sep.empty()) block_end.push_back((int)order.size());
         };
         {
             std::vector<int> all(nc);
@@ -578,7 +578,7 @@ struct DataflowChol {
             for (int q = 0; q < nc; ++q) {
                 if (q == q0) off = (off + CHOL_NB - 1) / CHOL_NB * CHOL_NB;
                 rowpos[order[q]] = off; off += 6;
-                if (b < block_end.size() && q + 1 == block_end[b]) { q0 = q + 1; ++b; }
+                while (b < block_end.size() && block_end[b] <= q + 1) { q0 = q + 1; ++b; }
             }
         }
         const int io0 = nio > 0 ? (off + CHOL_NB - 1) / CHOL_NB * CHOL_NB : off;

@@ -187,7 +187,10 @@ struct Core {
             if (use_perm) {
                 std::vector<double> xyz((size_t)3 * P.nc);
                 for (int c = 0; c < P.nc; ++c)
-                    for (int k = 0; k < 3; ++k) xyz[(size_t)3 * c + k] = P.z0[(size_t)6 * c + k];
+                    for (int k = 0; k < 3; ++k) {
+                        const double v = P.z0[(size_t)6 * c + k];
+                        xyz[(size_t)3 * c + k] = std::isfinite(v) ? v : 0.0;      // only steers the bisection
+                    }
                 if (!dfchol.setup_permuted(P.nc, P.nIOu, P.cam_adj.data(), P.cam_adj_words, xyz.data()))
                     throw DeviceError{"out of device memory (Cholesky schedule)"};
             }
@@ -309,9 +312,9 @@ struct Core {
         DISPATCH_MODEL(L_RES, 0)
 #undef L_RES
         mark(7);
-        hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(256), 0, stream, partial.p, (int64_t)grid_obs, scal.p, 0);
+        hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_obs, scal.p, 0);
         hipLaunchKernelGGL(k_prior_sq, dim3(grid_z), dim3(256), 0, stream, d, zz, partial.p);
-        hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(256), 0, stream, partial.p, (int64_t)grid_z, scal.p, 1);
+        hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_z, scal.p, 1);
         do_allreduce(scal.p, 1);
         double s;
         read_scal(&s, 1);
@@ -369,12 +372,12 @@ struct Core {
             memset(h, 0, sizeof(h));
             HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_tile2_prof), h, sizeof(h)));
         }
-        hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(256), 0, stream, partial.p, npart, red_scal, 0);
+        hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(1024), 0, stream, partial.p, npart, red_scal, 0);
         hipLaunchKernelGGL(k_prior_sq, dim3(grid_z), dim3(256), 0, stream, d, zz, partial.p);
-        hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(256), 0, stream, partial.p, (int64_t)grid_z, red_scal, 1);
+        hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_z, red_scal, 1);
         // owned squared column norms of the point columns -> red_scal[1]
         hipLaunchKernelGGL(k_dot, dim3(grid_z), dim3(256), 0, stream, (int64_t)3 * P.np, z_mine.p + P.NS, jn2p.p, (const double *)nullptr, partial.p);
-        hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(256), 0, stream, partial.p, (int64_t)grid_z, red_scal + 1, 0);
+        hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_z, red_scal + 1, 0);
     }
     void build(const double *zz, double lambda, int scale) {
         build_enqueue(zz, lambda, scale);
@@ -383,7 +386,7 @@ struct Core {
         if (zz != zlin.p) HIPCHK(hipMemcpyAsync(zlin.p, zz, P.NZ * 8, hipMemcpyDeviceToDevice, stream));
         // trace(J'J): camera part from jn2c (estimated), point part from red_scal[1]
         hipLaunchKernelGGL(k_dot, dim3(grid_z), dim3(256), 0, stream, P.NS, z_est.p, jn2c.p, (const double *)nullptr, partial.p);
-        hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(256), 0, stream, partial.p, (int64_t)grid_z, scal.p, 0);
+        hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_z, scal.p, 0);
         double hs[2], hr[2];
         HIPCHK(hipMemcpyAsync(hr, red_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
         read_scal(hs, 1);
@@ -432,9 +435,9 @@ struct Core {
 #undef L_BACKG
         }
         mark(5);
-        hipLaunchKernelGGL((k_sum_partials<2>), dim3(1), dim3(256), 0, stream, partial.p, nb + ngiant, scal.p, 0);
+        hipLaunchKernelGGL((k_sum_partials<2>), dim3(1), dim3(1024), 0, stream, partial.p, nb + ngiant, scal.p, 0);
         hipLaunchKernelGGL(k_prior_jv, dim3(grid_z), dim3(256), 0, stream, d, zlin.p, dz.p, partial.p);
-        hipLaunchKernelGGL((k_sum_partials<3>), dim3(1), dim3(256), 0, stream, partial.p, (int64_t)grid_z, scal.p + 4, 0);
+        hipLaunchKernelGGL((k_sum_partials<3>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_z, scal.p + 4, 0);
     }
     // solve at the current linearisation: p in dz.  Returns true if the
     // factorisation failed outright (non-positive pivot / non-finite step);
@@ -525,9 +528,9 @@ struct Core {
 #define L_JT(M, IO) hipLaunchKernelGGL((k_jtimes<M, IO>), dim3(grid_obs), dim3(256), 0, stream, d, zlin.p, cams.p, v, r_w.p, partial.p)
         if (P.with_io) { DISPATCH_MODEL(L_JT, true) } else { DISPATCH_MODEL(L_JT, false) }
 #undef L_JT
-        hipLaunchKernelGGL((k_sum_partials<2>), dim3(1), dim3(256), 0, stream, partial.p, (int64_t)grid_obs, scal.p, 0);
+        hipLaunchKernelGGL((k_sum_partials<2>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_obs, scal.p, 0);
         hipLaunchKernelGGL(k_prior_jv, dim3(grid_z), dim3(256), 0, stream, d, zlin.p, v, partial.p);
-        hipLaunchKernelGGL((k_sum_partials<3>), dim3(1), dim3(256), 0, stream, partial.p, (int64_t)grid_z, scal.p + 4, 0);
+        hipLaunchKernelGGL((k_sum_partials<3>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_z, scal.p + 4, 0);
         do_allreduce(scal.p, 8);
         double h[8];
         read_scal(h, 8);
@@ -535,7 +538,7 @@ struct Core {
     }
     double dot_owned(const double *a, const double *b) {
         hipLaunchKernelGGL(k_dot, dim3(grid_z), dim3(256), 0, stream, P.NZ, z_mine.p, a, b, partial.p);
-        hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(256), 0, stream, partial.p, (int64_t)grid_z, scal.p, 0);
+        hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_z, scal.p, 0);
         do_allreduce(scal.p, 1);
         double s;
         read_scal(&s, 1);

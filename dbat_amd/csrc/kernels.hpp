@@ -156,9 +156,9 @@ __global__ __launch_bounds__(256) void k_prior_sq(DevProblem d, const double *__
 
 // sum npart partials (NV interleaved values each) into out[NV]; single block
 template <int NV>
-__global__ __launch_bounds__(256) void k_sum_partials(const double *__restrict__ partial, int64_t npart,
-                                                      double *__restrict__ out, int accumulate) {
-    __shared__ double sh[NV * 4];
+__global__ __launch_bounds__(1024) void k_sum_partials(const double *__restrict__ partial, int64_t npart,
+                                                       double *__restrict__ out, int accumulate) {
+    __shared__ double sh[NV * 16];
     double acc[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) acc[i] = 0;
