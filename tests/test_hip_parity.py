@@ -611,3 +611,38 @@ def test_posterior_covariance_C1_sampled(hip):
         want = block(src[keep])
         got = CEO[m * c:m * c + 6, m * c:m * c + 6].toarray()[np.ix_(keep, keep)]
         assert np.abs(got - want).max() <= 1e-6 * np.abs(want).max()
+
+
+@pytest.mark.parametrize('case', ['fixed_eo', 'fixed_op', 'unobserved'])
+def test_degenerate_but_valid_inputs(hip, case):
+    """Only the object points estimated (spatial intersection), only the
+    cameras estimated (spatial resection of every image), and object points
+    without any observation (fixed, as bundle.m needs them): same results as
+    the oracle."""
+    from dbat_amd import bundle
+    s, truth = synth_struct('tiny', 'plain')
+    if case == 'fixed_eo':
+        s.bundle.est.EO[:] = False
+        s.EO.val[:6] = truth['EO']
+    elif case == 'fixed_op':
+        s.bundle.est.OP[:] = False
+        s.OP.val[:] = truth['OP']
+        s.bundle.est.EO[:6] = True
+    else:
+        # drop all observations of three points and fix them (an unobserved free point is
+        # structurally rank deficient, code -4, in the reference as well)
+        drop = np.isin(s.IP.pt, [0, 7, 11])
+        s.IP.val, s.IP.std = s.IP.val[:, ~drop], s.IP.std[:, ~drop]
+        s.IP.cam, s.IP.pt = s.IP.cam[~drop], s.IP.pt[~drop]
+        s.bundle.est.OP[:, [0, 7, 11]] = False
+    res, ok, iters, s0, E = bundle(s, 'gna')
+    ro, oko, ito, s0o, Eo = o.bundle(s, 'gna')
+    assert E.code == Eo.code
+    assert ok == oko and iters == ito
+    assert relerr(E.x, Eo.x) < TOL_X
+    if case == 'unobserved':
+        # and left free: both report the structural rank deficiency
+        s.bundle.est.OP[:, 0] = True
+        res, ok, iters, s0, E = bundle(s, 'gna')
+        ro, oko, ito, s0o, Eo = o.bundle(s, 'gna')
+        assert E.code == Eo.code == -4
