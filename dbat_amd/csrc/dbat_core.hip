@@ -213,7 +213,7 @@ struct Core {
         lds_back = (size_t)P.BT * 6 * sizeof(double);
         lds_tile = ((size_t)2 * 3 * TILE_PC * TILE_LD + (size_t)P.BT * 9 + (size_t)36 * P.CMAX + 3 * TILE_LD +
                     (P.with_io ? (size_t)P.CMAX * 6 * 16 + 256 : 0)) * sizeof(double);
-        lds_tile2 = ((size_t)2 * 2 * 3 * TILE2_PC * TILE_LD + (size_t)256 * 9 + (size_t)128 * 9 + (size_t)36 * P.CMAX +
+        lds_tile2 = ((size_t)TILE2_NBUF * 3 * TILE2_PC * TILE_LD + (size_t)256 * 9 + (size_t)128 * 15 + (size_t)36 * P.CMAX +
                      3 * TILE_LD) * sizeof(double);
         // the wave-specialised tile kernel covers the fixed-IO case with 256-observation batches
         use_tile2 = P.BT == 256 && !P.with_io && getenv("DBAT_HIP_TILE_V1") == nullptr;

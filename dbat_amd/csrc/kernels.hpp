@@ -1023,18 +1023,50 @@ __global__ __launch_bounds__(256) void k_build_tile(DevProblem d, const double *
 // and P3 of batch b (its W and V^-1 stay in registers meanwhile), so the matrix
 // pipe works under the residual/Jacobian arithmetic, the global-load latencies
 // and the LDS atomics instead of after them.
-// Hand-over is by LDS counters (full/freed per panel).  A panel slot is zeroed
-// again by the thread that filled it ("stage") and refilled ("commit") only
-// after a producer barrier, because the slot's next writer is in general a
-// different thread.  The producers synchronise among themselves with a counter
-// barrier; the hardware s_barrier is only used where all eight waves take part.
+// Hand-over is by LDS counters (full/done/freed per panel): the producers fill
+// a zeroed panel and signal `full`; a consumer wave signals `done` after its
+// products, waits for the other three, zeroes its quarter of the panel and
+// signals `freed`.  With four panels in flight the producers of batch b+1 run
+// under the matrix work of batch b.  The producers synchronise among themselves
+// (P1 -> P2 -> P3) with a counter barrier; the hardware s_barrier is only used
+// where all eight waves take part.
 // Every spin has a cap that poisons the objective value instead of hanging.
 constexpr int TILE2_PC = 8;
+constexpr int TILE2_NBUF = 4;                    // operand panels in flight between producers and consumers
+
+// sum_p Y_p W_p' with Y = W V^-1 is the symmetric product Z Z' for Z = W R, V^-1 = R R'
+// (R = lower Cholesky factor of the 3x3 inverse): ONE operand panel instead of two.  Wave w
+// owns row tiles w and 7-w of the lower triangle; both its A fragments are among the B
+// fragments it loads anyway.
+template <int WV>
+__device__ __forceinline__ void tile_syrk_steps(const double *Zt, int lane, int ksteps, mfma_d4 (&acc)[9]) {
+    constexpr int LD = TILE_LD, RA = WV, RB = 7 - WV;      // RA <= RB
+    if (ksteps <= 0) return;
+    const double *zr = Zt + (lane >> 4) * LD + (lane & 15);
+    double wa[RB + 1];
+#pragma unroll
+    for (int c = 0; c <= RB; ++c) wa[c] = zr[16 * c];
+    for (int kk = 0; kk < ksteps; ++kk) {
+        const int kn = kk + 1 < ksteps ? kk + 1 : kk;      // last step re-reads itself (harmless)
+        const double *zn = zr + 4 * kn * LD;
+        double nwa[RB + 1];
+#pragma unroll
+        for (int c = 0; c <= RB; ++c) nwa[c] = zn[16 * c];
+#pragma unroll
+        for (int c = 0; c <= RA; ++c)
+            acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[RA], wa[c], acc[c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c <= RB; ++c)
+            acc[RA + 1 + c] = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[RB], wa[c], acc[RA + 1 + c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c <= RB; ++c) wa[c] = nwa[c];
+    }
+}
 constexpr int TILE2_SPIN_CAP = 1 << 24;
 
 __device__ unsigned long long g_tile2_prof[16];    // DBAT_HIP_ABLATE & 32: phase times (10 ns ticks), summed over tiles
 
-struct Tile2Sync { int full[2], freed[2], ks[2], pbar, abort_, npts[2]; };
+struct Tile2Sync { int full[TILE2_NBUF], done[TILE2_NBUF], freed[TILE2_NBUF], ks[TILE2_NBUF], pbar, abort_, npts[2]; };
 
 __device__ __forceinline__ void lds_fence() {           // all LDS traffic of this wave has completed
     __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0)
@@ -1066,14 +1098,14 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
                                                      double *__restrict__ jn2p, double *__restrict__ r_w,
                                                      double *__restrict__ partial,
                                                      unsigned long long *__restrict__ pivmm) {
-    constexpr int PC = TILE2_PC, KC = 3 * PC, LD = TILE_LD, PANEL = 2 * KC * LD;
+    constexpr int PC = TILE2_PC, KC = 3 * PC, LD = TILE_LD, PANEL = KC * LD, NBUF = TILE2_NBUF;
     constexpr int NPROD = 256;                       // producer threads = batch size
     extern __shared__ double smem[];
     const int CM = d.CMAX;
-    double *pan = smem;                              // [2][Yt KC*LD | Wt KC*LD]
-    double *red = pan + 2 * PANEL;                   // [NPROD][9]  B'B | B'r per observation
-    double *pinv = red + (size_t)NPROD * 9;          // [NPROD/2][9] V^-1 | g_p per point of the batch
-    double *Ud = pinv + (size_t)(NPROD / 2) * 9;     // [CM][36]
+    double *pan = smem;                              // [NBUF][KC*LD]  Z = W R panels
+    double *red = pan + NBUF * PANEL;                // [NPROD][9]  B'B | B'r per observation
+    double *pinv = red + (size_t)NPROD * 9;          // [NPROD/2][15] V^-1 | g_p | R per point of the batch
+    double *Ud = pinv + (size_t)(NPROD / 2) * 15;    // [CM][36]
     double *vt = Ud + (size_t)CM * 36;               // [3][LD]
     __shared__ double sh[16];
     __shared__ Tile2Sync sy;
@@ -1086,9 +1118,10 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
     const int c0 = d.tile_cam_start[tile];
     const int ncam = d.tile_cam_start[tile + 1] - c0;
     const int nrows = 6 * ncam;
-    for (int i = t; i < 2 * PANEL; i += 512) pan[i] = 0.0;
+    for (int i = t; i < NBUF * PANEL; i += 512) pan[i] = 0.0;
     for (int i = t; i < CM * 36 + 3 * LD; i += 512) Ud[i] = 0.0;
-    if (t == 0) { sy.full[0] = sy.full[1] = sy.freed[0] = sy.freed[1] = 0; sy.ks[0] = sy.ks[1] = 0; sy.pbar = 0; sy.abort_ = 0; sy.npts[0] = sy.npts[1] = 0; }
+    if (t < NBUF) { sy.full[t] = 0; sy.done[t] = 0; sy.freed[t] = 0; sy.ks[t] = 0; }
+    if (t == 0) { sy.pbar = 0; sy.abort_ = 0; sy.npts[0] = sy.npts[1] = 0; }
     mfma_d4 acc[9];
 #pragma unroll
     for (int s = 0; s < 9; ++s) acc[s] = mfma_d4{0, 0, 0, 0};
@@ -1098,58 +1131,12 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
     long long tp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = prof ? wall_clock64() : 0;
     auto lap = [&](int i) { if (prof) { const long long now = wall_clock64(); tp[i] += now - tlast; tlast = now; } };
     if (producer) {
-        int nchunk = 0;                              // chunks handed over so far (panel = nchunk & 1)
+        int nchunk = 0;                              // chunks handed over so far (panel = nchunk % NBUF)
         int pbar_gen = 0;
-        int prev_kb[2] = {-1, -1}, prev_lc[2] = {0, 0};   // what this thread last wrote into each panel
         bool ok = true;
-        // the batch whose chunks are being handed over (one behind the batch being evaluated)
-        double qW[6][3], qv0 = 0, qv1 = 0, qv2 = 0, qv3 = 0, qv4 = 0, qv5 = 0;
-        int q_pidx = 0, q_lc = 0, q_npts = 0, q_p0 = 0;
-        bool q_active = false, staged = false;
-#pragma unroll
-        for (int a = 0; a < 6; ++a) qW[a][0] = qW[a][1] = qW[a][2] = 0.0;
         auto pbarrier = [&]() -> bool {
             lds_signal(&sy.pbar); ++pbar_gen;
             return lds_wait_ge(&sy.pbar, 4 * pbar_gen, &sy.abort_);
-        };
-        // stage: wait until the consumers have released the panel of the next chunk and zero
-        // what this thread wrote there before
-        auto stage = [&]() {
-            if (!(q_p0 < q_npts) || !ok) return;
-            const int s = nchunk & 1, u = nchunk >> 1;
-            if (u > 0 && !lds_wait_ge(&sy.freed[s], 4 * u, &sy.abort_)) { ok = false; return; }
-            if (prev_kb[s] >= 0) {
-                double *Yt = pan + s * PANEL, *Wt = Yt + KC * LD;
-                const int kb = prev_kb[s], row0 = 6 * prev_lc[s];
-#pragma unroll
-                for (int a = 0; a < 6; ++a)
-#pragma unroll
-                    for (int e = 0; e < 3; ++e) { Wt[(kb + e) * LD + row0 + a] = 0.0; Yt[(kb + e) * LD + row0 + a] = 0.0; }
-                prev_kb[s] = -1;
-            }
-            staged = true;
-        };
-        // commit (after a producer barrier): scatter the chunk and hand it to the consumers
-        auto commit = [&]() {
-            if (!staged || !ok) return;
-            staged = false;
-            const int s = nchunk & 1;
-            double *Yt = pan + s * PANEL, *Wt = Yt + KC * LD;
-            if (q_active && q_pidx >= q_p0 && q_pidx < q_p0 + PC) {
-                const int kb = 3 * (q_pidx - q_p0), row0 = 6 * q_lc;
-                prev_kb[s] = kb; prev_lc[s] = q_lc;
-#pragma unroll
-                for (int a = 0; a < 6; ++a) {
-                    const double w0 = qW[a][0], w1 = qW[a][1], w2 = qW[a][2];
-                    Wt[(kb + 0) * LD + row0 + a] = w0; Wt[(kb + 1) * LD + row0 + a] = w1; Wt[(kb + 2) * LD + row0 + a] = w2;
-                    Yt[(kb + 0) * LD + row0 + a] = w0 * qv0 + w1 * qv1 + w2 * qv2;
-                    Yt[(kb + 1) * LD + row0 + a] = w0 * qv1 + w1 * qv3 + w2 * qv4;
-                    Yt[(kb + 2) * LD + row0 + a] = w0 * qv2 + w1 * qv4 + w2 * qv5;
-                }
-            }
-            if (t == 0) sy.ks[s] = (3 * min(PC, q_npts - q_p0) + 3) >> 2;
-            lds_signal(&sy.full[s]);
-            ++nchunk; q_p0 += PC;
         };
         // observation header of the next batch and the object point of its observations are
         // fetched one batch ahead, so their HBM latency hides behind the current batch
@@ -1193,8 +1180,6 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
             if (t == 0) *npts_sh = 0;
             fetch_header(b + 1);
             lap(9);
-            stage();
-            lap(0);
             if (active) {                            // ---- P1
                 const CamRec &C = cams[cam];
                 const double w0 = d.o_w ? d.o_w[2 * o] : C.w[0], w1 = d.o_w ? d.o_w[2 * o + 1] : C.w[1];
@@ -1216,9 +1201,6 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
             lap(1);
             if (!pbarrier()) { ok = false; break; }
             lap(2);
-            commit();
-            stage();
-            lap(0);
             if (active && t == seg_start) {          // ---- P2
                 atomicMax(npts_sh, pidx + 1);
                 double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
@@ -1264,23 +1246,30 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
                             pmin = fmin(pmin, v); pmax = fmax(pmax, v);
                         }
                 }
-                double *pi = pinv + (size_t)pidx * 9;
+                double *pi = pinv + (size_t)pidx * 15;
 #pragma unroll
                 for (int k = 0; k < 6; ++k) { pi[k] = inv[k]; Vinv[6 * (int64_t)pt + k] = inv[k]; }
 #pragma unroll
                 for (int k = 0; k < 3; ++k) { pi[6 + k] = g[k]; gp[3 * (int64_t)pt + k] = g[k]; }
+                {   // V^-1 = R R', R lower triangular
+                    const double r00 = sqrt(inv[0]), ir00 = fast_rcp(r00);
+                    const double r10 = inv[1] * ir00, r20 = inv[2] * ir00;
+                    const double r11 = sqrt(inv[3] - r10 * r10);
+                    const double r21 = (inv[4] - r20 * r10) * fast_rcp(r11);
+                    const double r22 = sqrt(inv[5] - r20 * r20 - r21 * r21);
+                    pi[9] = r00; pi[10] = r10; pi[11] = r20; pi[12] = r11; pi[13] = r21; pi[14] = r22;
+                }
             }
             lap(3);
             if (!pbarrier()) { ok = false; break; }
             lap(2);
-            commit();
-            stage();
-            lap(0);
             const int npts = *npts_sh;
             double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
+            double nr0 = 0, nr1 = 0, nr2 = 0, nr3 = 0, nr4 = 0, nr5 = 0;
             if (active) {                            // ---- P3: E'E, gradient pieces
-                const double *pi = pinv + (size_t)pidx * 9;
+                const double *pi = pinv + (size_t)pidx * 15;
                 v0 = pi[0]; v1 = pi[1]; v2 = pi[2]; v3 = pi[3]; v4 = pi[4]; v5 = pi[5];
+                nr0 = pi[9]; nr1 = pi[10]; nr2 = pi[11]; nr3 = pi[12]; nr4 = pi[13]; nr5 = pi[14];
                 const double g0 = pi[6], g1 = pi[7], g2 = pi[8];
                 double *ud = Ud + (size_t)lc * 36;
 #pragma unroll
@@ -1302,30 +1291,33 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
                 }
             }
             lap(4);
-            // drain what is left of the previous batch, then queue this one
-            while (ok && (staged || q_p0 < q_npts)) {
-                if (!staged) stage();
-                if (!pbarrier()) { ok = false; break; }
-                commit();
-            }
-            lap(5);
-            if (!ok) break;
-            q_active = active; q_pidx = pidx; q_lc = lc; q_npts = npts; q_p0 = 0;
-            qv0 = v0; qv1 = v1; qv2 = v2; qv3 = v3; qv4 = v4; qv5 = v5;
+            // ---- P4: Z = W R of this batch, chunk by chunk, into panels the consumers have
+            // released AND zeroed: no restore pass, no barrier between the producers
+            for (int p0 = 0; p0 < npts && ok; p0 += PC, ++nchunk) {
+                const int s = nchunk % NBUF, u = nchunk / NBUF;
+                if (u > 0 && !lds_wait_ge(&sy.freed[s], 4 * u, &sy.abort_)) { ok = false; break; }
+                lap(0);
+                double *Zt = pan + s * PANEL;
+                if (active && pidx >= p0 && pidx < p0 + PC) {
+                    const int kb = 3 * (pidx - p0), row0 = 6 * lc;
 #pragma unroll
-            for (int a = 0; a < 6; ++a) {
-                qW[a][0] = E[0][a] * B[0][0] + E[1][a] * B[1][0];
-                qW[a][1] = E[0][a] * B[0][1] + E[1][a] * B[1][1];
-                qW[a][2] = E[0][a] * B[0][2] + E[1][a] * B[1][2];
+                    for (int a = 0; a < 6; ++a) {
+                        const double w0 = E[0][a] * B[0][0] + E[1][a] * B[1][0];
+                        const double w1 = E[0][a] * B[0][1] + E[1][a] * B[1][1];
+                        const double w2 = E[0][a] * B[0][2] + E[1][a] * B[1][2];
+                        Zt[(kb + 0) * LD + row0 + a] = w0 * nr0 + w1 * nr1 + w2 * nr2;
+                        Zt[(kb + 1) * LD + row0 + a] = w1 * nr3 + w2 * nr4;
+                        Zt[(kb + 2) * LD + row0 + a] = w2 * nr5;
+                    }
+                }
+                if (t == 0) sy.ks[s] = (3 * min(PC, npts - p0) + 3) >> 2;
+                lds_signal(&sy.full[s]);
+                lap(5);
             }
-        }
-        while (ok && (staged || q_p0 < q_npts)) {    // the last batch
-            if (!staged) stage();
-            if (!pbarrier()) { ok = false; break; }
-            commit();
+            if (!ok) break;
         }
         {   // terminating chunk
-            const int s = nchunk & 1, u = nchunk >> 1;
+            const int s = nchunk % NBUF, u = nchunk / NBUF;
             if (ok && u > 0) ok = lds_wait_ge(&sy.freed[s], 4 * u, &sy.abort_);
             if (t == 0) sy.ks[s] = -1;
             lds_signal(&sy.full[s]);
@@ -1343,30 +1335,37 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
             yoff[s] = 16 * rt; woff[s] = 16 * ct; ton[s] = 16 * rt < nrows;
         }
         for (int n = 0;; ++n) {
-            const int s = n & 1, u = n >> 1;
+            const int s = n % NBUF, u = n / NBUF;
             if (!lds_wait_ge(&sy.full[s], 4 * (u + 1), &sy.abort_)) break;
             lap(6);
             int ksteps = __hip_atomic_load(&sy.ks[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (ksteps < 0) break;
             if (d.ablate & 8) ksteps = 0;                // profiling: hand-over without the matrix work
-            const double *Yt = pan + s * PANEL, *Wt = Yt + KC * LD;
+            const double *Zt = pan + s * PANEL;
             if (full_tile) {
                 switch (wave) {
-                    case 0: tile_mfma_steps<0>(Yt, Wt, lane, ksteps, acc); break;
-                    case 1: tile_mfma_steps<1>(Yt, Wt, lane, ksteps, acc); break;
-                    case 2: tile_mfma_steps<2>(Yt, Wt, lane, ksteps, acc); break;
-                    default: tile_mfma_steps<3>(Yt, Wt, lane, ksteps, acc); break;
+                    case 0: tile_syrk_steps<0>(Zt, lane, ksteps, acc); break;
+                    case 1: tile_syrk_steps<1>(Zt, lane, ksteps, acc); break;
+                    case 2: tile_syrk_steps<2>(Zt, lane, ksteps, acc); break;
+                    default: tile_syrk_steps<3>(Zt, lane, ksteps, acc); break;
                 }
             } else {
                 for (int kk = 0; kk < ksteps; ++kk) {
                     const int krow = 4 * kk + (lane >> 4);
-                    const double *yr = Yt + krow * LD + (lane & 15);
-                    const double *wr = Wt + krow * LD + (lane & 15);
+                    const double *yr = Zt + krow * LD + (lane & 15);
+                    const double *wr = yr;
 #pragma unroll
                     for (int q = 0; q < 9; ++q)
                         if (ton[q])
                             acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(yr[yoff[q]], wr[woff[q]], acc[q], 0, 0, 0);
                 }
+            }
+            // every consumer wave has read the panel -> zero it (a quarter per wave) -> hand it back
+            lds_signal(&sy.done[s]);
+            if (!lds_wait_ge(&sy.done[s], 4 * (u + 1), &sy.abort_)) break;
+            {
+                double *Zw = pan + s * PANEL + wave * (PANEL / 4);
+                for (int i = lane; i < PANEL / 4; i += 64) Zw[i] = 0.0;
             }
             lds_signal(&sy.freed[s]);
             lap(7);
