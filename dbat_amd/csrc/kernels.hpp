@@ -1031,8 +1031,8 @@ __global__ __launch_bounds__(256) void k_build_tile(DevProblem d, const double *
 // (P1 -> P2 -> P3) with a counter barrier; the hardware s_barrier is only used
 // where all eight waves take part.
 // Every spin has a cap that poisons the objective value instead of hanging.
-constexpr int TILE2_PC = 8;
-constexpr int TILE2_NBUF = 4;                    // operand panels in flight between producers and consumers
+constexpr int TILE2_PC = 16;
+constexpr int TILE2_NBUF = 2;                    // operand panels in flight between producers and consumers
 
 // sum_p Y_p W_p' with Y = W V^-1 is the symmetric product Z Z' for Z = W R, V^-1 = R R'
 // (R = lower Cholesky factor of the 3x3 inverse): ONE operand panel instead of two.  Wave w
