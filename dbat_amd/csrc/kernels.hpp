@@ -1109,6 +1109,7 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
     double *vt = Ud + (size_t)CM * 36;               // [3][LD]
     __shared__ double sh[16];
     __shared__ Tile2Sync sy;
+    __shared__ int64_t bs_sh[64];                    // batch_start of this tile's batches (a tile is capped at 16)
     const int t = threadIdx.x, lane = t & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(t >> 6);
     const bool producer = wave8 < 4;
@@ -1118,6 +1119,7 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
     const int c0 = d.tile_cam_start[tile];
     const int ncam = d.tile_cam_start[tile + 1] - c0;
     const int nrows = 6 * ncam;
+    for (int i = t; i <= b1 - b0 && i < 64; i += 512) bs_sh[i] = d.batch_start[b0 + i];
     for (int i = t; i < NBUF * PANEL; i += 512) pan[i] = 0.0;
     for (int i = t; i < CM * 36 + 3 * LD; i += 512) Ud[i] = 0.0;
     if (t < NBUF) { sy.full[t] = 0; sy.done[t] = 0; sy.freed[t] = 0; sy.ks[t] = 0; }
@@ -1134,6 +1136,7 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
         int nchunk = 0;                              // chunks handed over so far (panel = nchunk % NBUF)
         int pbar_gen = 0;
         bool ok = true;
+        auto bstart = [&](int bb) -> int64_t { return bb - b0 < 64 ? bs_sh[bb - b0] : d.batch_start[bb]; };
         auto pbarrier = [&]() -> bool {
             lds_signal(&sy.pbar); ++pbar_gen;
             return lds_wait_ge(&sy.pbar, 4 * pbar_gen, &sy.abort_);
@@ -1144,8 +1147,8 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
         double qn[3] = {0, 0, 0}, pwn[3] = {0, 0, 0}; unsigned estn = 0;
         auto fetch_header = [&](int bb) {
             if (bb >= b1) return;
-            const int64_t oo0 = d.batch_start[bb];
-            if (t < (int)(d.batch_start[bb + 1] - oo0)) {
+            const int64_t oo0 = bstart(bb);
+            if (t < (int)(bstart(bb + 1) - oo0)) {
                 const int64_t oo = oo0 + t;
                 hn_cam = d.o_cam[oo]; hn_pt = d.o_pt[oo]; hn_lc = d.o_lc[oo]; hn_pidx = d.o_pidx[oo];
                 hn_sg = d.o_seg[oo]; hn_u = d.o_uv[2 * oo]; hn_v = d.o_uv[2 * oo + 1];
@@ -1153,7 +1156,7 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
         };
         auto fetch_point = [&](int bb) {
             if (bb >= b1) return;
-            if (t < (int)(d.batch_start[bb + 1] - d.batch_start[bb])) {
+            if (t < (int)(bstart(bb + 1) - bstart(bb))) {
                 const int64_t zp = d.NS + 3 * (int64_t)hn_pt;
                 qn[0] = z[zp]; qn[1] = z[zp + 1]; qn[2] = z[zp + 2];
                 estn = (d.z_est[zp] ? 1u : 0u) | (d.z_est[zp + 1] ? 2u : 0u) | (d.z_est[zp + 2] ? 4u : 0u);
@@ -1163,8 +1166,8 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
         fetch_header(b0);
         fetch_point(b0);
         for (int b = b0; b < b1 && ok; ++b) {
-            const int64_t o0 = d.batch_start[b];
-            const int nobs = (int)(d.batch_start[b + 1] - o0);
+            const int64_t o0 = bstart(b);
+            const int nobs = (int)(bstart(b + 1) - o0);
             const bool active = t < nobs;
             const int64_t o = o0 + t;
             int *npts_sh = &sy.npts[b & 1];

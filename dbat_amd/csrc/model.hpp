@@ -242,12 +242,18 @@ DBAT_HD void obs_eval(const CamRec &cam, int nK, int nP, const double Q[3], doub
         C[1][1] = im.dU0[1][0]; C[1][2] = im.dU0[1][1];
         C[0][3] = im.dB[0][0];  C[0][4] = im.dB[0][1];
         C[1][3] = im.dB[1][0];  C[1][4] = im.dB[1][1];
-        for (int j = 0; j < MAXK; ++j)
-            if (j < nK) { C[0][5 + j] = im.dK[0][j]; C[1][5 + j] = im.dK[1][j]; }
-        for (int j = 0; j < MAXP; ++j)
-            if (j < nP && 5 + nK + j < MAXIO) {
-                C[0][5 + nK + j] = im.dP[0][j]; C[1][5 + nK + j] = im.dP[1][j];
-            }
+        // rows 5.. : K1..KnK then P1..PnP.  nK is a run-time value: place the P rows with
+        // compile-time indices and selects (a dynamic index would push C into scratch memory)
+#pragma unroll
+        for (int rr = 5; rr < MAXIO; ++rr) {
+            double c0 = 0.0, c1 = 0.0;
+            const int j = rr - 5;
+            if (j < MAXK && j < nK) { c0 = im.dK[0][j < MAXK ? j : 0]; c1 = im.dK[1][j < MAXK ? j : 0]; }
+#pragma unroll
+            for (int jp = 0; jp < MAXP; ++jp)
+                if (jp < nP && rr == 5 + nK + jp) { c0 = im.dP[0][jp]; c1 = im.dP[1][jp]; }
+            C[0][rr] = c0; C[1][rr] = c1;
+        }
     }
 }
 
