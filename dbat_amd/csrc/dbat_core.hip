@@ -425,8 +425,8 @@ struct Core {
     void backsub_enqueue() {
         mark(4);
         if (nb > 0) {
-#define L_BACK(M, IO) hipLaunchKernelGGL((k_backsub<M, IO>), dim3((unsigned)nb), dim3(P.BT), lds_back, stream, d, zlin.p, cams.p, Vinv.p, gp.p, r_w.p, dz.p, partial.p)
-            if (P.with_io) { DISPATCH_MODEL(L_BACK, true) } else { DISPATCH_MODEL(L_BACK, false) }
+#define L_BACK(M, NCXV) hipLaunchKernelGGL((k_backsub<M, NCXV>), dim3((unsigned)nb), dim3(P.BT), lds_back, stream, d, zlin.p, cams.p, Vinv.p, gp.p, r_w.p, dz.p, partial.p)
+            if (tile_ncx == 6) { DISPATCH_MODEL(L_BACK, 6) } else if (tile_ncx == 14) { DISPATCH_MODEL(L_BACK, 14) } else { DISPATCH_MODEL(L_BACK, MAXCOL) }
 #undef L_BACK
         }
         if (ngiant > 0) {
@@ -525,8 +525,8 @@ struct Core {
     // ||J v||^2 and r'Jv at the linearisation point, ||v||^2 over owned entries
     void jtimes(const double *v, double &JvJv, double &rJv, double &vv) {
         prep_cams(zlin.p);
-#define L_JT(M, IO) hipLaunchKernelGGL((k_jtimes<M, IO>), dim3(grid_obs), dim3(256), 0, stream, d, zlin.p, cams.p, v, r_w.p, partial.p)
-        if (P.with_io) { DISPATCH_MODEL(L_JT, true) } else { DISPATCH_MODEL(L_JT, false) }
+#define L_JT(M, NCXV) hipLaunchKernelGGL((k_jtimes<M, NCXV>), dim3(grid_obs), dim3(256), 0, stream, d, zlin.p, cams.p, v, r_w.p, partial.p)
+        if (tile_ncx == 6) { DISPATCH_MODEL(L_JT, 6) } else if (tile_ncx == 14) { DISPATCH_MODEL(L_JT, 14) } else { DISPATCH_MODEL(L_JT, MAXCOL) }
 #undef L_JT
         hipLaunchKernelGGL((k_sum_partials<2>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_obs, scal.p, 0);
         hipLaunchKernelGGL(k_prior_jv, dim3(grid_z), dim3(256), 0, stream, d, zlin.p, v, partial.p);

@@ -1706,13 +1706,15 @@ __global__ void k_unscale(int64_t NS, const double *__restrict__ q, const double
 // ---------------------------------------------------------------- K7 ----
 // Back-substitution dp = -V^-1 (g_p + W' dc) and the sums ||Jp||^2, r'Jp over
 // the image rows.  dz[0..NS) holds dc on entry; dz[NS..) receives dp.
-template <int MODEL, bool WITH_IO>
+// NCXT: capacity of the camera-side column list (6 = fixed IO, 14, MAXCOL).
+template <int MODEL, int NCXT>
 __global__ __launch_bounds__(256) void k_backsub(DevProblem d, const double *__restrict__ z,
                                                  const CamRec *__restrict__ cams,
                                                  const double *__restrict__ Vinv, const double *__restrict__ gp,
                                                  const double *__restrict__ r_w, double *__restrict__ dz,
                                                  double *__restrict__ partial /* [nb][2] */) {
-    constexpr int NCX = WITH_IO ? MAXCOL : 6;
+    constexpr int NCX = NCXT;
+    constexpr bool WITH_IO = NCXT > 6;
     extern __shared__ double smem[];
     double *red = smem;                 // [BT][3]  B't
     double *dpl = red + (size_t)blockDim.x * 3;   // [BT][3]  dp at leader slot
@@ -1731,8 +1733,8 @@ __global__ __launch_bounds__(256) void k_backsub(DevProblem d, const double *__r
         const uint32_t sg = d.o_seg[o];
         seg_start = sg & 0xFFFF; seg_len = sg >> 16;
         const CamRec &C = cams[cam];
-        const int ncol = WITH_IO ? C.ncol : 6;
-        eval_obs_cols<MODEL, WITH_IO>(d, C, z, o, pt, r, E, B);
+        const int ncol = WITH_IO ? min(C.ncol, NCX) : 6;
+        eval_obs_cols_n<MODEL, NCX>(d, C, z, o, pt, r, E, B);
 #pragma unroll
         for (int a = 0; a < NCX; ++a)
             if (a < ncol) { const double dc = dz[C.col[a]]; tt[0] += E[0][a] * dc; tt[1] += E[1][a] * dc; }
@@ -1769,20 +1771,21 @@ __global__ __launch_bounds__(256) void k_backsub(DevProblem d, const double *__r
 // ---------------------------------------------------------------- K8 ----
 // partial[2*blk] += ||J v||^2, partial[2*blk+1] += r'Jv over image rows
 // (grid-stride; v in z layout).
-template <int MODEL, bool WITH_IO>
+template <int MODEL, int NCXT>
 __global__ __launch_bounds__(256) void k_jtimes(DevProblem d, const double *__restrict__ z,
                                                 const CamRec *__restrict__ cams, const double *__restrict__ v,
                                                 const double *__restrict__ r_w, double *__restrict__ partial) {
-    constexpr int NCX = WITH_IO ? MAXCOL : 6;
+    constexpr int NCX = NCXT;
+    constexpr bool WITH_IO = NCXT > 6;
     __shared__ double sh[16];
     double acc[2] = {0, 0};
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < d.nobs; o += stride) {
         const int cam = d.o_cam[o], pt = d.o_pt[o];
         const CamRec &C = cams[cam];
-        const int ncol = WITH_IO ? C.ncol : 6;
+        const int ncol = WITH_IO ? min(C.ncol, NCX) : 6;
         double r[2], E[2][NCX], B[2][3];
-        eval_obs_cols<MODEL, WITH_IO>(d, C, z, o, pt, r, E, B);
+        eval_obs_cols_n<MODEL, NCX>(d, C, z, o, pt, r, E, B);
         const double *vp = v + d.NS + 3 * (int64_t)pt;
         double j0 = B[0][0] * vp[0] + B[0][1] * vp[1] + B[0][2] * vp[2];
         double j1 = B[1][0] * vp[0] + B[1][1] * vp[1] + B[1][2] * vp[2];
