@@ -203,7 +203,7 @@ struct Core {
         HIPCHK(hipMemset(gp.p, 0, (size_t)3 * P.np * 8));
         HIPCHK(hipMemset(jn2p.p, 0, (size_t)3 * P.np * 8));
         r_w.alloc(std::max<int64_t>(2 * nobs, 2));
-        grid_obs = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(nobs, 256), 2048));
+        grid_obs = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(nobs, 256), env_grid_obs()));
         grid_z = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(P.NZ, 256), 2048));
         scal.alloc(16);
         info.alloc(1);
@@ -224,6 +224,9 @@ struct Core {
         HIPCHK(hipDeviceSynchronize());
     }
 
+    // grid of the grid-stride observation kernels: one resident round (k_residual: 6 waves/SIMD
+    // of 4-wave workgroups on 256 CUs)
+    static int env_grid_obs() { const char *e = getenv("DBAT_HIP_GRID_OBS"); return e ? std::max(1, atoi(e)) : 1536; }
     // kernels that use more than 64 KB of dynamic LDS must opt in
     void set_lds_limits() {
 #define SET_LDS(K, BYTES) HIPCHK(hipFuncSetAttribute((const void *)(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)))
