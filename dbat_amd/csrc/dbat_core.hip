@@ -65,6 +65,7 @@ struct Core {
     int tile_ncx = 6;
     int64_t ntiles = 0;
     size_t lds_tile = 0, lds_tile2 = 0;
+    int tile2_pc = TILE2_PC;
     bool use_tile2 = true;
     DevBuf<int64_t> o_row, batch_start, x2z, giant_start;
     DevBuf<double> giant_W;
@@ -213,10 +214,12 @@ struct Core {
         lds_back = (size_t)P.BT * 6 * sizeof(double);
         lds_tile = ((size_t)2 * 3 * TILE_PC * TILE_LD + (size_t)P.BT * 9 + (size_t)36 * P.CMAX + 3 * TILE_LD +
                     (P.with_io ? (size_t)P.CMAX * 6 * 16 + 256 : 0)) * sizeof(double);
-        lds_tile2 = ((size_t)TILE2_NBUF * 3 * TILE2_PC * TILE_LD + (size_t)256 * 9 + (size_t)128 * 15 + (size_t)36 * P.CMAX +
-                     3 * TILE_LD) * sizeof(double);
-        // the wave-specialised tile kernel covers the fixed-IO case with 256-observation batches
-        use_tile2 = P.BT == 256 && !P.with_io && getenv("DBAT_HIP_TILE_V1") == nullptr;
+        // wave-specialised tile kernel: 256-observation batches; fixed IO: 16-point chunks, 2 panels;
+        // self-calibration (<= 8 IO columns per camera): 8-point chunks, 2 panels + the IO blocks
+        tile2_pc = P.with_io ? 8 : TILE2_PC;
+        lds_tile2 = ((size_t)TILE2_NBUF * 3 * tile2_pc * TILE_LD + (size_t)256 * 9 + (size_t)128 * 15 + (size_t)36 * P.CMAX +
+                     3 * TILE_LD + (P.with_io ? (size_t)P.CMAX * 6 * 16 + 256 : 0)) * sizeof(double);
+        use_tile2 = P.BT == 256 && P.ncolmax <= 14 && getenv("DBAT_HIP_TILE_V1") == nullptr;
         partial.alloc((size_t)4 * std::max<int64_t>(std::max<int64_t>(nb + ntiles + ngiant, 2048), 1));
         set_lds_limits();
         HIPCHK(hipMemcpy(z.p, P.z0.data(), P.NZ * 8, hipMemcpyHostToDevice));
@@ -237,8 +240,13 @@ struct Core {
         SET_LDS((k_build_tile<2, MAXCOL>), lds_tile); SET_LDS((k_build_tile<3, MAXCOL>), lds_tile);
         SET_LDS((k_build_tile<4, MAXCOL>), lds_tile); SET_LDS((k_build_tile<5, MAXCOL>), lds_tile);
         if (use_tile2) {
-            SET_LDS((k_build_tile2<2>), lds_tile2); SET_LDS((k_build_tile2<3>), lds_tile2);
-            SET_LDS((k_build_tile2<4>), lds_tile2); SET_LDS((k_build_tile2<5>), lds_tile2);
+            if (P.with_io) {
+                SET_LDS((k_build_tile2<2, 14, 8, TILE2_NBUF>), lds_tile2); SET_LDS((k_build_tile2<3, 14, 8, TILE2_NBUF>), lds_tile2);
+                SET_LDS((k_build_tile2<4, 14, 8, TILE2_NBUF>), lds_tile2); SET_LDS((k_build_tile2<5, 14, 8, TILE2_NBUF>), lds_tile2);
+            } else {
+                SET_LDS((k_build_tile2<2, 6, TILE2_PC, TILE2_NBUF>), lds_tile2); SET_LDS((k_build_tile2<3, 6, TILE2_PC, TILE2_NBUF>), lds_tile2);
+                SET_LDS((k_build_tile2<4, 6, TILE2_PC, TILE2_NBUF>), lds_tile2); SET_LDS((k_build_tile2<5, 6, TILE2_PC, TILE2_NBUF>), lds_tile2);
+            }
         }
         {
             const size_t lds_cov = ((size_t)P.BT * P.ncolmax * 3 + (size_t)P.BT * 6) * sizeof(double);
@@ -343,8 +351,9 @@ struct Core {
         if (ntiles > 0 && nb_tiled > 0) {
             npart = ntiles;
 #define L_TILE(M, NCXV) hipLaunchKernelGGL((k_build_tile<M, NCXV>), dim3((unsigned)ntiles), dim3(P.BT), lds_tile, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p, pivmm.p)
-#define L_TILE2(M, NCXV) hipLaunchKernelGGL((k_build_tile2<M>), dim3((unsigned)ntiles), dim3(512), lds_tile2, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p, pivmm.p)
+#define L_TILE2(M, NCXV) hipLaunchKernelGGL((k_build_tile2<M, NCXV, (NCXV == 6 ? TILE2_PC : 8), TILE2_NBUF>), dim3((unsigned)ntiles), dim3(512), lds_tile2, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p, pivmm.p)
             if (use_tile2 && tile_ncx == 6) { DISPATCH_MODEL(L_TILE2, 6) }
+            else if (use_tile2 && tile_ncx == 14) { DISPATCH_MODEL(L_TILE2, 14) }
             else if (tile_ncx == 6) { DISPATCH_MODEL(L_TILE, 6) }
             else if (tile_ncx == 14) { DISPATCH_MODEL(L_TILE, 14) }
             else { DISPATCH_MODEL(L_TILE, MAXCOL) }

@@ -224,16 +224,17 @@ __device__ __forceinline__ void eval_obs_cols_n(const DevProblem &d, const CamRe
     }
 }
 
-// Fixed-IO variant with the operands already in registers (prefetched one batch
-// ahead by k_build_tile2): Q = object point, (u,v), weights, est = bit k set if
-// point coordinate k is estimated.
-template <int MODEL>
+// Variant with the operands already in registers (prefetched one batch ahead by
+// k_build_tile2): Q = object point, (u,v), weights, est = bit k set if point
+// coordinate k is estimated.  NCX = 6 (fixed IO) or the capacity of E.
+template <int MODEL, int NCX>
 __device__ __forceinline__ void eval_obs_pre(const DevProblem &d, const CamRec &C, const double Q[3], double u,
                                              double v, double w0, double w1, unsigned est, double r[2],
-                                             double E[2][6], double B[2][3]) {
+                                             double E[2][NCX], double B[2][3]) {
+    constexpr bool WITH_IO = NCX > 6;
     double A[2][6];
     double Cf[2][MAXIO];
-    obs_eval<MODEL, true, false>(C, d.nK, d.nP, Q, u, v, r, A, B, Cf);
+    obs_eval<MODEL, true, WITH_IO>(C, d.nK, d.nP, Q, u, v, r, A, B, Cf);
     r[0] *= w0; r[1] *= w1;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -244,6 +245,18 @@ __device__ __forceinline__ void eval_obs_pre(const DevProblem &d, const CamRec &
     for (int k = 0; k < 6; ++k) {
         const double m = ((C.eo_est >> k) & 1u) ? 1.0 : 0.0;
         E[0][k] = A[0][k] * w0 * m; E[1][k] = A[1][k] * w1 * m;
+    }
+    if constexpr (WITH_IO) {
+#pragma unroll
+        for (int j = 0; j < NCX - 6; ++j) {
+            double c0 = 0, c1 = 0;
+            if (6 + j < C.ncol) {
+                const int row = C.iorow[j];
+#pragma unroll
+                for (int rr = 0; rr < MAXIO; ++rr) if (rr == row) { c0 = Cf[0][rr]; c1 = Cf[1][rr]; }
+            }
+            E[0][6 + j] = c0 * w0; E[1][6 + j] = c1 * w1;
+        }
     }
 }
 
@@ -1031,7 +1044,7 @@ __global__ __launch_bounds__(256) void k_build_tile(DevProblem d, const double *
 // (P1 -> P2 -> P3) with a counter barrier; the hardware s_barrier is only used
 // where all eight waves take part.
 // Every spin has a cap that poisons the objective value instead of hanging.
-constexpr int TILE2_PC = 16;
+constexpr int TILE2_PC = 16;                     // fixed IO; self-calibration: 8 (LDS also holds the IO blocks)
 constexpr int TILE2_NBUF = 2;                    // operand panels in flight between producers and consumers
 
 // sum_p Y_p W_p' with Y = W V^-1 is the symmetric product Z Z' for Z = W R, V^-1 = R R'
@@ -1066,7 +1079,7 @@ constexpr int TILE2_SPIN_CAP = 1 << 24;
 
 __device__ unsigned long long g_tile2_prof[16];    // DBAT_HIP_ABLATE & 32: phase times (10 ns ticks), summed over tiles
 
-struct Tile2Sync { int full[TILE2_NBUF], done[TILE2_NBUF], freed[TILE2_NBUF], ks[TILE2_NBUF], pbar, abort_, npts[2]; };
+struct Tile2Sync { int full[4], done[4], freed[4], ks[4], pbar, abort_, npts[2]; };
 
 __device__ __forceinline__ void lds_fence() {           // all LDS traffic of this wave has completed
     __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0)
@@ -1089,7 +1102,11 @@ __device__ __forceinline__ void lds_signal(int *cnt) {   // one count per wave
     if ((threadIdx.x & 63) == 0) atomicAdd(cnt, 1);
 }
 
-template <int MODEL>
+// NCX = 6: fixed IO.  NCX > 6: self-calibration -- the estimated IO columns of the tile's
+// cameras are extra rows of the tile (as in k_build_tile); an IO row is shared by the
+// observations of a point, so its panel entries are summed with LDS atomics into the
+// zeroed panel.  PC points per chunk, NBUF panels.
+template <int MODEL, int NCX, int PC, int NBUF>
 __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double *__restrict__ z,
                                                      const CamRec *__restrict__ cams, double lambda, int scale,
                                                      double *__restrict__ S, double *__restrict__ g_c,
@@ -1098,7 +1115,9 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
                                                      double *__restrict__ jn2p, double *__restrict__ r_w,
                                                      double *__restrict__ partial,
                                                      unsigned long long *__restrict__ pivmm) {
-    constexpr int PC = TILE2_PC, KC = 3 * PC, LD = TILE_LD, PANEL = KC * LD, NBUF = TILE2_NBUF;
+    constexpr int KC = 3 * PC, LD = TILE_LD, PANEL = KC * LD;
+    constexpr bool IO = NCX > 6;
+    constexpr int IOT = 16;                          // Plan::IOT
     constexpr int NPROD = 256;                       // producer threads = batch size
     extern __shared__ double smem[];
     const int CM = d.CMAX;
@@ -1107,6 +1126,8 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
     double *pinv = red + (size_t)NPROD * 9;          // [NPROD/2][15] V^-1 | g_p | R per point of the batch
     double *Ud = pinv + (size_t)(NPROD / 2) * 15;    // [CM][36]
     double *vt = Ud + (size_t)CM * 36;               // [3][LD]
+    double *Uci = vt + 3 * LD;                       // [CM][6][IOT] camera x IO part of J_c'J_c   (IO only)
+    double *Uii = Uci + (IO ? (size_t)CM * 6 * IOT : 0);   // [IOT][IOT] IO x IO part, lower       (IO only)
     __shared__ double sh[16];
     __shared__ Tile2Sync sy;
     __shared__ int64_t bs_sh[64];                    // batch_start of this tile's batches (a tile is capped at 16)
@@ -1118,10 +1139,13 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
     const int b0 = d.tile_batch[tile], b1 = d.tile_batch[tile + 1];
     const int c0 = d.tile_cam_start[tile];
     const int ncam = d.tile_cam_start[tile + 1] - c0;
-    const int nrows = 6 * ncam;
+    const int io0 = IO ? d.tile_io_start[tile] : 0;
+    const int nio = IO ? d.tile_io_start[tile + 1] - io0 : 0;
+    const int iobase = 6 * ncam;                     // first IO row of the tile-local system
+    const int nrows = iobase + nio;
     for (int i = t; i <= b1 - b0 && i < 64; i += 512) bs_sh[i] = d.batch_start[b0 + i];
     for (int i = t; i < NBUF * PANEL; i += 512) pan[i] = 0.0;
-    for (int i = t; i < CM * 36 + 3 * LD; i += 512) Ud[i] = 0.0;
+    for (int i = t; i < CM * 36 + 3 * LD + (IO ? CM * 6 * IOT + IOT * IOT : 0); i += 512) Ud[i] = 0.0;
     if (t < NBUF) { sy.full[t] = 0; sy.done[t] = 0; sy.freed[t] = 0; sy.ks[t] = 0; }
     if (t == 0) { sy.pbar = 0; sy.abort_ = 0; sy.npts[0] = sy.npts[1] = 0; }
     mfma_d4 acc[9];
@@ -1172,8 +1196,14 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
             const int64_t o = o0 + t;
             int *npts_sh = &sy.npts[b & 1];
             double r[2] = {0, 0};
-            double E[2][6];
+            const int hn_lc_cur = hn_lc;
+            double E[2][NCX];
             double B[2][3];
+            int ncol = 6;
+            uint32_t ciop[4] = {0, 0, 0, 0};         // local IO rows of this camera's IO columns (1 byte each)
+            auto lrow = [&](int a) -> int {          // tile-local row of camera-side column a
+                return a < 6 ? 6 * hn_lc_cur + a : iobase + (int)((ciop[(a - 6) >> 2] >> (8 * ((a - 6) & 3))) & 255u);
+            };
             const int cam = hn_cam, pt = hn_pt, lc = hn_lc, pidx = hn_pidx;
             const int seg_start = hn_sg & 0xFFFF, seg_len = hn_sg >> 16;
             const double uu = hn_u, vv = hn_v;
@@ -1186,7 +1216,12 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
             if (active) {                            // ---- P1
                 const CamRec &C = cams[cam];
                 const double w0 = d.o_w ? d.o_w[2 * o] : C.w[0], w1 = d.o_w ? d.o_w[2 * o + 1] : C.w[1];
-                eval_obs_pre<MODEL>(d, C, Q, uu, vv, w0, w1, est, r, E, B);
+                if constexpr (IO) {
+                    ncol = min(C.ncol, NCX);
+                    const uint32_t *cp = (const uint32_t *)(d.tile_cam_io + (size_t)(c0 + lc) * 16);
+                    ciop[0] = cp[0]; ciop[1] = cp[1]; ciop[2] = cp[2]; ciop[3] = cp[3];
+                }
+                eval_obs_pre<MODEL, NCX>(d, C, Q, uu, vv, w0, w1, est, r, E, B);
                 r_w[2 * o] = r[0]; r_w[2 * o + 1] = r[1];
                 rr += r[0] * r[0] + r[1] * r[1];
                 double *rd = red + (size_t)t * 9;
@@ -1276,7 +1311,8 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
                 const double g0 = pi[6], g1 = pi[7], g2 = pi[8];
                 double *ud = Ud + (size_t)lc * 36;
 #pragma unroll
-                for (int a = 0; a < 6; ++a) {
+                for (int a = 0; a < NCX; ++a) {
+                    if (a >= ncol) continue;
                     const double w0 = E[0][a] * B[0][0] + E[1][a] * B[1][0];
                     const double w1 = E[0][a] * B[0][1] + E[1][a] * B[1][1];
                     const double w2 = E[0][a] * B[0][2] + E[1][a] * B[1][2];
@@ -1284,13 +1320,31 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
                     const double y1 = w0 * v1 + w1 * v3 + w2 * v4;
                     const double y2 = w0 * v2 + w1 * v4 + w2 * v5;
                     const double ga = E[0][a] * r[0] + E[1][a] * r[1];
-                    const int ra = 6 * lc + a;
+                    const int ra = lrow(a);
                     atomic_add_f64(vt + ra, ga);
                     atomic_add_f64(vt + LD + ra, ga - (y0 * g0 + y1 * g1 + y2 * g2));
                     atomic_add_f64(vt + 2 * LD + ra, E[0][a] * E[0][a] + E[1][a] * E[1][a]);
+                    if (a < 6) {
 #pragma unroll
-                    for (int b2 = a; b2 < 6; ++b2)
-                        atomic_add_f64(ud + a * 6 + b2, E[0][a] * E[0][b2] + E[1][a] * E[1][b2]);
+                        for (int b2 = a; b2 < 6; ++b2)
+                            atomic_add_f64(ud + a * 6 + b2, E[0][a] * E[0][b2] + E[1][a] * E[1][b2]);
+                        if constexpr (IO) {
+#pragma unroll
+                            for (int b2 = 6; b2 < NCX; ++b2)
+                                if (b2 < ncol)
+                                    atomic_add_f64(Uci + ((size_t)lc * 6 + a) * IOT + (lrow(b2) - iobase),
+                                                   E[0][a] * E[0][b2] + E[1][a] * E[1][b2]);
+                        }
+                    } else if constexpr (IO) {
+                        const int ia = ra - iobase;
+#pragma unroll
+                        for (int b2 = 6; b2 < NCX; ++b2)
+                            if (b2 < ncol) {
+                                const int ib = lrow(b2) - iobase;
+                                if (ib >= ia)        // lower triangle: row ib, column ia
+                                    atomic_add_f64(Uii + (size_t)ia * IOT + ib, E[0][a] * E[0][b2] + E[1][a] * E[1][b2]);
+                            }
+                    }
                 }
             }
             lap(4);
@@ -1302,15 +1356,21 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
                 lap(0);
                 double *Zt = pan + s * PANEL;
                 if (active && pidx >= p0 && pidx < p0 + PC) {
-                    const int kb = 3 * (pidx - p0), row0 = 6 * lc;
+                    const int kb = 3 * (pidx - p0);
 #pragma unroll
-                    for (int a = 0; a < 6; ++a) {
+                    for (int a = 0; a < NCX; ++a) {
+                        if (a >= ncol) continue;
+                        const int row = lrow(a);
                         const double w0 = E[0][a] * B[0][0] + E[1][a] * B[1][0];
                         const double w1 = E[0][a] * B[0][1] + E[1][a] * B[1][1];
                         const double w2 = E[0][a] * B[0][2] + E[1][a] * B[1][2];
-                        Zt[(kb + 0) * LD + row0 + a] = w0 * nr0 + w1 * nr1 + w2 * nr2;
-                        Zt[(kb + 1) * LD + row0 + a] = w1 * nr3 + w2 * nr4;
-                        Zt[(kb + 2) * LD + row0 + a] = w2 * nr5;
+                        const double z0 = w0 * nr0 + w1 * nr1 + w2 * nr2, z1 = w1 * nr3 + w2 * nr4, z2 = w2 * nr5;
+                        if (a < 6) {                 // a camera row belongs to one observation of the point
+                            Zt[(kb + 0) * LD + row] = z0; Zt[(kb + 1) * LD + row] = z1; Zt[(kb + 2) * LD + row] = z2;
+                        } else {                     // an IO row is shared by the point's observations: sum
+                            atomic_add_f64(Zt + (kb + 0) * LD + row, z0); atomic_add_f64(Zt + (kb + 1) * LD + row, z1);
+                            atomic_add_f64(Zt + (kb + 2) * LD + row, z2);
+                        }
                     }
                 }
                 if (t == 0) sy.ks[s] = (3 * min(PC, npts - p0) + 3) >> 2;
@@ -1373,7 +1433,11 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
             lds_signal(&sy.freed[s]);
             lap(7);
         }
-        // ---- flush this wave's part of the tile:  S -= sum_p Y W'
+        // ---- flush this wave's part of the tile:  S -= sum_p Z Z'
+        auto grow = [&](int lr) -> int64_t {         // tile-local row -> row of the reduced system
+            if (lr < iobase) return 6 * (int64_t)d.tile_cams[c0 + lr / 6] + lr % 6;
+            return 6 * (int64_t)d.nc + d.tile_iocols[io0 + lr - iobase];
+        };
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
             if (ton[s]) {
@@ -1383,8 +1447,7 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
                     const int lr = yoff[s] + (lane >> 4) + 4 * e;
                     const double v = acc[s][e];
                     if (lr < nrows && lcol <= lr && v != 0.0)
-                        atomic_add_f64(S + (6 * (int64_t)d.tile_cams[c0 + lcol / 6] + lcol % 6) * d.ldS +
-                                           6 * (int64_t)d.tile_cams[c0 + lr / 6] + lr % 6, -v);
+                        atomic_add_f64(S + grow(lcol) * d.ldS + grow(lr), -v);
                 }
             }
         }
@@ -1404,8 +1467,26 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
         const int64_t cb = 6 * (int64_t)d.tile_cams[c0 + lcam];
         atomic_add_f64(S + (cb + a) * d.ldS + (cb + b2), Ud[i]);
     }
+    auto grow2 = [&](int lr) -> int64_t {
+        if (lr < iobase) return 6 * (int64_t)d.tile_cams[c0 + lr / 6] + lr % 6;
+        return 6 * (int64_t)d.nc + d.tile_iocols[io0 + lr - iobase];
+    };
+    if constexpr (IO) {
+        for (int i = t; i < ncam * 6 * IOT; i += 512) {
+            const int li = i % IOT, ca = i / IOT;    // ca = lcam*6 + a
+            if (li >= nio) continue;
+            const double v = Uci[i];
+            if (v != 0.0) atomic_add_f64(S + grow2(ca) * d.ldS + grow2(iobase + li), v);
+        }
+        for (int i = t; i < IOT * IOT; i += 512) {
+            const int ia = i / IOT, ib = i % IOT;
+            if (ia >= nio || ib >= nio || ib < ia) continue;
+            const double v = Uii[i];
+            if (v != 0.0) atomic_add_f64(S + grow2(iobase + ia) * d.ldS + grow2(iobase + ib), v);
+        }
+    }
     for (int i = t; i < nrows; i += 512) {
-        const int64_t col = 6 * (int64_t)d.tile_cams[c0 + i / 6] + i % 6;
+        const int64_t col = grow2(i);
         atomic_add_f64(g_c + col, vt[i]);
         atomic_add_f64(g_red + col, vt[LD + i]);
         atomic_add_f64(diagU + col, vt[2 * LD + i]);
