@@ -261,7 +261,8 @@ __device__ __forceinline__ bool df_backward(double *smem, const DfView &V, int n
     }
     __syncthreads();
     if (ty == 0 && tx < nc) {
-        const double qj = (red[tx] + red[NB + tx]) + (red[2 * NB + tx] + red[3 * NB + tx]);
+        double qj = (red[tx] + red[NB + tx]) + (red[2 * NB + tx] + red[3 * NB + tx]);
+        if (qj != qj) qj = __longlong_as_double(0x7ff8000000000000ll);   // any NaN -> the canonical one, never DF_SENTINEL
         st_coh(q_out + col0 + tx, qj);
         if (q_nat != q_out) {
             const int zn = V.iperm ? V.iperm[col0 + tx] : (int)(col0 + tx);

@@ -260,6 +260,27 @@ __device__ __forceinline__ void eval_obs_pre(const DevProblem &d, const CamRec &
     }
 }
 
+// Sum of x over the 64 lanes of the wave (result valid in every lane): inclusive row sums by
+// DPP row shifts (VALU only, no LDS), then the four row totals by v_readlane.
+__device__ __forceinline__ double wave_sum_f64(double x) {
+#define DBAT_DPP_ADD(CTRL)                                                                          \
+    {                                                                                               \
+        const long long b_ = __double_as_longlong(x);                                               \
+        const int lo_ = __builtin_amdgcn_update_dpp(0, (int)(b_ & 0xffffffffll), CTRL, 0xf, 0xf, true); \
+        const int hi_ = __builtin_amdgcn_update_dpp(0, (int)(b_ >> 32), CTRL, 0xf, 0xf, true);      \
+        x += __longlong_as_double(((long long)hi_ << 32) | (unsigned int)lo_);                      \
+    }
+    DBAT_DPP_ADD(0x111) DBAT_DPP_ADD(0x112) DBAT_DPP_ADD(0x114) DBAT_DPP_ADD(0x118)   // row_shr:1,2,4,8
+#undef DBAT_DPP_ADD
+    const long long b = __double_as_longlong(x);
+    const int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+    auto rl = [&](int lane) {
+        return __longlong_as_double(((long long)__builtin_amdgcn_readlane(hi, lane) << 32) |
+                                    (unsigned int)__builtin_amdgcn_readlane(lo, lane));
+    };
+    return (rl(15) + rl(31)) + (rl(47) + rl(63));
+}
+
 // 1/x by v_rcp_f64 and two Newton steps (no division sequence on the path)
 __device__ __forceinline__ double fast_rcp(double x) {
     double r = __builtin_amdgcn_rcp(x);
@@ -1304,15 +1325,30 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
             const int npts = *npts_sh;
             double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
             double nr0 = 0, nr1 = 0, nr2 = 0, nr3 = 0, nr4 = 0, nr5 = 0;
+            double g0 = 0, g1 = 0, g2 = 0;
+            // Self-calibration: the IO rows of a shared camera are hit by every observation.  If all
+            // lanes of the wave map their IO columns to the same tile rows (one camera / IO block --
+            // the usual case), the IO x IO block and the IO entries of the vectors are summed over the
+            // wave in registers and added once; otherwise every lane uses LDS atomics.
+            bool io_uniform = false;
+            if constexpr (IO) {
+                const uint32_t c0f = __builtin_amdgcn_readfirstlane(ciop[0]), c1f = __builtin_amdgcn_readfirstlane(ciop[1]);
+                const uint32_t c2f = __builtin_amdgcn_readfirstlane(ciop[2]), c3f = __builtin_amdgcn_readfirstlane(ciop[3]);
+                const int ncf = __builtin_amdgcn_readfirstlane(ncol);
+                io_uniform = __all(!active || (ciop[0] == c0f && ciop[1] == c1f && ciop[2] == c2f && ciop[3] == c3f && ncol == ncf)) &&
+                             __builtin_amdgcn_readfirstlane(active ? 1 : 0) == 1;
+                if (io_uniform) { ciop[0] = c0f; ciop[1] = c1f; ciop[2] = c2f; ciop[3] = c3f; }   // idle lanes too: uniform row lookups
+            }
             if (active) {                            // ---- P3: E'E, gradient pieces
                 const double *pi = pinv + (size_t)pidx * 15;
                 v0 = pi[0]; v1 = pi[1]; v2 = pi[2]; v3 = pi[3]; v4 = pi[4]; v5 = pi[5];
                 nr0 = pi[9]; nr1 = pi[10]; nr2 = pi[11]; nr3 = pi[12]; nr4 = pi[13]; nr5 = pi[14];
-                const double g0 = pi[6], g1 = pi[7], g2 = pi[8];
+                g0 = pi[6]; g1 = pi[7]; g2 = pi[8];
                 double *ud = Ud + (size_t)lc * 36;
 #pragma unroll
                 for (int a = 0; a < NCX; ++a) {
-                    if (a >= ncol) continue;
+                    if (a >= ncol || (d.ablate & 2)) continue;       // ablate: profiling only
+                    if (IO && a >= 6 && io_uniform) continue;        // summed over the wave below
                     const double w0 = E[0][a] * B[0][0] + E[1][a] * B[1][0];
                     const double w1 = E[0][a] * B[0][1] + E[1][a] * B[1][1];
                     const double w2 = E[0][a] * B[0][2] + E[1][a] * B[1][2];
@@ -1344,6 +1380,43 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
                                 if (ib >= ia)        // lower triangle: row ib, column ia
                                     atomic_add_f64(Uii + (size_t)ia * IOT + ib, E[0][a] * E[0][b2] + E[1][a] * E[1][b2]);
                             }
+                    }
+                }
+            }
+            if constexpr (IO) {
+                if (io_uniform && !(d.ablate & 2)) {
+                    const int ncw = __builtin_amdgcn_readfirstlane(ncol);
+#pragma unroll
+                    for (int a = 6; a < NCX; ++a) {
+                        if (a >= ncw) break;                         // wave-uniform
+                        // idle lanes hold undefined E and B: they must contribute exact zeros
+                        const double e0 = active ? E[0][a] : 0.0, e1 = active ? E[1][a] : 0.0;
+                        double ga = 0.0, gr = 0.0;
+                        if (active) {
+                            const double w0 = e0 * B[0][0] + e1 * B[1][0];
+                            const double w1 = e0 * B[0][1] + e1 * B[1][1];
+                            const double w2 = e0 * B[0][2] + e1 * B[1][2];
+                            const double y0 = w0 * v0 + w1 * v1 + w2 * v2;
+                            const double y1 = w0 * v1 + w1 * v3 + w2 * v4;
+                            const double y2 = w0 * v2 + w1 * v4 + w2 * v5;
+                            ga = e0 * r[0] + e1 * r[1];
+                            gr = ga - (y0 * g0 + y1 * g1 + y2 * g2);
+                        }
+                        const double s_g = wave_sum_f64(ga);
+                        const double s_r = wave_sum_f64(gr);
+                        const double s_d = wave_sum_f64(e0 * e0 + e1 * e1);
+                        const int ra = lrow(a), ia = ra - iobase;    // same in every lane
+                        if (lane == 0) {
+                            atomic_add_f64(vt + ra, s_g); atomic_add_f64(vt + LD + ra, s_r); atomic_add_f64(vt + 2 * LD + ra, s_d);
+                        }
+#pragma unroll
+                        for (int b2 = 6; b2 < NCX; ++b2) {
+                            if (b2 >= ncw) break;
+                            const int ib = lrow(b2) - iobase;
+                            if (ib < ia) continue;                   // wave-uniform
+                            const double s_u = wave_sum_f64(active ? e0 * E[0][b2] + e1 * E[1][b2] : 0.0);
+                            if (lane == 0) atomic_add_f64(Uii + (size_t)ia * IOT + ib, s_u);
+                        }
                     }
                 }
             }
