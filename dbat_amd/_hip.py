@@ -120,6 +120,13 @@ def load():
             '%s not built: run `python -c "import __graft_entry__ as g; g.build()"` or '
             '`make -C dbat_amd/csrc` (needs hipcc).  There is no CPU fallback.' % LIB_PATH)
     try:
+        # PyTorch-ROCm ships its own HIP runtime; when this library (linked against /opt/rocm) is
+        # loaded first and torch afterwards, the second runtime finds no device.  Load order
+        # torch -> libdbat_hip works, so make it the order always.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         lib = C.CDLL(LIB_PATH)
     except OSError as e:
         raise DbatHipUnavailable('cannot load %s: %s' % (LIB_PATH, e)) from e
