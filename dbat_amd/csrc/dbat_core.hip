@@ -67,7 +67,10 @@ struct Core {
     size_t lds_tile = 0, lds_tile2 = 0;
     int tile2_pc = TILE2_PC;
     bool use_tile2 = true;
-    DevBuf<int64_t> o_row, batch_start, x2z, giant_start;
+    DevBuf<int64_t> o_row, batch_start, x2z, giant_start, cm_chunk_start;
+    DevBuf<int32_t> cm_pt, cm_chunk_cam;
+    DevBuf<double> cm_uv, cm_w;
+    int64_t n_cm_chunks = 0;
     DevBuf<double> giant_W;
     int64_t ngiant = 0;
     int giant_threads = 256;            // DBAT_HIP_GIANT_THREADS (64/128/256): tests force several chunks per point
@@ -144,6 +147,9 @@ struct Core {
         d.o_seg = o_seg.p; d.o_row = o_row.p; d.batch_start = batch_start.p;
         d.CMAX = P.CMAX; d.ablate = getenv("DBAT_HIP_ABLATE") ? atoi(getenv("DBAT_HIP_ABLATE")) : 0;
         d.ntiles = (int)ntiles; d.o_lc = o_lc.p; d.o_pidx = o_pidx.p;
+        cm_pt.upload(P.cm_pt); cm_uv.upload(P.cm_uv); cm_w.upload(P.cm_w);
+        cm_chunk_cam.upload(P.cm_chunk_cam); cm_chunk_start.upload(P.cm_chunk_start);
+        n_cm_chunks = (int64_t)P.cm_chunk_cam.size();
         ngiant = P.giant_start.empty() ? 0 : (int64_t)P.giant_start.size() - 1;
         if (ngiant > 0) {
             giant_start.upload(P.giant_start);
@@ -214,11 +220,9 @@ struct Core {
         lds_back = (size_t)P.BT * 6 * sizeof(double);
         lds_tile = ((size_t)2 * 3 * TILE_PC * TILE_LD + (size_t)P.BT * 9 + (size_t)36 * P.CMAX + 3 * TILE_LD +
                     (P.with_io ? (size_t)P.CMAX * 6 * 16 + 256 : 0)) * sizeof(double);
-        // wave-specialised tile kernel: 256-observation batches; fixed IO: 16-point chunks, 2 panels;
-        // self-calibration (<= 8 IO columns per camera): 8-point chunks, 2 panels + the IO blocks
-        tile2_pc = P.with_io ? 8 : TILE2_PC;
-        lds_tile2 = ((size_t)TILE2_NBUF * 3 * tile2_pc * TILE_LD + (size_t)256 * 9 + (size_t)128 * 15 + (size_t)36 * P.CMAX +
-                     3 * TILE_LD + (P.with_io ? (size_t)P.CMAX * 6 * 16 + 256 : 0)) * sizeof(double);
+        // wave-specialised tile kernel: 256-observation batches, 16-point chunks, 2 panels
+        tile2_pc = TILE2_PC;
+        lds_tile2 = ((size_t)TILE2_NBUF * 3 * tile2_pc * TILE_LD + (size_t)256 * 9 + (size_t)128 * 15 + TILE_LD) * sizeof(double);
         use_tile2 = P.BT == 256 && P.ncolmax <= 14 && getenv("DBAT_HIP_TILE_V1") == nullptr;
         partial.alloc((size_t)4 * std::max<int64_t>(std::max<int64_t>(nb + ntiles + ngiant, 2048), 1));
         set_lds_limits();
@@ -241,8 +245,8 @@ struct Core {
         SET_LDS((k_build_tile<4, MAXCOL>), lds_tile); SET_LDS((k_build_tile<5, MAXCOL>), lds_tile);
         if (use_tile2) {
             if (P.with_io) {
-                SET_LDS((k_build_tile2<2, 14, 8, TILE2_NBUF>), lds_tile2); SET_LDS((k_build_tile2<3, 14, 8, TILE2_NBUF>), lds_tile2);
-                SET_LDS((k_build_tile2<4, 14, 8, TILE2_NBUF>), lds_tile2); SET_LDS((k_build_tile2<5, 14, 8, TILE2_NBUF>), lds_tile2);
+                SET_LDS((k_build_tile2<2, 14, TILE2_PC, TILE2_NBUF>), lds_tile2); SET_LDS((k_build_tile2<3, 14, TILE2_PC, TILE2_NBUF>), lds_tile2);
+                SET_LDS((k_build_tile2<4, 14, TILE2_PC, TILE2_NBUF>), lds_tile2); SET_LDS((k_build_tile2<5, 14, TILE2_PC, TILE2_NBUF>), lds_tile2);
             } else {
                 SET_LDS((k_build_tile2<2, 6, TILE2_PC, TILE2_NBUF>), lds_tile2); SET_LDS((k_build_tile2<3, 6, TILE2_PC, TILE2_NBUF>), lds_tile2);
                 SET_LDS((k_build_tile2<4, 6, TILE2_PC, TILE2_NBUF>), lds_tile2); SET_LDS((k_build_tile2<5, 6, TILE2_PC, TILE2_NBUF>), lds_tile2);
@@ -351,7 +355,13 @@ struct Core {
         if (ntiles > 0 && nb_tiled > 0) {
             npart = ntiles;
 #define L_TILE(M, NCXV) hipLaunchKernelGGL((k_build_tile<M, NCXV>), dim3((unsigned)ntiles), dim3(P.BT), lds_tile, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p, pivmm.p)
-#define L_TILE2(M, NCXV) hipLaunchKernelGGL((k_build_tile2<M, NCXV, (NCXV == 6 ? TILE2_PC : 8), TILE2_NBUF>), dim3((unsigned)ntiles), dim3(512), lds_tile2, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p, pivmm.p)
+#define L_TILE2(M, NCXV) hipLaunchKernelGGL((k_build_tile2<M, NCXV, TILE2_PC, TILE2_NBUF>), dim3((unsigned)ntiles), dim3(512), lds_tile2, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p, pivmm.p)
+#define L_CAMN(M, NCXV) hipLaunchKernelGGL((k_cam_normal<M, NCXV>), dim3((unsigned)n_cm_chunks), dim3(256), 0, stream, d, zz, cams.p, cm_pt.p, cm_uv.p, P.uniform_w ? (const double *)nullptr : cm_w.p, cm_chunk_cam.p, cm_chunk_start.p, S, g_c, g_red, diagU)
+            if (use_tile2 && tile_ncx <= 14 && n_cm_chunks > 0) {
+                // camera side of the tiled observations: J_c'J_c, J_c'r, squared column norms
+                if (tile_ncx == 6) { DISPATCH_MODEL(L_CAMN, 6) } else { DISPATCH_MODEL(L_CAMN, 14) }
+            }
+#undef L_CAMN
             if (use_tile2 && tile_ncx == 6) { DISPATCH_MODEL(L_TILE2, 6) }
             else if (use_tile2 && tile_ncx == 14) { DISPATCH_MODEL(L_TILE2, 14) }
             else if (tile_ncx == 6) { DISPATCH_MODEL(L_TILE, 6) }

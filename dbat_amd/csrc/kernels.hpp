@@ -1046,10 +1046,99 @@ __global__ __launch_bounds__(256) void k_build_tile(DevProblem d, const double *
     }
 }
 
+// all LDS traffic of this wave has completed
+__device__ __forceinline__ void lds_fence() {           // all LDS traffic of this wave has completed
+    __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0)
+    asm volatile("" ::: "memory");
+}
+
+// ---------------------------------------------------------------- K3c ---
+// J_c'J_c and J_c'r of the tiled observations, camera by camera: one workgroup
+// per chunk of ONE camera's observations (camera-major copy of the plan,
+// coalesced reads of (u,v) and the point index; the camera record is uniform
+// for the whole workgroup).  Every lane evaluates one observation and writes its
+// two rows [E | r] (16 columns) into the wave's LDS panel; the 16 x 16 Gram matrix
+//   G = sum_obs [E r]' [E r]
+// accumulates on the f64 matrix cores (v_mfma_f64_16x16x4_f64, A = B = panel
+// fragment).  G holds the camera's 6 x 6 block, its camera-IO and IO-IO blocks,
+// E'r and the squared column norms at once; it is added to S, g_c, g_red, diagU
+// with a handful of atomics per chunk -- instead of ~40 (fixed IO) to ~150
+// (self-calibration) LDS atomics per observation in the tile kernel.
+template <int MODEL, int NCX>
+__global__ __launch_bounds__(256) void k_cam_normal(DevProblem d, const double *__restrict__ z,
+                                                    const CamRec *__restrict__ cams,
+                                                    const int32_t *__restrict__ cm_pt, const double *__restrict__ cm_uv,
+                                                    const double *__restrict__ cm_w,
+                                                    const int32_t *__restrict__ chunk_cam,
+                                                    const int64_t *__restrict__ chunk_start, double *__restrict__ S,
+                                                    double *__restrict__ g_c, double *__restrict__ g_red,
+                                                    double *__restrict__ diagU) {
+    constexpr bool IO = NCX > 6;
+    constexpr int GLD = 130;                         // panel [16 columns][128 rows], column stride 130
+    __shared__ double Gl[4 * 16 * GLD];
+    __shared__ double Gs[4 * 256];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int cam = chunk_cam[blockIdx.x];
+    const int64_t q0 = chunk_start[blockIdx.x], q1 = chunk_start[blockIdx.x + 1];
+    const CamRec &C = cams[cam];
+    const int ncol = IO ? min(C.ncol, NCX) : 6;
+    double *Gw = Gl + w * 16 * GLD;
+    // columns that stay zero
+    for (int c = NCX + 1; c < 16; ++c) { Gw[c * GLD + 2 * lane] = 0.0; Gw[c * GLD + 2 * lane + 1] = 0.0; }
+    mfma_d4 acc = {0, 0, 0, 0};
+    for (int64_t base = q0 + 64 * w; base < q1; base += 256) {
+        const int64_t q = base + lane;
+        double r[2] = {0, 0}, E[2][NCX];
+#pragma unroll
+        for (int c = 0; c < NCX; ++c) { E[0][c] = 0.0; E[1][c] = 0.0; }
+        if (q < q1) {
+            const int pt = cm_pt[q];
+            const int64_t zp = d.NS + 3 * (int64_t)pt;
+            const double Q[3] = {z[zp], z[zp + 1], z[zp + 2]};
+            const double w0 = cm_w ? cm_w[2 * q] : C.w[0], w1 = cm_w ? cm_w[2 * q + 1] : C.w[1];
+            double B[2][3];
+            eval_obs_pre<MODEL, NCX>(d, C, Q, cm_uv[2 * q], cm_uv[2 * q + 1], w0, w1, 7u, r, E, B);
+        }
+#pragma unroll
+        for (int c = 0; c < NCX; ++c) {
+            const bool on = c < ncol;
+            Gw[c * GLD + 2 * lane] = on ? E[0][c] : 0.0;
+            Gw[c * GLD + 2 * lane + 1] = on ? E[1][c] : 0.0;
+        }
+        Gw[NCX * GLD + 2 * lane] = r[0]; Gw[NCX * GLD + 2 * lane + 1] = r[1];
+        lds_fence();                                 // the panel is private to the wave
+#pragma unroll 8
+        for (int kk = 0; kk < 32; ++kk) {
+            const double a = Gw[(lane & 15) * GLD + 4 * kk + (lane >> 4)];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
+        }
+        lds_fence();
+    }
+    // G(i, j): register e of lane l holds i = (l>>4) + 4e, j = l&15.  Sum the four waves.
+#pragma unroll
+    for (int e = 0; e < 4; ++e) Gs[w * 256 + ((lane >> 4) + 4 * e) * 16 + (lane & 15)] = acc[e];
+    __syncthreads();
+    const int i = t >> 4, j = t & 15;
+    const double g = (Gs[t] + Gs[256 + t]) + (Gs[512 + t] + Gs[768 + t]);
+    if (i < ncol && g != 0.0) {
+        const int64_t ri = C.col[i];
+        if (j < ncol) {
+            const int64_t rj = C.col[j];
+            // every unordered pair once: local i > j, or the diagonal
+            if (i > j) atomic_add_f64(S + (ri >= rj ? rj * d.ldS + ri : ri * d.ldS + rj), g);
+            else if (i == j) { atomic_add_f64(S + ri * d.ldS + ri, g); atomic_add_f64(diagU + ri, g); }
+        } else if (j == NCX) {
+            atomic_add_f64(g_c + ri, g);
+            atomic_add_f64(g_red + ri, g);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- K1t2 --
 // Wave-specialised tile kernel for the fixed-IO path: 512 threads.  Waves 0-3
 // ("producers") evaluate the observations of the tile's batches exactly as
-// k_build_tile does (P1-P3) and scatter the Y / W fragments of chunks of
+// k_build_tile does (P1-P3, without the camera-side products J_c'J_c and
+// J_c'r: those are k_cam_normal's) and scatter the Y / W fragments of chunks of
 // TILE2_PC points into one of TWO operand panels in LDS; waves 4-7
 // ("consumers") run the 128 x 128 x 3*PC contraction of a filled panel on the
 // f64 matrix cores and hand the panel back.  Producer w and consumer w+4 share
@@ -1102,10 +1191,6 @@ __device__ unsigned long long g_tile2_prof[16];    // DBAT_HIP_ABLATE & 32: phas
 
 struct Tile2Sync { int full[4], done[4], freed[4], ks[4], pbar, abort_, npts[2]; };
 
-__device__ __forceinline__ void lds_fence() {           // all LDS traffic of this wave has completed
-    __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0)
-    asm volatile("" ::: "memory");
-}
 __device__ __forceinline__ bool lds_wait_ge(int *cnt, int target, int *abort_) {
     int spins = 0;
     while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
@@ -1138,17 +1223,13 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
                                                      unsigned long long *__restrict__ pivmm) {
     constexpr int KC = 3 * PC, LD = TILE_LD, PANEL = KC * LD;
     constexpr bool IO = NCX > 6;
-    constexpr int IOT = 16;                          // Plan::IOT
     constexpr int NPROD = 256;                       // producer threads = batch size
     extern __shared__ double smem[];
-    const int CM = d.CMAX;
     double *pan = smem;                              // [NBUF][KC*LD]  Z = W R panels
     double *red = pan + NBUF * PANEL;                // [NPROD][9]  B'B | B'r per observation
     double *pinv = red + (size_t)NPROD * 9;          // [NPROD/2][15] V^-1 | g_p | R per point of the batch
-    double *Ud = pinv + (size_t)(NPROD / 2) * 15;    // [CM][36]
-    double *vt = Ud + (size_t)CM * 36;               // [3][LD]
-    double *Uci = vt + 3 * LD;                       // [CM][6][IOT] camera x IO part of J_c'J_c   (IO only)
-    double *Uii = Uci + (IO ? (size_t)CM * 6 * IOT : 0);   // [IOT][IOT] IO x IO part, lower       (IO only)
+    double *vt = pinv + (size_t)(NPROD / 2) * 15;    // [LD]  -(W V^-1 g_p) by local row (the rest of the
+                                                     // camera side, J_c'J_c and J_c'r, is k_cam_normal's)
     __shared__ double sh[16];
     __shared__ Tile2Sync sy;
     __shared__ int64_t bs_sh[64];                    // batch_start of this tile's batches (a tile is capped at 16)
@@ -1166,7 +1247,7 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
     const int nrows = iobase + nio;
     for (int i = t; i <= b1 - b0 && i < 64; i += 512) bs_sh[i] = d.batch_start[b0 + i];
     for (int i = t; i < NBUF * PANEL; i += 512) pan[i] = 0.0;
-    for (int i = t; i < CM * 36 + 3 * LD + (IO ? CM * 6 * IOT + IOT * IOT : 0); i += 512) Ud[i] = 0.0;
+    for (int i = t; i < LD; i += 512) vt[i] = 0.0;
     if (t < NBUF) { sy.full[t] = 0; sy.done[t] = 0; sy.freed[t] = 0; sy.ks[t] = 0; }
     if (t == 0) { sy.pbar = 0; sy.abort_ = 0; sy.npts[0] = sy.npts[1] = 0; }
     mfma_d4 acc[9];
@@ -1344,7 +1425,6 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
                 v0 = pi[0]; v1 = pi[1]; v2 = pi[2]; v3 = pi[3]; v4 = pi[4]; v5 = pi[5];
                 nr0 = pi[9]; nr1 = pi[10]; nr2 = pi[11]; nr3 = pi[12]; nr4 = pi[13]; nr5 = pi[14];
                 g0 = pi[6]; g1 = pi[7]; g2 = pi[8];
-                double *ud = Ud + (size_t)lc * 36;
 #pragma unroll
                 for (int a = 0; a < NCX; ++a) {
                     if (a >= ncol || (d.ablate & 2)) continue;       // ablate: profiling only
@@ -1355,32 +1435,7 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
                     const double y0 = w0 * v0 + w1 * v1 + w2 * v2;
                     const double y1 = w0 * v1 + w1 * v3 + w2 * v4;
                     const double y2 = w0 * v2 + w1 * v4 + w2 * v5;
-                    const double ga = E[0][a] * r[0] + E[1][a] * r[1];
-                    const int ra = lrow(a);
-                    atomic_add_f64(vt + ra, ga);
-                    atomic_add_f64(vt + LD + ra, ga - (y0 * g0 + y1 * g1 + y2 * g2));
-                    atomic_add_f64(vt + 2 * LD + ra, E[0][a] * E[0][a] + E[1][a] * E[1][a]);
-                    if (a < 6) {
-#pragma unroll
-                        for (int b2 = a; b2 < 6; ++b2)
-                            atomic_add_f64(ud + a * 6 + b2, E[0][a] * E[0][b2] + E[1][a] * E[1][b2]);
-                        if constexpr (IO) {
-#pragma unroll
-                            for (int b2 = 6; b2 < NCX; ++b2)
-                                if (b2 < ncol)
-                                    atomic_add_f64(Uci + ((size_t)lc * 6 + a) * IOT + (lrow(b2) - iobase),
-                                                   E[0][a] * E[0][b2] + E[1][a] * E[1][b2]);
-                        }
-                    } else if constexpr (IO) {
-                        const int ia = ra - iobase;
-#pragma unroll
-                        for (int b2 = 6; b2 < NCX; ++b2)
-                            if (b2 < ncol) {
-                                const int ib = lrow(b2) - iobase;
-                                if (ib >= ia)        // lower triangle: row ib, column ia
-                                    atomic_add_f64(Uii + (size_t)ia * IOT + ib, E[0][a] * E[0][b2] + E[1][a] * E[1][b2]);
-                            }
-                    }
+                    atomic_add_f64(vt + lrow(a), -(y0 * g0 + y1 * g1 + y2 * g2));
                 }
             }
             if constexpr (IO) {
@@ -1390,33 +1445,19 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
                     for (int a = 6; a < NCX; ++a) {
                         if (a >= ncw) break;                         // wave-uniform
                         // idle lanes hold undefined E and B: they must contribute exact zeros
-                        const double e0 = active ? E[0][a] : 0.0, e1 = active ? E[1][a] : 0.0;
-                        double ga = 0.0, gr = 0.0;
+                        double gr = 0.0;
                         if (active) {
+                            const double e0 = E[0][a], e1 = E[1][a];
                             const double w0 = e0 * B[0][0] + e1 * B[1][0];
                             const double w1 = e0 * B[0][1] + e1 * B[1][1];
                             const double w2 = e0 * B[0][2] + e1 * B[1][2];
                             const double y0 = w0 * v0 + w1 * v1 + w2 * v2;
                             const double y1 = w0 * v1 + w1 * v3 + w2 * v4;
                             const double y2 = w0 * v2 + w1 * v4 + w2 * v5;
-                            ga = e0 * r[0] + e1 * r[1];
-                            gr = ga - (y0 * g0 + y1 * g1 + y2 * g2);
+                            gr = -(y0 * g0 + y1 * g1 + y2 * g2);
                         }
-                        const double s_g = wave_sum_f64(ga);
                         const double s_r = wave_sum_f64(gr);
-                        const double s_d = wave_sum_f64(e0 * e0 + e1 * e1);
-                        const int ra = lrow(a), ia = ra - iobase;    // same in every lane
-                        if (lane == 0) {
-                            atomic_add_f64(vt + ra, s_g); atomic_add_f64(vt + LD + ra, s_r); atomic_add_f64(vt + 2 * LD + ra, s_d);
-                        }
-#pragma unroll
-                        for (int b2 = 6; b2 < NCX; ++b2) {
-                            if (b2 >= ncw) break;
-                            const int ib = lrow(b2) - iobase;
-                            if (ib < ia) continue;                   // wave-uniform
-                            const double s_u = wave_sum_f64(active ? e0 * E[0][b2] + e1 * E[1][b2] : 0.0);
-                            if (lane == 0) atomic_add_f64(Uii + (size_t)ia * IOT + ib, s_u);
-                        }
+                        if (lane == 0) atomic_add_f64(vt + lrow(a), s_r);
                     }
                 }
             }
@@ -1532,37 +1573,11 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
 #pragma unroll
         for (int i = 0; i < 10; ++i) if (tp[i]) atomicAdd(&g_tile2_prof[base + i], (unsigned long long)tp[i]);
     }
-    // ---- J_c'J_c, gradient pieces (all 512 threads)
-    for (int i = t; i < ncam * 36; i += 512) {
-        const int lcam = i / 36, e = i - lcam * 36;
-        const int a = e / 6, b2 = e - a * 6;
-        if (b2 < a) continue;
-        const int64_t cb = 6 * (int64_t)d.tile_cams[c0 + lcam];
-        atomic_add_f64(S + (cb + a) * d.ldS + (cb + b2), Ud[i]);
-    }
-    auto grow2 = [&](int lr) -> int64_t {
-        if (lr < iobase) return 6 * (int64_t)d.tile_cams[c0 + lr / 6] + lr % 6;
-        return 6 * (int64_t)d.nc + d.tile_iocols[io0 + lr - iobase];
-    };
-    if constexpr (IO) {
-        for (int i = t; i < ncam * 6 * IOT; i += 512) {
-            const int li = i % IOT, ca = i / IOT;    // ca = lcam*6 + a
-            if (li >= nio) continue;
-            const double v = Uci[i];
-            if (v != 0.0) atomic_add_f64(S + grow2(ca) * d.ldS + grow2(iobase + li), v);
-        }
-        for (int i = t; i < IOT * IOT; i += 512) {
-            const int ia = i / IOT, ib = i % IOT;
-            if (ia >= nio || ib >= nio || ib < ia) continue;
-            const double v = Uii[i];
-            if (v != 0.0) atomic_add_f64(S + grow2(iobase + ia) * d.ldS + grow2(iobase + ib), v);
-        }
-    }
+    // ---- reduced right-hand side: -(W V^-1 g_p) of this tile (all 512 threads)
     for (int i = t; i < nrows; i += 512) {
-        const int64_t col = grow2(i);
-        atomic_add_f64(g_c + col, vt[i]);
-        atomic_add_f64(g_red + col, vt[LD + i]);
-        atomic_add_f64(diagU + col, vt[2 * LD + i]);
+        const int64_t col = i < iobase ? 6 * (int64_t)d.tile_cams[c0 + i / 6] + i % 6
+                                       : 6 * (int64_t)d.nc + d.tile_iocols[io0 + i - iobase];
+        atomic_add_f64(g_red + col, vt[i]);
     }
     double accr[1] = {rr};
     block_sum<1>(accr, sh);
