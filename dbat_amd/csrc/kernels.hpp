@@ -1226,7 +1226,7 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
     constexpr int NPROD = 256;                       // producer threads = batch size
     extern __shared__ double smem[];
     double *pan = smem;                              // [NBUF][KC*LD]  Z = W R panels
-    double *red = pan + NBUF * PANEL;                // [NPROD][9]  B'B | B'r per observation
+    double *red = pan + NBUF * PANEL;                // [2][NPROD/2][9]  sum of B'B | B'r per point, even/odd batch
     double *pinv = red + (size_t)NPROD * 9;          // [NPROD/2][15] V^-1 | g_p | R per point of the batch
     double *vt = pinv + (size_t)(NPROD / 2) * 15;    // [LD]  -(W V^-1 g_p) by local row (the rest of the
                                                      // camera side, J_c'J_c and J_c'r, is k_cam_normal's)
@@ -1246,7 +1246,7 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
     const int iobase = 6 * ncam;                     // first IO row of the tile-local system
     const int nrows = iobase + nio;
     for (int i = t; i <= b1 - b0 && i < 64; i += 512) bs_sh[i] = d.batch_start[b0 + i];
-    for (int i = t; i < NBUF * PANEL; i += 512) pan[i] = 0.0;
+    for (int i = t; i < NBUF * PANEL + NPROD * 9; i += 512) pan[i] = 0.0;     // panels and the point sums
     for (int i = t; i < LD; i += 512) vt[i] = 0.0;
     if (t < NBUF) { sy.full[t] = 0; sy.done[t] = 0; sy.freed[t] = 0; sy.ks[t] = 0; }
     if (t == 0) { sy.pbar = 0; sy.abort_ = 0; sy.npts[0] = sy.npts[1] = 0; }
@@ -1326,30 +1326,32 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
                 eval_obs_pre<MODEL, NCX>(d, C, Q, uu, vv, w0, w1, est, r, E, B);
                 r_w[2 * o] = r[0]; r_w[2 * o + 1] = r[1];
                 rr += r[0] * r[0] + r[1] * r[1];
-                double *rd = red + (size_t)t * 9;
-                rd[0] = B[0][0] * B[0][0] + B[1][0] * B[1][0];
-                rd[1] = B[0][0] * B[0][1] + B[1][0] * B[1][1];
-                rd[2] = B[0][0] * B[0][2] + B[1][0] * B[1][2];
-                rd[3] = B[0][1] * B[0][1] + B[1][1] * B[1][1];
-                rd[4] = B[0][1] * B[0][2] + B[1][1] * B[1][2];
-                rd[5] = B[0][2] * B[0][2] + B[1][2] * B[1][2];
-                rd[6] = B[0][0] * r[0] + B[1][0] * r[1];
-                rd[7] = B[0][1] * r[0] + B[1][1] * r[1];
-                rd[8] = B[0][2] * r[0] + B[1][2] * r[1];
+                // per-point sums of B'B and B'r with LDS atomics (the LDS unit, not the FP64 pipe the
+                // matrix work of the consumer wave on this SIMD is using)
+                double *ps = red + (size_t)(b & 1) * (NPROD / 2) * 9 + (size_t)pidx * 9;
+                atomic_add_f64(ps + 0, B[0][0] * B[0][0] + B[1][0] * B[1][0]);
+                atomic_add_f64(ps + 1, B[0][0] * B[0][1] + B[1][0] * B[1][1]);
+                atomic_add_f64(ps + 2, B[0][0] * B[0][2] + B[1][0] * B[1][2]);
+                atomic_add_f64(ps + 3, B[0][1] * B[0][1] + B[1][1] * B[1][1]);
+                atomic_add_f64(ps + 4, B[0][1] * B[0][2] + B[1][1] * B[1][2]);
+                atomic_add_f64(ps + 5, B[0][2] * B[0][2] + B[1][2] * B[1][2]);
+                atomic_add_f64(ps + 6, B[0][0] * r[0] + B[1][0] * r[1]);
+                atomic_add_f64(ps + 7, B[0][1] * r[0] + B[1][1] * r[1]);
+                atomic_add_f64(ps + 8, B[0][2] * r[0] + B[1][2] * r[1]);
             }
             fetch_point(b + 1);
             lap(1);
             if (!pbarrier()) { ok = false; break; }
             lap(2);
+            {   // the sums of the next batch start from zero: clear the other buffer now (its last readers,
+                // the leaders of batch b-1, finished before that batch's second barrier)
+                double *pz = red + (size_t)((b + 1) & 1) * (NPROD / 2) * 9;
+                for (int i = t; i < (NPROD / 2) * 9; i += NPROD) pz[i] = 0.0;
+            }
             if (active && t == seg_start) {          // ---- P2
                 atomicMax(npts_sh, pidx + 1);
-                double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
-                for (int j = 0; j < seg_len; ++j) {
-                    const double *rd = red + (size_t)(t + j) * 9;
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) V[k] += rd[k];
-                    g[0] += rd[6]; g[1] += rd[7]; g[2] += rd[8];
-                }
+                const double *ps = red + (size_t)(b & 1) * (NPROD / 2) * 9 + (size_t)pidx * 9;
+                double V[6] = {ps[0], ps[1], ps[2], ps[3], ps[4], ps[5]}, g[3] = {ps[6], ps[7], ps[8]};
                 const int64_t zp = d.NS + 3 * (int64_t)pt;
                 const int dix[3] = {0, 3, 5};
                 double jn[3];
