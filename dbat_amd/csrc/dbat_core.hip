@@ -499,6 +499,7 @@ struct Core {
         return failed;
     }
     // ---- posterior covariance blocks at z (bundle_cov.m): s0^2 * blocks of inv(J'J)
+    std::vector<double> cop_tmp;
     void posterior_cov(double s0, double *hCEO, double *hCIO, double *hCOP, double *hSinv) {
         build(z.p, 0.0, 0);                          // unscaled, undamped reduced system + V^-1 per point
         s_valid = false;
@@ -535,7 +536,8 @@ struct Core {
                 if (P.with_io) { DISPATCH_MODEL(L_COVG, true) } else { DISPATCH_MODEL(L_COVG, false) }
 #undef L_COVG
             }
-            HIPCHK(hipMemcpyAsync(hCOP, dCOP.p, (size_t)9 * P.np * sizeof(double), hipMemcpyDeviceToHost, stream));
+            cop_tmp.resize((size_t)9 * P.np);
+            HIPCHK(hipMemcpyAsync(cop_tmp.data(), dCOP.p, (size_t)9 * P.np * sizeof(double), hipMemcpyDeviceToHost, stream));
         }
         if (hCEO) HIPCHK(hipMemcpyAsync(hCEO, dCEO.p, (size_t)36 * P.nc * sizeof(double), hipMemcpyDeviceToHost, stream));
         if (hCIO && P.nIOu > 0) HIPCHK(hipMemcpyAsync(hCIO, dCIO.p, (size_t)P.nIOu * P.nIOu * sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -543,6 +545,9 @@ struct Core {
             HIPCHK(hipMemcpy2DAsync(hSinv, (size_t)P.NS * sizeof(double), S, (size_t)ldS * sizeof(double),
                                     (size_t)P.NS * sizeof(double), (size_t)P.NS, hipMemcpyDeviceToHost, stream));
         sync();
+        if (hCOP)                                    // device blocks are in processing order
+            for (int64_t p = 0; p < P.np; ++p)
+                std::copy(cop_tmp.begin() + 9 * (int64_t)P.pt_rank[p], cop_tmp.begin() + 9 * (int64_t)P.pt_rank[p] + 9, hCOP + 9 * p);
     }
     // ||J v||^2 and r'Jv at the linearisation point, ||v||^2 over owned entries
     void jtimes(const double *v, double &JvJv, double &rJv, double &vv) {
@@ -922,7 +927,9 @@ int dbat_hip_deserialize(const dbat_hip_handle *h, const double *x, double *IO, 
     std::vector<double> z(P.z0);
     for (int64_t i = 0; i < P.n; ++i) z[P.x2z[i]] = x[i];
     if (EO) std::copy(z.begin(), z.begin() + 6 * (int64_t)P.nc, EO);
-    if (OP) std::copy(z.begin() + P.NS, z.end(), OP);
+    if (OP)                                             // z holds the points in processing order
+        for (int64_t p = 0; p < P.np; ++p)
+            for (int k = 0; k < 3; ++k) OP[3 * p + k] = z[P.NS + 3 * (int64_t)P.pt_rank[p] + k];
     if (IO)
         for (size_t e = 0; e < P.io_src.size(); ++e)
             IO[e] = P.io_src[e] >= 0 ? z[6 * (int64_t)P.nc + P.io_src[e]] : P.io_fixed[e];

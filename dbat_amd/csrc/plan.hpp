@@ -47,6 +47,9 @@ struct Plan {
     // observations of this shard in processing (point-major) order
     int64_t pt_lo = 0, pt_hi = 0;                  // range in processing order
     std::vector<int32_t> porder;                   // processing order -> point
+    std::vector<int32_t> pt_rank;                  // point -> position in the processing order; the object points
+                                                   // sit in z in THAT order (neighbouring observations then
+                                                   // gather neighbouring coordinates), o_pt holds ranks
     std::vector<int32_t> o_cam, o_pt;
     std::vector<double> o_uv;                      // 2 per obs
     std::vector<double> o_w;                       // 2 per obs (1/sigma_mm) or empty if uniform
@@ -403,11 +406,29 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         P.pt_lo = cut(P.rank); P.pt_hi = cut(P.rank + 1);
         if (P.pt_hi < P.pt_lo) P.pt_hi = P.pt_lo;
     }
+    // the point part of z follows the processing order: permute everything that was laid out by point id
+    P.pt_rank.assign(np, 0);
+    for (int i = 0; i < np; ++i) P.pt_rank[P.porder[i]] = i;
+    {
+        auto zperm = [&](int64_t zi) -> int64_t {
+            if (zi < P.NS) return zi;
+            const int64_t e = zi - P.NS;
+            return P.NS + 3 * (int64_t)P.pt_rank[e / 3] + e % 3;
+        };
+        std::vector<double> a(P.z0), b(P.z_prw), c(P.z_prv);
+        std::vector<uint8_t> e(P.z_est);
+        for (int64_t zi = P.NS; zi < P.NZ; ++zi) {
+            const int64_t q = zperm(zi);
+            P.z0[q] = a[zi]; P.z_prw[q] = b[zi]; P.z_prv[q] = c[zi]; P.z_est[q] = e[zi];
+        }
+        for (auto &v : P.x2z) v = zperm(v);
+        for (auto &v : P.prior_z) v = zperm(v);
+    }
     // z_mine: EO/IO counted by rank 0, OP by the owning shard
     P.z_mine.assign(P.NZ, 0);
     if (P.rank == 0) for (int64_t z = 0; z < P.NS; ++z) P.z_mine[z] = 1;
     for (int64_t i = P.pt_lo; i < P.pt_hi; ++i)
-        for (int d = 0; d < 3; ++d) P.z_mine[P.NS + 3 * (int64_t)P.porder[i] + d] = 1;
+        for (int d = 0; d < 3; ++d) P.z_mine[P.NS + 3 * i + d] = 1;
     if (!with_obs) return true;
 
     // ---- batches of whole points, at most BT observations each; tiles of
@@ -476,7 +497,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
             for (int j = 0; j < k; ++j, ++pos) {
                 const int64_t o = by_pt[pstart[p] + j];
                 const int32_t c = pb.ip_cam[o];
-                P.o_cam[pos] = c; P.o_pt[pos] = p;
+                P.o_cam[pos] = c; P.o_pt[pos] = P.pt_rank[p];
                 P.o_uv[2 * pos] = pb.ip_val[2 * o]; P.o_uv[2 * pos + 1] = pb.ip_val[2 * o + 1];
                 P.o_seg[pos] = 0; P.o_row[pos] = o;
                 if (!P.uniform_w) {
@@ -530,7 +551,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         for (int j = 0; j < k; ++j, ++pos) {
             const int64_t o = by_pt[pstart[p] + j];
             const int32_t c = pb.ip_cam[o];
-            P.o_cam[pos] = c; P.o_pt[pos] = p;
+            P.o_cam[pos] = c; P.o_pt[pos] = P.pt_rank[p];
             P.o_uv[2 * pos] = pb.ip_val[2 * o]; P.o_uv[2 * pos + 1] = pb.ip_val[2 * o + 1];
             P.o_seg[pos] = seg; P.o_row[pos] = o; P.o_pidx[pos] = (uint8_t)pidx;
             if (!P.uniform_w) {
