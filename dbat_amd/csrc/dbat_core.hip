@@ -70,7 +70,7 @@ struct Core {
     DevBuf<int64_t> o_row, batch_start, x2z, giant_start, cm_chunk_start;
     DevBuf<int32_t> cm_pt, cm_chunk_cam;
     DevBuf<double> cm_uv, cm_w;
-    int64_t n_cm_chunks = 0;
+    int64_t n_cm_chunks = 0, n_cm_chunks_all = 0;
     DevBuf<double> giant_W;
     int64_t ngiant = 0;
     int giant_threads = 256;            // DBAT_HIP_GIANT_THREADS (64/128/256): tests force several chunks per point
@@ -149,7 +149,7 @@ struct Core {
         d.ntiles = (int)ntiles; d.o_lc = o_lc.p; d.o_pidx = o_pidx.p;
         cm_pt.upload(P.cm_pt); cm_uv.upload(P.cm_uv); cm_w.upload(P.cm_w);
         cm_chunk_cam.upload(P.cm_chunk_cam); cm_chunk_start.upload(P.cm_chunk_start);
-        n_cm_chunks = (int64_t)P.cm_chunk_cam.size();
+        n_cm_chunks = P.n_cm_chunks_tiled; n_cm_chunks_all = (int64_t)P.cm_chunk_cam.size();
         ngiant = P.giant_start.empty() ? 0 : (int64_t)P.giant_start.size() - 1;
         if (ngiant > 0) {
             giant_start.upload(P.giant_start);
@@ -224,7 +224,7 @@ struct Core {
         tile2_pc = TILE2_PC;
         lds_tile2 = ((size_t)TILE2_NBUF * 3 * tile2_pc * TILE_LD + (size_t)256 * 9 + (size_t)128 * 15 + TILE_LD) * sizeof(double);
         use_tile2 = P.BT == 256 && P.ncolmax <= 14 && getenv("DBAT_HIP_TILE_V1") == nullptr;
-        partial.alloc((size_t)4 * std::max<int64_t>(std::max<int64_t>(nb + ntiles + ngiant, 2048), 1));
+        partial.alloc((size_t)4 * std::max<int64_t>(std::max<int64_t>(std::max<int64_t>(nb + ntiles + ngiant, n_cm_chunks_all), 2048), 1));
         set_lds_limits();
         HIPCHK(hipMemcpy(z.p, P.z0.data(), P.NZ * 8, hipMemcpyHostToDevice));
         HIPCHK(hipMemset(dz.p, 0, P.NZ * 8));
@@ -323,11 +323,21 @@ struct Core {
     double eval_f(const double *zz, double *r_w_out, double *r_unw_out) {
         prep_cams(zz);
         mark(6);
-#define L_RES(M, dummy) hipLaunchKernelGGL((k_residual<M>), dim3(grid_obs), dim3(256), 0, stream, d, zz, cams.p, partial.p, r_w_out, r_unw_out)
-        DISPATCH_MODEL(L_RES, 0)
-#undef L_RES
+        // the objective value always comes from the camera-major kernel (one summation order for
+        // every value the damping loops compare); the point-major one only when residuals are exported
+        int64_t npart_res = n_cm_chunks_all;
+        if (n_cm_chunks_all > 0) {
+#define L_RESCM(M, dummy) hipLaunchKernelGGL((k_residual_cm<M>), dim3((unsigned)n_cm_chunks_all), dim3(256), 0, stream, d, zz, cams.p, cm_pt.p, cm_uv.p, P.uniform_w ? (const double *)nullptr : cm_w.p, cm_chunk_cam.p, cm_chunk_start.p, partial.p)
+            DISPATCH_MODEL(L_RESCM, 0)
+#undef L_RESCM
+        }
         mark(7);
-        hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_obs, scal.p, 0);
+        hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(1024), 0, stream, partial.p, npart_res, scal.p, 0);
+        if (r_w_out || r_unw_out) {
+#define L_RES(M, dummy) hipLaunchKernelGGL((k_residual<M>), dim3(grid_obs), dim3(256), 0, stream, d, zz, cams.p, partial.p, r_w_out, r_unw_out)
+            DISPATCH_MODEL(L_RES, 0)
+#undef L_RES
+        }
         hipLaunchKernelGGL(k_prior_sq, dim3(grid_z), dim3(256), 0, stream, d, zz, partial.p);
         hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_z, scal.p, 1);
         do_allreduce(scal.p, 1);

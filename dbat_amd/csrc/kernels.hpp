@@ -140,6 +140,35 @@ __global__ __launch_bounds__(256) void k_residual(DevProblem d, const double *__
     if (threadIdx.x == 0) partial[blockIdx.x] = acc[0];
 }
 
+// Residual only, camera-major: one workgroup per chunk of one camera's observations (camera
+// record uniform, (u,v) and point index coalesced).  partial[blockIdx] = sum of squared
+// weighted residuals.  Used for every objective value the damping loops compare.
+template <int MODEL>
+__global__ __launch_bounds__(256) void k_residual_cm(DevProblem d, const double *__restrict__ z,
+                                                     const CamRec *__restrict__ cams,
+                                                     const int32_t *__restrict__ cm_pt,
+                                                     const double *__restrict__ cm_uv, const double *__restrict__ cm_w,
+                                                     const int32_t *__restrict__ chunk_cam,
+                                                     const int64_t *__restrict__ chunk_start,
+                                                     double *__restrict__ partial) {
+    __shared__ double sh[8];
+    const CamRec &C = cams[chunk_cam[blockIdx.x]];
+    const int64_t q0 = chunk_start[blockIdx.x], q1 = chunk_start[blockIdx.x + 1];
+    double acc[1] = {0.0};
+    for (int64_t q = q0 + threadIdx.x; q < q1; q += 256) {
+        const double *p = z + d.NS + 3 * (int64_t)cm_pt[q];
+        const double Q[3] = {p[0], p[1], p[2]};
+        double r[2];
+        double(*nil6)[6] = nullptr; double(*nil3)[3] = nullptr; double(*nilc)[MAXIO] = nullptr;
+        obs_eval<MODEL, false, false>(C, d.nK, d.nP, Q, cm_uv[2 * q], cm_uv[2 * q + 1], r, nil6, nil3, nilc);
+        const double w0 = cm_w ? cm_w[2 * q] : C.w[0], w1 = cm_w ? cm_w[2 * q + 1] : C.w[1];
+        r[0] *= w0; r[1] *= w1;
+        acc[0] += r[0] * r[0] + r[1] * r[1];
+    }
+    block_sum<1>(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc[0];
+}
+
 // prior-observation rows (prior_obs.m:26-43): sum over owned z of w*(z-prior)^2
 __global__ __launch_bounds__(256) void k_prior_sq(DevProblem d, const double *__restrict__ z,
                                                   double *__restrict__ partial) {

@@ -65,14 +65,16 @@ struct Plan {
     std::vector<int32_t> tile_cams;                // global camera ids, ascending inside a tile
     int CMAX = 0;                                  // 0 = no tiling (global atomics)
     int64_t nb_tiled = 0;                          // batches [0,nb_tiled) belong to tiles; the rest hold heavy points
-    // camera-major copy of the TILED observations (k_cam_normal: J_c'J_c, J_c'r per camera):
-    // chunks of one camera's observations, at most CM_CHUNK each
+    // camera-major copy of the observations, tiled ones first (k_cam_normal: J_c'J_c, J_c'r per
+    // camera over the tiled part; k_residual_cm over everything): chunks of one camera's
+    // observations, at most CM_CHUNK each
     static constexpr int CM_CHUNK = 2048;
     std::vector<int32_t> cm_pt;                    // object point
     std::vector<double> cm_uv;                     // 2 per observation
     std::vector<double> cm_w;                      // 2 per observation or empty if uniform
     std::vector<int32_t> cm_chunk_cam;             // camera of every chunk
     std::vector<int64_t> cm_chunk_start;           // [nchunks+1]
+    int64_t n_cm_chunks_tiled = 0;                 // chunks of tiled observations come first
     // "giant" points (more observations than a batch holds) come last, outside the batches
     std::vector<int64_t> giant_start;              // [ngiant+1] first observation of every giant point
     // self-calibration: the estimated IO columns of a tile's cameras are extra rows
@@ -576,28 +578,36 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         P.nb_tiled = (int64_t)P.batch_start.size() - 1;
     }
     if (!P.CMAX) P.nb_tiled = 0;
-    {   // camera-major copy of the tiled observations (stable counting sort by camera)
+    {   // camera-major copy of the observations (stable counting sort by camera): first the tiled
+        // ones (chunks [0, n_cm_chunks_tiled): k_cam_normal), then the rest (heavy / giant points);
+        // k_residual_cm runs over all chunks
         const int64_t ntiled = P.nb_tiled > 0 ? P.batch_start[P.nb_tiled] : 0;
-        std::vector<int64_t> cnt((size_t)nc + 1, 0);
-        for (int64_t o = 0; o < ntiled; ++o) ++cnt[(size_t)P.o_cam[o] + 1];
-        for (int c = 0; c < nc; ++c) cnt[c + 1] += cnt[c];
-        P.cm_pt.resize(ntiled); P.cm_uv.resize(2 * ntiled);
-        if (!P.uniform_w) P.cm_w.resize(2 * ntiled); else P.cm_w.clear();
-        std::vector<int64_t> fillc(cnt.begin(), cnt.end() - 1);
-        for (int64_t o = 0; o < ntiled; ++o) {
-            const int64_t q = fillc[P.o_cam[o]]++;
-            P.cm_pt[q] = P.o_pt[o];
-            P.cm_uv[2 * q] = P.o_uv[2 * o]; P.cm_uv[2 * q + 1] = P.o_uv[2 * o + 1];
-            if (!P.uniform_w) { P.cm_w[2 * q] = P.o_w[2 * o]; P.cm_w[2 * q + 1] = P.o_w[2 * o + 1]; }
-        }
+        const int64_t nall = (int64_t)P.o_cam.size();
+        P.cm_pt.resize(nall); P.cm_uv.resize(2 * nall);
+        if (!P.uniform_w) P.cm_w.resize(2 * nall); else P.cm_w.clear();
         P.cm_chunk_cam.clear(); P.cm_chunk_start.clear();
-        for (int c = 0; c < nc; ++c)
-            for (int64_t s0 = cnt[c]; s0 < cnt[c + 1]; s0 += Plan::CM_CHUNK) {
-                P.cm_chunk_cam.push_back(c); P.cm_chunk_start.push_back(s0);
+        auto part = [&](int64_t lo, int64_t hi) {
+            std::vector<int64_t> cnt((size_t)nc + 1, 0);
+            for (int64_t o = lo; o < hi; ++o) ++cnt[(size_t)P.o_cam[o] + 1];
+            for (int c = 0; c < nc; ++c) cnt[c + 1] += cnt[c];
+            std::vector<int64_t> fillc(cnt.begin(), cnt.end() - 1);
+            for (int64_t o = lo; o < hi; ++o) {
+                const int64_t q = lo + fillc[P.o_cam[o]]++;
+                P.cm_pt[q] = P.o_pt[o];
+                P.cm_uv[2 * q] = P.o_uv[2 * o]; P.cm_uv[2 * q + 1] = P.o_uv[2 * o + 1];
+                if (!P.uniform_w) { P.cm_w[2 * q] = P.o_w[2 * o]; P.cm_w[2 * q + 1] = P.o_w[2 * o + 1]; }
             }
-        P.cm_chunk_start.push_back(ntiled);
-        // a chunk ends where the next one starts or where its camera ends
-        // (cm_chunk_start is ascending; the kernel clips with the camera's end via the next start)
+            for (int c = 0; c < nc; ++c)
+                for (int64_t s0 = cnt[c]; s0 < cnt[c + 1]; s0 += Plan::CM_CHUNK) {
+                    P.cm_chunk_cam.push_back(c); P.cm_chunk_start.push_back(lo + s0);
+                }
+        };
+        part(0, ntiled);
+        P.n_cm_chunks_tiled = (int64_t)P.cm_chunk_cam.size();
+        part(ntiled, nall);
+        P.cm_chunk_start.push_back(nall);
+        // a chunk ends where the next one starts (same camera + CM_CHUNK, the next camera's first
+        // observation, or the end of its part)
     }
     if (getenv("DBAT_HIP_PLAN_STATS") && P.tile_batch.size() > 1) {      // tile size distribution
         std::vector<int> nbt;
