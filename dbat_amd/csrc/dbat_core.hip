@@ -68,7 +68,7 @@ struct Core {
     int tile2_pc = TILE2_PC;
     bool use_tile2 = true;
     DevBuf<int64_t> o_row, batch_start, x2z, giant_start, cm_chunk_start;
-    DevBuf<int32_t> cm_pt, cm_chunk_cam;
+    DevBuf<int32_t> cm_pt, cm_chunk_cam, tile_order;
     DevBuf<double> cm_uv, cm_w;
     int64_t n_cm_chunks = 0, n_cm_chunks_all = 0;
     DevBuf<double> giant_W;
@@ -147,6 +147,7 @@ struct Core {
         d.o_seg = o_seg.p; d.o_row = o_row.p; d.batch_start = batch_start.p;
         d.CMAX = P.CMAX; d.ablate = getenv("DBAT_HIP_ABLATE") ? atoi(getenv("DBAT_HIP_ABLATE")) : 0;
         d.ntiles = (int)ntiles; d.o_lc = o_lc.p; d.o_pidx = o_pidx.p;
+        tile_order.upload(P.tile_order); d.tile_order = tile_order.p;
         cm_pt.upload(P.cm_pt); cm_uv.upload(P.cm_uv); cm_w.upload(P.cm_w);
         cm_chunk_cam.upload(P.cm_chunk_cam); cm_chunk_start.upload(P.cm_chunk_start);
         n_cm_chunks = P.n_cm_chunks_tiled; n_cm_chunks_all = (int64_t)P.cm_chunk_cam.size();

@@ -48,6 +48,7 @@ struct DevProblem {
     int ablate;                     // profiling only (DBAT_HIP_ABLATE): bit0 skip MFMA, bit1 skip P3 atomics, bit2 skip eval
     const uint8_t *o_lc, *o_pidx;
     const int32_t *tile_batch, *tile_cam_start, *tile_cams;
+    const int32_t *tile_order;                      // launch index -> tile (longest first)
     const int32_t *tile_io_start, *tile_iocols;     // IO columns (IOu indices) of every tile
     const uint8_t *tile_cam_io;                     // [#tile cams][16] local IO row of a camera's j-th IO column
     // "giant" points: more observations than a batch holds; one workgroup per point
@@ -801,7 +802,7 @@ __global__ __launch_bounds__(256) void k_build_tile(DevProblem d, const double *
     __shared__ int npts_sh;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);        // scalar: keeps the tile choices out of EXEC
-    const int tile = blockIdx.x;
+    const int tile = d.tile_order[blockIdx.x];
     const int b0 = d.tile_batch[tile], b1 = d.tile_batch[tile + 1];
     const int c0 = d.tile_cam_start[tile];
     const int ncam = d.tile_cam_start[tile + 1] - c0;
@@ -1266,7 +1267,7 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
     const int wave8 = __builtin_amdgcn_readfirstlane(t >> 6);
     const bool producer = wave8 < 4;
     const int wave = wave8 & 3;
-    const int tile = blockIdx.x;
+    const int tile = d.tile_order[blockIdx.x];
     const int b0 = d.tile_batch[tile], b1 = d.tile_batch[tile + 1];
     const int c0 = d.tile_cam_start[tile];
     const int ncam = d.tile_cam_start[tile + 1] - c0;

@@ -62,6 +62,7 @@ struct Plan {
     std::vector<uint8_t> o_pidx;                   // ordinal of the observation's point inside its batch
     std::vector<int32_t> tile_batch;               // [ntiles+1] first batch of every tile
     std::vector<int32_t> tile_cam_start;           // [ntiles+1]
+    std::vector<int32_t> tile_order;               // launch order: longest tiles first (shorter tail)
     std::vector<int32_t> tile_cams;                // global camera ids, ascending inside a tile
     int CMAX = 0;                                  // 0 = no tiling (global atomics)
     int64_t nb_tiled = 0;                          // batches [0,nb_tiled) belong to tiles; the rest hold heavy points
@@ -578,6 +579,15 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         P.nb_tiled = (int64_t)P.batch_start.size() - 1;
     }
     if (!P.CMAX) P.nb_tiled = 0;
+    {   // launch the longest tiles first
+        const int nt = (int)P.tile_batch.size() - 1;
+        P.tile_order.resize(std::max(nt, 0));
+        std::iota(P.tile_order.begin(), P.tile_order.end(), 0);
+        std::stable_sort(P.tile_order.begin(), P.tile_order.end(), [&](int32_t a, int32_t b) {
+            return P.batch_start[P.tile_batch[a + 1]] - P.batch_start[P.tile_batch[a]] >
+                   P.batch_start[P.tile_batch[b + 1]] - P.batch_start[P.tile_batch[b]];
+        });
+    }
     {   // camera-major copy of the observations (stable counting sort by camera): first the tiled
         // ones (chunks [0, n_cm_chunks_tiled): k_cam_normal), then the rest (heavy / giant points);
         // k_residual_cm runs over all chunks
