@@ -480,7 +480,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     int32_t tile_id = 0;
     int pidx = 0;
     bool in_heavy = false;
-    const int tile_bmax = std::max(1, env_int0("DBAT_HIP_TILE_BMAX", 16));   // batches per tile
+    const int tile_bmax = std::max(1, env_int0("DBAT_HIP_TILE_BMAX", 48));   // batches per tile
     for (int64_t i = P.pt_lo; i < P.pt_hi; ++i) {
         const int32_t p = P.porder[i];
         const int k = k_pt[p];
