@@ -1300,7 +1300,8 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
         // observation header of the next batch and the object point of its observations are
         // fetched one batch ahead, so their HBM latency hides behind the current batch
         int hn_cam = 0, hn_pt = 0, hn_lc = 0, hn_pidx = 0; uint32_t hn_sg = 0; double hn_u = 0, hn_v = 0;
-        double qn[3] = {0, 0, 0}, pwn[3] = {0, 0, 0}; unsigned estn = 0;
+        double qn[3] = {0, 0, 0}, pwn[3] = {0, 0, 0};
+        unsigned estr0 = 0, estr1 = 0, estr2 = 0;   // raw flags: combining them here would wait for the loads
         auto fetch_header = [&](int bb) {
             if (bb >= b1) return;
             const int64_t oo0 = bstart(bb);
@@ -1315,7 +1316,7 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
             if (t < (int)(bstart(bb + 1) - bstart(bb))) {
                 const int64_t zp = d.NS + 3 * (int64_t)hn_pt;
                 qn[0] = z[zp]; qn[1] = z[zp + 1]; qn[2] = z[zp + 2];
-                estn = (d.z_est[zp] ? 1u : 0u) | (d.z_est[zp + 1] ? 2u : 0u) | (d.z_est[zp + 2] ? 4u : 0u);
+                estr0 = d.z_est[zp]; estr1 = d.z_est[zp + 1]; estr2 = d.z_est[zp + 2];
                 if (t == (int)(hn_sg & 0xFFFF)) { pwn[0] = d.z_prw[zp]; pwn[1] = d.z_prw[zp + 1]; pwn[2] = d.z_prw[zp + 2]; }
             }
         };
@@ -1341,7 +1342,7 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
             const double uu = hn_u, vv = hn_v;
             const double Q[3] = {qn[0], qn[1], qn[2]};
             const double pw3[3] = {pwn[0], pwn[1], pwn[2]};
-            const unsigned est = estn;
+            const unsigned est = (estr0 ? 1u : 0u) | (estr1 ? 2u : 0u) | (estr2 ? 4u : 0u);
             if (t == 0) *npts_sh = 0;
             fetch_header(b + 1);
             lap(9);
