@@ -1338,7 +1338,7 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
                 return a < 6 ? 6 * hn_lc_cur + a : iobase + (int)((ciop[(a - 6) >> 2] >> (8 * ((a - 6) & 3))) & 255u);
             };
             const int cam = hn_cam, pt = hn_pt, lc = hn_lc, pidx = hn_pidx;
-            const int seg_start = hn_sg & 0xFFFF, seg_len = hn_sg >> 16;
+            const int seg_start = hn_sg & 0xFFFF;
             const double uu = hn_u, vv = hn_v;
             const double Q[3] = {qn[0], qn[1], qn[2]};
             const double pw3[3] = {pwn[0], pwn[1], pwn[2]};
