@@ -358,7 +358,6 @@ struct Core {
             memcpy(&init[0], &big, 8); init[1] = 0; init[2] = init[0]; init[3] = 0;
             HIPCHK(hipMemcpyAsync(pivmm.p, init, sizeof(init), hipMemcpyHostToDevice, stream));
         }
-        mark(0);
         // tiled batches through the MFMA kernel, the remaining ("heavy point") batches
         // -- or all of them when tiling is off -- through k_build
         int64_t npart = 0;
@@ -373,27 +372,31 @@ struct Core {
                 if (tile_ncx == 6) { DISPATCH_MODEL(L_CAMN, 6) } else { DISPATCH_MODEL(L_CAMN, 14) }
             }
 #undef L_CAMN
+            mark(0);                                 // events around the tile kernel alone (bench roofline)
             if (use_tile2 && tile_ncx == 6) { DISPATCH_MODEL(L_TILE2, 6) }
             else if (use_tile2 && tile_ncx == 14) { DISPATCH_MODEL(L_TILE2, 14) }
             else if (tile_ncx == 6) { DISPATCH_MODEL(L_TILE, 6) }
             else if (tile_ncx == 14) { DISPATCH_MODEL(L_TILE, 14) }
             else { DISPATCH_MODEL(L_TILE, MAXCOL) }
+            mark(1);
 #undef L_TILE
 #undef L_TILE2
         }
+        const bool no_tiles = !(ntiles > 0 && nb_tiled > 0);
+        if (no_tiles) mark(0);                       // no tile kernel: the events bracket k_build instead
         if (nb > nb_tiled) {
 #define L_BUILD(M, IO) hipLaunchKernelGGL((k_build<M, IO>), dim3((unsigned)(nb - nb_tiled)), dim3(P.BT), lds_build, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p + npart, pivmm.p, (int)nb_tiled)
             if (P.with_io) { DISPATCH_MODEL(L_BUILD, true) } else { DISPATCH_MODEL(L_BUILD, false) }
 #undef L_BUILD
             npart += nb - nb_tiled;
         }
+        if (no_tiles) mark(1);
         if (ngiant > 0) {                            // points with more observations than a batch holds
 #define L_GIANT(M, IO) hipLaunchKernelGGL((k_build_giant<M, IO>), dim3((unsigned)ngiant), dim3(giant_threads), 0, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p + npart, pivmm.p)
             if (P.with_io) { DISPATCH_MODEL(L_GIANT, true) } else { DISPATCH_MODEL(L_GIANT, false) }
 #undef L_GIANT
             npart += ngiant;
         }
-        mark(1);
         if ((d.ablate & 32) && use_tile2) {          // phase profile of the wave-specialised tile kernel
             unsigned long long h[16];
             HIPCHK(hipStreamSynchronize(stream));

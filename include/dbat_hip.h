@@ -246,8 +246,9 @@ int  dbat_hip_owned_mask(const dbat_hip_handle *h, uint8_t *mask);
  * residual-only evaluation at the trial point.  x is not advanced, so every
  * step does identical work.  ms[8], from HIP events on the handle's stream:
  * phases { linearize+Schur build, factor+solve, back-substitution, trial
- * residual } then single kernels { k_build, potrf+potrs, k_backsub,
- * k_residual }. */
+ * residual } then single kernels { the tile kernel k_build_tile2 / k_build_tile
+ * alone (k_build when nothing is tiled), k_chol_df incl. the tile gather,
+ * k_backsub, k_residual_cm }. */
 int  dbat_hip_bench_step(dbat_hip_handle *h, double lambda, int32_t scale_columns, double *ms);
 /* load x into the handle (device resident) before bench steps */
 int  dbat_hip_set_x(dbat_hip_handle *h, const double *x);
