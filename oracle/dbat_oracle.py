@@ -1086,6 +1086,10 @@ def bundle(s, *args):
     dof = len(r) + p_extra - len(x)
     s0 = np.sqrt((r @ r) / dof)                                  # :483
     s.post.sigmas = s0 * np.asarray(s.IP.sigmas)
+    # sensor format updated by the estimated aspect (bundle.m:360-366)
+    aspect = np.ones((2, s.IO.val.shape[1])); aspect[0] = 1.0 + s.IO.val[3]
+    s.post.sensor = type(s.post)(imSize=np.array(s.IO.sensor.imSize, float), pxSize=s.IO.sensor.pxSize * aspect,
+                                  ssSize=s.IO.sensor.imSize * s.IO.sensor.pxSize * aspect)
     E.numObs, E.numParams, E.redundancy, E.s0 = len(r), len(x), dof, s0
     E.sigmas = s.post.sigmas
     E.x = x

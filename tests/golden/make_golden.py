@@ -8,6 +8,8 @@ Inputs copied verbatim (data files, not source):
   data/script/romabundledemo/prior/initial_eo.txt
 Expected values parsed from the reference's committed reports:
   data/dbat/dbatexports/camcal-dbatreport{,-model2..5}.txt
+  (camcal-dbatreport.txt is also kept whole for the line-by-line comparison of
+  dbat_amd.report's output, tests/test_oracle.py::test_report_lines)
 """
 import json
 import os
@@ -86,6 +88,8 @@ def main():
                 os.path.join(HERE, 'camcal-pmexport.txt'))
     shutil.copy(os.path.join(REF, 'ref/camcal-fixed.txt'),
                 os.path.join(HERE, 'camcal-fixed.txt'))
+    # the committed result file of camcaldemo itself (an output of the reference: data, not source)
+    shutil.copy(os.path.join(REF, 'dbatexports/camcal-dbatreport.txt'), os.path.join(HERE, 'camcal-dbatreport.txt'))
     exp = {'model3': parse_report(os.path.join(REF, 'dbatexports/camcal-dbatreport.txt'))}
     for m in (2, 4, 5):
         exp['model%d' % m] = parse_report(

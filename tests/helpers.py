@@ -87,6 +87,46 @@ def check_camcal_cov_against_report(s, CIO, CEO, COP, exp):
         assert close(np.sqrt(np.nanmax(var[c])), exp['OP_max_std'][c], 2), ('OP', c)
 
 
+def check_report_lines(lines, ref_path=os.path.join(GOLDEN, 'camcal-dbatreport.txt')):
+    """Every line of dbat_amd.report's output must occur, in order, in the
+    reference's committed result file -- verbatim, or with numbers that differ by
+    one unit in the last printed digit (the reference stops at convTol 1e-6) or by
+    a full turn (angles).  The iteration count and the first error depend on the
+    demo's initial values (EXIF + resection), which the fixture does not have.
+    Returns the number of verbatim matches."""
+    import re
+    ref = [l.rstrip() for l in open(ref_path).read().splitlines()]
+    num = re.compile(r'[-+]?\d+\.?\d*(?:[eE][-+]?\d+)?')
+    skel = lambda l: num.sub('#', l)
+
+    def close(a, b):
+        if a == b:
+            return True
+        fa, fb = float(a), float(b)
+        digits = len(re.sub(r'[eE].*$', '', b).replace('-', '').replace('+', '').replace('.', '').lstrip('0')) or 1
+        tol = 1.01 * 10.0 ** (np.floor(np.log10(abs(fb))) - digits + 1) if fb != 0 else 1e-12
+        return abs(fa - fb) <= tol or abs(abs(fa - fb) - 360.0) <= tol
+
+    pos, verbatim = 0, 0
+    for l in lines:
+        l = l.rstrip()
+        if 'Number of iterations:' in l or 'First error:' in l:
+            continue
+        hit = None
+        for q in range(pos, len(ref)):
+            if ref[q] == l:
+                hit = q; verbatim += 1
+                break
+            if skel(ref[q]) == skel(l):
+                na, nb = num.findall(l), num.findall(ref[q])
+                if len(na) == len(nb) and all(close(a, b) for a, b in zip(na, nb)):
+                    hit = q
+                    break
+        assert hit is not None, 'line not found in the reference report: %r' % l
+        pos = hit + 1
+    return verbatim
+
+
 # ---------------------------------------------------------------------------
 # seeded synthetic variants used by the parity tests
 # ---------------------------------------------------------------------------

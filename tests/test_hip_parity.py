@@ -646,3 +646,15 @@ def test_degenerate_but_valid_inputs(hip, case):
         res, ok, iters, s0, E = bundle(s, 'gna')
         ro, oko, ito, s0o, Eo = o.bundle(s, 'gna')
         assert E.code == Eo.code == -4
+
+
+def test_report_lines_hip(hip):
+    """The same report lines from the GPU result (bundle + bundle_cov on the device)."""
+    from dbat_amd import bundle, bundle_cov
+    from dbat_amd.report import bundle_result_lines
+    from helpers import check_report_lines
+    res, ok, iters, s0, E = bundle(camcal_struct(3), 'gna')
+    assert ok
+    CIO, CEO, COP = bundle_cov(res, E, 'CIO', 'CEO', 'COP')
+    lines = bundle_result_lines(res, E, CIO, CEO, COP)
+    assert check_report_lines(lines) >= len(lines) - 10

@@ -43,6 +43,18 @@ def test_camcal_posterior_covariance_known_answer(model):
     assert np.allclose(np.sqrt(np.diag(CXX)[src]), np.sqrt(CEO.diagonal()[res.bundle.deserial.EO.dest]))
 
 
+def test_report_lines():
+    """dbat_amd.report (numeric subset of bundle_result_file.m) on the oracle's camcal
+    result: line by line against the reference's committed result file."""
+    from helpers import check_report_lines
+    from dbat_amd.report import bundle_result_lines
+    res, ok, iters, s0, E = o.bundle(camcal_struct(3), 'gna')
+    CIO, CEO, COP = o.bundle_cov(res, E, 'CIO', 'CEO', 'COP')
+    lines = bundle_result_lines(res, E, CIO, CEO, COP)
+    assert len(lines) > 450
+    assert check_report_lines(lines) >= len(lines) - 10          # all but a handful verbatim
+
+
 @pytest.mark.parametrize('damping', ['lm', 'lmp', 'gm'])
 def test_camcal_known_answer_other_dampings(damping):
     exp = camcal_expected()['model3']
