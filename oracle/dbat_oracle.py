@@ -1088,8 +1088,9 @@ def bundle(s, *args):
     s.post.sigmas = s0 * np.asarray(s.IP.sigmas)
     # sensor format updated by the estimated aspect (bundle.m:360-366)
     aspect = np.ones((2, s.IO.val.shape[1])); aspect[0] = 1.0 + s.IO.val[3]
-    s.post.sensor = type(s.post)(imSize=np.array(s.IO.sensor.imSize, float), pxSize=s.IO.sensor.pxSize * aspect,
-                                  ssSize=s.IO.sensor.imSize * s.IO.sensor.pxSize * aspect)
+    if hasattr(s.IO.sensor, 'imSize'):               # structs built without image sizes have no format to update
+        s.post.sensor = type(s.post)(imSize=np.array(s.IO.sensor.imSize, float), pxSize=s.IO.sensor.pxSize * aspect,
+                                      ssSize=s.IO.sensor.imSize * s.IO.sensor.pxSize * aspect)
     E.numObs, E.numParams, E.redundancy, E.s0 = len(r), len(x), dof, s0
     E.sigmas = s.post.sigmas
     E.x = x
