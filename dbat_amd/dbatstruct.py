@@ -77,7 +77,7 @@ def make_struct(IO, EO, OP, ip_val, ip_cam, ip_pt, pxSize, *, ip_std=None,
     s.EO = NS(val=EO,
               struct=NS(block=(np.tile(np.arange(1, nc + 1), (6, 1))
                                if EOblock is None else np.array(EOblock, np.int64))))
-    s.OP = NS(val=OP)
+    s.OP = NS(val=OP, id=np.arange(1, OP.shape[1] + 1))      # prob2dbatstruct.m: OP.id
     s.IP = NS(val=ip_val, std=np.array(std, float),
               cam=np.asarray(ip_cam, np.int64).copy(),
               pt=np.asarray(ip_pt, np.int64).copy(),

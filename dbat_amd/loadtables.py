@@ -67,47 +67,8 @@ def struct_from_tables(io_col, sensor, imsz, eo_table, mark_table, mark_fmt='im,
     return s
 
 
-def _rot(ang):
-    so, co = np.sin(ang[0]), np.cos(ang[0])
-    sp, cp = np.sin(ang[1]), np.cos(ang[1])
-    sk, ck = np.sin(ang[2]), np.cos(ang[2])
-    R1 = np.array([[1, 0, 0], [0, co, -so], [0, so, co]])
-    R2 = np.array([[cp, 0, sp], [0, 1, 0], [-sp, 0, cp]])
-    R3 = np.array([[ck, -sk, 0], [sk, ck, 0], [0, 0, 1]])
-    return R1 @ R2 @ R3
-
-
 def forwintersect(s):
-    """Initial object points: least-squares intersection of the image rays
-    (lens-corrected with the current IO), photogrammetry/forwintersect.m:27-46."""
-    nK, nP = s.IO.model.nK, s.IO.model.nP
-    cam, pt = s.IP.cam, s.IP.pt
-    IO = s.IO.val[:, cam]
-    sz = s.IO.sensor.pxSize[0, cam]
-    x = np.stack([sz * s.IP.val[0] - IO[1], -sz * s.IP.val[1] - IO[2]])
-    a = np.stack([(1 + IO[3]) * x[0] + IO[4] * x[1], x[1]])
-    rho = np.sum(a * a, 0)
-    rs = np.zeros_like(rho)
-    pw = np.ones_like(rho)
-    for j in range(nK):
-        pw = pw * rho
-        rs = rs - IO[5 + j] * pw
-    l = a * (1 + rs)
-    if nP >= 2:
-        p1, p2 = -IO[5 + nK], -IO[6 + nK]
-        pTu = p1 * a[0] + p2 * a[1]
-        l = l + np.stack([p1 * rho + 2 * pTu * a[0], p2 * rho + 2 * pTu * a[1]])
-    # ray in the camera frame: lhs = -f X/Z = l  =>  X ~ [l; -f]
-    d_cam = np.stack([l[0], l[1], -IO[0]])
-    M = np.stack([_rot(s.EO.val[3:6, i]) for i in range(s.EO.val.shape[1])])     # (nc,3,3)
-    d = np.einsum('nij,jn->in', M[cam], d_cam)
-    d = d / np.linalg.norm(d, axis=0)
-    c = s.EO.val[:3, cam]
-    npnt = s.OP.val.shape[1]
-    A = np.zeros((npnt, 3, 3))
-    b = np.zeros((npnt, 3))
-    P = np.eye(3)[None] - np.einsum('in,jn->nij', d, d)                          # I - d d'
-    np.add.at(A, pt, P)
-    np.add.at(b, pt, np.einsum('nij,jn->ni', P, c))
-    s.OP.val = np.linalg.solve(A, b[:, :, None])[:, :, 0].T.copy()
-    return s
+    """Initial object points by forward intersection of every point
+    (photogrammetry/forwintersect.m:27-46); see dbat_amd.initial."""
+    from .initial import forwintersect as fwd
+    return fwd(s, 'all')

@@ -658,3 +658,29 @@ def test_report_lines_hip(hip):
     CIO, CEO, COP = bundle_cov(res, E, 'CIO', 'CEO', 'COP')
     lines = bundle_result_lines(res, E, CIO, CEO, COP)
     assert check_report_lines(lines) >= len(lines) - 10
+
+
+@pytest.mark.parametrize('damping', ['gna', 'lmp'])
+def test_camcal_demo_pipeline_hip(hip, damping):
+    """The whole demo/camcaldemo.m pipeline -- EXIF camera, 3-point resection,
+    forward intersection (dbat_amd.initial) -- then the bundle on the GPU.  From
+    these initial values the committed report also pins the path:
+    camcal-dbatreport.txt:39-43 '9 iterations', 'First error: 30873.9'."""
+    from dbat_amd import bundle, bundle_cov
+    from dbat_amd.report import bundle_result_lines
+    from helpers import camcal_demo_struct, check_report_lines
+    exp = camcal_expected()['model3']
+    s = camcal_demo_struct(3)
+    res, ok, iters, s0, E = bundle(s, damping)
+    ro, oko, ito, s0o, Eo = o.bundle(s, damping)
+    assert ok and oko and E.code == 0
+    check_history(E, Eo, iters, ito, damping)
+    assert relerr(E.x, Eo.x) < TOL_X
+    assert relerr(E.trace, Eo.trace) < 1e-6
+    check_camcal_against_report(res, s0, E, exp)
+    assert abs(E.res[0] / 30873.9 - 1) < 1e-5        # tests/test_initial.py: sixth digit is resection noise
+    if damping == 'gna':
+        assert iters == exp['iterations'] == 9
+        CIO, CEO, COP = bundle_cov(res, E, 'CIO', 'CEO', 'COP')
+        lines = bundle_result_lines(res, E, CIO, CEO, COP)
+        assert check_report_lines(lines, demo_x0=True) >= len(lines) - 10
