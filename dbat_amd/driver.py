@@ -2,7 +2,8 @@
 
 Mirrors `bundle/bundle.m:1-132` (argument conventions), `:156-192` (set-up),
 `:267-358` (dispatch on damping, result struct E, deserialise only if ok) and
-`:449-491` (residual scatter, sigma0).  All arithmetic of the path --
+`:449-491` (residual scatter, sigma0); the post-mortem of a rank-deficient
+design matrix (`:368-446`) is in dbat_amd.diagnose.  All arithmetic of the path --
 residuals, Jacobian blocks, normal equations, Schur solve, damping loops --
 runs in libdbat_hip.so through the C ABI of include/dbat_hip.h; nothing here
 computes them on the CPU.
@@ -14,7 +15,7 @@ import types
 
 import numpy as np
 
-from . import _hip
+from . import _hip, diagnose
 
 NS = types.SimpleNamespace
 
@@ -130,13 +131,11 @@ def bundle(s, *args, device=0, comm=None, store_trace=True):
             s.IO.val, s.OP.val = IO, OP
             s.EO.val = np.vstack([EO, s.EO.val[6:]]) if s.EO.val.shape[0] > 6 else EO
         # residuals at the last linearisation point (bundle.m:449-460)
-        if E.code == -4:
-            ru = np.full(h.m, np.nan)
-            rw = ru
-        else:
-            ru, rw = h.final_residuals()
-            if comm is not None and world > 1:
-                ru, rw = comm.allreduce_numpy(ru), comm.allreduce_numpy(rw)
+        # (code -4 stops after the first linearisation: the residual is that of x0,
+        # gauss_newton_armijo.m:112-142, and sigma0 below is computed from it)
+        ru, rw = h.final_residuals()
+        if comm is not None and world > 1:
+            ru, rw = comm.allreduce_numpy(ru), comm.allreduce_numpy(rw)
         no = s.IP.val.shape[1]
         s.post = getattr(s, 'post', NS())
         s.post.res = NS()
@@ -179,6 +178,18 @@ def bundle(s, *args, device=0, comm=None, store_trace=True):
         E.numObs, E.numParams, E.redundancy, E.s0 = h.m, h.n, dof, s0
         E.sigmas = s.post.sigmas
         E.x = x
+        # post-mortem of a rank-deficient design matrix (bundle.m:368-446)
+        maps = (IOix, EOix, OPix)
+        E.paramTypes = diagnose.param_types(s, maps, h.n)
+        E.weakness = NS(structural=None, numerical=NS(rank=h.n, deficiency=0))
+        if E.code == -2:
+            E.weakness.numerical = NS(rank=float('nan'), deficiency=float('nan'), suspectedParams=[])
+            if world == 1:
+                E.weakness.numerical = diagnose.numerical_weakness(
+                    diagnose.weighted_jacobian(h, s, x), E.paramTypes)
+        elif E.code == -4:
+            E.weakness.structural = diagnose.structural_weakness(s, maps, h.n, E.paramTypes)
+            E.weakness.numerical = NS(rank=float('nan'), deficiency=float('nan'))
         if o['doTrace']:
             for k, v in enumerate(rr):
                 print('%s: iteration %d, residual norm=%.6g' % (name, k, v))

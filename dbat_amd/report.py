@@ -21,6 +21,12 @@ import numpy as np
 _P = '   '          # one indentation level (bundle_result_file.m:34-40)
 
 
+def _g(x):
+    """MATLAB's %g: NaN and Inf are spelled with capitals."""
+    x = float(x)
+    return 'NaN' if np.isnan(x) else ('-Inf' if x < 0 else 'Inf') if np.isinf(x) else '%g' % x
+
+
 def _pretty(prefix, values, min_len=np.inf, max_len=-np.inf):
     """pretty_print (bundle_result_file.m:940-954): pad the names to a common width."""
     name_len = np.array([len(v[0]) for v in values])
@@ -28,29 +34,65 @@ def _pretty(prefix, values, min_len=np.inf, max_len=-np.inf):
     return ['%s%s%s%s' % (prefix, name, ' ' * max(int(width - len(name)), 0), text) for name, text in values]
 
 
-def bundle_result_lines(s, E, CIO, CEO, COP):
+def _problem_lines(E):
+    """'Problems and suggestions' (bundle_result_file.m:142-175,196-199): the rank
+    diagnosis of E.weakness and the failure line.  The count of processing
+    problems also covers correlation and significance tests, which are not
+    produced, so that one line is left out."""
     p, p2, p3, p4, p5, p6 = (_P * k for k in range(1, 7))
-    out = []
+    out = [p + 'Problems and suggestions:', p2 + 'Project Problems:']
+    w = getattr(E, 'weakness', None)
+    st = getattr(w, 'structural', None)
+    if st is None:
+        out.append(p3 + 'Structural rank: ok.')
+    else:
+        out.append(p3 + 'Structural rank: %d (deficiency: %d)' % (st.rank, st.deficiency))
+        out.append(p4 + 'DMPERM suggests the following parameters have problems:')
+        out += [p5 + str(name) for name in st.suspectedParams]
+    nu = getattr(w, 'numerical', None)
+    if nu is None or nu.deficiency == 0:
+        out.append(p3 + 'Numerical rank: ok.')
+    elif np.isnan(nu.rank):
+        out.append(p3 + 'Numerical rank: not tested.')
+    else:
+        out.append(p3 + 'Numerical rank: %d (deficiency: %d)' % (nu.rank, nu.deficiency))
+        out.append(p4 + 'Null-space suggest the following parameters are part of the problem:')
+        for i, sp in enumerate(nu.suspectedParams):
+            out.append(p5 + 'Vector %d (eigenvalue %g):' % (i + 1, nu.d[i]))
+            out += [p6 + '(%s, %.3g)' % (name, v) for name, v in zip(sp.params, sp.values)]
+    if int(E.code) != 0:
+        out.append(p3 + 'Bundle failed with code %d (see below for details).' % int(E.code))
+    return out
+
+
+def bundle_result_lines(s, E, CIO=None, CEO=None, COP=None):
+    """Report lines; without covariances (a failed bundle has none) the report
+    stops after the iteration summary."""
+    p, p2, p3, p4, p5, p6 = (_P * k for k in range(1, 7))
+    out = _problem_lines(E)
     nIO = int(np.count_nonzero(s.IO.struct.leading)) if hasattr(s.IO.struct, 'leading') else int(E.numParams - np.count_nonzero(s.bundle.est.EO) - np.count_nonzero(s.bundle.est.OP))
     nEO = int(np.count_nonzero(np.asarray(s.bundle.est.EO, bool)[:6]))
     nOP = int(np.count_nonzero(s.bundle.est.OP))
     n_prior = [int(np.count_nonzero(getattr(s.prior, nm).use)) for nm in ('IO', 'EO', 'OP')]
     nIP = 2 * s.IP.val.shape[1]
     # ---- Information from last bundle (bundle_result_file.m:179-237)
-    codes = {0: 'OK', -1: 'fail (code -1: too many iterations)', -2: 'fail (code -2: rank deficit)',
-             -3: 'fail (code -3: stepsize below threshold)', -4: 'fail (code -4: structural rank deficit)'}
+    codes = {0: 'OK', -1: 'fail (code -1: Too many iterations)', -2: 'fail (code -2: Normal matrix is singular)',
+             -3: 'fail (code -3: No step length found by the line search)',
+             -4: 'fail (code -4: Normal matrix is structurally rank deficient)'}           # :203-213
     out.append(p + 'Information from last bundle')
     out += _pretty(p2, [
         ('Status:', codes.get(int(E.code), 'fail (code %d: unknown code)' % int(E.code))),
-        ('Sigma0:', '%g' % E.s0),
-        ('Sigma0 (pixels):', '%g' % float(np.ravel(s.post.sigmas)[0])),
+        ('Sigma0:', _g(E.s0)),
+        ('Sigma0 (pixels):', _g(np.ravel(s.post.sigmas)[0])),
         ('Redundancy', '%d' % E.redundancy),
         ('Number of params:', '%d (%d IO, %d EO, %d OP)' % (E.numParams, nIO, nEO, nOP)),
         ('Number of observations:', '%d (%d IP, %d IO, %d EO, %d OP)' % (E.numObs, nIP, *n_prior))])
     # ---- Total error (:257-266)
     out.append(p2 + 'Total error:')
     out += _pretty(p3, [('Number of stages:', '1'), ('Number of iterations:', '%d' % E.usedIters),
-                        ('First error:', '%g' % E.res[0]), ('Last error:', '%g' % E.res[-1])])
+                        ('First error:', _g(E.res[0])), ('Last error:', _g(E.res[-1]))])
+    if CIO is None or CEO is None or COP is None:
+        return out
     # ---- Cameras (:293-440): value and deviation of every camera parameter
     out.append(p2 + 'Cameras:')
     nK, nP = int(s.IO.model.nK), int(s.IO.model.nP)
@@ -122,7 +164,7 @@ def bundle_result_lines(s, E, CIO, CEO, COP):
     return out
 
 
-def bundle_result_file(s, E, CIO, CEO, COP, path):
+def bundle_result_file(s, E, CIO=None, CEO=None, COP=None, path='report.txt'):
     lines = ['Damped Bundle Adjustment Toolbox result file (numeric subset, dbat_amd.report)']
     lines += bundle_result_lines(s, E, CIO, CEO, COP)
     with open(path, 'w') as fh:

@@ -449,6 +449,117 @@ def serialize(s):
     return x
 
 
+def paramtypes(s):
+    """Names of the elements of x: misc/buildparamtypes.m:52-128 scattered by
+    misc/serialize.m:20-25."""
+    nK, nP = s.IO.model.nK, s.IO.model.nP
+    io = ['cc', 'px', 'py', 'as', 'sk'] + ['K%d' % k for k in range(1, nK + 1)] + ['P%d' % k for k in range(1, nP + 1)]
+    nc = s.IO.val.shape[1]
+    blk = np.asarray(s.IO.struct.block)
+    IOt = []
+    for j in range(nc):                                      # :58-77
+        for i, b in enumerate(io):
+            if nc == 1 or np.unique(blk).size == 1:
+                IOt.append(b)
+            elif np.all(blk == blk[:1]):
+                IOt.append('%s-%d' % (b, j + 1))
+            else:
+                IOt.append('%s-%d(%d)' % (b, j + 1, blk[i, j]))
+    ne = s.EO.val.shape[1]
+    eid = np.asarray(getattr(s.EO, 'id', np.arange(1, ne + 1)))
+    ids = np.any(eid != np.arange(1, ne + 1))                # :85-96
+    EOt = []
+    for j in range(ne):
+        tail = '' if ne == 1 else ('-%d(%d)' % (j + 1, eid[j]) if ids else '-%d' % (j + 1))
+        EOt += [b + tail for b in ('EX', 'EY', 'EZ', 'om', 'ph', 'ka')] + [''] * (s.EO.val.shape[0] - 6)
+    npnt = s.OP.val.shape[1]
+    oid = np.asarray(getattr(s.OP, 'id', np.arange(1, npnt + 1)))
+    raw = np.asarray(getattr(s.OP, 'rawId', oid))
+    lab = getattr(s.OP, 'label', None)
+    ctrl = np.asarray(getattr(s.prior.OP, 'isCtrl', np.zeros(npnt, bool)), bool)
+    chk = np.asarray(getattr(s.prior.OP, 'isCheck', np.zeros(npnt, bool)), bool)
+    OPt = []
+    for j in range(npnt):                                    # :100-128
+        pre = 'H' if chk[j] else 'C' if ctrl[j] else 'O'
+        tail = ''
+        if npnt > 1:
+            tail = '-%d' % (j + 1)
+            if oid[j] != j + 1:
+                tail += '/%d' % oid[j]
+            if raw[j] != oid[j]:
+                tail += '/%d' % raw[j]
+            if lab is not None and lab[j]:
+                tail += '-' + lab[j]
+        OPt += [pre + c + tail for c in 'XYZ']
+    t = np.empty(s.bundle.serial.n, object)
+    for ser, names in ((s.bundle.serial.IO, IOt), (s.bundle.serial.EO, EOt), (s.bundle.serial.OP, OPt)):
+        t[ser.dest] = np.array(names, object)[ser.src]
+    return t
+
+
+def dmperm_cols(J):
+    """Row matched to each column by a maximum matching that takes the columns
+    in order (what dmperm(J) returns for a tall J, bundle.m:436); -1 = none.
+    Kuhn's algorithm, recursive, on the stored pattern of J."""
+    import sys
+    J = sp.csc_matrix(J)
+    m, n = J.shape
+    owner = np.full(m, -1)
+
+    def try_col(j, seen):
+        for i in J.indices[J.indptr[j]:J.indptr[j + 1]]:
+            if owner[i] < 0:
+                owner[i] = j
+                return True
+        for i in J.indices[J.indptr[j]:J.indptr[j + 1]]:
+            if i not in seen:
+                seen.add(i)
+                if try_col(owner[i], seen):
+                    owner[i] = j
+                    return True
+        return False
+    old = sys.getrecursionlimit()
+    sys.setrecursionlimit(max(old, 20000))
+    try:
+        for j in range(n):
+            try_col(j, set())
+    finally:
+        sys.setrecursionlimit(old)
+    p = np.full(n, -1)
+    p[owner[owner >= 0]] = np.flatnonzero(owner >= 0)
+    return p
+
+
+def weakness(code, final, types):
+    """bundle.m:372-446: post-mortem of codes -2 (numerical rank and null
+    space of the scaled normal matrix; one dense eigen-decomposition in place
+    of spnrank + eigs) and -4 (dmperm)."""
+    W = NS(structural=None, numerical=NS(rank=final.weighted.J.shape[1], deficiency=0))
+    J = final.weighted.J
+    n = J.shape[1]
+    if code == -2:
+        cn = np.sqrt(np.asarray(J.multiply(J).sum(0)).ravel())
+        Js = sp.csc_matrix(J) @ sp.diags(1.0 / np.where(cn == 0, 1.0, cn))
+        JTJ = (Js.T @ Js).toarray()
+        d, V = np.linalg.eigh(JTJ)
+        null = np.abs(d) <= n * np.finfo(float).eps * np.abs(d).max()
+        W.numerical = NS(rank=int(n - null.sum()), deficiency=int(null.sum()), suspectedParams=[])
+        k = np.flatnonzero(null)
+        k = k[np.argsort(np.abs(d[k]), kind='stable')]
+        W.numerical.V, W.numerical.d, W.numerical.trace = V[:, k], d[k], np.trace(JTJ)
+        for j in range(len(k)):                                  # :411-423
+            v = V[:, k[j]]
+            o = np.argsort(-np.abs(v), kind='stable')
+            o = o[np.abs(v[o]) > np.mean([np.sqrt(1 / n), np.abs(v[o[0]])])]
+            W.numerical.suspectedParams.append(NS(values=v[o], indices=o + 1, params=list(types[o])))
+    if code == -4:
+        p = dmperm_cols(J)
+        W.structural = NS(dmperm=p + 1, rank=int((p >= 0).sum()), deficiency=int((p < 0).sum()),
+                          suspectedParams=list(types[p < 0]))
+        W.numerical = NS(rank=np.nan, deficiency=np.nan)
+    return W
+
+
 def deserialize(s, x):
     """misc/deserialize.m:28-30.  Returns (IO, EO, OP) value arrays."""
     def put(val, des):
@@ -1092,6 +1203,8 @@ def bundle(s, *args):
         s.post.sensor = type(s.post)(imSize=np.array(s.IO.sensor.imSize, float), pxSize=s.IO.sensor.pxSize * aspect,
                                       ssSize=s.IO.sensor.imSize * s.IO.sensor.pxSize * aspect)
     E.numObs, E.numParams, E.redundancy, E.s0 = len(r), len(x), dof, s0
+    E.paramTypes = paramtypes(s)                                 # :162,368
+    E.weakness = weakness(code, final, E.paramTypes)             # :372-446
     E.sigmas = s.post.sigmas
     E.x = x
     return s, ok, iters, s0, E

@@ -6,7 +6,12 @@ Inputs copied verbatim (data files, not source):
   data/dbat/pmexports/camcal-pmexport.txt, data/dbat/ref/camcal-fixed.txt
   data/script/romabundledemo/measurements/markpts.txt (xz-compressed),
   data/script/romabundledemo/prior/initial_eo.txt
+  data/dbat/pmexports/camcal-pmexport-{1ray,missing-obs}.txt (xz-compressed):
+  the inputs of the failure-mode demos camcaldemo_1ray / _missing_obs
 Expected values parsed from the reference's committed reports:
+  data/dbat/dbatexports/camcal-dbatreport-{1ray,missing-obs,no-datum}.txt
+  (status code, structural / numerical rank, DMPERM's suspected parameters,
+  counts, sigma0, first error) -> camcal_failures_expected.json
   data/dbat/dbatexports/camcal-dbatreport{,-model2..5}.txt
   (camcal-dbatreport.txt is also kept whole for the line-by-line comparison of
   dbat_amd.report's output, tests/test_oracle.py::test_report_lines)
@@ -98,6 +103,48 @@ def main():
         json.dump(exp, fh, indent=1)
     print({k: (v['sigma0'], len(v['EO_report_deg'])) for k, v in exp.items()})
     roma()
+    failures()
+
+
+def parse_failure(path):
+    txt = open(path).read()
+    g = lambda pat: re.search(pat, txt)
+    out = {}
+    m = g(r'Structural rank: (\d+) \(deficiency: (\d+)\)')
+    out['structural'] = None if m is None else {'rank': int(m.group(1)), 'deficiency': int(m.group(2))}
+    if m:
+        blk = txt[txt.index('DMPERM suggests'):txt.index('Numerical rank')]
+        out['structural']['suspectedParams'] = [l.strip() for l in blk.splitlines()[1:] if l.strip()]
+    m = g(r'Numerical rank: (\d+) \(deficiency: (\d+)\)')
+    out['numerical'] = None if m is None else {'rank': int(m.group(1)), 'deficiency': int(m.group(2))}
+    out['numerical_not_tested'] = 'Numerical rank: not tested.' in txt
+    out['code'] = int(g(r'Status:\s+fail \(code (-\d+):').group(1))
+    out['status'] = g(r'Status:\s+(fail[^\n]*)').group(1).strip()
+    num = lambda pat: float(g(pat).group(1))
+    out['sigma0'] = num(r'Sigma0:\s+(\S+)')
+    out['redundancy'] = int(g(r'Redundancy\s+(\d+)').group(1))
+    out['numParams'] = int(g(r'Number of params:\s+(\d+)').group(1))
+    out['numObs'] = int(g(r'Number of observations:\s+(\d+)').group(1))
+    out['iterations'] = int(g(r'Number of iterations:\s+(\d+)').group(1))
+    out['firstError'] = num(r'First error:\s+(\S+)')
+    out['lastError'] = num(r'Last error:\s+(\S+)')
+    # the head of the report up to the timings, for the line-by-line check
+    out['head'] = txt[:txt.index('      Execution times')].splitlines()
+    return out
+
+
+def failures():
+    import lzma
+    exp = {}
+    for kind in ('1ray', 'missing-obs', 'no-datum'):
+        if kind != 'no-datum':
+            with open(os.path.join(REF, 'pmexports/camcal-pmexport-%s.txt' % kind), 'rb') as fi, \
+                    lzma.open(os.path.join(HERE, 'camcal-pmexport-%s.txt.xz' % kind), 'wb', preset=9) as fo:
+                fo.write(fi.read())
+        exp[kind] = parse_failure(os.path.join(REF, 'dbatexports/camcal-dbatreport-%s.txt' % kind))
+    with open(os.path.join(HERE, 'camcal_failures_expected.json'), 'w') as fh:
+        json.dump(exp, fh, indent=1)
+    print({k: (v['code'], v['structural'] and v['structural']['rank'], v['numerical'], v['sigma0']) for k, v in exp.items()})
 
 
 def roma():

@@ -9,11 +9,26 @@ from dbat_amd import loadpm as L
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
-def camcal_struct(model=3):
+def _golden_path(name):
+    """Path of a fixture; .xz fixtures are unpacked next to pytest's temp files."""
+    path = os.path.join(GOLDEN, name)
+    if os.path.exists(path):
+        return path
+    import lzma
+    import tempfile
+    out = os.path.join(tempfile.gettempdir(), 'dbat_amd_golden_' + name)
+    if not os.path.exists(out):
+        with lzma.open(path + '.xz', 'rb') as fi, open(out + '.part%d' % os.getpid(), 'wb') as fo:
+            fo.write(fi.read())
+        os.replace(out + '.part%d' % os.getpid(), out)
+    return out
+
+
+def camcal_struct(model=3, export='camcal-pmexport.txt', ctrl=True):
     """demo/camcaldemo.m:56-100 set-up, starting from PhotoModeler's own EO/OP
     instead of resect/forwintersect (the converged solution is x0-independent
     inside the basin)."""
-    prob = L.loadpm(os.path.join(GOLDEN, 'camcal-pmexport.txt'))
+    prob = L.loadpm(_golden_path(export))
     s = L.prob2dbatstruct(prob, distModel=model)
     s.IO.val[0, :] = 7.3                                   # setcamvals 'default',7.3
     s.IO.val[1:3, :] = 0.5 * np.diag([1, -1]) @ s.IO.sensor.ssSize
@@ -23,19 +38,57 @@ def camcal_struct(model=3):
     if model < 3:
         s.bundle.est.IO[3, :] = False
     s.bundle.est.EO[:] = True
+    if not ctrl:                                           # camcaldemo_no_datum.m:65
+        return s
     s.prior.OP.isCtrl = s.OP.id > 1000
     pts = L.loadcpt(os.path.join(GOLDEN, 'camcal-fixed.txt'))
     return L.setcpt(s, pts)
 
 
-def camcal_demo_struct(model=3):
+def camcal_failure_struct(kind):
+    """The failure-mode demos on their own inputs: camcaldemo_1ray.m (all but
+    one observation of OP 88 removed), camcaldemo_missing_obs.m (no observation
+    of OP 13 and 60) -- same pipeline as camcaldemo -- and camcaldemo_no_datum.m
+    (no control points, PhotoModeler's EO/OP as initial values)."""
+    if kind == 'no-datum':
+        return camcal_struct(3, ctrl=False)
+    return camcal_demo_struct(3, 'camcal-pmexport-%s.txt' % kind)
+
+
+def camcal_failures_expected():
+    with open(os.path.join(GOLDEN, 'camcal_failures_expected.json')) as fh:
+        return json.load(fh)
+
+
+def check_failure_against_report(ok, iters, s0, E, exp):
+    assert not ok and E.code == exp['code'] and iters == exp['iterations'] == 0
+    assert (E.numParams, E.numObs, E.redundancy) == (exp['numParams'], exp['numObs'], exp['redundancy'])
+    if np.isnan(exp['sigma0']):
+        assert np.isnan(s0) and np.isnan(E.res[0])
+    else:       # values at x0: 1e-5, see check_report_lines
+        assert abs(s0 / exp['sigma0'] - 1) < 1e-5 and abs(E.res[0] / exp['firstError'] - 1) < 1e-5
+    w = E.weakness
+    if exp['structural'] is None:
+        assert w.structural is None
+    else:
+        assert (w.structural.rank, w.structural.deficiency) == (exp['structural']['rank'], exp['structural']['deficiency'])
+        assert list(w.structural.suspectedParams) == exp['structural']['suspectedParams']
+        assert np.isnan(w.numerical.rank) and exp['numerical_not_tested']
+    if exp['numerical'] is not None:
+        assert (w.numerical.rank, w.numerical.deficiency) == (exp['numerical']['rank'], exp['numerical']['deficiency'])
+        assert len(w.numerical.suspectedParams) == exp['numerical']['deficiency']
+        # every null-space vector is one: J v = 0 to rounding, eigenvalues ~ eps
+        assert np.abs(w.numerical.d).max() < 1e-12
+
+
+def camcal_demo_struct(model=3, export='camcal-pmexport.txt'):
     """The whole demo/camcaldemo.m:56-107 set-up: EXIF camera, EO cleared and
     computed by 3-point resection from the four control points, free OP cleared
     and computed by forward intersection.  With these initial values the
     reference's committed report also pins the iteration count and the first
     residual norm."""
     from dbat_amd import initial as I
-    s = I.clearop(I.cleareo(camcal_struct(model)))
+    s = I.clearop(I.cleareo(camcal_struct(model, export)))
     assert np.isnan(s.EO.val).all() and np.isnan(s.OP.val[:, ~s.prior.OP.isCtrl]).all()
     cpId = s.OP.id[s.prior.OP.isCtrl]
     s1, rms, fail = I.resect(s, 'all', cpId, 1, 0, cpId)
@@ -102,7 +155,8 @@ def check_camcal_cov_against_report(s, CIO, CEO, COP, exp):
         assert close(np.sqrt(np.nanmax(var[c])), exp['OP_max_std'][c], 2), ('OP', c)
 
 
-def check_report_lines(lines, ref_path=os.path.join(GOLDEN, 'camcal-dbatreport.txt'), demo_x0=False):
+def check_report_lines(lines, ref_path=os.path.join(GOLDEN, 'camcal-dbatreport.txt'), demo_x0=False,
+                       ref_lines=None, x0_lines=('First error:',)):
     """Every line of dbat_amd.report's output must occur, in order, in the
     reference's committed result file -- verbatim, or with numbers that differ by
     one unit in the last printed digit (the reference stops at convTol 1e-6) or by
@@ -113,7 +167,7 @@ def check_report_lines(lines, ref_path=os.path.join(GOLDEN, 'camcal-dbatreport.t
     the sixth digit (tests/test_oracle.py::test_resect_first_error_conditioning).
     Returns the number of verbatim matches."""
     import re
-    ref = [l.rstrip() for l in open(ref_path).read().splitlines()]
+    ref = [l.rstrip() for l in (ref_lines if ref_lines is not None else open(ref_path).read().splitlines())]
     num = re.compile(r'[-+]?\d+\.?\d*(?:[eE][-+]?\d+)?')
     skel = lambda l: num.sub('#', l)
 
@@ -130,9 +184,11 @@ def check_report_lines(lines, ref_path=os.path.join(GOLDEN, 'camcal-dbatreport.t
         l = l.rstrip()
         if ('Number of iterations:' in l or 'First error:' in l) and not demo_x0:
             continue
-        if 'First error:' in l:
-            want = [float(num.findall(r)[0]) for r in ref if 'First error:' in r][0]
-            assert abs(float(num.findall(l)[0]) / want - 1) < 1e-5, (l, want)
+        key = [k for k in x0_lines if l.strip().startswith(k)]
+        if key and 'nan' not in l.lower():
+            # values at the resected x0 (a failed bundle's sigma0 and last error are such values too)
+            want = [float(num.findall(r)[-1]) for r in ref if r.strip().startswith(key[0])][0]
+            assert abs(float(num.findall(l)[-1]) / want - 1) < 1e-5, (l, want)
             continue
         hit = None
         for q in range(pos, len(ref)):

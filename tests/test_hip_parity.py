@@ -660,8 +660,8 @@ def test_report_lines_hip(hip):
     assert check_report_lines(lines) >= len(lines) - 10
 
 
-@pytest.mark.parametrize('damping', ['gna', 'lmp'])
-def test_camcal_demo_pipeline_hip(hip, damping):
+@pytest.mark.parametrize('model,damping', [(3, 'gna'), (3, 'lmp'), (2, 'gna'), (4, 'gna'), (5, 'gna')])
+def test_camcal_demo_pipeline_hip(hip, model, damping):
     """The whole demo/camcaldemo.m pipeline -- EXIF camera, 3-point resection,
     forward intersection (dbat_amd.initial) -- then the bundle on the GPU.  From
     these initial values the committed report also pins the path:
@@ -669,8 +669,8 @@ def test_camcal_demo_pipeline_hip(hip, damping):
     from dbat_amd import bundle, bundle_cov
     from dbat_amd.report import bundle_result_lines
     from helpers import camcal_demo_struct, check_report_lines
-    exp = camcal_expected()['model3']
-    s = camcal_demo_struct(3)
+    exp = camcal_expected()['model%d' % model]
+    s = camcal_demo_struct(model)
     res, ok, iters, s0, E = bundle(s, damping)
     ro, oko, ito, s0o, Eo = o.bundle(s, damping)
     assert ok and oko and E.code == 0
@@ -681,6 +681,32 @@ def test_camcal_demo_pipeline_hip(hip, damping):
     assert abs(E.res[0] / 30873.9 - 1) < 1e-5        # tests/test_initial.py: sixth digit is resection noise
     if damping == 'gna':
         assert iters == exp['iterations'] == 9
+    if damping == 'gna' and model == 3:
         CIO, CEO, COP = bundle_cov(res, E, 'CIO', 'CEO', 'COP')
         lines = bundle_result_lines(res, E, CIO, CEO, COP)
         assert check_report_lines(lines, demo_x0=True) >= len(lines) - 10
+
+
+@pytest.mark.parametrize('kind', ['1ray', 'missing-obs', 'no-datum'])
+def test_camcal_failure_demos_hip(hip, kind):
+    """The failure-mode demos through bundle() on the GPU against their committed
+    reports (camcal-dbatreport-{1ray,missing-obs,no-datum}.txt): code -4 with the
+    structural rank and DMPERM's suspected parameters, code -2 with the
+    numerical rank; sigma0 and the error at x0; the report's head line by line."""
+    from dbat_amd import bundle
+    from dbat_amd.report import bundle_result_lines
+    from helpers import (camcal_failure_struct, camcal_failures_expected, check_failure_against_report,
+                         check_report_lines)
+    exp = camcal_failures_expected()[kind]
+    s = camcal_failure_struct(kind)
+    res, ok, iters, s0, E = bundle(s, 'gna')
+    check_failure_against_report(ok, iters, s0, E, exp)
+    ro, oko, ito, s0o, Eo = o.bundle(s, 'gna')
+    assert E.code == Eo.code and list(E.paramTypes) == list(Eo.paramTypes)
+    if kind != '1ray':                                # 1ray: x0 holds NaN (a one-ray point cannot be intersected)
+        assert relerr(E.res, Eo.res) < 1e-10 and abs(s0 / s0o - 1) < 1e-10
+        assert relerr(res.post.res.IP, ro.post.res.IP) < 1e-9
+    assert np.array_equal(res.EO.val, s.EO.val, equal_nan=True)       # not updated (bundle.m:356-358)
+    lines = [l for l in bundle_result_lines(res, E) if not l.strip().startswith(('Vector', '('))]
+    check_report_lines(lines, ref_lines=exp['head'], demo_x0=True,
+                       x0_lines=('First error:', 'Last error:', 'Sigma0:', 'Sigma0 (pixels):'))

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import dbat_oracle as o
-from helpers import (camcal_struct, camcal_expected, check_camcal_against_report, roma_struct,
+from helpers import (check_failure_against_report, camcal_struct, camcal_expected, check_camcal_against_report, roma_struct,
                      roma_expected, check_roma_against_result)
 
 
@@ -53,6 +53,24 @@ def test_report_lines():
     lines = bundle_result_lines(res, E, CIO, CEO, COP)
     assert len(lines) > 450
     assert check_report_lines(lines) >= len(lines) - 10          # all but a handful verbatim
+
+
+@pytest.mark.parametrize('kind', ['1ray', 'missing-obs', 'no-datum'])
+def test_camcal_failure_demos_known_answer(kind):
+    """camcaldemo_1ray / _missing_obs / _no_datum against their committed reports
+    (camcal-dbatreport-{1ray,missing-obs,no-datum}.txt:7-50): status code,
+    structural rank with DMPERM's suspected parameters, numerical rank, counts,
+    sigma0 and error at x0."""
+    from helpers import camcal_failure_struct, camcal_failures_expected, check_report_lines
+    from dbat_amd.report import bundle_result_lines
+    exp = camcal_failures_expected()[kind]
+    res, ok, iters, s0, E = o.bundle(camcal_failure_struct(kind), 'gna')
+    check_failure_against_report(ok, iters, s0, E, exp)
+    lines = bundle_result_lines(res, E)
+    assert any(exp['status'] in l for l in lines)
+    lines = [l for l in lines if not l.strip().startswith(('Vector', '('))]     # null-space basis is not unique
+    check_report_lines(lines, ref_lines=exp['head'], demo_x0=True,
+                       x0_lines=('First error:', 'Last error:', 'Sigma0:', 'Sigma0 (pixels):'))
 
 
 @pytest.mark.parametrize('damping', ['lm', 'lmp', 'gm'])
