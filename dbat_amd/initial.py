@@ -211,7 +211,12 @@ def resect(s0, cams='all', cpId=None, n=1, v=0.0, chkId=None):
                 best, bestP = res.min(), P
         rms[k] = best
         if bestP is not None:
-            s.EO.val[:3, ci] = -bestP[:, :3].T @ bestP[:, 3]      # euclidean(null(P))
+            # euclidean(null(P)), through the SVD as the reference does it: with
+            # project coordinates of 1e6 m this carries |C|^2*eps ~ 1e-4 m of rounding
+            # noise that -R'*t would not, and the reference's committed first
+            # errors (data/script/sxb/result/report.txt:42) include it
+            nv = np.linalg.svd(bestP)[2][-1]
+            s.EO.val[:3, ci] = nv[:3] / nv[3]
             s.EO.val[3:6, ci] = derotmat3d(bestP[:, :3])
         else:
             fail = True

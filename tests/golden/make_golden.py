@@ -104,6 +104,7 @@ def main():
     print({k: (v['sigma0'], len(v['EO_report_deg'])) for k, v in exp.items()})
     roma()
     failures()
+    sxb()
 
 
 def parse_failure(path):
@@ -145,6 +146,34 @@ def failures():
     with open(os.path.join(HERE, 'camcal_failures_expected.json'), 'w') as fh:
         json.dump(exp, fh, indent=1)
     print({k: (v['code'], v['structural'] and v['structural']['rank'], v['numerical'], v['sigma0']) for k, v in exp.items()})
+
+
+def sxb():
+    """Script inputs of data/script/sxb (5 aerial images, 16 control/check
+    points with prior standard deviations, 381 OP, project coordinates of
+    1e6 m, two image-point files with different standard deviations) and its
+    committed result file."""
+    R = '/root/reference/data/script/sxb'
+    for src, dst in (('measurements/markpts.txt', 'sxb-markpts.txt'), ('measurements/smartpts.txt', 'sxb-smartpts.txt'),
+                     ('reference/sxb-control.txt', 'sxb-control.txt'), ('result/report.txt', 'sxb-report.txt')):
+        shutil.copy(os.path.join(R, src), os.path.join(HERE, dst))
+        os.chmod(os.path.join(HERE, dst), 0o644)
+    rep = parse_report(os.path.join(R, 'result/report.txt'))
+    txt = open(os.path.join(R, 'result/report.txt')).read()
+    rep['firstError'] = float(re.search(r'First error:\s+([-\d.eE+]+)', txt).group(1))
+    rep['sigma0_px'] = float(re.search(r'Sigma0 \(pixels\):\s+([-\d.eE+]+)', txt).group(1))
+    xml = open(os.path.join(R, 'sxb.xml')).read()
+    tag = lambda t_: re.search(r'<%s>([^<]*)</%s>' % (t_, t_), xml).group(1)
+    nums = lambda v: [float(x) for x in v.split(',')]
+    exp = {'camera': {'sensor': nums(tag('sensor')), 'image': nums(tag('image')), 'cc': float(tag('cc')),
+                      'pp': nums(tag('pp')), 'K': nums(tag('K')), 'P': nums(tag('P')), 'model': int(tag('model'))},
+           'check_ids': [351, 410], 'sxy': {'markpts': 0.5, 'smartpts': 1.0},
+           'images': [int(l.split(',')[0]) for l in open(os.path.join(R, 'images/images.txt')) if l[0] != '#'],
+           'image_paths': [l.split(',')[1].strip() for l in open(os.path.join(R, 'images/images.txt')) if l[0] != '#'],
+           'report': rep}
+    with open(os.path.join(HERE, 'sxb_expected.json'), 'w') as fh:
+        json.dump(exp, fh, indent=1)
+    print('sxb', rep['sigma0'], rep['numParams'], rep['numObs'], rep['iterations'], rep['firstError'], rep['lastError'])
 
 
 def roma():

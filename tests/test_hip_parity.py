@@ -710,3 +710,36 @@ def test_camcal_failure_demos_hip(hip, kind):
     lines = [l for l in bundle_result_lines(res, E) if not l.strip().startswith(('Vector', '('))]
     check_report_lines(lines, ref_lines=exp['head'], demo_x0=True,
                        x0_lines=('First error:', 'Last error:', 'Sigma0:', 'Sigma0 (pixels):'))
+
+
+def test_sxb_script_known_answer_hip(hip):
+    """data/script/sxb through bundle() and bundle_cov() on the GPU: weighted
+    prior observations of control points, two image-point standard deviations,
+    project coordinates of 1e6 m (the f64 path has no head-room to lose there).
+    Known answers of result/report.txt, and the oracle's iteration history."""
+    import os
+    from dbat_amd import bundle, bundle_cov
+    from dbat_amd.report import bundle_result_lines
+    from helpers import (sxb_struct, sxb_expected, check_sxb_against_report, check_camcal_cov_against_report,
+                         check_report_lines, GOLDEN)
+    exp = sxb_expected()
+    s = sxb_struct()
+    res, ok, iters, s0, E = bundle(s, 'gna')
+    assert ok and E.code == 0
+    check_sxb_against_report(res, s0, E, iters, exp)
+    ro, oko, ito, s0o, Eo = o.bundle(s, 'gna')
+    check_history(E, Eo, iters, ito, 'gna')
+    assert relerr(E.x, Eo.x) < 1e-12                  # |x| ~ 1e6: 1e-12 relative = 1e-6 m
+    assert np.abs(E.x - Eo.x).max() < 1e-5
+    assert abs(s0 - s0o) < 1e-9 * s0o
+    assert relerr(res.post.res.OP[res.prior.OP.use], ro.post.res.OP[ro.prior.OP.use]) < 1e-6
+    CIO, CEO, COP = bundle_cov(res, E, 'CIO', 'CEO', 'COP')
+    check_camcal_cov_against_report(res, CIO, CEO, COP, exp['report'])
+    Co = o.bundle_cov(ro, Eo, 'CEO', 'COP')
+    assert relerr(CEO.toarray() if hasattr(CEO, 'toarray') else CEO, Co[0].toarray() if hasattr(Co[0], 'toarray') else Co[0]) < 1e-5
+    lines = bundle_result_lines(res, E, CIO, CEO, COP)
+    n = check_report_lines(lines, ref_path=os.path.join(GOLDEN, 'sxb-report.txt'), demo_x0=True, x0_tol=1e-4)
+    assert n >= len(lines) - 3
+    for damping in ('lm', 'lmp'):
+        r2, ok2, it2, s02, E2 = bundle(s, damping)
+        assert ok2 and abs(s02 / s0 - 1) < 1e-7

@@ -55,6 +55,28 @@ def test_report_lines():
     assert check_report_lines(lines) >= len(lines) - 10          # all but a handful verbatim
 
 
+def test_sxb_script_known_answer():
+    """data/script/sxb: control points as weighted prior observations, check
+    points, two image-point standard deviations, fixed camera, coordinates of
+    1e6 m; resection + forward intersection + GNA.  result/report.txt: sigma0
+    1.1786 (0.589299 px), 1173 params, 2434 obs (42 OP priors), 4 iterations,
+    61.0904 -> 41.8527, every EO value and deviation, point precision."""
+    from helpers import (sxb_struct, sxb_expected, check_sxb_against_report, check_camcal_cov_against_report,
+                         check_report_lines, GOLDEN)
+    from dbat_amd.report import bundle_result_lines
+    import os
+    exp = sxb_expected()
+    res, ok, iters, s0, E = o.bundle(sxb_struct(), 'gna')
+    assert ok
+    check_sxb_against_report(res, s0, E, iters, exp)
+    assert np.count_nonzero(res.prior.OP.use) == 42 and list(res.IP.sigmas) == [0.5, 1.0]
+    CIO, CEO, COP = o.bundle_cov(res, E, 'CIO', 'CEO', 'COP')
+    check_camcal_cov_against_report(res, CIO, CEO, COP, exp['report'])
+    lines = bundle_result_lines(res, E, CIO, CEO, COP)
+    n = check_report_lines(lines, ref_path=os.path.join(GOLDEN, 'sxb-report.txt'), demo_x0=True, x0_tol=1e-4)
+    assert len(lines) >= 160 and n >= len(lines) - 3
+
+
 @pytest.mark.parametrize('kind', ['1ray', 'missing-obs', 'no-datum'])
 def test_camcal_failure_demos_known_answer(kind):
     """camcaldemo_1ray / _missing_obs / _no_datum against their committed reports
