@@ -324,6 +324,56 @@ def check_sxb_against_report(res, s0, E, iters, exp):
     assert np.abs(res.EO.val[:3].T - eo[:, 3:]).max() < 2e-6          # metres, at 1e6 m
 
 
+def roma_demo_struct(variant):
+    """demo/romabundledemo{,_selfcal,_imagevariant}.m:57-84: PhotoModeler's
+    camera (printed in roma-dbatreport.txt:58-92: 36.036 x 24 mm format as an
+    off-unit aspect of 0.000998889 on square 24/3744 mm pixels), fixed or
+    self-calibrated without skew, or with one principal point per image; OP by
+    forward intersection, datum by dependency on camera 1.  The image points
+    are those of the script fixture (same 181 122 observations)."""
+    from dbat_amd import loadtables as T
+    from dbat_amd.dbatstruct import seteoest_depend
+    cam = roma_variants_expected()['fixed']['IO_report']
+    eo = T.load_table(os.path.join(GOLDEN, 'roma-initial_eo.txt'))
+    mk = T.load_table(os.path.join(GOLDEN, 'roma-markpts.txt.xz'))
+    io = T.camera_io(cam['cc'], (cam['px'], cam['py']), [cam['K1'], cam['K2'], cam['K3']], [cam['P1'], cam['P2']],
+                     aspect=1.0 - cam['as'])
+    s = T.struct_from_tables(io, (36.0, 24.0), (5616, 3744), eo, mk, 'im,id,x,y', 1.0, distModel=3)
+    s = T.forwintersect(s)
+    if variant != 'fixed':
+        s.bundle.est.IO[:] = True                              # setcamest 'all','not','sk'
+        s.bundle.est.IO[4] = False
+    if variant == 'imagevariant':                              # romabundledemo_imagevariant.m:63
+        s.IO.struct.block[1:3] = np.arange(1, s.EO.val.shape[1] + 1)[None, :]
+    return seteoest_depend(s, 0)
+
+
+def roma_variants_expected():
+    with open(os.path.join(GOLDEN, 'roma_variants_expected.json')) as fh:
+        return json.load(fh)
+
+
+def check_roma_variant(res, s0, E, exp, CIO=None):
+    """sigma0, counts, and -- when estimated -- the camera values (and their
+    posterior deviations) of roma-dbatreport{,-selfcal,-imagevariant}.txt, six
+    (three) significant digits; report signs as bundle_result_file.m:357-358."""
+    close = lambda a, b, d: abs(a - b) <= 1.01 * 10.0 ** (np.floor(np.log10(abs(b))) - d + 1) if b else abs(a) < 1e-12
+    assert (E.numParams, E.numObs, E.redundancy) == (exp['numParams'], exp['numObs'], exp['redundancy'])
+    assert close(s0, exp['sigma0'], 6), (s0, exp['sigma0'])
+    io = res.IO.val[:, 0]
+    got = {'cc': io[0], 'px': io[1], 'py': -io[2], 'as': io[3], 'K1': -io[5], 'K2': -io[6], 'K3': -io[7],
+           'P1': -io[8], 'P2': -io[9]}
+    for k, v in exp['IO_report'].items():
+        assert close(got[k], v, 6), (k, got[k], v)
+    if CIO is not None:
+        sd = np.sqrt(CIO.diagonal()).reshape(res.IO.val.shape, order='F')[:, 0]
+        gsd = {'cc': sd[0], 'px': sd[1], 'py': sd[2], 'as': sd[3], 'K1': sd[5], 'K2': sd[6], 'K3': sd[7],
+               'P1': sd[8], 'P2': sd[9]}
+        assert len(exp['IO_deviation']) >= 8
+        for k, v in exp['IO_deviation'].items():
+            assert abs(gsd[k] - v) <= 0.52 * 10.0 ** (np.floor(np.log10(abs(v))) - 2), ('dev', k, gsd[k], v)
+
+
 def roma_expected():
     with open(os.path.join(GOLDEN, 'roma_expected.json')) as fh:
         return json.load(fh)

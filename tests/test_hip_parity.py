@@ -743,3 +743,25 @@ def test_sxb_script_known_answer_hip(hip):
     for damping in ('lm', 'lmp'):
         r2, ok2, it2, s02, E2 = bundle(s, damping)
         assert ok2 and abs(s02 / s0 - 1) < 1e-7
+
+
+@pytest.mark.parametrize('variant', ['fixed', 'selfcal', 'imagevariant'])
+def test_roma_demo_variants_known_answer_hip(hip, variant):
+    """demo/romabundledemo{,_selfcal,_imagevariant}.m on the GPU against their
+    committed reports (roma-dbatreport*.txt): sigma0 0.623075 / 0.566548 /
+    0.502538, parameter counts, and for the self-calibrating runs all nine
+    camera values with their posterior deviations (60 cameras, 26 321 points,
+    aspect estimated; image-variant: one principal point per image)."""
+    from dbat_amd import bundle, bundle_cov
+    from helpers import roma_demo_struct, roma_variants_expected, check_roma_variant
+    exp = roma_variants_expected()[variant]
+    s = roma_demo_struct(variant)
+    res, ok, iters, s0, E = bundle(s, 'gna')
+    assert ok and E.code == 0
+    CIO = bundle_cov(res, E, 'CIO') if variant != 'fixed' else None
+    check_roma_variant(res, s0, E, exp, CIO)
+    if variant == 'imagevariant':
+        assert len(np.unique(np.round(res.IO.val[1], 9))) == 60 and len(np.unique(res.IO.val[0])) == 1
+    for damping in ('lm', 'lmp'):                    # same minimum from the other damping schemes
+        r2, ok2, it2, s02, E2 = bundle(s, damping)
+        assert ok2 and abs(s02 / s0 - 1) < 1e-6

@@ -55,6 +55,17 @@ def test_report_lines():
     assert check_report_lines(lines) >= len(lines) - 10          # all but a handful verbatim
 
 
+def test_roma_demo_fixed_camera_known_answer():
+    """demo/romabundledemo.m with PhotoModeler's fixed camera (non-zero aspect):
+    roma-dbatreport.txt:20-24 sigma0 0.623075, 79 316 params, redundancy 101 806.
+    (The self-calibration and image-variant reports are checked on the GPU,
+    tests/test_hip_parity.py; the oracle needs over a minute for each.)"""
+    from helpers import roma_demo_struct, roma_variants_expected, check_roma_variant
+    res, ok, iters, s0, E = o.bundle(roma_demo_struct('fixed'), 'gna')
+    assert ok
+    check_roma_variant(res, s0, E, roma_variants_expected()['fixed'])
+
+
 def test_sxb_script_known_answer():
     """data/script/sxb: control points as weighted prior observations, check
     points, two image-point standard deviations, fixed camera, coordinates of
