@@ -77,6 +77,7 @@ SYMBOLS = {
     'dbat_hip_abi_version': (C.c_int, []),
     'dbat_hip_default_options': (C.c_int, [C.c_int32, C.POINTER(Options)]),
     'dbat_hip_plan': (C.c_int, [C.POINTER(Problem)] + [C.POINTER(C.c_int64)] * 7),
+    'dbat_hip_plan_structural_rank_ok': (C.c_int, [C.POINTER(Problem), C.POINTER(C.c_int32)]),
     'dbat_hip_plan_point_owner': (C.c_int, [C.POINTER(Problem), _ip]),
     'dbat_hip_plan_serialize': (C.c_int, [C.POINTER(Problem), _dp]),
     'dbat_hip_create': (C.c_int, [C.POINTER(Problem), C.POINTER(_H)]),
@@ -382,6 +383,15 @@ def plan(s, shard_rank=0, shard_count=1):
     check(lib.dbat_hip_plan(C.byref(p), *[C.byref(a) for a in v]))
     keys = ('n', 'm', 'nIO', 'nEO', 'nOP', 'pt_lo', 'pt_hi')
     return dict(zip(keys, [a.value for a in v]))
+
+
+def plan_structural_rank_ok(s):
+    """Host-only: does J have full structural rank (sprank(J) == n)?  No GPU needed."""
+    lib = load()
+    p, keep = problem_from_struct(s)
+    ok = C.c_int32(0)
+    check(lib.dbat_hip_plan_structural_rank_ok(C.byref(p), C.byref(ok)))
+    return bool(ok.value)
 
 
 def plan_point_owner(s, shard_count):

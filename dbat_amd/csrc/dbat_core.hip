@@ -876,6 +876,16 @@ int dbat_hip_plan(const dbat_hip_problem *prob, int64_t *n_params, int64_t *n_re
     API_CATCH
 }
 
+int dbat_hip_plan_structural_rank_ok(const dbat_hip_problem *prob, int32_t *ok) {
+    API_TRY
+    if (!prob || !ok) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
+    Plan P;
+    if (!build_plan(*prob, P, false)) { g_err = P.err; return DBAT_HIP_EINVAL; }
+    *ok = P.rank_ok ? 1 : 0;
+    return DBAT_HIP_OK;
+    API_CATCH
+}
+
 int dbat_hip_plan_point_owner(const dbat_hip_problem *prob, int32_t *owner) {
     API_TRY
     if (!prob || !owner) { g_err = "null argument"; return DBAT_HIP_EINVAL; }

@@ -269,8 +269,8 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     for (int64_t o = 0; o < P.no; ++o)
         if (!(pb.ip_std[2 * o] > 0) || !(pb.ip_std[2 * o + 1] > 0)) return fail(P, "IP.std must be positive");
 
-    // ---- structural rank test (subset of sprank(J), gauss_newton_armijo.m:132-142):
-    // Hall-type counting conditions on the natural parameter groups.
+    // ---- structural rank test (sprank(J), gauss_newton_armijo.m:132-142).  First the cheap
+    // necessary conditions on the natural parameter groups; the exact matching follows below.
     P.rank_ok = P.m >= P.n;
     for (int p = 0; p < np && P.rank_ok; ++p) {
         int e = 0, pr = 0;
@@ -297,6 +297,82 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     std::vector<int64_t> fill(pstart.begin(), pstart.end() - 1);
     std::vector<int64_t> by_pt(P.no);
     for (int64_t o = 0; o < P.no; ++o) by_pt[fill[pb.ip_pt[o]]++] = o;   // image-major scan => cams ascending per point
+    // ---- exact structural rank (sprank(J) < n  =>  code -4): when the counting conditions
+    // above hold, a maximum matching of the unknowns to the rows of J decides.  An unknown
+    // with a prior observation owns that row.  The others are matched to image rows (two per
+    // observation) -- IO columns first, then EO, then OP, each to the first free row it has
+    // ("cheap assignment", which settles all of them in a healthy network) and otherwise
+    // along an augmenting path.  J is never formed: the rows of an EO or IO column are the
+    // contiguous observation ranges of its cameras, those of an OP column the observations
+    // of its point.
+    if (P.rank_ok && !getenv("DBAT_HIP_SPRANK_OFF")) {
+        const int64_t ncol_all = P.NZ;
+        std::vector<int64_t> cam_obs0(nc + 1, 0);
+        for (int c = 0; c < nc; ++c) cam_obs0[c + 1] = cam_obs0[c] + n_cam[c];
+        std::vector<std::vector<int32_t>> io_cams(P.nIOu);     // cameras of each IO column
+        std::vector<std::vector<int64_t>> io_cum(P.nIOu);      // cumulative row counts over them
+        for (int c = 0; c < nc; ++c)
+            for (int r = 0; r < R; ++r) {
+                const int32_t s = distIO[(size_t)c * R + r];
+                if (s >= 0 && n_cam[c] > 0) io_cams[s].push_back(c);
+            }
+        for (int k = 0; k < P.nIOu; ++k) {
+            io_cum[k].assign(io_cams[k].size() + 1, 0);
+            for (size_t i = 0; i < io_cams[k].size(); ++i) io_cum[k][i + 1] = io_cum[k][i] + 2 * (int64_t)n_cam[io_cams[k][i]];
+        }
+        const int64_t eo_end = 6 * (int64_t)nc, io_end = P.NS;
+        auto nrows = [&](int64_t col) -> int64_t {
+            if (col < eo_end) return 2 * (int64_t)n_cam[col / 6];
+            if (col < io_end) return io_cum[col - eo_end].back();
+            return 2 * (int64_t)k_pt[(col - io_end) / 3];
+        };
+        auto row_at = [&](int64_t col, int64_t i) -> int64_t {
+            if (col < eo_end) return 2 * cam_obs0[col / 6] + i;
+            if (col < io_end) {
+                const auto &cum = io_cum[col - eo_end];
+                const size_t q = std::upper_bound(cum.begin(), cum.end(), i) - cum.begin() - 1;
+                return 2 * cam_obs0[io_cams[col - eo_end][q]] + (i - cum[q]);
+            }
+            const int64_t p = (col - io_end) / 3;
+            return 2 * by_pt[pstart[p] + (i >> 1)] + (i & 1);
+        };
+        std::vector<int32_t> row_owner((size_t)2 * P.no, -1);
+        std::vector<int64_t> cheap(ncol_all, 0), iter(ncol_all, 0), take(ncol_all, -1);
+        std::vector<int32_t> stamp(ncol_all, -1);
+        std::vector<int64_t> stack;
+        int32_t gen = 0;
+        auto match_column = [&](int64_t k) -> bool {
+            stack.assign(1, k); iter[k] = 0; stamp[k] = ++gen;
+            while (!stack.empty()) {
+                const int64_t j = stack.back(), nr = nrows(j);
+                bool found = false;
+                while (cheap[j] < nr) {
+                    const int64_t r = row_at(j, cheap[j]++);
+                    if (row_owner[r] < 0) { take[j] = r; found = true; break; }
+                }
+                if (found) {
+                    for (int64_t c : stack) row_owner[take[c]] = (int32_t)c;
+                    return true;
+                }
+                bool deeper = false;
+                while (iter[j] < nr) {
+                    const int64_t r = row_at(j, iter[j]++), j2 = row_owner[r];
+                    if (stamp[j2] != gen) {
+                        stamp[j2] = gen; take[j] = r; iter[j2] = 0;
+                        stack.push_back(j2); deeper = true;
+                        break;
+                    }
+                }
+                if (!deeper) stack.pop_back();
+            }
+            return false;
+        };
+        auto wanted = [&](int64_t col) -> bool { return P.z_est[col] && !(P.z_prw[col] > 0); };
+        for (int64_t col = eo_end; col < io_end && P.rank_ok; ++col) if (wanted(col) && !match_column(col)) P.rank_ok = false;
+        for (int64_t col = 0; col < eo_end && P.rank_ok; ++col) if (wanted(col) && !match_column(col)) P.rank_ok = false;
+        for (int64_t col = io_end; col < ncol_all && P.rank_ok; ++col) if (wanted(col) && !match_column(col)) P.rank_ok = false;
+    }
+
     // camera co-visibility: the envelope of the reduced system (chol.hpp)
     P.cam_first.resize(nc);
     for (int c = 0; c < nc; ++c) P.cam_first[c] = c;

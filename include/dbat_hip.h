@@ -141,6 +141,12 @@ int  dbat_hip_plan(const dbat_hip_problem *prob, int64_t *n_params, int64_t *n_r
                    int64_t *n_io, int64_t *n_eo, int64_t *n_op,
                    int64_t *shard_pt_lo, int64_t *shard_pt_hi);
 
+/* Host-only: the structural rank test of the damping loops at iteration 0
+ * (sprank(J) < size(J,2) => code -4; gauss_newton_armijo.m:132-142,
+ * levenberg_marquardt.m:126-135, levenberg_marquardt_powell.m:113-122), decided
+ * by a maximum matching of the unknowns to the rows of J.  No GPU needed. */
+int  dbat_hip_plan_structural_rank_ok(const dbat_hip_problem *prob, int32_t *ok);
+
 /* Host-only: owner[p] = rank (0..prob->shard_count-1) whose shard holds object
  * point p (contiguous ranges of the spatially sorted processing order,
  * balanced by observation count).  prob->shard_rank is ignored. */

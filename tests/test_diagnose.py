@@ -63,3 +63,54 @@ def test_structural_pattern_and_numerical_null_space_small():
     assert all(len(sp_.params) > 0 for sp_ in nw.suspectedParams)
     big = D.numerical_weakness(sp.csc_matrix(Jw), types, dense_limit=10)
     assert np.isnan(big.rank)
+
+
+def _drop_obs(s, keep):
+    s.IP.val, s.IP.std = s.IP.val[:, keep], s.IP.std[:, keep]
+    s.IP.cam, s.IP.pt = s.IP.cam[keep], s.IP.pt[keep]
+    return s
+
+
+def test_plan_structural_rank_equals_sprank():
+    """The host-side matching of libdbat_hip.so (dbat_hip_plan_structural_rank_ok)
+    against the structural rank of the oracle's Jacobian, on healthy scenes and
+    on scenes thinned until sub-networks lose their rows -- including cases every
+    per-group counting condition passes (two cameras that only see three points
+    nobody else sees: 12 rows for 21 unknowns)."""
+    from dbat_amd import _hip
+    rng = np.random.default_rng(11)
+    seen = {True: 0, False: 0}
+    isolated = 0
+    for trial in range(40):
+        variant = ['plain', 'selfcal', 'priors', 'imagevar'][trial % 4]
+        s, _ = synth_struct('tiny', variant)
+        no = s.IP.val.shape[1]
+        keep = np.ones(no, bool)
+        if trial >= 4:
+            frac = rng.uniform(0.05, 0.6)
+            keep = rng.random(no) < frac
+            if trial % 3 == 0:            # an isolated pair of cameras with three private points:
+                # every camera keeps 6 rows for 6 unknowns and every point 4 rows for 3,
+                # but together they have 12 rows for 21 unknowns
+                keep[:] = True
+                vis = np.zeros((s.EO.val.shape[1], s.OP.val.shape[1]), bool)
+                vis[s.IP.cam, s.IP.pt] = True
+                pairs = [(a, b) for a in range(vis.shape[0]) for b in range(a + 1, vis.shape[0])
+                         if np.count_nonzero(vis[a] & vis[b]) >= 3]
+                ca, cb = pairs[rng.integers(len(pairs))]
+                pts = rng.choice(np.flatnonzero(vis[ca] & vis[cb]), 3, replace=False)
+                keep &= ~np.isin(s.IP.cam, [ca, cb]) & ~np.isin(s.IP.pt, pts)
+                keep |= np.isin(s.IP.cam, [ca, cb]) & np.isin(s.IP.pt, pts)
+                s.bundle.est.EO[:, [ca, cb]] = True
+                isolated += 1
+        s = _drop_obs(s, keep)
+        so = o.buildserialindices(s)
+        x0 = o.serialize(so)
+        r, J = o.brown_euler_cam4(x0, so, jac=True)
+        J = sp.csr_matrix(J)
+        J.data[:] = 1.0
+        want = int(np.count_nonzero(maximum_bipartite_matching(J, perm_type='column') >= 0)) == len(x0)
+        got = _hip.plan_structural_rank_ok(s)
+        assert got == want, (trial, variant, got, want)
+        seen[want] += 1
+    assert seen[True] >= 4 and seen[False] >= 10 and isolated >= 10

@@ -266,6 +266,24 @@ def test_failure_codes(hip):
     ro, oko, ito, s0o, Eo = o.bundle(s, 'gna')
     assert Eo.code == -2
     assert E.code == -2 and not ok
+    # a sub-network that no per-camera / per-point count gives away: two cameras that only
+    # see three points nobody else sees (12 rows, 21 unknowns) -- sprank finds it, and so
+    # does the matching in the plan
+    s, _ = synth_struct('tiny', 'plain')
+    vis = np.zeros((s.EO.val.shape[1], s.OP.val.shape[1]), bool)
+    vis[s.IP.cam, s.IP.pt] = True
+    ca, cb = next((a, b) for a in range(1, vis.shape[0]) for b in range(a + 1, vis.shape[0])
+                  if np.count_nonzero(vis[a] & vis[b]) >= 3)
+    pts = np.flatnonzero(vis[ca] & vis[cb])[:3]
+    keep = (~np.isin(s.IP.cam, [ca, cb]) & ~np.isin(s.IP.pt, pts)) | (np.isin(s.IP.cam, [ca, cb]) & np.isin(s.IP.pt, pts))
+    s.IP.val, s.IP.std = s.IP.val[:, keep], s.IP.std[:, keep]
+    s.IP.cam, s.IP.pt = s.IP.cam[keep], s.IP.pt[keep]
+    for damping in ('gna', 'lm', 'lmp'):
+        res, ok, iters, s0, E = bundle(s, damping)
+        ro, oko, ito, s0o, Eo = o.bundle(s, damping)
+        assert E.code == Eo.code == -4 and not ok and iters == 0
+        assert E.weakness.structural.deficiency == Eo.weakness.structural.deficiency == 9
+        assert list(E.weakness.structural.suspectedParams) == list(Eo.weakness.structural.suspectedParams)
     # too few iterations: code -1, s not updated (bundle.m:356-358)
     s, _ = synth_struct('tiny', 'plain')
     res, ok, iters, s0, E = bundle(s, 'gna', 1)
