@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof4
+O=$R/gpurun_out/prof5
 mkdir -p $O
 cd $R
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o r01d -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_stdout.json 2> $O/kt.err; echo kt rc=$?
@@ -9,6 +9,8 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o r01d_write -- pyth
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/mfma -o r01d_mfma -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/mfma.err; echo mfma rc=$?
 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo bench rc=$?
 python bench.py --config C2 --no-cpu-baseline > $O/bench_c2.json 2>/dev/null; echo c2 rc=$?
+python bench.py --config C1 --no-cpu-baseline > $O/bench_c1.json 2>/dev/null; echo c1 rc=$?
+python bench.py --config C4 --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_c4.json 2>/dev/null; echo c4 rc=$?
 find $O -name "*.csv" | head -20
 # keep only the small csv files
 find $O -name "*kernel_trace.csv" -size +20M -delete

@@ -97,6 +97,7 @@ struct Plan {
     int cam_adj_words = 0;
     int max_k = 0;                                 // max observations of one point
     bool rank_ok = true;                           // structural rank test
+    int order_dims = 3;                            // dimensions of the point-ordering curve (2 = flat cloud)
     std::string err;
 };
 
@@ -431,21 +432,67 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
             if (ns > Plan::IOT) heavy[p] = 1;
         }
     }
-    // Key = 3-D Morton code of the point's initial coordinates: points that are
-    // close in object space are seen by the same cameras, so neighbouring
-    // points touch the same blocks of the reduced system (tiles below).
-    // Unobserved points sort last.
+    // Key = Morton code of the point's initial coordinates in the principal axes of the
+    // point cloud: points that are close in object space are seen by the same cameras, so
+    // neighbouring points touch the same blocks of the reduced system (tiles below).  A
+    // flat cloud (terrain under an aerial block, a facade: smallest principal extent
+    // below a fifth of the largest) is ordered along its plane only -- interleaving the
+    // thin direction would widen the footprint of a run of points, and with it the set
+    // of cameras a tile has to hold.  Unobserved points sort last.
     std::vector<uint64_t> key(np);
     {
+        double mean[3] = {0, 0, 0}, cov[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        int64_t nfin = 0;
+        for (int p = 0; p < np; ++p) {
+            const double *q = pb.OP_val + (size_t)3 * p;
+            if (std::isfinite(q[0]) && std::isfinite(q[1]) && std::isfinite(q[2])) { ++nfin; for (int d = 0; d < 3; ++d) mean[d] += q[d]; }
+        }
+        for (int d = 0; d < 3; ++d) mean[d] /= (double)std::max<int64_t>(nfin, 1);
+        for (int p = 0; p < np; ++p) {
+            const double *q = pb.OP_val + (size_t)3 * p;
+            if (!(std::isfinite(q[0]) && std::isfinite(q[1]) && std::isfinite(q[2]))) continue;
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) cov[i][j] += (q[i] - mean[i]) * (q[j] - mean[j]);
+        }
+        double ax[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};          // columns = principal axes (cyclic Jacobi)
+        for (int sweep = 0; sweep < 30; ++sweep) {
+            const double off = std::fabs(cov[0][1]) + std::fabs(cov[0][2]) + std::fabs(cov[1][2]);
+            if (!(off > 1e-14 * (std::fabs(cov[0][0]) + std::fabs(cov[1][1]) + std::fabs(cov[2][2])))) break;
+            for (int i = 0; i < 2; ++i)
+                for (int j = i + 1; j < 3; ++j) {
+                    if (cov[i][j] == 0.0) continue;
+                    const double th = 0.5 * std::atan2(2 * cov[i][j], cov[j][j] - cov[i][i]);
+                    const double cs = std::cos(th), sn = std::sin(th);
+                    for (int k = 0; k < 3; ++k) {                      // cov <- G' cov G, ax <- ax G
+                        const double a = cov[k][i], b = cov[k][j];
+                        cov[k][i] = cs * a - sn * b; cov[k][j] = sn * a + cs * b;
+                    }
+                    for (int k = 0; k < 3; ++k) {
+                        const double a = cov[i][k], b = cov[j][k];
+                        cov[i][k] = cs * a - sn * b; cov[j][k] = sn * a + cs * b;
+                    }
+                    for (int k = 0; k < 3; ++k) {
+                        const double a = ax[k][i], b = ax[k][j];
+                        ax[k][i] = cs * a - sn * b; ax[k][j] = sn * a + cs * b;
+                    }
+                }
+        }
+        auto coord = [&](int p, int a) {
+            const double *q = pb.OP_val + (size_t)3 * p;
+            return (q[0] - mean[0]) * ax[0][a] + (q[1] - mean[1]) * ax[1][a] + (q[2] - mean[2]) * ax[2][a];
+        };
         double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
         for (int p = 0; p < np; ++p)
             for (int d = 0; d < 3; ++d) {
-                const double v = pb.OP_val[(size_t)3 * p + d];
+                const double v = coord(p, d);
                 if (std::isfinite(v)) { lo[d] = std::min(lo[d], v); hi[d] = std::max(hi[d], v); }
             }
-        double ext = 0;
-        for (int d = 0; d < 3; ++d) ext = std::max(ext, hi[d] - lo[d]);
+        int axis[3] = {0, 1, 2};
+        std::sort(axis, axis + 3, [&](int a, int b) { return hi[a] - lo[a] > hi[b] - lo[b]; });
+        double ext = hi[axis[0]] - lo[axis[0]];
         if (!(ext > 0)) ext = 1;
+        const char *od = getenv("DBAT_HIP_ORDER_DIMS");               // 2 or 3: override the flatness rule
+        const int dims = od ? std::min(3, std::max(2, atoi(od))) : ((hi[axis[2]] - lo[axis[2]]) < 0.2 * ext ? 2 : 3);
+        P.order_dims = dims;
         auto spread = [](uint64_t v) {      // 21 bits -> every third bit
             v &= 0x1FFFFF;
             v = (v | v << 32) & 0x1F00000000FFFFull;
@@ -457,8 +504,8 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         };
         for (int p = 0; p < np; ++p) {
             uint64_t k = 0;
-            for (int d = 0; d < 3; ++d) {
-                double v = (pb.OP_val[(size_t)3 * p + d] - lo[d]) / ext;
+            for (int d = 0; d < dims; ++d) {
+                double v = (coord(p, axis[d]) - lo[axis[d]]) / ext;
                 if (!(v >= 0)) v = 0;
                 if (v > 1) v = 1;
                 k |= spread((uint64_t)(v * 2097151.0)) << d;
@@ -556,7 +603,12 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     int32_t tile_id = 0;
     int pidx = 0;
     bool in_heavy = false;
-    const int tile_bmax = std::max(1, env_int0("DBAT_HIP_TILE_BMAX", 48));   // batches per tile
+    // batches per tile: long tiles amortise the flush of the tile into S, but a small
+    // problem must still break into enough tiles to occupy the 256 CUs twice over
+    int64_t shard_obs = 0;
+    for (int64_t i = P.pt_lo; i < P.pt_hi; ++i) shard_obs += k_pt[P.porder[i]];
+    const int bmax_auto = (int)std::min<int64_t>(48, std::max<int64_t>(4, (shard_obs / std::max(1, P.BT) + 511) / 512));
+    const int tile_bmax = std::max(1, env_int0("DBAT_HIP_TILE_BMAX", bmax_auto));
     for (int64_t i = P.pt_lo; i < P.pt_hi; ++i) {
         const int32_t p = P.porder[i];
         const int k = k_pt[p];
@@ -700,6 +752,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         for (size_t i = 0; i + 1 < P.tile_batch.size(); ++i) nbt.push_back(P.tile_batch[i + 1] - P.tile_batch[i]);
         std::sort(nbt.begin(), nbt.end());
         double s = 0; for (int v : nbt) s += v;
+        fprintf(stderr, "[plan] points ordered along a %d-D curve in the principal axes of the cloud\n", P.order_dims);
         fprintf(stderr, "[plan] %zu tiles, batches/tile min %d median %d mean %.1f p90 %d p99 %d max %d; cams/tile mean %.1f\n",
                 nbt.size(), nbt.front(), nbt[nbt.size() / 2], s / nbt.size(), nbt[nbt.size() * 9 / 10],
                 nbt[nbt.size() * 99 / 100], nbt.back(), (double)P.tile_cams.size() / nbt.size());
