@@ -5,7 +5,8 @@ Host-side mirror of the reference's interface for the bundle hot path:
     driver       bundle(s, ...) -> (s, ok, iters, sigma0, E); bundle_cov(s, E, 'CIO','CEO','COP')
     loadpm       PhotoModeler export loader (known-answer fixtures)
     initial      resect / forwintersect: initial EO and OP (photogrammetry/resect.m, forwintersect.m)
-    report       numeric subset of the result file (bundle_result_file.m)
+    report       the result file (bundle_result_file.m)
+    diagnose     post-mortem of rank-deficient problems (bundle.m:368-446)
     parallel     torch.distributed / RCCL plumbing for sharded object points
     _hip         ctypes binding of include/dbat_hip.h (libdbat_hip.so)
 """

@@ -161,6 +161,11 @@ def setcpt(s, pts):
     s.OP.val[:, i] = pts['pos'][:, j]
     s.prior.OP.std[:, i] = pts['std'][:, j]
     s.prior.OP.isCtrl[i] = True
+    if not hasattr(s.OP, 'label') or s.OP.label is None:
+        s.OP.label = [''] * s.OP.val.shape[1]
+    for a, b in zip(i, j):                                   # setcpt.m:33-37: non-blank labels
+        if pts['name'][b]:
+            s.OP.label[a] = pts['name'][b]
     isFixed = np.all(pts['std'][:, j] == 0, 0)
     s.prior.OP.use[:, i] = np.tile(~isFixed, (3, 1))
     s.bundle.est.OP[:, i] = np.tile(~isFixed, (3, 1))

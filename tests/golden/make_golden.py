@@ -130,8 +130,8 @@ def parse_failure(path):
     out['iterations'] = int(g(r'Number of iterations:\s+(\d+)').group(1))
     out['firstError'] = num(r'First error:\s+(\S+)')
     out['lastError'] = num(r'Last error:\s+(\S+)')
-    # the head of the report up to the timings, for the line-by-line check
-    out['head'] = txt[:txt.index('      Execution times')].splitlines()
+    # the head of the report up to the camera section, for the line-by-line check
+    out['head'] = txt[:txt.index('      Cameras:')].splitlines()
     return out
 
 

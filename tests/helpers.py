@@ -39,9 +39,11 @@ def camcal_struct(model=3, export='camcal-pmexport.txt', ctrl=True):
         s.bundle.est.IO[3, :] = False
     s.bundle.est.EO[:] = True
     if not ctrl:                                           # camcaldemo_no_datum.m:65
+        s.proj = type(s.post)(objUnit='m', x0desc='')
         return s
     s.prior.OP.isCtrl = s.OP.id > 1000
     pts = L.loadcpt(os.path.join(GOLDEN, 'camcal-fixed.txt'))
+    s.proj = type(s.post)(objUnit='m', x0desc='Camera calibration from EXIF value')      # camcaldemo.m:107
     return L.setcpt(s, pts)
 
 
@@ -301,6 +303,7 @@ def sxb_struct():
     s = T.struct_from_script(io, cam['sensor'], cam['image'], exp['images'], marks, pick(False), pick(True),
                              distModel=cam['model'], im_names=exp['image_paths'])
     s = T.set_script_defaults(s)
+    s.proj = type(s.post)(objUnit='m', x0desc='')
     cpId = s.OP.id[s.prior.OP.isCtrl]
     s, rms, fail = I.resect(s, 'all', cpId, 1, 0, cpId)
     assert not fail

@@ -45,7 +45,7 @@ def test_param_types_match_oracle_and_reference_naming():
     assert got[9 + 126] == 'OX-1/2' and got[-1] == 'OZ-96/97'     # sequence number / id (ids start at 2)
     # control points are 'C', ids that differ from the sequence number are appended
     IOt, EOt, OPt = D.buildparamtypes(s)
-    assert OPt[0, -1] == 'CX-100/1004'
+    assert OPt[0, -1] == 'CX-100/1004-CP4'                 # sequence number / id - label
 
 
 def test_structural_pattern_and_numerical_null_space_small():

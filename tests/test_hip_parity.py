@@ -702,7 +702,7 @@ def test_camcal_demo_pipeline_hip(hip, model, damping):
     if damping == 'gna' and model == 3:
         CIO, CEO, COP = bundle_cov(res, E, 'CIO', 'CEO', 'COP')
         lines = bundle_result_lines(res, E, CIO, CEO, COP)
-        assert check_report_lines(lines, demo_x0=True) >= len(lines) - 10
+        assert len(lines) >= 590 and check_report_lines(lines, demo_x0=True) >= len(lines) - 2    # all but the first error verbatim
 
 
 @pytest.mark.parametrize('kind', ['1ray', 'missing-obs', 'no-datum'])
@@ -757,7 +757,7 @@ def test_sxb_script_known_answer_hip(hip):
     assert relerr(CEO.toarray() if hasattr(CEO, 'toarray') else CEO, Co[0].toarray() if hasattr(Co[0], 'toarray') else Co[0]) < 1e-5
     lines = bundle_result_lines(res, E, CIO, CEO, COP)
     n = check_report_lines(lines, ref_path=os.path.join(GOLDEN, 'sxb-report.txt'), demo_x0=True, x0_tol=1e-4)
-    assert n >= len(lines) - 3
+    assert len(lines) >= 455 and n >= len(lines) - 2     # every line but the first error verbatim
     for damping in ('lm', 'lmp'):
         r2, ok2, it2, s02, E2 = bundle(s, damping)
         assert ok2 and abs(s02 / s0 - 1) < 1e-7

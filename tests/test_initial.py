@@ -101,7 +101,7 @@ def test_camcal_demo_pipeline_known_answer(model):
     CIO, CEO, COP = o.bundle_cov(res, E, 'CIO', 'CEO', 'COP')
     lines = bundle_result_lines(res, E, CIO, CEO, COP)
     assert any('Number of iterations: 9' in l for l in lines)
-    assert check_report_lines(lines, demo_x0=True) >= len(lines) - 10
+    assert len(lines) >= 590 and check_report_lines(lines, demo_x0=True) >= len(lines) - 2    # all but the first error verbatim
 
 
 def test_resect_first_error_conditioning():
