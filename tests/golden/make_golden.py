@@ -99,6 +99,10 @@ def main():
     for m in (2, 4, 5):
         exp['model%d' % m] = parse_report(
             os.path.join(REF, 'dbatexports/camcal-dbatreport-model%d.txt' % m))
+        # kept whole as well, for the line-by-line comparison of the other lens models
+        dst = os.path.join(HERE, 'camcal-dbatreport-model%d.txt' % m)
+        shutil.copy(os.path.join(REF, 'dbatexports/camcal-dbatreport-model%d.txt' % m), dst)
+        os.chmod(dst, 0o644)
     with open(os.path.join(HERE, 'camcal_expected.json'), 'w') as fh:
         json.dump(exp, fh, indent=1)
     print({k: (v['sigma0'], len(v['EO_report_deg'])) for k, v in exp.items()})
