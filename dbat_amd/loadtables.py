@@ -64,6 +64,8 @@ def struct_from_tables(io_col, sensor, imsz, eo_table, mark_table, mark_fmt='im,
                     distModel=distModel, nK=nK, nP=nP)
     s.OP.id = ids
     s.EO.id = im_ids
+    s.IO.sensor.ssSize = np.tile(np.asarray(sensor, float)[:, None], (1, nc))
+    s.IO.sensor.imSize = np.tile(np.asarray(imsz, float)[:, None], (1, nc))
     return s
 
 

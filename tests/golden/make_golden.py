@@ -224,7 +224,11 @@ def roma():
         'camera_out': {'cc': float(tag(cam_out, 'cc')), 'pp': nums(tag(cam_out, 'pp')),
                        'K': nums(tag(cam_out, 'K')), 'sensor': nums(tag(cam_out, 'sensor'))},
         'report': rep,
+        'image_paths': [l.split(',')[1].strip() for l in open(os.path.join(R, 'images/images.txt')) if l.strip() and l[0] != '#'],
     }
+    # the committed result file whole, for the line-by-line comparison
+    shutil.copy(os.path.join(R, 'result/report.txt'), os.path.join(HERE, 'roma-report.txt'))
+    os.chmod(os.path.join(HERE, 'roma-report.txt'), 0o644)
     with open(os.path.join(HERE, 'roma_expected.json'), 'w') as fh:
         json.dump(exp, fh, indent=1)
     print('roma', rep['sigma0'], rep['numParams'], rep['iterations'], rep['firstError'], rep['lastError'])

@@ -272,6 +272,8 @@ def roma_struct():
     s = T.struct_from_tables(io, sensor, ci['image'], eo, mk, 'im,id,x,y', 1.0, distModel=ci['model'])
     s = T.forwintersect(s)
     s.bundle.est.IO[[0, 1, 2, 5, 6]] = True
+    s.EO.name = exp['image_paths']
+    s.proj = type(s.post)(objUnit='m', x0desc='')
     return seteoest_depend(s, 0)
 
 

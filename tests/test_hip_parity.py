@@ -787,3 +787,24 @@ def test_roma_demo_variants_known_answer_hip(hip, variant):
     for damping in ('lm', 'lmp'):                    # same minimum from the other damping schemes
         r2, ok2, it2, s02, E2 = bundle(s, damping)
         assert ok2 and abs(s02 / s0 - 1) < 1e-6
+
+
+def test_roma_script_report_lines_hip(hip):
+    """The committed result file of the roma script run
+    (data/script/romabundledemo/result/report.txt, 1334 lines: 60 images,
+    26 321 points, self-calibration, dependent datum) written from the GPU's
+    bundle() and bundle_cov() results: every line the report module produces
+    -- all but the 17 bookkeeping lines -- must be a verbatim line of it, in
+    order: camera values, deviations, significances and correlations, 360 EO
+    values with deviations and correlations, coverage, ray counts, residual
+    statistics, point precision of 26 321 points, intersection angles."""
+    import os
+    from dbat_amd import bundle, bundle_cov
+    from dbat_amd.report import bundle_result_lines
+    from helpers import check_report_lines, GOLDEN
+    res, ok, iters, s0, E = bundle(roma_struct(), 'gna')
+    assert ok
+    CIO, CEO, COP = bundle_cov(res, E, 'CIO', 'CEO', 'COP')
+    lines = bundle_result_lines(res, E, CIO, CEO, COP)
+    n = check_report_lines(lines, ref_path=os.path.join(GOLDEN, 'roma-report.txt'), demo_x0=True)
+    assert len(lines) >= 1310 and n >= len(lines) - 2
