@@ -290,12 +290,17 @@ def _quality_lines(s, E, COP, vop):
     tstd = np.sqrt(var.sum(0))
     out.append(p2 + 'Point Precision')
     out.append(p3 + 'Total standard deviation (RMS of X/Y/Z std):')
-    out.append(p4 + 'Minimum: %.2g (OP %d)' % (np.nanmin(tstd), ids[np.nanargmin(tstd)]))
-    out.append(p4 + 'Maximum: %.2g (OP %d)' % (np.nanmax(tstd), ids[np.nanargmax(tstd)]))
+    g2 = lambda v: 'NaN' if np.isnan(v) else '%.2g' % v
+
+    def arg(v, f):                                   # MATLAB's min/max skip NaN; all NaN -> NaN, index 1
+        return 0 if np.all(np.isnan(v)) else int(f(v))
+    a, b = arg(tstd, np.nanargmin), arg(tstd, np.nanargmax)
+    out.append(p4 + 'Minimum: %s (OP %d)' % (g2(tstd[a]), ids[a]))
+    out.append(p4 + 'Maximum: %s (OP %d)' % (g2(tstd[b]), ids[b]))
     sd = np.sqrt(var)
     for c, ax in enumerate('XYZ'):
-        j = int(np.nanargmax(sd[c]))
-        out.append(p3 + 'Maximum %s standard deviation: %.2g (OP %d)' % (ax, sd[c, j], ids[j]))
+        j = arg(sd[c], np.nanargmax)
+        out.append(p3 + 'Maximum %s standard deviation: %s (OP %d)' % (ax, g2(sd[c, j]), ids[j]))
     # ---- Points with high correlations (:702-724)
     vi, vj, vv = vop
     out.append(p3 + 'Points with high correlations')

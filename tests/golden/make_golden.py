@@ -110,6 +110,7 @@ def main():
     failures()
     sxb()
     roma_variants()
+    prague()
 
 
 def parse_failure(path):
@@ -151,6 +152,31 @@ def failures():
     with open(os.path.join(HERE, 'camcal_failures_expected.json'), 'w') as fh:
         json.dump(exp, fh, indent=1)
     print({k: (v['code'], v['structural'] and v['structural']['rank'], v['numerical'], v['sigma0']) for k, v in exp.items()})
+
+
+def prague():
+    """demo/prague2016_pm.m: PhotoModeler projects of the camcal sheet ('cam': c1
+    fixed / c2 weighted control points) and of the Strasbourg block ('sxb': s1
+    fixed, s2 weighted control points only, s3 plus one object point, s4 plus
+    365 smart points), each with its loaded (fixed) camera.  Inputs: the
+    PhotoModeler exports (xz) and the control point files; known answers: the
+    committed DBAT reports, kept whole.  (The -with-orient variants have
+    identical exports and reports up to the bookkeeping lines.)"""
+    import lzma
+    P = '/root/reference/data/prague2016'
+    for site, stubs in (('cam', ('fixed', 'weighted')), ('sxb', ('f-op0', 'w-op0', 'w-op1', 'wsmart'))):
+        for stub in stubs:
+            with open(os.path.join(P, site, 'pmexports', stub + '-no-orient-pmexport.txt'), 'rb') as fi, \
+                    lzma.open(os.path.join(HERE, 'prague-%s-%s-pmexport.txt.xz' % (site, stub)), 'wb', preset=9) as fo:
+                fo.write(fi.read())
+            dst = os.path.join(HERE, 'prague-%s-%s-dbatreport.txt' % (site, stub))
+            shutil.copy(os.path.join(P, site, 'dbatexports', stub + '-no-orient-dbatreport.txt'), dst)
+            os.chmod(dst, 0o644)
+        for nm in ('ctrlpts-fixed.txt', 'ctrlpts-weighted.txt'):
+            dst = os.path.join(HERE, 'prague-%s-%s' % (site, nm))
+            shutil.copy(os.path.join(P, site, 'ref', nm), dst)
+            os.chmod(dst, 0o644)
+    print('prague fixtures copied')
 
 
 def roma_variants():

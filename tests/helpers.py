@@ -277,6 +277,38 @@ def roma_struct():
     return seteoest_depend(s, 0)
 
 
+PRAGUE = {'c1': ('cam', 'fixed', False), 'c2': ('cam', 'weighted', True), 's1': ('sxb', 'f-op0', False),
+          's2': ('sxb', 'w-op0', True), 's3': ('sxb', 'w-op1', True), 's4': ('sxb', 'wsmart', True)}
+
+
+def prague_struct(label):
+    """demo/prague2016_pm.m:82-190 for experiment label c1, c2, s1..s4: the
+    PhotoModeler export with its loaded, fixed camera; control points from
+    the reference file, shifted by the mean offset to PhotoModeler's frame
+    (:150-166), fixed or weighted; EO by resection, OP by forward intersection.
+    The demo runs lens model 1, which is numerically model 2 (bundle.m:49-51,
+    and the committed camcal reports of both: sigma0 1.68901); model 2 here.
+    Returns (s, path of the committed report)."""
+    from dbat_amd import initial as I
+    site, stub, weighted = PRAGUE[label]
+    prob = L.loadpm(_golden_path('prague-%s-%s-pmexport.txt' % (site, stub)))
+    s = L.prob2dbatstruct(prob, distModel=2)
+    s.bundle.est.IO[:] = False                             # setcamvals 'loaded'; setcamest 'not','all'
+    pts = L.loadcpt(os.path.join(GOLDEN, 'prague-%s-ctrlpts-%s.txt' % (site, 'weighted' if weighted else 'fixed')))
+    pm = prob['ctrlPts']
+    assert np.all(np.isin(pm[:, 0], pts['id']))
+    _, ia, ib = np.intersect1d(pm[:, 0].astype(int), pts['id'], return_indices=True)
+    offset = pm[ia, 1:4].T - pts['pos'][:, ib]
+    pts['pos'] = pts['pos'] + offset.mean(1)[:, None]
+    s = L.setcpt(s, pts)
+    s.proj = type(s.post)(objUnit='m', x0desc='')
+    s = I.clearop(I.cleareo(s))
+    cpId = s.OP.id[s.prior.OP.isCtrl]
+    s, rms, fail = I.resect(s, 'all', cpId, 1, 0, cpId)
+    assert not fail
+    return I.forwintersect(s, 'all', True), os.path.join(GOLDEN, 'prague-%s-%s-dbatreport.txt' % (site, stub))
+
+
 def sxb_expected():
     with open(os.path.join(GOLDEN, 'sxb_expected.json')) as fh:
         return json.load(fh)

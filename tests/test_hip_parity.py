@@ -808,3 +808,24 @@ def test_roma_script_report_lines_hip(hip):
     lines = bundle_result_lines(res, E, CIO, CEO, COP)
     n = check_report_lines(lines, ref_path=os.path.join(GOLDEN, 'roma-report.txt'), demo_x0=True)
     assert len(lines) >= 1310 and n >= len(lines) - 2
+
+
+@pytest.mark.parametrize('label', ['c1', 'c2', 's1', 's2', 's3', 's4'])
+def test_prague2016_reports_hip(hip, label):
+    """The six prague2016 PhotoModeler projects through bundle() / bundle_cov()
+    on the GPU, line by line against the committed DBAT reports (s1: every
+    object point fixed, 30 unknowns; s2/s3: control points as the only or
+    almost the only points; c2/s2-s4: weighted control points)."""
+    from dbat_amd import bundle, bundle_cov
+    from dbat_amd.report import bundle_result_lines
+    from helpers import prague_struct, check_report_lines
+    s, ref = prague_struct(label)
+    res, ok, iters, s0, E = bundle(s, 'gna')
+    assert ok and E.code == 0
+    ro, oko, ito, s0o, Eo = o.bundle(s, 'gna')
+    check_history(E, Eo, iters, ito, 'gna')
+    assert np.abs(E.x - Eo.x).max() < 1e-7 * max(1.0, np.abs(Eo.x).max())
+    CIO, CEO, COP = bundle_cov(res, E, 'CIO', 'CEO', 'COP')
+    lines = [l.replace('(Photogrammetry) model 2', '(Photogrammetry) model 1') for l in bundle_result_lines(res, E, CIO, CEO, COP)]
+    n = check_report_lines(lines, ref_path=ref, demo_x0=True)
+    assert len(lines) >= 319 and n >= len(lines) - 1

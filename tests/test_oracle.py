@@ -66,6 +66,25 @@ def test_roma_demo_fixed_camera_known_answer():
     check_roma_variant(res, s0, E, roma_variants_expected()['fixed'])
 
 
+@pytest.mark.parametrize('label', ['c1', 'c2', 's1', 's2', 's3', 's4'])
+def test_prague2016_reports(label):
+    """demo/prague2016_pm.m, six PhotoModeler projects (fixed / weighted control
+    points; control points only, one object point, 365 smart points; loaded
+    fixed camera with distortion; image sigma 0.1 and 1 px): the committed DBAT
+    reports data/prague2016/{cam,sxb}/dbatexports/*-no-orient-dbatreport.txt
+    line by line -- everything but the bookkeeping lines, first error included."""
+    from helpers import prague_struct, check_report_lines
+    from dbat_amd.report import bundle_result_lines
+    s, ref = prague_struct(label)
+    res, ok, iters, s0, E = o.bundle(s, 'gna')
+    assert ok
+    CIO, CEO, COP = o.bundle_cov(res, E, 'CIO', 'CEO', 'COP')
+    # the demo runs the legacy lens model 1, numerically model 2 (bundle.m:49-51)
+    lines = [l.replace('(Photogrammetry) model 2', '(Photogrammetry) model 1') for l in bundle_result_lines(res, E, CIO, CEO, COP)]
+    n = check_report_lines(lines, ref_path=ref, demo_x0=True)
+    assert len(lines) >= 319 and n >= len(lines) - 1
+
+
 def test_sxb_script_known_answer():
     """data/script/sxb: control points as weighted prior observations, check
     points, two image-point standard deviations, fixed camera, coordinates of
