@@ -176,6 +176,16 @@ def prague():
             dst = os.path.join(HERE, 'prague-%s-%s' % (site, nm))
             shutil.copy(os.path.join(P, site, 'ref', nm), dst)
             os.chmod(dst, 0o644)
+    # demo/sxb_prior_eo.m: the wsmart project in the original 1e6-m frame, with and without
+    # prior observations of four camera positions
+    with open(os.path.join(P, 'sxb/pmexports/wsmart-with-orient-pmexport.txt'), 'rb') as fi, \
+            lzma.open(os.path.join(HERE, 'prague-sxb-wsmart-with-orient-pmexport.txt.xz'), 'wb', preset=9) as fo:
+        fo.write(fi.read())
+    for src, dst in (('sxb/ref/fake-camera-positions.txt', 'prague-sxb-fake-camera-positions.txt'),
+                     ('sxb/dbatexports/sxb-prior-eo-dbatreport.txt', 'prague-sxb-prior-eo-dbatreport.txt'),
+                     ('sxb/dbatexports/sxb-no-prior-eo-dbatreport.txt', 'prague-sxb-no-prior-eo-dbatreport.txt')):
+        shutil.copy(os.path.join(P, src), os.path.join(HERE, dst))
+        os.chmod(os.path.join(HERE, dst), 0o644)
     print('prague fixtures copied')
 
 

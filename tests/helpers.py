@@ -309,6 +309,38 @@ def prague_struct(label):
     return I.forwintersect(s, 'all', True), os.path.join(GOLDEN, 'prague-%s-%s-dbatreport.txt' % (site, stub))
 
 
+def sxb_prior_eo_struct(use_prior_eo):
+    """demo/sxb_prior_eo.m:33-83: the Strasbourg smart-point project in its
+    1e6-m frame, weighted control points, loaded fixed camera, and optionally
+    prior observations (0.05 m) of four of the five camera positions from
+    ref/fake-camera-positions.txt (misc/setprioreo.m).  Returns (s, report)."""
+    from dbat_amd import initial as I
+    prob = L.loadpm(_golden_path('prague-sxb-wsmart-with-orient-pmexport.txt'))
+    s = L.prob2dbatstruct(prob, distModel=2)               # demo: model 1 == model 2 (bundle.m:49-51)
+    s.bundle.est.IO[:] = False
+    s = L.setcpt(s, L.loadcpt(os.path.join(GOLDEN, 'prague-sxb-ctrlpts-weighted.txt')))
+    s.proj = type(s.post)(objUnit='m', x0desc='')
+    if use_prior_eo:
+        names = [os.path.basename(n) for n in s.EO.name]
+        for line in open(os.path.join(GOLDEN, 'prague-sxb-fake-camera-positions.txt')):
+            if line.startswith('#') or not line.strip():
+                continue
+            tok = [v.strip() for v in line.split(',')]
+            i = names.index(tok[0])
+            pos, sd = np.array([float(v) for v in tok[1:4]]), float(tok[4])
+            s.prior.EO.val[:3, i] = pos
+            s.EO.val[:3, i] = pos
+            s.prior.EO.std[:3, i] = sd
+            s.prior.EO.use[:3, i] = sd != 0
+            s.bundle.est.EO[:3, i] = sd != 0
+    s = I.clearop(I.cleareo(s))
+    cpId = s.OP.id[s.prior.OP.isCtrl]
+    s, rms, fail = I.resect(s, 'all', cpId, 1, 0, cpId)
+    assert not fail
+    return I.forwintersect(s, 'all', True), os.path.join(
+        GOLDEN, 'prague-sxb-%sprior-eo-dbatreport.txt' % ('' if use_prior_eo else 'no-'))
+
+
 def sxb_expected():
     with open(os.path.join(GOLDEN, 'sxb_expected.json')) as fh:
         return json.load(fh)

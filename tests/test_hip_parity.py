@@ -829,3 +829,25 @@ def test_prague2016_reports_hip(hip, label):
     lines = [l.replace('(Photogrammetry) model 2', '(Photogrammetry) model 1') for l in bundle_result_lines(res, E, CIO, CEO, COP)]
     n = check_report_lines(lines, ref_path=ref, demo_x0=True)
     assert len(lines) >= 319 and n >= len(lines) - 1
+
+
+@pytest.mark.parametrize('use_prior_eo', [False, True])
+def test_sxb_prior_eo_reports_hip(hip, use_prior_eo):
+    """demo/sxb_prior_eo.m on the GPU: prior observations of camera positions
+    (EO prior rows) with weighted control points at 1e6-m coordinates; the
+    committed reports line by line, and the oracle's iteration history."""
+    from dbat_amd import bundle, bundle_cov
+    from dbat_amd.report import bundle_result_lines
+    from helpers import sxb_prior_eo_struct, check_report_lines
+    s, ref = sxb_prior_eo_struct(use_prior_eo)
+    res, ok, iters, s0, E = bundle(s, 'gna')
+    assert ok and E.code == 0
+    ro, oko, ito, s0o, Eo = o.bundle(s, 'gna')
+    check_history(E, Eo, iters, ito, 'gna')
+    assert np.abs(E.x - Eo.x).max() < 1e-5 and relerr(E.x, Eo.x) < 1e-12
+    if use_prior_eo:
+        assert relerr(res.post.res.EO[res.prior.EO.use[:6]], ro.post.res.EO[ro.prior.EO.use]) < 1e-6
+    CIO, CEO, COP = bundle_cov(res, E, 'CIO', 'CEO', 'COP')
+    lines = [l.replace('(Photogrammetry) model 2', '(Photogrammetry) model 1') for l in bundle_result_lines(res, E, CIO, CEO, COP)]
+    n = check_report_lines(lines, ref_path=ref, demo_x0=True, x0_tol=1e-4)
+    assert len(lines) >= 430 and n >= len(lines) - 2

@@ -85,6 +85,23 @@ def test_prague2016_reports(label):
     assert len(lines) >= 319 and n >= len(lines) - 1
 
 
+@pytest.mark.parametrize('use_prior_eo', [False, True])
+def test_sxb_prior_eo_reports(use_prior_eo):
+    """demo/sxb_prior_eo.m: prior observations of four camera positions (12 EO
+    rows, 0.05 m) next to weighted control points, coordinates of 1e6 m.
+    sxb-{,no-}prior-eo-dbatreport.txt line by line; the first error to 1e-4
+    (resected centres at 1e6 m, see check_sxb_against_report)."""
+    from helpers import sxb_prior_eo_struct, check_report_lines
+    from dbat_amd.report import bundle_result_lines
+    s, ref = sxb_prior_eo_struct(use_prior_eo)
+    res, ok, iters, s0, E = o.bundle(s, 'gna')
+    assert ok and np.count_nonzero(res.prior.EO.use) == (12 if use_prior_eo else 0)
+    CIO, CEO, COP = o.bundle_cov(res, E, 'CIO', 'CEO', 'COP')
+    lines = [l.replace('(Photogrammetry) model 2', '(Photogrammetry) model 1') for l in bundle_result_lines(res, E, CIO, CEO, COP)]
+    n = check_report_lines(lines, ref_path=ref, demo_x0=True, x0_tol=1e-4)
+    assert len(lines) >= 430 and n >= len(lines) - 2
+
+
 def test_sxb_script_known_answer():
     """data/script/sxb: control points as weighted prior observations, check
     points, two image-point standard deviations, fixed camera, coordinates of
