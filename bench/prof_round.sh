@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof5
+O=$R/gpurun_out/prof6
 mkdir -p $O
 cd $R
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o r01d -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_stdout.json 2> $O/kt.err; echo kt rc=$?

@@ -401,9 +401,9 @@ struct Core {
             unsigned long long h[16];
             HIPCHK(hipStreamSynchronize(stream));
             HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tile2_prof), sizeof(h)));
-            static const char *nm[10] = {"stage(wait freed+restore)", "P1", "pbarrier", "P2", "P3", "drain", "cons wait full", "cons mfma", "tail/flush", "loop head"};
+            static const char *nm[12] = {"stage(wait freed)", "P1", "pbarrier", "P2", "P3", "drain", "cons wait full", "cons zero+free", "tail/flush", "loop head", "cons product", "cons wait done"};
             fprintf(stderr, "[tile2 prof, us per tile avg over %d tiles]", (int)ntiles);
-            for (int i = 0; i < 10; ++i) fprintf(stderr, " %s=%.2f", nm[i], h[i] * 0.01 / (double)std::max<int64_t>(ntiles, 1));
+            for (int i = 0; i < 12; ++i) fprintf(stderr, " %s=%.2f", nm[i], h[i] * 0.01 / (double)std::max<int64_t>(ntiles, 1));
             fprintf(stderr, "\n");
             memset(h, 0, sizeof(h));
             HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_tile2_prof), h, sizeof(h)));

@@ -1286,7 +1286,7 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
     double pmin = 1e300, pmax = 0.0, rr = 0.0;
     __syncthreads();
     const bool prof = (d.ablate & 32) && lane == 0 && wave == 0;
-    long long tp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = prof ? wall_clock64() : 0;
+    long long tp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = prof ? wall_clock64() : 0;
     auto lap = [&](int i) { if (prof) { const long long now = wall_clock64(); tp[i] += now - tlast; tlast = now; } };
     if (producer) {
         int nchunk = 0;                              // chunks handed over so far (panel = nchunk % NBUF)
@@ -1570,12 +1570,15 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
                             acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(yr[yoff[q]], wr[woff[q]], acc[q], 0, 0, 0);
                 }
             }
+            lap(10);
             // every consumer wave has read the panel -> zero it (a quarter per wave) -> hand it back
             lds_signal(&sy.done[s]);
             if (!lds_wait_ge(&sy.done[s], 4 * (u + 1), &sy.abort_)) break;
-            {
-                double *Zw = pan + s * PANEL + wave * (PANEL / 4);
-                for (int i = lane; i < PANEL / 4; i += 64) Zw[i] = 0.0;
+            lap(11);
+            {   // 16 bytes per lane and instruction: half as many trips through the LDS queue
+                static_assert((PANEL / 4) % 2 == 0 && (PANEL * sizeof(double)) % 64 == 0, "panel quarters are 16-byte aligned");
+                double2 *Zw = reinterpret_cast<double2 *>(pan + s * PANEL + wave * (PANEL / 4));
+                for (int i = lane; i < PANEL / 8; i += 64) Zw[i] = double2{0.0, 0.0};
             }
             lds_signal(&sy.freed[s]);
             lap(7);
@@ -1604,7 +1607,7 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
     if (prof) {
         const int base = producer ? 0 : 0;
 #pragma unroll
-        for (int i = 0; i < 10; ++i) if (tp[i]) atomicAdd(&g_tile2_prof[base + i], (unsigned long long)tp[i]);
+        for (int i = 0; i < 12; ++i) if (tp[i]) atomicAdd(&g_tile2_prof[base + i], (unsigned long long)tp[i]);
     }
     // ---- reduced right-hand side: -(W V^-1 g_p) of this tile (all 512 threads)
     for (int i = t; i < nrows; i += 512) {
