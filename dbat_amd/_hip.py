@@ -179,6 +179,13 @@ def problem_from_struct(s, device=0, shard_rank=0, shard_count=1):
     dm = np.unique(s.IO.model.distModel)
     if dm.size != 1:
         raise ValueError('Mixed lens distortion models not implemented.')   # brown_euler_cam4.m:31-33
+    model = int(dm[0])
+    if model == 1:
+        # legacy model 1 = the model that model 2 replicates (bundle.m:49-51); the library
+        # implements 2..5, so a model-1 project runs as model 2
+        if np.any(np.asarray(s.IO.val)[3:5] != 0) or np.any(np.asarray(s.bundle.est.IO)[3:5]):
+            raise ValueError('lens distortion model 1 has no aspect/skew')
+        model = 2
     if npnt >= 2 ** 31 or nc >= 2 ** 31:
         raise ValueError('too many points/images for int32 indices')
     keep = dict(
@@ -197,7 +204,7 @@ def problem_from_struct(s, device=0, shard_rank=0, shard_count=1):
     p = Problem()
     p.abi_version = ABI_VERSION
     p.n_images, p.n_points, p.n_obs = nc, npnt, no
-    p.dist_model, p.nK, p.nP = int(dm[0]), int(s.IO.model.nK), int(s.IO.model.nP)
+    p.dist_model, p.nK, p.nP = model, int(s.IO.model.nK), int(s.IO.model.nP)
     for k, v in keep.items():
         ptr_t = dict(Problem._fields_)[k]
         setattr(p, k, v.ctypes.data_as(ptr_t))

@@ -750,8 +750,15 @@ def brown_euler_cam4(x, s, jac=False):
     if len(dm) != 1:
         raise ValueError('Mixed lens distortion models not implemented.')  # :31-33
     model = int(dm[0])
+    if model == 1:
+        # the legacy model 1 is the model the flexible model 2 replicates (bundle.m:49-51:
+        # "2 - Flexible Photogrammetry, no affine (replica of 1)"; the committed camcal
+        # reports of both agree to every printed digit): evaluated as model 2
+        if np.any(np.asarray(s.IO.val)[3:5] != 0) or np.any(np.asarray(s.bundle.est.IO)[3:5]):
+            raise ValueError('lens distortion model 1 has no aspect/skew')
+        model = 2
     if model not in (2, 3, 4, 5):
-        raise ValueError('oracle restates distModel 2..5 only')
+        raise ValueError('oracle restates distModel 1..5 only')
     ix = s.post.res.ix
     f = np.full(ix.n, np.nan)
     if not jac:

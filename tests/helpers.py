@@ -286,13 +286,13 @@ def prague_struct(label):
     PhotoModeler export with its loaded, fixed camera; control points from
     the reference file, shifted by the mean offset to PhotoModeler's frame
     (:150-166), fixed or weighted; EO by resection, OP by forward intersection.
-    The demo runs lens model 1, which is numerically model 2 (bundle.m:49-51,
-    and the committed camcal reports of both: sigma0 1.68901); model 2 here.
-    Returns (s, path of the committed report)."""
+    The demo runs the legacy lens model 1 (prob2dbatstruct's default), the model
+    that model 2 replicates (bundle.m:49-51); oracle and library evaluate it as
+    model 2.  Returns (s, path of the committed report)."""
     from dbat_amd import initial as I
     site, stub, weighted = PRAGUE[label]
     prob = L.loadpm(_golden_path('prague-%s-%s-pmexport.txt' % (site, stub)))
-    s = L.prob2dbatstruct(prob, distModel=2)
+    s = L.prob2dbatstruct(prob, distModel=1)
     s.bundle.est.IO[:] = False                             # setcamvals 'loaded'; setcamest 'not','all'
     pts = L.loadcpt(os.path.join(GOLDEN, 'prague-%s-ctrlpts-%s.txt' % (site, 'weighted' if weighted else 'fixed')))
     pm = prob['ctrlPts']
@@ -316,7 +316,7 @@ def sxb_prior_eo_struct(use_prior_eo):
     ref/fake-camera-positions.txt (misc/setprioreo.m).  Returns (s, report)."""
     from dbat_amd import initial as I
     prob = L.loadpm(_golden_path('prague-sxb-wsmart-with-orient-pmexport.txt'))
-    s = L.prob2dbatstruct(prob, distModel=2)               # demo: model 1 == model 2 (bundle.m:49-51)
+    s = L.prob2dbatstruct(prob, distModel=1)               # the demo's model; evaluated as model 2 (bundle.m:49-51)
     s.bundle.est.IO[:] = False
     s = L.setcpt(s, L.loadcpt(os.path.join(GOLDEN, 'prague-sxb-ctrlpts-weighted.txt')))
     s.proj = type(s.post)(objUnit='m', x0desc='')

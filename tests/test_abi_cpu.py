@@ -79,8 +79,14 @@ def test_plan_rejects_bad_input():
     with pytest.raises(_hip.DbatHipError):
         _hip.plan(s)
     s, _ = synth_struct('tiny')
-    s.IO.model.distModel[:] = 1                # legacy model: outside the hot path
+    s.IO.model.distModel[:] = -1               # forward (computer vision) model: outside the hot path
     with pytest.raises(_hip.DbatHipError):
+        _hip.plan(s)
+    s, _ = synth_struct('tiny')
+    s.IO.model.distModel[:] = 1                # legacy model 1 runs as the model 2 that replicates it ...
+    assert _hip.plan(s)['n'] > 0
+    s.IO.val[3] = 1e-3                         # ... but has no aspect parameter
+    with pytest.raises(ValueError):
         _hip.plan(s)
     s, _ = synth_struct('tiny')
     s.bundle.est.IO[[5, 7]] = True             # K1,K3 without K2 (multi_res.m:182-186)

@@ -79,8 +79,7 @@ def test_prague2016_reports(label):
     res, ok, iters, s0, E = o.bundle(s, 'gna')
     assert ok
     CIO, CEO, COP = o.bundle_cov(res, E, 'CIO', 'CEO', 'COP')
-    # the demo runs the legacy lens model 1, numerically model 2 (bundle.m:49-51)
-    lines = [l.replace('(Photogrammetry) model 2', '(Photogrammetry) model 1') for l in bundle_result_lines(res, E, CIO, CEO, COP)]
+    lines = bundle_result_lines(res, E, CIO, CEO, COP)
     n = check_report_lines(lines, ref_path=ref, demo_x0=True)
     assert len(lines) >= 319 and n >= len(lines) - 1
 
@@ -97,7 +96,7 @@ def test_sxb_prior_eo_reports(use_prior_eo):
     res, ok, iters, s0, E = o.bundle(s, 'gna')
     assert ok and np.count_nonzero(res.prior.EO.use) == (12 if use_prior_eo else 0)
     CIO, CEO, COP = o.bundle_cov(res, E, 'CIO', 'CEO', 'COP')
-    lines = [l.replace('(Photogrammetry) model 2', '(Photogrammetry) model 1') for l in bundle_result_lines(res, E, CIO, CEO, COP)]
+    lines = bundle_result_lines(res, E, CIO, CEO, COP)
     n = check_report_lines(lines, ref_path=ref, demo_x0=True, x0_tol=1e-4)
     assert len(lines) >= 430 and n >= len(lines) - 2
 
