@@ -96,7 +96,7 @@ def main():
     # the committed result file of camcaldemo itself (an output of the reference: data, not source)
     shutil.copy(os.path.join(REF, 'dbatexports/camcal-dbatreport.txt'), os.path.join(HERE, 'camcal-dbatreport.txt'))
     exp = {'model3': parse_report(os.path.join(REF, 'dbatexports/camcal-dbatreport.txt'))}
-    for m in (2, 4, 5):
+    for m in (1, 2, 4, 5):
         exp['model%d' % m] = parse_report(
             os.path.join(REF, 'dbatexports/camcal-dbatreport-model%d.txt' % m))
         # kept whole as well, for the line-by-line comparison of the other lens models

@@ -678,7 +678,7 @@ def test_report_lines_hip(hip):
     assert check_report_lines(lines) >= len(lines) - 10
 
 
-@pytest.mark.parametrize('model,damping', [(3, 'gna'), (3, 'lmp'), (2, 'gna'), (4, 'gna'), (5, 'gna')])
+@pytest.mark.parametrize('model,damping', [(3, 'gna'), (3, 'lmp'), (1, 'gna'), (2, 'gna'), (4, 'gna'), (5, 'gna')])
 def test_camcal_demo_pipeline_hip(hip, model, damping):
     """The whole demo/camcaldemo.m pipeline -- EXIF camera, 3-point resection,
     forward intersection (dbat_amd.initial) -- then the bundle on the GPU.  From

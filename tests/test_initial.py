@@ -82,7 +82,7 @@ def test_forwintersect_exact_and_skip_prior():
     assert np.isnan(t.OP.val[:, 5:]).all()
 
 
-@pytest.mark.parametrize('model', [2, 3, 4, 5])
+@pytest.mark.parametrize('model', [1, 2, 3, 4, 5])
 def test_camcal_demo_pipeline_known_answer(model):
     """The whole camcaldemo: resection + forward intersection + GNA bundle.
     camcal-dbatreport.txt:39-43: 9 iterations, first error 30873.9, last 98.556;
