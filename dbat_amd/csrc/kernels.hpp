@@ -1262,7 +1262,7 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
                                                      // camera side, J_c'J_c and J_c'r, is k_cam_normal's)
     __shared__ double sh[16];
     __shared__ Tile2Sync sy;
-    __shared__ int64_t bs_sh[64];                    // batch_start of this tile's batches (a tile is capped at 16)
+    __shared__ int64_t bs_sh[64];                    // batch_start of this tile's first 64 batches (a tile is capped at 48)
     const int t = threadIdx.x, lane = t & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(t >> 6);
     const bool producer = wave8 < 4;
