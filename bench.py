@@ -139,7 +139,8 @@ def main():
         # rank's shard.  k_build fuses K1,K3,K4 (HBM side: 40*no + 24*np + 48*nc +
         # 8*NS^2 bytes) with the Schur contraction K5 (sum_p 108*k_p + 216*k_p^2
         # flops); the larger of the two lower-bound times names its roof.
-        kname_t = ('k_build_tile2' if info['ncolmax'] <= 14 else 'k_build_tile') if info['n_tiles'] > 0 else 'k_build'
+        tile3 = info['ncolmax'] <= 6 and os.environ.get('DBAT_HIP_TILE3', '1') != '0' and 'DBAT_HIP_TILE_BMAX' not in os.environ
+        kname_t = (('k_build_tile3' if tile3 else 'k_build_tile2') if info['ncolmax'] <= 14 else 'k_build_tile') if info['n_tiles'] > 0 else 'k_build'
         no_s, np_s = info['n_obs_shard'], info['n_pts_shard']
         kp = np.bincount(s.IP.pt, minlength=npnt).astype(np.float64)
         flops_schur = float(np.sum(108.0 * kp + 216.0 * kp * kp)) * (no_s / max(no, 1))

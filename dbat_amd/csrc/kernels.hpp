@@ -1629,6 +1629,316 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
     }
 }
 
+// ---------------------------------------------------------------- K1t3 --
+// Fixed-IO variant of k_build_tile2 with TWO producer groups (waves 0-3 and 4-7) in front of
+// the four consumer waves (8-11): group g evaluates the batches b0+g, b0+g+2, ... of the tile,
+// so two batches are in flight per CU and the latency chain of one (camera gathers, the
+// evaluation, the 3x3 inverses) hides behind the other.  The chunk numbers are fixed in
+// advance -- chunk0[b] = chunks of the tile's earlier batches, from the point counts of the
+// batches -- so both groups fill the same ring of NBUF panels in a fixed order and the consumers
+// take the chunks in that order.  Per group: its own point sums (cleared by the leaders that read
+// them), V^-1 g | R records and barrier counter.
+struct Tile3Sync { int full[4], done[4], freed[4], ks[4], pbar[2], abort_, chunk0[65], npts[65]; };
+
+template <int MODEL, int PC, int NBUF>
+__global__ __launch_bounds__(768) void k_build_tile3(DevProblem d, const double *__restrict__ z,
+                                                     const CamRec *__restrict__ cams, double lambda, int scale,
+                                                     double *__restrict__ S, double *__restrict__ g_red,
+                                                     double *__restrict__ Vinv, double *__restrict__ gp,
+                                                     double *__restrict__ jn2p, double *__restrict__ r_w,
+                                                     double *__restrict__ partial,
+                                                     unsigned long long *__restrict__ pivmm) {
+    constexpr int NCX = 6;
+    constexpr int KC = 3 * PC, LD = TILE_LD, PANEL = KC * LD;
+    constexpr int NPROD = 256, NT = 768, PW = 9;     // PW: V^-1 g (3) | R (6) per point
+    extern __shared__ double smem[];
+    double *pan = smem;                              // [NBUF][KC*LD]  Z = W R panels
+    double *red = pan + NBUF * PANEL;                // [2 groups][NPROD/2][9]  sum of B'B | B'r per point
+    double *pinv = red + (size_t)NPROD * 9;          // [2 groups][NPROD/2][PW]
+    double *vt = pinv + (size_t)NPROD * PW;          // [LD]  -(W V^-1 g_p) by local row
+    __shared__ double sh[16];
+    __shared__ Tile3Sync sy;
+    __shared__ int64_t bs_sh[66];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave12 = __builtin_amdgcn_readfirstlane(t >> 6);
+    const bool producer = wave12 < 8;
+    const int grp = wave12 >> 2;                     // producer group 0/1 (consumers: 2)
+    const int wave = wave12 & 3;
+    const int tl = t & 255;                          // lane of the batch
+    const int tile = d.tile_order[blockIdx.x];
+    const int b0 = d.tile_batch[tile], b1 = d.tile_batch[tile + 1];
+    const int c0 = d.tile_cam_start[tile];
+    const int ncam = d.tile_cam_start[tile + 1] - c0;
+    const int nrows = 6 * ncam;
+    const int nbt = b1 - b0;                         // plan: at most 64 batches per tile for this kernel
+    for (int i = t; i <= nbt && i <= 65; i += NT) bs_sh[i] = d.batch_start[b0 + i];
+    for (int i = t; i < NBUF * PANEL + NPROD * 9; i += NT) pan[i] = 0.0;
+    for (int i = t; i < LD; i += NT) vt[i] = 0.0;
+    if (t < NBUF) { sy.full[t] = 0; sy.done[t] = 0; sy.freed[t] = 0; sy.ks[t] = 0; }
+    if (t == 0) { sy.pbar[0] = sy.pbar[1] = 0; sy.abort_ = 0; }
+    __syncthreads();
+    if (t == 0) {                                    // chunk numbering of the tile
+        int c = 0;
+        for (int i = 0; i < nbt; ++i) {
+            sy.chunk0[i] = c;
+            const int npts_i = d.o_pidx[bs_sh[i + 1] - 1] + 1;      // points of the batch = last observation's point slot + 1
+            sy.npts[i] = npts_i;
+            c += (npts_i + PC - 1) / PC;
+        }
+        sy.chunk0[nbt] = c;
+    }
+    mfma_d4 acc[9];
+#pragma unroll
+    for (int s = 0; s < 9; ++s) acc[s] = mfma_d4{0, 0, 0, 0};
+    double pmin = 1e300, pmax = 0.0, rr = 0.0;
+    __syncthreads();
+    if (producer) {
+        double *redg = red + (size_t)grp * (NPROD / 2) * 9;
+        double *pinvg = pinv + (size_t)grp * (NPROD / 2) * PW;
+        int pbar_gen = 0;
+        bool ok = true;
+        auto pbarrier = [&]() -> bool {
+            lds_signal(&sy.pbar[grp]); ++pbar_gen;
+            return lds_wait_ge(&sy.pbar[grp], 4 * pbar_gen, &sy.abort_);
+        };
+        int hn_cam = 0, hn_pt = 0, hn_lc = 0, hn_pidx = 0; uint32_t hn_sg = 0; double hn_u = 0, hn_v = 0;
+        double qn[3] = {0, 0, 0}, pwn[3] = {0, 0, 0};
+        unsigned estr0 = 0, estr1 = 0, estr2 = 0;
+        auto fetch_header = [&](int bb) {
+            if (bb >= b1) return;
+            const int64_t oo0 = bs_sh[bb - b0];
+            if (tl < (int)(bs_sh[bb + 1 - b0] - oo0)) {
+                const int64_t oo = oo0 + tl;
+                hn_cam = d.o_cam[oo]; hn_pt = d.o_pt[oo]; hn_lc = d.o_lc[oo]; hn_pidx = d.o_pidx[oo];
+                hn_sg = d.o_seg[oo]; hn_u = d.o_uv[2 * oo]; hn_v = d.o_uv[2 * oo + 1];
+            }
+        };
+        auto fetch_point = [&](int bb) {
+            if (bb >= b1) return;
+            if (tl < (int)(bs_sh[bb + 1 - b0] - bs_sh[bb - b0])) {
+                const int64_t zp = d.NS + 3 * (int64_t)hn_pt;
+                qn[0] = z[zp]; qn[1] = z[zp + 1]; qn[2] = z[zp + 2];
+                estr0 = d.z_est[zp]; estr1 = d.z_est[zp + 1]; estr2 = d.z_est[zp + 2];
+                if (tl == (int)(hn_sg & 0xFFFF)) { pwn[0] = d.z_prw[zp]; pwn[1] = d.z_prw[zp + 1]; pwn[2] = d.z_prw[zp + 2]; }
+            }
+        };
+        fetch_header(b0 + grp);
+        fetch_point(b0 + grp);
+        for (int b = b0 + grp; b < b1 && ok; b += 2) {
+            const int64_t o0 = bs_sh[b - b0];
+            const int nobs = (int)(bs_sh[b + 1 - b0] - o0);
+            const bool active = tl < nobs;
+            const int64_t o = o0 + tl;
+            double r[2] = {0, 0};
+            double E[2][NCX];
+            double B[2][3];
+            const int cam = hn_cam, pt = hn_pt, lc = hn_lc, pidx = hn_pidx;
+            const int seg_start = hn_sg & 0xFFFF;
+            const double uu = hn_u, vv = hn_v;
+            const double Q[3] = {qn[0], qn[1], qn[2]};
+            const double pw3[3] = {pwn[0], pwn[1], pwn[2]};
+            const unsigned est = (estr0 ? 1u : 0u) | (estr1 ? 2u : 0u) | (estr2 ? 4u : 0u);
+            const int npts = sy.npts[b - b0];
+            fetch_header(b + 2);
+            if (active) {                            // ---- P1
+                const CamRec &C = cams[cam];
+                const double w0 = d.o_w ? d.o_w[2 * o] : C.w[0], w1 = d.o_w ? d.o_w[2 * o + 1] : C.w[1];
+                eval_obs_pre<MODEL, NCX>(d, C, Q, uu, vv, w0, w1, est, r, E, B);
+                r_w[2 * o] = r[0]; r_w[2 * o + 1] = r[1];
+                rr += r[0] * r[0] + r[1] * r[1];
+                double *ps = redg + (size_t)pidx * 9;
+                atomic_add_f64(ps + 0, B[0][0] * B[0][0] + B[1][0] * B[1][0]);
+                atomic_add_f64(ps + 1, B[0][0] * B[0][1] + B[1][0] * B[1][1]);
+                atomic_add_f64(ps + 2, B[0][0] * B[0][2] + B[1][0] * B[1][2]);
+                atomic_add_f64(ps + 3, B[0][1] * B[0][1] + B[1][1] * B[1][1]);
+                atomic_add_f64(ps + 4, B[0][1] * B[0][2] + B[1][1] * B[1][2]);
+                atomic_add_f64(ps + 5, B[0][2] * B[0][2] + B[1][2] * B[1][2]);
+                atomic_add_f64(ps + 6, B[0][0] * r[0] + B[1][0] * r[1]);
+                atomic_add_f64(ps + 7, B[0][1] * r[0] + B[1][1] * r[1]);
+                atomic_add_f64(ps + 8, B[0][2] * r[0] + B[1][2] * r[1]);
+            }
+            fetch_point(b + 2);
+            if (!pbarrier()) { ok = false; break; }
+            if (active && tl == seg_start) {         // ---- P2
+                double *ps = redg + (size_t)pidx * 9;
+                double V[6] = {ps[0], ps[1], ps[2], ps[3], ps[4], ps[5]}, g[3] = {ps[6], ps[7], ps[8]};
+#pragma unroll
+                for (int k = 0; k < 9; ++k) ps[k] = 0.0;     // the group's next batch starts from zero
+                const int64_t zp = d.NS + 3 * (int64_t)pt;
+                const int dix[3] = {0, 3, 5};
+                double jn[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const double pw = pw3[k];
+                    if (pw > 0) { V[dix[k]] += pw; g[k] += pw * (Q[k] - d.z_prv[zp + k]); }
+                    jn[k] = V[dix[k]];
+                    jn2p[3 * (int64_t)pt + k] = jn[k];
+                    if ((est >> k) & 1u) V[dix[k]] += lambda; else V[dix[k]] = 1.0;
+                }
+                double inv[6];
+                {
+                    const double c00 = V[3] * V[5] - V[4] * V[4];
+                    const double c01 = V[2] * V[4] - V[1] * V[5];
+                    const double c02 = V[1] * V[4] - V[2] * V[3];
+                    const double det = V[0] * c00 + V[1] * c01 + V[2] * c02;
+                    const double id = fast_rcp(det);
+                    inv[0] = c00 * id; inv[1] = c01 * id; inv[2] = c02 * id;
+                    inv[3] = (V[0] * V[5] - V[2] * V[2]) * id;
+                    inv[4] = (V[1] * V[2] - V[0] * V[4]) * id;
+                    inv[5] = (V[0] * V[3] - V[1] * V[1]) * id;
+                    const double r0 = fast_rcp(V[0]);
+                    const double d1s = V[3] - V[1] * V[1] * r0;
+                    const double tt = V[4] - V[2] * V[1] * r0;
+                    const double d2s = V[5] - V[2] * V[2] * r0 - tt * tt * fast_rcp(d1s);
+                    const double dd[3] = {V[0], d1s, d2s};
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        if ((est >> k) & 1u) {
+                            double v = scale ? dd[k] * fast_rcp(jn[k]) : dd[k];
+                            v = v > 0.0 ? v : 0.0;
+                            pmin = fmin(pmin, v); pmax = fmax(pmax, v);
+                        }
+                }
+                double *pi = pinvg + (size_t)pidx * PW;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) Vinv[6 * (int64_t)pt + k] = inv[k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) gp[3 * (int64_t)pt + k] = g[k];
+                pi[0] = inv[0] * g[0] + inv[1] * g[1] + inv[2] * g[2];        // h = V^-1 g
+                pi[1] = inv[1] * g[0] + inv[3] * g[1] + inv[4] * g[2];
+                pi[2] = inv[2] * g[0] + inv[4] * g[1] + inv[5] * g[2];
+                {   // V^-1 = R R', R lower triangular
+                    const double r00 = sqrt(inv[0]), ir00 = fast_rcp(r00);
+                    const double r10 = inv[1] * ir00, r20 = inv[2] * ir00;
+                    const double r11 = sqrt(inv[3] - r10 * r10);
+                    const double r21 = (inv[4] - r20 * r10) * fast_rcp(r11);
+                    const double r22 = sqrt(inv[5] - r20 * r20 - r21 * r21);
+                    pi[3] = r00; pi[4] = r10; pi[5] = r20; pi[6] = r11; pi[7] = r21; pi[8] = r22;
+                }
+            }
+            if (!pbarrier()) { ok = false; break; }
+            double nr0 = 0, nr1 = 0, nr2 = 0, nr3 = 0, nr4 = 0, nr5 = 0;
+            if (active) {                            // ---- P3: -(W V^-1 g)
+                const double *pi = pinvg + (size_t)pidx * PW;
+                const double h0 = pi[0], h1 = pi[1], h2 = pi[2];
+                nr0 = pi[3]; nr1 = pi[4]; nr2 = pi[5]; nr3 = pi[6]; nr4 = pi[7]; nr5 = pi[8];
+#pragma unroll
+                for (int a = 0; a < NCX; ++a) {
+                    const double w0 = E[0][a] * B[0][0] + E[1][a] * B[1][0];
+                    const double w1 = E[0][a] * B[0][1] + E[1][a] * B[1][1];
+                    const double w2 = E[0][a] * B[0][2] + E[1][a] * B[1][2];
+                    atomic_add_f64(vt + 6 * lc + a, -(w0 * h0 + w1 * h1 + w2 * h2));
+                }
+            }
+            // ---- P4: Z = W R, chunk by chunk, into the ring of panels in the tile's chunk order
+            int nchunk = sy.chunk0[b - b0];
+            for (int p0 = 0; p0 < npts && ok; p0 += PC, ++nchunk) {
+                const int s = nchunk % NBUF, u = nchunk / NBUF;
+                double *Zt = pan + s * PANEL;
+                if (u > 0) {
+                    // the panel's previous chunk has been multiplied by all four consumer waves:
+                    // this group clears it (the consumers no longer do) and then fills it
+                    if (!lds_wait_ge(&sy.freed[s], 4 * u, &sy.abort_)) { ok = false; break; }
+                    double2 *Zw = reinterpret_cast<double2 *>(Zt);
+                    for (int i = tl; i < PANEL / 2; i += NPROD) Zw[i] = double2{0.0, 0.0};
+                    if (!pbarrier()) { ok = false; break; }
+                }
+                if (active && pidx >= p0 && pidx < p0 + PC) {
+                    const int kb = 3 * (pidx - p0);
+#pragma unroll
+                    for (int a = 0; a < NCX; ++a) {
+                        const int row = 6 * lc + a;
+                        const double w0 = E[0][a] * B[0][0] + E[1][a] * B[1][0];
+                        const double w1 = E[0][a] * B[0][1] + E[1][a] * B[1][1];
+                        const double w2 = E[0][a] * B[0][2] + E[1][a] * B[1][2];
+                        Zt[(kb + 0) * LD + row] = w0 * nr0 + w1 * nr1 + w2 * nr2;
+                        Zt[(kb + 1) * LD + row] = w1 * nr3 + w2 * nr4;
+                        Zt[(kb + 2) * LD + row] = w2 * nr5;
+                    }
+                }
+                if (tl == 0) sy.ks[s] = (3 * min(PC, npts - p0) + 3) >> 2;
+                lds_signal(&sy.full[s]);
+            }
+            if (!ok) break;
+        }
+        // terminating chunk: by the group that owns the tile's last batch (after its last chunk)
+        if (((nbt - 1) & 1) == grp) {
+            const int nchunk = sy.chunk0[nbt];
+            const int s = nchunk % NBUF, u = nchunk / NBUF;
+            if (ok && u > 0) ok = lds_wait_ge(&sy.freed[s], 4 * u, &sy.abort_);
+            if (tl == 0) sy.ks[s] = -1;
+            lds_signal(&sy.full[s]);
+        }
+        if (!ok) rr = __longlong_as_double(0x7ff8000000000000ll);
+    } else {
+        // ---- consumers (waves 8-11): as in k_build_tile2
+        const bool full_tile = 16 * (7 - wave) < nrows;
+        int yoff[9], woff[9];
+        bool ton[9];
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            const int rt = s <= wave ? wave : 7 - wave;
+            const int ct = s <= wave ? s : s - wave - 1;
+            yoff[s] = 16 * rt; woff[s] = 16 * ct; ton[s] = 16 * rt < nrows;
+        }
+        for (int n = 0;; ++n) {
+            const int s = n % NBUF, u = n / NBUF;
+            if (!lds_wait_ge(&sy.full[s], 4 * (u + 1), &sy.abort_)) break;
+            const int ksteps = __hip_atomic_load(&sy.ks[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (ksteps < 0) break;
+            const double *Zt = pan + s * PANEL;
+            if (full_tile) {
+                switch (wave) {
+                    case 0: tile_syrk_steps<0>(Zt, lane, ksteps, acc); break;
+                    case 1: tile_syrk_steps<1>(Zt, lane, ksteps, acc); break;
+                    case 2: tile_syrk_steps<2>(Zt, lane, ksteps, acc); break;
+                    default: tile_syrk_steps<3>(Zt, lane, ksteps, acc); break;
+                }
+            } else {
+                for (int kk = 0; kk < ksteps; ++kk) {
+                    const int krow = 4 * kk + (lane >> 4);
+                    const double *yr = Zt + krow * LD + (lane & 15);
+                    const double *wr = yr;
+#pragma unroll
+                    for (int q = 0; q < 9; ++q)
+                        if (ton[q])
+                            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(yr[yoff[q]], wr[woff[q]], acc[q], 0, 0, 0);
+                }
+            }
+            lds_signal(&sy.freed[s]);                // read; the next producer group clears and refills it
+        }
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            if (ton[s]) {
+                const int lcol = woff[s] + (lane & 15);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int lr = yoff[s] + (lane >> 4) + 4 * e;
+                    const double v = acc[s][e];
+                    if (lr < nrows && lcol <= lr && v != 0.0)
+                        atomic_add_f64(S + (6 * (int64_t)d.tile_cams[c0 + lcol / 6] + lcol % 6) * d.ldS
+                                         + 6 * (int64_t)d.tile_cams[c0 + lr / 6] + lr % 6, -v);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < nrows; i += NT)
+        atomic_add_f64(g_red + 6 * (int64_t)d.tile_cams[c0 + i / 6] + i % 6, vt[i]);
+    double accr[1] = {rr};
+    block_sum<1>(accr, sh);
+    if (t == 0) partial[blockIdx.x] = accr[0];
+    pmin = pmin < 1e300 ? sqrt(pmin) : pmin; pmax = sqrt(pmax);
+    for (int off = 32; off > 0; off >>= 1) {
+        pmin = fmin(pmin, __shfl_down(pmin, off, 64));
+        pmax = fmax(pmax, __shfl_down(pmax, off, 64));
+    }
+    if ((t & 63) == 0 && pmax > 0.0) {
+        atomicMin(pivmm, (unsigned long long)__double_as_longlong(pmin));
+        atomicMax(pivmm + 1, (unsigned long long)__double_as_longlong(pmax));
+    }
+}
+
 // ------------------------------------------------------- posterior cov ---
 // bundle_cov.m: blocks of C = s0^2 inv(J'J).  With the points eliminated,
 //   inv(J'J)[cams, cams] = inv(S)                         (CEO, CIO)
