@@ -254,14 +254,14 @@ struct Core {
                 SET_LDS((k_build_tile2<4, 6, TILE2_PC, TILE2_NBUF>), lds_tile2); SET_LDS((k_build_tile2<5, 6, TILE2_PC, TILE2_NBUF>), lds_tile2);
             }
         }
-        lds_tile3 = ((size_t)TILE2_NBUF * 3 * TILE2_PC * TILE_LD + (size_t)256 * 9 + (size_t)256 * 9 + TILE_LD) * sizeof(double);
+        lds_tile3 = ((size_t)TILE3_NBUF * 3 * TILE3_PC * TILE_LD + (size_t)256 * 9 + (size_t)256 * 9 + TILE_LD) * sizeof(double);
         // fixed IO: the variant with two producer groups (DBAT_HIP_TILE3=0 selects k_build_tile2);
         // it holds at most 64 batch offsets per tile, the plan's default cap is 48
         use_tile3 = use_tile2 && !P.with_io && !(getenv("DBAT_HIP_TILE3") && atoi(getenv("DBAT_HIP_TILE3")) == 0)
                     && getenv("DBAT_HIP_TILE_BMAX") == nullptr;
         if (use_tile3) {
-            SET_LDS((k_build_tile3<2, TILE2_PC, TILE2_NBUF>), lds_tile3); SET_LDS((k_build_tile3<3, TILE2_PC, TILE2_NBUF>), lds_tile3);
-            SET_LDS((k_build_tile3<4, TILE2_PC, TILE2_NBUF>), lds_tile3); SET_LDS((k_build_tile3<5, TILE2_PC, TILE2_NBUF>), lds_tile3);
+            SET_LDS((k_build_tile3<2, TILE3_PC, TILE3_NBUF>), lds_tile3); SET_LDS((k_build_tile3<3, TILE3_PC, TILE3_NBUF>), lds_tile3);
+            SET_LDS((k_build_tile3<4, TILE3_PC, TILE3_NBUF>), lds_tile3); SET_LDS((k_build_tile3<5, TILE3_PC, TILE3_NBUF>), lds_tile3);
         }
         {
             const size_t lds_cov = ((size_t)P.BT * P.ncolmax * 3 + (size_t)P.BT * 6) * sizeof(double);
@@ -383,7 +383,7 @@ struct Core {
             }
 #undef L_CAMN
             mark(0);                                 // events around the tile kernel alone (bench roofline)
-#define L_TILE3(M, DUMMY) hipLaunchKernelGGL((k_build_tile3<M, TILE2_PC, TILE2_NBUF>), dim3((unsigned)ntiles), dim3(768), lds_tile3, stream, d, zz, cams.p, lambda, scale, S, g_red, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p, pivmm.p)
+#define L_TILE3(M, DUMMY) hipLaunchKernelGGL((k_build_tile3<M, TILE3_PC, TILE3_NBUF>), dim3((unsigned)ntiles), dim3(768), lds_tile3, stream, d, zz, cams.p, lambda, scale, S, g_red, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p, pivmm.p)
             if (use_tile3 && tile_ncx == 6) { DISPATCH_MODEL(L_TILE3, 0) }
             else if (use_tile2 && tile_ncx == 6) { DISPATCH_MODEL(L_TILE2, 6) }
             else if (use_tile2 && tile_ncx == 14) { DISPATCH_MODEL(L_TILE2, 14) }

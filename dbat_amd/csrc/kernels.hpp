@@ -1638,6 +1638,13 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
 // batches -- so both groups fill the same ring of NBUF panels in a fixed order and the consumers
 // take the chunks in that order.  Per group: its own point sums (cleared by the leaders that read
 // them), V^-1 g | R records and barrier counter.
+#ifndef DBAT_TILE3_PC
+#define DBAT_TILE3_PC 16
+#endif
+#ifndef DBAT_TILE3_NBUF
+#define DBAT_TILE3_NBUF 2
+#endif
+constexpr int TILE3_PC = DBAT_TILE3_PC, TILE3_NBUF = DBAT_TILE3_NBUF;   // points per chunk, panels in the ring
 struct Tile3Sync { int full[4], done[4], freed[4], ks[4], pbar[2], abort_, chunk0[65], npts[65]; };
 
 template <int MODEL, int PC, int NBUF>
