@@ -851,3 +851,35 @@ def test_sxb_prior_eo_reports_hip(hip, use_prior_eo):
     lines = bundle_result_lines(res, E, CIO, CEO, COP)
     n = check_report_lines(lines, ref_path=ref, demo_x0=True, x0_tol=1e-4)
     assert len(lines) >= 430 and n >= len(lines) - 2
+
+
+@pytest.mark.parametrize('knob', ['DBAT_HIP_TILE3=0', 'DBAT_HIP_TILE_BMAX=3'])
+def test_fixed_io_single_producer_group_kernel(hip, knob, monkeypatch):
+    """Fixed-IO problems run k_build_tile3 (two producer groups) by default;
+    k_build_tile2 remains behind DBAT_HIP_TILE3=0 and when the tile length is
+    overridden: same step and the same bundle result as the oracle, and the
+    same step as the default kernel to rounding."""
+    from dbat_amd import bundle
+    s, truth = synth_struct('small', 'plain')
+    so, x0, w = oracle_setup(s)
+    R = np.sqrt(w)
+    r_o, K = o.brown_euler_cam4(x0, so, jac=True)
+    p_o, *_ = o._scaled_gn((sp.diags(R) @ K).tocsc(), R * r_o)
+    h = hip.Handle(s)
+    try:
+        p_default, _ = h.linearize_solve(x0, 0.0, True)
+    finally:
+        h.close()
+    name, val = knob.split('=')
+    monkeypatch.setenv(name, val)
+    h = hip.Handle(s)
+    try:
+        p_h, st = h.linearize_solve(x0, 0.0, True)
+    finally:
+        h.close()
+    assert relerr(p_h, p_o) < TOL_STEP and relerr(p_default, p_o) < TOL_STEP
+    assert relerr(p_h, p_default) < 1e-10
+    res, ok, iters, s0, E = bundle(s, 'lm')
+    monkeypatch.delenv(name)
+    ro, oko, ito, s0o, Eo = o.bundle(s, 'lm')
+    assert ok and oko and relerr(E.x, Eo.x) < TOL_X
