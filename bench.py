@@ -199,7 +199,19 @@ def main():
             out['cpu_baseline'] = cpu_baseline()
         else:
             out['cpu_baseline'] = None
-        print(json.dumps(out))
+    # RCCL writes a version banner through C stdio, which is block-buffered when stdout is a
+    # pipe and would otherwise land after the result: every rank flushes it, then rank 0 prints
+    # the JSON line as the last line of the job
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    sys.stdout.flush()
+    if comm is not None:
+        comm.barrier()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     h.close()
     if comm is not None:
         torch.distributed.destroy_process_group()
