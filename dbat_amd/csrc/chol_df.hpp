@@ -502,7 +502,7 @@ struct DataflowChol {
         if (hipMalloc(&d_flags, (size_t)(nT + 1) * nT * sizeof(int)) != hipSuccess) return false;
         if (hipMalloc(&d_ctl, 2 * sizeof(int)) != hipSuccess) return false;
         (void)hipMemset(d_flags, 0, (size_t)(nT + 1) * nT * sizeof(int));
-        if (const char *g = getenv("DBAT_HIP_DF_GRID")) grid = atoi(g);
+        if (const char *g = getenv("DBAT_HIP_DF_GRID")) grid = std::min(std::max(atoi(g), 1), 4096);
         epoch = 0;
         return true;
     }

@@ -30,6 +30,24 @@ struct DeviceError { std::string msg; };
             throw DeviceError{std::string(#expr) + ": " + hipGetErrorString(e_)};          \
     } while (0)
 
+// every kernel launch is checked: a launch rejected for its grid, LDS size or resources would
+// otherwise be skipped silently and the loops would carry on with stale buffers
+#define LAUNCHK(...)                                                                       \
+    do {                                                                                   \
+        hipLaunchKernelGGL(__VA_ARGS__);                                                   \
+        HIPCHK(hipGetLastError());                                                         \
+    } while (0)
+
+// RAII: make the handle's device current for the duration of an ABI call
+struct DeviceGuard {
+    int prev = -1, dev = -1;
+    explicit DeviceGuard(int device) : dev(device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) HIPCHK(hipSetDevice(dev));
+    }
+    ~DeviceGuard() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
+};
+
 template <class T>
 struct DevBuf {
     T *p = nullptr;
@@ -51,6 +69,7 @@ struct Core {
     Plan P;
     DevProblem d{};
     hipStream_t stream = nullptr;
+    int device = 0;
     rocblas_handle blas = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t kev[8] = {};      // per-kernel brackets, recorded only while timing is on
@@ -120,6 +139,7 @@ struct Core {
     }
 
     void init(const dbat_hip_problem &pb) {
+        device = pb.device;
         HIPCHK(hipSetDevice(pb.device));
         HIPCHK(hipStreamCreate(&stream));
         if (rocblas_create_handle(&blas) != rocblas_status_success) throw DeviceError{"rocblas_create_handle failed"};
@@ -235,7 +255,7 @@ struct Core {
 
     // grid of the grid-stride observation kernels: one resident round (k_residual: 6 waves/SIMD
     // of 4-wave workgroups on 256 CUs)
-    static int env_grid_obs() { const char *e = getenv("DBAT_HIP_GRID_OBS"); return e ? std::max(1, atoi(e)) : 1536; }
+    static int env_grid_obs() { const char *e = getenv("DBAT_HIP_GRID_OBS"); return e ? std::min(std::max(1, atoi(e)), 1 << 20) : 1536; }
     // kernels that use more than 64 KB of dynamic LDS must opt in
     void set_lds_limits() {
 #define SET_LDS(K, BYTES) HIPCHK(hipFuncSetAttribute((const void *)(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)))
@@ -287,11 +307,11 @@ struct Core {
         if (getenv("DBAT_HIP_DENSE_ALLREDUCE")) { do_allreduce(red.p, red_count); return; }
         const int64_t nvec = 3 * P.NS + 8;
         if (!pk.p) pk.alloc((size_t)(pk_s_count + nvec));
-        hipLaunchKernelGGL(k_pack_envelope, dim3((unsigned)P.NS), dim3(256), 0, stream, S, ldS, (int)P.NS, env_tail0,
+        LAUNCHK(k_pack_envelope, dim3((unsigned)P.NS), dim3(256), 0, stream, S, ldS, (int)P.NS, env_tail0,
                            col_bend.p, col_off.p, pk.p, 1);
         HIPCHK(hipMemcpyAsync(pk.p + pk_s_count, g_red, nvec * sizeof(double), hipMemcpyDeviceToDevice, stream));
         do_allreduce(pk.p, pk_s_count + nvec);
-        hipLaunchKernelGGL(k_pack_envelope, dim3((unsigned)P.NS), dim3(256), 0, stream, S, ldS, (int)P.NS, env_tail0,
+        LAUNCHK(k_pack_envelope, dim3((unsigned)P.NS), dim3(256), 0, stream, S, ldS, (int)P.NS, env_tail0,
                            col_bend.p, col_off.p, pk.p, 0);
         HIPCHK(hipMemcpyAsync(g_red, pk.p + pk_s_count, nvec * sizeof(double), hipMemcpyDeviceToDevice, stream));
     }
@@ -305,19 +325,19 @@ struct Core {
         sync();
     }
     void prep_cams(const double *zz) {
-        hipLaunchKernelGGL(k_cam_prep, dim3((unsigned)cdiv(P.nc, 64)), dim3(64), 0, stream, d, zz, cams.p);
+        LAUNCHK(k_cam_prep, dim3((unsigned)cdiv(P.nc, 64)), dim3(64), 0, stream, d, zz, cams.p);
     }
     void x_to_z(const double *x_host, double *z_dev) {
         // z keeps fixed entries; estimated entries overwritten from x
         HIPCHK(hipMemcpyAsync(z_dev, P.z0.data(), P.NZ * 8, hipMemcpyHostToDevice, stream));
         if (P.n) {
             HIPCHK(hipMemcpyAsync(xbuf.p, x_host, P.n * 8, hipMemcpyHostToDevice, stream));
-            hipLaunchKernelGGL(k_scatter_x, dim3((unsigned)cdiv(P.n, 256)), dim3(256), 0, stream, P.n, x2z.p, xbuf.p, z_dev);
+            LAUNCHK(k_scatter_x, dim3((unsigned)cdiv(P.n, 256)), dim3(256), 0, stream, P.n, x2z.p, xbuf.p, z_dev);
         }
     }
     void z_to_x(const double *z_dev, double *x_host) {
         if (!P.n) return;
-        hipLaunchKernelGGL(k_gather_x, dim3((unsigned)cdiv(P.n, 256)), dim3(256), 0, stream, P.n, x2z.p, z_dev, xbuf.p);
+        LAUNCHK(k_gather_x, dim3((unsigned)cdiv(P.n, 256)), dim3(256), 0, stream, P.n, x2z.p, z_dev, xbuf.p);
         HIPCHK(hipMemcpyAsync(x_host, xbuf.p, P.n * 8, hipMemcpyDeviceToHost, stream));
         sync();
     }
@@ -338,19 +358,19 @@ struct Core {
         // every value the damping loops compare); the point-major one only when residuals are exported
         int64_t npart_res = n_cm_chunks_all;
         if (n_cm_chunks_all > 0) {
-#define L_RESCM(M, dummy) hipLaunchKernelGGL((k_residual_cm<M>), dim3((unsigned)n_cm_chunks_all), dim3(256), 0, stream, d, zz, cams.p, cm_pt.p, cm_uv.p, P.uniform_w ? (const double *)nullptr : cm_w.p, cm_chunk_cam.p, cm_chunk_start.p, partial.p)
+#define L_RESCM(M, dummy) LAUNCHK((k_residual_cm<M>), dim3((unsigned)n_cm_chunks_all), dim3(256), 0, stream, d, zz, cams.p, cm_pt.p, cm_uv.p, P.uniform_w ? (const double *)nullptr : cm_w.p, cm_chunk_cam.p, cm_chunk_start.p, partial.p)
             DISPATCH_MODEL(L_RESCM, 0)
 #undef L_RESCM
         }
         mark(7);
-        hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(1024), 0, stream, partial.p, npart_res, scal.p, 0);
+        LAUNCHK((k_sum_partials<1>), dim3(1), dim3(1024), 0, stream, partial.p, npart_res, scal.p, 0);
         if (r_w_out || r_unw_out) {
-#define L_RES(M, dummy) hipLaunchKernelGGL((k_residual<M>), dim3(grid_obs), dim3(256), 0, stream, d, zz, cams.p, partial.p, r_w_out, r_unw_out)
+#define L_RES(M, dummy) LAUNCHK((k_residual<M>), dim3(grid_obs), dim3(256), 0, stream, d, zz, cams.p, partial.p, r_w_out, r_unw_out)
             DISPATCH_MODEL(L_RES, 0)
 #undef L_RES
         }
-        hipLaunchKernelGGL(k_prior_sq, dim3(grid_z), dim3(256), 0, stream, d, zz, partial.p);
-        hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_z, scal.p, 1);
+        LAUNCHK(k_prior_sq, dim3(grid_z), dim3(256), 0, stream, d, zz, partial.p);
+        LAUNCHK((k_sum_partials<1>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_z, scal.p, 1);
         do_allreduce(scal.p, 1);
         double s;
         read_scal(&s, 1);
@@ -374,16 +394,16 @@ struct Core {
         const int64_t nb_tiled = P.nb_tiled;
         if (ntiles > 0 && nb_tiled > 0) {
             npart = ntiles;
-#define L_TILE(M, NCXV) hipLaunchKernelGGL((k_build_tile<M, NCXV>), dim3((unsigned)ntiles), dim3(P.BT), lds_tile, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p, pivmm.p)
-#define L_TILE2(M, NCXV) hipLaunchKernelGGL((k_build_tile2<M, NCXV, TILE2_PC, TILE2_NBUF>), dim3((unsigned)ntiles), dim3(512), lds_tile2, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p, pivmm.p)
-#define L_CAMN(M, NCXV) hipLaunchKernelGGL((k_cam_normal<M, NCXV>), dim3((unsigned)n_cm_chunks), dim3(256), 0, stream, d, zz, cams.p, cm_pt.p, cm_uv.p, P.uniform_w ? (const double *)nullptr : cm_w.p, cm_chunk_cam.p, cm_chunk_start.p, S, g_c, g_red, diagU)
+#define L_TILE(M, NCXV) LAUNCHK((k_build_tile<M, NCXV>), dim3((unsigned)ntiles), dim3(P.BT), lds_tile, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p, pivmm.p)
+#define L_TILE2(M, NCXV) LAUNCHK((k_build_tile2<M, NCXV, TILE2_PC, TILE2_NBUF>), dim3((unsigned)ntiles), dim3(512), lds_tile2, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p, pivmm.p)
+#define L_CAMN(M, NCXV) LAUNCHK((k_cam_normal<M, NCXV>), dim3((unsigned)n_cm_chunks), dim3(256), 0, stream, d, zz, cams.p, cm_pt.p, cm_uv.p, P.uniform_w ? (const double *)nullptr : cm_w.p, cm_chunk_cam.p, cm_chunk_start.p, S, g_c, g_red, diagU)
             if (use_tile2 && tile_ncx <= 14 && n_cm_chunks > 0) {
                 // camera side of the tiled observations: J_c'J_c, J_c'r, squared column norms
                 if (tile_ncx == 6) { DISPATCH_MODEL(L_CAMN, 6) } else { DISPATCH_MODEL(L_CAMN, 14) }
             }
 #undef L_CAMN
             mark(0);                                 // events around the tile kernel alone (bench roofline)
-#define L_TILE3(M, DUMMY) hipLaunchKernelGGL((k_build_tile3<M, TILE3_PC, TILE3_NBUF>), dim3((unsigned)ntiles), dim3(768), lds_tile3, stream, d, zz, cams.p, lambda, scale, S, g_red, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p, pivmm.p)
+#define L_TILE3(M, DUMMY) LAUNCHK((k_build_tile3<M, TILE3_PC, TILE3_NBUF>), dim3((unsigned)ntiles), dim3(768), lds_tile3, stream, d, zz, cams.p, lambda, scale, S, g_red, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p, pivmm.p)
             if (use_tile3 && tile_ncx == 6) { DISPATCH_MODEL(L_TILE3, 0) }
             else if (use_tile2 && tile_ncx == 6) { DISPATCH_MODEL(L_TILE2, 6) }
             else if (use_tile2 && tile_ncx == 14) { DISPATCH_MODEL(L_TILE2, 14) }
@@ -397,14 +417,14 @@ struct Core {
         const bool no_tiles = !(ntiles > 0 && nb_tiled > 0);
         if (no_tiles) mark(0);                       // no tile kernel: the events bracket k_build instead
         if (nb > nb_tiled) {
-#define L_BUILD(M, IO) hipLaunchKernelGGL((k_build<M, IO>), dim3((unsigned)(nb - nb_tiled)), dim3(P.BT), lds_build, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p + npart, pivmm.p, (int)nb_tiled)
+#define L_BUILD(M, IO) LAUNCHK((k_build<M, IO>), dim3((unsigned)(nb - nb_tiled)), dim3(P.BT), lds_build, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p + npart, pivmm.p, (int)nb_tiled)
             if (P.with_io) { DISPATCH_MODEL(L_BUILD, true) } else { DISPATCH_MODEL(L_BUILD, false) }
 #undef L_BUILD
             npart += nb - nb_tiled;
         }
         if (no_tiles) mark(1);
         if (ngiant > 0) {                            // points with more observations than a batch holds
-#define L_GIANT(M, IO) hipLaunchKernelGGL((k_build_giant<M, IO>), dim3((unsigned)ngiant), dim3(giant_threads), 0, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p + npart, pivmm.p)
+#define L_GIANT(M, IO) LAUNCHK((k_build_giant<M, IO>), dim3((unsigned)ngiant), dim3(giant_threads), 0, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p + npart, pivmm.p)
             if (P.with_io) { DISPATCH_MODEL(L_GIANT, true) } else { DISPATCH_MODEL(L_GIANT, false) }
 #undef L_GIANT
             npart += ngiant;
@@ -420,12 +440,12 @@ struct Core {
             memset(h, 0, sizeof(h));
             HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_tile2_prof), h, sizeof(h)));
         }
-        hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(1024), 0, stream, partial.p, npart, red_scal, 0);
-        hipLaunchKernelGGL(k_prior_sq, dim3(grid_z), dim3(256), 0, stream, d, zz, partial.p);
-        hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_z, red_scal, 1);
+        LAUNCHK((k_sum_partials<1>), dim3(1), dim3(1024), 0, stream, partial.p, npart, red_scal, 0);
+        LAUNCHK(k_prior_sq, dim3(grid_z), dim3(256), 0, stream, d, zz, partial.p);
+        LAUNCHK((k_sum_partials<1>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_z, red_scal, 1);
         // owned squared column norms of the point columns -> red_scal[1]
-        hipLaunchKernelGGL(k_dot, dim3(grid_z), dim3(256), 0, stream, (int64_t)3 * P.np, z_mine.p + P.NS, jn2p.p, (const double *)nullptr, partial.p);
-        hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_z, red_scal + 1, 0);
+        LAUNCHK(k_dot, dim3(grid_z), dim3(256), 0, stream, (int64_t)3 * P.np, z_mine.p + P.NS, jn2p.p, (const double *)nullptr, partial.p);
+        LAUNCHK((k_sum_partials<1>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_z, red_scal + 1, 0);
     }
     void build(const double *zz, double lambda, int scale) {
         build_enqueue(zz, lambda, scale);
@@ -433,8 +453,8 @@ struct Core {
         finish_enqueue(zz, lambda, scale);
         if (zz != zlin.p) HIPCHK(hipMemcpyAsync(zlin.p, zz, P.NZ * 8, hipMemcpyDeviceToDevice, stream));
         // trace(J'J): camera part from jn2c (estimated), point part from red_scal[1]
-        hipLaunchKernelGGL(k_dot, dim3(grid_z), dim3(256), 0, stream, P.NS, z_est.p, jn2c.p, (const double *)nullptr, partial.p);
-        hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_z, scal.p, 0);
+        LAUNCHK(k_dot, dim3(grid_z), dim3(256), 0, stream, P.NS, z_est.p, jn2c.p, (const double *)nullptr, partial.p);
+        LAUNCHK((k_sum_partials<1>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_z, scal.p, 0);
         double hs[2], hr[2];
         HIPCHK(hipMemcpyAsync(hr, red_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
         read_scal(hs, 1);
@@ -447,9 +467,9 @@ struct Core {
         ++n_lin;
     }
     void finish_enqueue(const double *zz, double lambda, int scale) {
-        hipLaunchKernelGGL(k_finish, dim3((unsigned)cdiv(P.NS, 256)), dim3(256), 0, stream, d, zz, lambda, scale, S, g_c, g_red, diagU, jn2c.p, dscale.p);
+        LAUNCHK(k_finish, dim3((unsigned)cdiv(P.NS, 256)), dim3(256), 0, stream, d, zz, lambda, scale, S, g_c, g_red, diagU, jn2c.p, dscale.p);
         if (scale)
-            hipLaunchKernelGGL(k_scale_S, dim3((unsigned)cdiv(P.NS, 256), (unsigned)P.NS), dim3(256), 0, stream, P.NS, ldS, S, dscale.p);
+            LAUNCHK(k_scale_S, dim3((unsigned)cdiv(P.NS, 256), (unsigned)std::min<int64_t>(P.NS, 32768)), dim3(256), 0, stream, P.NS, ldS, S, dscale.p);
     }
 
     // ---- K6: Cholesky of the reduced system; returns 0 or the failing pivot
@@ -463,9 +483,10 @@ struct Core {
             HIPCHK(hipMemcpy2DAsync(ldiag.p, sizeof(double), S, (ldS + 1) * sizeof(double), sizeof(double), (size_t)P.NS,
                                     hipMemcpyDeviceToDevice, stream));
         }
+        HIPCHK(hipGetLastError());                   // launches inside the factorisation helpers
         mark(3);
-        hipLaunchKernelGGL(k_diag_minmax, dim3(1), dim3(256), 0, stream, d, ldiag.p, pivmm.p + 2);
-        hipLaunchKernelGGL(k_unscale, dim3((unsigned)cdiv(P.NS, 256)), dim3(256), 0, stream, P.NS, rhs.p, dscale.p, dz.p);
+        LAUNCHK(k_diag_minmax, dim3(1), dim3(256), 0, stream, d, ldiag.p, pivmm.p + 2);
+        LAUNCHK(k_unscale, dim3((unsigned)cdiv(P.NS, 256)), dim3(256), 0, stream, P.NS, rhs.p, dscale.p, dz.p);
         ++n_solves;
         return 0;
     }
@@ -473,19 +494,19 @@ struct Core {
     void backsub_enqueue() {
         mark(4);
         if (nb > 0) {
-#define L_BACK(M, NCXV) hipLaunchKernelGGL((k_backsub<M, NCXV>), dim3((unsigned)nb), dim3(P.BT), lds_back, stream, d, zlin.p, cams.p, Vinv.p, gp.p, r_w.p, dz.p, partial.p)
+#define L_BACK(M, NCXV) LAUNCHK((k_backsub<M, NCXV>), dim3((unsigned)nb), dim3(P.BT), lds_back, stream, d, zlin.p, cams.p, Vinv.p, gp.p, r_w.p, dz.p, partial.p)
             if (tile_ncx == 6) { DISPATCH_MODEL(L_BACK, 6) } else if (tile_ncx == 14) { DISPATCH_MODEL(L_BACK, 14) } else { DISPATCH_MODEL(L_BACK, MAXCOL) }
 #undef L_BACK
         }
         if (ngiant > 0) {
-#define L_BACKG(M, IO) hipLaunchKernelGGL((k_backsub_giant<M, IO>), dim3((unsigned)ngiant), dim3(giant_threads), 0, stream, d, zlin.p, cams.p, Vinv.p, gp.p, r_w.p, dz.p, partial.p + 2 * nb)
+#define L_BACKG(M, IO) LAUNCHK((k_backsub_giant<M, IO>), dim3((unsigned)ngiant), dim3(giant_threads), 0, stream, d, zlin.p, cams.p, Vinv.p, gp.p, r_w.p, dz.p, partial.p + 2 * nb)
             if (P.with_io) { DISPATCH_MODEL(L_BACKG, true) } else { DISPATCH_MODEL(L_BACKG, false) }
 #undef L_BACKG
         }
         mark(5);
-        hipLaunchKernelGGL((k_sum_partials<2>), dim3(1), dim3(1024), 0, stream, partial.p, nb + ngiant, scal.p, 0);
-        hipLaunchKernelGGL(k_prior_jv, dim3(grid_z), dim3(256), 0, stream, d, zlin.p, dz.p, partial.p);
-        hipLaunchKernelGGL((k_sum_partials<3>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_z, scal.p + 4, 0);
+        LAUNCHK((k_sum_partials<2>), dim3(1), dim3(1024), 0, stream, partial.p, nb + ngiant, scal.p, 0);
+        LAUNCHK(k_prior_jv, dim3(grid_z), dim3(256), 0, stream, d, zlin.p, dz.p, partial.p);
+        LAUNCHK((k_sum_partials<3>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_z, scal.p + 4, 0);
     }
     // solve at the current linearisation: p in dz.  Returns true if the
     // factorisation failed outright (non-positive pivot / non-finite step);
@@ -546,19 +567,19 @@ struct Core {
         if (hCIO && P.nIOu > 0) dCIO.alloc((size_t)P.nIOu * P.nIOu);
         if (hCEO || (hCIO && P.nIOu > 0)) {
             const int64_t tot = 36 * (int64_t)P.nc + (int64_t)P.nIOu * P.nIOu;
-            hipLaunchKernelGGL(k_cov_cam, dim3((unsigned)cdiv(tot, 256)), dim3(256), 0, stream, d, S, s02, dCEO.p, dCIO.p);
+            LAUNCHK(k_cov_cam, dim3((unsigned)cdiv(tot, 256)), dim3(256), 0, stream, d, S, s02, dCEO.p, dCIO.p);
         }
         if (hCOP) {
             dCOP.alloc((size_t)9 * P.np);
             HIPCHK(hipMemsetAsync(dCOP.p, 0, (size_t)9 * P.np * sizeof(double), stream));
             const size_t lds_cov = ((size_t)P.BT * P.ncolmax * 3 + (size_t)P.BT * 6) * sizeof(double);
             if (nb > 0) {
-#define L_COV(M, IO) hipLaunchKernelGGL((k_cov_points<M, IO>), dim3((unsigned)nb), dim3(P.BT), lds_cov, stream, d, z.p, cams.p, Vinv.p, S, s02, dCOP.p)
+#define L_COV(M, IO) LAUNCHK((k_cov_points<M, IO>), dim3((unsigned)nb), dim3(P.BT), lds_cov, stream, d, z.p, cams.p, Vinv.p, S, s02, dCOP.p)
                 if (P.with_io) { DISPATCH_MODEL(L_COV, true) } else { DISPATCH_MODEL(L_COV, false) }
 #undef L_COV
             }
             if (ngiant > 0) {
-#define L_COVG(M, IO) hipLaunchKernelGGL((k_cov_giant<M, IO>), dim3((unsigned)ngiant), dim3(giant_threads), 0, stream, d, z.p, cams.p, Vinv.p, S, s02, dCOP.p)
+#define L_COVG(M, IO) LAUNCHK((k_cov_giant<M, IO>), dim3((unsigned)ngiant), dim3(giant_threads), 0, stream, d, z.p, cams.p, Vinv.p, S, s02, dCOP.p)
                 if (P.with_io) { DISPATCH_MODEL(L_COVG, true) } else { DISPATCH_MODEL(L_COVG, false) }
 #undef L_COVG
             }
@@ -578,33 +599,33 @@ struct Core {
     // ||J v||^2 and r'Jv at the linearisation point, ||v||^2 over owned entries
     void jtimes(const double *v, double &JvJv, double &rJv, double &vv) {
         prep_cams(zlin.p);
-#define L_JT(M, NCXV) hipLaunchKernelGGL((k_jtimes<M, NCXV>), dim3(grid_obs), dim3(256), 0, stream, d, zlin.p, cams.p, v, r_w.p, partial.p)
+#define L_JT(M, NCXV) LAUNCHK((k_jtimes<M, NCXV>), dim3(grid_obs), dim3(256), 0, stream, d, zlin.p, cams.p, v, r_w.p, partial.p)
         if (tile_ncx == 6) { DISPATCH_MODEL(L_JT, 6) } else if (tile_ncx == 14) { DISPATCH_MODEL(L_JT, 14) } else { DISPATCH_MODEL(L_JT, MAXCOL) }
 #undef L_JT
-        hipLaunchKernelGGL((k_sum_partials<2>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_obs, scal.p, 0);
-        hipLaunchKernelGGL(k_prior_jv, dim3(grid_z), dim3(256), 0, stream, d, zlin.p, v, partial.p);
-        hipLaunchKernelGGL((k_sum_partials<3>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_z, scal.p + 4, 0);
+        LAUNCHK((k_sum_partials<2>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_obs, scal.p, 0);
+        LAUNCHK(k_prior_jv, dim3(grid_z), dim3(256), 0, stream, d, zlin.p, v, partial.p);
+        LAUNCHK((k_sum_partials<3>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_z, scal.p + 4, 0);
         do_allreduce(scal.p, 8);
         double h[8];
         read_scal(h, 8);
         JvJv = h[0] + h[4]; rJv = h[1] + h[5]; vv = h[6];
     }
     double dot_owned(const double *a, const double *b) {
-        hipLaunchKernelGGL(k_dot, dim3(grid_z), dim3(256), 0, stream, P.NZ, z_mine.p, a, b, partial.p);
-        hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_z, scal.p, 0);
+        LAUNCHK(k_dot, dim3(grid_z), dim3(256), 0, stream, P.NZ, z_mine.p, a, b, partial.p);
+        LAUNCHK((k_sum_partials<1>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_z, scal.p, 0);
         do_allreduce(scal.p, 1);
         double s;
         read_scal(&s, 1);
         return s;
     }
     void axpby(double a, const double *x, double b, const double *y2, double *y) {
-        hipLaunchKernelGGL(k_axpby, dim3((unsigned)cdiv(P.NZ, 256)), dim3(256), 0, stream, P.NZ, a, x, b, y2, y);
+        LAUNCHK(k_axpby, dim3((unsigned)cdiv(P.NZ, 256)), dim3(256), 0, stream, P.NZ, a, x, b, y2, y);
     }
     void gradient(double *g) {
-        hipLaunchKernelGGL(k_gradient, dim3((unsigned)cdiv(P.NZ, 256)), dim3(256), 0, stream, d, g_c, gp.p, g);
+        LAUNCHK(k_gradient, dim3((unsigned)cdiv(P.NZ, 256)), dim3(256), 0, stream, d, g_c, gp.p, g);
     }
     void colnorm2(double *out) {
-        hipLaunchKernelGGL(k_jn2, dim3((unsigned)cdiv(P.NZ, 256)), dim3(256), 0, stream, d, jn2c.p, jn2p.p, out);
+        LAUNCHK(k_jn2, dim3((unsigned)cdiv(P.NZ, 256)), dim3(256), 0, stream, d, jn2c.p, jn2p.p, out);
     }
     void copy(double *dst, const double *src) { HIPCHK(hipMemcpyAsync(dst, src, P.NZ * 8, hipMemcpyDeviceToDevice, stream)); }
 };
@@ -939,7 +960,11 @@ int dbat_hip_create(const dbat_hip_problem *prob, dbat_hip_handle **out) {
         return g_err.find("not supported") != std::string::npos || g_err.find("more observations") != std::string::npos
                    ? DBAT_HIP_EUNSUPPORTED : DBAT_HIP_EINVAL;
     }
-    h->core->init(*prob);
+    {
+        if (prob->device < 0 || prob->device >= ndev) { g_err = "bad device index"; return DBAT_HIP_EINVAL; }
+        DeviceGuard dev_guard(prob->device);
+        h->core->init(*prob);
+    }
     *out = h.release();
     return DBAT_HIP_OK;
     API_CATCH
@@ -1019,6 +1044,7 @@ int dbat_hip_residual(dbat_hip_handle *h, const double *x, double *r_unweighted,
     API_TRY
     if (!h || !x) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
     Core &c = *h->core;
+    DeviceGuard dev_guard(c.device);
     c.x_to_z(x, c.zt.p);
     export_residuals(c, c.zt.p, r_unweighted, nullptr, f);
     return DBAT_HIP_OK;
@@ -1029,6 +1055,7 @@ int dbat_hip_jacobian_blocks(dbat_hip_handle *h, const double *x, double *JEO, d
     API_TRY
     if (!h || !x) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
     Core &c = *h->core;
+    DeviceGuard dev_guard(c.device);
     const Plan &P = c.P;
     c.x_to_z(x, c.zt.p);
     c.prep_cams(c.zt.p);
@@ -1038,7 +1065,7 @@ int dbat_hip_jacobian_blocks(dbat_hip_handle *h, const double *x, double *JEO, d
     if (JOP) { b.alloc(6 * no); HIPCHK(hipMemsetAsync(b.p, 0, 6 * no * 8, c.stream)); }
     if (JIO) { cc.alloc(2 * (int64_t)P.nIOrows * no); HIPCHK(hipMemsetAsync(cc.p, 0, 2 * (int64_t)P.nIOrows * no * 8, c.stream)); }
     if (c.nobs > 0) {
-#define L_JB(M, dummy) hipLaunchKernelGGL((k_jac_blocks<M>), dim3((unsigned)cdiv(c.nobs, 256)), dim3(256), 0, c.stream, c.d, c.zt.p, c.cams.p, a.p, b.p, cc.p)
+#define L_JB(M, dummy) LAUNCHK((k_jac_blocks<M>), dim3((unsigned)cdiv(c.nobs, 256)), dim3(256), 0, c.stream, c.d, c.zt.p, c.cams.p, a.p, b.p, cc.p)
         switch (P.model) { case 2: L_JB(2, 0); break; case 3: L_JB(3, 0); break; case 4: L_JB(4, 0); break; default: L_JB(5, 0); break; }
 #undef L_JB
     }
@@ -1055,6 +1082,7 @@ int dbat_hip_linearize_solve(dbat_hip_handle *h, const double *x, double lambda,
     API_TRY
     if (!h || !x) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
     Core &c = *h->core;
+    DeviceGuard dev_guard(c.device);
     c.x_to_z(x, c.z.p);
     c.build(c.z.p, lambda, scale_columns);
     double JpJp, rJp, pp;
@@ -1073,6 +1101,7 @@ int dbat_hip_gradient(dbat_hip_handle *h, double *g) {
     API_TRY
     if (!h || !g || !h->core->have_lin) { g_err = "no linearisation"; return DBAT_HIP_EINVAL; }
     Core &c = *h->core;
+    DeviceGuard dev_guard(c.device);
     c.gradient(c.vtmp.p);
     c.z_to_x(c.vtmp.p, g);
     return DBAT_HIP_OK;
@@ -1083,6 +1112,7 @@ int dbat_hip_colnorms(dbat_hip_handle *h, double *Jn) {
     API_TRY
     if (!h || !Jn || !h->core->have_lin) { g_err = "no linearisation"; return DBAT_HIP_EINVAL; }
     Core &c = *h->core;
+    DeviceGuard dev_guard(c.device);
     c.colnorm2(c.vtmp.p);
     c.z_to_x(c.vtmp.p, Jn);
     for (int64_t i = 0; i < c.P.n; ++i) Jn[i] = std::sqrt(Jn[i]);
@@ -1094,10 +1124,11 @@ int dbat_hip_jtimes_sqnorm(dbat_hip_handle *h, const double *v, double *sqnorm) 
     API_TRY
     if (!h || !v || !sqnorm || !h->core->have_lin) { g_err = "no linearisation"; return DBAT_HIP_EINVAL; }
     Core &c = *h->core;
+    DeviceGuard dev_guard(c.device);
     HIPCHK(hipMemsetAsync(c.vtmp.p, 0, c.P.NZ * 8, c.stream));
     if (c.P.n) {
         HIPCHK(hipMemcpyAsync(c.xbuf.p, v, c.P.n * 8, hipMemcpyHostToDevice, c.stream));
-        hipLaunchKernelGGL(k_scatter_x, dim3((unsigned)cdiv(c.P.n, 256)), dim3(256), 0, c.stream, c.P.n, c.x2z.p, c.xbuf.p, c.vtmp.p);
+        LAUNCHK(k_scatter_x, dim3((unsigned)cdiv(c.P.n, 256)), dim3(256), 0, c.stream, c.P.n, c.x2z.p, c.xbuf.p, c.vtmp.p);
     }
     double a, b, vv;
     c.jtimes(c.vtmp.p, a, b, vv);
@@ -1113,6 +1144,7 @@ int dbat_hip_solve(dbat_hip_handle *h, const dbat_hip_options *opt, double *x, d
     if (opt->damping < 0 || opt->damping > 3) { g_err = "Unknown damping"; return DBAT_HIP_EINVAL; }
     if (opt->store_trace && !trace) { g_err = "store_trace without a trace buffer"; return DBAT_HIP_EINVAL; }
     Core &c = *h->core;
+    DeviceGuard dev_guard(c.device);
     c.n_res_evals = c.n_lin = c.n_solves = 0;
     c.x_to_z(x, c.z.p);
     c.lambda_lin = NAN;
@@ -1161,6 +1193,7 @@ int dbat_hip_final_residuals(dbat_hip_handle *h, double *r_unweighted, double *r
     API_TRY
     if (!h || !h->core->have_lin) { g_err = "no linearisation"; return DBAT_HIP_EINVAL; }
     Core &c = *h->core;
+    DeviceGuard dev_guard(c.device);
     export_residuals(c, c.zlin.p, r_unweighted, r_weighted, nullptr);
     return DBAT_HIP_OK;
     API_CATCH
@@ -1183,6 +1216,7 @@ int dbat_hip_set_x(dbat_hip_handle *h, const double *x) {
     API_TRY
     if (!h || !x) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
     Core &c = *h->core;
+    DeviceGuard dev_guard(c.device);
     c.x_to_z(x, c.z.p);
     c.sync();
     return DBAT_HIP_OK;
@@ -1193,6 +1227,7 @@ int dbat_hip_bench_step(dbat_hip_handle *h, double lambda, int32_t scale_columns
     API_TRY
     if (!h) { g_err = "null handle"; return DBAT_HIP_EINVAL; }
     Core &c = *h->core;
+    DeviceGuard dev_guard(c.device);
     c.timing = true;
     HIPCHK(hipEventRecord(c.ev[0], c.stream));
     c.build_enqueue(c.z.p, lambda, scale_columns);
@@ -1232,6 +1267,7 @@ int dbat_hip_posterior_cov(dbat_hip_handle *h, const double *x, double sigma0, d
     API_TRY
     if (!h || !x) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
     Core &c = *h->core;
+    DeviceGuard dev_guard(c.device);
     if (c.P.nranks > 1) { g_err = "posterior covariance is computed on one GPU (not supported on a sharded handle)"; return DBAT_HIP_EUNSUPPORTED; }
     c.x_to_z(x, c.z.p);
     c.posterior_cov(sigma0, CEO, CIO, COP, Sinv);

@@ -2214,9 +2214,10 @@ __global__ void k_finish(DevProblem d, const double *__restrict__ z, double lamb
 // S(i,j) *= d_i d_j on the lower triangle
 __global__ void k_scale_S(int64_t NS, int64_t ldS, double *__restrict__ S, const double *__restrict__ ds) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // row
-    const int64_t j = blockIdx.y;                                        // column
-    if (i >= NS || i < j) return;
-    S[j * ldS + i] *= ds[i] * ds[j];
+    if (i >= NS) return;
+    const double di = ds[i];
+    for (int64_t j = blockIdx.y; j <= i; j += gridDim.y)                 // column (grid-stride: NS may exceed the y limit)
+        S[j * ldS + i] *= di * ds[j];
 }
 
 __global__ void k_unscale(int64_t NS, const double *__restrict__ q, const double *__restrict__ ds,

@@ -60,7 +60,7 @@ def _parse_args(args):
     return o
 
 
-def bundle(s, *args, device=0, comm=None, store_trace=True):
+def bundle(s, *args, device=None, comm=None, store_trace=True):
     """[s,ok,iters,s0,E] = bundle(s[,maxIter][,damping][,'trace'][,tol]
     [,'absterm'][,'singulartest'|'nosingulartest'][,veto][,'pmdof'][,'dofverb'])
 
@@ -85,6 +85,10 @@ def bundle(s, *args, device=0, comm=None, store_trace=True):
             print('Setting %s parameters to fixed' % nm)
             pr.use = pr.use & est
     rank, world = (comm.rank, comm.world_size) if comm is not None else (0, 1)
+    if device is None:
+        # a rank of a multi-GPU run works on the device its process selected
+        device = getattr(comm, 'device', None) if comm is not None else 0
+        device = 0 if device is None else device
     h = _hip.Handle(s, device=device, shard_rank=rank, shard_count=world)
     try:
         if comm is not None and world > 1:
@@ -166,7 +170,8 @@ def bundle(s, *args, device=0, comm=None, store_trace=True):
             p_extra = int(np.count_nonzero(~np.asarray(s.bundle.est.OP, bool)[:, seen_pt])
                           + np.count_nonzero(~np.asarray(s.bundle.est.EO, bool)[:6, seen_cam]))
         dof = h.m + p_extra - h.n
-        s0 = float(res.sigma0) * np.sqrt((h.m - h.n) / dof) if dof > 0 else np.nan
+        # bundle.m:476-483: sqrt(r'r/dof) of the weighted residual (finite for m == n with 'pmdof')
+        s0 = float(np.sqrt(rw @ rw / dof)) if dof > 0 else np.nan
         if o['dofVerb']:
             print('bundle: dof=%d+%d-%d=%d.' % (h.m, p_extra, h.n, dof))
         s.post.sigmas = s0 * np.asarray(s.IP.sigmas)

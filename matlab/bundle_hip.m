@@ -86,15 +86,27 @@ E.s0=s0; E.sigmas=s.post.sigmas;
 % --- posterior covariance blocks from the device (bundle_cov.m:193-210 reads
 % s.post.cov.CEO / COP when they are present; E.final.weighted.J is not shipped)
 if ok
-    m=size(s.EO.val,1); B=zeros(m,m,size(s.EO.val,2)); B(1:6,1:6,:)=CEOb;
-    c=squeeze(num2cell(B,[1,2])); s.post.cov.CEO=sparse(blkdiag(c{:}));
-    c=squeeze(num2cell(COPb,[1,2])); s.post.cov.COP=sparse(blkdiag(c{:}));
+    % block diagonals from (i,j,v) triplets: no dense intermediate (roma: 78 963^2 doubles)
+    m=size(s.EO.val,1); nI=size(s.EO.val,2);
+    [bi,bj]=ndgrid(1:6,1:6); ofs=reshape(m*(0:nI-1),1,1,[]);
+    s.post.cov.CEO=sparse(reshape(bi+ofs,[],1),reshape(bj+ofs,[],1),CEOb(:),m*nI,m*nI);
+    nO=size(s.OP.val,2);
+    [bi,bj]=ndgrid(1:3,1:3); ofs=reshape(3*(0:nO-1),1,1,[]);
+    s.post.cov.COP=sparse(reshape(bi+ofs,[],1),reshape(bj+ofs,[],1),COPb(:),3*nO,3*nO);
     % IO: every array entry that maps to IO unknown k gets row/column k of CIOu,
     % per-image diagonal blocks only
     ix=zeros(size(s.IO.val)); ix(s.bundle.deserial.IO.dest)=s.bundle.deserial.IO.src;
-    C=zeros(numel(ix)); e=find(ix); C(e,e)=CIOu(ix(e),ix(e));
-    s.post.cov.CIO=sparse(C.*kron(eye(size(ix,2)),ones(size(ix,1))));
+    [r,cI]=find(ix); e=find(ix); ti=[]; tj=[]; tv=[];
+    for c=unique(cI)'
+        k=e(cI==c); [ki,kj]=ndgrid(k,k);
+        ti=[ti;ki(:)]; tj=[tj;kj(:)]; tv=[tv;reshape(CIOu(ix(k),ix(k)),[],1)]; %#ok<AGROW>
+    end
+    s.post.cov.CIO=sparse(ti,tj,tv,numel(ix),numel(ix));
 end
+% --- bundle.m:368-371: parameter names for the post-mortem; the rank analysis of a failed
+% run (bundle.m:372-446) needs J and stays with BUNDLE (E.final.weighted.J is not shipped)
+[~,E.paramTypes]=serialize(s);     % bundle.m:162,368
+E.weakness=struct('structural',[],'numerical',struct('rank',E.numParams,'deficiency',0));
 
 function a=zeroifnan(a)
 a(isnan(a))=0;
