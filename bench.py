@@ -9,14 +9,18 @@ in HBM before the timed region.
 
     python bench.py --gpus N --steps K --warmup W [--config C3]
 
-For N>1 it is launched by torch.distributed.run (one rank per GPU, RCCL); the
-object points of the same scene are sharded over the ranks (strong scaling)
-and the reduced system is summed with one all-reduce per iteration.  Rank 0
-prints one JSON line.
+N > 1: one rank per GPU.  Under torch.distributed.run (WORLD_SIZE set) this
+process is one of the ranks; started plainly, it launches
+`python -m torch.distributed.run --nproc-per-node N` itself before anything
+touches a GPU, relays the ranks' output and exits with their code.  The object
+points of the same scene are sharded over the ranks (strong scaling); the
+reduced camera system is summed with one RCCL all-reduce per iteration inside
+libdbat_hip.so (dbat_hip_comm_init).  Rank 0 prints one JSON line.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -29,42 +33,82 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_PEAK_TFLOPS = 78.6    # MI355X FP64 vector = matrix peak (vendor)
 
 
-def cpu_baseline(seconds=20.0):
-    """Time the CPU oracle (a port of the reference algorithm as written:
-    explicit sparse J, J'J, sparse direct solve of the FULL normal matrix) on a
-    bounded sample of the workload: LM iterations on a 100-camera / 10k-point /
-    100k-observation scene cut from the same generator."""
-    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
-    import dbat_oracle as o
-    import scipy.sparse as sp
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(s_main, name_main, budget_s=25.0):
+    """The reference algorithm as written (explicit sparse J, J'*J, sparse
+    Cholesky of the FULL normal matrix, levenberg_marquardt.m:81-82,119) in
+    C++/OpenMP on all host cores -- bench/cpu_ref.cpp, checked against the
+    oracle in tests/test_cpu_ref.py.  Timed on the bench's own scene (a
+    bounded number of LM iterations) and on the smaller BASELINE configs."""
+    sys.path.insert(0, os.path.join(ROOT, 'bench'))
+    import cpu_ref
     from dbat_amd import synth
-    s, _ = synth.make_scene('C1')
-    s = o.buildserialindices(s)
-    x = o.serialize(s)
-    w = o.buildweightvector(s)
-    R = np.sqrt(w)
-    n_it, t0 = 0, time.perf_counter()
-    while True:
-        r_, K = o.brown_euler_cam4(x, s, jac=True)           # residual + Jacobian
-        r = R * r_
-        J = (sp.diags(R) @ K).tocsc()
-        JTJ = (J.T @ J).tocsc()                              # levenberg_marquardt.m:81
-        lam = 1e-10 * JTJ.diagonal().sum() / J.shape[1]
-        p, _ = o.normal_solve((JTJ + lam * sp.identity(J.shape[1])).tocsc(), -(J.T @ r))
-        rt = R * o.brown_euler_cam4(x + p, s)                # trial point
-        if rt @ rt < r @ r:
-            x = x + p
-        n_it += 1
-        if time.perf_counter() - t0 > seconds or n_it >= 50:
-            break
-    dt = time.perf_counter() - t0
-    no = s.IP.val.shape[1]
+
+    def run(s, max_it, budget):
+        c = cpu_ref.CpuRef(s)                      # all cores (omp_get_max_threads)
+        try:
+            x = c.serialize()
+            p, st = c.lm_step(x, -1e-10)           # untimed: first touch of every buffer
+            n_it, t_all, ms = 0, 0.0, {}
+            while n_it < max_it and (n_it == 0 or t_all < budget):
+                t0 = time.perf_counter()
+                p, st = c.lm_step(x, -1e-10)
+                t_all += time.perf_counter() - t0
+                for k, v in st['ms'].items():
+                    ms[k] = ms.get(k, 0.0) + v
+                if st['code'] == 0 and st['f_trial'] < st['f']:
+                    x = x + p
+                n_it += 1
+            return {'it_per_s': n_it / t_all, 'iterations': n_it, 'threads': c.threads, 'n_params': c.n,
+                    'setup_s': c.setup_ms * 1e-3, 'nnz': c.nnz,
+                    'ms_per_phase': {k: v / n_it for k, v in ms.items()}}
+        finally:
+            c.close()
+
+    out = {}
+    t_start = time.perf_counter()
+    for name in ('C1', 'C2'):
+        if name == name_main:
+            continue
+        out[name] = run(synth.make_scene(name)[0], 20, 4.0)
+    left = max(5.0, budget_s - (time.perf_counter() - t_start))
+    main = run(s_main, 10, left)
+    out[name_main] = main
+    no = s_main.IP.val.shape[1]
     return {
-        'value': n_it / dt, 'unit': 'it/s', 'cores': 1, 'kind': 'port',
-        'sample': 'NumPy/SciPy oracle, %d LM iterations on a 100 cam / 10k pt / %d obs scene '
-                  '(1/100 of the C3 observations); full sparse normal matrix, SuperLU' % (n_it, no),
-        'obs_per_s': n_it * no / dt,
+        'value': main['it_per_s'], 'unit': 'it/s', 'cores': main['threads'], 'kind': 'port',
+        'cpu': cpu_model(), 'nproc': os.cpu_count(),
+        'sample': '%d LM iterations of bench/cpu_ref.cpp (C++17/OpenMP: explicit CSC Jacobian, J\'J by sparse '
+                  'product, supernodal Cholesky of the full %d x %d normal matrix, trial residual) on the '
+                  'bench scene %s itself (%d obs), %d threads'
+                  % (main['iterations'], main['n_params'], main['n_params'], name_main, no, main['threads']),
+        'obs_per_s': main['it_per_s'] * no, 'configs': out,
+        'reference_published': 'DBAT MATLAB R2020a (other machine, core count unknown): roma 1.04 s/it at 181k rows, '
+                               'St-Pierre 5.9 s/it at 394k rows (SURVEY 6)',
     }
+
+
+def launch_ranks(args):
+    """Start one rank per GPU (torch.distributed.run) as a child process; the
+    parent never initialises a GPU."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -74,24 +118,31 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--config', default='C3')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-solve', action='store_true', help='skip the timed dbat_hip_solve("lm") run')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args))
 
     import torch
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and world > 1:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the dbat_hip core has no CPU path)')
     torch.cuda.set_device(local)
     comm = None
     if world > 1 or os.environ.get('DBAT_BENCH_FORCE_COMM') == '1':
-        # one rank per GPU over RCCL (a forced one-rank group exercises the same code path)
+        # control plane only (unique id, barrier, max over ranks): gloo.  The data-path
+        # collectives are RCCL inside the library (a forced one-rank group takes the same path).
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29555')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        dist.init_process_group('gloo')
         from dbat_amd.parallel import Comm
         comm = Comm()
     from dbat_amd import _hip, synth
@@ -104,7 +155,7 @@ def main():
     h = _hip.Handle(s, device=local, shard_rank=rank, shard_count=world)
     t_plan = time.perf_counter() - t_plan
     if comm is not None:
-        h.set_allreduce(comm.allreduce_ptr)
+        comm.attach(h)                       # ncclCommInitRank inside the library
     info = h.info()
     x0 = h.serialize()
     h.set_x(x0)
@@ -128,10 +179,27 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if comm is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        t = torch.tensor([dt], dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     ms /= max(args.steps, 1)
+
+    # the shipped loop: a real dbat_hip_solve('lm') from x0 (host control flow, scalar
+    # read-backs and all), outside the timed region above
+    solve = None
+    if not args.no_solve:
+        opt = _hip.default_options('lm')
+        opt.store_trace = 0
+        barrier()
+        t1 = time.perf_counter()
+        xs, res, rr, damp, aux, T = h.solve(x0, opt)
+        barrier()
+        t_solve = time.perf_counter() - t1
+        solve = {'code': int(res.code), 'iterations': int(res.iters), 'linearizations': int(res.n_linearizations),
+                 'residual_evals': int(res.n_residual_evals), 'solves': int(res.n_solves),
+                 'time_s': float(res.time_s), 'wall_s': t_solve, 'sigma0': float(res.sigma0),
+                 'it_per_s': res.iters / res.time_s if res.time_s > 0 else None,
+                 'ms_per_linearization': res.time_s / max(res.n_linearizations, 1) * 1e3}
 
     if rank == 0:
         NS = info['NS']
@@ -139,21 +207,24 @@ def main():
         # rank's shard.  k_build fuses K1,K3,K4 (HBM side: 40*no + 24*np + 48*nc +
         # 8*NS^2 bytes) with the Schur contraction K5 (sum_p 108*k_p + 216*k_p^2
         # flops); the larger of the two lower-bound times names its roof.
-        tile3 = info['ncolmax'] <= 6 and os.environ.get('DBAT_HIP_TILE3', '1') != '0' and 'DBAT_HIP_TILE_BMAX' not in os.environ
-        kname_t = (('k_build_tile3' if tile3 else 'k_build_tile2') if info['ncolmax'] <= 14 else 'k_build_tile') if info['n_tiles'] > 0 else 'k_build'
+        kname = h.build_kernel_name()
         no_s, np_s = info['n_obs_shard'], info['n_pts_shard']
         kp = np.bincount(s.IP.pt, minlength=npnt).astype(np.float64)
         flops_schur = float(np.sum(108.0 * kp + 216.0 * kp * kp)) * (no_s / max(no, 1))
         bytes_build = 40 * no_s + 24 * np_s + 48 * nc + 8 * NS * NS
         # ms[4]: the tile kernel alone (k_cam_normal and the heavy-point kernels are outside its events)
-        k_ms = {kname_t: ms[4], 'potrf+potrs': ms[5], 'k_backsub': ms[6], 'k_residual': ms[7]}
-        traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-        if world == 1 and args.config == 'C3' and os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get('traffic_bytes_per_launch')   # PMC, see profiles/
+        k_ms = {kname: ms[4], 'k_chol_df': ms[5], 'k_backsub': ms[6], 'k_residual_cm': ms[7]}
+        # HBM traffic of the dominant kernel: PMC counters cannot be read inside this run
+        # (rocprofv3 --pmc is its own pass); the figure of the committed profile of the same
+        # command is attached with its source, or null when there is none for this kernel
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if world == 1 and os.path.exists(tpath):
+            tj = json.load(open(tpath)).get(args.config, {})
+            if tj.get('kernel') == kname:
+                traffic, traffic_src = tj.get('traffic_bytes_per_launch'), tj.get('source')
         t_build = ms[4] * 1e-3
         mfma_binds = flops_schur / (FP64_PEAK_TFLOPS * 1e12) > bytes_build / (HBM_PEAK_GBS * 1e9)
-        kname = kname_t
         if mfma_binds:
             ach = flops_schur / t_build / 1e12
             roof = {'kernel': kname, 'bound': 'mfma', 'achieved': ach, 'peak': FP64_PEAK_TFLOPS,
@@ -162,6 +233,7 @@ def main():
             ach = bytes_build / t_build / 1e9
             roof = {'kernel': kname, 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS,
                     'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'traffic': traffic}
+        roof['traffic_source'] = traffic_src
         roof['algorithmic_flops'] = flops_schur
         roof['algorithmic_bytes'] = bytes_build
         roof['hbm_GBs_on_algorithmic_bytes'] = bytes_build / t_build / 1e9
@@ -179,6 +251,13 @@ def main():
                      'bound': 'mfma', 'achieved': ach_c, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': ach_c / FP64_PEAK_TFLOPS, 'traffic': None, 'algorithmic_flops': flops_chol,
                      'dense_equivalent_flops': NS ** 3 / 3.0}
+        # HBM-bound kernels of the step on their algorithmic bytes
+        gb = lambda b, t_ms: b / (t_ms * 1e-3) / 1e9 if t_ms > 0 else None
+        hbm = {'k_backsub': {'algorithmic_bytes': 40 * no_s + 48 * np_s + 48 * nc},
+               'k_residual_cm': {'algorithmic_bytes': 20 * no_s + 24 * np_s + 48 * nc}}
+        for k, v in hbm.items():
+            v['GBs'] = gb(v['algorithmic_bytes'], k_ms[k])
+            v['frac_of_8TBs'] = v['GBs'] / HBM_PEAK_GBS if v['GBs'] else None
         out = {
             'metric': 'LM iterations/sec', 'value': args.steps / dt, 'unit': 'it/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -189,14 +268,16 @@ def main():
                                    % (args.config, nc, npnt, no,
                                       'self-calibrating' if info['ncolmax'] > 6 else 'fixed IO'),
                        'reduced_system_order': NS, 'n_params': h.n, 'parallelism': 'points/%d' % world,
+                       'collective': 'RCCL all-reduce in libdbat_hip.so' if comm is not None else None,
                        'n_tiles': info['n_tiles'], 'n_batches': info['n_batches'], 'batch': info['BT']},
             'ms_build_schur': ms[0], 'ms_factor_solve': ms[1], 'ms_backsub': ms[2],
             'ms_trial_residual': ms[3], 'kernel_ms': k_ms,
-            'roofline': roof, 'roofline_factorisation': roof_chol,
+            'roofline': roof, 'roofline_factorisation': roof_chol, 'hbm_kernels': hbm,
+            'solve_lm': solve, 'solve_it_s': solve['it_per_s'] if solve else None,
             'host_s': {'scene_generation': t_gen, 'plan_and_upload': t_plan},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline()
+            out['cpu_baseline'] = cpu_baseline(s, args.config)
         else:
             out['cpu_baseline'] = None
     # RCCL writes a version banner through C stdio, which is block-buffered when stdout is a

@@ -95,11 +95,15 @@ SYMBOLS = {
     'dbat_hip_jtimes_sqnorm': (C.c_int, [_H, _dp, _dp]),
     'dbat_hip_solve': (C.c_int, [_H, C.POINTER(Options), _dp, C.POINTER(Result), _dp, _dp, _dp, _dp]),
     'dbat_hip_final_residuals': (C.c_int, [_H, _dp, _dp]),
+    'dbat_hip_comm_unique_id': (C.c_int, [_bp]),
+    'dbat_hip_comm_init': (C.c_int, [_H, _bp]),
+    'dbat_hip_comm_allreduce_host': (C.c_int, [_H, _dp, C.c_int64, C.c_int32]),
     'dbat_hip_set_allreduce': (C.c_int, [_H, ALLREDUCE_FN, C.c_void_p]),
     'dbat_hip_owned_mask': (C.c_int, [_H, _bp]),
     'dbat_hip_bench_step': (C.c_int, [_H, C.c_double, C.c_int32, _dp]),
     'dbat_hip_set_x': (C.c_int, [_H, _dp]),
     'dbat_hip_info': (C.c_int, [_H, C.POINTER(C.c_int64)]),
+    'dbat_hip_build_kernel_name': (C.c_int, [_H, C.c_char_p, C.c_int32]),
     'dbat_hip_chol_stats': (C.c_int, [_H, C.POINTER(C.c_int64)]),
     'dbat_hip_posterior_cov': (C.c_int, [_H, _dp, C.c_double, _dp, _dp, _dp, _dp]),
 }
@@ -142,6 +146,16 @@ def load():
         raise DbatHipUnavailable('ABI version mismatch')
     _lib = lib
     return lib
+
+
+UNIQUE_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """A fresh RCCL unique id (rank 0 creates it and hands it to the other ranks)."""
+    buf = (C.c_uint8 * UNIQUE_ID_BYTES)()
+    check(load().dbat_hip_comm_unique_id(buf))
+    return bytes(buf)
 
 
 def last_error():
@@ -307,6 +321,22 @@ class Handle:
         ru, rw = np.zeros(self.m), np.zeros(self.m)
         check(self.lib.dbat_hip_final_residuals(self.h, dptr(ru), dptr(rw)))
         return ru, rw
+
+    def build_kernel_name(self):
+        buf = C.create_string_buffer(64)
+        check(self.lib.dbat_hip_build_kernel_name(self.h, buf, 64))
+        return buf.value.decode()
+
+    def comm_init(self, unique_id):
+        """Join the RCCL communicator of `unique_id` (128 bytes from comm_unique_id()
+        on rank 0) as rank shard_rank of shard_count.  Collective."""
+        buf = (C.c_uint8 * UNIQUE_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        check(self.lib.dbat_hip_comm_init(self.h, buf))
+
+    def comm_allreduce_host(self, a, op='sum'):
+        a = np.ascontiguousarray(a, np.float64).copy()
+        check(self.lib.dbat_hip_comm_allreduce_host(self.h, dptr(a), a.size, {'sum': 0, 'max': 1, 'min': 2}[op]))
+        return a
 
     def set_allreduce(self, pyfunc):
         """pyfunc(ptr:int, count:int, stream:int) -> int (0 ok)."""

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
+#include <rccl/rccl.h>
 
 #include <chrono>
 #include <cmath>
@@ -47,6 +48,13 @@ struct DeviceGuard {
     }
     ~DeviceGuard() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
 };
+
+#define NCCLCHK(expr)                                                                      \
+    do {                                                                                   \
+        ncclResult_t r_ = (expr);                                                          \
+        if (r_ != ncclSuccess)                                                             \
+            throw DeviceError{std::string(#expr) + ": " + ncclGetErrorString(r_)};         \
+    } while (0)
 
 template <class T>
 struct DevBuf {
@@ -108,7 +116,6 @@ struct Core {
     int64_t ldS = 0;
     CholEnvelope env;
     DevBuf<unsigned long long> pivmm;   // [0..1] point pivots min/max, [2..3] reduced-system pivots
-    DevBuf<double> mmx;                 // [2*nranks] min/max exchange through the sum-all-reduce
     double *S = nullptr, *g_red = nullptr, *g_c = nullptr, *diagU = nullptr, *red_scal = nullptr;
     int64_t red_count = 0;
     // multi-GPU: envelope of S + the vectors, contiguous (what the all-reduce carries)
@@ -120,8 +127,13 @@ struct Core {
     int64_t nb = 0, nobs = 0;
     int grid_obs = 1, grid_z = 1;
     size_t lds_build = 0, lds_back = 0;
+    // multi-GPU: the RCCL communicator of this handle's rank (dbat_hip_comm_init), or the
+    // caller's all-reduce callback (gloo / host tests)
+    ncclComm_t nccl = nullptr;
     dbat_hip_allreduce_fn allreduce = nullptr;
     void *allreduce_user = nullptr;
+    DevBuf<double> zgather;             // [NZ] owned entries of a z-vector, summed over the ranks
+    bool multi() const { return nccl != nullptr || allreduce != nullptr; }
     // linearisation state
     double f_lin = 0, trace_jtj = 0, lambda_lin = 0;
     int scale_lin = 0;
@@ -134,6 +146,7 @@ struct Core {
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         for (auto &e : kev) if (e) (void)hipEventDestroy(e);
         dfchol.release(); dfchol_ip.release();
+        if (nccl) (void)ncclCommDestroy(nccl);
         if (blas) rocblas_destroy_handle(blas);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -234,10 +247,9 @@ struct Core {
         r_w.alloc(std::max<int64_t>(2 * nobs, 2));
         grid_obs = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(nobs, 256), env_grid_obs()));
         grid_z = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(P.NZ, 256), 2048));
-        scal.alloc(16);
+        scal.alloc((size_t)16 + 2 * (size_t)P.nranks);
         info.alloc(1);
         pivmm.alloc(4);
-        mmx.alloc((size_t)2 * P.nranks);
         lds_build = ((size_t)P.BT * P.ncolmax * 3 + (size_t)P.BT * 18) * sizeof(double);
         lds_back = (size_t)P.BT * 6 * sizeof(double);
         lds_tile = ((size_t)2 * 3 * TILE_PC * TILE_LD + (size_t)P.BT * 9 + (size_t)36 * P.CMAX + 3 * TILE_LD +
@@ -303,7 +315,7 @@ struct Core {
     // sum of [S | g_red | g_c | diagU | scalars] over the ranks: the envelope of S is packed
     // next to the vectors, one all-reduce, unpacked again
     void allreduce_system() {
-        if (!allreduce) return;
+        if (!multi()) return;
         if (getenv("DBAT_HIP_DENSE_ALLREDUCE")) { do_allreduce(red.p, red_count); return; }
         const int64_t nvec = 3 * P.NS + 8;
         if (!pk.p) pk.alloc((size_t)(pk_s_count + nvec));
@@ -316,9 +328,20 @@ struct Core {
         HIPCHK(hipMemcpyAsync(g_red, pk.p + pk_s_count, nvec * sizeof(double), hipMemcpyDeviceToDevice, stream));
     }
     void do_allreduce(double *buf, int64_t count) {
-        if (allreduce) {     // installed only by multi-rank drivers (a one-rank group exercises the same path)
+        if (nccl) {          // RCCL over xGMI, in place, ordered on the handle's stream
+            NCCLCHK(ncclAllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, nccl, stream));
+        } else if (allreduce) {     // installed only by multi-rank drivers (a one-rank group exercises the same path)
             if (allreduce(allreduce_user, buf, count, (void *)stream) != 0) throw DeviceError{"all-reduce callback failed"};
         }
+    }
+    // A z-vector whose entries are valid on their owning rank only (object points on their
+    // shard, EO/IO on rank 0) -> the full vector on every rank.  Collective.
+    const double *gathered(const double *z_dev) {
+        if (!multi()) return z_dev;
+        if (!zgather.p) zgather.alloc((size_t)P.NZ);
+        LAUNCHK(k_mask_owned, dim3((unsigned)cdiv(P.NZ, 256)), dim3(256), 0, stream, P.NZ, z_mine.p, z_dev, zgather.p);
+        do_allreduce(zgather.p, P.NZ);
+        return zgather.p;
     }
     void read_scal(double *host, int n) {
         HIPCHK(hipMemcpyAsync(host, scal.p, n * sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -335,8 +358,9 @@ struct Core {
             LAUNCHK(k_scatter_x, dim3((unsigned)cdiv(P.n, 256)), dim3(256), 0, stream, P.n, x2z.p, xbuf.p, z_dev);
         }
     }
-    void z_to_x(const double *z_dev, double *x_host) {
+    void z_to_x(const double *z_dev, double *x_host) {     // collective on a sharded handle
         if (!P.n) return;
+        z_dev = gathered(z_dev);
         LAUNCHK(k_gather_x, dim3((unsigned)cdiv(P.n, 256)), dim3(256), 0, stream, P.n, x2z.p, z_dev, xbuf.p);
         HIPCHK(hipMemcpyAsync(x_host, xbuf.p, P.n * 8, hipMemcpyDeviceToHost, stream));
         sync();
@@ -524,22 +548,21 @@ struct Core {
         unsigned long long hmm[4];
         HIPCHK(hipMemcpyAsync(&hinfo, info.p, sizeof(hinfo), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipMemcpyAsync(hmm, pivmm.p, sizeof(hmm), hipMemcpyDeviceToHost, stream));
-        do_allreduce(scal.p, 8);
-        double h[8];
-        read_scal(h, 8);
+        // one all-reduce per solve: the 8 scalar sums and, behind them, one {min,max} slot per rank
+        // with this rank's point-block pivots (the extremes travel through the sum)
+        const int nsl = multi() ? 2 * P.nranks : 0;
+        if (nsl) {
+            HIPCHK(hipMemsetAsync(scal.p + 8, 0, (size_t)nsl * sizeof(double), stream));
+            HIPCHK(hipMemcpyAsync(scal.p + 8 + 2 * P.rank, pivmm.p, 2 * sizeof(double), hipMemcpyDeviceToDevice, stream));
+            do_allreduce(scal.p, 8 + nsl);
+        }
+        std::vector<double> h((size_t)8 + nsl);
+        read_scal(h.data(), 8 + nsl);
         JpJp = h[0] + h[4]; rJp = h[1] + h[5]; pp = h[6];
         double mm[4];
         memcpy(mm, hmm, sizeof(mm));
         double pmin = std::min(mm[0], mm[2]), pmax = std::max(mm[1], mm[3]);
-        if (allreduce) {                              // min/max over ranks through the sum-all-reduce
-            std::vector<double> slots((size_t)2 * P.nranks, 0.0);
-            slots[2 * P.rank] = pmin; slots[2 * P.rank + 1] = pmax;
-            HIPCHK(hipMemcpyAsync(mmx.p, slots.data(), slots.size() * 8, hipMemcpyHostToDevice, stream));
-            do_allreduce(mmx.p, (int64_t)slots.size());
-            HIPCHK(hipMemcpyAsync(slots.data(), mmx.p, slots.size() * 8, hipMemcpyDeviceToHost, stream));
-            sync();
-            for (int r = 0; r < P.nranks; ++r) { pmin = std::min(pmin, slots[2 * r]); pmax = std::max(pmax, slots[2 * r + 1]); }
-        }
+        for (int r = 0; r < nsl / 2; ++r) { pmin = std::min(pmin, h[8 + 2 * r]); pmax = std::max(pmax, h[8 + 2 * r + 1]); }
         const bool failed = hinfo != 0 || !std::isfinite(pp) || !std::isfinite(JpJp);
         const double ratio = pmax > 0 ? pmin / pmax : 0.0;
         near_singular = failed || !(ratio * ratio >= 2.220446049250313e-16);
@@ -583,6 +606,7 @@ struct Core {
                 if (P.with_io) { DISPATCH_MODEL(L_COVG, true) } else { DISPATCH_MODEL(L_COVG, false) }
 #undef L_COVG
             }
+            if (multi()) do_allreduce(dCOP.p, (int64_t)9 * P.np);   // blocks of the other shards' points
             cop_tmp.resize((size_t)9 * P.np);
             HIPCHK(hipMemcpyAsync(cop_tmp.data(), dCOP.p, (size_t)9 * P.np * sizeof(double), hipMemcpyDeviceToHost, stream));
         }
@@ -1011,31 +1035,32 @@ static void export_residuals(Core &c, const double *zdev, double *r_unw, double 
     const double ff = c.eval_f(zdev, nullptr, dev_unw);
     if (f) *f = ff;
     if (!(r_unw || r_wgt)) return;
-    std::vector<double> img(2 * c.P.no), zh(c.P.NZ);
-    HIPCHK(hipMemcpyAsync(img.data(), dev_unw, 2 * c.P.no * 8, hipMemcpyDeviceToHost, c.stream));
-    HIPCHK(hipMemcpyAsync(zh.data(), zdev, c.P.NZ * 8, hipMemcpyDeviceToHost, c.stream));
-    c.sync();
     const Plan &P = c.P;
-    // only this shard's rows are written; other rows keep the caller's content
-    for (size_t k = 0; k < P.o_row.size(); ++k) {
-        const int64_t row = P.o_row[k];
-        const int cam = P.o_cam[k];
-        for (int d = 0; d < 2; ++d) {
-            const double u = img[2 * row + d];
-            if (r_unw) r_unw[2 * row + d] = u;
-            if (r_wgt) {
-                const double w = P.uniform_w ? P.cam_w[2 * cam + d] : P.o_w[2 * k + d];
-                r_wgt[2 * row + d] = u * w;
-            }
-        }
+    // a sharded handle computes the rows of its own observations; the sum over the ranks
+    // (zeros elsewhere) gives every rank the whole vector.  Weighted rows on the device
+    // as well, so that the weights of the other shards' observations are not needed here.
+    DevBuf<double> tmpw;
+    if (r_wgt) {
+        tmpw.alloc(2 * std::max<int64_t>(P.no, 1));
+        HIPCHK(hipMemsetAsync(tmpw.p, 0, 2 * P.no * 8, c.stream));
+        if (c.nobs > 0)
+            LAUNCHK(k_weight_rows, dim3((unsigned)cdiv(c.nobs, 256)), dim3(256), 0, c.stream, c.d, dev_unw, tmpw.p);
     }
+    if (c.multi()) {
+        c.do_allreduce(dev_unw, 2 * P.no);
+        if (r_wgt) c.do_allreduce(tmpw.p, 2 * P.no);
+    }
+    const double *zfull = c.gathered(zdev);
+    std::vector<double> zh(P.NZ);
+    if (r_unw) HIPCHK(hipMemcpyAsync(r_unw, dev_unw, 2 * P.no * 8, hipMemcpyDeviceToHost, c.stream));
+    if (r_wgt) HIPCHK(hipMemcpyAsync(r_wgt, tmpw.p, 2 * P.no * 8, hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipMemcpyAsync(zh.data(), zfull, P.NZ * 8, hipMemcpyDeviceToHost, c.stream));
+    c.sync();
     int64_t row = 2 * P.no;
     for (int64_t zi : P.prior_z) {
         const double e = zh[zi] - P.z_prv[zi];
-        if (P.z_mine[zi] || P.nranks == 1) {
-            if (r_unw) r_unw[row] = e;
-            if (r_wgt) r_wgt[row] = e * std::sqrt(P.z_prw[zi]);
-        }
+        if (r_unw) r_unw[row] = e;
+        if (r_wgt) r_wgt[row] = e * std::sqrt(P.z_prw[zi]);
         ++row;
     }
 }
@@ -1205,6 +1230,47 @@ int dbat_hip_set_allreduce(dbat_hip_handle *h, dbat_hip_allreduce_fn fn, void *u
     return DBAT_HIP_OK;
 }
 
+int dbat_hip_comm_unique_id(uint8_t *id) {
+    API_TRY
+    if (!id) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
+    static_assert(sizeof(ncclUniqueId) <= DBAT_HIP_UNIQUE_ID_BYTES, "unique id does not fit");
+    ncclUniqueId uid;
+    NCCLCHK(ncclGetUniqueId(&uid));
+    memset(id, 0, DBAT_HIP_UNIQUE_ID_BYTES);
+    memcpy(id, &uid, sizeof(uid));
+    return DBAT_HIP_OK;
+    API_CATCH
+}
+
+int dbat_hip_comm_init(dbat_hip_handle *h, const uint8_t *id) {
+    API_TRY
+    if (!h || !id) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
+    Core &c = *h->core;
+    DeviceGuard dev_guard(c.device);
+    if (c.nccl) { g_err = "the handle already has a communicator"; return DBAT_HIP_EINVAL; }
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof(uid));
+    NCCLCHK(ncclCommInitRank(&c.nccl, c.P.nranks, uid, c.P.rank));
+    return DBAT_HIP_OK;
+    API_CATCH
+}
+
+int dbat_hip_comm_allreduce_host(dbat_hip_handle *h, double *buf, int64_t count, int32_t op) {
+    API_TRY
+    if (!h || !buf || count < 0 || op < 0 || op > 2) { g_err = "bad argument"; return DBAT_HIP_EINVAL; }
+    Core &c = *h->core;
+    DeviceGuard dev_guard(c.device);
+    if (!c.nccl) return DBAT_HIP_OK;                  // one rank: the identity
+    DevBuf<double> tmp;
+    tmp.alloc((size_t)std::max<int64_t>(count, 1));
+    HIPCHK(hipMemcpyAsync(tmp.p, buf, count * 8, hipMemcpyHostToDevice, c.stream));
+    NCCLCHK(ncclAllReduce(tmp.p, tmp.p, (size_t)count, ncclDouble, op == 0 ? ncclSum : (op == 1 ? ncclMax : ncclMin), c.nccl, c.stream));
+    HIPCHK(hipMemcpyAsync(buf, tmp.p, count * 8, hipMemcpyDeviceToHost, c.stream));
+    c.sync();
+    return DBAT_HIP_OK;
+    API_CATCH
+}
+
 int dbat_hip_owned_mask(const dbat_hip_handle *h, uint8_t *mask) {
     if (!h || !mask) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
     const Plan &P = h->core->P;
@@ -1268,7 +1334,6 @@ int dbat_hip_posterior_cov(dbat_hip_handle *h, const double *x, double sigma0, d
     if (!h || !x) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
     Core &c = *h->core;
     DeviceGuard dev_guard(c.device);
-    if (c.P.nranks > 1) { g_err = "posterior covariance is computed on one GPU (not supported on a sharded handle)"; return DBAT_HIP_EUNSUPPORTED; }
     c.x_to_z(x, c.z.p);
     c.posterior_cov(sigma0, CEO, CIO, COP, Sinv);
     return DBAT_HIP_OK;
@@ -1280,6 +1345,19 @@ int dbat_hip_chol_stats(const dbat_hip_handle *h, int64_t *st) {
     const Core &c = *h->core;
     const DataflowChol &f = c.use_perm ? c.dfchol : c.dfchol_ip;
     st[0] = f.n; st[1] = f.ntasks; st[2] = f.n_products; st[3] = f.nT; st[4] = c.use_perm ? 1 : 0; st[5] = c.use_df ? 1 : 0;
+    return DBAT_HIP_OK;
+}
+
+int dbat_hip_build_kernel_name(const dbat_hip_handle *h, char *buf, int32_t buf_len) {
+    if (!h || !buf || buf_len < 2) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
+    const Core &c = *h->core;
+    const char *nm = "k_build";
+    if (c.ntiles > 0 && c.P.nb_tiled > 0) {
+        if (c.use_tile3 && c.tile_ncx == 6) nm = "k_build_tile3";
+        else if (c.use_tile2 && c.tile_ncx <= 14) nm = "k_build_tile2";
+        else nm = "k_build_tile";
+    }
+    snprintf(buf, (size_t)buf_len, "%s", nm);
     return DBAT_HIP_OK;
 }
 

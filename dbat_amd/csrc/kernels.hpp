@@ -2211,6 +2211,24 @@ __global__ void k_finish(DevProblem d, const double *__restrict__ z, double lamb
     dscale[i] = ds;
 }
 
+// out = in where this rank owns the entry, 0 elsewhere (sum over ranks = the full vector)
+__global__ void k_mask_owned(int64_t n, const uint8_t *__restrict__ mine, const double *__restrict__ in,
+                             double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = mine[i] ? in[i] : 0.0;
+}
+
+// weighted image rows from the unweighted ones (reference row order o_row), this shard's observations
+__global__ void k_weight_rows(DevProblem d, const double *__restrict__ r_unw, double *__restrict__ r_wgt) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= d.nobs) return;
+    const int64_t row = d.o_row[k];
+    const int cam = d.o_cam[k];
+    const double w0 = d.o_w ? d.o_w[2 * k] : d.cam_w[2 * cam], w1 = d.o_w ? d.o_w[2 * k + 1] : d.cam_w[2 * cam + 1];
+    r_wgt[2 * row] = r_unw[2 * row] * w0;
+    r_wgt[2 * row + 1] = r_unw[2 * row + 1] * w1;
+}
+
 // S(i,j) *= d_i d_j on the lower triangle
 __global__ void k_scale_S(int64_t NS, int64_t ldS, double *__restrict__ S, const double *__restrict__ ds) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // row

@@ -59,6 +59,8 @@ def make_struct(IO, EO, OP, ip_val, ip_cam, ip_pt, pxSize, *, ip_std=None,
     std = np.ones((2, no)) if ip_std is None else np.asarray(ip_std, float)
     if std.ndim == 0:
         std = np.full((2, no), float(std))
+    # IP.sigmas = the distinct standard deviations (one sort of 2*no values unless they are all equal)
+    sigmas = np.array([std.flat[0]]) if std.size and std.min() == std.max() else np.unique(std)
 
     def prior(p, val):
         if p is None:
@@ -78,10 +80,10 @@ def make_struct(IO, EO, OP, ip_val, ip_cam, ip_pt, pxSize, *, ip_std=None,
               struct=NS(block=(np.tile(np.arange(1, nc + 1), (6, 1))
                                if EOblock is None else np.array(EOblock, np.int64))))
     s.OP = NS(val=OP, id=np.arange(1, OP.shape[1] + 1))      # prob2dbatstruct.m: OP.id
-    s.IP = NS(val=ip_val, std=np.array(std, float),
+    s.IP = NS(val=ip_val, std=np.array(std, float, order='F'),
               cam=np.asarray(ip_cam, np.int64).copy(),
               pt=np.asarray(ip_pt, np.int64).copy(),
-              sigmas=np.unique(std))
+              sigmas=sigmas)
     s.bundle = NS(est=NS(
         IO=np.zeros(IO.shape, bool) if estIO is None else np.array(estIO, bool),
         EO=np.ones(EO.shape, bool) if estEO is None else np.array(estEO, bool),

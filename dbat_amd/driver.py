@@ -92,7 +92,10 @@ def bundle(s, *args, device=None, comm=None, store_trace=True):
     h = _hip.Handle(s, device=device, shard_rank=rank, shard_count=world)
     try:
         if comm is not None and world > 1:
-            h.set_allreduce(comm.allreduce_ptr)
+            if hasattr(comm, 'attach'):
+                comm.attach(h)                                       # RCCL communicator inside the library
+            else:
+                h.set_allreduce(comm.allreduce_ptr)                  # test hook
         x0 = h.serialize()                                           # bundle.m:162
         opt = _hip.default_options(o['damping'])
         opt.max_iter = o['maxIter']
@@ -100,12 +103,7 @@ def bundle(s, *args, device=None, comm=None, store_trace=True):
         opt.abs_term = int(o['absTerm'])
         opt.singular_test = int(o['singularTest'])
         opt.store_trace = int(bool(store_trace))
-        x, res, rr, damp, aux, T = h.solve(x0, opt)
-        if comm is not None and world > 1:
-            mask = h.owned_mask()
-            x = comm.allreduce_numpy(np.where(mask, x, 0.0))
-            if T is not None:
-                T = comm.allreduce_numpy(np.where(mask[:, None], T, 0.0))
+        x, res, rr, damp, aux, T = h.solve(x0, opt)      # complete on every rank of a sharded run
         E = NS(maxIter=o['maxIter'], convTol=o['convTol'], absTerm=o['absTerm'],
                singularTest=o['singularTest'], chirality=False)
         name = 'gm' if o['damping'] in ('none', 'gm') else o['damping']
@@ -138,8 +136,6 @@ def bundle(s, *args, device=None, comm=None, store_trace=True):
         # (code -4 stops after the first linearisation: the residual is that of x0,
         # gauss_newton_armijo.m:112-142, and sigma0 below is computed from it)
         ru, rw = h.final_residuals()
-        if comm is not None and world > 1:
-            ru, rw = comm.allreduce_numpy(ru), comm.allreduce_numpy(rw)
         no = s.IP.val.shape[1]
         s.post = getattr(s, 'post', NS())
         s.post.res = NS()

@@ -2,11 +2,12 @@
 
 The reduced camera system [S | g | diag] built from each rank's shard of
 object points is summed over the ranks once per linearisation (SURVEY.md
-8(e)); scalar packs (r'r, ||Jp||^2, ...) likewise.  The collective is
-`torch.distributed.all_reduce` -- backend "nccl" is RCCL over xGMI on ROCm,
-"gloo" on CPU for the world_size-2 tests.  The C core calls back into
-`Comm.allreduce_ptr` with a raw device pointer (include/dbat_hip.h,
-dbat_hip_allreduce_fn).
+8(e)); scalar packs (r'r, ||Jp||^2, ...) likewise.  On GPUs the collective
+is RCCL inside libdbat_hip.so (ncclAllReduce on the handle's stream over
+xGMI): `Comm.attach(handle)` only carries rank 0's unique id to the other
+ranks through the torch.distributed group (any backend -- it is 128 bytes of
+control plane) and calls dbat_hip_comm_init.  `Comm.allreduce_ptr` is the
+test hook (dbat_hip_set_allreduce) for groups without RCCL.
 """
 from __future__ import annotations
 
@@ -37,6 +38,21 @@ class Comm:
         self.backend = dist.get_backend(group)
         self.n_collectives = 0
         self.bytes_reduced = 0
+        self.device = None
+        try:
+            import torch
+            if torch.cuda.is_available():
+                self.device = torch.cuda.current_device()    # the rank's GPU (set_device(LOCAL_RANK) by the launcher)
+        except ImportError:
+            pass
+
+    def attach(self, handle):
+        """Give `handle` (this rank's shard) its RCCL communicator.  Collective."""
+        from . import _hip
+        box = [_hip.comm_unique_id() if self.rank == 0 else None]
+        src = self.dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        self.dist.broadcast_object_list(box, src=src, group=self.group)
+        handle.comm_init(box[0])
 
     def allreduce_tensor(self, t):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
@@ -48,8 +64,11 @@ class Comm:
         """Sum-all-reduce `count` doubles at device address `ptr`, ordered on
         the HIP stream `stream` (the core's stream)."""
         import torch
-        t = torch.as_tensor(_DevMem(ptr, count), device='cuda')
-        ext = torch.cuda.ExternalStream(stream) if stream else torch.cuda.current_stream()
+        dev = torch.device('cuda', torch.cuda.current_device() if self.device is None else self.device)
+        t = torch.as_tensor(_DevMem(ptr, count), device=dev)
+        if t.data_ptr() != ptr:      # a pointer of another device would have been copied, not wrapped
+            raise RuntimeError('the buffer does not live on %s' % dev)
+        ext = torch.cuda.ExternalStream(stream, device=dev) if stream else torch.cuda.current_stream(dev)
         with torch.cuda.stream(ext):
             self.allreduce_tensor(t)
         return 0

@@ -82,6 +82,75 @@ def project(IO, EO, OP, cam, pt, px, nK=3, nP=2):
     return np.stack([u, v]), X[:, 2]
 
 
+def _n_workers():
+    import os
+    try:
+        return max(1, min(16, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        return max(1, min(16, os.cpu_count() or 1))
+
+
+def _select_rays(IO, EO, M, Q, cand, px, imsz, nK, k):
+    """For every point the first k candidate cameras that have it in frame:
+    (good, cam_sel (m,k), u_sel (m,k), v_sel (m,k)); rows of points with fewer
+    than k such cameras are undefined and `good` is False there.
+
+    `project` for the case of one lens (K equal in all cameras, P = 0) on
+    coordinate columns, in cache-sized chunks over a thread pool (NumPy
+    releases the GIL inside its loops).  Element for element the arithmetic
+    of `project`/`_brown`; a zero tangential term is not added."""
+    from concurrent.futures import ThreadPoolExecutor
+    m, kq = cand.shape
+    Kn = [-float(IO[5 + j, 0]) for j in range(nK)]
+    good = np.empty(m, bool)
+    cam_sel = np.empty((m, k), np.int64); u_sel = np.empty((m, k)); v_sel = np.empty((m, k))
+    Mf = M.reshape(len(M), 9)
+    step = max(1, (1 << 15) // kq)
+
+    def work(lo):
+        hi = min(m, lo + step)
+        c = cand[lo:hi].ravel()
+        rep = lambda a: np.repeat(a[lo:hi], kq)
+        d0 = rep(Q[0]) - EO[0, c]; d1 = rep(Q[1]) - EO[1, c]; d2 = rep(Q[2]) - EO[2, c]
+        Mc = Mf[c]
+        X0 = Mc[:, 0] * d0 + Mc[:, 3] * d1 + Mc[:, 6] * d2          # M'(Q-q0)
+        X1 = Mc[:, 1] * d0 + Mc[:, 4] * d1 + Mc[:, 7] * d2
+        X2 = Mc[:, 2] * d0 + Mc[:, 5] * d1 + Mc[:, 8] * d2
+        f = IO[0, c]
+        l0 = -f * X0 / X2; l1 = -f * X1 / X2
+        c0 = np.clip(l0, -100.0, 100.0); c1 = np.clip(l1, -100.0, 100.0)
+        a0 = c0.copy(); a1 = c1.copy()
+        for _ in range(14):
+            rho = a0 * a0 + a1 * a1
+            rs = Kn[0] * rho
+            pw = rho
+            for j in range(1, nK):
+                pw = pw * rho
+                rs = rs + Kn[j] * pw
+            a0 = np.clip(a0 + (c0 - (a0 + a0 * rs)), -200.0, 200.0)
+            a1 = np.clip(a1 + (c1 - (a1 + a1 * rs)), -200.0, 200.0)
+        a0 = np.where(np.abs(l0) < 100.0, a0, l0); a1 = np.where(np.abs(l1) < 100.0, a1, l1)
+        x0 = (a0 - IO[4, c] * a1) / (1 + IO[3, c])
+        u = (x0 + IO[1, c]) / px
+        v = -(a1 + IO[2, c]) / px
+        ok = ((u > 0) & (u < imsz[0]) & (v > 0) & (v < imsz[1]) & (X2 < 0)).reshape(-1, kq)
+        good[lo:hi] = ok.sum(1) >= k
+        if ok[:, :k].all():                                          # the usual case: the k nearest all see it
+            idx = slice(0, k)
+            cam_sel[lo:hi] = cand[lo:hi, :k]
+            u_sel[lo:hi] = u.reshape(-1, kq)[:, :k]; v_sel[lo:hi] = v.reshape(-1, kq)[:, :k]
+        else:
+            take = ok & (np.cumsum(ok, 1, dtype=np.int8) <= k)
+            idx = np.argsort(~take, axis=1, kind='stable')[:, :k]    # first k visible candidates
+            cam_sel[lo:hi] = np.take_along_axis(cand[lo:hi], idx, 1)
+            u_sel[lo:hi] = np.take_along_axis(u.reshape(-1, kq), idx, 1)
+            v_sel[lo:hi] = np.take_along_axis(v.reshape(-1, kq), idx, 1)
+
+    with ThreadPoolExecutor(_n_workers()) as ex:
+        list(ex.map(work, range(0, m, step)))
+    return good, cam_sel, u_sel, v_sel
+
+
 def make_scene(name='C1', seed=None, cams=None, points=None, rays=None, selfcal=None,
                groups=None, noise_px=0.5, verbose=False):
     """Build a DBAT struct for a named config.  Returns (s, truth) where truth
@@ -125,44 +194,44 @@ def make_scene(name='C1', seed=None, cams=None, points=None, rays=None, selfcal=
     # frame.  Points with fewer than k such cameras are redrawn, so every point
     # has exactly k rays (n_obs = k * n_points by construction).
     tree = cKDTree(EO[:2].T)
+    Mrot = _rotmat(EO[3:6])
     kq = min(nc, max(4 * k, 48)) if nc < 500 else min(nc, k + 6)
     OP = np.zeros((3, npnt))
     cam_sel = np.zeros((npnt, k), np.int64)
-    uv_sel = np.zeros((npnt, k, 2))
+    u_sel = np.zeros((npnt, k)); v_sel = np.zeros((npnt, k))
     todo = np.arange(npnt)
     for _round in range(200):
         if len(todo) == 0:
             break
         m = len(todo)
         Q = np.stack([rng.uniform(0, L, m), rng.uniform(0, L, m), rng.uniform(0, 10, m)])
-        _, cand = tree.query(Q[:2].T, k=kq)
+        _, cand = tree.query(Q[:2].T, k=kq, workers=_n_workers())
         cand = cand.reshape(m, kq)
-        cam_rep = cand.ravel()
-        uv, depth = project(IO, EO, Q, cam_rep, np.repeat(np.arange(m), kq), px)
-        ok = ((uv[0] > 0) & (uv[0] < cam0['imsz'][0]) & (uv[1] > 0) & (uv[1] < cam0['imsz'][1])
-              & (depth < 0)).reshape(m, kq)
-        good = ok.sum(1) >= k
-        take = ok & (np.cumsum(ok, 1) <= k)
-        gi = np.flatnonzero(good)
-        idx = np.argsort(~take[gi], axis=1, kind='stable')[:, :k]   # first k visible candidates
-        OP[:, todo[gi]] = Q[:, gi]
-        cam_sel[todo[gi]] = np.take_along_axis(cand[gi], idx, 1)
-        uvr = uv.reshape(2, m, kq)
-        uv_sel[todo[gi], :, 0] = np.take_along_axis(uvr[0][gi], idx, 1)
-        uv_sel[todo[gi], :, 1] = np.take_along_axis(uvr[1][gi], idx, 1)
+        good, cs, us, vs = _select_rays(IO, EO, Mrot, Q, cand, px, cam0['imsz'], 3, k)
+        if m == npnt and good.all():
+            OP[:], cam_sel, u_sel, v_sel = Q, cs, us, vs
+        else:
+            gi = np.flatnonzero(good)
+            OP[:, todo[gi]] = Q[:, gi]
+            cam_sel[todo[gi]] = cs[gi]; u_sel[todo[gi]] = us[gi]; v_sel[todo[gi]] = vs[gi]
         todo = todo[~good]
     if len(todo):
         raise RuntimeError('could not place %d points with %d rays' % (len(todo), k))
     cam_s = cam_sel.ravel()
     pt_s = np.repeat(np.arange(npnt), k)
-    uv_s = uv_sel.reshape(-1, 2).T
-    order = np.lexsort((pt_s, cam_s))                 # image-major, ascending OP
-    cam_s, pt_s, uv_s = cam_s[order], pt_s[order], uv_s[:, order]
+    # image-major, ascending OP: pt_s is ascending, so a stable sort by camera is enough
+    # (16-bit keys take NumPy's radix sort)
+    order = (np.argsort(cam_s.astype(np.uint16), kind='stable') if nc < 65536
+             else np.lexsort((pt_s, cam_s)))
+    cam_s, pt_s = cam_s[order], pt_s[order]
+    uv_s = np.empty((2, len(order)), order='F')
+    uv_s[0] = u_sel.ravel()[order]; uv_s[1] = v_sel.ravel()[order]
     if verbose:
         cnt = np.bincount(pt_s, minlength=npnt)
         print('scene %s: %d cams %d pts %d obs (rays/pt min %d max %d)'
               % (name, nc, npnt, len(cam_s), cnt.min(), cnt.max()))
-    ip = uv_s + rng.normal(0, noise_px, uv_s.shape)
+    ip = uv_s
+    ip += rng.normal(0, noise_px, uv_s.shape)
     truth = dict(IO=IO.copy(), EO=EO.copy(), OP=OP.copy())
     # initial values: truth + noise
     EO0 = EO.copy()

@@ -180,8 +180,8 @@ int  dbat_hip_structural_rank_ok(const dbat_hip_handle *h, int32_t *ok);
 /* r = brown_euler_cam4(x,s) (brown_euler_cam4.m:122-148; multi_res.m:20-55;
  * prior_obs.m:26-43).  r_unweighted [n_residuals] in the reference row order
  * [image rows; IO priors; EO priors; OP priors] (may be NULL);
- * f = 0.5*r'*W*r (gauss_newton_armijo.m:253).  With shard_count>1 the image
- * rows of other shards are left untouched and *f is this shard's share. */
+ * f = 0.5*r'*W*r (gauss_newton_armijo.m:253).  Collective on a sharded handle
+ * (every rank calls it and receives the whole vector and the whole f). */
 int  dbat_hip_residual(dbat_hip_handle *h, const double *x, double *r_unweighted, double *f);
 
 /* [r,J] = resFun(x), J returned as the per-observation blocks the sparse J is
@@ -233,16 +233,39 @@ int  dbat_hip_final_residuals(dbat_hip_handle *h, double *r_unweighted, double *
 
 /* ---- multi-GPU: one handle per rank, object points sharded -------------- */
 
-/* Sum-all-reduce of `count` doubles at device address `buf_dev` over all
- * ranks, enqueued on `stream` (a hipStream_t).  Installed by the host
- * language binding (torch.distributed / RCCL in this repo); the core calls it
- * once per linearisation for [S | g | diag] and for scalar packs. */
+/* The reference is one MATLAB thread; the sharded path has no
+ * counterpart there.  One handle per rank (prob->shard_rank of
+ * prob->shard_count, one GPU each); object points and their observations are
+ * sharded, cameras/IO replicated.  Per linearisation the ranks sum the envelope
+ * of the reduced camera system [S | J_c'r | diag] with ONE RCCL all-reduce on
+ * the handle's stream (ncclAllReduce = reduce-scatter + all-gather over xGMI);
+ * per solve one all-reduce of 8 + 2*shard_count doubles carries the scalar
+ * sums and the pivot extremes; per objective value one double.  With a
+ * communicator every entry point below "the damping loops", dbat_hip_residual,
+ * dbat_hip_final_residuals, dbat_hip_gradient/_colnorms and
+ * dbat_hip_posterior_cov is COLLECTIVE: all ranks call it with the same
+ * arguments and all receive the complete result (x, residual rows, blocks). */
+#define DBAT_HIP_UNIQUE_ID_BYTES 128
+/* rank 0: a fresh RCCL unique id (ncclGetUniqueId); the caller hands the 128
+ * bytes to the other ranks by whatever channel it has (MPI, a store, a file) */
+int  dbat_hip_comm_unique_id(uint8_t *id /*[128]*/);
+/* every rank: join the communicator (ncclCommInitRank with the handle's
+ * shard_rank / shard_count on the handle's device).  Collective. */
+int  dbat_hip_comm_init(dbat_hip_handle *h, const uint8_t *id /*[128]*/);
+/* helper for the host side of a multi-rank driver: all-reduce `count` host
+ * doubles over the handle's communicator; op 0 = sum, 1 = max, 2 = min
+ * (a barrier is a reduce of one double).  Identity without a communicator. */
+int  dbat_hip_comm_allreduce_host(dbat_hip_handle *h, double *buf, int64_t count, int32_t op);
+
+/* Test hook (gloo on CPU boxes, two shards on one GPU through the host):
+ * sum-all-reduce of `count` doubles at device address `buf_dev`, enqueued on
+ * `stream` (a hipStream_t), used in place of RCCL when no communicator is set. */
 typedef int (*dbat_hip_allreduce_fn)(void *user, void *buf_dev, int64_t count, void *stream);
 int  dbat_hip_set_allreduce(dbat_hip_handle *h, dbat_hip_allreduce_fn fn, void *user);
 
 /* mask[n_params]: 1 where this handle's shard owns the x entry (its object
- * points; rank 0 also owns IO and EO).  The final x of a sharded solve is the
- * sum over ranks of mask.*x.  Host only. */
+ * points; rank 0 also owns IO and EO).  Host only; results returned by the
+ * library are already complete on every rank. */
 int  dbat_hip_owned_mask(const dbat_hip_handle *h, uint8_t *mask);
 
 /* ---- measurement hooks -------------------------------------------------- */
@@ -264,6 +287,10 @@ int  dbat_hip_set_x(dbat_hip_handle *h, const double *x);
  * info[6]=max camera-side columns per observation info[7]=#tiles */
 int  dbat_hip_info(const dbat_hip_handle *h, int64_t *info /*[8]*/);
 
+/* name of the kernel that builds the Schur complement of the tiled points in this handle
+ * (the dominant kernel of a step; the one the bench's roofline entry is about) */
+int  dbat_hip_build_kernel_name(const dbat_hip_handle *h, char *buf, int32_t buf_len);
+
 /* Schedule of the Cholesky of the reduced system (measurement only): st[0] order of the
  * factorised system incl. block padding, st[1] tile tasks, st[2] 64x64x64 tile products of
  * the update phase, st[3] tile rows, st[4] 1 = nested-dissection order, st[5] 1 = dataflow kernel. */
@@ -280,7 +307,8 @@ int  dbat_hip_chol_stats(const dbat_hip_handle *h, int64_t *st /*[6]*/);
  * COP  [9*n_points]   3x3 block per object point, rows/columns of fixed coordinates zero
  * Sinv [NS*NS]        optional: inv(S) itself (lower triangle valid; NOT scaled by sigma0^2),
  *                     order [EO of image 0..n-1 | IO unknowns], for 'CEOF'/'CIOF'
- * Any output may be NULL.  One GPU only (DBAT_HIP_EUNSUPPORTED on a sharded handle). */
+ * Any output may be NULL.  On a sharded handle (collective) inv(S) is computed on every rank,
+ * the per-point blocks by the owning rank, and all ranks receive all blocks. */
 int  dbat_hip_posterior_cov(dbat_hip_handle *h, const double *x, double sigma0, double *CEO, double *CIO,
                             double *COP, double *Sinv);
 

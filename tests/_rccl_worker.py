@@ -1,0 +1,42 @@
+"""Two-rank GPU worker (launched by test_two_ranks_rccl_match_single): each rank
+runs bundle() on its shard of the object points with the RCCL communicator
+inside libdbat_hip.so and compares with the one-GPU run on the same device."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')):
+    sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from dbat_amd import bundle, bundle_cov  # noqa: E402
+from dbat_amd.parallel import Comm  # noqa: E402
+from helpers import synth_struct, relerr  # noqa: E402
+
+
+def main():
+    local = int(os.environ['LOCAL_RANK'])
+    torch.cuda.set_device(local)
+    dist.init_process_group('gloo')
+    comm = Comm()
+    assert comm.device == local
+    s, _ = synth_struct('small', 'priors')
+    for damping in ('gna', 'lm', 'lmp'):
+        ref = bundle(s, damping, device=local)
+        res, ok, iters, s0, E = bundle(s, damping, comm=comm)
+        assert ok == ref[1] and E.code == ref[4].code
+        assert relerr(E.x, ref[4].x) < 1e-8, relerr(E.x, ref[4].x)
+        assert abs(s0 - ref[3]) < 1e-9 * ref[3]
+        if damping != 'lm':
+            assert iters == ref[2]
+        assert relerr(res.post.res.IP, ref[0].post.res.IP) < 1e-6
+    print('RANK_OK %d' % comm.rank, flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

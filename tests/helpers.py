@@ -219,8 +219,13 @@ def synth_struct(name='tiny', variant='plain', seed=None):
                   cc,K shared  (demo/romabundledemo_imagevariant.m:42-48)
        'priors'   EO position priors on every 3rd camera, OP priors on control
                   points, a few fixed control points, non-uniform IP.std
+       'groups4'  four camera groups with independent self-calibrated IO blocks
+                  (BASELINE.json configs[4]; script/setdbatcamsandimages.m:28,
+                  buildserialindices.m:162-221)
     """
     from dbat_amd import synth
+    if variant == 'groups4':
+        return synth.make_scene(name, seed=seed, selfcal=True, groups=4)
     s, truth = synth.make_scene(name, seed=seed)
     nc, npnt = s.EO.val.shape[1], s.OP.val.shape[1]
     rng = np.random.default_rng(12345)
