@@ -95,10 +95,11 @@ struct Ref {
     std::vector<int32_t> sn_rows;               // root-local row indices (sorted)
     std::vector<double> LD;                     // 9 per supernode (3x3 lower, column-major, padded)
     std::vector<double> LR;                     // [rows][3] per supernode
-    // per root column: the supernodes that have it as a row, and where
-    std::vector<int64_t> rc_ptr;
-    std::vector<int32_t> rc_sn;
-    std::vector<uint16_t> rc_pos;
+    // supernodes with identical off-diagonal rows (object points seen by the same images) are
+    // amalgamated for the update of the root: one dense block per group (CHOLMOD merges such
+    // columns into one supernode)
+    std::vector<int64_t> grp_ptr;
+    std::vector<int32_t> grp_sn;
     // root supernode
     std::vector<double> T;                      // NS x NS lower, column-major
     int nt = 0;
@@ -312,18 +313,27 @@ static bool setup(Ref &R) {
         const int64_t nsn = (int64_t)R.sn_col0.size() - 1;
         R.LD.assign((size_t)9 * nsn, 0.0);
         R.LR.assign((size_t)3 * R.sn_rows.size(), 0.0);
-        // per root column: who updates it
-        R.rc_ptr.assign((size_t)R.NS + 1, 0);
-        for (int32_t rr : R.sn_rows) ++R.rc_ptr[rr + 1];
-        for (int64_t j = 0; j < R.NS; ++j) R.rc_ptr[j + 1] += R.rc_ptr[j];
-        R.rc_sn.resize(R.sn_rows.size()); R.rc_pos.resize(R.sn_rows.size());
-        std::vector<int64_t> fill(R.rc_ptr.begin(), R.rc_ptr.end() - 1);
-        for (int64_t s = 0; s < nsn; ++s) {
-            const int64_t len = R.sn_rptr[s + 1] - R.sn_rptr[s];
-            if (len > 65535) { R.err = "an object point with more than 65535 coupled columns"; return false; }
-            for (int64_t k = 0; k < len; ++k) {
-                const int32_t rr = R.sn_rows[R.sn_rptr[s] + k];
-                R.rc_sn[fill[rr]] = (int32_t)s; R.rc_pos[fill[rr]] = (uint16_t)k; ++fill[rr];
+        // groups of supernodes with the same row list
+        {
+            std::vector<int32_t> order((size_t)nsn);
+            for (int64_t i = 0; i < nsn; ++i) order[i] = (int32_t)i;
+            auto rows_of = [&](int32_t sidx) { return std::make_pair(&R.sn_rows[R.sn_rptr[sidx]], R.sn_rptr[sidx + 1] - R.sn_rptr[sidx]); };
+            std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b2) {
+                auto ra = rows_of(a), rb = rows_of(b2);
+                if (ra.second != rb.second) return ra.second < rb.second;
+                const int c = std::memcmp(ra.first, rb.first, (size_t)ra.second * sizeof(int32_t));
+                return c != 0 ? c < 0 : a < b2;
+            });
+            R.grp_sn = order;
+            R.grp_ptr.assign(1, 0);
+            for (int64_t i = 1; i <= nsn; ++i) {
+                bool same = i < nsn;
+                if (same) {
+                    auto ra = rows_of(order[i - 1]), rb = rows_of(order[i]);
+                    same = ra.second == rb.second && std::memcmp(ra.first, rb.first, (size_t)ra.second * sizeof(int32_t)) == 0;
+                    if (same && i - R.grp_ptr.back() >= 4096) same = false;      // bound the work of one task
+                }
+                if (!same) R.grp_ptr.push_back(i);
             }
         }
     }
@@ -404,6 +414,7 @@ static void gemm_nt(int m, int n, int k, const double *A, int64_t lda, const dou
 // dense Cholesky of the root supernode in place (lower), skipping empty tiles; returns false if not SPD
 static bool root_cholesky(Ref &R) {
     const int64_t n = R.NS, ld = R.NS;
+    const int nth = std::min(R.nthreads, 32);      // 47 panels of 128 columns at C3: more threads only wait at the barriers
     double *T = R.T.data();
     bool ok = true;
     for (int k = 0; k < R.nt && ok; ++k) {
@@ -422,7 +433,7 @@ static bool root_cholesky(Ref &R) {
             }
         }
         if (!ok) break;
-#pragma omp parallel for schedule(dynamic, 1) num_threads(R.nthreads)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nth)
         for (int i = k + 1; i < R.nt; ++i) {                   // panel: X = A L^-T
             if (!R.tnz[(size_t)i * R.nt + k]) continue;
             const int64_t i0 = (int64_t)i * NB, ib = std::min<int64_t>(NB, n - i0);
@@ -444,7 +455,7 @@ static bool root_cholesky(Ref &R) {
         std::vector<std::pair<int, int>> work;
         for (int i = k + 1; i < R.nt; ++i) if (R.tnz[(size_t)i * R.nt + k])
             for (int j = k + 1; j <= i; ++j) if (R.tnz[(size_t)j * R.nt + k]) work.emplace_back(i, j);
-#pragma omp parallel for schedule(dynamic, 1) num_threads(R.nthreads)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nth)
         for (int64_t t = 0; t < (int64_t)work.size(); ++t) {
             const int i = work[t].first, j = work[t].second;
             const int64_t i0 = (int64_t)i * NB, ib = std::min<int64_t>(NB, n - i0);
@@ -501,22 +512,42 @@ static bool factorize(Ref &R, double *ms_leaves, double *ms_update, double *ms_r
     *ms_leaves = ms_since(t0);
     if (!ok) return false;
     t0 = clk::now();
-    // root := N(root, root) - sum over leaves L_R L_R'   (left-looking, one root column per task)
+    // root := N(root, root) - sum over leaves L_R L_R': one dense block per group of leaves with
+    // the same rows, summed in cache and added to the root once
     const int64_t NS = R.NS;
-#pragma omp parallel for schedule(dynamic, 8) num_threads(R.nthreads)
+#pragma omp parallel for schedule(static) num_threads(R.nthreads)
     for (int64_t j = 0; j < NS; ++j) {
         double *tc = &R.T[(size_t)j * NS];
         std::fill(tc + j, tc + NS, 0.0);
         const int64_t jq = R.npts_cols + j;
-        for (int64_t s = R.Np[jq]; s < R.Np[jq + 1]; ++s) tc[R.Ni[s] - R.npts_cols] = R.Nx[s];
-        for (int64_t e = R.rc_ptr[j]; e < R.rc_ptr[j + 1]; ++e) {
-            const int64_t s = R.rc_sn[e];
-            const int pos = R.rc_pos[e];
-            const int64_t r0 = R.sn_rptr[s], len = R.sn_rptr[s + 1] - r0;
-            const double *lr = &R.LR[(size_t)3 * r0];
-            const int32_t *rows = &R.sn_rows[r0];
-            const double y0 = lr[3 * pos], y1 = lr[3 * pos + 1], y2 = lr[3 * pos + 2];
-            for (int64_t k = pos; k < len; ++k) tc[rows[k]] -= lr[3 * k] * y0 + lr[3 * k + 1] * y1 + lr[3 * k + 2] * y2;
+        for (int64_t s2 = R.Np[jq]; s2 < R.Np[jq + 1]; ++s2) tc[R.Ni[s2] - R.npts_cols] = R.Nx[s2];
+    }
+    const int64_t ngrp = (int64_t)R.grp_ptr.size() - 1;
+#pragma omp parallel num_threads(R.nthreads)
+    {
+        std::vector<double> blk;
+#pragma omp for schedule(dynamic, 4)
+        for (int64_t gi = 0; gi < ngrp; ++gi) {
+            const int32_t s0 = R.grp_sn[R.grp_ptr[gi]];
+            const int64_t len = R.sn_rptr[s0 + 1] - R.sn_rptr[s0];
+            const int32_t *rows = &R.sn_rows[R.sn_rptr[s0]];
+            blk.assign((size_t)len * len, 0.0);                 // column-major, lower triangle used
+            for (int64_t e = R.grp_ptr[gi]; e < R.grp_ptr[gi + 1]; ++e) {
+                const double *lr = &R.LR[(size_t)3 * R.sn_rptr[R.grp_sn[e]]];
+                for (int64_t c = 0; c < len; ++c) {
+                    const double y0 = lr[3 * c], y1 = lr[3 * c + 1], y2 = lr[3 * c + 2];
+                    double *bc = &blk[(size_t)c * len];
+                    for (int64_t k = c; k < len; ++k) bc[k] += lr[3 * k] * y0 + lr[3 * k + 1] * y1 + lr[3 * k + 2] * y2;
+                }
+            }
+            for (int64_t c = 0; c < len; ++c) {
+                double *tc = &R.T[(size_t)rows[c] * NS];
+                const double *bc = &blk[(size_t)c * len];
+                for (int64_t k = c; k < len; ++k) {
+#pragma omp atomic
+                    tc[rows[k]] -= bc[k];
+                }
+            }
         }
     }
     *ms_update = ms_since(t0);
