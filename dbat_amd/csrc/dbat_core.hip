@@ -16,6 +16,7 @@
 #include "../../include/dbat_hip.h"
 #include "chol_df.hpp"
 #include "kernels.hpp"
+#include "sig.hpp"
 #include "plan.hpp"
 
 namespace dbat {
@@ -89,6 +90,11 @@ struct Core {
     DevBuf<uint8_t> z_est, z_mine, o_lc, o_pidx;
     DevBuf<int32_t> tile_batch, tile_cam_start, tile_cams, tile_io_start, tile_iocols;
     DevBuf<uint8_t> tile_cam_io;
+    DevBuf<int32_t> sg_chunk, sg_tile_chunk0;       // signature groups (sig.hpp)
+    DevBuf<uint8_t> sg_lc;
+    DevBuf<double> sg_uv, sg_w;
+    bool use_sig = false;
+    int sig_rb = 4;
     int tile_ncx = 6;
     int64_t ntiles = 0;
     size_t lds_tile = 0, lds_tile2 = 0, lds_tile3 = 0;
@@ -194,6 +200,13 @@ struct Core {
         if (const char *e = getenv("DBAT_HIP_GIANT_THREADS")) { const int v = atoi(e); if (v == 64 || v == 128) giant_threads = v; }
         d.tile_batch = tile_batch.p; d.tile_cam_start = tile_cam_start.p; d.tile_cams = tile_cams.p;
         d.tile_io_start = tile_io_start.p; d.tile_iocols = tile_iocols.p; d.tile_cam_io = tile_cam_io.p;
+        use_sig = P.sg_ok && ntiles > 0;
+        if (use_sig) {
+            sg_chunk.upload(P.sg_chunk); sg_tile_chunk0.upload(P.sg_tile_chunk0); sg_lc.upload(P.sg_lc);
+            sg_uv.upload(P.sg_uv);
+            if (!P.uniform_w) sg_w.upload(P.sg_w);
+            sig_rb = 6 * P.sg_kmax + 1 <= 64 ? 4 : 5;
+        }
         cams.alloc(P.nc);
         z.alloc(P.NZ); zt.alloc(P.NZ); dz.alloc(P.NZ); zlin.alloc(P.NZ); vtmp.alloc(P.NZ); vtmp2.alloc(P.NZ);
         xbuf.alloc(std::max<int64_t>(P.n, 1));
@@ -291,6 +304,12 @@ struct Core {
         // it holds at most 64 batch offsets per tile, the plan's default cap is 48
         use_tile3 = use_tile2 && !P.with_io && !(getenv("DBAT_HIP_TILE3") && atoi(getenv("DBAT_HIP_TILE3")) == 0)
                     && getenv("DBAT_HIP_TILE_BMAX") == nullptr;
+        if (use_sig) {
+            SET_LDS((k_build_sig<2, 4>), sig_lds_bytes(4)); SET_LDS((k_build_sig<3, 4>), sig_lds_bytes(4));
+            SET_LDS((k_build_sig<4, 4>), sig_lds_bytes(4)); SET_LDS((k_build_sig<5, 4>), sig_lds_bytes(4));
+            SET_LDS((k_build_sig<2, 5>), sig_lds_bytes(5)); SET_LDS((k_build_sig<3, 5>), sig_lds_bytes(5));
+            SET_LDS((k_build_sig<4, 5>), sig_lds_bytes(5)); SET_LDS((k_build_sig<5, 5>), sig_lds_bytes(5));
+        }
         if (use_tile3) {
             SET_LDS((k_build_tile3<2, TILE3_PC, TILE3_NBUF>), lds_tile3); SET_LDS((k_build_tile3<3, TILE3_PC, TILE3_NBUF>), lds_tile3);
             SET_LDS((k_build_tile3<4, TILE3_PC, TILE3_NBUF>), lds_tile3); SET_LDS((k_build_tile3<5, TILE3_PC, TILE3_NBUF>), lds_tile3);
@@ -428,7 +447,10 @@ struct Core {
 #undef L_CAMN
             mark(0);                                 // events around the tile kernel alone (bench roofline)
 #define L_TILE3(M, DUMMY) LAUNCHK((k_build_tile3<M, TILE3_PC, TILE3_NBUF>), dim3((unsigned)ntiles), dim3(768), lds_tile3, stream, d, zz, cams.p, lambda, scale, S, g_red, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p, pivmm.p)
-            if (use_tile3 && tile_ncx == 6) { DISPATCH_MODEL(L_TILE3, 0) }
+#define L_SIG(M, RBV) LAUNCHK((k_build_sig<M, RBV>), dim3((unsigned)ntiles), dim3(256), sig_lds_bytes(RBV), stream, d, zz, cams.p, lambda, scale, S, g_red, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p, pivmm.p, sg_chunk.p, sg_tile_chunk0.p, sg_lc.p, sg_uv.p, P.uniform_w ? (const double *)nullptr : sg_w.p)
+            if (use_sig && sig_rb == 4) { DISPATCH_MODEL(L_SIG, 4) }
+            else if (use_sig) { DISPATCH_MODEL(L_SIG, 5) }
+            else if (use_tile3 && tile_ncx == 6) { DISPATCH_MODEL(L_TILE3, 0) }
             else if (use_tile2 && tile_ncx == 6) { DISPATCH_MODEL(L_TILE2, 6) }
             else if (use_tile2 && tile_ncx == 14) { DISPATCH_MODEL(L_TILE2, 14) }
             else if (tile_ncx == 6) { DISPATCH_MODEL(L_TILE, 6) }
@@ -1353,7 +1375,8 @@ int dbat_hip_build_kernel_name(const dbat_hip_handle *h, char *buf, int32_t buf_
     const Core &c = *h->core;
     const char *nm = "k_build";
     if (c.ntiles > 0 && c.P.nb_tiled > 0) {
-        if (c.use_tile3 && c.tile_ncx == 6) nm = "k_build_tile3";
+        if (c.use_sig) nm = "k_build_sig";
+        else if (c.use_tile3 && c.tile_ncx == 6) nm = "k_build_tile3";
         else if (c.use_tile2 && c.tile_ncx <= 14) nm = "k_build_tile2";
         else nm = "k_build_tile";
     }

@@ -84,6 +84,21 @@ struct Plan {
     std::vector<int32_t> tile_io_start;            // [ntiles+1]
     std::vector<int32_t> tile_iocols;              // IOu indices, ascending inside a tile
     std::vector<uint8_t> tile_cam_io;              // [#tile cams][16]: local IO row of the camera's j-th IO column
+    // signature groups (k_build_sig): consecutive points of a tile that are seen by exactly the
+    // same cameras share their rows of the reduced system.  A chunk = at most 64 points of one
+    // group; 8 ints per chunk {first point (processing order), #points, #cameras k, first
+    // observation (point-major arrays), #points of the whole group, index of the chunk's first
+    // point in the group, first observation of the group (slot-major copy), offset into sg_lc}.
+    static constexpr int SG_KMAX = 13;             // 6*13 + 1 rows fit five 16-row blocks
+    static constexpr int SG_CHUNK = 64;
+    std::vector<int32_t> sg_chunk;                 // [nchunks][8]
+    std::vector<int32_t> sg_tile_chunk0;           // [ntiles+1]
+    std::vector<uint8_t> sg_lc;                    // tile-local camera index of every slot of every group
+    std::vector<double> sg_uv;                     // slot-major copy of o_uv: group g, slot j, point i at 2*(obs0_g + j*m_g + i)
+    std::vector<double> sg_w;                      // the same for o_w (empty if uniform)
+    int sg_kmax = 0;                               // largest k among the tiled points
+    int64_t sg_ngroups = 0, sg_npoints = 0;
+    bool sg_ok = false;                            // the tiled points can go through k_build_sig
     int BT = 256;
     int ncolmax = 6;
     bool with_io = false;
@@ -518,7 +533,38 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     }
     P.porder.resize(np);
     std::iota(P.porder.begin(), P.porder.end(), 0);
-    std::stable_sort(P.porder.begin(), P.porder.end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });
+    {
+        // Inside a coarse cell of the curve (about 512 points) the points are ordered by their
+        // camera list, so that points seen by exactly the same cameras -- they update the same
+        // rows and columns of the reduced system -- follow each other (signature groups of
+        // k_build_sig).  Across cells the order stays the curve's.
+        int64_t nobs_pts = 0;
+        for (int p = 0; p < np; ++p) nobs_pts += k_pt[p] > 0;
+        int cell_bits = 0;
+        while (((int64_t)512 << cell_bits) < nobs_pts && cell_bits < 60) ++cell_bits;
+        // the code interleaves `order_dims` of three bit lanes into the top 62 bits of the key
+        const int eff_bits = (cell_bits * 3 + P.order_dims - 1) / P.order_dims;
+        const int low_bits = getenv("DBAT_HIP_SIG_SORT_OFF") ? 0 : std::max(0, 62 - eff_bits);
+        std::vector<uint64_t> sig(np, 0);
+        if (low_bits > 0)
+            for (int p = 0; p < np; ++p) {
+                // first four cameras (16 bits each) lead, so that groups with neighbouring camera sets stay close
+                uint64_t lead = 0, h = 1469598103934665603ull;
+                for (int j = 0; j < k_pt[p]; ++j) {
+                    const uint64_t c = (uint64_t)pb.ip_cam[by_pt[pstart[p] + j]];
+                    if (j < 3) lead |= (c & 0xFFFF) << (48 - 16 * j);
+                    h = (h ^ c) * 1099511628211ull;
+                }
+                sig[p] = lead | (h & 0xFFFF);
+            }
+        auto cell = [&](int32_t a) { return low_bits > 0 && key[a] < (1ull << 62) ? key[a] >> low_bits : key[a]; };
+        std::stable_sort(P.porder.begin(), P.porder.end(), [&](int32_t a, int32_t b) {
+            const uint64_t ca = cell(a), cb = cell(b);
+            if (ca != cb) return ca < cb;
+            if (low_bits > 0 && key[a] < (1ull << 62) && sig[a] != sig[b]) return sig[a] < sig[b];
+            return key[a] < key[b];
+        });
+    }
     // shard = contiguous range of the processing order balanced by observation count
     {
         std::vector<int64_t> cum(np + 1, 0);
@@ -575,7 +621,36 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     P.tile_io_start.clear(); P.tile_iocols.clear(); P.tile_cam_io.clear();
     P.tile_io_start.push_back(0);
     int64_t pos = 0, bstart = 0, tile_first_obs = 0;
+    // signature groups of the current tile
+    P.sg_chunk.clear(); P.sg_tile_chunk0.assign(1, 0); P.sg_lc.clear(); P.sg_kmax = 0; P.sg_ngroups = 0; P.sg_npoints = 0;
+    P.sg_uv.assign(P.o_uv.size(), 0.0);
+    if (!P.uniform_w) P.sg_w.assign(P.o_w.size(), 0.0); else P.sg_w.clear();
+    std::vector<int32_t> sg_gc;                      // global camera of every sg_lc entry (converted when the tile closes)
+    size_t sg_lc_tile0 = 0;
+    std::vector<int32_t> g_cams;                     // cameras of the open group
+    int64_t g_pos0 = 0, g_rank0 = 0, g_npts = 0;
+    auto close_group = [&]() {
+        if (g_npts == 0) return;
+        const int k = (int)g_cams.size();
+        const int32_t lc0 = (int32_t)sg_gc.size();
+        for (int32_t c : g_cams) sg_gc.push_back(c);
+        for (int64_t c0 = 0; c0 < g_npts; c0 += Plan::SG_CHUNK) {
+            const int32_t ch[8] = {(int32_t)(g_rank0 + c0), (int32_t)std::min<int64_t>(Plan::SG_CHUNK, g_npts - c0), k,
+                                   (int32_t)(g_pos0 + c0 * k), (int32_t)g_npts, (int32_t)c0, (int32_t)g_pos0, lc0};
+            P.sg_chunk.insert(P.sg_chunk.end(), ch, ch + 8);
+        }
+        for (int64_t i = 0; i < g_npts; ++i)         // slot-major copy of the group's image coordinates
+            for (int j = 0; j < k; ++j) {
+                const int64_t src = g_pos0 + i * k + j, dst = g_pos0 + (int64_t)j * g_npts + i;
+                P.sg_uv[2 * dst] = P.o_uv[2 * src]; P.sg_uv[2 * dst + 1] = P.o_uv[2 * src + 1];
+                if (!P.uniform_w) { P.sg_w[2 * dst] = P.o_w[2 * src]; P.sg_w[2 * dst + 1] = P.o_w[2 * src + 1]; }
+            }
+        P.sg_kmax = std::max(P.sg_kmax, k);
+        ++P.sg_ngroups; P.sg_npoints += g_npts;
+        g_npts = 0; g_cams.clear();
+    };
     auto close_tile = [&](int64_t end_obs) {
+        close_group();
         // local indices in ascending global camera order
         std::sort(cur_cams.begin(), cur_cams.end());
         std::vector<int32_t> &loc = stamp;            // reuse as cam -> local index (restored below)
@@ -594,6 +669,10 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         for (int32_t io : cur_io) { P.tile_iocols.push_back(io); io_stamp[io] = -1; }
         P.tile_io_start.push_back((int32_t)P.tile_iocols.size());
         cur_io.clear();
+        P.sg_lc.resize(sg_gc.size());
+        for (size_t e = sg_lc_tile0; e < sg_gc.size(); ++e) P.sg_lc[e] = (uint8_t)loc[sg_gc[e]];
+        sg_lc_tile0 = sg_gc.size();
+        P.sg_tile_chunk0.push_back((int32_t)(P.sg_chunk.size() / 8));
         for (int32_t c : cur_cams) { P.tile_cams.push_back(c); loc[c] = -1; }
         P.tile_cam_start.push_back((int32_t)P.tile_cams.size());
         P.tile_batch.push_back((int32_t)P.batch_start.size() - 1);   // = number of closed batches
@@ -678,6 +757,16 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         }
         if (pos - bstart + k > P.BT) { P.batch_start.push_back(pos); bstart = pos; }
         if (pos == bstart) pidx = 0;
+        if (P.CMAX && !in_heavy) {                   // same cameras as the previous point of the tile: same group
+            bool same = g_npts > 0 && (int)g_cams.size() == k && g_npts < (1 << 20);
+            for (int j = 0; same && j < k; ++j) same = g_cams[j] == pb.ip_cam[by_pt[pstart[p] + j]];
+            if (!same) {
+                close_group();
+                g_pos0 = pos; g_rank0 = i;
+                for (int j = 0; j < k; ++j) g_cams.push_back(pb.ip_cam[by_pt[pstart[p] + j]]);
+            }
+            ++g_npts;
+        }
         const uint32_t seg = (uint32_t)(pos - bstart) | ((uint32_t)k << 16);
         for (int j = 0; j < k; ++j, ++pos) {
             const int64_t o = by_pt[pstart[p] + j];
@@ -747,6 +836,15 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         // a chunk ends where the next one starts (same camera + CM_CHUNK, the next camera's first
         // observation, or the end of its part)
     }
+    // k_build_sig takes the tiled points when every one of them fits its five row blocks, the
+    // interior orientation is fixed and the groups are long enough to fill a wave's lanes
+    const bool sg_can = P.CMAX > 0 && P.nb_tiled > 0 && !P.with_io && P.sg_kmax > 0 && P.sg_kmax <= Plan::SG_KMAX && P.BT == 256;
+    P.sg_ok = sg_can && P.sg_npoints >= 8 * P.sg_ngroups;
+    if (const char *e = getenv("DBAT_HIP_SIG")) P.sg_ok = atoi(e) == 0 ? false : (atoi(e) >= 2 ? sg_can : P.sg_ok);   // 0 off, 2 whenever possible
+    if (getenv("DBAT_HIP_PLAN_STATS") && P.sg_ngroups > 0)
+        fprintf(stderr, "[plan] %lld signature groups, %.1f points/group, %zu chunks, k max %d, sig kernel %s\n",
+                (long long)P.sg_ngroups, (double)P.sg_npoints / P.sg_ngroups, P.sg_chunk.size() / 8, P.sg_kmax,
+                P.sg_ok ? "on" : "off");
     if (getenv("DBAT_HIP_PLAN_STATS") && P.tile_batch.size() > 1) {      // tile size distribution
         std::vector<int> nbt;
         for (size_t i = 0; i + 1 < P.tile_batch.size(); ++i) nbt.push_back(P.tile_batch[i + 1] - P.tile_batch[i]);

@@ -471,3 +471,34 @@ def check_roma_against_result(res, s0, E, iters, exp):
     dang = (np.rad2deg(res.EO.val[3:6]).T - eo[:, :3] + 180.0) % 360.0 - 180.0
     assert np.abs(dang).max() < 1.01e-6
     assert np.abs(res.EO.val[:3].T - eo[:, 3:]).max() < 1.01e-6
+
+
+# ---------------------------------------------------------------- C ABI driver (tests/abi_c_driver.c)
+def build_abi_c_driver():
+    """Compile tests/abi_c_driver.c as plain C11 against include/dbat_hip.h and link it with
+    libdbat_hip.so.  Returns the path of the executable."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(root, 'tests', 'abi_c_driver.out')
+    src = os.path.join(root, 'tests', 'abi_c_driver.c')
+    lib = os.path.join(root, 'dbat_amd')
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(
+            os.path.join(root, 'include', 'dbat_hip.h'))):
+        subprocess.run(['gcc', '-std=c11', '-Wall', '-Wextra', '-pedantic', '-Werror', '-O1', '-I' + os.path.join(root, 'include'),
+                        src, '-o', out, '-L' + lib, '-ldbat_hip', '-Wl,-rpath,' + lib, '-Wl,-rpath,/opt/rocm/lib'],
+                       check=True, capture_output=True)
+    return out
+
+
+def dump_problem(s, path):
+    """The arrays of dbat_hip_problem in declaration order (abi_c_driver.c::load)."""
+    from dbat_amd import _hip
+    p, keep = _hip.problem_from_struct(s)
+    hdr = np.array([p.n_images, p.n_points, p.n_obs, p.dist_model, p.nK, p.nP, 5 + p.nK + p.nP, 0], np.int64)
+    order = ['ip_cam', 'ip_pt', 'ip_val', 'ip_std', 'IO_val', 'px_size', 'EO_val', 'OP_val', 'est_IO', 'est_EO',
+             'est_OP', 'IO_block', 'EO_block', 'prior_IO_use', 'prior_IO_val', 'prior_IO_std', 'prior_EO_use',
+             'prior_EO_val', 'prior_EO_std', 'prior_OP_use', 'prior_OP_val', 'prior_OP_std']
+    with open(path, 'wb') as f:
+        f.write(hdr.tobytes())
+        for k in order:
+            f.write(keep[k].tobytes())

@@ -124,3 +124,38 @@ def test_bundle_argument_parsing():
         _parse_args(('newton',))
     with pytest.raises(BadInput):
         _parse_args(([1, 2],))
+
+
+def test_header_is_c_and_layout_matches_ctypes():
+    """include/dbat_hip.h compiles as plain C11 (-Wall -Wextra -pedantic -Werror) in a caller that
+    is not Python, and sizeof/offsetof of the three ABI structs there equal the ctypes mirror."""
+    import ctypes as C
+    import json
+    import subprocess
+    from helpers import build_abi_c_driver
+    exe = build_abi_c_driver()
+    lay = json.loads(subprocess.run([exe, 'layout'], check=True, capture_output=True, text=True).stdout)
+    assert lay['abi_version'] == _hip.ABI_VERSION and lay['unique_id_bytes'] == _hip.UNIQUE_ID_BYTES
+    for cname, cls in (('dbat_hip_problem', _hip.Problem), ('dbat_hip_options', _hip.Options),
+                       ('dbat_hip_result', _hip.Result)):
+        assert lay[cname]['sizeof'] == C.sizeof(cls)
+        offs = {name: getattr(cls, name).offset for name, _ in cls._fields_}
+        assert offs == lay[cname]['offsets'], cname
+
+
+@pytest.mark.parametrize('case', ['plain', 'priors', 'groups4'])
+def test_c_driver_plan_matches_python_binding(case, tmp_path):
+    """The host-only entry points called from C on a problem dumped to a file: same sizes,
+    rank verdict and x0 as through the Python binding."""
+    import json
+    import subprocess
+    from helpers import build_abi_c_driver, dump_problem
+    s = synth_struct('tiny', case)[0]
+    path = str(tmp_path / 'problem.bin')
+    dump_problem(s, path)
+    out = json.loads(subprocess.run([build_abi_c_driver(), 'plan', path], check=True, capture_output=True, text=True).stdout)
+    pl = _hip.plan(s)
+    assert (out['n'], out['m'], out['nIO'], out['nEO'], out['nOP']) == (pl['n'], pl['m'], pl['nIO'], pl['nEO'], pl['nOP'])
+    assert out['rank_ok'] == 1
+    x0 = _hip.plan_serialize(s)
+    assert abs(out['sum_x0'] - float(np.sum(x0))) <= 1e-12 * float(np.sum(np.abs(x0)))

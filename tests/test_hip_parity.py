@@ -900,6 +900,54 @@ def test_sxb_prior_eo_reports_hip(hip, use_prior_eo):
     assert len(lines) >= 430 and n >= len(lines) - 2
 
 
+@pytest.mark.parametrize('name,variant', [('tiny', 'plain'), ('small', 'plain'), ('small', 'priors'), ('C1', 'plain')])
+def test_signature_group_kernel(hip, name, variant, monkeypatch):
+    """k_build_sig (signature groups: points seen by the same cameras share one dense block on
+    the matrix cores) forced on for scenes whose groups are short, where it is off by default:
+    step parity with the oracle's full sparse solve, same step as the tile kernel, and the
+    same bundle result as the oracle.  (At C3, where it is the default, the full-size property
+    test runs it.)"""
+    from dbat_amd import bundle
+    s, truth = synth_struct(name, variant)
+    so, x0, w = oracle_setup(s)
+    R = np.sqrt(w)
+    r_o, K = o.brown_euler_cam4(x0, so, jac=True)
+    J = (sp.diags(R) @ K).tocsc()
+    p_o, *_ = o._scaled_gn(J, R * r_o)
+    monkeypatch.setenv('DBAT_HIP_SIG', '0')
+    h = hip.Handle(s)
+    try:
+        assert h.build_kernel_name() != 'k_build_sig'
+        p_tile, _ = h.linearize_solve(x0, 0.0, True)
+    finally:
+        h.close()
+    monkeypatch.setenv('DBAT_HIP_SIG', '2')
+    h = hip.Handle(s)
+    try:
+        assert h.build_kernel_name() == 'k_build_sig'
+        p_h, st = h.linearize_solve(x0, 0.0, True)
+        assert not st['singular']
+        assert relerr(p_h, p_o) < TOL_STEP and relerr(p_h, p_tile) < 1e-9
+        assert abs(st['f'] - 0.5 * (R * r_o) @ (R * r_o)) <= 1e-11 * st['f']
+        Jp = J @ p_o
+        assert abs(st['JpJp'] - Jp @ Jp) <= 1e-7 * (Jp @ Jp)
+        assert relerr(h.gradient(), J.T @ (R * r_o)) < 1e-10
+        assert relerr(h.colnorms(), np.sqrt(np.asarray(J.multiply(J).sum(0)).ravel())) < 1e-10
+        JTJ = (J.T @ J).tocsc()
+        lam = 1e-4 * JTJ.diagonal().sum() / J.shape[1]
+        q_o, _ = o.normal_solve((JTJ + lam * sp.identity(J.shape[1])).tocsc(), -(J.T @ (R * r_o)))
+        q_h, _ = h.linearize_solve(x0, lam, False)
+        assert relerr(q_h, q_o) < TOL_STEP
+    finally:
+        h.close()
+    if name != 'C1':
+        for damping in ('gna', 'lm', 'lmp'):
+            res, ok, iters, s0, E = bundle(s, damping)
+            ro, oko, ito, s0o, Eo = o.bundle(s, damping)
+            assert ok and oko and relerr(E.x, Eo.x) < TOL_X
+            check_history(E, Eo, iters, ito, damping)
+
+
 @pytest.mark.parametrize('knob', ['DBAT_HIP_TILE3=0', 'DBAT_HIP_TILE_BMAX=3'])
 def test_fixed_io_single_producer_group_kernel(hip, knob, monkeypatch):
     """Fixed-IO problems run k_build_tile3 (two producer groups) by default;
@@ -930,3 +978,27 @@ def test_fixed_io_single_producer_group_kernel(hip, knob, monkeypatch):
     monkeypatch.delenv(name)
     ro, oko, ito, s0o, Eo = o.bundle(s, 'lm')
     assert ok and oko and relerr(E.x, Eo.x) < TOL_X
+
+
+@pytest.mark.parametrize('damping', ['gna', 'lm'])
+def test_c_driver_solve_matches_bundle(hip, damping, tmp_path):
+    """create -> solve -> final residuals -> destroy from a compiled C caller of the ABI
+    (tests/abi_c_driver.c, no Python in the process): same x, sigma0 and iteration count as
+    bundle() through the ctypes binding."""
+    import json
+    import subprocess
+    from dbat_amd import bundle, _hip
+    from helpers import build_abi_c_driver, dump_problem
+    s, _ = synth_struct('tiny', 'priors')
+    path = str(tmp_path / 'problem.bin')
+    dump_problem(s, path)
+    r = subprocess.run([build_abi_c_driver(), 'solve', path, str(_hip.DAMP[damping])], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout)
+    res, ok, iters, s0, E = bundle(s, damping)
+    assert out['code'] == E.code == 0
+    assert relerr(np.array(out['x']), E.x) < 1e-9
+    assert abs(out['sigma0'] - s0) < 1e-9 * s0
+    assert abs(out['rtr'] - float(E.final.weighted.r @ E.final.weighted.r)) < 1e-8 * out['rtr']
+    if damping != 'lm':
+        assert out['iters'] == iters
