@@ -457,7 +457,8 @@ struct DataflowChol {
     uint64_t *d_rowbits = nullptr;
     DfTask *d_tasks = nullptr, *d_tile_ij = nullptr;
     double *d_tiles = nullptr, *d_qperm = nullptr;
-    long long *d_trace = nullptr;                       // optional per-task timestamps (chol_test)
+    long long *d_trace = nullptr;                       // optional per-task timestamps (DBAT_HIP_DF_TRACE=file)
+    std::vector<DfTask> h_tasks;
     std::vector<int> perm;                              // natural -> permuted (empty: identity)
     // doubles of the linv_work argument of solve(): one 64 x 64 inverse per tile row of the
     // factorised (padded) system
@@ -468,6 +469,22 @@ struct DataflowChol {
         for (void *p : ps) if (p) (void)hipFree(p);
         d_flags = d_ctl = d_bk_ptr = d_bk_idx = d_iperm = nullptr; d_toff = nullptr; d_rowbits = nullptr;
         d_tasks = d_tile_ij = nullptr; d_tiles = d_qperm = nullptr;
+    }
+    // per-task timestamps of the last solve (100 MHz ticks): task, i, k, t[0..15] per line
+    void dump_trace(hipStream_t stream, const char *path) const {
+        if (!d_trace) return;
+        std::vector<long long> h((size_t)(ntasks + nT) * 16);
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(h.data(), d_trace, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+        FILE *f = fopen(path, "w");
+        if (!f) return;
+        for (int t = 0; t < ntasks + nT; ++t) {
+            const int i = t < ntasks ? h_tasks[t].i : -1, k = t < ntasks ? h_tasks[t].k : nT - 1 - (t - ntasks);
+            fprintf(f, "%d,%d,%d", t, i, k);
+            for (int q = 0; q < 16; ++q) fprintf(f, ",%lld", h[(size_t)t * 16 + q]);
+            fprintf(f, "\n");
+        }
+        fclose(f);
     }
     template <class T>
     static bool up(T *&dst, const std::vector<T> &v) {
@@ -484,6 +501,8 @@ struct DataflowChol {
             for (int i = k; i <= nT; ++i)
                 if (has(i, k)) tasks.push_back(DfTask{i, k});
         ntasks = (int)tasks.size();
+        h_tasks = tasks;
+        if (getenv("DBAT_HIP_DF_TRACE") && hipMalloc(&d_trace, (size_t)(ntasks + nT) * 16 * sizeof(long long)) != hipSuccess) d_trace = nullptr;
         n_products = 0;
         for (const DfTask &tk : tasks)
             for (int w = 0; w <= (tk.k >> 6); ++w) {
@@ -650,6 +669,7 @@ struct DataflowChol {
                double *ldiag = nullptr) {
         (void)hipMemsetAsync(info_dev, 0, sizeof(int), stream);
         (void)hipMemsetAsync(d_ctl, 0, 2 * sizeof(int), stream);
+        if (d_trace) (void)hipMemsetAsync(d_trace, 0, (size_t)(ntasks + nT) * 16 * sizeof(long long), stream);
         ++epoch;
         DfView V;
         V.toff = d_toff; V.rowbits = d_rowbits; V.W = W;

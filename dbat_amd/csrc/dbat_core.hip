@@ -90,7 +90,8 @@ struct Core {
     DevBuf<uint8_t> z_est, z_mine, o_lc, o_pidx;
     DevBuf<int32_t> tile_batch, tile_cam_start, tile_cams, tile_io_start, tile_iocols;
     DevBuf<uint8_t> tile_cam_io;
-    DevBuf<int32_t> sg_chunk, sg_tile_chunk0;       // signature groups (sig.hpp)
+    DevBuf<int32_t> sg_chunk, sg_tile_chunk0, sg_gcam;   // signature groups (sig.hpp)
+    int64_t sg_nchunks = 0;
     DevBuf<uint8_t> sg_lc;
     DevBuf<double> sg_uv, sg_w;
     bool use_sig = false;
@@ -112,7 +113,7 @@ struct Core {
     DevBuf<CamRec> cams;
     DevBuf<double> z, zt, dz, zlin, vtmp, vtmp2, xbuf;  // NZ each (xbuf: n)
     DevBuf<double> red;      // [S | g_red | g_c | diagU | scal(8)]
-    DevBuf<double> jn2c, dscale, rhs, Vinv, gp, jn2p, r_w, partial, scal;
+    DevBuf<double> jn2c, dscale, rhs, Vinv, gp, jn2p, partial, scal;
     DevBuf<int> info;
     DevBuf<double> ywork, linv, ldiag;
     DataflowChol dfchol;                // persistent task-graph Cholesky, cameras in nested-dissection order (chol_df.hpp)
@@ -202,7 +203,8 @@ struct Core {
         d.tile_io_start = tile_io_start.p; d.tile_iocols = tile_iocols.p; d.tile_cam_io = tile_cam_io.p;
         use_sig = P.sg_ok && ntiles > 0;
         if (use_sig) {
-            sg_chunk.upload(P.sg_chunk); sg_tile_chunk0.upload(P.sg_tile_chunk0); sg_lc.upload(P.sg_lc);
+            sg_chunk.upload(P.sg_chunk); sg_tile_chunk0.upload(P.sg_tile_chunk0); sg_lc.upload(P.sg_lc); sg_gcam.upload(P.sg_gcam);
+            sg_nchunks = (int64_t)P.sg_chunk.size() / 8;
             sg_uv.upload(P.sg_uv);
             if (!P.uniform_w) sg_w.upload(P.sg_w);
             sig_rb = 6 * P.sg_kmax + 1 <= 64 ? 4 : 5;
@@ -257,7 +259,6 @@ struct Core {
         HIPCHK(hipMemset(Vinv.p, 0, (size_t)6 * P.np * 8));
         HIPCHK(hipMemset(gp.p, 0, (size_t)3 * P.np * 8));
         HIPCHK(hipMemset(jn2p.p, 0, (size_t)3 * P.np * 8));
-        r_w.alloc(std::max<int64_t>(2 * nobs, 2));
         grid_obs = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(nobs, 256), env_grid_obs()));
         grid_z = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(P.NZ, 256), 2048));
         scal.alloc((size_t)16 + 2 * (size_t)P.nranks);
@@ -271,7 +272,7 @@ struct Core {
         tile2_pc = TILE2_PC;
         lds_tile2 = ((size_t)TILE2_NBUF * 3 * tile2_pc * TILE_LD + (size_t)256 * 9 + (size_t)128 * 15 + TILE_LD) * sizeof(double);
         use_tile2 = P.BT == 256 && P.ncolmax <= 14 && getenv("DBAT_HIP_TILE_V1") == nullptr;
-        partial.alloc((size_t)4 * std::max<int64_t>(std::max<int64_t>(std::max<int64_t>(nb + ntiles + ngiant, n_cm_chunks_all), 2048), 1));
+        partial.alloc((size_t)4 * std::max<int64_t>(std::max<int64_t>(std::max<int64_t>(nb + ntiles + ngiant + (int64_t)P.sg_chunk.size() / 8, n_cm_chunks_all), 2048), 1));
         set_lds_limits();
         HIPCHK(hipMemcpy(z.p, P.z0.data(), P.NZ * 8, hipMemcpyHostToDevice));
         HIPCHK(hipMemset(dz.p, 0, P.NZ * 8));
@@ -437,8 +438,8 @@ struct Core {
         const int64_t nb_tiled = P.nb_tiled;
         if (ntiles > 0 && nb_tiled > 0) {
             npart = ntiles;
-#define L_TILE(M, NCXV) LAUNCHK((k_build_tile<M, NCXV>), dim3((unsigned)ntiles), dim3(P.BT), lds_tile, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p, pivmm.p)
-#define L_TILE2(M, NCXV) LAUNCHK((k_build_tile2<M, NCXV, TILE2_PC, TILE2_NBUF>), dim3((unsigned)ntiles), dim3(512), lds_tile2, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p, pivmm.p)
+#define L_TILE(M, NCXV) LAUNCHK((k_build_tile<M, NCXV>), dim3((unsigned)ntiles), dim3(P.BT), lds_tile, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, partial.p, pivmm.p)
+#define L_TILE2(M, NCXV) LAUNCHK((k_build_tile2<M, NCXV, TILE2_PC, TILE2_NBUF>), dim3((unsigned)ntiles), dim3(512), lds_tile2, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, partial.p, pivmm.p)
 #define L_CAMN(M, NCXV) LAUNCHK((k_cam_normal<M, NCXV>), dim3((unsigned)n_cm_chunks), dim3(256), 0, stream, d, zz, cams.p, cm_pt.p, cm_uv.p, P.uniform_w ? (const double *)nullptr : cm_w.p, cm_chunk_cam.p, cm_chunk_start.p, S, g_c, g_red, diagU)
             if (use_tile2 && tile_ncx <= 14 && n_cm_chunks > 0) {
                 // camera side of the tiled observations: J_c'J_c, J_c'r, squared column norms
@@ -446,8 +447,8 @@ struct Core {
             }
 #undef L_CAMN
             mark(0);                                 // events around the tile kernel alone (bench roofline)
-#define L_TILE3(M, DUMMY) LAUNCHK((k_build_tile3<M, TILE3_PC, TILE3_NBUF>), dim3((unsigned)ntiles), dim3(768), lds_tile3, stream, d, zz, cams.p, lambda, scale, S, g_red, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p, pivmm.p)
-#define L_SIG(M, RBV) LAUNCHK((k_build_sig<M, RBV>), dim3((unsigned)ntiles), dim3(256), sig_lds_bytes(RBV), stream, d, zz, cams.p, lambda, scale, S, g_red, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p, pivmm.p, sg_chunk.p, sg_tile_chunk0.p, sg_lc.p, sg_uv.p, P.uniform_w ? (const double *)nullptr : sg_w.p)
+#define L_TILE3(M, DUMMY) LAUNCHK((k_build_tile3<M, TILE3_PC, TILE3_NBUF>), dim3((unsigned)ntiles), dim3(768), lds_tile3, stream, d, zz, cams.p, lambda, scale, S, g_red, Vinv.p, gp.p, jn2p.p, partial.p, pivmm.p)
+#define L_SIG(M, RBV) LAUNCHK((k_build_sig<M, RBV>), dim3((unsigned)ntiles), dim3(64 * sig_waves(RBV)), sig_lds_bytes(RBV), stream, d, zz, cams.p, lambda, scale, S, g_red, Vinv.p, gp.p, jn2p.p, partial.p, pivmm.p, sg_chunk.p, sg_tile_chunk0.p, sg_lc.p, sg_uv.p, P.uniform_w ? (const double *)nullptr : sg_w.p)
             if (use_sig && sig_rb == 4) { DISPATCH_MODEL(L_SIG, 4) }
             else if (use_sig) { DISPATCH_MODEL(L_SIG, 5) }
             else if (use_tile3 && tile_ncx == 6) { DISPATCH_MODEL(L_TILE3, 0) }
@@ -463,19 +464,29 @@ struct Core {
         const bool no_tiles = !(ntiles > 0 && nb_tiled > 0);
         if (no_tiles) mark(0);                       // no tile kernel: the events bracket k_build instead
         if (nb > nb_tiled) {
-#define L_BUILD(M, IO) LAUNCHK((k_build<M, IO>), dim3((unsigned)(nb - nb_tiled)), dim3(P.BT), lds_build, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p + npart, pivmm.p, (int)nb_tiled)
+#define L_BUILD(M, IO) LAUNCHK((k_build<M, IO>), dim3((unsigned)(nb - nb_tiled)), dim3(P.BT), lds_build, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, partial.p + npart, pivmm.p, (int)nb_tiled)
             if (P.with_io) { DISPATCH_MODEL(L_BUILD, true) } else { DISPATCH_MODEL(L_BUILD, false) }
 #undef L_BUILD
             npart += nb - nb_tiled;
         }
         if (no_tiles) mark(1);
         if (ngiant > 0) {                            // points with more observations than a batch holds
-#define L_GIANT(M, IO) LAUNCHK((k_build_giant<M, IO>), dim3((unsigned)ngiant), dim3(giant_threads), 0, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, r_w.p, partial.p + npart, pivmm.p)
+#define L_GIANT(M, IO) LAUNCHK((k_build_giant<M, IO>), dim3((unsigned)ngiant), dim3(giant_threads), 0, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, partial.p + npart, pivmm.p)
             if (P.with_io) { DISPATCH_MODEL(L_GIANT, true) } else { DISPATCH_MODEL(L_GIANT, false) }
 #undef L_GIANT
             npart += ngiant;
         }
-        if ((d.ablate & 32) && use_tile2) {          // phase profile of the wave-specialised tile kernel
+        if ((d.ablate & 32) && use_sig) {            // phase profile of the signature kernel (wave 0 of every tile)
+            unsigned long long h[16];
+            HIPCHK(hipStreamSynchronize(stream));
+            HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tile2_prof), sizeof(h)));
+            static const char *nm[8] = {"tile init", "chunk head", "pass 1", "pass 2 eval+write", "pass 2 mfma", "chunk flush", "wait for the tile", "tile flush"};
+            fprintf(stderr, "[sig prof, us per tile (wave 0) avg over %d tiles]", (int)ntiles);
+            for (int i = 0; i < 8; ++i) fprintf(stderr, " %s=%.2f", nm[i], h[i] * 0.01 / (double)std::max<int64_t>(ntiles, 1));
+            fprintf(stderr, "\n");
+            memset(h, 0, sizeof(h));
+            HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_tile2_prof), h, sizeof(h)));
+        } else if ((d.ablate & 32) && use_tile2) {   // phase profile of the wave-specialised tile kernel
             unsigned long long h[16];
             HIPCHK(hipStreamSynchronize(stream));
             HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tile2_prof), sizeof(h)));
@@ -530,6 +541,7 @@ struct Core {
                                     hipMemcpyDeviceToDevice, stream));
         }
         HIPCHK(hipGetLastError());                   // launches inside the factorisation helpers
+        if (const char *tp = getenv("DBAT_HIP_DF_TRACE")) (use_perm && !chol_in_place ? dfchol : dfchol_ip).dump_trace(stream, tp);
         mark(3);
         LAUNCHK(k_diag_minmax, dim3(1), dim3(256), 0, stream, d, ldiag.p, pivmm.p + 2);
         LAUNCHK(k_unscale, dim3((unsigned)cdiv(P.NS, 256)), dim3(256), 0, stream, P.NS, rhs.p, dscale.p, dz.p);
@@ -539,19 +551,29 @@ struct Core {
     // ---- K7: back-substitution; sums {||Jp||^2, r'Jp, ||p||^2}
     void backsub_enqueue() {
         mark(4);
-        if (nb > 0) {
-#define L_BACK(M, NCXV) LAUNCHK((k_backsub<M, NCXV>), dim3((unsigned)nb), dim3(P.BT), lds_back, stream, d, zlin.p, cams.p, Vinv.p, gp.p, r_w.p, dz.p, partial.p)
+        // the points of the signature chunks by k_backsub_sig (one wave per chunk), the other batches by
+        // k_backsub; partial: [nb batches][2] (the tiled batches' slots stay zero), giants, sig workgroups
+        const int64_t b_first = use_sig ? P.nb_tiled : 0;
+        const int64_t n_sig_wg = use_sig ? cdiv(sg_nchunks, 4) : 0;
+        if (use_sig) HIPCHK(hipMemsetAsync(partial.p, 0, (size_t)2 * P.nb_tiled * sizeof(double), stream));
+        if (n_sig_wg > 0) {
+#define L_BACKS(M, dummy) LAUNCHK((k_backsub_sig<M>), dim3((unsigned)n_sig_wg), dim3(256), 0, stream, d, zlin.p, cams.p, Vinv.p, gp.p, dz.p, partial.p + 2 * (nb + ngiant), sg_chunk.p, (int)sg_nchunks, sg_gcam.p, sg_uv.p, P.uniform_w ? (const double *)nullptr : sg_w.p)
+            DISPATCH_MODEL(L_BACKS, 0)
+#undef L_BACKS
+        }
+        if (nb > b_first) {
+#define L_BACK(M, NCXV) LAUNCHK((k_backsub<M, NCXV>), dim3((unsigned)(nb - b_first)), dim3(P.BT), lds_back, stream, d, zlin.p, cams.p, Vinv.p, gp.p, dz.p, partial.p, (int)b_first)
             if (tile_ncx == 6) { DISPATCH_MODEL(L_BACK, 6) } else if (tile_ncx == 14) { DISPATCH_MODEL(L_BACK, 14) } else { DISPATCH_MODEL(L_BACK, MAXCOL) }
 #undef L_BACK
         }
         if (ngiant > 0) {
-#define L_BACKG(M, IO) LAUNCHK((k_backsub_giant<M, IO>), dim3((unsigned)ngiant), dim3(giant_threads), 0, stream, d, zlin.p, cams.p, Vinv.p, gp.p, r_w.p, dz.p, partial.p + 2 * nb)
+#define L_BACKG(M, IO) LAUNCHK((k_backsub_giant<M, IO>), dim3((unsigned)ngiant), dim3(giant_threads), 0, stream, d, zlin.p, cams.p, Vinv.p, gp.p, dz.p, partial.p + 2 * nb)
             if (P.with_io) { DISPATCH_MODEL(L_BACKG, true) } else { DISPATCH_MODEL(L_BACKG, false) }
 #undef L_BACKG
         }
         mark(5);
-        LAUNCHK((k_sum_partials<2>), dim3(1), dim3(1024), 0, stream, partial.p, nb + ngiant, scal.p, 0);
-        LAUNCHK(k_prior_jv, dim3(grid_z), dim3(256), 0, stream, d, zlin.p, dz.p, partial.p);
+        LAUNCHK((k_sum_partials<2>), dim3(1), dim3(1024), 0, stream, partial.p, nb + ngiant + n_sig_wg, scal.p, 0);
+        LAUNCHK(k_prior_jv, dim3(grid_z), dim3(256), 0, stream, d, zlin.p, dz.p, g_c, gp.p, partial.p);
         LAUNCHK((k_sum_partials<3>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_z, scal.p + 4, 0);
     }
     // solve at the current linearisation: p in dz.  Returns true if the
@@ -645,11 +667,11 @@ struct Core {
     // ||J v||^2 and r'Jv at the linearisation point, ||v||^2 over owned entries
     void jtimes(const double *v, double &JvJv, double &rJv, double &vv) {
         prep_cams(zlin.p);
-#define L_JT(M, NCXV) LAUNCHK((k_jtimes<M, NCXV>), dim3(grid_obs), dim3(256), 0, stream, d, zlin.p, cams.p, v, r_w.p, partial.p)
+#define L_JT(M, NCXV) LAUNCHK((k_jtimes<M, NCXV>), dim3(grid_obs), dim3(256), 0, stream, d, zlin.p, cams.p, v, partial.p)
         if (tile_ncx == 6) { DISPATCH_MODEL(L_JT, 6) } else if (tile_ncx == 14) { DISPATCH_MODEL(L_JT, 14) } else { DISPATCH_MODEL(L_JT, MAXCOL) }
 #undef L_JT
         LAUNCHK((k_sum_partials<2>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_obs, scal.p, 0);
-        LAUNCHK(k_prior_jv, dim3(grid_z), dim3(256), 0, stream, d, zlin.p, v, partial.p);
+        LAUNCHK(k_prior_jv, dim3(grid_z), dim3(256), 0, stream, d, zlin.p, v, g_c, gp.p, partial.p);
         LAUNCHK((k_sum_partials<3>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_z, scal.p + 4, 0);
         do_allreduce(scal.p, 8);
         double h[8];

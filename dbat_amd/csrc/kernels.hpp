@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void k_build(DevProblem d, const double *__res
                                                double *__restrict__ S, double *__restrict__ g_c,
                                                double *__restrict__ g_red, double *__restrict__ diagU,
                                                double *__restrict__ Vinv, double *__restrict__ gp,
-                                               double *__restrict__ jn2p, double *__restrict__ r_w,
+                                               double *__restrict__ jn2p,
                                                double *__restrict__ partial,
                                                unsigned long long *__restrict__ pivmm, int batch0) {
     constexpr int NCX = WITH_IO ? MAXCOL : 6;
@@ -367,7 +367,6 @@ __global__ __launch_bounds__(256) void k_build(DevProblem d, const double *__res
         C = cams + cam;
         ncol = WITH_IO ? C->ncol : 6;
         eval_obs_cols<MODEL, WITH_IO>(d, *C, z, o, pt, r, E, B);
-        r_w[2 * o] = r[0]; r_w[2 * o + 1] = r[1];
         double *rd = red + (size_t)t * 9;
         rd[0] = B[0][0] * B[0][0] + B[1][0] * B[1][0];
         rd[1] = B[0][0] * B[0][1] + B[1][0] * B[1][1];
@@ -532,7 +531,7 @@ __global__ __launch_bounds__(256) void k_build_giant(DevProblem d, const double 
                                                      double *__restrict__ S, double *__restrict__ g_c,
                                                      double *__restrict__ g_red, double *__restrict__ diagU,
                                                      double *__restrict__ Vinv, double *__restrict__ gp,
-                                                     double *__restrict__ jn2p, double *__restrict__ r_w,
+                                                     double *__restrict__ jn2p,
                                                      double *__restrict__ partial,
                                                      unsigned long long *__restrict__ pivmm) {
     constexpr int NCX = WITH_IO ? MAXCOL : 6;
@@ -551,7 +550,6 @@ __global__ __launch_bounds__(256) void k_build_giant(DevProblem d, const double 
         const int ncol = WITH_IO ? C.ncol : 6;
         double r[2], E[2][NCX], B[2][3];
         eval_obs_cols<MODEL, WITH_IO>(d, C, z, o, pt, r, E, B);
-        r_w[2 * o] = r[0]; r_w[2 * o + 1] = r[1];
         rr += r[0] * r[0] + r[1] * r[1];
         acc[0] += B[0][0] * B[0][0] + B[1][0] * B[1][0];
         acc[1] += B[0][0] * B[0][1] + B[1][0] * B[1][1];
@@ -660,7 +658,7 @@ template <int MODEL, bool WITH_IO>
 __global__ __launch_bounds__(256) void k_backsub_giant(DevProblem d, const double *__restrict__ z,
                                                        const CamRec *__restrict__ cams,
                                                        const double *__restrict__ Vinv, const double *__restrict__ gp,
-                                                       const double *__restrict__ r_w, double *__restrict__ dz,
+                                                 double *__restrict__ dz,
                                                        double *__restrict__ partial /* [ngiant][2] */) {
     constexpr int NCX = WITH_IO ? MAXCOL : 6;
     __shared__ double sh[3 * 4];
@@ -708,7 +706,6 @@ __global__ __launch_bounds__(256) void k_backsub_giant(DevProblem d, const doubl
         const double j0 = tt[0] + B[0][0] * dps[0] + B[0][1] * dps[1] + B[0][2] * dps[2];
         const double j1 = tt[1] + B[1][0] * dps[0] + B[1][1] * dps[1] + B[1][2] * dps[2];
         acc[0] += j0 * j0 + j1 * j1;
-        acc[1] += r_w[2 * o] * j0 + r_w[2 * o + 1] * j1;
     }
     block_sum<2>(acc, sh);
     if (t == 0) { partial[2 * blockIdx.x] = acc[0]; partial[2 * blockIdx.x + 1] = acc[1]; }
@@ -782,7 +779,7 @@ __global__ __launch_bounds__(256) void k_build_tile(DevProblem d, const double *
                                                     double *__restrict__ S, double *__restrict__ g_c,
                                                     double *__restrict__ g_red, double *__restrict__ diagU,
                                                     double *__restrict__ Vinv, double *__restrict__ gp,
-                                                    double *__restrict__ jn2p, double *__restrict__ r_w,
+                                                    double *__restrict__ jn2p,
                                                     double *__restrict__ partial,
                                                     unsigned long long *__restrict__ pivmm) {
     constexpr int PC = TILE_PC, KC = 3 * PC, LD = TILE_LD;
@@ -854,7 +851,6 @@ __global__ __launch_bounds__(256) void k_build_tile(DevProblem d, const double *
             }
             if (d.ablate & 4) { for (int q = 0; q < NCX; ++q) { E[0][q] = 1e-3 * (q + lc); E[1][q] = 2e-3 * q; } for (int q = 0; q < 3; ++q) { B[0][q] = q + 1.0; B[1][q] = 0.5 * q; } }
             else eval_obs_cols_n<MODEL, NCX>(d, C, z, o, pt, r, E, B);
-            r_w[2 * o] = r[0]; r_w[2 * o + 1] = r[1];
             rr += r[0] * r[0] + r[1] * r[1];
             double *rd = red + (size_t)t * 9;
             rd[0] = B[0][0] * B[0][0] + B[1][0] * B[1][0];
@@ -1248,7 +1244,7 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
                                                      double *__restrict__ S, double *__restrict__ g_c,
                                                      double *__restrict__ g_red, double *__restrict__ diagU,
                                                      double *__restrict__ Vinv, double *__restrict__ gp,
-                                                     double *__restrict__ jn2p, double *__restrict__ r_w,
+                                                     double *__restrict__ jn2p,
                                                      double *__restrict__ partial,
                                                      unsigned long long *__restrict__ pivmm) {
     constexpr int KC = 3 * PC, LD = TILE_LD, PANEL = KC * LD;
@@ -1355,7 +1351,6 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
                     ciop[0] = cp[0]; ciop[1] = cp[1]; ciop[2] = cp[2]; ciop[3] = cp[3];
                 }
                 eval_obs_pre<MODEL, NCX>(d, C, Q, uu, vv, w0, w1, est, r, E, B);
-                r_w[2 * o] = r[0]; r_w[2 * o + 1] = r[1];
                 rr += r[0] * r[0] + r[1] * r[1];
                 // per-point sums of B'B and B'r with LDS atomics (the LDS unit, not the FP64 pipe the
                 // matrix work of the consumer wave on this SIMD is using)
@@ -1652,7 +1647,7 @@ __global__ __launch_bounds__(768) void k_build_tile3(DevProblem d, const double 
                                                      const CamRec *__restrict__ cams, double lambda, int scale,
                                                      double *__restrict__ S, double *__restrict__ g_red,
                                                      double *__restrict__ Vinv, double *__restrict__ gp,
-                                                     double *__restrict__ jn2p, double *__restrict__ r_w,
+                                                     double *__restrict__ jn2p,
                                                      double *__restrict__ partial,
                                                      unsigned long long *__restrict__ pivmm) {
     constexpr int NCX = 6;
@@ -1751,7 +1746,6 @@ __global__ __launch_bounds__(768) void k_build_tile3(DevProblem d, const double 
                 const CamRec &C = cams[cam];
                 const double w0 = d.o_w ? d.o_w[2 * o] : C.w[0], w1 = d.o_w ? d.o_w[2 * o + 1] : C.w[1];
                 eval_obs_pre<MODEL, NCX>(d, C, Q, uu, vv, w0, w1, est, r, E, B);
-                r_w[2 * o] = r[0]; r_w[2 * o + 1] = r[1];
                 rr += r[0] * r[0] + r[1] * r[1];
                 double *ps = redg + (size_t)pidx * 9;
                 atomic_add_f64(ps + 0, B[0][0] * B[0][0] + B[1][0] * B[1][0]);
@@ -2252,8 +2246,8 @@ template <int MODEL, int NCXT>
 __global__ __launch_bounds__(256) void k_backsub(DevProblem d, const double *__restrict__ z,
                                                  const CamRec *__restrict__ cams,
                                                  const double *__restrict__ Vinv, const double *__restrict__ gp,
-                                                 const double *__restrict__ r_w, double *__restrict__ dz,
-                                                 double *__restrict__ partial /* [nb][2] */) {
+                                                 double *__restrict__ dz,
+                                                 double *__restrict__ partial /* [nb][2] */, int batch0) {
     constexpr int NCX = NCXT;
     constexpr bool WITH_IO = NCXT > 6;
     extern __shared__ double smem[];
@@ -2261,8 +2255,9 @@ __global__ __launch_bounds__(256) void k_backsub(DevProblem d, const double *__r
     double *dpl = red + (size_t)blockDim.x * 3;   // [BT][3]  dp at leader slot
     __shared__ double sh[16];
     const int t = threadIdx.x;
-    const int64_t o0 = d.batch_start[blockIdx.x];
-    const int nobs = (int)(d.batch_start[blockIdx.x + 1] - o0);
+    const int batch = batch0 + blockIdx.x;
+    const int64_t o0 = d.batch_start[batch];
+    const int nobs = (int)(d.batch_start[batch + 1] - o0);
     const bool active = t < nobs;
     const int64_t o = o0 + t;
     double r[2] = {0, 0}, tt[2] = {0, 0};
@@ -2303,10 +2298,10 @@ __global__ __launch_bounds__(256) void k_backsub(DevProblem d, const double *__r
         const double j0 = tt[0] + B[0][0] * dp[0] + B[0][1] * dp[1] + B[0][2] * dp[2];
         const double j1 = tt[1] + B[1][0] * dp[0] + B[1][1] * dp[1] + B[1][2] * dp[2];
         acc[0] = j0 * j0 + j1 * j1;
-        acc[1] = r_w[2 * o] * j0 + r_w[2 * o + 1] * j1;
+        // r'Jp = g'p is summed over the unknowns in k_prior_jv (no residual needed here)
     }
     block_sum<2>(acc, sh);
-    if (t == 0) { partial[2 * blockIdx.x] = acc[0]; partial[2 * blockIdx.x + 1] = acc[1]; }
+    if (t == 0) { partial[2 * (int64_t)batch] = acc[0]; partial[2 * (int64_t)batch + 1] = acc[1]; }
 }
 
 // ---------------------------------------------------------------- K8 ----
@@ -2315,7 +2310,7 @@ __global__ __launch_bounds__(256) void k_backsub(DevProblem d, const double *__r
 template <int MODEL, int NCXT>
 __global__ __launch_bounds__(256) void k_jtimes(DevProblem d, const double *__restrict__ z,
                                                 const CamRec *__restrict__ cams, const double *__restrict__ v,
-                                                const double *__restrict__ r_w, double *__restrict__ partial) {
+                                                double *__restrict__ partial) {
     constexpr int NCX = NCXT;
     constexpr bool WITH_IO = NCXT > 6;
     __shared__ double sh[16];
@@ -2334,22 +2329,25 @@ __global__ __launch_bounds__(256) void k_jtimes(DevProblem d, const double *__re
         for (int a = 0; a < NCX; ++a)
             if (a < ncol) { const double vc = v[C.col[a]]; j0 += E[0][a] * vc; j1 += E[1][a] * vc; }
         acc[0] += j0 * j0 + j1 * j1;
-        acc[1] += r_w[2 * o] * j0 + r_w[2 * o + 1] * j1;
     }
     block_sum<2>(acc, sh);
     if (threadIdx.x == 0) { partial[2 * blockIdx.x] = acc[0]; partial[2 * blockIdx.x + 1] = acc[1]; }
 }
 
-// prior rows' share of {||Jv||^2, r'Jv, ||v||^2(owned)}: out[3] per block
+// {prior rows' share of ||Jv||^2, r'Jv of ALL rows, ||v||^2 (owned)}: out[3] per block.
+// r'Jv = (J'r)'v = g'v with the gradient of the last linearisation (g_c incl. the camera/IO
+// priors, g_p incl. the point priors): no pass over the observations, no stored residual.
 __global__ __launch_bounds__(256) void k_prior_jv(DevProblem d, const double *__restrict__ z,
-                                                  const double *__restrict__ v, double *__restrict__ partial) {
+                                                  const double *__restrict__ v, const double *__restrict__ g_c,
+                                                  const double *__restrict__ gp, double *__restrict__ partial) {
     __shared__ double sh[24];
     double acc[3] = {0, 0, 0};
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.NZ; i += stride) {
         if (!d.z_mine[i]) continue;
         const double w = d.z_prw[i], vi = d.z_est[i] ? v[i] : 0.0;
-        if (w > 0) { acc[0] += w * vi * vi; acc[1] += w * (z[i] - d.z_prv[i]) * vi; }
+        if (w > 0) acc[0] += w * vi * vi;
+        acc[1] += (i < d.NS ? g_c[i] : gp[i - d.NS]) * vi;
         acc[2] += vi * vi;
     }
     block_sum<3>(acc, sh);

@@ -93,7 +93,8 @@ struct Plan {
     static constexpr int SG_CHUNK = 64;
     std::vector<int32_t> sg_chunk;                 // [nchunks][8]
     std::vector<int32_t> sg_tile_chunk0;           // [ntiles+1]
-    std::vector<uint8_t> sg_lc;                    // tile-local camera index of every slot of every group
+    std::vector<uint8_t> sg_lc;                    // [nchunks][16] tile-local camera index of every slot
+    std::vector<int32_t> sg_gcam;                  // [nchunks][16] the same cameras by their global index
     std::vector<double> sg_uv;                     // slot-major copy of o_uv: group g, slot j, point i at 2*(obs0_g + j*m_g + i)
     std::vector<double> sg_w;                      // the same for o_w (empty if uniform)
     int sg_kmax = 0;                               // largest k among the tiled points
@@ -622,7 +623,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     P.tile_io_start.push_back(0);
     int64_t pos = 0, bstart = 0, tile_first_obs = 0;
     // signature groups of the current tile
-    P.sg_chunk.clear(); P.sg_tile_chunk0.assign(1, 0); P.sg_lc.clear(); P.sg_kmax = 0; P.sg_ngroups = 0; P.sg_npoints = 0;
+    P.sg_chunk.clear(); P.sg_tile_chunk0.assign(1, 0); P.sg_lc.clear(); P.sg_gcam.clear(); P.sg_kmax = 0; P.sg_ngroups = 0; P.sg_npoints = 0;
     P.sg_uv.assign(P.o_uv.size(), 0.0);
     if (!P.uniform_w) P.sg_w.assign(P.o_w.size(), 0.0); else P.sg_w.clear();
     std::vector<int32_t> sg_gc;                      // global camera of every sg_lc entry (converted when the tile closes)
@@ -632,12 +633,14 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     auto close_group = [&]() {
         if (g_npts == 0) return;
         const int k = (int)g_cams.size();
-        const int32_t lc0 = (int32_t)sg_gc.size();
-        for (int32_t c : g_cams) sg_gc.push_back(c);
-        for (int64_t c0 = 0; c0 < g_npts; c0 += Plan::SG_CHUNK) {
-            const int32_t ch[8] = {(int32_t)(g_rank0 + c0), (int32_t)std::min<int64_t>(Plan::SG_CHUNK, g_npts - c0), k,
-                                   (int32_t)(g_pos0 + c0 * k), (int32_t)g_npts, (int32_t)c0, (int32_t)g_pos0, lc0};
+        // chunks of equal length (a group of 70 points: 35 + 35, not 64 + 6)
+        const int64_t nchunks = (g_npts + Plan::SG_CHUNK - 1) / Plan::SG_CHUNK;
+        for (int64_t q = 0; q < nchunks; ++q) {
+            const int64_t c0 = q * g_npts / nchunks, c1 = (q + 1) * g_npts / nchunks;
+            const int32_t ch[8] = {(int32_t)(g_rank0 + c0), (int32_t)(c1 - c0), k,
+                                   (int32_t)(g_pos0 + c0 * k), (int32_t)g_npts, (int32_t)c0, (int32_t)g_pos0, 0};
             P.sg_chunk.insert(P.sg_chunk.end(), ch, ch + 8);
+            for (int j = 0; j < 16; ++j) sg_gc.push_back(j < k ? g_cams[j] : -1);      // 16 camera slots per chunk
         }
         for (int64_t i = 0; i < g_npts; ++i)         // slot-major copy of the group's image coordinates
             for (int j = 0; j < k; ++j) {
@@ -670,7 +673,24 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         P.tile_io_start.push_back((int32_t)P.tile_iocols.size());
         cur_io.clear();
         P.sg_lc.resize(sg_gc.size());
-        for (size_t e = sg_lc_tile0; e < sg_gc.size(); ++e) P.sg_lc[e] = (uint8_t)loc[sg_gc[e]];
+        for (size_t e = sg_lc_tile0; e < sg_gc.size(); ++e) P.sg_lc[e] = sg_gc[e] >= 0 ? (uint8_t)loc[sg_gc[e]] : 0;
+        {   // the tile's chunks longest first: its waves take them in this order and finish together
+            const size_t q0 = (size_t)P.sg_tile_chunk0.back(), q1 = P.sg_chunk.size() / 8;
+            std::vector<int32_t> ord(q1 - q0);
+            std::iota(ord.begin(), ord.end(), 0);
+            std::stable_sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) {
+                return (int64_t)P.sg_chunk[8 * (q0 + a) + 1] * P.sg_chunk[8 * (q0 + a) + 2] >
+                       (int64_t)P.sg_chunk[8 * (q0 + b) + 1] * P.sg_chunk[8 * (q0 + b) + 2];
+            });
+            std::vector<int32_t> cd(P.sg_chunk.begin() + 8 * q0, P.sg_chunk.end());
+            std::vector<uint8_t> lcs(P.sg_lc.begin() + 16 * q0, P.sg_lc.end());
+            for (size_t a = 0; a < ord.size(); ++a) {
+                std::copy(cd.begin() + 8 * ord[a], cd.begin() + 8 * ord[a] + 8, P.sg_chunk.begin() + 8 * (q0 + a));
+                std::copy(lcs.begin() + 16 * ord[a], lcs.begin() + 16 * ord[a] + 16, P.sg_lc.begin() + 16 * (q0 + a));
+            }
+        }
+        P.sg_gcam.resize(P.sg_lc.size());
+        for (size_t e = sg_lc_tile0; e < sg_gc.size(); ++e) P.sg_gcam[e] = cur_cams.empty() ? 0 : cur_cams[P.sg_lc[e]];
         sg_lc_tile0 = sg_gc.size();
         P.sg_tile_chunk0.push_back((int32_t)(P.sg_chunk.size() / 8));
         for (int32_t c : cur_cams) { P.tile_cams.push_back(c); loc[c] = -1; }

@@ -36,71 +36,116 @@
 
 namespace dbat {
 
-constexpr int SIG_LDK = 22;          // k-columns per panel row: 18 used (6 points), stride = 2 mod 4 doubles
+constexpr int SIG_LDK = 18;          // k-columns per panel row: 6 points of a round; stride = 2 mod 4 doubles
 constexpr int SIG_PPR = 6;           // points per round of pass 2
-constexpr int SIG_PV = 13;           // per point in LDS: R (6) | R'g (3) | Q (3) | est bits
+constexpr int SIG_KMAXR = 13;        // cameras per group at most (Plan::SG_KMAX)
+constexpr int SIG_NW = 8;            // waves per workgroup (two per SIMD: one evaluates while the other multiplies)
 constexpr int SIG_CAMW = 58;         // doubles of a CamRec that the fixed-IO evaluation reads (.. w[2]) + eo_est
 constexpr int SIG_STILE = 8064;      // 126*127/2 = 8001 packed lower triangle of the tile, padded
 
 struct SigLds {                      // static part
     int next_chunk, abort_;
-    int lc[4][16];                   // tile-local camera of every slot of the wave's chunk
+    int grow[128];                   // row of the reduced system of every row of the tile
+    int lc[SIG_NW][16];              // tile-local camera of every slot of the wave's chunk
+    short tmap[SIG_NW][80];          // tile row of every row of the wave's chunk
 };
 
+__host__ __device__ constexpr int sig_waves(int RB) { return RB <= 4 ? SIG_NW : 6; }   // what 160 KB of LDS hold
 __host__ __device__ constexpr size_t sig_lds_bytes(int RB) {
-    return ((size_t)SIG_STILE + 128 + 21 * SIG_CAMW + 4 * ((size_t)RB * 16 * SIG_LDK + 64 * SIG_PV)) * sizeof(double);
+    return ((size_t)SIG_STILE + 128 + 21 * SIG_CAMW + sig_waves(RB) * ((size_t)RB * 16 * SIG_LDK)) * sizeof(double);
+}
+
+// value of x in lane `src` (ds_bpermute_b32 on both halves)
+__device__ __forceinline__ double lane_get(double x, int src) {
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_ds_bpermute(4 * src, (int)(b & 0xffffffffll));
+    const int hi = __builtin_amdgcn_ds_bpermute(4 * src, (int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
 template <int MODEL, int RB>
-__global__ __launch_bounds__(256) void k_build_sig(DevProblem d, const double *__restrict__ z,
+__global__ __launch_bounds__(64 * sig_waves(RB)) void k_build_sig(DevProblem d, const double *__restrict__ z,
                                                    const CamRec *__restrict__ cams, double lambda, int scale,
                                                    double *__restrict__ S, double *__restrict__ g_red,
                                                    double *__restrict__ Vinv, double *__restrict__ gp,
-                                                   double *__restrict__ jn2p, double *__restrict__ r_w,
+                                                   double *__restrict__ jn2p,
                                                    double *__restrict__ partial, unsigned long long *__restrict__ pivmm,
                                                    const int32_t *__restrict__ sg_chunk,
                                                    const int32_t *__restrict__ sg_tile_chunk0,
                                                    const uint8_t *__restrict__ sg_lc, const double *__restrict__ sg_uv,
                                                    const double *__restrict__ sg_w) {
-    constexpr int NBLK = RB * (RB + 1) / 2, PROWS = RB * 16, LDK = SIG_LDK;
+    constexpr int NBLK = RB * (RB + 1) / 2, PROWS = RB * 16, LDK = SIG_LDK, NW = sig_waves(RB), NT = 64 * NW;
     extern __shared__ double smem[];
     double *stile = smem;                            // packed lower triangle of the tile's block of S (negated sum)
     double *vt = stile + SIG_STILE;                  // [128] -(W V^-1 g) by tile row
     double *camw = vt + 128;                         // [21][SIG_CAMW]
     double *wave_base = camw + 21 * SIG_CAMW;
     __shared__ SigLds sy;
-    __shared__ double sh[8];
+    __shared__ double sh[16];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    double *pan = wave_base + (size_t)wave * (PROWS * LDK + 64 * SIG_PV);   // [PROWS][LDK]
-    double *pv = pan + PROWS * LDK;                                        // [64][SIG_PV]
+    double *pan = wave_base + (size_t)wave * (PROWS * LDK);                // [PROWS][LDK]
     const int tile = d.tile_order[blockIdx.x];
     const int c0 = d.tile_cam_start[tile];
     const int ncam = d.tile_cam_start[tile + 1] - c0;
     const int nrows = 6 * ncam;
     const int ch0 = sg_tile_chunk0[tile], ch1 = sg_tile_chunk0[tile + 1];
-    for (int i = t; i < SIG_STILE + 128; i += 256) stile[i] = 0.0;
-    for (int i = t; i < 4 * (PROWS * LDK + 64 * SIG_PV); i += 256) wave_base[i] = 0.0;
-    for (int i = t; i < ncam * SIG_CAMW; i += 256) {
+    for (int i = t; i < SIG_STILE + 128; i += NT) stile[i] = 0.0;
+    for (int i = t; i < NW * (PROWS * LDK); i += NT) wave_base[i] = 0.0;
+    for (int i = t; i < ncam * SIG_CAMW; i += NT) {
         const int c = i / SIG_CAMW, f = i - c * SIG_CAMW;
         const CamRec &C = cams[d.tile_cams[c0 + c]];
         camw[i] = f < SIG_CAMW - 1 ? reinterpret_cast<const double *>(&C)[f] : (double)C.eo_est;
     }
+    if (t < nrows) sy.grow[t] = 6 * d.tile_cams[c0 + t / 6] + t % 6;
     if (t == 0) { sy.next_chunk = ch0; sy.abort_ = 0; }
+    // DBAT_HIP_ABLATE & 32: phase clocks of wave 0 (100 MHz ticks), summed over the tiles into g_tile2_prof
+    const bool prof = (d.ablate & 32) && t == 0;
+    long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = prof ? wall_clock64() : 0;
+    auto lap = [&](int i) { if (prof) { const long long now = wall_clock64(); tp[i] += now - tlast; tlast = now; } };
     __syncthreads();
+    lap(0);
     double pmin = 1e300, pmax = 0.0, rr = 0.0;
     const int dix[3] = {0, 3, 5};
-    for (;;) {
-        int ch = 0;
-        if (lane == 0) ch = atomicAdd(&sy.next_chunk, 1);
-        ch = __builtin_amdgcn_readfirstlane(ch);
-        if (ch >= ch1) break;
-        const int32_t *cd = sg_chunk + 8 * (int64_t)ch;
-        const int pt0 = cd[0], npts = cd[1], k = cd[2], obs0 = cd[3], gm = cd[4], gi0 = cd[5], uv0 = cd[6], lc0 = cd[7];
-        if (lane < k) sy.lc[wave][lane] = sg_lc[lc0 + lane];
+    // the descriptor of the wave's next chunk is fetched while the current one is being worked on
+    auto grab = [&]() -> int {
+        int c = 0;
+        if (lane == 0) c = atomicAdd(&sy.next_chunk, 1);
+        return __builtin_amdgcn_readfirstlane(c);
+    };
+    int ch = grab();
+    int nd = 0, nlc = 0;                             // lane l < 8: word l of the next descriptor; l < 16: its camera list
+    if (ch < ch1) {
+        if (lane < 8) nd = sg_chunk[8 * (int64_t)ch + lane];
+        if (lane < 16) nlc = sg_lc[16 * (int64_t)ch + lane];
+    }
+    while (ch < ch1) {
+        const int pt0 = __builtin_amdgcn_readlane(nd, 0), npts = __builtin_amdgcn_readlane(nd, 1);
+        const int k = __builtin_amdgcn_readlane(nd, 2), obs0 = __builtin_amdgcn_readlane(nd, 3);
+        const int gm = __builtin_amdgcn_readlane(nd, 4), gi0 = __builtin_amdgcn_readlane(nd, 5);
+        const int uv0 = __builtin_amdgcn_readlane(nd, 6);
+        if (lane < k) sy.lc[wave][lane] = nlc;
+        {   // tile row of the chunk's rows 0 .. 6k-1 (row 6k is the right-hand side)
+            const int kq = lane / 6;
+            const int lcq = __builtin_amdgcn_ds_bpermute(4 * (kq < k ? kq : 0), nlc);
+            if (lane < 6 * k) sy.tmap[wave][lane] = (short)(6 * lcq + (lane - 6 * kq));
+            if (lane + 64 < 6 * k) {
+                const int kq2 = (lane + 64) / 6;
+                const int lcq2 = __builtin_amdgcn_ds_bpermute(4 * kq2, nlc);
+                sy.tmap[wave][lane + 64] = (short)(6 * lcq2 + (lane + 64 - 6 * kq2));
+            }
+        }
+        ch = grab();
+        if (ch < ch1) {
+            if (lane < 8) nd = sg_chunk[8 * (int64_t)ch + lane];
+            if (lane < 16) nlc = sg_lc[16 * (int64_t)ch + lane];
+        }
         for (int i = lane; i < PROWS * LDK; i += 64) pan[i] = 0.0;     // rows / k-columns this chunk does not write
         __builtin_amdgcn_wave_barrier();
+        lap(1);
         // ------------------------------------------------------------ pass 1: lane = object point
+        double pR[6] = {0, 0, 0, 0, 0, 0}, pY[3] = {0, 0, 0}, pQ[3] = {0, 0, 0};     // of this lane's point, for pass 2
+        unsigned pEst = 0;
         {
             const bool act = lane < npts;
             const int pt = pt0 + (act ? lane : 0);
@@ -108,12 +153,19 @@ __global__ __launch_bounds__(256) void k_build_sig(DevProblem d, const double *_
             double Q[3] = {z[zp], z[zp + 1], z[zp + 2]};
             const unsigned est = (d.z_est[zp] ? 1u : 0u) | (d.z_est[zp + 1] ? 2u : 0u) | (d.z_est[zp + 2] ? 4u : 0u);
             double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
-            for (int j = 0; j < k; ++j) {
+            const int64_t q0 = uv0 + gi0 + (act ? lane : 0);
+            const double2 *uvp = reinterpret_cast<const double2 *>(sg_uv), *wp = reinterpret_cast<const double2 *>(sg_w);
+            double2 uv_n = uvp[q0], w_n = sg_w ? wp[q0] : double2{0, 0};
+            for (int j = 0; j < ((d.ablate & 4) ? 1 : k); ++j) {
                 const int lc = sy.lc[wave][j];
                 const CamRec &C = *reinterpret_cast<const CamRec *>(camw + lc * SIG_CAMW);
-                const int64_t q = uv0 + (int64_t)j * gm + gi0 + (act ? lane : 0);
-                const double uu = sg_uv[2 * q], vv = sg_uv[2 * q + 1];
-                const double w0 = sg_w ? sg_w[2 * q] : C.w[0], w1 = sg_w ? sg_w[2 * q + 1] : C.w[1];
+                const int64_t q = q0 + (int64_t)j * gm;
+                const double uu = uv_n.x, vv = uv_n.y;
+                const double w0 = sg_w ? w_n.x : C.w[0], w1 = sg_w ? w_n.y : C.w[1];
+                if (j + 1 < k) {                      // next slot's image coordinates, one slot ahead
+                    uv_n = uvp[q + gm];
+                    if (sg_w) w_n = wp[q + gm];
+                }
                 double r[2], A[2][6], B[2][3], Cf[2][MAXIO];
                 obs_eval<MODEL, true, false>(C, d.nK, d.nP, Q, uu, vv, r, A, B, Cf);    // A is dead code here
                 r[0] *= w0; r[1] *= w1;
@@ -122,11 +174,7 @@ __global__ __launch_bounds__(256) void k_build_sig(DevProblem d, const double *_
                     const double m = ((est >> c) & 1u) ? 1.0 : 0.0;
                     B[0][c] *= w0 * m; B[1][c] *= w1 * m;
                 }
-                if (act) {
-                    const int64_t o = obs0 + (int64_t)lane * k + j;
-                    r_w[2 * o] = r[0]; r_w[2 * o + 1] = r[1];
-                    rr += r[0] * r[0] + r[1] * r[1];
-                }
+                if (act) rr += r[0] * r[0] + r[1] * r[1];
                 V[0] += B[0][0] * B[0][0] + B[1][0] * B[1][0];
                 V[1] += B[0][0] * B[0][1] + B[1][0] * B[1][1];
                 V[2] += B[0][0] * B[0][2] + B[1][0] * B[1][2];
@@ -181,16 +229,15 @@ __global__ __launch_bounds__(256) void k_build_sig(DevProblem d, const double *_
                 const double r11 = sqrt(inv[3] - r10 * r10);
                 const double r21 = (inv[4] - r20 * r10) * fast_rcp(r11);
                 const double r22 = sqrt(inv[5] - r20 * r20 - r21 * r21);
-                double *pp = pv + lane * SIG_PV;
-                pp[0] = r00; pp[1] = r10; pp[2] = r20; pp[3] = r11; pp[4] = r21; pp[5] = r22;
-                pp[6] = r00 * g[0] + r10 * g[1] + r20 * g[2];                  // y = R' g
-                pp[7] = r11 * g[1] + r21 * g[2];
-                pp[8] = r22 * g[2];
-                pp[9] = Q[0]; pp[10] = Q[1]; pp[11] = Q[2];
-                pp[12] = (double)est;
+                pR[0] = r00; pR[1] = r10; pR[2] = r20; pR[3] = r11; pR[4] = r21; pR[5] = r22;
+                pY[0] = r00 * g[0] + r10 * g[1] + r20 * g[2];                  // y = R' g
+                pY[1] = r11 * g[1] + r21 * g[2];
+                pY[2] = r22 * g[2];
+                pQ[0] = Q[0]; pQ[1] = Q[1]; pQ[2] = Q[2];
+                pEst = est;
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        lap(2);
         // ------------------------------------------------------------ pass 2: lane = observation
         mfma_d4 acc[NBLK];
 #pragma unroll
@@ -202,20 +249,31 @@ __global__ __launch_bounds__(256) void k_build_sig(DevProblem d, const double *_
         const int lcj = lane_on ? sy.lc[wave][j] : 0;
         const CamRec &C = *reinterpret_cast<const CamRec *>(camw + lcj * SIG_CAMW);
         const unsigned eo_est = (unsigned)camw[lcj * SIG_CAMW + SIG_CAMW - 1];
+        const double2 *uvp2 = reinterpret_cast<const double2 *>(sg_uv), *wp2 = reinterpret_cast<const double2 *>(sg_w);
+        const int64_t qj = uv0 + (int64_t)j * gm + gi0;
+        double2 uv2 = double2{0, 0}, w2 = double2{0, 0};
+        if (lane_on && ir < npts) { uv2 = uvp2[qj + ir]; if (sg_w) w2 = wp2[qj + ir]; }
         for (int p0 = 0; p0 < npts; p0 += ppr) {
             const int i = p0 + ir;
             const bool on = lane_on && i < npts;
+            const double2 uv_c = uv2, w_c = w2;
+            if (lane_on && i + ppr < npts) { uv2 = uvp2[qj + i + ppr]; if (sg_w) w2 = wp2[qj + i + ppr]; }   // next round's
             double Zr[6][3];
 #pragma unroll
             for (int a = 0; a < 6; ++a) Zr[a][0] = Zr[a][1] = Zr[a][2] = 0.0;
             double y3[3] = {0, 0, 0};
-            if (on) {
-                const double *pp = pv + i * SIG_PV;
-                const double Q[3] = {pp[9], pp[10], pp[11]};
-                const unsigned est = (unsigned)pp[12];
-                const int64_t q = uv0 + (int64_t)j * gm + gi0 + i;
-                const double uu = sg_uv[2 * q], vv = sg_uv[2 * q + 1];
-                const double w0 = sg_w ? sg_w[2 * q] : C.w[0], w1 = sg_w ? sg_w[2 * q + 1] : C.w[1];
+            // R | y | Q | est of this lane's point, from the lane that holds it
+            const int src = on ? i : lane;
+            double gR[6], gY[3], gQ[3];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) gR[c] = lane_get(pR[c], src);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { gY[c] = lane_get(pY[c], src); gQ[c] = lane_get(pQ[c], src); }
+            const unsigned est = (unsigned)__builtin_amdgcn_ds_bpermute(4 * src, (int)pEst);
+            if (on && !(d.ablate & 2)) {
+                const double Q[3] = {gQ[0], gQ[1], gQ[2]};
+                const double uu = uv_c.x, vv = uv_c.y;
+                const double w0 = sg_w ? w_c.x : C.w[0], w1 = sg_w ? w_c.y : C.w[1];
                 double r[2], A[2][6], B[2][3], Cf[2][MAXIO];
                 obs_eval<MODEL, true, false>(C, d.nK, d.nP, Q, uu, vv, r, A, B, Cf);
 #pragma unroll
@@ -223,7 +281,7 @@ __global__ __launch_bounds__(256) void k_build_sig(DevProblem d, const double *_
                     const double m = ((est >> c) & 1u) ? 1.0 : 0.0;
                     B[0][c] *= w0 * m; B[1][c] *= w1 * m;
                 }
-                const double r00 = pp[0], r10 = pp[1], r20 = pp[2], r11 = pp[3], r21 = pp[4], r22 = pp[5];
+                const double r00 = gR[0], r10 = gR[1], r20 = gR[2], r11 = gR[3], r21 = gR[4], r22 = gR[5];
 #pragma unroll
                 for (int a = 0; a < 6; ++a) {
                     const double m = ((eo_est >> a) & 1u) ? 1.0 : 0.0;
@@ -235,7 +293,7 @@ __global__ __launch_bounds__(256) void k_build_sig(DevProblem d, const double *_
                     Zr[a][1] = wa1 * r11 + wa2 * r21;
                     Zr[a][2] = wa2 * r22;
                 }
-                y3[0] = pp[6]; y3[1] = pp[7]; y3[2] = pp[8];
+                y3[0] = gY[0]; y3[1] = gY[1]; y3[2] = gY[2];
             }
             if (lane_on) {                           // lanes of missing points overwrite the previous round with zeros
                 double *pr = pan + (6 * j) * LDK + 3 * ir;
@@ -245,59 +303,77 @@ __global__ __launch_bounds__(256) void k_build_sig(DevProblem d, const double *_
             }
             lds_fence();
             __builtin_amdgcn_wave_barrier();
-            const int ksteps = (3 * min(ppr, npts - p0) + 3) >> 2;
+            lap(3);
+            // 18 k-columns = 4 1/2 k-steps: all operands of the round are read first, then the products
+            // run back to back; the last step's lanes 32..63 would read k-columns 18, 19 (the next row)
+            const int ksteps = (d.ablate & 1) ? 0 : (3 * min(ppr, npts - p0) + 3) >> 2;
             const double *zr = pan + (lane & 15) * LDK + (lane >> 4);
-            for (int ks = 0; ks < ksteps; ++ks) {
-                double op[RB];
+            double op[5][RB];
 #pragma unroll
-                for (int rb = 0; rb < RB; ++rb) op[rb] = rb < rbk ? zr[rb * 16 * LDK + 4 * ks] : 0.0;
+            for (int ks = 0; ks < 5; ++ks)
 #pragma unroll
-                for (int r1 = 0; r1 < RB; ++r1)
-                    if (r1 < rbk) {
+                for (int rb = 0; rb < RB; ++rb)
+                    op[ks][rb] = (rb < rbk && ks < ksteps && !(ks == 4 && lane >= 32)) ? zr[rb * 16 * LDK + 4 * ks] : 0.0;
 #pragma unroll
-                        for (int r2 = 0; r2 <= r1; ++r2)
-                            acc[r1 * (r1 + 1) / 2 + r2] =
-                                __builtin_amdgcn_mfma_f64_16x16x4f64(op[r1], op[r2], acc[r1 * (r1 + 1) / 2 + r2], 0, 0, 0);
-                    }
-            }
+            for (int ks = 0; ks < 5; ++ks)
+                if (ks < ksteps) {
+#pragma unroll
+                    for (int r1 = 0; r1 < RB; ++r1)
+                        if (r1 < rbk) {
+#pragma unroll
+                            for (int r2 = 0; r2 <= r1; ++r2)
+                                acc[r1 * (r1 + 1) / 2 + r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(
+                                    op[ks][r1], op[ks][r2], acc[r1 * (r1 + 1) / 2 + r2], 0, 0, 0);
+                        }
+                }
             lds_fence();
             __builtin_amdgcn_wave_barrier();
+            lap(4);
         }
         // ------------------------------------------------------------ chunk -> tile (LDS atomics)
+        // one predicated ds_add_f64 per accumulator element; vt follows stile, so the right-hand-side
+        // row (6k) only changes the index and the sign
+        {
+            const int r6k = 6 * k;
+            int tcm[RB];
 #pragma unroll
-        for (int r1 = 0; r1 < RB; ++r1)
-            if (r1 < rbk) {
+            for (int r2 = 0; r2 < RB; ++r2) tcm[r2] = sy.tmap[wave][min(16 * r2 + (lane & 15), 6 * SIG_KMAXR - 1)];
 #pragma unroll
-                for (int r2 = 0; r2 <= r1; ++r2) {
-                    const int lcol = 16 * r2 + (lane & 15);
+            for (int r1 = 0; r1 < RB; ++r1) {
+                if (r1 >= rbk) break;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int lr = 16 * r1 + (lane >> 4) + 4 * e;
+                for (int e = 0; e < 4; ++e) {
+                    const int lr = 16 * r1 + (lane >> 4) + 4 * e;
+                    const int tr = sy.tmap[wave][min(lr, 6 * SIG_KMAXR - 1)];
+                    const bool yrow = lr == r6k;
+                    const int rowbase = yrow ? SIG_STILE : tr * (tr + 1) / 2;
+#pragma unroll
+                    for (int r2 = 0; r2 <= r1; ++r2) {
+                        const int lcol = 16 * r2 + (lane & 15);
                         const double v = acc[r1 * (r1 + 1) / 2 + r2][e];
-                        if (lcol <= lr && lr <= 6 * k && lcol < 6 * k && v != 0.0) {
-                            const int sc = lcol / 6, tc = 6 * sy.lc[wave][sc] + (lcol - 6 * sc);
-                            if (lr == 6 * k) atomic_add_f64(vt + tc, -v);      // row of y: W V^-1 g
-                            else {
-                                const int sr = lr / 6, tr = 6 * sy.lc[wave][sr] + (lr - 6 * sr);
-                                atomic_add_f64(stile + tr * (tr + 1) / 2 + tc, v);
-                            }
-                        }
+                        if (lcol <= lr && lr <= r6k && lcol < r6k && v != 0.0 && !(d.ablate & 8))
+                            atomic_add_f64(stile + rowbase + tcm[r2], yrow ? -v : v);
                     }
                 }
             }
+        }
         __builtin_amdgcn_wave_barrier();
+        lap(5);
     }
+    lap(6);
     __syncthreads();
+    lap(6);
     // ---------------------------------------------------------------- tile -> HBM
-    for (int tc = wave; tc < nrows; tc += 4) {       // one column per wave: consecutive lanes, consecutive rows
-        const int64_t gcol = 6 * (int64_t)d.tile_cams[c0 + tc / 6] + tc % 6;
+#pragma unroll 4
+    for (int tc = wave; tc < nrows; tc += NW) {      // one column per wave: consecutive lanes, consecutive rows
+        const int64_t gcol = sy.grow[tc];
         for (int tr = tc + lane; tr < nrows; tr += 64) {
             const double v = stile[tr * (tr + 1) / 2 + tc];
-            if (v != 0.0) atomic_add_f64(S + gcol * d.ldS + 6 * (int64_t)d.tile_cams[c0 + tr / 6] + tr % 6, -v);
+            if (v != 0.0 && !(d.ablate & 16)) atomic_add_f64(S + gcol * d.ldS + sy.grow[tr], -v);
         }
     }
-    for (int i = t; i < nrows; i += 256)
-        if (vt[i] != 0.0) atomic_add_f64(g_red + 6 * (int64_t)d.tile_cams[c0 + i / 6] + i % 6, vt[i]);
+    for (int i = t; i < nrows; i += NT)
+        if (vt[i] != 0.0) atomic_add_f64(g_red + sy.grow[i], vt[i]);
     double accr[1] = {rr};
     block_sum<1>(accr, sh);
     if (t == 0) partial[blockIdx.x] = accr[0];
@@ -310,6 +386,74 @@ __global__ __launch_bounds__(256) void k_build_sig(DevProblem d, const double *_
         atomicMin(pivmm, (unsigned long long)__double_as_longlong(pmin));
         atomicMax(pivmm + 1, (unsigned long long)__double_as_longlong(pmax));
     }
+    lap(7);
+    if (prof)
+        for (int i = 0; i < 8; ++i) if (tp[i]) atomicAdd(&g_tile2_prof[i], (unsigned long long)tp[i]);
+}
+
+// k_backsub_sig: back-substitution dp = -V^-1 (g_p + W' dc) and ||J p||^2 over the image rows for the
+// points of the signature chunks (K7, K8).  One wave per chunk, lane = object point; the chunk's
+// cameras are the same for every lane, so their records and their steps dc are wave-uniform
+// (scalar loads), (u,v) comes coalesced from the slot-major copy, and the sums over a point's
+// observations stay in the lane's registers: no LDS, no atomics, no per-lane camera gathers.
+// Two sweeps over the k cameras: B't for dp, then (t + B dp)^2.
+template <int MODEL>
+__global__ __launch_bounds__(256) void k_backsub_sig(DevProblem d, const double *__restrict__ z,
+                                                     const CamRec *__restrict__ cams,
+                                                     const double *__restrict__ Vinv, const double *__restrict__ gp,
+                                                     double *__restrict__ dz, double *__restrict__ partial /* [grid][2] */,
+                                                     const int32_t *__restrict__ sg_chunk, int nchunks,
+                                                     const int32_t *__restrict__ sg_gcam,
+                                                     const double *__restrict__ sg_uv, const double *__restrict__ sg_w) {
+    __shared__ double sh[8];
+    const int t = threadIdx.x, lane = t & 63;
+    const int ch = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (t >> 6));
+    double acc[2] = {0, 0};
+    if (ch < nchunks) {
+        const int32_t *cd = sg_chunk + 8 * (int64_t)ch;
+        const int pt0 = cd[0], npts = cd[1], k = cd[2], gm = cd[4], gi0 = cd[5], uv0 = cd[6];
+        const bool act = lane < npts;
+        const int pt = pt0 + (act ? lane : 0);
+        const int64_t zp = d.NS + 3 * (int64_t)pt;
+        const double Q[3] = {z[zp], z[zp + 1], z[zp + 2]};
+        const unsigned est = (d.z_est[zp] ? 1u : 0u) | (d.z_est[zp + 1] ? 2u : 0u) | (d.z_est[zp + 2] ? 4u : 0u);
+        const double2 *uvp = reinterpret_cast<const double2 *>(sg_uv), *wp = reinterpret_cast<const double2 *>(sg_w);
+        const int64_t q0 = uv0 + gi0 + (act ? lane : 0);
+        double s[3] = {gp[3 * (int64_t)pt], gp[3 * (int64_t)pt + 1], gp[3 * (int64_t)pt + 2]};
+        double dp[3] = {0, 0, 0};
+        for (int sweep = 0; sweep < 2; ++sweep) {
+            for (int j = 0; j < k; ++j) {
+                const int cam = __builtin_amdgcn_readfirstlane(sg_gcam[16 * (int64_t)ch + j]);
+                const CamRec &C = cams[cam];
+                const double2 uv = uvp[q0 + (int64_t)j * gm];
+                const double w0 = sg_w ? wp[q0 + (int64_t)j * gm].x : C.w[0], w1 = sg_w ? wp[q0 + (int64_t)j * gm].y : C.w[1];
+                double r[2], E[2][6], B[2][3];
+                eval_obs_pre<MODEL, 6>(d, C, Q, uv.x, uv.y, w0, w1, est, r, E, B);
+                double t0 = 0, t1 = 0;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) { const double dc = dz[C.col[a]]; t0 += E[0][a] * dc; t1 += E[1][a] * dc; }
+                if (sweep == 0) {
+                    s[0] += B[0][0] * t0 + B[1][0] * t1;
+                    s[1] += B[0][1] * t0 + B[1][1] * t1;
+                    s[2] += B[0][2] * t0 + B[1][2] * t1;
+                } else {
+                    const double j0 = t0 + B[0][0] * dp[0] + B[0][1] * dp[1] + B[0][2] * dp[2];
+                    const double j1 = t1 + B[1][0] * dp[0] + B[1][1] * dp[1] + B[1][2] * dp[2];
+                    if (act) acc[0] += j0 * j0 + j1 * j1;
+                }
+            }
+            if (sweep == 0) {
+                const double *vi = Vinv + 6 * (int64_t)pt;
+                const double p0 = -(vi[0] * s[0] + vi[1] * s[1] + vi[2] * s[2]);
+                const double p1 = -(vi[1] * s[0] + vi[3] * s[1] + vi[4] * s[2]);
+                const double p2 = -(vi[2] * s[0] + vi[4] * s[1] + vi[5] * s[2]);
+                dp[0] = (est & 1u) ? p0 : 0.0; dp[1] = (est & 2u) ? p1 : 0.0; dp[2] = (est & 4u) ? p2 : 0.0;
+                if (act) { dz[zp] = dp[0]; dz[zp + 1] = dp[1]; dz[zp + 2] = dp[2]; }
+            }
+        }
+    }
+    block_sum<2>(acc, sh);
+    if (t == 0) { partial[2 * blockIdx.x] = acc[0]; partial[2 * blockIdx.x + 1] = acc[1]; }
 }
 
 }  // namespace dbat

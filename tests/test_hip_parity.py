@@ -483,7 +483,11 @@ def _full_size_properties(name, damping):
         assert np.sqrt(st['JpJp']) <= 1e-5 * np.sqrt(2 * st['f'])
     finally:
         h.close()
-    assert np.abs(res.EO.val[:3] - truth['EO'][:3]).max() < 1.0
+    # truth recovered up to what the network determines: with fixed IO to the noise level (< 1 m over
+    # the 100 m block); with self-calibration of a nadir block over nearly flat terrain the camera
+    # constant and the flying height (40 m) are strongly correlated, a few per cent of it remain open
+    selfcal = bool(np.any(s.bundle.est.IO))
+    assert np.abs(res.EO.val[:3] - truth['EO'][:3]).max() < (0.05 * 40.0 if selfcal else 1.0)
     other = 'gna' if damping != 'gna' else 'lmp'
     r2, ok2, it2, s02, E2 = bundle(s, other, store_trace=False)
     assert ok2 and abs(s02 - s0) < 1e-7 * s0
