@@ -501,6 +501,38 @@ struct DataflowChol {
             for (int i = k; i <= nT; ++i)
                 if (has(i, k)) tasks.push_back(DfTask{i, k});
         ntasks = (int)tasks.size();
+        if (!getenv("DBAT_HIP_DF_COLMAJOR")) {
+            // Task order = the order in which workgroups take them.  Any topological order is
+            // deadlock free (a dependency always has a smaller number, so it is owned by a running
+            // workgroup); column-major order, however, hands out ALL tiles of the first blocks of
+            // the dissection before the first tile of the others, and the few hundred resident
+            // workgroups then sit in the dependent chains of a few leaves while the other leaves
+            // have not started.  Order by the earliest time a task can start (list schedule with
+            // rough costs after the last input: 17 us for a diagonal tile, 6 us for the others):
+            // all leaves advance together and the separators follow when their inputs exist.
+            std::vector<int> tix((size_t)(nT + 1) * nT, -1);
+            for (int t = 0; t < ntasks; ++t) tix[(size_t)tasks[t].i * nT + tasks[t].k] = t;
+            std::vector<double> est(ntasks, 0.0), fin(ntasks, 0.0);
+            for (int t = 0; t < ntasks; ++t) {              // column-major: dependencies come earlier
+                const int i = tasks[t].i, k = tasks[t].k;
+                double e = 0.0;
+                int nprod = 0;
+                for (int j = 0; j < k; ++j)
+                    if (has(i, j) && has(k, j)) {
+                        ++nprod;
+                        e = std::max(e, std::max(fin[tix[(size_t)i * nT + j]], fin[tix[(size_t)k * nT + j]]));
+                    }
+                if (i != k) e = std::max(e, fin[tix[(size_t)k * nT + k]]);
+                est[t] = e;
+                fin[t] = e + (i == k ? 17.0 : 6.0) + (nprod ? 0.0 : -2.0);   // after the last input: its product, then potf2 / the L^-1 product, stores, flag
+            }
+            std::vector<int> ord(ntasks);
+            for (int t = 0; t < ntasks; ++t) ord[t] = t;
+            std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return est[a] < est[b]; });
+            std::vector<DfTask> sorted(ntasks);
+            for (int t = 0; t < ntasks; ++t) sorted[t] = tasks[ord[t]];
+            tasks.swap(sorted);
+        }
         h_tasks = tasks;
         if (getenv("DBAT_HIP_DF_TRACE") && hipMalloc(&d_trace, (size_t)(ntasks + nT) * 16 * sizeof(long long)) != hipSuccess) d_trace = nullptr;
         n_products = 0;
