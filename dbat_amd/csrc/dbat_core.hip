@@ -201,13 +201,13 @@ struct Core {
         if (const char *e = getenv("DBAT_HIP_GIANT_THREADS")) { const int v = atoi(e); if (v == 64 || v == 128) giant_threads = v; }
         d.tile_batch = tile_batch.p; d.tile_cam_start = tile_cam_start.p; d.tile_cams = tile_cams.p;
         d.tile_io_start = tile_io_start.p; d.tile_iocols = tile_iocols.p; d.tile_cam_io = tile_cam_io.p;
-        use_sig = P.sg_ok && ntiles > 0;
+        use_sig = P.sg_ok && ntiles > 0 && tile_ncx <= 14;
         if (use_sig) {
             sg_chunk.upload(P.sg_chunk); sg_tile_chunk0.upload(P.sg_tile_chunk0); sg_lc.upload(P.sg_lc); sg_gcam.upload(P.sg_gcam);
             sg_nchunks = (int64_t)P.sg_chunk.size() / 8;
             sg_uv.upload(P.sg_uv);
             if (!P.uniform_w) sg_w.upload(P.sg_w);
-            sig_rb = 6 * P.sg_kmax + 1 <= 64 ? 4 : 5;
+            sig_rb = P.sg_rows_max <= 64 ? 4 : 5;
         }
         cams.alloc(P.nc);
         z.alloc(P.NZ); zt.alloc(P.NZ); dz.alloc(P.NZ); zlin.alloc(P.NZ); vtmp.alloc(P.NZ); vtmp2.alloc(P.NZ);
@@ -306,10 +306,10 @@ struct Core {
         use_tile3 = use_tile2 && !P.with_io && !(getenv("DBAT_HIP_TILE3") && atoi(getenv("DBAT_HIP_TILE3")) == 0)
                     && getenv("DBAT_HIP_TILE_BMAX") == nullptr;
         if (use_sig) {
-            SET_LDS((k_build_sig<2, 4>), sig_lds_bytes(4)); SET_LDS((k_build_sig<3, 4>), sig_lds_bytes(4));
-            SET_LDS((k_build_sig<4, 4>), sig_lds_bytes(4)); SET_LDS((k_build_sig<5, 4>), sig_lds_bytes(4));
-            SET_LDS((k_build_sig<2, 5>), sig_lds_bytes(5)); SET_LDS((k_build_sig<3, 5>), sig_lds_bytes(5));
-            SET_LDS((k_build_sig<4, 5>), sig_lds_bytes(5)); SET_LDS((k_build_sig<5, 5>), sig_lds_bytes(5));
+#define SET_SIG(M) SET_LDS((k_build_sig<M, 4, 6>), sig_lds_bytes(4, false)); SET_LDS((k_build_sig<M, 5, 6>), sig_lds_bytes(5, false)); \
+                   SET_LDS((k_build_sig<M, 4, 14>), sig_lds_bytes(4, true)); SET_LDS((k_build_sig<M, 5, 14>), sig_lds_bytes(5, true))
+            SET_SIG(2); SET_SIG(3); SET_SIG(4); SET_SIG(5);
+#undef SET_SIG
         }
         if (use_tile3) {
             SET_LDS((k_build_tile3<2, TILE3_PC, TILE3_NBUF>), lds_tile3); SET_LDS((k_build_tile3<3, TILE3_PC, TILE3_NBUF>), lds_tile3);
@@ -448,9 +448,12 @@ struct Core {
 #undef L_CAMN
             mark(0);                                 // events around the tile kernel alone (bench roofline)
 #define L_TILE3(M, DUMMY) LAUNCHK((k_build_tile3<M, TILE3_PC, TILE3_NBUF>), dim3((unsigned)ntiles), dim3(768), lds_tile3, stream, d, zz, cams.p, lambda, scale, S, g_red, Vinv.p, gp.p, jn2p.p, partial.p, pivmm.p)
-#define L_SIG(M, RBV) LAUNCHK((k_build_sig<M, RBV>), dim3((unsigned)ntiles), dim3(64 * sig_waves(RBV)), sig_lds_bytes(RBV), stream, d, zz, cams.p, lambda, scale, S, g_red, Vinv.p, gp.p, jn2p.p, partial.p, pivmm.p, sg_chunk.p, sg_tile_chunk0.p, sg_lc.p, sg_uv.p, P.uniform_w ? (const double *)nullptr : sg_w.p)
-            if (use_sig && sig_rb == 4) { DISPATCH_MODEL(L_SIG, 4) }
-            else if (use_sig) { DISPATCH_MODEL(L_SIG, 5) }
+#define L_SIG(M, RBV) LAUNCHK((k_build_sig<M, (RBV) % 8, (RBV) / 8>), dim3((unsigned)ntiles), dim3(64 * sig_waves((RBV) % 8, (RBV) / 8 > 6)), sig_lds_bytes((RBV) % 8, (RBV) / 8 > 6), stream, d, zz, cams.p, lambda, scale, S, g_red, Vinv.p, gp.p, jn2p.p, partial.p, pivmm.p, sg_chunk.p, sg_tile_chunk0.p, sg_lc.p, sg_uv.p, P.uniform_w ? (const double *)nullptr : sg_w.p)
+            // (row blocks, camera-side columns) packed into one macro argument: RB + 8 * NCX
+            if (use_sig && tile_ncx == 6 && sig_rb == 4) { DISPATCH_MODEL(L_SIG, 4 + 8 * 6) }
+            else if (use_sig && tile_ncx == 6) { DISPATCH_MODEL(L_SIG, 5 + 8 * 6) }
+            else if (use_sig && sig_rb == 4) { DISPATCH_MODEL(L_SIG, 4 + 8 * 14) }
+            else if (use_sig) { DISPATCH_MODEL(L_SIG, 5 + 8 * 14) }
             else if (use_tile3 && tile_ncx == 6) { DISPATCH_MODEL(L_TILE3, 0) }
             else if (use_tile2 && tile_ncx == 6) { DISPATCH_MODEL(L_TILE2, 6) }
             else if (use_tile2 && tile_ncx == 14) { DISPATCH_MODEL(L_TILE2, 14) }
@@ -557,8 +560,8 @@ struct Core {
         const int64_t n_sig_wg = use_sig ? cdiv(sg_nchunks, 4) : 0;
         if (use_sig) HIPCHK(hipMemsetAsync(partial.p, 0, (size_t)2 * P.nb_tiled * sizeof(double), stream));
         if (n_sig_wg > 0) {
-#define L_BACKS(M, dummy) LAUNCHK((k_backsub_sig<M>), dim3((unsigned)n_sig_wg), dim3(256), 0, stream, d, zlin.p, cams.p, Vinv.p, gp.p, dz.p, partial.p + 2 * (nb + ngiant), sg_chunk.p, (int)sg_nchunks, sg_gcam.p, sg_uv.p, P.uniform_w ? (const double *)nullptr : sg_w.p)
-            DISPATCH_MODEL(L_BACKS, 0)
+#define L_BACKS(M, NCXV) LAUNCHK((k_backsub_sig<M, NCXV>), dim3((unsigned)n_sig_wg), dim3(256), 0, stream, d, zlin.p, cams.p, Vinv.p, gp.p, dz.p, partial.p + 2 * (nb + ngiant), sg_chunk.p, (int)sg_nchunks, sg_gcam.p, sg_uv.p, P.uniform_w ? (const double *)nullptr : sg_w.p)
+            if (tile_ncx == 6) { DISPATCH_MODEL(L_BACKS, 6) } else { DISPATCH_MODEL(L_BACKS, 14) }
 #undef L_BACKS
         }
         if (nb > b_first) {

@@ -98,6 +98,7 @@ struct Plan {
     std::vector<double> sg_uv;                     // slot-major copy of o_uv: group g, slot j, point i at 2*(obs0_g + j*m_g + i)
     std::vector<double> sg_w;                      // the same for o_w (empty if uniform)
     int sg_kmax = 0;                               // largest k among the tiled points
+    int sg_rows_max = 0;                           // most rows of a chunk: 6k + IO columns of its tile + 1
     int64_t sg_ngroups = 0, sg_npoints = 0;
     bool sg_ok = false;                            // the tiled points can go through k_build_sig
     int BT = 256;
@@ -623,7 +624,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     P.tile_io_start.push_back(0);
     int64_t pos = 0, bstart = 0, tile_first_obs = 0;
     // signature groups of the current tile
-    P.sg_chunk.clear(); P.sg_tile_chunk0.assign(1, 0); P.sg_lc.clear(); P.sg_gcam.clear(); P.sg_kmax = 0; P.sg_ngroups = 0; P.sg_npoints = 0;
+    P.sg_chunk.clear(); P.sg_tile_chunk0.assign(1, 0); P.sg_lc.clear(); P.sg_gcam.clear(); P.sg_kmax = 0; P.sg_rows_max = 0; P.sg_ngroups = 0; P.sg_npoints = 0;
     P.sg_uv.assign(P.o_uv.size(), 0.0);
     if (!P.uniform_w) P.sg_w.assign(P.o_w.size(), 0.0); else P.sg_w.clear();
     std::vector<int32_t> sg_gc;                      // global camera of every sg_lc entry (converted when the tile closes)
@@ -689,6 +690,8 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
                 std::copy(lcs.begin() + 16 * ord[a], lcs.begin() + 16 * ord[a] + 16, P.sg_lc.begin() + 16 * (q0 + a));
             }
         }
+        for (size_t q = (size_t)P.sg_tile_chunk0.back(); q < P.sg_chunk.size() / 8; ++q)
+            P.sg_rows_max = std::max(P.sg_rows_max, 6 * P.sg_chunk[8 * q + 2] + (P.tile_io_start.back() - P.tile_io_start[P.tile_io_start.size() - 2]) + 1);
         P.sg_gcam.resize(P.sg_lc.size());
         for (size_t e = sg_lc_tile0; e < sg_gc.size(); ++e) P.sg_gcam[e] = cur_cams.empty() ? 0 : cur_cams[P.sg_lc[e]];
         sg_lc_tile0 = sg_gc.size();
@@ -858,7 +861,8 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     }
     // k_build_sig takes the tiled points when every one of them fits its five row blocks, the
     // interior orientation is fixed and the groups are long enough to fill a wave's lanes
-    const bool sg_can = P.CMAX > 0 && P.nb_tiled > 0 && !P.with_io && P.sg_kmax > 0 && P.sg_kmax <= Plan::SG_KMAX && P.BT == 256;
+    // every chunk's rows (6k + the IO columns of its tile + the right-hand-side row) fit five 16-row blocks
+    const bool sg_can = P.CMAX > 0 && P.nb_tiled > 0 && P.sg_kmax > 0 && P.sg_rows_max <= 80 && P.ncolmax <= 14 && P.BT == 256;
     P.sg_ok = sg_can && P.sg_npoints >= 8 * P.sg_ngroups;
     if (const char *e = getenv("DBAT_HIP_SIG")) P.sg_ok = atoi(e) == 0 ? false : (atoi(e) >= 2 ? sg_can : P.sg_ok);   // 0 off, 2 whenever possible
     if (getenv("DBAT_HIP_PLAN_STATS") && P.sg_ngroups > 0)

@@ -41,6 +41,7 @@ constexpr int SIG_PPR = 6;           // points per round of pass 2
 constexpr int SIG_KMAXR = 13;        // cameras per group at most (Plan::SG_KMAX)
 constexpr int SIG_NW = 8;            // waves per workgroup (two per SIMD: one evaluates while the other multiplies)
 constexpr int SIG_CAMW = 58;         // doubles of a CamRec that the fixed-IO evaluation reads (.. w[2]) + eo_est
+constexpr int SIG_CAMW_IO = (int)((sizeof(CamRec) + 7) / 8);   // self-calibration: the whole record (column lists)
 constexpr int SIG_STILE = 8064;      // 126*127/2 = 8001 packed lower triangle of the tile, padded
 
 struct SigLds {                      // static part
@@ -48,11 +49,14 @@ struct SigLds {                      // static part
     int grow[128];                   // row of the reduced system of every row of the tile
     int lc[SIG_NW][16];              // tile-local camera of every slot of the wave's chunk
     short tmap[SIG_NW][80];          // tile row of every row of the wave's chunk
+    unsigned char camio[21][16];     // self-calibration: tile IO row of a camera's q-th IO column
 };
 
-__host__ __device__ constexpr int sig_waves(int RB) { return RB <= 4 ? SIG_NW : 6; }   // what 160 KB of LDS hold
-__host__ __device__ constexpr size_t sig_lds_bytes(int RB) {
-    return ((size_t)SIG_STILE + 128 + 21 * SIG_CAMW + sig_waves(RB) * ((size_t)RB * 16 * SIG_LDK)) * sizeof(double);
+// eight waves (two per SIMD, 256 registers each) where the kernel fits them; the variants with five row
+// blocks or with the IO Jacobian need more registers: four waves with 512 each
+__host__ __device__ constexpr int sig_waves(int RB, bool io) { return RB <= 4 && !io ? SIG_NW : 4; }
+__host__ __device__ constexpr size_t sig_lds_bytes(int RB, bool io) {
+    return ((size_t)SIG_STILE + 128 + 21 * (io ? SIG_CAMW_IO : SIG_CAMW) + sig_waves(RB, io) * ((size_t)RB * 16 * SIG_LDK)) * sizeof(double);
 }
 
 // value of x in lane `src` (ds_bpermute_b32 on both halves)
@@ -63,8 +67,12 @@ __device__ __forceinline__ double lane_get(double x, int src) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-template <int MODEL, int RB>
-__global__ __launch_bounds__(64 * sig_waves(RB)) void k_build_sig(DevProblem d, const double *__restrict__ z,
+// NCX = 6: fixed IO.  NCX = 14: self-calibration -- the estimated IO columns of the tile's cameras are
+// nio further rows of every chunk (after its 6k camera rows, before the row of y): an IO row is
+// shared by the k observations of a point, so its k-columns are summed with ds_add_f64 into the
+// zeroed panel rows.
+template <int MODEL, int RB, int NCX>
+__global__ __launch_bounds__(64 * sig_waves(RB, (NCX > 6))) void k_build_sig(DevProblem d, const double *__restrict__ z,
                                                    const CamRec *__restrict__ cams, double lambda, int scale,
                                                    double *__restrict__ S, double *__restrict__ g_red,
                                                    double *__restrict__ Vinv, double *__restrict__ gp,
@@ -74,12 +82,14 @@ __global__ __launch_bounds__(64 * sig_waves(RB)) void k_build_sig(DevProblem d, 
                                                    const int32_t *__restrict__ sg_tile_chunk0,
                                                    const uint8_t *__restrict__ sg_lc, const double *__restrict__ sg_uv,
                                                    const double *__restrict__ sg_w) {
-    constexpr int NBLK = RB * (RB + 1) / 2, PROWS = RB * 16, LDK = SIG_LDK, NW = sig_waves(RB), NT = 64 * NW;
+    constexpr bool IO = NCX > 6;
+    constexpr int NBLK = RB * (RB + 1) / 2, PROWS = RB * 16, LDK = SIG_LDK, NW = sig_waves(RB, IO), NT = 64 * NW;
+    constexpr int CAMW = IO ? SIG_CAMW_IO : SIG_CAMW;
     extern __shared__ double smem[];
     double *stile = smem;                            // packed lower triangle of the tile's block of S (negated sum)
     double *vt = stile + SIG_STILE;                  // [128] -(W V^-1 g) by tile row
     double *camw = vt + 128;                         // [21][SIG_CAMW]
-    double *wave_base = camw + 21 * SIG_CAMW;
+    double *wave_base = camw + 21 * CAMW;
     __shared__ SigLds sy;
     __shared__ double sh[16];
     const int t = threadIdx.x, lane = t & 63;
@@ -88,16 +98,21 @@ __global__ __launch_bounds__(64 * sig_waves(RB)) void k_build_sig(DevProblem d, 
     const int tile = d.tile_order[blockIdx.x];
     const int c0 = d.tile_cam_start[tile];
     const int ncam = d.tile_cam_start[tile + 1] - c0;
-    const int nrows = 6 * ncam;
+    const int io0 = IO ? d.tile_io_start[tile] : 0;
+    const int nio = IO ? d.tile_io_start[tile + 1] - io0 : 0;      // IO rows of the tile (and of each of its chunks)
+    const int nrows = 6 * ncam + nio;
     const int ch0 = sg_tile_chunk0[tile], ch1 = sg_tile_chunk0[tile + 1];
     for (int i = t; i < SIG_STILE + 128; i += NT) stile[i] = 0.0;
     for (int i = t; i < NW * (PROWS * LDK); i += NT) wave_base[i] = 0.0;
-    for (int i = t; i < ncam * SIG_CAMW; i += NT) {
-        const int c = i / SIG_CAMW, f = i - c * SIG_CAMW;
+    for (int i = t; i < ncam * CAMW; i += NT) {
+        const int c = i / CAMW, f = i - c * CAMW;
         const CamRec &C = cams[d.tile_cams[c0 + c]];
-        camw[i] = f < SIG_CAMW - 1 ? reinterpret_cast<const double *>(&C)[f] : (double)C.eo_est;
+        if constexpr (IO) camw[i] = reinterpret_cast<const double *>(&C)[f];
+        else camw[i] = f < CAMW - 1 ? reinterpret_cast<const double *>(&C)[f] : (double)C.eo_est;
     }
-    if (t < nrows) sy.grow[t] = 6 * d.tile_cams[c0 + t / 6] + t % 6;
+    if (t < 6 * ncam) sy.grow[t] = 6 * d.tile_cams[c0 + t / 6] + t % 6;
+    else if (t < nrows) sy.grow[t] = 6 * d.nc + d.tile_iocols[io0 + t - 6 * ncam];
+    if constexpr (IO) { for (int i = t; i < 16 * ncam; i += NT) sy.camio[i >> 4][i & 15] = d.tile_cam_io[(size_t)c0 * 16 + i]; }
     if (t == 0) { sy.next_chunk = ch0; sy.abort_ = 0; }
     // DBAT_HIP_ABLATE & 32: phase clocks of wave 0 (100 MHz ticks), summed over the tiles into g_tile2_prof
     const bool prof = (d.ablate & 32) && t == 0;
@@ -134,6 +149,7 @@ __global__ __launch_bounds__(64 * sig_waves(RB)) void k_build_sig(DevProblem d, 
                 const int lcq2 = __builtin_amdgcn_ds_bpermute(4 * kq2, nlc);
                 sy.tmap[wave][lane + 64] = (short)(6 * lcq2 + (lane + 64 - 6 * kq2));
             }
+            if (lane < nio) sy.tmap[wave][6 * k + lane] = (short)(6 * ncam + lane);      // IO rows follow the camera rows
         }
         ch = grab();
         if (ch < ch1) {
@@ -158,7 +174,7 @@ __global__ __launch_bounds__(64 * sig_waves(RB)) void k_build_sig(DevProblem d, 
             double2 uv_n = uvp[q0], w_n = sg_w ? wp[q0] : double2{0, 0};
             for (int j = 0; j < ((d.ablate & 4) ? 1 : k); ++j) {
                 const int lc = sy.lc[wave][j];
-                const CamRec &C = *reinterpret_cast<const CamRec *>(camw + lc * SIG_CAMW);
+                const CamRec &C = *reinterpret_cast<const CamRec *>(camw + lc * CAMW);
                 const int64_t q = q0 + (int64_t)j * gm;
                 const double uu = uv_n.x, vv = uv_n.y;
                 const double w0 = sg_w ? w_n.x : C.w[0], w1 = sg_w ? w_n.y : C.w[1];
@@ -245,10 +261,12 @@ __global__ __launch_bounds__(64 * sig_waves(RB)) void k_build_sig(DevProblem d, 
         const int ppr = min(SIG_PPR, 64 / k);        // points per round
         const int ir = lane / k, j = lane - ir * k;
         const bool lane_on = ir < ppr;
-        const int rbk = (6 * k + 1 + 15) >> 4;       // row blocks this chunk needs
+        const int ry = 6 * k + nio;                  // row of y; rows 6k .. ry-1 are the IO rows
+        const int rbk = (ry + 1 + 15) >> 4;          // row blocks this chunk needs
         const int lcj = lane_on ? sy.lc[wave][j] : 0;
-        const CamRec &C = *reinterpret_cast<const CamRec *>(camw + lcj * SIG_CAMW);
-        const unsigned eo_est = (unsigned)camw[lcj * SIG_CAMW + SIG_CAMW - 1];
+        const CamRec &C = *reinterpret_cast<const CamRec *>(camw + lcj * CAMW);
+        unsigned eo_est;
+        if constexpr (IO) eo_est = C.eo_est; else eo_est = (unsigned)camw[lcj * CAMW + CAMW - 1];
         const double2 *uvp2 = reinterpret_cast<const double2 *>(sg_uv), *wp2 = reinterpret_cast<const double2 *>(sg_w);
         const int64_t qj = uv0 + (int64_t)j * gm + gi0;
         double2 uv2 = double2{0, 0}, w2 = double2{0, 0};
@@ -262,6 +280,9 @@ __global__ __launch_bounds__(64 * sig_waves(RB)) void k_build_sig(DevProblem d, 
 #pragma unroll
             for (int a = 0; a < 6; ++a) Zr[a][0] = Zr[a][1] = Zr[a][2] = 0.0;
             double y3[3] = {0, 0, 0};
+            if constexpr (IO) {                      // the IO rows are sums over a point's observations: start from zero
+                for (int q = lane; q < nio * LDK; q += 64) pan[6 * k * LDK + q] = 0.0;
+            }
             // R | y | Q | est of this lane's point, from the lane that holds it
             const int src = on ? i : lane;
             double gR[6], gY[3], gQ[3];
@@ -275,13 +296,32 @@ __global__ __launch_bounds__(64 * sig_waves(RB)) void k_build_sig(DevProblem d, 
                 const double uu = uv_c.x, vv = uv_c.y;
                 const double w0 = sg_w ? w_c.x : C.w[0], w1 = sg_w ? w_c.y : C.w[1];
                 double r[2], A[2][6], B[2][3], Cf[2][MAXIO];
-                obs_eval<MODEL, true, false>(C, d.nK, d.nP, Q, uu, vv, r, A, B, Cf);
+                obs_eval<MODEL, true, IO>(C, d.nK, d.nP, Q, uu, vv, r, A, B, Cf);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const double m = ((est >> c) & 1u) ? 1.0 : 0.0;
                     B[0][c] *= w0 * m; B[1][c] *= w1 * m;
                 }
                 const double r00 = gR[0], r10 = gR[1], r20 = gR[2], r11 = gR[3], r21 = gR[4], r22 = gR[5];
+                if constexpr (IO) {                  // IO columns of this camera -> the chunk's IO rows (LDS atomics)
+                    const int ncol = min(C.ncol, NCX);
+#pragma unroll
+                    for (int q = 0; q < NCX - 6; ++q)
+                        if (6 + q < ncol) {
+                            const int row = C.iorow[q];
+                            double c0 = 0, c1 = 0;
+#pragma unroll
+                            for (int rr2 = 0; rr2 < MAXIO; ++rr2) if (rr2 == row) { c0 = Cf[0][rr2]; c1 = Cf[1][rr2]; }
+                            const double e0 = c0 * w0, e1 = c1 * w1;
+                            const double wa0 = e0 * B[0][0] + e1 * B[1][0];
+                            const double wa1 = e0 * B[0][1] + e1 * B[1][1];
+                            const double wa2 = e0 * B[0][2] + e1 * B[1][2];
+                            double *pio = pan + (6 * k + sy.camio[lcj][q]) * LDK + 3 * ir;
+                            atomic_add_f64(pio, wa0 * r00 + wa1 * r10 + wa2 * r20);
+                            atomic_add_f64(pio + 1, wa1 * r11 + wa2 * r21);
+                            atomic_add_f64(pio + 2, wa2 * r22);
+                        }
+                }
 #pragma unroll
                 for (int a = 0; a < 6; ++a) {
                     const double m = ((eo_est >> a) & 1u) ? 1.0 : 0.0;
@@ -299,7 +339,7 @@ __global__ __launch_bounds__(64 * sig_waves(RB)) void k_build_sig(DevProblem d, 
                 double *pr = pan + (6 * j) * LDK + 3 * ir;
 #pragma unroll
                 for (int a = 0; a < 6; ++a) { pr[a * LDK] = Zr[a][0]; pr[a * LDK + 1] = Zr[a][1]; pr[a * LDK + 2] = Zr[a][2]; }
-                if (j == 0) { double *py = pan + (6 * k) * LDK + 3 * ir; py[0] = y3[0]; py[1] = y3[1]; py[2] = y3[2]; }
+                if (j == 0) { double *py = pan + ry * LDK + 3 * ir; py[0] = y3[0]; py[1] = y3[1]; py[2] = y3[2]; }
             }
             lds_fence();
             __builtin_amdgcn_wave_barrier();
@@ -308,14 +348,19 @@ __global__ __launch_bounds__(64 * sig_waves(RB)) void k_build_sig(DevProblem d, 
             // run back to back; the last step's lanes 32..63 would read k-columns 18, 19 (the next row)
             const int ksteps = (d.ablate & 1) ? 0 : (3 * min(ppr, npts - p0) + 3) >> 2;
             const double *zr = pan + (lane & 15) * LDK + (lane >> 4);
-            double op[5][RB];
-#pragma unroll
-            for (int ks = 0; ks < 5; ++ks)
+            // operands of k-step ks+1 are read while the products of k-step ks run
+            auto load_ops = [&](int ks, double (&o)[RB]) {
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb)
-                    op[ks][rb] = (rb < rbk && ks < ksteps && !(ks == 4 && lane >= 32)) ? zr[rb * 16 * LDK + 4 * ks] : 0.0;
+                    o[rb] = (rb < rbk && ks < ksteps && !(ks == 4 && lane >= 32)) ? zr[rb * 16 * LDK + 4 * ks] : 0.0;
+            };
+            double opa[RB], opb[RB];
+            load_ops(0, opa);
 #pragma unroll
-            for (int ks = 0; ks < 5; ++ks)
+            for (int ks = 0; ks < 5; ++ks) {
+                double (&cur)[RB] = (ks & 1) ? opb : opa;
+                double (&nxt)[RB] = (ks & 1) ? opa : opb;
+                if (ks + 1 < 5) load_ops(ks + 1, nxt);
                 if (ks < ksteps) {
 #pragma unroll
                     for (int r1 = 0; r1 < RB; ++r1)
@@ -323,9 +368,10 @@ __global__ __launch_bounds__(64 * sig_waves(RB)) void k_build_sig(DevProblem d, 
 #pragma unroll
                             for (int r2 = 0; r2 <= r1; ++r2)
                                 acc[r1 * (r1 + 1) / 2 + r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(
-                                    op[ks][r1], op[ks][r2], acc[r1 * (r1 + 1) / 2 + r2], 0, 0, 0);
+                                    cur[r1], cur[r2], acc[r1 * (r1 + 1) / 2 + r2], 0, 0, 0);
                         }
                 }
+            }
             lds_fence();
             __builtin_amdgcn_wave_barrier();
             lap(4);
@@ -334,17 +380,17 @@ __global__ __launch_bounds__(64 * sig_waves(RB)) void k_build_sig(DevProblem d, 
         // one predicated ds_add_f64 per accumulator element; vt follows stile, so the right-hand-side
         // row (6k) only changes the index and the sign
         {
-            const int r6k = 6 * k;
+            const int r6k = ry;                      // the row of y closes the chunk's rows
             int tcm[RB];
 #pragma unroll
-            for (int r2 = 0; r2 < RB; ++r2) tcm[r2] = sy.tmap[wave][min(16 * r2 + (lane & 15), 6 * SIG_KMAXR - 1)];
+            for (int r2 = 0; r2 < RB; ++r2) tcm[r2] = sy.tmap[wave][min(16 * r2 + (lane & 15), 79)];
 #pragma unroll
             for (int r1 = 0; r1 < RB; ++r1) {
                 if (r1 >= rbk) break;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int lr = 16 * r1 + (lane >> 4) + 4 * e;
-                    const int tr = sy.tmap[wave][min(lr, 6 * SIG_KMAXR - 1)];
+                    const int tr = sy.tmap[wave][min(lr, 79)];
                     const bool yrow = lr == r6k;
                     const int rowbase = yrow ? SIG_STILE : tr * (tr + 1) / 2;
 #pragma unroll
@@ -397,7 +443,7 @@ __global__ __launch_bounds__(64 * sig_waves(RB)) void k_build_sig(DevProblem d, 
 // (scalar loads), (u,v) comes coalesced from the slot-major copy, and the sums over a point's
 // observations stay in the lane's registers: no LDS, no atomics, no per-lane camera gathers.
 // Two sweeps over the k cameras: B't for dp, then (t + B dp)^2.
-template <int MODEL>
+template <int MODEL, int NCX>
 __global__ __launch_bounds__(256) void k_backsub_sig(DevProblem d, const double *__restrict__ z,
                                                      const CamRec *__restrict__ cams,
                                                      const double *__restrict__ Vinv, const double *__restrict__ gp,
@@ -427,11 +473,13 @@ __global__ __launch_bounds__(256) void k_backsub_sig(DevProblem d, const double 
                 const CamRec &C = cams[cam];
                 const double2 uv = uvp[q0 + (int64_t)j * gm];
                 const double w0 = sg_w ? wp[q0 + (int64_t)j * gm].x : C.w[0], w1 = sg_w ? wp[q0 + (int64_t)j * gm].y : C.w[1];
-                double r[2], E[2][6], B[2][3];
-                eval_obs_pre<MODEL, 6>(d, C, Q, uv.x, uv.y, w0, w1, est, r, E, B);
+                double r[2], E[2][NCX], B[2][3];
+                eval_obs_pre<MODEL, NCX>(d, C, Q, uv.x, uv.y, w0, w1, est, r, E, B);
+                const int ncol = NCX > 6 ? min(C.ncol, NCX) : 6;
                 double t0 = 0, t1 = 0;
 #pragma unroll
-                for (int a = 0; a < 6; ++a) { const double dc = dz[C.col[a]]; t0 += E[0][a] * dc; t1 += E[1][a] * dc; }
+                for (int a = 0; a < NCX; ++a)
+                    if (a < ncol) { const double dc = dz[C.col[a]]; t0 += E[0][a] * dc; t1 += E[1][a] * dc; }
                 if (sweep == 0) {
                     s[0] += B[0][0] * t0 + B[1][0] * t1;
                     s[1] += B[0][1] * t0 + B[1][1] * t1;
