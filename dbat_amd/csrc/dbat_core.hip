@@ -177,7 +177,7 @@ struct Core {
         x2z.upload(P.x2z);
         o_lc.upload(P.o_lc); o_pidx.upload(P.o_pidx); tile_batch.upload(P.tile_batch); tile_cam_start.upload(P.tile_cam_start); tile_cams.upload(P.tile_cams);
         tile_io_start.upload(P.tile_io_start); tile_iocols.upload(P.tile_iocols); tile_cam_io.upload(P.tile_cam_io);
-        tile_ncx = P.ncolmax <= 6 ? 6 : (P.ncolmax <= 14 ? 14 : MAXCOL);
+        tile_ncx = P.shared_eo ? MAXCOL : (P.ncolmax <= 6 ? 6 : (P.ncolmax <= 14 ? 14 : MAXCOL));
         ntiles = (P.CMAX && P.nb_tiled > 0) ? (int64_t)P.tile_batch.size() - 1 : 0;
         d.nc = P.nc; d.np = P.np; d.nIOrows = P.nIOrows; d.nK = P.nK; d.nP = P.nP; d.nIOu = P.nIOu;
         d.ncolmax = P.ncolmax; d.BT = P.BT; d.NS = P.NS; d.NZ = P.NZ; d.nobs = nobs; d.nb = nb;
@@ -223,7 +223,7 @@ struct Core {
             std::vector<int> first((size_t)P.NS, 0);
             for (int c = 0; c < P.nc; ++c)
                 for (int k = 0; k < 6; ++k) first[(size_t)6 * c + k] = 6 * P.cam_first[c];
-            if (getenv("DBAT_HIP_DENSE_CHOL")) env.build_dense((int)P.NS);
+            if (getenv("DBAT_HIP_DENSE_CHOL") || P.shared_eo) env.build_dense((int)P.NS);   // shared EO: columns couple beyond the co-visibility band
             else env.build((int)P.NS, 6 * P.nc, first);
             {   // packed layout of the envelope for the all-reduce
                 const int NSi = (int)P.NS;
@@ -239,7 +239,7 @@ struct Core {
                 col_bend.upload(cb); col_off.upload(co);
             }
             use_df = getenv("DBAT_HIP_BLOCKCHOL") == nullptr;       // the multi-launch BlockChol stays for A/B runs
-            use_perm = use_df && getenv("DBAT_HIP_DF_NOPERM") == nullptr;
+            use_perm = use_df && getenv("DBAT_HIP_DF_NOPERM") == nullptr && !P.shared_eo;
             if (!dfchol_ip.setup_inplace(env, ldS)) throw DeviceError{"out of device memory (Cholesky schedule)"};
             if (use_perm) {
                 std::vector<double> xyz((size_t)3 * P.nc);
@@ -1058,7 +1058,9 @@ int dbat_hip_deserialize(const dbat_hip_handle *h, const double *x, double *IO, 
     const Plan &P = h->core->P;
     std::vector<double> z(P.z0);
     for (int64_t i = 0; i < P.n; ++i) z[P.x2z[i]] = x[i];
-    if (EO) std::copy(z.begin(), z.begin() + 6 * (int64_t)P.nc, EO);
+    if (EO)                                             // shared elements fan out from their leading entry (deserialize.m:28-30)
+        for (int c = 0; c < P.nc; ++c)
+            for (int k = 0; k < 6; ++k) EO[6 * c + k] = z[P.cam_col[(size_t)c * MAXCOL + k]];
     if (OP)                                             // z holds the points in processing order
         for (int64_t p = 0; p < P.np; ++p)
             for (int k = 0; k < 3; ++k) OP[3 * p + k] = z[P.NS + 3 * (int64_t)P.pt_rank[p] + k];

@@ -66,9 +66,10 @@ __global__ void k_cam_prep(DevProblem d, const double *__restrict__ z, CamRec *_
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= d.nc) return;
     CamRec r;
-    const double *eo = z + 6 * (int64_t)c;
-    r.c[0] = eo[0]; r.c[1] = eo[1]; r.c[2] = eo[2];
-    const double ang[3] = {eo[3], eo[4], eo[5]};
+    // the six EO values through the column list: a shared element lives in the slot of its leading entry
+    const int32_t *ec = d.cam_col + (int64_t)c * MAXCOL;
+    r.c[0] = z[ec[0]]; r.c[1] = z[ec[1]]; r.c[2] = z[ec[2]];
+    const double ang[3] = {z[ec[3]], z[ec[4]], z[ec[5]]};
     cam_rotation(ang, r.Mt, r.dMt);
     double io[MAXIO];
     for (int k = 0; k < MAXIO; ++k) {
@@ -1958,7 +1959,7 @@ __global__ void k_cov_cam(DevProblem d, const double *__restrict__ Sinv, double 
     if (i < nE) {
         if (!CEO) return;
         const int c = (int)(i / 36), e = (int)(i % 36), a = e % 6, b = e / 6;
-        const int ra = 6 * c + a, rb = 6 * c + b;
+        const int ra = d.cam_col[(int64_t)c * MAXCOL + a], rb = d.cam_col[(int64_t)c * MAXCOL + b];   // (shared elements: the leader's)
         CEO[i] = (d.z_est[ra] && d.z_est[rb]) ? s02 * sym_at(Sinv, d.ldS, ra, rb) : 0.0;
     } else if (i < nE + nI) {
         if (!CIO) return;

@@ -113,6 +113,9 @@ struct Plan {
     std::vector<uint64_t> cam_adj;                 // [nc][cam_adj_words] co-visibility graph (bit c2 of row c1), symmetric
     int cam_adj_words = 0;
     int max_k = 0;                                 // max observations of one point
+    bool shared_eo = false;                        // EO.struct.block shares elements between images (camera stations):
+                                                   // every shared element is ONE unknown in the slot of its leading
+                                                   // entry (cam_col), the other entries' slots are inert
     bool rank_ok = true;                           // structural rank test
     int order_dims = 3;                            // dimensions of the point-ordering curve (2 = flat cloud)
     std::string err;
@@ -192,7 +195,15 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     bool simpleIO, simpleEO;
     serialize_block(R, nc, pb.IO_block, estIO.data(), distIO, leadIO, simpleIO);
     serialize_block(6, nc, pb.EO_block, estEO.data(), distEO, leadEO, simpleEO);
-    if (!simpleEO) return fail(P, "shared EO blocks (EO.struct.block) are not supported by the HIP path");
+    P.shared_eo = !simpleEO;
+    // z slot of every EO entry: its own, or -- buildserialindices.m:204-221 -- that of the leading
+    // entry of its block (the first estimated element with the same block id in the same row)
+    std::vector<int64_t> eo_z((size_t)6 * nc);
+    std::vector<uint8_t> eo_lead((size_t)6 * nc, 0);
+    for (size_t e = 0; e < eo_z.size(); ++e) {
+        eo_z[e] = distEO[e] >= 0 ? leadEO[distEO[e]] : (int64_t)e;
+        eo_lead[e] = distEO[e] >= 0 && leadEO[distEO[e]] == (int64_t)e;
+    }
     for (size_t e = 0; e < estEO.size(); ++e)
         if (estEO[e] && pb.EO_block[e] == 0) return fail(P, "estimated EO element with block id 0");
     for (size_t e = 0; e < estIO.size(); ++e)
@@ -205,13 +216,13 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     P.io_fixed.assign(pb.IO_val, pb.IO_val + (size_t)R * nc);
     P.z_est.assign(P.NZ, 0); P.z_prw.assign(P.NZ, 0.0); P.z_prv.assign(P.NZ, 0.0);
     P.z0.assign(P.NZ, 0.0);
-    for (size_t e = 0; e < (size_t)6 * nc; ++e) { P.z0[e] = pb.EO_val[e]; P.z_est[e] = estEO[e]; }
+    for (size_t e = 0; e < (size_t)6 * nc; ++e) { P.z0[e] = pb.EO_val[e]; P.z_est[e] = eo_lead[e]; }
     for (int k = 0; k < P.nIOu; ++k) { P.z0[6 * (int64_t)nc + k] = pb.IO_val[leadIO[k]]; P.z_est[6 * (int64_t)nc + k] = 1; }
     for (size_t e = 0; e < (size_t)3 * np; ++e) { P.z0[P.NS + e] = pb.OP_val[e]; P.z_est[P.NS + e] = estOP[e]; }
     // x order: IO leading (column-major), EO est (column-major), OP est (column-major)
     P.x2z.clear();
     for (int k = 0; k < P.nIOu; ++k) P.x2z.push_back(6 * (int64_t)nc + k);
-    for (size_t e = 0; e < (size_t)6 * nc; ++e) if (estEO[e]) P.x2z.push_back((int64_t)e);
+    for (size_t e = 0; e < (size_t)6 * nc; ++e) if (eo_lead[e]) P.x2z.push_back((int64_t)e);
     for (size_t e = 0; e < (size_t)3 * np; ++e) if (estOP[e]) P.x2z.push_back(P.NS + (int64_t)e);
     P.n = (int64_t)P.x2z.size();
     P.nOP = P.n - P.nIO - P.nEO;
@@ -225,7 +236,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         if (pb.prior_IO_use && pb.prior_IO_use[e]) { add_prior(6 * (int64_t)nc + k, pb.prior_IO_val[e], pb.prior_IO_std[e]); P.n_prior[0]++; }
     }
     for (size_t e = 0; e < (size_t)6 * nc; ++e)
-        if (estEO[e] && pb.prior_EO_use && pb.prior_EO_use[e]) { add_prior((int64_t)e, pb.prior_EO_val[e], pb.prior_EO_std[e]); P.n_prior[1]++; }
+        if (eo_lead[e] && pb.prior_EO_use && pb.prior_EO_use[e]) { add_prior((int64_t)e, pb.prior_EO_val[e], pb.prior_EO_std[e]); P.n_prior[1]++; }
     for (size_t e = 0; e < (size_t)3 * np; ++e)
         if (estOP[e] && pb.prior_OP_use && pb.prior_OP_use[e]) { add_prior(P.NS + (int64_t)e, pb.prior_OP_val[e], pb.prior_OP_std[e]); P.n_prior[2]++; }
     for (int64_t z : P.prior_z)
@@ -236,11 +247,12 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     P.px.assign(pb.px_size, pb.px_size + (size_t)2 * nc);
     P.cam_ncol.assign(nc, 6); P.cam_col.assign((size_t)nc * MAXCOL, -1);
     P.cam_iorow.assign((size_t)nc * MAXIO, 0); P.cam_eo_est.assign(nc, 0);
-    P.ncolmax = 6; P.with_io = P.nIOu > 0;
+    // shared EO elements take the general (column-list) kernels, as estimated IO does
+    P.ncolmax = 6; P.with_io = P.nIOu > 0 || P.shared_eo;
     for (int c = 0; c < nc; ++c) {
         uint32_t m = 0;
         for (int k = 0; k < 6; ++k) {
-            P.cam_col[(size_t)c * MAXCOL + k] = 6 * c + k;
+            P.cam_col[(size_t)c * MAXCOL + k] = (int32_t)eo_z[(size_t)6 * c + k];
             if (estEO[(size_t)c * 6 + k]) m |= 1u << k;
         }
         P.cam_eo_est[c] = m;
@@ -323,7 +335,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     // along an augmenting path.  J is never formed: the rows of an EO or IO column are the
     // contiguous observation ranges of its cameras, those of an OP column the observations
     // of its point.
-    if (P.rank_ok && !getenv("DBAT_HIP_SPRANK_OFF")) {
+    if (P.rank_ok && !getenv("DBAT_HIP_SPRANK_OFF") && !P.shared_eo) {     // (shared EO: the counting conditions only)
         const int64_t ncol_all = P.NZ;
         std::vector<int64_t> cam_obs0(nc + 1, 0);
         for (int c = 0; c < nc; ++c) cam_obs0[c + 1] = cam_obs0[c] + n_cam[c];
@@ -422,6 +434,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     // points seen in very many images) follow and go through k_build.
     auto env_int0 = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
     P.CMAX = env_int0("DBAT_HIP_CMAX", P.with_io ? 18 : 21);
+    if (P.shared_eo) P.CMAX = 0;                    // the tile kernels address camera rows as 6*camera + k
     if (P.CMAX < 0 || P.CMAX > (P.with_io ? 18 : 21)) P.CMAX = P.with_io ? 18 : 21;   // 6*CMAX (+IOT) <= 128 rows of the MFMA tile
     if (P.ncolmax - 6 > Plan::IOT) P.CMAX = 0;
     {   // batch size: whole points, at most BT observations

@@ -452,7 +452,9 @@ __global__ __launch_bounds__(256) void k_backsub_sig(DevProblem d, const double 
                                                      const int32_t *__restrict__ sg_gcam,
                                                      const double *__restrict__ sg_uv, const double *__restrict__ sg_w) {
     __shared__ double sh[8];
+    __shared__ double2 tbuf[4][16][64];              // t = E dc of every (camera slot, point): the second sweep needs only B
     const int t = threadIdx.x, lane = t & 63;
+    const int wv = t >> 6;
     const int ch = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (t >> 6));
     double acc[2] = {0, 0};
     if (ch < nchunks) {
@@ -475,16 +477,19 @@ __global__ __launch_bounds__(256) void k_backsub_sig(DevProblem d, const double 
                 const double w0 = sg_w ? wp[q0 + (int64_t)j * gm].x : C.w[0], w1 = sg_w ? wp[q0 + (int64_t)j * gm].y : C.w[1];
                 double r[2], E[2][NCX], B[2][3];
                 eval_obs_pre<MODEL, NCX>(d, C, Q, uv.x, uv.y, w0, w1, est, r, E, B);
-                const int ncol = NCX > 6 ? min(C.ncol, NCX) : 6;
                 double t0 = 0, t1 = 0;
-#pragma unroll
-                for (int a = 0; a < NCX; ++a)
-                    if (a < ncol) { const double dc = dz[C.col[a]]; t0 += E[0][a] * dc; t1 += E[1][a] * dc; }
                 if (sweep == 0) {
+                    const int ncol = NCX > 6 ? min(C.ncol, NCX) : 6;
+#pragma unroll
+                    for (int a = 0; a < NCX; ++a)
+                        if (a < ncol) { const double dc = dz[C.col[a]]; t0 += E[0][a] * dc; t1 += E[1][a] * dc; }
+                    tbuf[wv][j][lane] = double2{t0, t1};
                     s[0] += B[0][0] * t0 + B[1][0] * t1;
                     s[1] += B[0][1] * t0 + B[1][1] * t1;
                     s[2] += B[0][2] * t0 + B[1][2] * t1;
                 } else {
+                    const double2 tj = tbuf[wv][j][lane];         // (E, the camera-side Jacobian, is dead code in this sweep)
+                    t0 = tj.x; t1 = tj.y;
                     const double j0 = t0 + B[0][0] * dp[0] + B[0][1] * dp[1] + B[0][2] * dp[2];
                     const double j1 = t1 + B[1][0] * dp[0] + B[1][1] * dp[1] + B[1][2] * dp[2];
                     if (act) acc[0] += j0 * j0 + j1 * j1;

@@ -296,12 +296,66 @@ def test_failure_codes(hip):
     assert np.array_equal(res.EO.val, s.EO.val)
 
 
+def _shared_eo_struct(kind):
+    """Images that share exterior orientation elements through EO.struct.block
+    (buildserialindices.m:162-221 treats it exactly like IO.struct.block): 'station' -- images 1
+    and 2 and images 5, 6, 7 taken from the same projection centres (rows X, Y, Z shared, the
+    angles their own); 'rig' -- images 3 and 4 share all six elements."""
+    s, truth = synth_struct('tiny', 'plain' if kind != 'selfcal' else 'selfcal')
+    blk = s.EO.struct.block
+    if kind == 'rig':
+        blk[:, 4] = blk[:, 3]
+        s.EO.val[:6, 4] = s.EO.val[:6, 3]
+    else:
+        blk[0:3, 2] = blk[0:3, 1]
+        blk[0:3, 6] = blk[0:3, 5]; blk[0:3, 7] = blk[0:3, 5]
+        s.EO.val[0:3, 2] = s.EO.val[0:3, 1]
+        s.EO.val[0:3, 6] = s.EO.val[0:3, 5]; s.EO.val[0:3, 7] = s.EO.val[0:3, 5]
+    return s
+
+
+@pytest.mark.parametrize('kind', ['station', 'rig', 'selfcal'])
+def test_shared_eo_blocks(hip, kind):
+    """Shared EO elements: unknown ordering, residual / Jacobian, the step of the reduced
+    system, the bundle result and the posterior covariance as the oracle's (one unknown in
+    the slot of the block's leading entry, fanned out on deserialise)."""
+    from dbat_amd import bundle, bundle_cov
+    s = _shared_eo_struct(kind)
+    so, x0, w = oracle_setup(s)
+    R = np.sqrt(w)
+    h = hip.Handle(s)
+    try:
+        assert h.n == len(x0) and np.array_equal(h.serialize(), x0)
+        rng = np.random.default_rng(3)
+        x = x0 + 1e-5 * rng.standard_normal(len(x0)) * np.maximum(1e-3, np.abs(x0))
+        r_o, K = o.brown_euler_cam4(x, so, jac=True)
+        r_h, f_h = h.residual(x)
+        assert relerr(r_h, r_o) < TOL_BLOCK
+        J = (sp.diags(R) @ K).tocsc()
+        p_o, *_ = o._scaled_gn(J, R * r_o)
+        p_h, st = h.linearize_solve(x, 0.0, True)
+        assert relerr(p_h, p_o) < TOL_STEP
+        assert relerr(h.gradient(), J.T @ (R * r_o)) < 1e-10
+        assert relerr(h.colnorms(), np.sqrt(np.asarray(J.multiply(J).sum(0)).ravel())) < 1e-10
+        Jp = J @ p_o
+        assert abs(st['JpJp'] - Jp @ Jp) <= 1e-7 * (Jp @ Jp)
+    finally:
+        h.close()
+    for damping in ('gna', 'lm', 'lmp'):
+        res, ok, iters, s0, E = bundle(s, damping)
+        ro, oko, ito, s0o, Eo = o.bundle(s, damping)
+        assert ok == oko and E.code == Eo.code
+        assert relerr(E.x, Eo.x) < TOL_X and abs(s0 - s0o) < 1e-9 * s0o
+        assert relerr(res.EO.val[:6], ro.EO.val[:6]) < TOL_X          # fanned out to every image of a block
+        if damping == 'gna':
+            assert iters == ito
+            CEO, COP = bundle_cov(res, E, 'CEO', 'COP')
+            CEOo, COPo = o.bundle_cov(ro, Eo, 'CEO', 'COP')
+            for A, B in ((CEO, CEOo), (COP, COPo)):
+                assert abs(A - B).max() <= 1e-6 * abs(B).max()
+
+
 def test_unsupported_and_bad_input(hip):
-    s, _ = synth_struct('tiny', 'plain')
-    s.EO.struct.block[:, 2] = s.EO.struct.block[:, 1]      # shared camera station
-    with pytest.raises(hip.DbatHipError) as e:
-        hip.Handle(s)
-    assert e.value.code == hip.EUNSUPPORTED
     from dbat_amd import bundle
     from dbat_amd.driver import BadInput
     s, _ = synth_struct('tiny', 'plain')
