@@ -100,6 +100,7 @@ SYMBOLS = {
     'dbat_hip_comm_allreduce_host': (C.c_int, [_H, _dp, C.c_int64, C.c_int32]),
     'dbat_hip_set_allreduce': (C.c_int, [_H, ALLREDUCE_FN, C.c_void_p]),
     'dbat_hip_owned_mask': (C.c_int, [_H, _bp]),
+    'dbat_hip_forwintersect': (C.c_int, [_H, _dp, _bp, _dp]),
     'dbat_hip_bench_step': (C.c_int, [_H, C.c_double, C.c_int32, _dp]),
     'dbat_hip_set_x': (C.c_int, [_H, _dp]),
     'dbat_hip_info': (C.c_int, [_H, C.POINTER(C.c_int64)]),
@@ -321,6 +322,15 @@ class Handle:
         ru, rw = np.zeros(self.m), np.zeros(self.m)
         check(self.lib.dbat_hip_final_residuals(self.h, dptr(ru), dptr(rw)))
         return ru, rw
+
+    def forwintersect(self, x, OP, skip=None):
+        """OP (3 x n_points) with the points of skip == False replaced by the forward
+        intersection of their rays at the IO / EO of x."""
+        x = np.ascontiguousarray(x, float)
+        out = np.ascontiguousarray(np.asarray(OP, float).flatten('F'))
+        sk = None if skip is None else np.ascontiguousarray(np.asarray(skip, bool).astype(np.uint8))
+        check(self.lib.dbat_hip_forwintersect(self.h, dptr(x), None if sk is None else sk.ctypes.data_as(_bp), dptr(out)))
+        return out.reshape(3, -1, order='F')
 
     def build_kernel_name(self):
         buf = C.create_string_buffer(64)

@@ -1389,6 +1389,36 @@ int dbat_hip_posterior_cov(dbat_hip_handle *h, const double *x, double sigma0, d
     API_CATCH
 }
 
+int dbat_hip_forwintersect(dbat_hip_handle *h, const double *x, const uint8_t *skip, double *OP) {
+    API_TRY
+    if (!h || !x || !OP) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
+    Core &c = *h->core;
+    DeviceGuard dev_guard(c.device);
+    const Plan &P = c.P;
+    c.x_to_z(x, c.zt.p);                              // IO / EO of the rays
+    c.prep_cams(c.zt.p);
+    DevBuf<double> dOP;
+    dOP.alloc((size_t)3 * std::max(P.np, 1));
+    HIPCHK(hipMemsetAsync(dOP.p, 0, (size_t)3 * P.np * sizeof(double), c.stream));
+    if (c.nb > 0) LAUNCHK(k_forwintersect, dim3((unsigned)c.nb), dim3(P.BT), (size_t)P.BT * 9 * sizeof(double), c.stream, c.d, c.cams.p, dOP.p);
+    if (c.ngiant > 0) LAUNCHK(k_forwintersect_giant, dim3((unsigned)c.ngiant), dim3(256), 0, c.stream, c.d, c.cams.p, dOP.p);
+    if (c.multi()) c.do_allreduce(dOP.p, (int64_t)3 * P.np);             // every point is computed by its owner
+    std::vector<double> tmp((size_t)3 * P.np);
+    HIPCHK(hipMemcpyAsync(tmp.data(), dOP.p, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+    c.sync();
+    std::vector<uint8_t> seen((size_t)P.np, 0);       // points without any observation: NaN (pm_multiforwintersect.m:41)
+    for (int32_t r : P.o_pt) seen[r] = 1;
+    if (c.multi()) std::fill(seen.begin(), seen.end(), 1);               // (other shards' points arrive through the sum)
+    const double nan = std::nan("");
+    for (int64_t p = 0; p < P.np; ++p) {
+        if (skip && skip[p]) continue;                // keeps the caller's value (forwintersect.m:32-36)
+        const int64_t r = P.pt_rank[p];
+        for (int k = 0; k < 3; ++k) OP[3 * p + k] = seen[r] ? tmp[3 * r + k] : nan;
+    }
+    return DBAT_HIP_OK;
+    API_CATCH
+}
+
 int dbat_hip_chol_stats(const dbat_hip_handle *h, int64_t *st) {
     if (!h || !st) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
     const Core &c = *h->core;

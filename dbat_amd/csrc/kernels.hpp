@@ -2305,6 +2305,87 @@ __global__ __launch_bounds__(256) void k_backsub(DevProblem d, const double *__r
     if (t == 0) { partial[2 * (int64_t)batch] = acc[0]; partial[2 * (int64_t)batch + 1] = acc[1]; }
 }
 
+// ------------------------------------------------- forward intersection ---
+// photogrammetry/forwintersect.m:27-46 (+ cammodel/pm_multilenscorr1.m:45-69,
+// pm_multiforwintersect.m, pm_forwintersect3.m:55-82): the object point that minimises the
+// summed squared distance to its lens-corrected image rays,
+//     (sum_j (I - d_j d_j')) Q = sum_j (I - d_j d_j') c_j,
+// d_j = M_j K^-1 [x; y; 1] normalised, c_j the projection centre.  One lane per observation of
+// a batch (the point-major layout of k_backsub), 3 x 3 system per point at its leader lane.
+// OPout (processing order): the point, or NaN with fewer than two rays.
+__device__ __forceinline__ void fwd_ray_terms(const CamRec &C, int nK, int nP, double u, double v, double out[9]) {
+    const double qx = C.sz * u, qy = -C.sz * v;                  // mm, y up
+    const double xb = qx - C.pp[0], yb = qy - C.pp[1];
+    const double r2 = xb * xb + yb * yb;
+    double Kr = 0, pw = 1;
+    for (int j = 0; j < MAXK; ++j) if (j < nK) { pw *= r2; Kr += C.K[j] * pw; }
+    double dx = xb * Kr, dy = yb * Kr;
+    if (nP >= 2) {
+        const double P1 = C.P[0], P2 = C.P[1], P3 = nP > 2 ? 1.0 + C.P[2] : 1.0;
+        dx += (P1 * (r2 + 2 * xb * xb) + 2 * P2 * xb * yb) * P3;
+        dy += (P2 * (r2 + 2 * yb * yb) + 2 * P1 * xb * yb) * P3;
+    }
+    const double dc[3] = {qx - dx - C.pp[0], qy - dy - C.pp[1], -C.f};
+    double dw[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dw[i] = C.Mt[i] * dc[0] + C.Mt[3 + i] * dc[1] + C.Mt[6 + i] * dc[2];     // M dc, Mt = M'
+    const double inn = 1.0 / sqrt(dw[0] * dw[0] + dw[1] * dw[1] + dw[2] * dw[2]);
+    const double d0 = dw[0] * inn, d1 = dw[1] * inn, d2 = dw[2] * inn;
+    const double p00 = 1 - d0 * d0, p01 = -d0 * d1, p02 = -d0 * d2, p11 = 1 - d1 * d1, p12 = -d1 * d2, p22 = 1 - d2 * d2;
+    out[0] = p00; out[1] = p01; out[2] = p02; out[3] = p11; out[4] = p12; out[5] = p22;
+    out[6] = p00 * C.c[0] + p01 * C.c[1] + p02 * C.c[2];
+    out[7] = p01 * C.c[0] + p11 * C.c[1] + p12 * C.c[2];
+    out[8] = p02 * C.c[0] + p12 * C.c[1] + p22 * C.c[2];
+}
+__device__ __forceinline__ void fwd_solve(const double a[9], int rays, double *op) {
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    double inv[6];
+    if (rays < 2) { op[0] = op[1] = op[2] = nan; return; }
+    inv3_sym(a, inv);
+    op[0] = inv[0] * a[6] + inv[1] * a[7] + inv[2] * a[8];
+    op[1] = inv[1] * a[6] + inv[3] * a[7] + inv[4] * a[8];
+    op[2] = inv[2] * a[6] + inv[4] * a[7] + inv[5] * a[8];
+}
+__global__ __launch_bounds__(256) void k_forwintersect(DevProblem d, const CamRec *__restrict__ cams,
+                                                       double *__restrict__ OPout) {
+    extern __shared__ double smem[];                 // [BT][9]
+    const int t = threadIdx.x;
+    const int64_t o0 = d.batch_start[blockIdx.x];
+    const int nobs = (int)(d.batch_start[blockIdx.x + 1] - o0);
+    int pt = 0, seg_start = 0, seg_len = 0;
+    if (t < nobs) {
+        const int64_t o = o0 + t;
+        pt = d.o_pt[o];
+        const uint32_t sg = d.o_seg[o];
+        seg_start = sg & 0xFFFF; seg_len = sg >> 16;
+        fwd_ray_terms(cams[d.o_cam[o]], d.nK, d.nP, d.o_uv[2 * o], d.o_uv[2 * o + 1], smem + 9 * t);
+    }
+    __syncthreads();
+    if (t < nobs && t == seg_start) {
+        double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int j = 0; j < seg_len; ++j)
+#pragma unroll
+            for (int q = 0; q < 9; ++q) a[q] += smem[9 * (t + j) + q];
+        fwd_solve(a, seg_len, OPout + 3 * (int64_t)pt);
+    }
+}
+// points with more observations than a batch holds: one workgroup per point
+__global__ __launch_bounds__(256) void k_forwintersect_giant(DevProblem d, const CamRec *__restrict__ cams,
+                                                             double *__restrict__ OPout) {
+    __shared__ double sh[9 * 4];
+    const int t = threadIdx.x;
+    const int64_t o0 = d.giant_start[blockIdx.x], o1 = d.giant_start[blockIdx.x + 1];
+    double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t o = o0 + t; o < o1; o += blockDim.x) {
+        double q[9];
+        fwd_ray_terms(cams[d.o_cam[o]], d.nK, d.nP, d.o_uv[2 * o], d.o_uv[2 * o + 1], q);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) a[i] += q[i];
+    }
+    block_sum<9>(a, sh);
+    if (t == 0) fwd_solve(a, (int)(o1 - o0), OPout + 3 * (int64_t)d.o_pt[o0]);
+}
+
 // ---------------------------------------------------------------- K8 ----
 // partial[2*blk] += ||J v||^2, partial[2*blk+1] += r'Jv over image rows
 // (grid-stride; v in z layout).

@@ -442,7 +442,7 @@ __global__ __launch_bounds__(64 * sig_waves(RB, (NCX > 6))) void k_build_sig(Dev
 // cameras are the same for every lane, so their records and their steps dc are wave-uniform
 // (scalar loads), (u,v) comes coalesced from the slot-major copy, and the sums over a point's
 // observations stay in the lane's registers: no LDS, no atomics, no per-lane camera gathers.
-// Two sweeps over the k cameras: B't for dp, then (t + B dp)^2.
+// One sweep over the k cameras (see the formula below).
 template <int MODEL, int NCX>
 __global__ __launch_bounds__(256) void k_backsub_sig(DevProblem d, const double *__restrict__ z,
                                                      const CamRec *__restrict__ cams,
@@ -451,8 +451,10 @@ __global__ __launch_bounds__(256) void k_backsub_sig(DevProblem d, const double 
                                                      const int32_t *__restrict__ sg_chunk, int nchunks,
                                                      const int32_t *__restrict__ sg_gcam,
                                                      const double *__restrict__ sg_uv, const double *__restrict__ sg_w) {
+    constexpr int CW = (int)((sizeof(CamRec) + 7) / 8);
     __shared__ double sh[8];
-    __shared__ double2 tbuf[4][16][64];              // t = E dc of every (camera slot, point): the second sweep needs only B
+    __shared__ double crec[4][SIG_KMAXR][CW];        // the chunk's camera records, fetched once by the whole wave
+    __shared__ double dcs[4][SIG_KMAXR][NCX];        // ... and their steps dc, column by column
     const int t = threadIdx.x, lane = t & 63;
     const int wv = t >> 6;
     const int ch = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (t >> 6));
@@ -460,6 +462,19 @@ __global__ __launch_bounds__(256) void k_backsub_sig(DevProblem d, const double 
     if (ch < nchunks) {
         const int32_t *cd = sg_chunk + 8 * (int64_t)ch;
         const int pt0 = cd[0], npts = cd[1], k = cd[2], gm = cd[4], gi0 = cd[5], uv0 = cd[6];
+        const int mycam = lane < k ? sg_gcam[16 * (int64_t)ch + lane] : 0;
+        for (int idx = lane; idx < k * CW; idx += 64) {
+            const int c = idx / CW, f = idx - c * CW;
+            const int cam = __builtin_amdgcn_ds_bpermute(4 * c, mycam);
+            crec[wv][c][f] = reinterpret_cast<const double *>(cams + cam)[f];
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int idx = lane; idx < k * NCX; idx += 64) {
+            const int c = idx / NCX, a = idx - c * NCX;
+            const CamRec &C = *reinterpret_cast<const CamRec *>(crec[wv][c]);
+            dcs[wv][c][a] = a < (NCX > 6 ? min(C.ncol, NCX) : 6) ? dz[C.col[a]] : 0.0;
+        }
+        __builtin_amdgcn_wave_barrier();
         const bool act = lane < npts;
         const int pt = pt0 + (act ? lane : 0);
         const int64_t zp = d.NS + 3 * (int64_t)pt;
@@ -467,41 +482,43 @@ __global__ __launch_bounds__(256) void k_backsub_sig(DevProblem d, const double 
         const unsigned est = (d.z_est[zp] ? 1u : 0u) | (d.z_est[zp + 1] ? 2u : 0u) | (d.z_est[zp + 2] ? 4u : 0u);
         const double2 *uvp = reinterpret_cast<const double2 *>(sg_uv), *wp = reinterpret_cast<const double2 *>(sg_w);
         const int64_t q0 = uv0 + gi0 + (act ? lane : 0);
-        double s[3] = {gp[3 * (int64_t)pt], gp[3 * (int64_t)pt + 1], gp[3 * (int64_t)pt + 2]};
-        double dp[3] = {0, 0, 0};
-        for (int sweep = 0; sweep < 2; ++sweep) {
-            for (int j = 0; j < k; ++j) {
-                const int cam = __builtin_amdgcn_readfirstlane(sg_gcam[16 * (int64_t)ch + j]);
-                const CamRec &C = cams[cam];
-                const double2 uv = uvp[q0 + (int64_t)j * gm];
-                const double w0 = sg_w ? wp[q0 + (int64_t)j * gm].x : C.w[0], w1 = sg_w ? wp[q0 + (int64_t)j * gm].y : C.w[1];
-                double r[2], E[2][NCX], B[2][3];
-                eval_obs_pre<MODEL, NCX>(d, C, Q, uv.x, uv.y, w0, w1, est, r, E, B);
-                double t0 = 0, t1 = 0;
-                if (sweep == 0) {
-                    const int ncol = NCX > 6 ? min(C.ncol, NCX) : 6;
+        // one sweep over the cameras: with t_j = E_j dc_j (2-vector of observation j),
+        //   dp = -V^-1 (g_p + sum_j B_j' t_j)
+        //   sum_j |t_j + B_j dp|^2 = sum |t_j|^2 + 2 dp' (sum B_j' t_j) + dp' (sum B_j' B_j) dp
+        // so |J p|^2 of the point's rows needs no second evaluation of its observations
+        double sB[3] = {0, 0, 0}, V0[6] = {0, 0, 0, 0, 0, 0}, tt2 = 0;
+        for (int j = 0; j < k; ++j) {
+            const CamRec &C = *reinterpret_cast<const CamRec *>(crec[wv][j]);
+            const double2 uv = uvp[q0 + (int64_t)j * gm];
+            const double w0 = sg_w ? wp[q0 + (int64_t)j * gm].x : C.w[0], w1 = sg_w ? wp[q0 + (int64_t)j * gm].y : C.w[1];
+            double r[2], E[2][NCX], B[2][3];
+            eval_obs_pre<MODEL, NCX>(d, C, Q, uv.x, uv.y, w0, w1, est, r, E, B);
+            double t0 = 0, t1 = 0;
 #pragma unroll
-                    for (int a = 0; a < NCX; ++a)
-                        if (a < ncol) { const double dc = dz[C.col[a]]; t0 += E[0][a] * dc; t1 += E[1][a] * dc; }
-                    tbuf[wv][j][lane] = double2{t0, t1};
-                    s[0] += B[0][0] * t0 + B[1][0] * t1;
-                    s[1] += B[0][1] * t0 + B[1][1] * t1;
-                    s[2] += B[0][2] * t0 + B[1][2] * t1;
-                } else {
-                    const double2 tj = tbuf[wv][j][lane];         // (E, the camera-side Jacobian, is dead code in this sweep)
-                    t0 = tj.x; t1 = tj.y;
-                    const double j0 = t0 + B[0][0] * dp[0] + B[0][1] * dp[1] + B[0][2] * dp[2];
-                    const double j1 = t1 + B[1][0] * dp[0] + B[1][1] * dp[1] + B[1][2] * dp[2];
-                    if (act) acc[0] += j0 * j0 + j1 * j1;
-                }
-            }
-            if (sweep == 0) {
-                const double *vi = Vinv + 6 * (int64_t)pt;
-                const double p0 = -(vi[0] * s[0] + vi[1] * s[1] + vi[2] * s[2]);
-                const double p1 = -(vi[1] * s[0] + vi[3] * s[1] + vi[4] * s[2]);
-                const double p2 = -(vi[2] * s[0] + vi[4] * s[1] + vi[5] * s[2]);
-                dp[0] = (est & 1u) ? p0 : 0.0; dp[1] = (est & 2u) ? p1 : 0.0; dp[2] = (est & 4u) ? p2 : 0.0;
-                if (act) { dz[zp] = dp[0]; dz[zp + 1] = dp[1]; dz[zp + 2] = dp[2]; }
+            for (int a = 0; a < NCX; ++a) { const double dc = dcs[wv][j][a]; t0 += E[0][a] * dc; t1 += E[1][a] * dc; }
+            tt2 += t0 * t0 + t1 * t1;
+            sB[0] += B[0][0] * t0 + B[1][0] * t1;
+            sB[1] += B[0][1] * t0 + B[1][1] * t1;
+            sB[2] += B[0][2] * t0 + B[1][2] * t1;
+            V0[0] += B[0][0] * B[0][0] + B[1][0] * B[1][0];
+            V0[1] += B[0][0] * B[0][1] + B[1][0] * B[1][1];
+            V0[2] += B[0][0] * B[0][2] + B[1][0] * B[1][2];
+            V0[3] += B[0][1] * B[0][1] + B[1][1] * B[1][1];
+            V0[4] += B[0][1] * B[0][2] + B[1][1] * B[1][2];
+            V0[5] += B[0][2] * B[0][2] + B[1][2] * B[1][2];
+        }
+        {
+            const double s0 = gp[3 * (int64_t)pt] + sB[0], s1 = gp[3 * (int64_t)pt + 1] + sB[1], s2 = gp[3 * (int64_t)pt + 2] + sB[2];
+            const double *vi = Vinv + 6 * (int64_t)pt;
+            const double p0 = -(vi[0] * s0 + vi[1] * s1 + vi[2] * s2);
+            const double p1 = -(vi[1] * s0 + vi[3] * s1 + vi[4] * s2);
+            const double p2 = -(vi[2] * s0 + vi[4] * s1 + vi[5] * s2);
+            const double d0 = (est & 1u) ? p0 : 0.0, d1 = (est & 2u) ? p1 : 0.0, d2 = (est & 4u) ? p2 : 0.0;
+            if (act) {
+                dz[zp] = d0; dz[zp + 1] = d1; dz[zp + 2] = d2;
+                acc[0] = tt2 + 2.0 * (d0 * sB[0] + d1 * sB[1] + d2 * sB[2])
+                       + d0 * (V0[0] * d0 + V0[1] * d1 + V0[2] * d2) + d1 * (V0[1] * d0 + V0[3] * d1 + V0[4] * d2)
+                       + d2 * (V0[2] * d0 + V0[4] * d1 + V0[5] * d2);
             }
         }
     }

@@ -270,3 +270,26 @@ def forwintersect(s0, ids='all', skipPrior=False):
     s.OP.val[:, do & (rays < 2)] = np.nan
     s.OP.val[:, ok] = np.linalg.solve(A[ok], b[ok][:, :, None])[:, :, 0].T
     return s
+
+
+def forwintersect_hip(s0, ids='all', skipPrior=False, device=0):
+    """forwintersect() with the per-point 3 x 3 systems built and solved on the GPU
+    (dbat_hip_forwintersect: one lane per image ray in the point-major batches of the
+    bundle core).  Same arguments and result as `forwintersect`."""
+    from . import _hip
+    from .dbatstruct import copy_struct
+    if not np.all(np.isfinite(s0.EO.val)):
+        raise ValueError('Bad or uninitialized EO data')
+    if not np.all(np.isfinite(s0.IO.val)):
+        raise ValueError('Bad or uninitialized IO data')
+    s = copy_struct(s0)
+    npnt = s0.OP.val.shape[1]
+    do = np.ones(npnt, bool) if isinstance(ids, str) and ids == 'all' else np.isin(s0.OP.id, ids)
+    if skipPrior:
+        do &= np.all(s0.bundle.est.OP, 0) & ~np.any(s0.prior.OP.use, 0)
+    h = _hip.Handle(s0, device=device)
+    try:
+        s.OP.val = h.forwintersect(h.serialize(), s0.OP.val, skip=~do)
+    finally:
+        h.close()
+    return s

@@ -268,6 +268,16 @@ int  dbat_hip_set_allreduce(dbat_hip_handle *h, dbat_hip_allreduce_fn fn, void *
  * library are already complete on every rank. */
 int  dbat_hip_owned_mask(const dbat_hip_handle *h, uint8_t *mask);
 
+/* ---- initial values ------------------------------------------------------ */
+
+/* s = forwintersect(s0, ids, skipPrior) (photogrammetry/forwintersect.m:27-46;
+ * pm_multilenscorr1.m:45-69, pm_multiforwintersect.m:41, pm_forwintersect3.m:55-82): object
+ * points by forward intersection of their lens-corrected image rays with the IO / EO of x
+ * (the OP part of x is not used).  OP [3*n_points] in: current values, out: intersected
+ * points; skip[p] != 0 (may be NULL) leaves point p as it is; a point with fewer than two
+ * rays becomes NaN.  Collective on a sharded handle. */
+int  dbat_hip_forwintersect(dbat_hip_handle *h, const double *x, const uint8_t *skip, double *OP);
+
 /* ---- measurement hooks -------------------------------------------------- */
 
 /* One benchmark step = one Levenberg-Marquardt iteration's device work at

@@ -159,3 +159,33 @@ def test_c_driver_plan_matches_python_binding(case, tmp_path):
     assert out['rank_ok'] == 1
     x0 = _hip.plan_serialize(s)
     assert abs(out['sum_x0'] - float(np.sum(x0))) <= 1e-12 * float(np.sum(np.abs(x0)))
+
+
+def test_plan_under_sanitizers(tmp_path):
+    """plan.hpp (index building, matching, ordering, batches, tiles, signature chunks -- all host
+    code) compiled with -fsanitize=address,undefined and run on dumped problems, one and three
+    shards: no report, and every tiled point is in exactly one signature chunk."""
+    import subprocess
+    from helpers import dump_problem
+    exe = str(tmp_path / 'asan_plan')
+    subprocess.run(['g++', '-std=c++17', '-g', '-O1', '-fsanitize=address,undefined', '-fno-sanitize-recover=all',
+                    '-fno-omit-frame-pointer', '-D__HIP_PLATFORM_AMD__', '-I/opt/rocm/include',
+                    '-I' + os.path.join(ROOT, 'include'), os.path.join(ROOT, 'tests', 'asan_plan.cpp'), '-o', exe],
+                   check=True, capture_output=True)
+    paths = []
+    for i, (name, variant) in enumerate([('tiny', 'plain'), ('tiny', 'priors'), ('tiny', 'groups4'), ('tiny', 'imagevar'),
+                                         ('small', 'selfcal')]):
+        paths.append(str(tmp_path / ('p%d.bin' % i)))
+        dump_problem(synth_struct(name, variant)[0], paths[-1])
+    paths.append(str(tmp_path / 'camcal.bin'))
+    dump_problem(camcal_struct(3), paths[-1])
+    s, _ = synth_struct('tiny', 'plain')                      # shared camera station
+    s.EO.struct.block[0:3, 2] = s.EO.struct.block[0:3, 1]
+    paths.append(str(tmp_path / 'shared.bin'))
+    dump_problem(s, paths[-1])
+    r = subprocess.run([exe] + paths, capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS='detect_leaks=1'))
+    assert r.returncode == 0 and 'ERROR' not in r.stderr and 'runtime error' not in r.stderr, r.stderr[-3000:]
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 4 * len(paths) and not any('rejected' in l for l in lines), r.stdout
+    first = [l for l in lines if 'p0.bin rank 0/1' in l][0]
+    assert 'chunks' in first and '(300 pts)' in first

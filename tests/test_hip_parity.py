@@ -300,17 +300,24 @@ def _shared_eo_struct(kind):
     """Images that share exterior orientation elements through EO.struct.block
     (buildserialindices.m:162-221 treats it exactly like IO.struct.block): 'station' -- images 1
     and 2 and images 5, 6, 7 taken from the same projection centres (rows X, Y, Z shared, the
-    angles their own); 'rig' -- images 3 and 4 share all six elements."""
+    angles their own); 'rig' -- images 3 and 4 share all six elements.  The observations of the
+    images that follow a leader are re-projected from the shared truth, so the network stays
+    consistent and the adjustment converges."""
+    from dbat_amd import synth
     s, truth = synth_struct('tiny', 'plain' if kind != 'selfcal' else 'selfcal')
     blk = s.EO.struct.block
-    if kind == 'rig':
-        blk[:, 4] = blk[:, 3]
-        s.EO.val[:6, 4] = s.EO.val[:6, 3]
-    else:
-        blk[0:3, 2] = blk[0:3, 1]
-        blk[0:3, 6] = blk[0:3, 5]; blk[0:3, 7] = blk[0:3, 5]
-        s.EO.val[0:3, 2] = s.EO.val[0:3, 1]
-        s.EO.val[0:3, 6] = s.EO.val[0:3, 5]; s.EO.val[0:3, 7] = s.EO.val[0:3, 5]
+    share = [(slice(0, 6), 4, 3)] if kind == 'rig' else [(slice(0, 3), 2, 1), (slice(0, 3), 6, 5), (slice(0, 3), 7, 5)]
+    EOt = truth['EO'].copy()
+    for rows, c, lead in share:
+        blk[rows, c] = blk[rows, lead]
+        EOt[rows, c] = EOt[rows, lead]
+        s.EO.val[rows, c] = s.EO.val[rows, lead]
+    px = float(np.ravel(s.IO.sensor.pxSize)[0])
+    rng = np.random.default_rng(11)
+    for _, c, _ in share:
+        m = s.IP.cam == c
+        uv, depth = synth.project(truth['IO'], EOt, truth['OP'], s.IP.cam[m], s.IP.pt[m], px)
+        s.IP.val[:, m] = uv + rng.normal(0, 0.5, uv.shape)
     return s
 
 
@@ -1065,3 +1072,34 @@ def test_c_driver_solve_matches_bundle(hip, damping, tmp_path):
     assert abs(out['rtr'] - float(E.final.weighted.r @ E.final.weighted.r)) < 1e-8 * out['rtr']
     if damping != 'lm':
         assert out['iters'] == iters
+
+
+@pytest.mark.parametrize('case', ['tiny', 'camcal', 'roma', 'C1'])
+def test_forward_intersection_hip(hip, case):
+    """dbat_hip_forwintersect (photogrammetry/forwintersect.m on the device) against the host
+    restatement dbat_amd.initial.forwintersect: synthetic scene, the camcal demo after its
+    resection (first error 30873.9 of camcal-dbatreport.txt:41 hangs on these points), the
+    roma script data (26 321 points, initial EO from the table) and a 10k-point scene; also
+    skipPrior, an id subset, and points with a single ray (NaN)."""
+    from dbat_amd import initial
+    if case == 'camcal':
+        from helpers import camcal_demo_struct
+        s = camcal_demo_struct(3)
+    elif case == 'roma':
+        s = roma_struct()
+    else:
+        s = synth_struct(case, 'priors' if case == 'tiny' else 'plain')[0]
+    if case == 'tiny':                                 # a one-ray point
+        p = s.IP.pt[5]
+        keep = ~((s.IP.pt == p) & (np.arange(len(s.IP.pt)) != 5))
+        s.IP.val, s.IP.std = s.IP.val[:, keep], s.IP.std[:, keep]
+        s.IP.cam, s.IP.pt = s.IP.cam[keep], s.IP.pt[keep]
+    s.OP.val = s.OP.val.copy()
+    for kw in (dict(), dict(skipPrior=True), dict(ids=s.OP.id[::3])):
+        a = initial.forwintersect(s, **kw)
+        b = initial.forwintersect_hip(s, **kw)
+        assert np.array_equal(np.isnan(a.OP.val), np.isnan(b.OP.val))
+        m = ~np.isnan(a.OP.val)
+        assert np.abs(a.OP.val[m] - b.OP.val[m]).max() <= 1e-9 * max(1.0, np.abs(a.OP.val[m]).max())
+    if case == 'tiny':
+        assert np.isnan(initial.forwintersect_hip(s).OP.val[:, p]).all()
