@@ -88,6 +88,13 @@ __global__ void k_cam_prep(DevProblem d, const double *__restrict__ z, CamRec *_
     for (int k = 0; k < MAXCOL; ++k) r.col[k] = d.cam_col[(int64_t)c * MAXCOL + k];
     for (int k = 0; k < MAXIO; ++k) r.iorow[k] = d.cam_iorow[(int64_t)c * MAXIO + k];
     r.eo_est = d.cam_eo_est[c];
+    {   // bit 8: the camera's estimated IO rows are cc, px, py, K1-K3, P1, P2 in this order (the usual
+        // self-calibration): the kernels then pick the IO columns without a select chain
+        static const int std8[8] = {0, 1, 2, 5, 6, 7, 8, 9};
+        bool is8 = r.ncol == 14 && d.nK == 3 && d.nP == 2;
+        for (int k = 0; k < 8 && is8; ++k) is8 = r.iorow[k] == std8[k];
+        if (is8) r.eo_est |= 0x100u;
+    }
     cams[c] = r;
 }
 
@@ -216,6 +223,31 @@ __device__ __forceinline__ bool inv3_sym(const double a[6], double inv[6]) {
     return det > 0 && c00 >= 0 && (a[0] > 0);
 }
 
+// E(:, 6+j) = w .* Cf(:, iorow[j]): the estimated IO rows of the camera as camera-side columns
+template <int NCX>
+__device__ __forceinline__ void io_columns(const CamRec &C, const double (*Cf)[MAXIO], double w0, double w1,
+                                           double (*E)[NCX]) {
+    if (NCX >= 14 && (C.eo_est & 0x100u)) {          // cc px py K1 K2 K3 P1 P2
+        constexpr int std8[8] = {0, 1, 2, 5, 6, 7, 8, 9};
+#pragma unroll
+        for (int j = 0; j < NCX - 6; ++j) {
+            E[0][6 + j] = j < 8 ? Cf[0][std8[j < 8 ? j : 0]] * w0 : 0.0;
+            E[1][6 + j] = j < 8 ? Cf[1][std8[j < 8 ? j : 0]] * w1 : 0.0;
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < NCX - 6; ++j) {
+        double c0 = 0, c1 = 0;
+        if (6 + j < C.ncol) {
+            const int row = C.iorow[j];
+#pragma unroll
+            for (int rr = 0; rr < MAXIO; ++rr) if (rr == row) { c0 = Cf[0][rr]; c1 = Cf[1][rr]; }
+        }
+        E[0][6 + j] = c0 * w0; E[1][6 + j] = c1 * w1;
+    }
+}
+
 // Evaluate one observation, weight it, mask fixed parameters and gather the
 // camera-side columns E = [A | C(:,estimated IO rows)].  NCX = 6 (fixed IO) or
 // the capacity of E (6 + up to NCX-6 estimated IO rows).
@@ -241,18 +273,7 @@ __device__ __forceinline__ void eval_obs_cols_n(const DevProblem &d, const CamRe
         const double m = ((C.eo_est >> k) & 1u) ? 1.0 : 0.0;
         E[0][k] = A[0][k] * w0 * m; E[1][k] = A[1][k] * w1 * m;
     }
-    if constexpr (WITH_IO) {
-#pragma unroll
-        for (int j = 0; j < NCX - 6; ++j) {
-            double c0 = 0, c1 = 0;
-            if (6 + j < C.ncol) {
-                const int row = C.iorow[j];
-#pragma unroll
-                for (int rr = 0; rr < MAXIO; ++rr) if (rr == row) { c0 = Cf[0][rr]; c1 = Cf[1][rr]; }
-            }
-            E[0][6 + j] = c0 * w0; E[1][6 + j] = c1 * w1;
-        }
-    }
+    if constexpr (WITH_IO) io_columns<NCX>(C, Cf, w0, w1, E);
 }
 
 // Variant with the operands already in registers (prefetched one batch ahead by
@@ -277,18 +298,7 @@ __device__ __forceinline__ void eval_obs_pre(const DevProblem &d, const CamRec &
         const double m = ((C.eo_est >> k) & 1u) ? 1.0 : 0.0;
         E[0][k] = A[0][k] * w0 * m; E[1][k] = A[1][k] * w1 * m;
     }
-    if constexpr (WITH_IO) {
-#pragma unroll
-        for (int j = 0; j < NCX - 6; ++j) {
-            double c0 = 0, c1 = 0;
-            if (6 + j < C.ncol) {
-                const int row = C.iorow[j];
-#pragma unroll
-                for (int rr = 0; rr < MAXIO; ++rr) if (rr == row) { c0 = Cf[0][rr]; c1 = Cf[1][rr]; }
-            }
-            E[0][6 + j] = c0 * w0; E[1][6 + j] = c1 * w1;
-        }
-    }
+    if constexpr (WITH_IO) io_columns<NCX>(C, Cf, w0, w1, E);
 }
 
 // Sum of x over the 64 lanes of the wave (result valid in every lane): inclusive row sums by

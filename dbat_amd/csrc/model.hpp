@@ -243,7 +243,15 @@ DBAT_HD void obs_eval(const CamRec &cam, int nK, int nP, const double Q[3], doub
         C[0][3] = im.dB[0][0];  C[0][4] = im.dB[0][1];
         C[1][3] = im.dB[1][0];  C[1][4] = im.dB[1][1];
         // rows 5.. : K1..KnK then P1..PnP.  nK is a run-time value: place the P rows with
-        // compile-time indices and selects (a dynamic index would push C into scratch memory)
+        // compile-time indices and selects (a dynamic index would push C into scratch memory).
+        // The usual layout (K1-K3, P1-P2: wave-uniform test) needs no selects at all.
+        if (nK == 3 && nP == 2) {
+            C[0][5] = im.dK[0][0]; C[1][5] = im.dK[1][0]; C[0][6] = im.dK[0][1]; C[1][6] = im.dK[1][1];
+            C[0][7] = im.dK[0][2]; C[1][7] = im.dK[1][2];
+            C[0][8] = im.dP[0][0]; C[1][8] = im.dP[1][0]; C[0][9] = im.dP[0][1]; C[1][9] = im.dP[1][1];
+#pragma unroll
+            for (int rr = 10; rr < MAXIO; ++rr) { C[0][rr] = 0.0; C[1][rr] = 0.0; }
+        } else
 #pragma unroll
         for (int rr = 5; rr < MAXIO; ++rr) {
             double c0 = 0.0, c1 = 0.0;

@@ -305,14 +305,12 @@ __global__ __launch_bounds__(64 * sig_waves(RB, (NCX > 6))) void k_build_sig(Dev
                 const double r00 = gR[0], r10 = gR[1], r20 = gR[2], r11 = gR[3], r21 = gR[4], r22 = gR[5];
                 if constexpr (IO) {                  // IO columns of this camera -> the chunk's IO rows (LDS atomics)
                     const int ncol = min(C.ncol, NCX);
+                    double Eio[2][NCX];
+                    io_columns<NCX>(C, Cf, w0, w1, Eio);
 #pragma unroll
                     for (int q = 0; q < NCX - 6; ++q)
                         if (6 + q < ncol) {
-                            const int row = C.iorow[q];
-                            double c0 = 0, c1 = 0;
-#pragma unroll
-                            for (int rr2 = 0; rr2 < MAXIO; ++rr2) if (rr2 == row) { c0 = Cf[0][rr2]; c1 = Cf[1][rr2]; }
-                            const double e0 = c0 * w0, e1 = c1 * w1;
+                            const double e0 = Eio[0][6 + q], e1 = Eio[1][6 + q];
                             const double wa0 = e0 * B[0][0] + e1 * B[1][0];
                             const double wa1 = e0 * B[0][1] + e1 * B[1][1];
                             const double wa2 = e0 * B[0][2] + e1 * B[1][2];
