@@ -146,6 +146,7 @@ struct Core {
     int scale_lin = 0;
     bool have_lin = false;
     bool s_valid = false;      // S holds an unfactorised reduced system
+    bool s_dense_dirty = true; // S may hold non-zeros outside its envelope (fresh allocation, dense inverse)
     // counters
     int n_res_evals = 0, n_lin = 0, n_solves = 0;
 
@@ -425,7 +426,15 @@ struct Core {
     // ---- K1: linearise at zz with damping lambda; builds the reduced system.
     void build_enqueue(const double *zz, double lambda, int scale) {
         prep_cams(zz);
-        HIPCHK(hipMemsetAsync(red.p, 0, red_count * sizeof(double), stream));
+        // only the envelope of S is ever written or read: zero that (and the vectors behind S); the whole
+        // array once, and again after something filled it densely (the inverse of the posterior covariance)
+        if (s_dense_dirty || getenv("DBAT_HIP_DENSE_ALLREDUCE")) {
+            HIPCHK(hipMemsetAsync(red.p, 0, red_count * sizeof(double), stream));
+            s_dense_dirty = false;
+        } else {
+            LAUNCHK(k_envelope_op, dim3((unsigned)P.NS), dim3(256), 0, stream, S, ldS, (int)P.NS, env_tail0, col_bend.p, (const double *)nullptr);
+            HIPCHK(hipMemsetAsync(g_red, 0, (size_t)(3 * P.NS + 8) * sizeof(double), stream));
+        }
         {
             const double big = 1e300;
             unsigned long long init[4];
@@ -443,7 +452,10 @@ struct Core {
 #define L_CAMN(M, NCXV) LAUNCHK((k_cam_normal<M, NCXV>), dim3((unsigned)n_cm_chunks), dim3(256), 0, stream, d, zz, cams.p, cm_pt.p, cm_uv.p, P.uniform_w ? (const double *)nullptr : cm_w.p, cm_chunk_cam.p, cm_chunk_start.p, S, g_c, g_red, diagU)
             if (use_tile2 && tile_ncx <= 14 && n_cm_chunks > 0) {
                 // camera side of the tiled observations: J_c'J_c, J_c'r, squared column norms
-                if (tile_ncx == 6) { DISPATCH_MODEL(L_CAMN, 6) } else { DISPATCH_MODEL(L_CAMN, 14) }
+#define L_CAMN6(M, dummy) LAUNCHK((k_cam_normal6<M>), dim3((unsigned)n_cm_chunks), dim3(256), 0, stream, d, zz, cams.p, cm_pt.p, cm_uv.p, P.uniform_w ? (const double *)nullptr : cm_w.p, cm_chunk_cam.p, cm_chunk_start.p, S, g_c, g_red, diagU)
+                if (tile_ncx == 6 && !getenv("DBAT_HIP_CAMN_MFMA")) { DISPATCH_MODEL(L_CAMN6, 0) }
+                else if (tile_ncx == 6) { DISPATCH_MODEL(L_CAMN, 6) } else { DISPATCH_MODEL(L_CAMN, 14) }
+#undef L_CAMN6
             }
 #undef L_CAMN
             mark(0);                                 // events around the tile kernel alone (bench roofline)
@@ -528,8 +540,8 @@ struct Core {
     }
     void finish_enqueue(const double *zz, double lambda, int scale) {
         LAUNCHK(k_finish, dim3((unsigned)cdiv(P.NS, 256)), dim3(256), 0, stream, d, zz, lambda, scale, S, g_c, g_red, diagU, jn2c.p, dscale.p);
-        if (scale)
-            LAUNCHK(k_scale_S, dim3((unsigned)cdiv(P.NS, 256), (unsigned)std::min<int64_t>(P.NS, 32768)), dim3(256), 0, stream, P.NS, ldS, S, dscale.p);
+        if (scale)      // D S D on the envelope
+            LAUNCHK(k_envelope_op, dim3((unsigned)P.NS), dim3(256), 0, stream, S, ldS, (int)P.NS, env_tail0, col_bend.p, (const double *)dscale.p);
     }
 
     // ---- K6: Cholesky of the reduced system; returns 0 or the failing pivot
@@ -627,6 +639,7 @@ struct Core {
         HIPCHK(hipMemcpyAsync(&hinfo, info.p, sizeof(hinfo), hipMemcpyDeviceToHost, stream));
         sync();
         if (hinfo != 0) throw DeviceError{"posterior covariance: the reduced normal matrix is not positive definite"};
+        s_dense_dirty = true;                         // inv(S) is dense
         if (rocsolver_dpotri(blas, rocblas_fill_lower, (rocblas_int)P.NS, S, (rocblas_int)ldS, info.p) != rocblas_status_success)
             throw DeviceError{"rocsolver_dpotri failed"};
         have_lin = false;

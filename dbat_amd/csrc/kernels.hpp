@@ -1171,6 +1171,68 @@ __global__ __launch_bounds__(256) void k_cam_normal(DevProblem d, const double *
     }
 }
 
+// Fixed interior orientation: the Gram matrix of [E | r] is 7 x 7 -- 27 useful sums.  On the matrix
+// cores that is one 16 x 16 x 4 product per two observation rows with a fifth of its outputs
+// used (2 048 cycles per 64 observations, more than their evaluation).  Here every lane keeps the 27
+// sums of ITS observations (a chunk has up to eight per lane) in registers -- 54 FMAs per
+// observation -- and the workgroup adds them up once per chunk (DPP wave sums, four partials in LDS).
+template <int MODEL>
+__global__ __launch_bounds__(256) void k_cam_normal6(DevProblem d, const double *__restrict__ z,
+                                                     const CamRec *__restrict__ cams,
+                                                     const int32_t *__restrict__ cm_pt, const double *__restrict__ cm_uv,
+                                                     const double *__restrict__ cm_w,
+                                                     const int32_t *__restrict__ chunk_cam,
+                                                     const int64_t *__restrict__ chunk_start, double *__restrict__ S,
+                                                     double *__restrict__ g_c, double *__restrict__ g_red,
+                                                     double *__restrict__ diagU) {
+    __shared__ double Gs[4 * 27];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int cam = chunk_cam[blockIdx.x];
+    const int64_t q0 = chunk_start[blockIdx.x], q1 = chunk_start[blockIdx.x + 1];
+    const CamRec &C = cams[cam];
+    double G[27];                                    // 21: E'E lower triangle by rows (i >= j), then 6: E'r
+#pragma unroll
+    for (int i = 0; i < 27; ++i) G[i] = 0.0;
+    for (int64_t q = q0 + t; q < q1; q += 256) {
+        const int pt = cm_pt[q];
+        const int64_t zp = d.NS + 3 * (int64_t)pt;
+        const double Q[3] = {z[zp], z[zp + 1], z[zp + 2]};
+        const double w0 = cm_w ? cm_w[2 * q] : C.w[0], w1 = cm_w ? cm_w[2 * q + 1] : C.w[1];
+        double r[2], E[2][6], B[2][3];
+        eval_obs_pre<MODEL, 6>(d, C, Q, cm_uv[2 * q], cm_uv[2 * q + 1], w0, w1, 7u, r, E, B);
+        int n = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j, ++n) G[n] += E[0][i] * E[0][j] + E[1][i] * E[1][j];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) G[21 + i] += E[0][i] * r[0] + E[1][i] * r[1];
+    }
+#pragma unroll
+    for (int i = 0; i < 27; ++i) {
+        const double v = wave_sum_f64(G[i]);
+        if (lane == 0) Gs[w * 27 + i] = v;
+    }
+    __syncthreads();
+    if (t < 27) {
+        const double g = (Gs[t] + Gs[27 + t]) + (Gs[54 + t] + Gs[81 + t]);
+        if (g != 0.0) {
+            if (t < 21) {
+                int i = 0;
+                while ((i + 1) * (i + 2) / 2 <= t) ++i;
+                const int j = t - i * (i + 1) / 2;
+                const int64_t ri = C.col[i], rj = C.col[j];
+                if (i == j) { atomic_add_f64(S + ri * d.ldS + ri, g); atomic_add_f64(diagU + ri, g); }
+                else atomic_add_f64(S + (ri >= rj ? rj * d.ldS + ri : ri * d.ldS + rj), g);
+            } else {
+                const int64_t ri = C.col[t - 21];
+                atomic_add_f64(g_c + ri, g);
+                atomic_add_f64(g_red + ri, g);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- K1t2 --
 // Wave-specialised tile kernel for the fixed-IO path: 512 threads.  Waves 0-3
 // ("producers") evaluate the observations of the tile's batches exactly as
@@ -2160,6 +2222,26 @@ __global__ __launch_bounds__(256) void k_pack_envelope(double *__restrict__ S, i
     for (int i = threadIdx.x; i < ntot; i += 256) {
         const int r = i < nband ? c + i : t0 + (i - nband);
         if (to_packed) pk[i] = col[r]; else col[r] = pk[i];
+    }
+}
+
+// Zero (scale != 0: scale by d_i d_j) the envelope of the lower triangle of S only: column c
+// owns the rows [c, col_bend[c]) of the co-visibility band and the dense tail rows
+// [max(tail0, col_bend[c]), NS) -- nothing outside it is ever written by the build kernels or read
+// by the factorisation, and at C4 the dense 30 032^2 array is 7.2 GB.
+__global__ __launch_bounds__(256) void k_envelope_op(double *__restrict__ S, int64_t ldS, int NS, int tail0,
+                                                     const int *__restrict__ col_bend,
+                                                     const double *__restrict__ ds /* null: zero */) {
+    const int c = blockIdx.x;
+    const int be = col_bend[c];
+    const int nband = be - c;
+    const int t0 = max(tail0, be);
+    const int ntot = nband + (NS - t0);
+    double *col = S + (int64_t)c * ldS;
+    const double dc = ds ? ds[c] : 0.0;
+    for (int i = threadIdx.x; i < ntot; i += 256) {
+        const int r = i < nband ? c + i : t0 + (i - nband);
+        col[r] = ds ? col[r] * dc * ds[r] : 0.0;
     }
 }
 
