@@ -479,7 +479,8 @@ def test_library_rccl_communicator_one_rank(hip, damping):
     if damping != 'lm':       # LM: the count of trailing trial steps is rounding noise (check_history)
         assert i0 == i1 and relerr(r1, r0) < 1e-10
     assert relerr(x1, x0_) < 1e-9
-    assert relerr(u1, u0) < 1e-9 and relerr(w1, w0) < 1e-9
+    tol_r = 1e-9 if damping != 'lm' else 1e-6          # residuals of two end points that differ at the 1e-9 level
+    assert relerr(u1, u0) < tol_r and relerr(w1, w0) < tol_r
 
 
 def test_two_ranks_rccl_match_single(hip):
