@@ -163,24 +163,30 @@ __global__ __launch_bounds__(64 * sig_waves(RB, (NCX > 6))) void k_build_sig(Dev
         double pR[6] = {0, 0, 0, 0, 0, 0}, pY[3] = {0, 0, 0}, pQ[3] = {0, 0, 0};     // of this lane's point, for pass 2
         unsigned pEst = 0;
         {
-            const bool act = lane < npts;
-            const int pt = pt0 + (act ? lane : 0);
+            // a chunk of at most 32 points takes two lanes per point: lane l and lane l + 32 share the
+            // cameras (even / odd slots) and add their sums up afterwards
+            const bool split = npts <= 32;
+            const int pi = split ? (lane & 31) : lane;
+            const int jh = split ? (lane >> 5) : 0, jstep = split ? 2 : 1;
+            const bool act = pi < npts;
+            const int pt = pt0 + (act ? pi : 0);
             const int64_t zp = d.NS + 3 * (int64_t)pt;
             double Q[3] = {z[zp], z[zp + 1], z[zp + 2]};
             const unsigned est = (d.z_est[zp] ? 1u : 0u) | (d.z_est[zp + 1] ? 2u : 0u) | (d.z_est[zp + 2] ? 4u : 0u);
             double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
-            const int64_t q0 = uv0 + gi0 + (act ? lane : 0);
+            const int64_t q0 = uv0 + gi0 + (act ? pi : 0);
             const double2 *uvp = reinterpret_cast<const double2 *>(sg_uv), *wp = reinterpret_cast<const double2 *>(sg_w);
-            double2 uv_n = uvp[q0], w_n = sg_w ? wp[q0] : double2{0, 0};
-            for (int j = 0; j < ((d.ablate & 4) ? 1 : k); ++j) {
+            double2 uv_n = double2{0, 0}, w_n = double2{0, 0};
+            if (jh < k) { uv_n = uvp[q0 + (int64_t)jh * gm]; if (sg_w) w_n = wp[q0 + (int64_t)jh * gm]; }
+            for (int j = jh; j < ((d.ablate & 4) ? 1 : k); j += jstep) {
                 const int lc = sy.lc[wave][j];
                 const CamRec &C = *reinterpret_cast<const CamRec *>(camw + lc * CAMW);
                 const int64_t q = q0 + (int64_t)j * gm;
                 const double uu = uv_n.x, vv = uv_n.y;
                 const double w0 = sg_w ? w_n.x : C.w[0], w1 = sg_w ? w_n.y : C.w[1];
-                if (j + 1 < k) {                      // next slot's image coordinates, one slot ahead
-                    uv_n = uvp[q + gm];
-                    if (sg_w) w_n = wp[q + gm];
+                if (j + jstep < k) {                  // next slot's image coordinates, one slot ahead
+                    uv_n = uvp[q + (int64_t)jstep * gm];
+                    if (sg_w) w_n = wp[q + (int64_t)jstep * gm];
                 }
                 double r[2], A[2][6], B[2][3], Cf[2][MAXIO];
                 obs_eval<MODEL, true, false>(C, d.nK, d.nP, Q, uu, vv, r, A, B, Cf);    // A is dead code here
@@ -201,6 +207,13 @@ __global__ __launch_bounds__(64 * sig_waves(RB, (NCX > 6))) void k_build_sig(Dev
                 g[1] += B[0][1] * r[0] + B[1][1] * r[1];
                 g[2] += B[0][2] * r[0] + B[1][2] * r[1];
             }
+            if (split) {                              // the other half of the point's cameras (uniform branch)
+#pragma unroll
+                for (int c = 0; c < 6; ++c) V[c] += lane_get(V[c], lane ^ 32);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) g[c] += lane_get(g[c], lane ^ 32);
+            }
+            const bool writer = act && lane == pi;    // one lane per point writes to HBM
             if (act) {
                 double jn[3];
 #pragma unroll
@@ -208,7 +221,7 @@ __global__ __launch_bounds__(64 * sig_waves(RB, (NCX > 6))) void k_build_sig(Dev
                     const double pw = d.z_prw[zp + c];
                     if (pw > 0) { V[dix[c]] += pw; g[c] += pw * (Q[c] - d.z_prv[zp + c]); }
                     jn[c] = V[dix[c]];
-                    jn2p[3 * (int64_t)pt + c] = jn[c];
+                    if (writer) jn2p[3 * (int64_t)pt + c] = jn[c];
                     if ((est >> c) & 1u) V[dix[c]] += lambda; else V[dix[c]] = 1.0;
                 }
                 double inv[6];
@@ -235,10 +248,12 @@ __global__ __launch_bounds__(64 * sig_waves(RB, (NCX > 6))) void k_build_sig(Dev
                             pmin = fmin(pmin, v); pmax = fmax(pmax, v);
                         }
                 }
+                if (writer) {
 #pragma unroll
-                for (int c = 0; c < 6; ++c) Vinv[6 * (int64_t)pt + c] = inv[c];
+                    for (int c = 0; c < 6; ++c) Vinv[6 * (int64_t)pt + c] = inv[c];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) gp[3 * (int64_t)pt + c] = g[c];
+                    for (int c = 0; c < 3; ++c) gp[3 * (int64_t)pt + c] = g[c];
+                }
                 // V^-1 = R R', R lower triangular
                 const double r00 = sqrt(inv[0]), ir00 = fast_rcp(r00);
                 const double r10 = inv[1] * ir00, r20 = inv[2] * ir00;
