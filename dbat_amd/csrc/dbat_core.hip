@@ -98,7 +98,7 @@ struct Core {
     int sig_rb = 4;
     int tile_ncx = 6;
     int64_t ntiles = 0;
-    size_t lds_tile = 0, lds_tile2 = 0, lds_tile3 = 0;
+    size_t lds_tile2 = 0, lds_tile3 = 0;
     bool use_tile3 = false;
     int tile2_pc = TILE2_PC;
     bool use_tile2 = true;
@@ -267,12 +267,10 @@ struct Core {
         pivmm.alloc(4);
         lds_build = ((size_t)P.BT * P.ncolmax * 3 + (size_t)P.BT * 18) * sizeof(double);
         lds_back = (size_t)P.BT * 6 * sizeof(double);
-        lds_tile = ((size_t)2 * 3 * TILE_PC * TILE_LD + (size_t)P.BT * 9 + (size_t)36 * P.CMAX + 3 * TILE_LD +
-                    (P.with_io ? (size_t)P.CMAX * 6 * 16 + 256 : 0)) * sizeof(double);
         // wave-specialised tile kernel: 256-observation batches, 16-point chunks, 2 panels
         tile2_pc = TILE2_PC;
         lds_tile2 = ((size_t)TILE2_NBUF * 3 * tile2_pc * TILE_LD + (size_t)256 * 9 + (size_t)128 * 15 + TILE_LD) * sizeof(double);
-        use_tile2 = P.BT == 256 && P.ncolmax <= 14 && getenv("DBAT_HIP_TILE_V1") == nullptr;
+        use_tile2 = P.BT == 256 && P.ncolmax <= 14;      // (the plan does not tile anything else)
         partial.alloc((size_t)4 * std::max<int64_t>(std::max<int64_t>(std::max<int64_t>(nb + ntiles + ngiant + (int64_t)P.sg_chunk.size() / 8, n_cm_chunks_all), 2048), 1));
         set_lds_limits();
         HIPCHK(hipMemcpy(z.p, P.z0.data(), P.NZ * 8, hipMemcpyHostToDevice));
@@ -286,12 +284,6 @@ struct Core {
     // kernels that use more than 64 KB of dynamic LDS must opt in
     void set_lds_limits() {
 #define SET_LDS(K, BYTES) HIPCHK(hipFuncSetAttribute((const void *)(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)))
-        SET_LDS((k_build_tile<2, 6>), lds_tile); SET_LDS((k_build_tile<3, 6>), lds_tile);
-        SET_LDS((k_build_tile<4, 6>), lds_tile); SET_LDS((k_build_tile<5, 6>), lds_tile);
-        SET_LDS((k_build_tile<2, 14>), lds_tile); SET_LDS((k_build_tile<3, 14>), lds_tile);
-        SET_LDS((k_build_tile<4, 14>), lds_tile); SET_LDS((k_build_tile<5, 14>), lds_tile);
-        SET_LDS((k_build_tile<2, MAXCOL>), lds_tile); SET_LDS((k_build_tile<3, MAXCOL>), lds_tile);
-        SET_LDS((k_build_tile<4, MAXCOL>), lds_tile); SET_LDS((k_build_tile<5, MAXCOL>), lds_tile);
         if (use_tile2) {
             if (P.with_io) {
                 SET_LDS((k_build_tile2<2, 14, TILE2_PC, TILE2_NBUF>), lds_tile2); SET_LDS((k_build_tile2<3, 14, TILE2_PC, TILE2_NBUF>), lds_tile2);
@@ -447,7 +439,6 @@ struct Core {
         const int64_t nb_tiled = P.nb_tiled;
         if (ntiles > 0 && nb_tiled > 0) {
             npart = ntiles;
-#define L_TILE(M, NCXV) LAUNCHK((k_build_tile<M, NCXV>), dim3((unsigned)ntiles), dim3(P.BT), lds_tile, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, partial.p, pivmm.p)
 #define L_TILE2(M, NCXV) LAUNCHK((k_build_tile2<M, NCXV, TILE2_PC, TILE2_NBUF>), dim3((unsigned)ntiles), dim3(512), lds_tile2, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, partial.p, pivmm.p)
 #define L_CAMN(M, NCXV) LAUNCHK((k_cam_normal<M, NCXV>), dim3((unsigned)n_cm_chunks), dim3(256), 0, stream, d, zz, cams.p, cm_pt.p, cm_uv.p, P.uniform_w ? (const double *)nullptr : cm_w.p, cm_chunk_cam.p, cm_chunk_start.p, S, g_c, g_red, diagU)
             if (use_tile2 && tile_ncx <= 14 && n_cm_chunks > 0) {
@@ -469,11 +460,8 @@ struct Core {
             else if (use_tile3 && tile_ncx == 6) { DISPATCH_MODEL(L_TILE3, 0) }
             else if (use_tile2 && tile_ncx == 6) { DISPATCH_MODEL(L_TILE2, 6) }
             else if (use_tile2 && tile_ncx == 14) { DISPATCH_MODEL(L_TILE2, 14) }
-            else if (tile_ncx == 6) { DISPATCH_MODEL(L_TILE, 6) }
-            else if (tile_ncx == 14) { DISPATCH_MODEL(L_TILE, 14) }
-            else { DISPATCH_MODEL(L_TILE, MAXCOL) }
+            else throw DeviceError{"internal: tiles without a tile kernel"};
             mark(1);
-#undef L_TILE
 #undef L_TILE2
         }
         const bool no_tiles = !(ntiles > 0 && nb_tiled > 0);
@@ -1448,7 +1436,7 @@ int dbat_hip_build_kernel_name(const dbat_hip_handle *h, char *buf, int32_t buf_
         if (c.use_sig) nm = "k_build_sig";
         else if (c.use_tile3 && c.tile_ncx == 6) nm = "k_build_tile3";
         else if (c.use_tile2 && c.tile_ncx <= 14) nm = "k_build_tile2";
-        else nm = "k_build_tile";
+        else nm = "k_build";
     }
     snprintf(buf, (size_t)buf_len, "%s", nm);
     return DBAT_HIP_OK;

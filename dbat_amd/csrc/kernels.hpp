@@ -723,365 +723,15 @@ __global__ __launch_bounds__(256) void k_backsub_giant(DevProblem d, const doubl
 }
 
 // ---------------------------------------------------------------- K1t ---
-// Tiled variant of k_build for the fixed-IO path: one workgroup per TILE (a
-// run of batches whose observations touch at most CMAX <= 21 cameras, i.e. at
-// most 126 rows of the reduced system).  The tile's share of the Schur
-// complement  sum_p (W_p V_p^-1) W_p'  is a dense 128 x 128 x 3*npoints
-// contraction:  per chunk of 8 points the 6x3 blocks Y = W V^-1 and W of every
-// observation are scattered into zero-filled LDS panels Yt, Wt [24][128] and the
-// lower-triangular 16x16 tiles are accumulated on the f64 matrix cores
-// (v_mfma_f64_16x16x4_f64) in REGISTERS for the whole tile, then flushed to
-// HBM once -- no atomics on the k^2 pair terms.  E'E (camera diagonal blocks)
-// and the gradient pieces go through a few LDS atomics per observation.
+// MFMA tile kernels (k_build_tile2 / k_build_tile3 below, k_build_sig in sig.hpp): one workgroup
+// per TILE -- a run of batches whose observations touch at most CMAX <= 21 cameras, i.e. at most
+// 126 rows of the reduced system -- accumulates the tile's share of the Schur complement on the
+// f64 matrix cores and flushes it to HBM once.
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
-#ifndef DBAT_TILE_PC
-#define DBAT_TILE_PC 8
-#endif
-constexpr int TILE_PC = DBAT_TILE_PC;           // object points per MFMA chunk (K = 3*TILE_PC)
 // Row stride of the LDS operand panels: 144 doubles = 288 dwords == 32 (mod 64
 // banks), so the four k-rows one ds_read_b64 wave-instruction touches fall on
 // disjoint bank halves (128 would make lanes l and l+16 collide).
 constexpr int TILE_LD = 144;
-
-// Tile -> wave assignment of the 8x8 lower-triangular grid of 16x16 tiles:
-// wave w owns row tiles w and 7-w (w+1 and 8-w tiles: nine each), so that it
-// needs only two Y fragments and at most eight W fragments per k-step.
-template <int WV>
-__device__ __forceinline__ void tile_mfma_steps(const double *Yt, const double *Wt, int lane, int ksteps,
-                                                mfma_d4 (&acc)[9]) {
-    constexpr int LD = TILE_LD, RA = WV, RB = 7 - WV;      // RA <= RB
-    if (ksteps <= 0) return;
-    // software pipeline: the fragments of k-step kk+1 are fetched while the
-    // matrix pipe works on k-step kk
-    const double *yr = Yt + (lane >> 4) * LD + (lane & 15);
-    const double *wr = Wt + (lane >> 4) * LD + (lane & 15);
-    double ya = yr[16 * RA], yb = yr[16 * RB];
-    double wa[RB + 1];
-#pragma unroll
-    for (int c = 0; c <= RB; ++c) wa[c] = wr[16 * c];
-    for (int kk = 0; kk < ksteps; ++kk) {
-        const int kn = kk + 1 < ksteps ? kk + 1 : kk;      // last step re-reads itself (harmless)
-        const double *yn = yr + 4 * kn * LD;
-        const double *wn = wr + 4 * kn * LD;
-        const double nya = yn[16 * RA], nyb = yn[16 * RB];
-        double nwa[RB + 1];
-#pragma unroll
-        for (int c = 0; c <= RB; ++c) nwa[c] = wn[16 * c];
-#pragma unroll
-        for (int c = 0; c <= RA; ++c)
-            acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ya, wa[c], acc[c], 0, 0, 0);
-#pragma unroll
-        for (int c = 0; c <= RB; ++c)
-            acc[RA + 1 + c] = __builtin_amdgcn_mfma_f64_16x16x4f64(yb, wa[c], acc[RA + 1 + c], 0, 0, 0);
-        ya = nya; yb = nyb;
-#pragma unroll
-        for (int c = 0; c <= RB; ++c) wa[c] = nwa[c];
-    }
-}
-
-// NCX = 6: fixed IO.  NCX > 6: self-calibration -- the estimated IO columns of
-// the tile's cameras are extra rows (after the 6*ncam camera rows) of the same
-// tile-local system, so the camera-IO border and the IO-IO block come out of the
-// same contraction.  J_c'J_c (per camera 6x6, camera x IO, IO x IO) and the
-// gradient pieces are accumulated with LDS atomics.
-template <int MODEL, int NCX>
-__global__ __launch_bounds__(256) void k_build_tile(DevProblem d, const double *__restrict__ z,
-                                                    const CamRec *__restrict__ cams, double lambda, int scale,
-                                                    double *__restrict__ S, double *__restrict__ g_c,
-                                                    double *__restrict__ g_red, double *__restrict__ diagU,
-                                                    double *__restrict__ Vinv, double *__restrict__ gp,
-                                                    double *__restrict__ jn2p,
-                                                    double *__restrict__ partial,
-                                                    unsigned long long *__restrict__ pivmm) {
-    constexpr int PC = TILE_PC, KC = 3 * PC, LD = TILE_LD;
-    constexpr bool IO = NCX > 6;
-    constexpr int IOT = 16;                          // Plan::IOT
-    extern __shared__ double smem[];
-    const int BT = blockDim.x;
-    const int CM = d.CMAX;
-    double *Yt = smem;                               // [KC][LD]  Yt[k][row] = (W V^-1)(row, k)
-    double *Wt = Yt + KC * LD;                       // [KC][LD]
-    double *red = Wt + KC * LD;                      // [BT][9]   B'B | B'r, then V^-1 | g_p at the leader's row
-    double *Ud = red + (size_t)BT * 9;               // [CM][36]  E'E of every camera, entry [a*6+b], b>=a
-    double *vt = Ud + (size_t)CM * 36;               // [3][LD]   g_c | g_red | diagU by local row
-    double *Uci = vt + 3 * LD;                       // [CM][6][IOT] camera x IO part of J_c'J_c   (IO only)
-    double *Uii = Uci + (IO ? (size_t)CM * 6 * IOT : 0);   // [IOT][IOT] IO x IO part, lower       (IO only)
-    __shared__ double sh[8];
-    __shared__ int npts_sh;
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);        // scalar: keeps the tile choices out of EXEC
-    const int tile = d.tile_order[blockIdx.x];
-    const int b0 = d.tile_batch[tile], b1 = d.tile_batch[tile + 1];
-    const int c0 = d.tile_cam_start[tile];
-    const int ncam = d.tile_cam_start[tile + 1] - c0;
-    const int io0 = IO ? d.tile_io_start[tile] : 0;
-    const int nio = IO ? d.tile_io_start[tile + 1] - io0 : 0;
-    const int iobase = 6 * ncam;                     // first IO row of the tile-local system
-    const int nrows = iobase + nio;
-    // this wave's nine 16x16 tiles of the lower triangle: row tile `wave` with
-    // column tiles 0..wave, then row tile 7-wave with column tiles 0..7-wave
-    int yoff[9], woff[9];
-    bool ton[9];
-#pragma unroll
-    for (int s = 0; s < 9; ++s) {
-        const int rt = s <= wave ? wave : 7 - wave;
-        const int ct = s <= wave ? s : s - wave - 1;
-        yoff[s] = 16 * rt; woff[s] = 16 * ct; ton[s] = 16 * rt < nrows;
-    }
-    for (int i = t; i < 2 * KC * LD; i += BT) Yt[i] = 0.0;
-    for (int i = t; i < CM * 36 + 3 * LD + (IO ? CM * 6 * IOT + IOT * IOT : 0); i += BT) Ud[i] = 0.0;
-    mfma_d4 acc[9];
-#pragma unroll
-    for (int s = 0; s < 9; ++s) acc[s] = mfma_d4{0, 0, 0, 0};
-    double pmin = 1e300, pmax = 0.0, rr = 0.0;
-    __syncthreads();
-    for (int b = b0; b < b1; ++b) {
-        const int64_t o0 = d.batch_start[b];
-        const int nobs = (int)(d.batch_start[b + 1] - o0);
-        const bool active = t < nobs;
-        const int64_t o = o0 + t;
-        double r[2] = {0, 0};
-        double E[2][NCX];
-        double B[2][3];
-        int pt = 0, seg_start = 0, seg_len = 0, lc = 0, pidx = 0, ncol = 6;
-        uint32_t ciop[4] = {0, 0, 0, 0};             // local IO rows of this camera's IO columns (1 byte each)
-        auto lrow = [&](int a) -> int {              // tile-local row of camera-side column a
-            return a < 6 ? 6 * lc + a : iobase + (int)((ciop[(a - 6) >> 2] >> (8 * ((a - 6) & 3))) & 255u);
-        };
-        if (t == 0) npts_sh = 0;
-        if (active) {                                // ---- P1: residual + Jacobian blocks
-            const int cam = d.o_cam[o];
-            pt = d.o_pt[o]; lc = d.o_lc[o]; pidx = d.o_pidx[o];
-            const uint32_t sg = d.o_seg[o];
-            seg_start = sg & 0xFFFF; seg_len = sg >> 16;
-            const CamRec &C = cams[cam];
-            if (IO) {
-                ncol = min(C.ncol, NCX);
-                const uint32_t *cp = (const uint32_t *)(d.tile_cam_io + (size_t)(c0 + lc) * 16);
-                ciop[0] = cp[0]; ciop[1] = cp[1]; ciop[2] = cp[2]; ciop[3] = cp[3];
-            }
-            if (d.ablate & 4) { for (int q = 0; q < NCX; ++q) { E[0][q] = 1e-3 * (q + lc); E[1][q] = 2e-3 * q; } for (int q = 0; q < 3; ++q) { B[0][q] = q + 1.0; B[1][q] = 0.5 * q; } }
-            else eval_obs_cols_n<MODEL, NCX>(d, C, z, o, pt, r, E, B);
-            rr += r[0] * r[0] + r[1] * r[1];
-            double *rd = red + (size_t)t * 9;
-            rd[0] = B[0][0] * B[0][0] + B[1][0] * B[1][0];
-            rd[1] = B[0][0] * B[0][1] + B[1][0] * B[1][1];
-            rd[2] = B[0][0] * B[0][2] + B[1][0] * B[1][2];
-            rd[3] = B[0][1] * B[0][1] + B[1][1] * B[1][1];
-            rd[4] = B[0][1] * B[0][2] + B[1][1] * B[1][2];
-            rd[5] = B[0][2] * B[0][2] + B[1][2] * B[1][2];
-            rd[6] = B[0][0] * r[0] + B[1][0] * r[1];
-            rd[7] = B[0][1] * r[0] + B[1][1] * r[1];
-            rd[8] = B[0][2] * r[0] + B[1][2] * r[1];
-        }
-        __syncthreads();
-        if (active && t == seg_start) {              // ---- P2: per point V, damping, priors, V^-1
-            atomicMax(&npts_sh, pidx + 1);
-            double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
-            for (int j = 0; j < seg_len; ++j) {
-                const double *rd = red + (size_t)(t + j) * 9;
-#pragma unroll
-                for (int k = 0; k < 6; ++k) V[k] += rd[k];
-                g[0] += rd[6]; g[1] += rd[7]; g[2] += rd[8];
-            }
-            const int64_t zp = d.NS + 3 * (int64_t)pt;
-            const int dix[3] = {0, 3, 5};
-            double jn[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const double pw = d.z_prw[zp + k];
-                if (pw > 0) { V[dix[k]] += pw; g[k] += pw * (z[zp + k] - d.z_prv[zp + k]); }
-                jn[k] = V[dix[k]];
-                jn2p[3 * (int64_t)pt + k] = jn[k];
-                if (d.z_est[zp + k]) V[dix[k]] += lambda; else V[dix[k]] = 1.0;
-            }
-            double inv[6];
-            inv3_sym(V, inv);
-            {
-                const double d0 = sqrt(V[0]), l10 = V[1] / d0, l20 = V[2] / d0;
-                const double d1 = sqrt(V[3] - l10 * l10), l21 = (V[4] - l20 * l10) / d1;
-                const double d2 = sqrt(V[5] - l20 * l20 - l21 * l21);
-                const double dd[3] = {d0, d1, d2};
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    if (d.z_est[zp + k]) {
-                        double v = scale ? dd[k] / sqrt(jn[k]) : dd[k];
-                        v = v == v ? v : 0.0;
-                        pmin = fmin(pmin, v); pmax = fmax(pmax, v);
-                    }
-            }
-            double *pi = red + (size_t)t * 9;         // the leader's own row: safe to overwrite
-#pragma unroll
-            for (int k = 0; k < 6; ++k) { pi[k] = inv[k]; Vinv[6 * (int64_t)pt + k] = inv[k]; }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { pi[6 + k] = g[k]; gp[3 * (int64_t)pt + k] = g[k]; }
-        }
-        __syncthreads();
-        double W[NCX][3];
-        double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
-        if (active) {                                // ---- P3: W = E'B, E'E, gradient pieces
-            const double *pi = red + (size_t)seg_start * 9;
-            v0 = pi[0]; v1 = pi[1]; v2 = pi[2]; v3 = pi[3]; v4 = pi[4]; v5 = pi[5];
-            const double g0 = pi[6], g1 = pi[7], g2 = pi[8];
-            double *ud = Ud + (size_t)lc * 36;
-#pragma unroll
-            for (int a = 0; a < NCX; ++a) {
-                const double w0 = E[0][a] * B[0][0] + E[1][a] * B[1][0];
-                const double w1 = E[0][a] * B[0][1] + E[1][a] * B[1][1];
-                const double w2 = E[0][a] * B[0][2] + E[1][a] * B[1][2];
-                W[a][0] = w0; W[a][1] = w1; W[a][2] = w2;
-                if (a >= ncol || (d.ablate & 2)) continue;
-                const double y0 = w0 * v0 + w1 * v1 + w2 * v2;
-                const double y1 = w0 * v1 + w1 * v3 + w2 * v4;
-                const double y2 = w0 * v2 + w1 * v4 + w2 * v5;
-                const double ga = E[0][a] * r[0] + E[1][a] * r[1];
-                const int ra = lrow(a);
-                atomic_add_f64(vt + ra, ga);
-                atomic_add_f64(vt + LD + ra, ga - (y0 * g0 + y1 * g1 + y2 * g2));
-                atomic_add_f64(vt + 2 * LD + ra, E[0][a] * E[0][a] + E[1][a] * E[1][a]);
-                if (a < 6) {
-#pragma unroll
-                    for (int b2 = a; b2 < 6; ++b2)
-                        atomic_add_f64(ud + a * 6 + b2, E[0][a] * E[0][b2] + E[1][a] * E[1][b2]);
-                    if constexpr (IO) {
-#pragma unroll
-                        for (int b2 = 6; b2 < NCX; ++b2)
-                            if (b2 < ncol)
-                                atomic_add_f64(Uci + ((size_t)lc * 6 + a) * IOT + (lrow(b2) - iobase),
-                                               E[0][a] * E[0][b2] + E[1][a] * E[1][b2]);
-                    }
-                } else if constexpr (IO) {
-                    const int ia = ra - iobase;
-#pragma unroll
-                    for (int b2 = 6; b2 < NCX; ++b2)
-                        if (b2 < ncol) {
-                            const int ib = lrow(b2) - iobase;
-                            if (ib >= ia)            // lower triangle: row ib, column ia
-                                atomic_add_f64(Uii + (size_t)ia * IOT + ib, E[0][a] * E[0][b2] + E[1][a] * E[1][b2]);
-                        }
-                }
-            }
-        }
-        const int npts = (d.ablate & 1) ? 0 : npts_sh;   // written before the barrier after P2
-        // ---- P4: chunks of PC points through the matrix cores
-        for (int p0 = 0; p0 < npts; p0 += PC) {
-            const bool mine = active && pidx >= p0 && pidx < p0 + PC && !(d.ablate & 16);
-            if (mine) {
-                const int kb = 3 * (pidx - p0);
-#pragma unroll
-                for (int a = 0; a < NCX; ++a) {
-                    if (a >= ncol) continue;
-                    const int row = lrow(a);
-                    const double w0 = W[a][0], w1 = W[a][1], w2 = W[a][2];
-                    const double y0 = w0 * v0 + w1 * v1 + w2 * v2;
-                    const double y1 = w0 * v1 + w1 * v3 + w2 * v4;
-                    const double y2 = w0 * v2 + w1 * v4 + w2 * v5;
-                    if (a < 6) {                     // a camera row belongs to one observation of the point
-                        Wt[(kb + 0) * LD + row] = w0; Wt[(kb + 1) * LD + row] = w1; Wt[(kb + 2) * LD + row] = w2;
-                        Yt[(kb + 0) * LD + row] = y0; Yt[(kb + 1) * LD + row] = y1; Yt[(kb + 2) * LD + row] = y2;
-                    } else {                         // an IO row is shared by the point's observations: sum
-                        atomic_add_f64(Wt + (kb + 0) * LD + row, w0); atomic_add_f64(Wt + (kb + 1) * LD + row, w1);
-                        atomic_add_f64(Wt + (kb + 2) * LD + row, w2);
-                        atomic_add_f64(Yt + (kb + 0) * LD + row, y0); atomic_add_f64(Yt + (kb + 1) * LD + row, y1);
-                        atomic_add_f64(Yt + (kb + 2) * LD + row, y2);
-                    }
-                }
-            }
-            __syncthreads();
-            const int ksteps = (d.ablate & 8) ? 0 : (3 * min(PC, npts - p0) + 3) >> 2;
-            if (ton[8]) {
-                // full tile (the wave's larger row tile is populated): all nine products
-                // unconditionally, operands fetched first so that the LDS latency
-                // overlaps the matrix pipe (rows past the tile's cameras are zero)
-                switch (wave) {
-                    case 0: tile_mfma_steps<0>(Yt, Wt, lane, ksteps, acc); break;
-                    case 1: tile_mfma_steps<1>(Yt, Wt, lane, ksteps, acc); break;
-                    case 2: tile_mfma_steps<2>(Yt, Wt, lane, ksteps, acc); break;
-                    default: tile_mfma_steps<3>(Yt, Wt, lane, ksteps, acc); break;
-                }
-            } else {
-                for (int kk = 0; kk < ksteps; ++kk) {
-                    const int krow = 4 * kk + (lane >> 4);
-                    const double *yr = Yt + krow * LD + (lane & 15);
-                    const double *wr = Wt + krow * LD + (lane & 15);
-#pragma unroll
-                    for (int s = 0; s < 9; ++s)
-                        if (ton[s])                  // wave-uniform (scalar branch)
-                            acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(yr[yoff[s]], wr[woff[s]], acc[s], 0, 0, 0);
-                }
-            }
-            __syncthreads();
-            if (mine) {                              // restore the zero fill
-                const int kb = 3 * (pidx - p0);
-#pragma unroll
-                for (int a = 0; a < NCX; ++a) {
-                    if (a >= ncol) continue;
-                    const int row = lrow(a);
-#pragma unroll
-                    for (int e = 0; e < 3; ++e) { Wt[(kb + e) * LD + row] = 0.0; Yt[(kb + e) * LD + row] = 0.0; }
-                }
-            }
-            __syncthreads();
-        }
-        __syncthreads();       // red / npts_sh are reused by the next batch
-    }
-    // ---- flush the tile to HBM:  S -= sum_p Y W'  (lower triangle), S += J_c'J_c
-    auto grow = [&](int lr) -> int64_t {             // tile-local row -> row of the reduced system
-        if (lr < iobase) return 6 * (int64_t)d.tile_cams[c0 + lr / 6] + lr % 6;
-        return 6 * (int64_t)d.nc + d.tile_iocols[io0 + lr - iobase];
-    };
-#pragma unroll
-    for (int s = 0; s < 9; ++s) {
-        if (ton[s]) {
-            const int lcol = woff[s] + (lane & 15);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int lr = yoff[s] + (lane >> 4) + 4 * e;
-                const double v = acc[s][e];
-                if (lr < nrows && lcol <= lr && v != 0.0)
-                    atomic_add_f64(S + grow(lcol) * d.ldS + grow(lr), -v);
-            }
-        }
-    }
-    for (int i = t; i < ncam * 36; i += BT) {
-        const int lcam = i / 36, e = i - lcam * 36;
-        const int a = e / 6, b2 = e - a * 6;
-        if (b2 < a) continue;
-        const int64_t cb = 6 * (int64_t)d.tile_cams[c0 + lcam];
-        atomic_add_f64(S + (cb + a) * d.ldS + (cb + b2), Ud[i]);
-    }
-    if constexpr (IO) {
-        for (int i = t; i < ncam * 6 * IOT; i += BT) {
-            const int li = i % IOT, ca = i / IOT;    // ca = lcam*6 + a
-            if (li >= nio) continue;
-            const double v = Uci[i];
-            if (v != 0.0) atomic_add_f64(S + grow(ca) * d.ldS + grow(iobase + li), v);
-        }
-        for (int i = t; i < IOT * IOT; i += BT) {
-            const int ia = i / IOT, ib = i % IOT;
-            if (ia >= nio || ib >= nio || ib < ia) continue;
-            const double v = Uii[i];
-            if (v != 0.0) atomic_add_f64(S + grow(iobase + ia) * d.ldS + grow(iobase + ib), v);
-        }
-    }
-    for (int i = t; i < nrows; i += BT) {
-        const int64_t col = grow(i);
-        atomic_add_f64(g_c + col, vt[i]);
-        atomic_add_f64(g_red + col, vt[LD + i]);
-        atomic_add_f64(diagU + col, vt[2 * LD + i]);
-    }
-    double accr[1] = {rr};
-    block_sum<1>(accr, sh);
-    if (t == 0) partial[blockIdx.x] = accr[0];
-    for (int off = 32; off > 0; off >>= 1) {
-        pmin = fmin(pmin, __shfl_down(pmin, off, 64));
-        pmax = fmax(pmax, __shfl_down(pmax, off, 64));
-    }
-    if ((t & 63) == 0 && pmax > 0.0) {
-        atomicMin(pivmm, (unsigned long long)__double_as_longlong(pmin));
-        atomicMax(pivmm + 1, (unsigned long long)__double_as_longlong(pmax));
-    }
-}
 
 // all LDS traffic of this wave has completed
 __device__ __forceinline__ void lds_fence() {           // all LDS traffic of this wave has completed

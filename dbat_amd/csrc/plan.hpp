@@ -436,7 +436,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     P.CMAX = env_int0("DBAT_HIP_CMAX", P.with_io ? 18 : 21);
     if (P.shared_eo) P.CMAX = 0;                    // the tile kernels address camera rows as 6*camera + k
     if (P.CMAX < 0 || P.CMAX > (P.with_io ? 18 : 21)) P.CMAX = P.with_io ? 18 : 21;   // 6*CMAX (+IOT) <= 128 rows of the MFMA tile
-    if (P.ncolmax - 6 > Plan::IOT) P.CMAX = 0;
+    if (P.ncolmax > 14) P.CMAX = 0;                  // the tile kernels hold at most 8 IO columns per camera: untiled (k_build)
     {   // batch size: whole points, at most BT observations
         auto env_int = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
         P.BT = env_int("DBAT_HIP_BT", 256);

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(64 * sig_waves(RB, (NCX > 6))) void k_build_sig(Dev
     }
     while (ch < ch1) {
         const int pt0 = __builtin_amdgcn_readlane(nd, 0), npts = __builtin_amdgcn_readlane(nd, 1);
-        const int k = __builtin_amdgcn_readlane(nd, 2), obs0 = __builtin_amdgcn_readlane(nd, 3);
+        const int k = __builtin_amdgcn_readlane(nd, 2);
         const int gm = __builtin_amdgcn_readlane(nd, 4), gi0 = __builtin_amdgcn_readlane(nd, 5);
         const int uv0 = __builtin_amdgcn_readlane(nd, 6);
         if (lane < k) sy.lc[wave][lane] = nlc;

@@ -423,10 +423,13 @@ class _ThreadComm:
         return self._reduce(np.array(a, dtype=float, copy=True))
 
 
-@pytest.mark.parametrize('damping', ['gna', 'lm', 'lmp'])
-def test_two_shards_one_gpu_match_single(hip, damping):
+@pytest.mark.parametrize('damping', ['gna', 'lm', 'lmp', 'gna-sig'])
+def test_two_shards_one_gpu_match_single(hip, damping, monkeypatch):
     import threading
     from dbat_amd import bundle
+    if damping == 'gna-sig':             # the signature kernels on every shard (the default at C3 / C4)
+        monkeypatch.setenv('DBAT_HIP_SIG', '2')
+        damping = 'gna'
     s, truth = synth_struct('small', 'priors')
     ref = bundle(s, damping)
     shared = {'buf': [None, None], 'bar': threading.Barrier(2)}
