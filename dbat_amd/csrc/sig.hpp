@@ -397,21 +397,24 @@ __global__ __launch_bounds__(64 * sig_waves(RB, (NCX > 6))) void k_build_sig(Dev
             int tcm[RB];
 #pragma unroll
             for (int r2 = 0; r2 < RB; ++r2) tcm[r2] = sy.tmap[wave][min(16 * r2 + (lane & 15), 79)];
+            // Rows beyond the row of y and k-columns beyond the round were zero in the panel, so the
+            // accumulators are exactly 0.0 there: `v != 0` is the only test the blocks below the diagonal
+            // need; the diagonal blocks also drop their upper triangle and the (y, y) element.
 #pragma unroll
             for (int r1 = 0; r1 < RB; ++r1) {
                 if (r1 >= rbk) break;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int lr = 16 * r1 + (lane >> 4) + 4 * e;
-                    const int tr = sy.tmap[wave][min(lr, 79)];
                     const bool yrow = lr == r6k;
-                    const int rowbase = yrow ? SIG_STILE : tr * (tr + 1) / 2;
+                    const int tr = sy.tmap[wave][min(lr, 79)];
+                    double *row = stile + (yrow ? SIG_STILE : tr * (tr + 1) / 2);
 #pragma unroll
                     for (int r2 = 0; r2 <= r1; ++r2) {
-                        const int lcol = 16 * r2 + (lane & 15);
-                        const double v = acc[r1 * (r1 + 1) / 2 + r2][e];
-                        if (lcol <= lr && lr <= r6k && lcol < r6k && v != 0.0 && !(d.ablate & 8))
-                            atomic_add_f64(stile + rowbase + tcm[r2], yrow ? -v : v);
+                        double v = acc[r1 * (r1 + 1) / 2 + r2][e];
+                        bool take = v != 0.0 && !(d.ablate & 8);
+                        if (r2 == r1) { const int lcol = 16 * r2 + (lane & 15); take = take && lcol <= lr && lcol < r6k; }
+                        if (take) atomic_add_f64(row + tcm[r2], yrow ? -v : v);
                     }
                 }
             }
