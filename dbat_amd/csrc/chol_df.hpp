@@ -402,7 +402,9 @@ __global__ __launch_bounds__(256) void k_chol_df(DfView V, int n, int nT, const 
             // L -> tile (lower triangle), L^-1 -> Linv[c*64 + i] = Linv(i, c) = smem[i][64 + c]
 #pragma unroll 4
             for (int c = ty; c < NB; c += 4) {
-                if (tx < nc && c < nc && tx >= c) st_coh(Tik + (int64_t)c * V.ld + tx, smem[c * DF_TLD + tx]);
+                // L(k,k) itself is only wanted where the factor stays in S (in place: posterior covariance);
+                // in the compact-tile layout nothing reads the diagonal tile again (the solves use L^-1)
+                if (!V.iperm && tx < nc && c < nc && tx >= c) st_coh(Tik + (int64_t)c * V.ld + tx, smem[c * DF_TLD + tx]);
                 st_coh(Linv + c * NB + tx, (tx < nc && c < nc) ? smem[tx * DF_TLD + 64 + c] : 0.0);
             }
             if (ldiag && ty == 0 && tx < nc) {          // the pivots, by natural index (k_diag_minmax)

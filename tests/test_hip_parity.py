@@ -1107,3 +1107,31 @@ def test_forward_intersection_hip(hip, case):
         assert np.abs(a.OP.val[m] - b.OP.val[m]).max() <= 1e-9 * max(1.0, np.abs(a.OP.val[m]).max())
     if case == 'tiny':
         assert np.isnan(initial.forwintersect_hip(s).OP.val[:, p]).all()
+
+
+@pytest.mark.parametrize('name,sig', [('small', '0'), ('small', '2'), ('C1', '0'), ('C1', '2')])
+def test_run_to_run_repeatability(hip, name, sig, monkeypatch):
+    """The reduced system is summed with floating-point atomics (LDS and HBM), so two runs differ by
+    the rounding of a different summation order -- and by nothing else: a race between workgroups
+    (a tile read before it is published, a panel reused too early) shows up as run-to-run
+    differences far above rounding.  20 repeats of linearise + solve, tile kernels and signature
+    kernels: the step must repeat to 1e-10 relative (observed: 1e-13 ... 1e-12), the objective value
+    bit for bit (one reduction order)."""
+    from dbat_amd import synth
+    monkeypatch.setenv('DBAT_HIP_SIG', sig)
+    s, _ = synth.make_scene(name)
+    h = hip.Handle(s)
+    try:
+        x0 = h.serialize()
+        ref, f_ref, worst = None, None, 0.0
+        for i in range(20):
+            p, st = h.linearize_solve(x0, 0.0, True)
+            f = h.residual(x0, want_r=False)
+            if ref is None:
+                ref, f_ref = p.copy(), f
+            worst = max(worst, relerr(p, ref))
+            assert f == f_ref
+            assert not st['singular']
+        assert worst < 1e-10, worst
+    finally:
+        h.close()
