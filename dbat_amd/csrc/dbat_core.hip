@@ -80,6 +80,10 @@ struct Core {
     hipStream_t stream = nullptr;
     int device = 0;
     rocblas_handle blas = nullptr;
+    // pinned host mailbox for the scalar read-backs of the damping loops (a copy to pageable memory is
+    // staged and costs a blit kernel of ~18 us each, seven per LM step): [0..31] scalars, [32..35]
+    // build sums, [40..47] pivots / info, [48..51] the pivot reset pattern
+    double *hpin = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t kev[8] = {};      // per-kernel brackets, recorded only while timing is on
     bool timing = false;
@@ -154,6 +158,7 @@ struct Core {
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         for (auto &e : kev) if (e) (void)hipEventDestroy(e);
         dfchol.release(); dfchol_ip.release();
+        if (hpin) (void)hipHostFree(hpin);
         if (nccl) (void)ncclCommDestroy(nccl);
         if (blas) rocblas_destroy_handle(blas);
         if (stream) (void)hipStreamDestroy(stream);
@@ -163,6 +168,11 @@ struct Core {
         device = pb.device;
         HIPCHK(hipSetDevice(pb.device));
         HIPCHK(hipStreamCreate(&stream));
+        HIPCHK(hipHostMalloc((void **)&hpin, 64 * sizeof(double), hipHostMallocDefault));
+        {
+            const double big = 1e300;
+            memcpy(&hpin[48], &big, 8); hpin[49] = 0.0; memcpy(&hpin[50], &big, 8); hpin[51] = 0.0;   // bit patterns: min = 1e300, max = +0
+        }
         if (rocblas_create_handle(&blas) != rocblas_status_success) throw DeviceError{"rocblas_create_handle failed"};
         rocblas_set_stream(blas, stream);
         for (auto &e : ev) HIPCHK(hipEventCreate(&e));
@@ -357,6 +367,12 @@ struct Core {
         return zgather.p;
     }
     void read_scal(double *host, int n) {
+        if (n <= 32) {
+            HIPCHK(hipMemcpyAsync(hpin, scal.p, n * sizeof(double), hipMemcpyDeviceToHost, stream));
+            sync();
+            memcpy(host, hpin, n * sizeof(double));
+            return;
+        }
         HIPCHK(hipMemcpyAsync(host, scal.p, n * sizeof(double), hipMemcpyDeviceToHost, stream));
         sync();
     }
@@ -427,12 +443,7 @@ struct Core {
             LAUNCHK(k_envelope_op, dim3((unsigned)P.NS), dim3(256), 0, stream, S, ldS, (int)P.NS, env_tail0, col_bend.p, (const double *)nullptr);
             HIPCHK(hipMemsetAsync(g_red, 0, (size_t)(3 * P.NS + 8) * sizeof(double), stream));
         }
-        {
-            const double big = 1e300;
-            unsigned long long init[4];
-            memcpy(&init[0], &big, 8); init[1] = 0; init[2] = init[0]; init[3] = 0;
-            HIPCHK(hipMemcpyAsync(pivmm.p, init, sizeof(init), hipMemcpyHostToDevice, stream));
-        }
+        HIPCHK(hipMemcpyAsync(pivmm.p, hpin + 48, 4 * sizeof(double), hipMemcpyHostToDevice, stream));   // {min, max} x {points, cameras}
         // tiled batches through the MFMA kernel, the remaining ("heavy point") batches
         // -- or all of them when tiling is off -- through k_build
         int64_t npart = 0;
@@ -516,8 +527,9 @@ struct Core {
         LAUNCHK(k_dot, dim3(grid_z), dim3(256), 0, stream, P.NS, z_est.p, jn2c.p, (const double *)nullptr, partial.p);
         LAUNCHK((k_sum_partials<1>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_z, scal.p, 0);
         double hs[2], hr[2];
-        HIPCHK(hipMemcpyAsync(hr, red_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(hpin + 32, red_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
         read_scal(hs, 1);
+        hr[0] = hpin[32]; hr[1] = hpin[33];
         f_lin = 0.5 * hr[0];
         trace_jtj = hs[0] + hr[1];
         lambda_lin = lambda;
@@ -556,9 +568,10 @@ struct Core {
         mark(4);
         // the points of the signature chunks by k_backsub_sig (one wave per chunk), the other batches by
         // k_backsub; partial: [nb batches][2] (the tiled batches' slots stay zero), giants, sig workgroups
-        const int64_t b_first = use_sig ? P.nb_tiled : 0;
-        const int64_t n_sig_wg = use_sig ? cdiv(sg_nchunks, 4) : 0;
-        if (use_sig) HIPCHK(hipMemsetAsync(partial.p, 0, (size_t)2 * P.nb_tiled * sizeof(double), stream));
+        const bool sig_bs = use_sig && P.sg_backsub_ok;
+        const int64_t b_first = sig_bs ? P.nb_tiled : 0;
+        const int64_t n_sig_wg = sig_bs ? cdiv(sg_nchunks, 4) : 0;
+        if (sig_bs) HIPCHK(hipMemsetAsync(partial.p, 0, (size_t)2 * P.nb_tiled * sizeof(double), stream));
         if (n_sig_wg > 0) {
 #define L_BACKS(M, NCXV) LAUNCHK((k_backsub_sig<M, NCXV>), dim3((unsigned)n_sig_wg), dim3(256), 0, stream, d, zlin.p, cams.p, Vinv.p, gp.p, dz.p, partial.p + 2 * (nb + ngiant), sg_chunk.p, (int)sg_nchunks, sg_gcam.p, sg_uv.p, P.uniform_w ? (const double *)nullptr : sg_w.p)
             if (tile_ncx == 6) { DISPATCH_MODEL(L_BACKS, 6) } else { DISPATCH_MODEL(L_BACKS, 14) }
@@ -593,8 +606,8 @@ struct Core {
         backsub_enqueue();
         int hinfo = 0;
         unsigned long long hmm[4];
-        HIPCHK(hipMemcpyAsync(&hinfo, info.p, sizeof(hinfo), hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipMemcpyAsync(hmm, pivmm.p, sizeof(hmm), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(hpin + 40, pivmm.p, sizeof(hmm), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(hpin + 44, info.p, sizeof(hinfo), hipMemcpyDeviceToHost, stream));
         // one all-reduce per solve: the 8 scalar sums and, behind them, one {min,max} slot per rank
         // with this rank's point-block pivots (the extremes travel through the sum)
         const int nsl = multi() ? 2 * P.nranks : 0;
@@ -605,6 +618,8 @@ struct Core {
         }
         std::vector<double> h((size_t)8 + nsl);
         read_scal(h.data(), 8 + nsl);
+        memcpy(hmm, hpin + 40, sizeof(hmm));
+        memcpy(&hinfo, hpin + 44, sizeof(hinfo));
         JpJp = h[0] + h[4]; rJp = h[1] + h[5]; pp = h[6];
         double mm[4];
         memcpy(mm, hmm, sizeof(mm));

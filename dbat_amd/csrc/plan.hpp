@@ -101,6 +101,7 @@ struct Plan {
     int sg_rows_max = 0;                           // most rows of a chunk: 6k + IO columns of its tile + 1
     int64_t sg_ngroups = 0, sg_npoints = 0;
     bool sg_ok = false;                            // the tiled points can go through k_build_sig
+    bool sg_backsub_ok = false;                    // ... and through k_backsub_sig
     int BT = 256;
     int ncolmax = 6;
     bool with_io = false;
@@ -876,8 +877,14 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     // interior orientation is fixed and the groups are long enough to fill a wave's lanes
     // every chunk's rows (6k + the IO columns of its tile + the right-hand-side row) fit five 16-row blocks
     const bool sg_can = P.CMAX > 0 && P.nb_tiled > 0 && P.sg_kmax > 0 && P.sg_rows_max <= 80 && P.ncolmax <= 14 && P.BT == 256;
-    P.sg_ok = sg_can && P.sg_npoints >= 8 * P.sg_ngroups;
-    if (const char *e = getenv("DBAT_HIP_SIG")) P.sg_ok = atoi(e) == 0 ? false : (atoi(e) >= 2 ? sg_can : P.sg_ok);   // 0 off, 2 whenever possible
+    // the build kernel pays from about four points per group on, the back-substitution (one lane per
+    // point, one wave per chunk) from about eight (C1 / C2: 6 ... 7 points per group)
+    P.sg_ok = sg_can && P.sg_npoints >= 4 * P.sg_ngroups;
+    P.sg_backsub_ok = sg_can && P.sg_npoints >= 8 * P.sg_ngroups;
+    if (const char *e = getenv("DBAT_HIP_SIG")) {     // 0 off, 2 whenever possible
+        P.sg_ok = atoi(e) == 0 ? false : (atoi(e) >= 2 ? sg_can : P.sg_ok);
+        P.sg_backsub_ok = atoi(e) == 0 ? false : (atoi(e) >= 2 ? sg_can : P.sg_backsub_ok);
+    }
     if (getenv("DBAT_HIP_PLAN_STATS") && P.sg_ngroups > 0)
         fprintf(stderr, "[plan] %lld signature groups, %.1f points/group, %zu chunks, k max %d, sig kernel %s\n",
                 (long long)P.sg_ngroups, (double)P.sg_npoints / P.sg_ngroups, P.sg_chunk.size() / 8, P.sg_kmax,

@@ -1029,6 +1029,7 @@ def test_fixed_io_single_producer_group_kernel(hip, knob, monkeypatch):
     overridden: same step and the same bundle result as the oracle, and the
     same step as the default kernel to rounding."""
     from dbat_amd import bundle
+    monkeypatch.setenv('DBAT_HIP_SIG', '0')              # the tile kernels (the signature kernel would take this scene)
     s, truth = synth_struct('small', 'plain')
     so, x0, w = oracle_setup(s)
     R = np.sqrt(w)
@@ -1036,6 +1037,7 @@ def test_fixed_io_single_producer_group_kernel(hip, knob, monkeypatch):
     p_o, *_ = o._scaled_gn((sp.diags(R) @ K).tocsc(), R * r_o)
     h = hip.Handle(s)
     try:
+        assert h.build_kernel_name() == 'k_build_tile3'
         p_default, _ = h.linearize_solve(x0, 0.0, True)
     finally:
         h.close()
@@ -1043,6 +1045,7 @@ def test_fixed_io_single_producer_group_kernel(hip, knob, monkeypatch):
     monkeypatch.setenv(name, val)
     h = hip.Handle(s)
     try:
+        assert h.build_kernel_name() == 'k_build_tile2'
         p_h, st = h.linearize_solve(x0, 0.0, True)
     finally:
         h.close()
