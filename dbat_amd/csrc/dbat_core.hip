@@ -571,7 +571,7 @@ struct Core {
         const bool sig_bs = use_sig && P.sg_backsub_ok;
         const int64_t b_first = sig_bs ? P.nb_tiled : 0;
         const int64_t n_sig_wg = sig_bs ? cdiv(sg_nchunks, 4) : 0;
-        if (sig_bs) HIPCHK(hipMemsetAsync(partial.p, 0, (size_t)2 * P.nb_tiled * sizeof(double), stream));
+        // (the slots of the tiled batches are not written then, and not summed: see k_sum_partials below)
         if (n_sig_wg > 0) {
 #define L_BACKS(M, NCXV) LAUNCHK((k_backsub_sig<M, NCXV>), dim3((unsigned)n_sig_wg), dim3(256), 0, stream, d, zlin.p, cams.p, Vinv.p, gp.p, dz.p, partial.p + 2 * (nb + ngiant), sg_chunk.p, (int)sg_nchunks, sg_gcam.p, sg_uv.p, P.uniform_w ? (const double *)nullptr : sg_w.p)
             if (tile_ncx == 6) { DISPATCH_MODEL(L_BACKS, 6) } else { DISPATCH_MODEL(L_BACKS, 14) }
@@ -588,7 +588,7 @@ struct Core {
 #undef L_BACKG
         }
         mark(5);
-        LAUNCHK((k_sum_partials<2>), dim3(1), dim3(1024), 0, stream, partial.p, nb + ngiant + n_sig_wg, scal.p, 0);
+        LAUNCHK((k_sum_partials<2>), dim3(1), dim3(1024), 0, stream, partial.p + 2 * b_first, nb - b_first + ngiant + n_sig_wg, scal.p, 0);
         LAUNCHK(k_prior_jv, dim3(grid_z), dim3(256), 0, stream, d, zlin.p, dz.p, g_c, gp.p, partial.p);
         LAUNCHK((k_sum_partials<3>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_z, scal.p + 4, 0);
     }

@@ -144,11 +144,10 @@ __global__ __launch_bounds__(64 * sig_waves(RB, (NCX > 6))) void k_build_sig(Dev
             const int kq = lane / 6;
             const int lcq = __builtin_amdgcn_ds_bpermute(4 * (kq < k ? kq : 0), nlc);
             if (lane < 6 * k) sy.tmap[wave][lane] = (short)(6 * lcq + (lane - 6 * kq));
-            if (lane + 64 < 6 * k) {
-                const int kq2 = (lane + 64) / 6;
-                const int lcq2 = __builtin_amdgcn_ds_bpermute(4 * kq2, nlc);
-                sy.tmap[wave][lane + 64] = (short)(6 * lcq2 + (lane + 64 - 6 * kq2));
-            }
+            // (ds_bpermute returns 0 from lanes outside EXEC: both exchanges run with the whole wave)
+            const int kq2 = (lane + 64) / 6;
+            const int lcq2 = __builtin_amdgcn_ds_bpermute(4 * (kq2 < k ? kq2 : 0), nlc);
+            if (lane + 64 < 6 * k) sy.tmap[wave][lane + 64] = (short)(6 * lcq2 + (lane + 64 - 6 * kq2));
             if (lane < nio) sy.tmap[wave][6 * k + lane] = (short)(6 * ncam + lane);      // IO rows follow the camera rows
         }
         ch = grab();
@@ -479,10 +478,10 @@ __global__ __launch_bounds__(256) void k_backsub_sig(DevProblem d, const double 
         const int32_t *cd = sg_chunk + 8 * (int64_t)ch;
         const int pt0 = cd[0], npts = cd[1], k = cd[2], gm = cd[4], gi0 = cd[5], uv0 = cd[6];
         const int mycam = lane < k ? sg_gcam[16 * (int64_t)ch + lane] : 0;
-        for (int idx = lane; idx < k * CW; idx += 64) {
-            const int c = idx / CW, f = idx - c * CW;
+        for (int base = 0; base < k * CW; base += 64) {      // whole-wave exchange: ds_bpermute reads 0 from lanes outside EXEC
+            const int idx = base + lane, c = min(idx / CW, k - 1), f = idx - c * CW;
             const int cam = __builtin_amdgcn_ds_bpermute(4 * c, mycam);
-            crec[wv][c][f] = reinterpret_cast<const double *>(cams + cam)[f];
+            if (idx < k * CW) crec[wv][c][f] = reinterpret_cast<const double *>(cams + cam)[f];
         }
         __builtin_amdgcn_wave_barrier();
         for (int idx = lane; idx < k * NCX; idx += 64) {

@@ -1138,3 +1138,32 @@ def test_run_to_run_repeatability(hip, name, sig, monkeypatch):
         assert worst < 1e-10, worst
     finally:
         h.close()
+
+
+@pytest.mark.parametrize('rays,selfcal', [(12, False), (13, False), (11, True)])
+def test_signature_group_kernel_five_row_blocks(hip, rays, selfcal, monkeypatch):
+    """Chunks with 11 ... 13 cameras per point need five 16-row blocks (the four-wave instantiations
+    of k_build_sig, fixed IO and self-calibrating): step parity with the oracle and with the tile
+    kernels, bundle result as the oracle's."""
+    from dbat_amd import bundle, synth
+    s, truth = synth.make_scene('small', rays=rays, selfcal=selfcal)
+    so, x0, w = oracle_setup(s)
+    R = np.sqrt(w)
+    r_o, K = o.brown_euler_cam4(x0, so, jac=True)
+    J = (sp.diags(R) @ K).tocsc()
+    p_o, *_ = o._scaled_gn(J, R * r_o)
+    steps = {}
+    for sig in ('0', '2'):
+        monkeypatch.setenv('DBAT_HIP_SIG', sig)
+        h = hip.Handle(s)
+        try:
+            assert (h.build_kernel_name() == 'k_build_sig') == (sig == '2')
+            steps[sig], st = h.linearize_solve(x0, 0.0, True)
+            Jp = J @ p_o
+            assert abs(st['JpJp'] - Jp @ Jp) <= 1e-7 * (Jp @ Jp)
+        finally:
+            h.close()
+    assert relerr(steps['2'], p_o) < TOL_STEP and relerr(steps['2'], steps['0']) < 1e-9
+    res, ok, iters, s0, E = bundle(s, 'gna')
+    ro, oko, ito, s0o, Eo = o.bundle(s, 'gna')
+    assert ok and oko and iters == ito and relerr(E.x, Eo.x) < TOL_X
