@@ -7,6 +7,8 @@ import sys
 import numpy as np
 
 rows = np.loadtxt(sys.argv[1], delimiter=',', dtype=np.int64)
+cyc = (rows[:, 3 + 15] - rows[:, 3 + 14]).astype(float)      # s_memtime around df_potf2 (diagonal tasks)
+rows[:, 3 + 14:] = 0
 task, ti, tk, T = rows[:, 0], rows[:, 1], rows[:, 2], rows[:, 3:].astype(float) * 0.01   # us
 t0 = T[T > 0].min()
 T = np.where(T > 0, T - t0, np.nan)
@@ -22,6 +24,12 @@ print('diagonal   : updates+waits %.2f | to potf2 %.2f | potf2 %.2f (panels %s) 
          ph(diag, 12, 3), ph(diag, 3, 4)))
 print('off-diag   : updates+waits %.2f | wait diag %.2f | Linv load + product + stores %.2f | flag %.2f'
       % (ph(off, 0, 1), ph(off, 1, 2), ph(off, 2, 3), ph(off, 3, 4)))
+dm = diag & (cyc > 0)
+if dm.any():
+    print('df_potf2   : %.0f s_memtime ticks = %.2f us -> %.2f GHz shader clock inside the kernel'
+          % (cyc[dm].mean(), ph(dm, 2, 12), cyc[dm].mean() / ph(dm, 2, 12) * 1e-3))
+if np.isfinite(T[diag, 5]).any():
+    print('panel 1    : loads %.2f | elimination %.2f | stores + barrier %.2f us' % (ph(diag, 7, 5), ph(diag, 5, 13), ph(diag, 13, 8)))
 print('backward   : %.2f us per panel' % ph(back, 0, 4))
 # chain of diagonal completions
 d_idx = np.flatnonzero(diag)

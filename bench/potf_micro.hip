@@ -1,0 +1,190 @@
+// What does one column of the 16-column panel elimination of df_potf2 (chol_df.hpp) cost, and
+// which way of broadcasting the multipliers is cheapest?  One wave per SIMD, as in k_chol_df.
+//   V0  multipliers by v_readlane (SGPR operands), chain on wave-uniform values
+//   V1  multipliers through LDS (one ds_write of the column, broadcast ds_read_b128)
+//   P*  probes: dependent v_fma_f64 chain, independent v_fma_f64, readlane+fma pairs, v_rsq_f64 chain
+// hipcc --offload-arch=gfx950 -O3 bench/potf_micro.hip -o /tmp/potf_micro
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cmath>
+#include <vector>
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+template <int V>
+__device__ __forceinline__ void eliminate(double (&a)[16], double *col /* LDS, [2][16] of this wave */, int lane) {
+    if constexpr (V == 0) {
+        double piv = readlane_f64(a[0], 0);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const double araw = a[j];
+            const double c1 = j < 15 ? readlane_f64(araw, j + 1) : 0.0;
+            const double rn = j < 15 ? readlane_f64(a[j + 1], j + 1) : 0.0;
+            const double y0 = __builtin_amdgcn_rsq(piv);
+            const double e = __builtin_fma(-piv, y0 * y0, 1.0);
+            const double y = __builtin_fma(y0, __builtin_fma(e, 0.375, 0.5) * e, y0);
+            const double y2 = y * y;
+            piv = __builtin_fma(-c1, c1 * y2, rn);
+            const double ly = araw * y2;
+            a[j] = araw * y;
+            if (j < 15) a[j + 1] = __builtin_fma(-c1, ly, a[j + 1]);
+#pragma unroll
+            for (int k = j + 2; k < 16; ++k) a[k] = __builtin_fma(-readlane_f64(araw, k), ly, a[k]);
+        }
+    } else {
+        // column j of the diagonal rows -> LDS; every lane reads the multipliers back (same address: broadcast)
+        double piv = readlane_f64(a[0], 0);
+        if (lane < 16) col[lane] = a[0];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const double araw = a[j];
+            double c[16];
+            const double *cj = col + 16 * (j & 1);
+#pragma unroll
+            for (int k = (j + 1) & ~1; k < 16; k += 2) {     // 16-byte broadcast reads
+                const double2 v = *reinterpret_cast<const double2 *>(cj + k);
+                c[k] = v.x; c[k + 1] = v.y;
+            }
+            const double rn = j < 15 ? readlane_f64(a[j + 1], j + 1) : 0.0;
+            const double y0 = __builtin_amdgcn_rsq(piv);
+            const double e = __builtin_fma(-piv, y0 * y0, 1.0);
+            const double y = __builtin_fma(y0, __builtin_fma(e, 0.375, 0.5) * e, y0);
+            const double y2 = y * y;
+            const double ly = araw * y2;
+            a[j] = araw * y;
+            if (j < 15) {
+                const double c1 = c[j + 1];
+                piv = __builtin_fma(-c1, c1 * y2, rn);
+                a[j + 1] = __builtin_fma(-c1, ly, a[j + 1]);
+                if (lane < 16) col[16 * ((j + 1) & 1) + lane] = a[j + 1];     // the next column is final
+            }
+#pragma unroll
+            for (int k = j + 2; k < 16; ++k) a[k] = __builtin_fma(-c[k], ly, a[k]);
+        }
+    }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void k_elim(const double *A /* [16][32] col-major: 32 rows */, int iters,
+                                              unsigned long long *out, double *res) {
+    __shared__ double col[4][32];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double a0[16];
+    for (int q = 0; q < 16; ++q) a0[q] = lane < 32 ? A[q * 32 + lane] : 0.0;
+    double a[16];
+    double sum = 0;
+    __syncthreads();
+    const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a[q] = a0[q] + (double)it * 0.0;
+        eliminate<V>(a, col[w], lane);
+        sum += a[15];
+        __builtin_amdgcn_wave_barrier();
+    }
+    const unsigned long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+    if (lane == 0) { out[2 * w] = c1 - c0; out[2 * w + 1] = w1 - w0; }
+    if (w == 0 && lane < 32)
+        for (int q = 0; q < 16; ++q) res[q * 32 + lane] = a[q];
+    if (sum == 1234.5) res[0] = sum;
+}
+
+// probes: cycles per instruction of simple streams, one wave per SIMD
+template <int P>
+__global__ __launch_bounds__(256) void k_probe(int iters, unsigned long long *out, double *sink) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double x = 1.0 + lane * 1e-6, y = 0.999999, z[8];
+    for (int i = 0; i < 8; ++i) z[i] = 1.0 + i + lane;
+    __syncthreads();
+    const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+        if constexpr (P == 0) {                      // 16 dependent fma
+#pragma unroll
+            for (int i = 0; i < 16; ++i) x = __builtin_fma(x, y, 1e-9);
+        } else if constexpr (P == 1) {               // 16 independent fma (8 chains x 2)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) z[i] = __builtin_fma(z[i], y, 1e-9);
+        } else if constexpr (P == 2) {               // 8 x (readlane pair + fma), independent targets
+#pragma unroll
+            for (int i = 0; i < 8; ++i) z[i] = __builtin_fma(-readlane_f64(x, i + 1), y, z[i]);
+            x += 1e-9;
+        } else if constexpr (P == 3) {               // 4 dependent rsq + fma
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x = __builtin_fma(__builtin_amdgcn_rsq(x), y, 1.0);
+        } else if constexpr (P == 4) {               // 16 readlane_b32 only (feeding one add each 8)
+            int s = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s += __builtin_amdgcn_readlane(__double2loint(x) + i, i);
+            x += (double)s * 1e-300;
+        }
+    }
+    const unsigned long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+    double s = x;
+    for (int i = 0; i < 8; ++i) s += z[i];
+    sink[threadIdx.x] = s;
+    if (lane == 0) { out[2 * w] = c1 - c0; out[2 * w + 1] = w1 - w0; }
+}
+
+int main() {
+    // SPD 16 x 16 block + 16 more rows
+    std::vector<double> A(16 * 32);
+    for (int c = 0; c < 16; ++c)
+        for (int r = 0; r < 32; ++r) {
+            double v = r < 16 ? (r == c ? 20.0 + r : 1.0 / (1 + abs(r - c))) : sin(0.37 * r + c);
+            if (r < 16 && r < c) v = 0.0;
+            A[c * 32 + r] = v;
+        }
+    double *dA, *dres[2], *sink; unsigned long long *out;
+    hipMalloc(&dA, A.size() * 8); hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
+    hipMalloc(&dres[0], A.size() * 8); hipMalloc(&dres[1], A.size() * 8); hipMalloc(&sink, 256 * 8); hipMalloc(&out, 64);
+    const int iters = 2000;
+    std::vector<double> r0(A.size()), r1(A.size());
+    for (int v = 0; v < 2; ++v) {
+        for (int rep = 0; rep < 2; ++rep) {
+            if (v == 0) hipLaunchKernelGGL(k_elim<0>, dim3(1), dim3(256), 0, 0, dA, iters, out, dres[0]);
+            else hipLaunchKernelGGL(k_elim<1>, dim3(1), dim3(256), 0, 0, dA, iters, out, dres[1]);
+            hipDeviceSynchronize();
+        }
+        unsigned long long h[8]; hipMemcpy(h, out, 64, hipMemcpyDeviceToHost);
+        printf("V%d: %.0f shader ticks, %.3f us per 16-column panel (wave 0), %.1f ticks per column\n", v,
+               (double)h[0] / iters, (double)h[1] * 0.01 / iters, (double)h[0] / iters / 16);
+    }
+    hipMemcpy(r0.data(), dres[0], A.size() * 8, hipMemcpyDeviceToHost);
+    hipMemcpy(r1.data(), dres[1], A.size() * 8, hipMemcpyDeviceToHost);
+    double md = 0, chk = 0;
+    for (size_t i = 0; i < A.size(); ++i) { md = fmax(md, fabs(r0[i] - r1[i])); chk += r0[i]; }
+    // host check of L: L L' == A on the diagonal block
+    double err = 0;
+    for (int r = 0; r < 16; ++r)
+        for (int c = 0; c <= r; ++c) {
+            double s = 0;
+            for (int m = 0; m <= c; ++m) s += r0[m * 32 + r] * r0[m * 32 + c];
+            err = fmax(err, fabs(s - A[c * 32 + r]));
+        }
+    printf("max |V0 - V1| = %.3g, checksum %.12g, |L L' - A| = %.3g\n", md, chk, err);
+    const char *names[] = {"16 dependent v_fma_f64", "16 independent v_fma_f64", "8 x (2 v_readlane + v_fma_f64)",
+                           "4 dependent (v_rsq_f64 + v_fma_f64)", "16 v_readlane_b32 + adds"};
+    for (int p = 0; p < 5; ++p) {
+        for (int rep = 0; rep < 2; ++rep) {
+            switch (p) {
+                case 0: hipLaunchKernelGGL(k_probe<0>, dim3(1), dim3(256), 0, 0, 20000, out, sink); break;
+                case 1: hipLaunchKernelGGL(k_probe<1>, dim3(1), dim3(256), 0, 0, 20000, out, sink); break;
+                case 2: hipLaunchKernelGGL(k_probe<2>, dim3(1), dim3(256), 0, 0, 20000, out, sink); break;
+                case 3: hipLaunchKernelGGL(k_probe<3>, dim3(1), dim3(256), 0, 0, 20000, out, sink); break;
+                case 4: hipLaunchKernelGGL(k_probe<4>, dim3(1), dim3(256), 0, 0, 20000, out, sink); break;
+            }
+            hipDeviceSynchronize();
+        }
+        unsigned long long h[8]; hipMemcpy(h, out, 64, hipMemcpyDeviceToHost);
+        printf("probe %d (%s): %.1f shader ticks per iteration, %.4f us\n", p, names[p], (double)h[0] / 20000,
+               (double)h[1] * 0.01 / 20000);
+    }
+    return 0;
+}

@@ -115,72 +115,120 @@ __device__ __forceinline__ bool df_spin(const int *flag, int epoch, int *abort_f
 // non-positive pivot.
 constexpr int DF_TLD = 130;     // 64 * 130 doubles = the two 64 x 65 operand tiles
 
+// Trailing update of df_potf2 after panel p.  Tiles, numbered cb-major: for cb in p+1..3: T row
+// blocks rb = cb..3 (rowbase 16rb), then the identity blocks ib = 0..p (rowbase 64+16ib; ib == p is
+// touched for the first time: starts from zero).  9 / 7 / 4 tiles for p = 0 / 1 / 2; wave w takes
+// tiles w, w+4, w+8.  Straight-line code: all operands of the wave's NS tiles are fetched before
+// the first product (a slot beyond the last tile repeats the last tile and is not stored).
+template <int NS>
+__device__ __forceinline__ void df_trail(double *Tm, int p, int w, int lane) {
+    constexpr int LD = DF_TLD;
+    const int ntile = p == 0 ? 9 : (p == 1 ? 7 : 4);
+    chol_d4 c4[NS];
+    double av[NS][4], bv[NS][4];
+    int cbs[NS], rbs[NS];
+    bool valid[NS];
+#pragma unroll
+    for (int s3 = 0; s3 < NS; ++s3) {
+        int n = w + 4 * s3;
+        valid[s3] = n < ntile;
+        n = valid[s3] ? n : ntile - 1;
+        const int step = n < 4 ? 0 : (n < 7 ? 1 : 2);
+        const int cb = p + 1 + step;
+        n -= step == 0 ? 0 : (step == 1 ? 4 : 7);
+        const int nT_ = 4 - cb;
+        const int rowbase = n < nT_ ? 16 * (cb + n) : 64 + 16 * (n - nT_);
+        const bool fresh = n == nT_ + p;
+        cbs[s3] = cb; rbs[s3] = rowbase;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const double v = Tm[(16 * cb + (lane >> 4) + 4 * e) * LD + (fresh ? 16 * cb : rowbase) + (lane & 15)];
+            c4[s3][e] = fresh ? 0.0 : v;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = 16 * p + 4 * q + (lane >> 4);
+            av[s3][q] = -Tm[m * LD + 16 * cb + (lane & 15)];           // A[cc][m] = -P(16cb + cc, m)
+            bv[s3][q] = Tm[m * LD + rowbase + (lane & 15)];            // B[m][rr] =  P(rowbase + rr, m)
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int s3 = 0; s3 < NS; ++s3) c4[s3] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s3][q], bv[s3][q], c4[s3], 0, 0, 0);
+#pragma unroll
+    for (int s3 = 0; s3 < NS; ++s3)
+        if (valid[s3]) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Tm[(16 * cbs[s3] + (lane >> 4) + 4 * e) * LD + rbs[s3] + (lane & 15)] = c4[s3][e];
+        }
+}
+
 __device__ __forceinline__ void df_potf2(double *Tm, int nb, int j0, int *info, long long *tr) {
     constexpr int LD = DF_TLD;
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    // identity rows
-    for (int idx = t; idx < 64 * 64; idx += 256) { const int c = idx >> 6, r = idx & 63; Tm[c * LD + 64 + r] = r == c ? 1.0 : 0.0; }
-    __syncthreads();
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    // The identity rows are never initialised in LDS: block ib is the identity until panel ib
+    // (synthesised in registers there), zero right of it until the trailing update of panel ib
+    // (accumulators start from zero there), and nobody reads it left of its diagonal block.
+    __syncthreads();                                    // the caller's T is in place
 #pragma unroll 1
     for (int p = 0; p < 4; ++p) {
         // ---- A: panel columns [16p, 16p+16)
         {
             const int nlowT = 48 - 16 * p;                  // T rows below the diagonal block
-            int row;
+            int row, ident = -1;                            // ident: column of the 1 of a fresh identity row
             if (lane < 16) row = 16 * p + lane;
-            else { const int s = 16 * w + (lane - 16); row = s < nlowT ? 16 * (p + 1) + s : 64 + (s - nlowT); }
+            else {
+                const int s = 16 * w + (lane - 16);
+                row = s < nlowT ? 16 * (p + 1) + s : 64 + (s - nlowT);
+                if (lane < 32 && s - nlowT >= 16 * p) ident = s - nlowT - 16 * p;
+            }
             const bool act = lane < 32;
             double a[16];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) a[q] = act ? Tm[(16 * p + q) * LD + row] : 0.0;
-            int bad = 0;                                    // first non-positive pivot of the panel, 1-based
+            for (int q = 0; q < 16; ++q) a[q] = (act && ident < 0) ? Tm[(16 * p + q) * LD + row] : (ident == q ? 1.0 : 0.0);
+            if (tr && t == 0 && p == 1) tr[5] = wall_clock64();
+            unsigned badmask = 0;                           // bit j: pivot j of the panel is not positive
+            // The wave is alone on its SIMD, so the dependent chain pivot -> 1/sqrt -> next pivot is
+            // what a column costs.  It runs on wave-uniform values only: the multipliers c_k = a_j(lane k)
+            // are read BEFORE the column is scaled (their v_readlanes do not wait for 1/sqrt), every
+            // update is a_k -= c_k (a_j / d), and the next pivot d' = a_{j+1}(lane j+1) - c (c / d) is
+            // formed from scalars with the same two operations the lane itself performs (same bits).
+            // 1/sqrt: v_rsq_f64 and one third-order step y0 (1 + e/2 + 3e^2/8), e = 1 - d y0^2.
+            // (Padding columns of a ragged block are identity columns: their pivots are 1.)
+            double piv = readlane_f64(a[0], 0);
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const double piv = readlane_f64(a[j], j);
-                bad = (bad == 0 && !(piv > 0.0) && 16 * p + j < nb) ? 16 * p + j + 1 : bad;
-                double id = __builtin_amdgcn_rsq(piv);
-                id = id * (1.5 - 0.5 * piv * id * id);
-                id = id * (1.5 - 0.5 * piv * id * id);
-                const double l = a[j] * id;
-                a[j] = l;
+                badmask |= !(piv > 0.0) ? 1u << j : 0u;
+                const double araw = a[j];
+                const double c1 = j < 15 ? readlane_f64(araw, j + 1) : 0.0;
+                const double rn = j < 15 ? readlane_f64(a[j + 1], j + 1) : 0.0;
+                const double y0 = __builtin_amdgcn_rsq(piv);
+                const double e = __builtin_fma(-piv, y0 * y0, 1.0);
+                const double y = __builtin_fma(y0, __builtin_fma(e, 0.375, 0.5) * e, y0);
+                const double y2 = y * y;
+                piv = __builtin_fma(-c1, c1 * y2, rn);
+                const double ly = araw * y2;
+                a[j] = araw * y;
+                if (j < 15) a[j + 1] = __builtin_fma(-c1, ly, a[j + 1]);
 #pragma unroll
-                for (int k = j + 1; k < 16; ++k) a[k] -= l * readlane_f64(l, k);
+                for (int k = j + 2; k < 16; ++k) a[k] = __builtin_fma(-readlane_f64(araw, k), ly, a[k]);
             }
+            if (tr && t == 0 && p == 1) tr[13] = wall_clock64();
             if (lane >= 16 ? act : w == 0) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) Tm[(16 * p + q) * LD + row] = a[q];
             }
-            if (bad != 0 && t == 0 && *info == 0) *info = j0 + bad;
+            if (badmask != 0 && t == 0 && *info == 0) *info = j0 + 16 * p + __builtin_ctz(badmask) + 1;
         }
         __syncthreads();
         if (tr && t == 0) tr[6 + 2 * p] = wall_clock64();
         if (p == 3) break;
         // ---- B: columns cb > p:  Tm[16cb + cc][rowbase + rr] -= sum_m P(rowbase + rr, m) P(16cb + cc, m)
-        {
-            // tiles: for cb in p+1..3: T row blocks rb = cb..3 (rowbase 16rb), identity blocks ib = 0..p (rowbase 64+16ib)
-            int cnt = 0;
-#pragma unroll 1
-            for (int cb = p + 1; cb < 4; ++cb) {
-                const int nT_ = 4 - cb, nI = p + 1;
-#pragma unroll 1
-                for (int q = 0; q < nT_ + nI; ++q, ++cnt) {
-                    if ((cnt & 3) != w) continue;
-                    const int rowbase = q < nT_ ? 16 * (cb + q) : 64 + 16 * (q - nT_);
-                    chol_d4 c4;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) c4[e] = Tm[(16 * cb + (lane >> 4) + 4 * e) * LD + rowbase + (lane & 15)];
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        const int m = 16 * p + 4 * s + (lane >> 4);
-                        const double av = -Tm[m * LD + 16 * cb + (lane & 15)];      // A[cc][m] = -P(16cb + cc, m)
-                        const double bv = Tm[m * LD + rowbase + (lane & 15)];       // B[m][rr] =  P(rowbase + rr, m)
-                        c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c4, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) Tm[(16 * cb + (lane >> 4) + 4 * e) * LD + rowbase + (lane & 15)] = c4[e];
-                }
-            }
-        }
+        if (p == 0) df_trail<3>(Tm, 0, w, lane);
+        else if (p == 1) df_trail<2>(Tm, 1, w, lane);
+        else df_trail<1>(Tm, 2, w, lane);
         __syncthreads();
         if (tr && t == 0) tr[7 + 2 * p] = wall_clock64();
     }
@@ -398,14 +446,16 @@ __global__ __launch_bounds__(256) void k_chol_df(DfView V, int n, int nT, const 
                     smem[c * DF_TLD + r] = (r < nc && c < nc) ? (r >= c ? v : 0.0) : (r == c ? 1.0 : 0.0);
                 }
             if (trace && t == 0) trace[task * 16 + 2] = wall_clock64();
+            if (trace && t == 0) trace[task * 16 + 14] = (long long)__builtin_readcyclecounter();
             df_potf2(smem, nc, (int)col0, info, trace ? trace + task * 16 : nullptr);
+            if (trace && t == 0) trace[task * 16 + 15] = (long long)__builtin_readcyclecounter();
             // L -> tile (lower triangle), L^-1 -> Linv[c*64 + i] = Linv(i, c) = smem[i][64 + c]
 #pragma unroll 4
             for (int c = ty; c < NB; c += 4) {
                 // L(k,k) itself is only wanted where the factor stays in S (in place: posterior covariance);
                 // in the compact-tile layout nothing reads the diagonal tile again (the solves use L^-1)
                 if (!V.iperm && tx < nc && c < nc && tx >= c) st_coh(Tik + (int64_t)c * V.ld + tx, smem[c * DF_TLD + tx]);
-                st_coh(Linv + c * NB + tx, (tx < nc && c < nc) ? smem[tx * DF_TLD + 64 + c] : 0.0);
+                st_coh(Linv + c * NB + tx, (tx < nc && c < nc && (c >> 4) <= (tx >> 4)) ? smem[tx * DF_TLD + 64 + c] : 0.0);   // L^-1 is lower triangular
             }
             if (ldiag && ty == 0 && tx < nc) {          // the pivots, by natural index (k_diag_minmax)
                 const int zn = V.iperm ? V.iperm[col0 + tx] : (int)(col0 + tx);
@@ -553,6 +603,12 @@ struct DataflowChol {
                 if (i != k) e = std::max(e, fin[tix[(size_t)k * nT + k]]);
                 est[t] = e;
                 fin[t] = e + (i == k ? 17.0 : 6.0) + (nprod ? 0.0 : -2.0);   // after the last input: its product, then potf2 / the L^-1 product, stores, flag
+            }
+            if (getenv("DBAT_HIP_PLAN_STATS")) {
+                double cp = 0.0;
+                for (int t = 0; t < ntasks; ++t) cp = std::max(cp, fin[t]);
+                fprintf(stderr, "[chol] %d tasks, critical path of the factorisation by the schedule's cost model: %.0f us (= %.1f diagonal + off-diagonal steps)\n",
+                        ntasks, cp, cp / 23.0);
             }
             std::vector<int> ord(ntasks);
             for (int t = 0; t < ntasks; ++t) ord[t] = t;
@@ -718,6 +774,12 @@ struct DataflowChol {
         if (getenv("DBAT_HIP_PLAN_STATS"))
             fprintf(stderr, "[chol] order %d (%d with block padding, %zu blocks), %d tile rows, %d tiles (%.1f MB), dense lower triangle would be %d tiles\n",
                     n_nat, n, block_end.size(), nT, ntiles, ntiles * 32768.0 / 1e6, nT * (nT + 1) / 2 + nT);
+        if (getenv("DBAT_HIP_PLAN_STATS")) {
+            fprintf(stderr, "[chol] cameras per block, last (root separator) first:");
+            for (size_t b = block_end.size(); b-- > 0 && block_end.size() - b <= 24;)
+                fprintf(stderr, " %d", block_end[b] - (b ? block_end[b - 1] : 0));
+            fprintf(stderr, "\n");
+        }
         return finish_setup(rb, toff);
     }
     // Factor and solve S q = b (b' in row n of S, lower triangle of S, leading dimension lda).
