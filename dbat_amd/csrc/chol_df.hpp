@@ -278,7 +278,7 @@ struct DfView {
 __device__ __forceinline__ bool df_backward(double *smem, const DfView &V, int n, int nT, int j,
                                             const int *__restrict__ bk_ptr, const int *__restrict__ bk_idx,
                                             const int *flags, int epoch, int *abort_flag, const double *linv_all,
-                                            double *q_out, double *q_nat) {
+                                            double *q_out, double *q_nat, const double *qscale, double *dz_out) {
     constexpr int NB = 64, LD = 65;
     const int t = threadIdx.x, tx = t & 63, ty = t >> 6;
     const int nc = min(NB, n - NB * j);
@@ -341,9 +341,10 @@ __device__ __forceinline__ bool df_backward(double *smem, const DfView &V, int n
         double qj = (red[tx] + red[NB + tx]) + (red[2 * NB + tx] + red[3 * NB + tx]);
         if (qj != qj) qj = __longlong_as_double(0x7ff8000000000000ll);   // any NaN -> the canonical one, never DF_SENTINEL
         st_coh(q_out + col0 + tx, qj);
-        if (q_nat != q_out) {
+        if (q_nat != q_out || dz_out) {
             const int zn = V.iperm ? V.iperm[col0 + tx] : (int)(col0 + tx);
-            if (zn >= 0) q_nat[zn] = qj;                 // < 0: padding row of the permuted system
+            if (zn >= 0 && q_nat != q_out) q_nat[zn] = qj;          // < 0: padding row of the permuted system
+            if (zn >= 0 && dz_out) dz_out[zn] = qscale[zn] * qj;    // the step of the unscaled system (D q)
         }
     }
     __syncthreads();                                    // smem is reused by the next task
@@ -355,7 +356,8 @@ __global__ __launch_bounds__(256) void k_chol_df(DfView V, int n, int nT, const 
                                                  double *__restrict__ linv_all, int *__restrict__ info,
                                                  long long *__restrict__ trace, const int *__restrict__ bk_ptr,
                                                  const int *__restrict__ bk_idx, double *__restrict__ q_out,
-                                                 double *__restrict__ q_nat, double *__restrict__ ldiag) {
+                                                 double *__restrict__ q_nat, double *__restrict__ ldiag,
+                                                 const double *__restrict__ qscale, double *__restrict__ dz_out) {
     constexpr int NB = 64, LD = DF_LD;
     __shared__ double smem[2 * NB * LD];                // Pm | Qm, or the augmented block of df_potf2
     double *Pm = smem, *Qm = smem + NB * LD;
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(256) void k_chol_df(DfView V, int n, int nT, const 
             if (q_out == nullptr || task >= ntasks + nT) return;
             if (trace && t == 0) trace[task * 16 + 0] = wall_clock64();
             if (!df_backward(smem, V, n, nT, nT - 1 - (task - ntasks), bk_ptr, bk_idx, flags, epoch, abort_flag,
-                             linv_all, q_out, q_nat)) {
+                             linv_all, q_out, q_nat, qscale, dz_out)) {
                 if (t == 0) *info = -1;
                 return;
             }
@@ -500,8 +502,12 @@ __global__ __launch_bounds__(256) void k_chol_df(DfView V, int n, int nT, const 
 // -> the non-zero tiles of P S P' in compact storage.  One workgroup per tile.
 __global__ __launch_bounds__(256) void k_gather_tiles(const double *__restrict__ S, int64_t ldS, int n_nat, int nT,
                                                       const int *__restrict__ iperm, const DfTask *__restrict__ tile_ij,
-                                                      double *__restrict__ tiles) {
+                                                      double *__restrict__ tiles, int *__restrict__ info,
+                                                      int *__restrict__ ctl, unsigned long long *__restrict__ qflag) {
     const DfTask tk = tile_ij[blockIdx.x];
+    // what k_chol_df expects to find reset: error code, task counter / abort flag, "not solved yet" in q
+    if (blockIdx.x == 0 && threadIdx.x < 3) { if (threadIdx.x == 0) *info = 0; else ctl[threadIdx.x - 1] = 0; }
+    if (tk.i == tk.k && threadIdx.x < 64) qflag[64 * tk.k + threadIdx.x] = DF_SENTINEL;
     double *T = tiles + (size_t)blockIdx.x * 4096;
     for (int idx = threadIdx.x; idx < 4096; idx += 256) {
         const int c = idx >> 6, r = idx & 63;
@@ -788,24 +794,25 @@ struct DataflowChol {
     // BlockChol::linv_doubles.  info_dev: > 0 first non-positive pivot (index in the factorised
     // order), -1 dataflow abort (spin cap).
     void solve(hipStream_t stream, double *A, int64_t lda, double *q_out, double *linv_work, int *info_dev,
-               double *ldiag = nullptr) {
-        (void)hipMemsetAsync(info_dev, 0, sizeof(int), stream);
-        (void)hipMemsetAsync(d_ctl, 0, 2 * sizeof(int), stream);
+               double *ldiag = nullptr, const double *qscale = nullptr, double *dz_out = nullptr) {
         if (d_trace) (void)hipMemsetAsync(d_trace, 0, (size_t)(ntasks + nT) * 16 * sizeof(long long), stream);
         ++epoch;
         DfView V;
         V.toff = d_toff; V.rowbits = d_rowbits; V.W = W;
         double *qflag;
-        if (permuted) {
-            hipLaunchKernelGGL(k_gather_tiles, dim3(ntiles), dim3(256), 0, stream, A, lda, n_nat, nT, d_iperm, d_tile_ij, d_tiles);
+        if (permuted) {      // the gather also resets info, the task counter and the q flags (every tile row has its diagonal tile)
+            hipLaunchKernelGGL(k_gather_tiles, dim3(ntiles), dim3(256), 0, stream, A, lda, n_nat, nT, d_iperm, d_tile_ij, d_tiles,
+                               info_dev, d_ctl, reinterpret_cast<unsigned long long *>(d_qperm));
             V.base = d_tiles; V.ld = 64; V.iperm = d_iperm; qflag = d_qperm;
-            (void)hipMemsetAsync(d_qperm, 0xFF, (size_t)nT * CHOL_NB * sizeof(double), stream);   // DF_SENTINEL
         } else {
+            (void)hipMemsetAsync(info_dev, 0, sizeof(int), stream);
+            (void)hipMemsetAsync(d_ctl, 0, 2 * sizeof(int), stream);
             V.base = A; V.ld = lda; V.iperm = nullptr; qflag = q_out;
             (void)hipMemsetAsync(q_out, 0xFF, (size_t)n * sizeof(double), stream);
         }
         hipLaunchKernelGGL(k_chol_df, dim3(std::min(grid, ntasks + nT)), dim3(256), 0, stream, V, n, nT, d_tasks, ntasks,
-                           d_flags, d_ctl, epoch, linv_work, info_dev, d_trace, d_bk_ptr, d_bk_idx, qflag, q_out, ldiag);
+                           d_flags, d_ctl, epoch, linv_work, info_dev, d_trace, d_bk_ptr, d_bk_idx, qflag, q_out, ldiag,
+                           qscale, dz_out);
     }
 };
 

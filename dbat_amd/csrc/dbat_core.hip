@@ -114,7 +114,10 @@ struct Core {
     int64_t ngiant = 0;
     int giant_threads = 256;            // DBAT_HIP_GIANT_THREADS (64/128/256): tests force several chunks per point
     // state
-    DevBuf<CamRec> cams;
+    DevBuf<CamRec> cams, cams_f;                     // camera records at the linearisation point / at the last objective evaluation
+    bool cams_at_lin = false;                        // cams holds the records of zlin
+    DevBuf<unsigned> gctr;                           // tickets of the in-kernel grid sums (zero between launches)
+    DevBuf<double> gpart, rpart;                     // their per-block partial sums; sink of k_residual's (unused) sums
     DevBuf<double> z, zt, dz, zlin, vtmp, vtmp2, xbuf;  // NZ each (xbuf: n)
     DevBuf<double> red;      // [S | g_red | g_c | diagU | scal(8)]
     DevBuf<double> jn2c, dscale, rhs, Vinv, gp, jn2p, partial, scal;
@@ -136,7 +139,7 @@ struct Core {
     int64_t pk_s_count = 0;
     int env_tail0 = 0;
     int64_t nb = 0, nobs = 0;
-    int grid_obs = 1, grid_z = 1;
+    int grid_obs = 1, grid_z = 1, grid_zs = 1;       // grid_zs: blocks of 1024 threads of the kernels that end in a grid sum
     size_t lds_build = 0, lds_back = 0;
     // multi-GPU: the RCCL communicator of this handle's rank (dbat_hip_comm_init), or the
     // caller's all-reduce callback (gloo / host tests)
@@ -220,7 +223,7 @@ struct Core {
             if (!P.uniform_w) sg_w.upload(P.sg_w);
             sig_rb = P.sg_rows_max <= 64 ? 4 : 5;
         }
-        cams.alloc(P.nc);
+        cams.alloc(P.nc); cams_f.alloc(P.nc);
         z.alloc(P.NZ); zt.alloc(P.NZ); dz.alloc(P.NZ); zlin.alloc(P.NZ); vtmp.alloc(P.NZ); vtmp2.alloc(P.NZ);
         xbuf.alloc(std::max<int64_t>(P.n, 1));
         ldS = ((P.NS + 1 + 7) / 8) * 8;
@@ -272,9 +275,13 @@ struct Core {
         HIPCHK(hipMemset(jn2p.p, 0, (size_t)3 * P.np * 8));
         grid_obs = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(nobs, 256), env_grid_obs()));
         grid_z = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(P.NZ, 256), 2048));
+        grid_zs = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(P.NZ, 2048), 256));
         scal.alloc((size_t)16 + 2 * (size_t)P.nranks);
         info.alloc(1);
         pivmm.alloc(4);
+        gctr.alloc(16); HIPCHK(hipMemset(gctr.p, 0, 16 * sizeof(unsigned)));
+        rpart.alloc((size_t)grid_obs);
+        gpart.alloc((size_t)8 * std::max<int64_t>(std::max<int64_t>(grid_z, cdiv(P.NS, 256)), 2048));
         lds_build = ((size_t)P.BT * P.ncolmax * 3 + (size_t)P.BT * 18) * sizeof(double);
         lds_back = (size_t)P.BT * 6 * sizeof(double);
         // wave-specialised tile kernel: 256-observation batches, 16-point chunks, 2 panels
@@ -376,8 +383,9 @@ struct Core {
         HIPCHK(hipMemcpyAsync(host, scal.p, n * sizeof(double), hipMemcpyDeviceToHost, stream));
         sync();
     }
-    void prep_cams(const double *zz) {
-        LAUNCHK(k_cam_prep, dim3((unsigned)cdiv(P.nc, 64)), dim3(64), 0, stream, d, zz, cams.p);
+    void prep_cams(const double *zz, CamRec *into = nullptr) {
+        if (!into) { into = cams.p; cams_at_lin = false; }      // build() sets it again once zlin == zz
+        LAUNCHK(k_cam_prep, dim3((unsigned)cdiv(P.nc, 64)), dim3(64), 0, stream, d, zz, into);
     }
     void x_to_z(const double *x_host, double *z_dev) {
         // z keeps fixed entries; estimated entries overwritten from x
@@ -405,28 +413,29 @@ struct Core {
 
     // ---- K2: f = 0.5 r'r at zz (all ranks' sum).  Optionally store r.
     double eval_f(const double *zz, double *r_w_out, double *r_unw_out) {
-        prep_cams(zz);
+        // own camera records: the ones of the linearisation point stay valid for the next solve
+        prep_cams(zz, cams_f.p);
         mark(6);
         // the objective value always comes from the camera-major kernel (one summation order for
-        // every value the damping loops compare); the point-major one only when residuals are exported
-        int64_t npart_res = n_cm_chunks_all;
+        // every value the damping loops compare); the point-major one only when residuals are exported.
+        // Both kernels finish their grid sums themselves; the second one adds the prior rows and hands
+        // the total to the pinned mailbox (one rank) or to scal[0] for the all-reduce.
         if (n_cm_chunks_all > 0) {
-#define L_RESCM(M, dummy) LAUNCHK((k_residual_cm<M>), dim3((unsigned)n_cm_chunks_all), dim3(256), 0, stream, d, zz, cams.p, cm_pt.p, cm_uv.p, P.uniform_w ? (const double *)nullptr : cm_w.p, cm_chunk_cam.p, cm_chunk_start.p, partial.p)
+#define L_RESCM(M, dummy) LAUNCHK((k_residual_cm<M>), dim3((unsigned)n_cm_chunks_all), dim3(256), 0, stream, d, zz, cams_f.p, cm_pt.p, cm_uv.p, P.uniform_w ? (const double *)nullptr : cm_w.p, cm_chunk_cam.p, cm_chunk_start.p, partial.p)
             DISPATCH_MODEL(L_RESCM, 0)
 #undef L_RESCM
         }
         mark(7);
-        LAUNCHK((k_sum_partials<1>), dim3(1), dim3(1024), 0, stream, partial.p, npart_res, scal.p, 0);
         if (r_w_out || r_unw_out) {
-#define L_RES(M, dummy) LAUNCHK((k_residual<M>), dim3(grid_obs), dim3(256), 0, stream, d, zz, cams.p, partial.p, r_w_out, r_unw_out)
+#define L_RES(M, dummy) LAUNCHK((k_residual<M>), dim3(grid_obs), dim3(256), 0, stream, d, zz, cams_f.p, rpart.p, r_w_out, r_unw_out)
             DISPATCH_MODEL(L_RES, 0)
 #undef L_RES
         }
-        LAUNCHK(k_prior_sq, dim3(grid_z), dim3(256), 0, stream, d, zz, partial.p);
-        LAUNCHK((k_sum_partials<1>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_z, scal.p, 1);
-        do_allreduce(scal.p, 1);
+        LAUNCHK(k_prior_sq, dim3(grid_zs), dim3(1024), 0, stream, d, zz, gpart.p, gctr.p + 1, (const double *)partial.p, n_cm_chunks_all,
+                scal.p, multi() ? (double *)nullptr : hpin);
         double s;
-        read_scal(&s, 1);
+        if (multi()) { do_allreduce(scal.p, 1); read_scal(&s, 1); }
+        else { sync(); s = hpin[0]; }
         ++n_res_evals;
         return 0.5 * s;
     }
@@ -436,14 +445,16 @@ struct Core {
         prep_cams(zz);
         // only the envelope of S is ever written or read: zero that (and the vectors behind S); the whole
         // array once, and again after something filled it densely (the inverse of the posterior covariance)
+        bool pivmm_set = false;
         if (s_dense_dirty || getenv("DBAT_HIP_DENSE_ALLREDUCE")) {
             HIPCHK(hipMemsetAsync(red.p, 0, red_count * sizeof(double), stream));
             s_dense_dirty = false;
         } else {
-            LAUNCHK(k_envelope_op, dim3((unsigned)P.NS), dim3(256), 0, stream, S, ldS, (int)P.NS, env_tail0, col_bend.p, (const double *)nullptr);
-            HIPCHK(hipMemsetAsync(g_red, 0, (size_t)(3 * P.NS + 8) * sizeof(double), stream));
+            // ... and the vectors behind S, and the pivot extremes {min, max} x {points, cameras}
+            LAUNCHK(k_envelope_op, dim3((unsigned)P.NS), dim3(256), 0, stream, S, ldS, (int)P.NS, env_tail0, col_bend.p, (const double *)nullptr, g_red, pivmm.p);
+            pivmm_set = true;
         }
-        HIPCHK(hipMemcpyAsync(pivmm.p, hpin + 48, 4 * sizeof(double), hipMemcpyHostToDevice, stream));   // {min, max} x {points, cameras}
+        if (!pivmm_set) HIPCHK(hipMemcpyAsync(pivmm.p, hpin + 48, 4 * sizeof(double), hipMemcpyHostToDevice, stream));
         // tiled batches through the MFMA kernel, the remaining ("heavy point") batches
         // -- or all of them when tiling is off -- through k_build
         int64_t npart = 0;
@@ -511,27 +522,20 @@ struct Core {
             memset(h, 0, sizeof(h));
             HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_tile2_prof), h, sizeof(h)));
         }
-        LAUNCHK((k_sum_partials<1>), dim3(1), dim3(1024), 0, stream, partial.p, npart, red_scal, 0);
-        LAUNCHK(k_prior_sq, dim3(grid_z), dim3(256), 0, stream, d, zz, partial.p);
-        LAUNCHK((k_sum_partials<1>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_z, red_scal, 1);
-        // owned squared column norms of the point columns -> red_scal[1]
-        LAUNCHK(k_dot, dim3(grid_z), dim3(256), 0, stream, (int64_t)3 * P.np, z_mine.p + P.NS, jn2p.p, (const double *)nullptr, partial.p);
-        LAUNCHK((k_sum_partials<1>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_z, red_scal + 1, 0);
+        // red_scal[0] = the build kernels' residual sums + the prior rows' squares, red_scal[1] = owned
+        // squared column norms of the point columns
+        LAUNCHK(k_build_tail, dim3(grid_zs), dim3(1024), 0, stream, d, zz, partial.p, npart, jn2p.p, gpart.p, gctr.p + 2, red_scal);
     }
     void build(const double *zz, double lambda, int scale) {
         build_enqueue(zz, lambda, scale);
         allreduce_system();
-        finish_enqueue(zz, lambda, scale);
+        finish_enqueue(zz, lambda, scale);           // also: trace(J'J) of the camera part and red_scal -> mailbox
         if (zz != zlin.p) HIPCHK(hipMemcpyAsync(zlin.p, zz, P.NZ * 8, hipMemcpyDeviceToDevice, stream));
+        cams_at_lin = true;                          // build_enqueue prepared them at zz
+        sync();
         // trace(J'J): camera part from jn2c (estimated), point part from red_scal[1]
-        LAUNCHK(k_dot, dim3(grid_z), dim3(256), 0, stream, P.NS, z_est.p, jn2c.p, (const double *)nullptr, partial.p);
-        LAUNCHK((k_sum_partials<1>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_z, scal.p, 0);
-        double hs[2], hr[2];
-        HIPCHK(hipMemcpyAsync(hpin + 32, red_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
-        read_scal(hs, 1);
-        hr[0] = hpin[32]; hr[1] = hpin[33];
-        f_lin = 0.5 * hr[0];
-        trace_jtj = hs[0] + hr[1];
+        f_lin = 0.5 * hpin[32];
+        trace_jtj = hpin[0] + hpin[33];
         lambda_lin = lambda;
         scale_lin = scale;
         have_lin = true;
@@ -539,7 +543,8 @@ struct Core {
         ++n_lin;
     }
     void finish_enqueue(const double *zz, double lambda, int scale) {
-        LAUNCHK(k_finish, dim3((unsigned)cdiv(P.NS, 256)), dim3(256), 0, stream, d, zz, lambda, scale, S, g_c, g_red, diagU, jn2c.p, dscale.p);
+        LAUNCHK(k_finish, dim3((unsigned)cdiv(P.NS, 256)), dim3(256), 0, stream, d, zz, lambda, scale, S, g_c, g_red, diagU, jn2c.p, dscale.p,
+                gpart.p, gctr.p + 3, (const double *)red_scal, scal.p, hpin);
         if (scale)      // D S D on the envelope
             LAUNCHK(k_envelope_op, dim3((unsigned)P.NS), dim3(256), 0, stream, S, ldS, (int)P.NS, env_tail0, col_bend.p, (const double *)dscale.p);
     }
@@ -548,9 +553,12 @@ struct Core {
     int factor_solve_enqueue() {
         mark(2);
         // Cholesky + both substitutions; q -> rhs.  One persistent dataflow kernel (chol_df.hpp)
-        if (use_perm && !chol_in_place) dfchol.solve(stream, S, ldS, rhs.p, linv.p, info.p, ldiag.p);
-        else if (use_df) dfchol_ip.solve(stream, S, ldS, rhs.p, linv.p, info.p, ldiag.p);
+        // (the dataflow kernel also writes the step of the unscaled system dc = D q)
+        bool unscaled = true;
+        if (use_perm && !chol_in_place) dfchol.solve(stream, S, ldS, rhs.p, linv.p, info.p, ldiag.p, dscale.p, dz.p);
+        else if (use_df) dfchol_ip.solve(stream, S, ldS, rhs.p, linv.p, info.p, ldiag.p, dscale.p, dz.p);
         else {
+            unscaled = false;
             BlockChol::solve(blas, stream, S, ldS, (int)P.NS, rhs.p, ywork.p, linv.p, info.p, env);
             HIPCHK(hipMemcpy2DAsync(ldiag.p, sizeof(double), S, (ldS + 1) * sizeof(double), sizeof(double), (size_t)P.NS,
                                     hipMemcpyDeviceToDevice, stream));
@@ -558,8 +566,8 @@ struct Core {
         HIPCHK(hipGetLastError());                   // launches inside the factorisation helpers
         if (const char *tp = getenv("DBAT_HIP_DF_TRACE")) (use_perm && !chol_in_place ? dfchol : dfchol_ip).dump_trace(stream, tp);
         mark(3);
-        LAUNCHK(k_diag_minmax, dim3(1), dim3(256), 0, stream, d, ldiag.p, pivmm.p + 2);
-        LAUNCHK(k_unscale, dim3((unsigned)cdiv(P.NS, 256)), dim3(256), 0, stream, P.NS, rhs.p, dscale.p, dz.p);
+        // the pivot extremes of the reduced system are taken in k_prior_jv (the tail of the solve)
+        if (!unscaled) LAUNCHK(k_unscale, dim3((unsigned)cdiv(P.NS, 256)), dim3(256), 0, stream, P.NS, rhs.p, dscale.p, dz.p);
         ++n_solves;
         return 0;
     }
@@ -588,9 +596,11 @@ struct Core {
 #undef L_BACKG
         }
         mark(5);
-        LAUNCHK((k_sum_partials<2>), dim3(1), dim3(1024), 0, stream, partial.p + 2 * b_first, nb - b_first + ngiant + n_sig_wg, scal.p, 0);
-        LAUNCHK(k_prior_jv, dim3(grid_z), dim3(256), 0, stream, d, zlin.p, dz.p, g_c, gp.p, partial.p);
-        LAUNCHK((k_sum_partials<3>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_z, scal.p + 4, 0);
+        // one launch: the sums of the back-substitution kernels, the prior rows' share, g'p, p'p, the pivot
+        // extremes of the reduced system; on one rank straight into the pinned mailbox
+        LAUNCHK(k_prior_jv, dim3(grid_zs), dim3(1024), 0, stream, d, zlin.p, dz.p, g_c, gp.p, gpart.p, gctr.p + 4,
+                (const double *)(partial.p + 2 * b_first), nb - b_first + ngiant + n_sig_wg, (const double *)ldiag.p, pivmm.p,
+                (const int *)info.p, scal.p, multi() ? (double *)nullptr : hpin);
     }
     // solve at the current linearisation: p in dz.  Returns true if the
     // factorisation failed outright (non-positive pivot / non-finite step);
@@ -602,22 +612,25 @@ struct Core {
         if (!s_valid) build(zlin.p, lambda_lin, scale_lin);   // the factorisation overwrote S
         s_valid = false;
         factor_solve_enqueue();
-        prep_cams(zlin.p);
+        if (!cams_at_lin) { prep_cams(zlin.p); cams_at_lin = true; }     // something else used the camera records since build()
         backsub_enqueue();
         int hinfo = 0;
         unsigned long long hmm[4];
-        HIPCHK(hipMemcpyAsync(hpin + 40, pivmm.p, sizeof(hmm), hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipMemcpyAsync(hpin + 44, info.p, sizeof(hinfo), hipMemcpyDeviceToHost, stream));
         // one all-reduce per solve: the 8 scalar sums and, behind them, one {min,max} slot per rank
         // with this rank's point-block pivots (the extremes travel through the sum)
         const int nsl = multi() ? 2 * P.nranks : 0;
+        std::vector<double> h((size_t)8 + nsl);
         if (nsl) {
+            HIPCHK(hipMemcpyAsync(hpin + 40, pivmm.p, sizeof(hmm), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipMemcpyAsync(hpin + 44, info.p, sizeof(hinfo), hipMemcpyDeviceToHost, stream));
             HIPCHK(hipMemsetAsync(scal.p + 8, 0, (size_t)nsl * sizeof(double), stream));
             HIPCHK(hipMemcpyAsync(scal.p + 8 + 2 * P.rank, pivmm.p, 2 * sizeof(double), hipMemcpyDeviceToDevice, stream));
             do_allreduce(scal.p, 8 + nsl);
+            read_scal(h.data(), 8 + nsl);
+        } else {             // k_prior_jv left everything in the mailbox
+            sync();
+            memcpy(h.data(), hpin, 8 * sizeof(double));
         }
-        std::vector<double> h((size_t)8 + nsl);
-        read_scal(h.data(), 8 + nsl);
         memcpy(hmm, hpin + 40, sizeof(hmm));
         memcpy(&hinfo, hpin + 44, sizeof(hinfo));
         JpJp = h[0] + h[4]; rJp = h[1] + h[5]; pp = h[6];
@@ -685,13 +698,12 @@ struct Core {
     }
     // ||J v||^2 and r'Jv at the linearisation point, ||v||^2 over owned entries
     void jtimes(const double *v, double &JvJv, double &rJv, double &vv) {
-        prep_cams(zlin.p);
+        if (!cams_at_lin) { prep_cams(zlin.p); cams_at_lin = true; }
 #define L_JT(M, NCXV) LAUNCHK((k_jtimes<M, NCXV>), dim3(grid_obs), dim3(256), 0, stream, d, zlin.p, cams.p, v, partial.p)
         if (tile_ncx == 6) { DISPATCH_MODEL(L_JT, 6) } else if (tile_ncx == 14) { DISPATCH_MODEL(L_JT, 14) } else { DISPATCH_MODEL(L_JT, MAXCOL) }
 #undef L_JT
-        LAUNCHK((k_sum_partials<2>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_obs, scal.p, 0);
-        LAUNCHK(k_prior_jv, dim3(grid_z), dim3(256), 0, stream, d, zlin.p, v, g_c, gp.p, partial.p);
-        LAUNCHK((k_sum_partials<3>), dim3(1), dim3(1024), 0, stream, partial.p, (int64_t)grid_z, scal.p + 4, 0);
+        LAUNCHK(k_prior_jv, dim3(grid_zs), dim3(1024), 0, stream, d, zlin.p, v, g_c, gp.p, gpart.p, gctr.p + 4,
+                (const double *)partial.p, (int64_t)grid_obs, (const double *)nullptr, pivmm.p, (const int *)info.p, scal.p, (double *)nullptr);
         do_allreduce(scal.p, 8);
         double h[8];
         read_scal(h, 8);

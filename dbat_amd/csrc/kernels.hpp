@@ -120,6 +120,51 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double *sh /* >= NV*n
     __syncthreads();
 }
 
+// Grid-wide sum without a second launch.  Every block publishes its NV sums (agent-scope stores:
+// the L2 of the eight XCDs are not coherent among themselves), waits for them, and takes a ticket;
+// the block that draws the last ticket adds all the blocks' sums up in a FIXED order (thread t takes
+// blocks t, t + T, ...; then the block reduction), so the result does not depend on which block
+// finishes last.  Returns true in that block, with the totals in v[] of thread 0.  *ctr is zero on
+// entry and zero again on exit.  extra/n_extra: NV-interleaved partial sums of an EARLIER launch
+// (plain loads) that the last block adds on top: element i < NX of each goes to v[XO + i].  Atomics
+// of the calling kernel that the last block is to read must be waited for by their own waves.
+template <int NV, int NX = 0, int XO = 0>
+__device__ __forceinline__ bool grid_sum(double (&v)[NV], double *sh /* >= NV*nwaves */, double *__restrict__ partial,
+                                         unsigned *__restrict__ ctr, const double *__restrict__ extra = nullptr,
+                                         int64_t n_extra = 0, int extra_stride = 1) {
+    __shared__ int s_last;
+    block_sum<NV>(v, sh);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            __hip_atomic_store(partial + (int64_t)NV * blockIdx.x + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0);               // the stores (and this block's other atomics) have been performed
+        s_last = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return false;
+    double acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = 0.0;
+    for (int64_t b = threadIdx.x; b < gridDim.x; b += blockDim.x)
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            acc[i] += __hip_atomic_load(partial + NV * b + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if constexpr (NX > 0) {
+        for (int64_t b = threadIdx.x; b < n_extra; b += blockDim.x)
+#pragma unroll
+            for (int i = 0; i < NX; ++i) acc[XO + i] += extra[extra_stride * b + i];
+    }
+    __syncthreads();                                 // sh is reused
+    block_sum<NV>(acc, sh);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = acc[i];
+        __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return true;
+}
+
 // ---------------------------------------------------------------- K2 ----
 // Residual only.  partial[blockIdx] = sum of squared weighted residuals.
 // r_w (weighted, processing order) and r_unw (mm, reference row order) optional.
@@ -175,21 +220,46 @@ __global__ __launch_bounds__(256) void k_residual_cm(DevProblem d, const double 
         acc[0] += r[0] * r[0] + r[1] * r[1];
     }
     block_sum<1>(acc, sh);
-    if (threadIdx.x == 0) partial[blockIdx.x] = acc[0];
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc[0];      // summed by k_prior_sq (thousands of tickets on one address cost more)
 }
 
-// prior-observation rows (prior_obs.m:26-43): sum over owned z of w*(z-prior)^2
-__global__ __launch_bounds__(256) void k_prior_sq(DevProblem d, const double *__restrict__ z,
-                                                  double *__restrict__ partial) {
-    __shared__ double sh[8];
+// prior-observation rows (prior_obs.m:26-43): sum over owned z of w*(z-prior)^2, plus the n_res partial
+// sums res_partial of the residual kernel launched before.  The total goes to out[0] and
+// (mailbox != null) to the host's pinned mailbox.  Few, large blocks: a grid sum costs one
+// ticket per block on a single address.
+__global__ __launch_bounds__(1024) void k_prior_sq(DevProblem d, const double *__restrict__ z,
+                                                   double *__restrict__ partial, unsigned *__restrict__ ctr,
+                                                   const double *__restrict__ res_partial, int64_t n_res,
+                                                   double *__restrict__ out, double *__restrict__ mailbox) {
+    __shared__ double sh[16];
     double acc[1] = {0.0};
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.NZ; i += stride) {
         const double w = d.z_prw[i];
         if (w > 0 && d.z_mine[i]) { const double e = z[i] - d.z_prv[i]; acc[0] += w * e * e; }
     }
-    block_sum<1>(acc, sh);
-    if (threadIdx.x == 0) partial[blockIdx.x] = acc[0];
+    if (grid_sum<1, 1>(acc, sh, partial, ctr, res_partial, n_res) && threadIdx.x == 0) {
+        out[0] = acc[0];
+        if (mailbox) mailbox[0] = acc[0];
+    }
+}
+
+// After the build kernels: {sum of their npart residual partials + the prior rows' squares,
+// owned squared column norms of the point columns} -> out[0], out[1].  One launch.
+__global__ __launch_bounds__(1024) void k_build_tail(DevProblem d, const double *__restrict__ z,
+                                                     const double *__restrict__ build_partial, int64_t npart,
+                                                     const double *__restrict__ jn2p, double *__restrict__ partial,
+                                                     unsigned *__restrict__ ctr, double *__restrict__ out) {
+    __shared__ double sh[32];
+    double acc[2] = {0.0, 0.0};
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.NZ; i += stride) {
+        const double w = d.z_prw[i];
+        const bool mine = d.z_mine[i] != 0;
+        if (w > 0 && mine) { const double e = z[i] - d.z_prv[i]; acc[0] += w * e * e; }
+        if (i >= d.NS && mine) acc[1] += jn2p[i - d.NS];
+    }
+    if (grid_sum<2, 1>(acc, sh, partial, ctr, build_partial, npart) && threadIdx.x == 0) { out[0] = acc[0]; out[1] = acc[1]; }
 }
 
 // sum npart partials (NV interleaved values each) into out[NV]; single block
@@ -1881,8 +1951,14 @@ __global__ __launch_bounds__(256) void k_pack_envelope(double *__restrict__ S, i
 // by the factorisation, and at C4 the dense 30 032^2 array is 7.2 GB.
 __global__ __launch_bounds__(256) void k_envelope_op(double *__restrict__ S, int64_t ldS, int NS, int tail0,
                                                      const int *__restrict__ col_bend,
-                                                     const double *__restrict__ ds /* null: zero */) {
+                                                     const double *__restrict__ ds /* null: zero */,
+                                                     double *__restrict__ vec = nullptr /* [3 NS + 8] zeroed with S */,
+                                                     unsigned long long *__restrict__ pivmm = nullptr /* reset */) {
     const int c = blockIdx.x;
+    if (vec && threadIdx.x < 3) vec[(int64_t)threadIdx.x * NS + c] = 0.0;
+    if (c == 0 && vec && threadIdx.x >= 64 && threadIdx.x < 72) vec[(int64_t)3 * NS + (threadIdx.x - 64)] = 0.0;
+    if (c == 0 && pivmm && threadIdx.x >= 128 && threadIdx.x < 132)       // {min, max} x {points, cameras}
+        pivmm[threadIdx.x - 128] = (threadIdx.x & 1) ? 0ull : (unsigned long long)__double_as_longlong(1e300);
     const int be = col_bend[c];
     const int nband = be - c;
     const int t0 = max(tail0, be);
@@ -1924,28 +2000,38 @@ __global__ __launch_bounds__(256) void k_diag_minmax(DevProblem d, const double 
 __global__ void k_finish(DevProblem d, const double *__restrict__ z, double lambda, int scale,
                          double *__restrict__ S, double *__restrict__ g_c, double *__restrict__ g_red,
                          const double *__restrict__ diagU, double *__restrict__ jn2c,
-                         double *__restrict__ dscale) {
+                         double *__restrict__ dscale, double *__restrict__ partial, unsigned *__restrict__ ctr,
+                         const double *__restrict__ red_scal, double *__restrict__ out,
+                         double *__restrict__ mailbox) {
+    __shared__ double sh[8];
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= d.NS) return;
-    const double pw = d.z_prw[i];
-    double add = 0, g = g_red[i], jn2 = diagU[i];
-    if (pw > 0) {
-        const double e = pw * (z[i] - d.z_prv[i]);
-        add += pw; g += e; jn2 += pw; g_c[i] += e; g_red[i] = g;
+    double acc[1] = {0.0};                           // trace(J'J), camera/IO part: estimated columns
+    if (i < d.NS) {
+        const double pw = d.z_prw[i];
+        double add = 0, g = g_red[i], jn2 = diagU[i];
+        if (pw > 0) {
+            const double e = pw * (z[i] - d.z_prv[i]);
+            add += pw; g += e; jn2 += pw; g_c[i] += e; g_red[i] = g;
+        }
+        jn2c[i] = jn2;
+        const bool est = d.z_est[i] != 0;
+        double ds = 1.0;
+        if (est) {
+            add += lambda;
+            if (scale && jn2 > 0) ds = 1.0 / sqrt(jn2);
+            S[i * d.ldS + i] += add;
+            S[i * d.ldS + d.NS] = -ds * g;
+            acc[0] = jn2;
+        } else {
+            S[i * d.ldS + i] = 1.0;
+            S[i * d.ldS + d.NS] = 0.0;
+        }
+        dscale[i] = ds;
     }
-    jn2c[i] = jn2;
-    const bool est = d.z_est[i] != 0;
-    double ds = 1.0;
-    if (est) {
-        add += lambda;
-        if (scale && jn2 > 0) ds = 1.0 / sqrt(jn2);
-        S[i * d.ldS + i] += add;
-        S[i * d.ldS + d.NS] = -ds * g;
-    } else {
-        S[i * d.ldS + i] = 1.0;
-        S[i * d.ldS + d.NS] = 0.0;
+    if (grid_sum<1>(acc, sh, partial, ctr) && threadIdx.x == 0) {
+        out[0] = acc[0];
+        if (mailbox) { mailbox[0] = acc[0]; mailbox[32] = red_scal[0]; mailbox[33] = red_scal[1]; }
     }
-    dscale[i] = ds;
 }
 
 // out = in where this rank owns the entry, 0 elsewhere (sum over ranks = the full vector)
@@ -2161,21 +2247,56 @@ __global__ __launch_bounds__(256) void k_jtimes(DevProblem d, const double *__re
 // {prior rows' share of ||Jv||^2, r'Jv of ALL rows, ||v||^2 (owned)}: out[3] per block.
 // r'Jv = (J'r)'v = g'v with the gradient of the last linearisation (g_c incl. the camera/IO
 // priors, g_p incl. the point priors): no pass over the observations, no stored residual.
-__global__ __launch_bounds__(256) void k_prior_jv(DevProblem d, const double *__restrict__ z,
+// The tail of a solve in one launch: the sums above -> out[4..6]; the back-substitution kernels'
+// (or k_jtimes') nbs partial sum pairs over the image rows -> out[0], out[1]; the extremes
+// of the Cholesky pivots ldiag of the reduced system (estimated entries) -> pivmm[2..3]; and,
+// with a mailbox, everything the host reads after a solve: out[0..7] -> mailbox[0..7],
+// pivmm[0..3] -> mailbox[40..43], *info -> mailbox[44].
+__global__ __launch_bounds__(1024) void k_prior_jv(DevProblem d, const double *__restrict__ z,
                                                   const double *__restrict__ v, const double *__restrict__ g_c,
-                                                  const double *__restrict__ gp, double *__restrict__ partial) {
-    __shared__ double sh[24];
-    double acc[3] = {0, 0, 0};
+                                                  const double *__restrict__ gp, double *__restrict__ partial,
+                                                  unsigned *__restrict__ ctr, const double *__restrict__ bs_partial,
+                                                  int64_t nbs, const double *__restrict__ ldiag,
+                                                  unsigned long long *__restrict__ pivmm, const int *__restrict__ info,
+                                                  double *__restrict__ out, double *__restrict__ mailbox) {
+    __shared__ double sh[80];
+    double acc[5] = {0, 0, 0, 0, 0};                 // [3], [4]: the sums over the image rows, from bs_partial
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double pmin = 1e300, pmax = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.NZ; i += stride) {
+        if (ldiag && i < d.NS && d.z_est[i]) {
+            double p = ldiag[i];                     // diag(L) by natural index (the factorisation may be permuted)
+            p = p == p ? p : 0.0;
+            pmin = fmin(pmin, p); pmax = fmax(pmax, p);
+        }
         if (!d.z_mine[i]) continue;
         const double w = d.z_prw[i], vi = d.z_est[i] ? v[i] : 0.0;
         if (w > 0) acc[0] += w * vi * vi;
         acc[1] += (i < d.NS ? g_c[i] : gp[i - d.NS]) * vi;
         acc[2] += vi * vi;
     }
-    block_sum<3>(acc, sh);
-    if (threadIdx.x == 0) { partial[3 * blockIdx.x] = acc[0]; partial[3 * blockIdx.x + 1] = acc[1]; partial[3 * blockIdx.x + 2] = acc[2]; }
+    if (ldiag && (int64_t)blockIdx.x * blockDim.x < d.NS) {      // blocks that saw pivots
+        for (int off = 32; off > 0; off >>= 1) {
+            pmin = fmin(pmin, __shfl_down(pmin, off, 64));
+            pmax = fmax(pmax, __shfl_down(pmax, off, 64));
+        }
+        if ((threadIdx.x & 63) == 0 && pmax > 0.0) {
+            atomicMin(pivmm + 2, (unsigned long long)__double_as_longlong(fmax(pmin, 0.0)));
+            atomicMax(pivmm + 3, (unsigned long long)__double_as_longlong(pmax));
+        }
+        __builtin_amdgcn_s_waitcnt(0);               // performed before this block's ticket
+    }
+    if (grid_sum<5, 2, 3>(acc, sh, partial, ctr, bs_partial, nbs, 2) && threadIdx.x == 0) {
+        out[0] = acc[3]; out[1] = acc[4]; out[4] = acc[0]; out[5] = acc[1]; out[6] = acc[2];
+        if (mailbox) {
+            mailbox[0] = acc[3]; mailbox[1] = acc[4]; mailbox[4] = acc[0]; mailbox[5] = acc[1]; mailbox[6] = acc[2];
+            for (int q = 0; q < 4; ++q)
+                mailbox[40 + q] = __longlong_as_double((long long)__hip_atomic_load(pivmm + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            const int hi = __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            long long w = hi;
+            mailbox[44] = __longlong_as_double(w);
+        }
+    }
 }
 
 // ---------------------------------------------------------------- K9 ----
