@@ -9,13 +9,13 @@ import numpy as np
 rows = np.loadtxt(sys.argv[1], delimiter=',', dtype=np.int64)
 cyc = (rows[:, 3 + 15] - rows[:, 3 + 14]).astype(float)      # s_memtime around df_potf2 (diagonal tasks)
 rows[:, 3 + 14:] = 0
-task, ti, tk, T = rows[:, 0], rows[:, 1], rows[:, 2], rows[:, 3:].astype(float) * 0.01   # us
+task, ti, tk, T = rows[:, 0], rows[:, 1], rows[:, 2], rows[:, 3:19].astype(float) * 0.01   # us
 t0 = T[T > 0].min()
 T = np.where(T > 0, T - t0, np.nan)
 fact = ti >= 0
 diag = fact & (ti == tk)
 off = fact & (ti != tk)
-back = ~fact
+back = ti == -1                  # (ti <= -2: helpers of long sums)
 print('tasks: %d diagonal, %d off-diagonal, %d backward; span %.1f us (factor %.1f, backward %.1f)'
       % (diag.sum(), off.sum(), back.sum(), np.nanmax(T), np.nanmax(T[fact, 4]), np.nanmax(T) - np.nanmax(T[fact, 4])))
 ph = lambda m, a, b: np.nanmean(T[m, b] - T[m, a])

@@ -132,6 +132,54 @@ __global__ __launch_bounds__(256) void k_probe(int iters, unsigned long long *ou
     if (lane == 0) { out[2 * w] = c1 - c0; out[2 * w + 1] = w1 - w0; }
 }
 
+typedef double d4 __attribute__((ext_vector_type(4)));
+// the 64 x 64 x 64 tile product of chol.hpp (mfma_tile64) from LDS operands, 4 waves
+template <int LD, int VAR>
+__global__ __launch_bounds__(256) void k_tile64(int iters, unsigned long long *out, double *sink) {
+    __shared__ double Pm[64 * LD], Qm[64 * LD];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 64 * LD; i += 256) { Pm[i] = 1e-3 * (i % 17); Qm[i] = 1e-3 * (i % 13); }
+    __syncthreads();
+    d4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+        if (VAR == 0) {
+#pragma unroll 4
+            for (int kk = 0; kk < 16; ++kk) {
+                const int mrow = 4 * kk + (lane >> 4);
+                const double a = Pm[mrow * LD + 16 * w + (lane & 15)];
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) {
+                    const double b = Qm[mrow * LD + 16 * rt + (lane & 15)];
+                    acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[rt], 0, 0, 0);
+                }
+            }
+        } else {                                     // operands of k-step kk+1 on their way while kk multiplies
+            const double *pa = Pm + (lane >> 4) * LD + 16 * w + (lane & 15), *pb = Qm + (lane >> 4) * LD + (lane & 15);
+            double an = pa[0], bn[4] = {pb[0], pb[16], pb[32], pb[48]};
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const double a = an, b0 = bn[0], b1 = bn[1], b2 = bn[2], b3 = bn[3];
+                if (kk + 1 < 16) {
+                    an = pa[4 * (kk + 1) * LD];
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt) bn[rt] = pb[4 * (kk + 1) * LD + 16 * rt];
+                }
+                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b2, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b3, acc[3], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    const unsigned long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+    double s = 0;
+    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    sink[threadIdx.x] = s;
+    if (lane == 0) { out[2 * w] = c1 - c0; out[2 * w + 1] = w1 - w0; }
+}
+
 int main() {
     // SPD 16 x 16 block + 16 more rows
     std::vector<double> A(16 * 32);
@@ -169,6 +217,15 @@ int main() {
             err = fmax(err, fabs(s - A[c * 32 + r]));
         }
     printf("max |V0 - V1| = %.3g, checksum %.12g, |L L' - A| = %.3g\n", md, chk, err);
+    for (int var = 0; var < 2; ++var) {
+        for (int rep = 0; rep < 2; ++rep) {
+            if (var == 0) hipLaunchKernelGGL((k_tile64<65, 0>), dim3(1), dim3(256), 0, 0, 2000, out, sink);
+            else hipLaunchKernelGGL((k_tile64<65, 1>), dim3(1), dim3(256), 0, 0, 2000, out, sink);
+            hipDeviceSynchronize();
+        }
+        unsigned long long h[8]; hipMemcpy(h, out, 64, hipMemcpyDeviceToHost);
+        printf("64^3 tile product from LDS (64 MFMAs per wave), variant %d: %.0f shader ticks, %.3f us\n", var, (double)h[0] / 2000, (double)h[1] * 0.01 / 2000);
+    }
     const char *names[] = {"16 dependent v_fma_f64", "16 independent v_fma_f64", "8 x (2 v_readlane + v_fma_f64)",
                            "4 dependent (v_rsq_f64 + v_fma_f64)", "16 v_readlane_b32 + adds"};
     for (int p = 0; p < 5; ++p) {

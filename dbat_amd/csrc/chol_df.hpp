@@ -35,6 +35,7 @@
 #pragma once
 #include <cstdio>
 #include <functional>
+#include <queue>
 
 #include "chol.hpp"
 
@@ -44,6 +45,12 @@ constexpr int DF_LD = 65;
 constexpr int DF_SPIN_CAP = 1 << 22;
 
 struct DfTask { int i, k; };
+// One entry of the task list.  np >= 0: the task that owns tile (i,k): the products j in [jlo, k),
+// then the partial sums of its np helpers (slots part .. part+np-1), then the factorisation / the
+// L^-1 product.  np < 0: a helper: the products j in [jlo, jhi) of tile (i,k) into partial slot
+// `part` -- the sums of the dense rows (IO unknowns, right-hand side: one product per tile column
+// of the whole system) are cut into pieces that run side by side.
+struct DfJob { int i, k, jlo, jhi, part, np; };
 
 // Tiles that one workgroup writes and others read inside the same launch move
 // with agent-scope relaxed atomics (sc1 loads/stores that bypass the per-XCD
@@ -64,17 +71,59 @@ __device__ __forceinline__ df_d2 ld_coh16(const double *p) {
     asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
     return v;
 }
+// A FINISHED tile of the compact storage never changes again inside the launch, nobody but its
+// owner touched its (tile-private, 32 KB aligned) cache lines before it was finished, and the L2
+// are invalidated between launches: after its flag has been seen a tile may be read THROUGH the L2
+// of the reader's XCD (sc0: past the CU's vector cache only).  Every tile is read by dozens of
+// tasks; with sc1 loads each of those reads went to memory (C4: 7.8 GB per factorisation).
+// Not for the in-place layout, where the right-hand-side row shares lines with the last tile row.
+__device__ __forceinline__ df_d2 ld_l2_16(const double *p) {
+    df_d2 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ double ld_tile(const double *p, bool l2) {
+    return l2 ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+              : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ void df_wait16(df_d2 &a, df_d2 &b) {
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b) : : "memory");
 }
 // 64 x 64 tile (column-major, leading dimension ld, ld even, 16-byte aligned) -> Pm[c*LD + r]:
 // thread (tx, ty) takes the row pair 2*(tx&31) of the columns 2*(ty + 4q) + (tx>>5), q < 8
 template <int LD>
-__device__ __forceinline__ void df_load_tile16(const double *T, int64_t ld, double *Pm, int tx, int ty) {
+__device__ __forceinline__ void df_load_tile16(const double *T, int64_t ld, double *Pm, int tx, int ty, bool l2) {
     const double *src = T + 2 * (tx & 31);
     df_d2 v[8];
+    if (l2) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = ld_coh16(src + (int64_t)(2 * (ty + 4 * q) + (tx >> 5)) * ld);
+        for (int q = 0; q < 8; ++q) v[q] = ld_l2_16(src + (int64_t)(2 * (ty + 4 * q) + (tx >> 5)) * ld);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = ld_coh16(src + (int64_t)(2 * (ty + 4 * q) + (tx >> 5)) * ld);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q += 2) df_wait16(v[q], v[q + 1]);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        double *dst = Pm + (2 * (ty + 4 * q) + (tx >> 5)) * LD + 2 * (tx & 31);
+        dst[0] = v[q].x; dst[1] = v[q].y;
+    }
+}
+// The same in two halves for the pipelined sum: the loads of the next product are in flight while
+// the matrix cores work on the current one.
+__device__ __forceinline__ void df_tile16_issue(const double *T, int64_t ld, df_d2 (&v)[8], int tx, int ty, bool l2) {
+    const double *src = T + 2 * (tx & 31);
+    if (l2) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = ld_l2_16(src + (int64_t)(2 * (ty + 4 * q) + (tx >> 5)) * ld);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = ld_coh16(src + (int64_t)(2 * (ty + 4 * q) + (tx >> 5)) * ld);
+    }
+}
+template <int LD>
+__device__ __forceinline__ void df_tile16_commit(df_d2 (&v)[8], double *Pm, int tx, int ty) {
 #pragma unroll
     for (int q = 0; q < 8; q += 2) df_wait16(v[q], v[q + 1]);
 #pragma unroll
@@ -265,6 +314,7 @@ struct DfView {
     const uint64_t *rowbits;    // [(nT+1)*W]
     int W;
     const int *iperm;           // permuted index -> natural index (nullptr: identity)
+    int no_l2;                  // default 1: tiles with agent-scope loads everywhere; DBAT_HIP_DF_L2=1 reads finished tiles through the L2
 };
 
 // Backward substitution task of panel j:  q_j = Linv_j' (y_j - sum_{i>j} L(i,j)' q_i).
@@ -289,8 +339,9 @@ __device__ __forceinline__ bool df_backward(double *smem, const DfView &V, int n
     if (!df_spin_wave(flags + (int64_t)j * nT + j, epoch, abort_flag)) return false;
     if (!df_spin_wave(flags + (int64_t)nT * nT + j, epoch, abort_flag)) return false;
     double lv[16];                                      // Linv(k = ty + 4q, c = tx)
+    const bool l2 = V.iperm != nullptr && !V.no_l2;     // compact tiles: finished tiles through the L2 (see ld_l2_16)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) lv[q] = ld_coh(linv_all + (size_t)j * NB * NB + tx * NB + ty + 4 * q);
+    for (int q = 0; q < 16; ++q) lv[q] = ld_tile(linv_all + (size_t)j * NB * NB + tx * NB + ty + 4 * q, l2);
     const double yv = tx < nc ? ld_coh(V.base + V.toff[(int64_t)nT * nT + j] + (int64_t)tx * V.ld) : 0.0;   // y_j(tx)
     double acc[16];
 #pragma unroll
@@ -302,7 +353,7 @@ __device__ __forceinline__ bool df_backward(double *smem, const DfView &V, int n
         double v[16];
         const double *Lt = V.base + V.toff[(int64_t)i * nT + j] + tx;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = (tx < nr && ty + 4 * q < nc) ? ld_coh(Lt + (int64_t)(ty + 4 * q) * V.ld) : 0.0;
+        for (int q = 0; q < 16; ++q) v[q] = (tx < nr && ty + 4 * q < nc) ? ld_tile(Lt + (int64_t)(ty + 4 * q) * V.ld, l2) : 0.0;
         double qv = 0.0;
         int spins = 0;
         for (;;) {
@@ -351,19 +402,21 @@ __device__ __forceinline__ bool df_backward(double *smem, const DfView &V, int n
     return true;
 }
 
-__global__ __launch_bounds__(256) void k_chol_df(DfView V, int n, int nT, const DfTask *__restrict__ tasks,
+__global__ __launch_bounds__(256) void k_chol_df(DfView V, int n, int nT, const DfJob *__restrict__ tasks,
                                                  int ntasks, int *__restrict__ flags, int *__restrict__ ctl, int epoch,
                                                  double *__restrict__ linv_all, int *__restrict__ info,
                                                  long long *__restrict__ trace, const int *__restrict__ bk_ptr,
                                                  const int *__restrict__ bk_idx, double *__restrict__ q_out,
                                                  double *__restrict__ q_nat, double *__restrict__ ldiag,
-                                                 const double *__restrict__ qscale, double *__restrict__ dz_out) {
+                                                 const double *__restrict__ qscale, double *__restrict__ dz_out,
+                                                 double *__restrict__ parts) {
     constexpr int NB = 64, LD = DF_LD;
     __shared__ double smem[2 * NB * LD];                // Pm | Qm, or the augmented block of df_potf2
     double *Pm = smem, *Qm = smem + NB * LD;
     __shared__ int s_task, s_ok;
     const int t = threadIdx.x, tx = t & 63, ty = t >> 6;
     int *counter = ctl, *abort_flag = ctl + 1;
+    const bool l2 = V.iperm != nullptr && !V.no_l2;     // compact tiles: finished tiles through the L2 (see ld_l2_16)
     for (;;) {
         if (t == 0) s_task = atomicAdd(counter, 1);
         __syncthreads();
@@ -380,71 +433,156 @@ __global__ __launch_bounds__(256) void k_chol_df(DfView V, int n, int nT, const 
             if (trace && t == 0) trace[task * 16 + 4] = wall_clock64();
             continue;
         }
-        const int i = tasks[task].i, k = tasks[task].k;
+        const DfJob jb = tasks[task];
+        const int i = jb.i, k = jb.k;
+        const bool helper = jb.np < 0;                  // a piece of a long sum (see DfJob)
+        const int jend = helper ? jb.jhi : k;           // products j in [jb.jlo, jend)
+        int *pflags = flags + (int64_t)(nT + 1) * nT;   // flags of the helpers' partial sums
         const int nr = i == nT ? 1 : min(NB, n - NB * i);
         const int64_t col0 = (int64_t)NB * k;
         const int nc = min(NB, n - NB * k);
         double *Tik = V.base + V.toff[(int64_t)i * nT + k];
         if (trace && t == 0) trace[task * 16 + 0] = wall_clock64();
-        // original tile values in the accumulator layout: (c = 16*ty + (tx>>4) + 4e, r = 16*rt + (tx&15))
-        chol_d4 orig[4];
-        {
+        // the accumulators (layout: c = 16*ty + (tx>>4) + 4e, r = 16*rt + (tx&15)) start from MINUS the
+        // original tile values, so that T = -(acc) at the end and nothing else stays in registers over the sum
+        chol_d4 acc[4];
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt)
+        for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int c = 16 * ty + (tx >> 4) + 4 * e, r = 16 * rt + (tx & 15);
-                    orig[rt][e] = (r < nr && c < nc) ? Tik[(int64_t)c * V.ld + r] : 0.0;
-                }
-        }
-        chol_d4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+            for (int e = 0; e < 4; ++e) {
+                const int c = 16 * ty + (tx >> 4) + 4 * e, r = 16 * rt + (tx & 15);
+                acc[rt][e] = (!helper && r < nr && c < nc) ? -Tik[(int64_t)c * V.ld + r] : 0.0;
+            }
         bool alive = true;
         // T -= L(i,j) L(k,j)' over the columns j < k present in both tile rows
         const uint64_t *bi = V.rowbits + (size_t)i * V.W, *bk = V.rowbits + (size_t)k * V.W;
-        for (int w = 0; w <= (k >> 6) && alive; ++w) {
+        const int wend = (jend - 1) >> 6;               // last word with a bit below jend (jend = 0: no products)
+        auto word = [&](int w) {
             uint64_t m = bi[w] & bk[w];
-            if (w == (k >> 6)) m &= (1ull << (k & 63)) - 1;     // j < k
-            while (m) {
-                const int j = 64 * w + __builtin_ctzll(m);
-                m &= m - 1;
-                if (t == 0) {
-                    bool ok = df_spin(flags + (int64_t)k * nT + j, epoch, abort_flag);
-                    if (ok && i != k) ok = df_spin(flags + (int64_t)i * nT + j, epoch, abort_flag);
-                    s_ok = ok;
+            if (w == (jb.jlo >> 6)) m &= ~0ull << (jb.jlo & 63);
+            if (w == (jend >> 6)) m &= (1ull << (jend & 63)) - 1;
+            return m;
+        };
+        int jw = jb.jlo >> 6;
+        uint64_t jm = jend > jb.jlo ? word(jw) : 0ull;
+        auto next_j = [&]() -> int {                    // next common column in [jlo, jend), -1 at the end
+            for (;;) {
+                if (jm) { const int j = 64 * jw + __builtin_ctzll(jm); jm &= jm - 1; return j; }
+                if (jend <= jb.jlo || ++jw > wend) return -1;
+                jm = word(jw);
+            }
+        };
+        auto spin_both = [&](int j) {                   // thread 0: both tiles of product j exist (blocking)
+            bool ok = df_spin(flags + (int64_t)k * nT + j, epoch, abort_flag);
+            if (ok && i != k) ok = df_spin(flags + (int64_t)i * nT + j, epoch, abort_flag);
+            return ok;
+        };
+        // whole tiles (in the compact storage the right-hand-side row is a whole tile too, zero below its row)
+        if (nc == NB && (nr == NB || i == k || (V.iperm && i == nT)) && !(V.ld & 1)) {
+            // Software pipeline: while the matrix cores work on product n, the tiles of product n+1 are
+            // on their way into registers -- if its flags were up when thread 0 looked (one non-blocking
+            // look, issued before the wait for the tiles of product n, so its latency hides there).
+            // Otherwise the workgroup finishes product n first and then waits.  2.0 instead of 3.7 us per
+            // product for a task whose inputs exist (the long sums of the dense IO / right-hand-side rows).
+            df_d2 rp[8], rq[8];
+            int jn = next_j();
+            if (jn >= 0) {
+                if (t == 0) s_ok = spin_both(jn);
+                __syncthreads();
+                if (!s_ok) alive = false;
+                else {
+                    df_tile16_issue(V.base + V.toff[(int64_t)k * nT + jn], V.ld, rp, tx, ty, l2);
+                    if (i != k) df_tile16_issue(V.base + V.toff[(int64_t)i * nT + jn], V.ld, rq, tx, ty, l2);
                 }
+            }
+            while (alive && jn >= 0) {
+                jn = next_j();
+                int f1 = epoch, f2 = epoch;
+                if (t == 0 && jn >= 0) {                // the look at the next product's flags
+                    f1 = __hip_atomic_load(flags + (int64_t)k * nT + jn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (i != k) f2 = __hip_atomic_load(flags + (int64_t)i * nT + jn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();                        // the previous MFMA pass has read Pm/Qm
+                df_tile16_commit<LD>(rp, Pm, tx, ty);
+                if (i != k) df_tile16_commit<LD>(rq, Qm, tx, ty);
+                if (t == 0) s_ok = jn >= 0 && f1 == epoch && f2 == epoch;
+                __syncthreads();
+                const bool early = s_ok;
+                if (early) {
+                    df_tile16_issue(V.base + V.toff[(int64_t)k * nT + jn], V.ld, rp, tx, ty, l2);
+                    if (i != k) df_tile16_issue(V.base + V.toff[(int64_t)i * nT + jn], V.ld, rq, tx, ty, l2);
+                }
+                mfma_tile64<LD>(Pm, i == k ? Pm : Qm, ty, tx, acc);
+                if (jn >= 0 && !early) {
+                    __syncthreads();                    // s_ok has been read by everybody
+                    if (t == 0) s_ok = spin_both(jn);
+                    __syncthreads();
+                    if (!s_ok) { alive = false; break; }
+                    df_tile16_issue(V.base + V.toff[(int64_t)k * nT + jn], V.ld, rp, tx, ty, l2);
+                    if (i != k) df_tile16_issue(V.base + V.toff[(int64_t)i * nT + jn], V.ld, rq, tx, ty, l2);
+                }
+            }
+        } else {
+            for (int j = next_j(); j >= 0; j = next_j()) {
+                if (t == 0) s_ok = spin_both(j);
                 __syncthreads();                        // also: the previous MFMA pass has read Pm/Qm
                 if (!s_ok) { alive = false; break; }
-                if (nc == NB && (nr == NB || i == k) && !(V.ld & 1)) {      // whole tiles: 16-byte loads
-                    df_load_tile16<LD>(V.base + V.toff[(int64_t)k * nT + j], V.ld, Pm, tx, ty);
-                    if (i != k) df_load_tile16<LD>(V.base + V.toff[(int64_t)i * nT + j], V.ld, Qm, tx, ty);
-                } else {
-                    const double *Lk = V.base + V.toff[(int64_t)k * nT + j] + tx;     // L(64k + tx, 64j + m)
-                    const double *Li = V.base + V.toff[(int64_t)i * nT + j] + tx;     // L(row0 + tx, 64j + m)
-                    const bool okc = tx < nc, okr = tx < nr && i != k;
-                    double vk[16], vi[16];              // all loads in flight before the first use
+                const double *Lk = V.base + V.toff[(int64_t)k * nT + j] + tx;     // L(64k + tx, 64j + m)
+                const double *Li = V.base + V.toff[(int64_t)i * nT + j] + tx;     // L(row0 + tx, 64j + m)
+                const bool okc = tx < nc, okr = tx < nr && i != k;
+                double vk[16], vi[16];                  // all loads in flight before the first use
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) vk[q] = okc ? ld_coh(Lk + (int64_t)(ty + 4 * q) * V.ld) : 0.0;
+                for (int q = 0; q < 16; ++q) vk[q] = okc ? ld_tile(Lk + (int64_t)(ty + 4 * q) * V.ld, l2) : 0.0;
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) vi[q] = okr ? ld_coh(Li + (int64_t)(ty + 4 * q) * V.ld) : 0.0;
+                for (int q = 0; q < 16; ++q) vi[q] = okr ? ld_tile(Li + (int64_t)(ty + 4 * q) * V.ld, l2) : 0.0;
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) { Pm[(ty + 4 * q) * LD + tx] = vk[q]; Qm[(ty + 4 * q) * LD + tx] = vi[q]; }
-                }
+                for (int q = 0; q < 16; ++q) { Pm[(ty + 4 * q) * LD + tx] = vk[q]; Qm[(ty + 4 * q) * LD + tx] = vi[q]; }
                 __syncthreads();
                 mfma_tile64<LD>(Pm, i == k ? Pm : Qm, ty, tx, acc);
             }
         }
         if (!alive) { if (t == 0) *info = -1; return; }
         __syncthreads();
-        if (trace && t == 0) trace[task * 16 + 1] = wall_clock64();
-        double *Linv = linv_all + (size_t)k * NB * NB;
-        if (i == k) {
-            // T(r, c) = orig - acc -> augmented block, ragged part = identity, upper triangle = 0
+        if (helper) {                                   // partial sum -> its slot (tile layout), flag, next task
+            double *slot = parts + (size_t)jb.part * 4096;
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int c = 16 * ty + (tx >> 4) + 4 * e, r = 16 * rt + (tx & 15);
-                    const double v = orig[rt][e] - acc[rt][e];
+                    st_coh(slot + c * 64 + r, acc[rt][e]);
+                }
+            if (trace && t == 0) trace[task * 16 + 1] = wall_clock64();
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            if (t == 0) __hip_atomic_store(pflags + jb.part, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (trace && t == 0) trace[task * 16 + 4] = wall_clock64();
+            continue;
+        }
+        for (int h = 0; h < jb.np; ++h) {               // the helpers' pieces of this tile's sum
+            if (t == 0) s_ok = df_spin(pflags + jb.part + h, epoch, abort_flag);
+            __syncthreads();
+            if (!s_ok) { if (t == 0) *info = -1; return; }
+            const double *slot = parts + (size_t)(jb.part + h) * 4096;
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = 16 * ty + (tx >> 4) + 4 * e, r = 16 * rt + (tx & 15);
+                    acc[rt][e] += ld_coh(slot + c * 64 + r);
+                }
+            __syncthreads();                            // s_ok is rewritten in the next round
+        }
+        if (trace && t == 0) trace[task * 16 + 1] = wall_clock64();
+        double *Linv = linv_all + (size_t)k * NB * NB;
+        if (i == k) {
+            // T(r, c) = -acc -> augmented block, ragged part = identity, upper triangle = 0
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = 16 * ty + (tx >> 4) + 4 * e, r = 16 * rt + (tx & 15);
+                    const double v = -acc[rt][e];
                     smem[c * DF_TLD + r] = (r < nc && c < nc) ? (r >= c ? v : 0.0) : (r == c ? 1.0 : 0.0);
                 }
             if (trace && t == 0) trace[task * 16 + 2] = wall_clock64();
@@ -464,19 +602,19 @@ __global__ __launch_bounds__(256) void k_chol_df(DfView V, int n, int nT, const 
                 if (zn >= 0) ldiag[zn] = smem[tx * DF_TLD + tx];
             }
         } else {
-            // T(r, c) = orig - acc  ->  Qm[c][r]
+            // T(r, c) = -acc  ->  Qm[c][r]
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int c = 16 * ty + (tx >> 4) + 4 * e, r = 16 * rt + (tx & 15);
-                    Qm[c * LD + r] = orig[rt][e] - acc[rt][e];
+                    Qm[c * LD + r] = -acc[rt][e];
                 }
             if (t == 0) s_ok = df_spin(flags + (int64_t)k * nT + k, epoch, abort_flag);
             __syncthreads();
             if (!s_ok) { if (t == 0) *info = -1; return; }
             if (trace && t == 0) trace[task * 16 + 2] = wall_clock64();
-            df_load_tile16<LD>(Linv, NB, Pm, tx, ty);
+            df_load_tile16<LD>(Linv, NB, Pm, tx, ty, l2);
             __syncthreads();
             {
                 chol_d4 x[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -539,22 +677,25 @@ struct DataflowChol {
     int *d_flags = nullptr, *d_ctl = nullptr, *d_bk_ptr = nullptr, *d_bk_idx = nullptr, *d_iperm = nullptr;
     int64_t *d_toff = nullptr;
     uint64_t *d_rowbits = nullptr;
-    DfTask *d_tasks = nullptr, *d_tile_ij = nullptr;
+    DfJob *d_tasks = nullptr;
+    DfTask *d_tile_ij = nullptr;
+    int nparts = 0;                                     // partial-sum slots of the helper tasks
+    double *d_parts = nullptr;
     double *d_tiles = nullptr, *d_qperm = nullptr;
     long long *d_trace = nullptr;                       // optional per-task timestamps (DBAT_HIP_DF_TRACE=file)
-    std::vector<DfTask> h_tasks;
+    std::vector<DfJob> h_tasks;
     std::vector<int> perm;                              // natural -> permuted (empty: identity)
     // doubles of the linv_work argument of solve(): one 64 x 64 inverse per tile row of the
     // factorised (padded) system
     size_t linv_doubles() const { return (size_t)std::max(nT, 1) * CHOL_NB * CHOL_NB; }
 
     void release() {
-        void *ps[] = {d_flags, d_ctl, d_bk_ptr, d_bk_idx, d_iperm, d_toff, d_rowbits, d_tasks, d_tile_ij, d_tiles, d_qperm};
+        void *ps[] = {d_flags, d_ctl, d_bk_ptr, d_bk_idx, d_iperm, d_toff, d_rowbits, d_tasks, d_tile_ij, d_tiles, d_qperm, d_parts};
         for (void *p : ps) if (p) (void)hipFree(p);
         d_flags = d_ctl = d_bk_ptr = d_bk_idx = d_iperm = nullptr; d_toff = nullptr; d_rowbits = nullptr;
-        d_tasks = d_tile_ij = nullptr; d_tiles = d_qperm = nullptr;
+        d_tasks = nullptr; d_tile_ij = nullptr; d_tiles = d_qperm = d_parts = nullptr;
     }
-    // per-task timestamps of the last solve (100 MHz ticks): task, i, k, t[0..15] per line
+    // per-task timestamps of the last solve (100 MHz ticks): task, i, k, t[0..15], jlo, jhi per line
     void dump_trace(hipStream_t stream, const char *path) const {
         if (!d_trace) return;
         std::vector<long long> h((size_t)(ntasks + nT) * 16);
@@ -563,10 +704,11 @@ struct DataflowChol {
         FILE *f = fopen(path, "w");
         if (!f) return;
         for (int t = 0; t < ntasks + nT; ++t) {
-            const int i = t < ntasks ? h_tasks[t].i : -1, k = t < ntasks ? h_tasks[t].k : nT - 1 - (t - ntasks);
+            // owner tasks: i, k; helpers of long sums: -(i + 2), k; backward substitution: -1, panel
+            const int i = t < ntasks ? (h_tasks[t].np < 0 ? -(h_tasks[t].i + 2) : h_tasks[t].i) : -1, k = t < ntasks ? h_tasks[t].k : nT - 1 - (t - ntasks);
             fprintf(f, "%d,%d,%d", t, i, k);
             for (int q = 0; q < 16; ++q) fprintf(f, ",%lld", h[(size_t)t * 16 + q]);
-            fprintf(f, "\n");
+            fprintf(f, ",%d,%d\n", t < ntasks ? h_tasks[t].jlo : 0, t < ntasks ? (h_tasks[t].np < 0 ? h_tasks[t].jhi : h_tasks[t].k) : 0);   // its products: j in [jlo, jhi)
         }
         fclose(f);
     }
@@ -580,69 +722,163 @@ struct DataflowChol {
     // (row nT = right-hand side, all columns), fill included
     bool finish_setup(const std::vector<uint64_t> &rowbits, const std::vector<int64_t> &toff) {
         auto has = [&](int i, int k) { return (rowbits[(size_t)i * W + (k >> 6)] >> (k & 63)) & 1ull; };
-        std::vector<DfTask> tasks;
+        // ---- jobs, column-major (dependencies come earlier); long sums are cut into helpers
+        const int split_min = getenv("DBAT_HIP_DF_SPLIT") ? std::max(atoi(getenv("DBAT_HIP_DF_SPLIT")), 2) : 128;
+        const int chunk = getenv("DBAT_HIP_DF_CHUNK") ? std::max(atoi(getenv("DBAT_HIP_DF_CHUNK")), 1) : 32;
+        std::vector<DfJob> jobs;
+        std::vector<int> own((size_t)(nT + 1) * nT, -1);        // tile -> its owning job
+        std::vector<int> dptr(1, 0), dep;                       // per job: the two tiles of every product (ascending j)
+        std::vector<int> js;
+        nparts = 0; n_products = 0;
         for (int k = 0; k < nT; ++k)
-            for (int i = k; i <= nT; ++i)
-                if (has(i, k)) tasks.push_back(DfTask{i, k});
-        ntasks = (int)tasks.size();
+            for (int i = k; i <= nT; ++i) {
+                if (!has(i, k)) continue;
+                js.clear();
+                for (int j = 0; j < k; ++j) if (has(i, j) && has(k, j)) js.push_back(j);
+                n_products += (long long)js.size();
+                const int nj = (int)js.size();
+                const int nch = nj > split_min ? (nj + chunk - 1) / chunk : 1;
+                auto push_products = [&](int q0, int q1) {
+                    for (int q = q0; q < q1; ++q) { dep.push_back(own[(size_t)k * nT + js[q]]); dep.push_back(i != k ? own[(size_t)i * nT + js[q]] : -1); }
+                    dptr.push_back((int)dep.size());
+                };
+                for (int c = 0; c + 1 < nch; ++c) {             // helpers
+                    jobs.push_back(DfJob{i, k, js[chunk * c], js[chunk * (c + 1)], nparts + c, -1});
+                    push_products(chunk * c, chunk * (c + 1));
+                }
+                own[(size_t)i * nT + k] = (int)jobs.size();
+                jobs.push_back(DfJob{i, k, nch > 1 ? js[chunk * (nch - 1)] : 0, k, nparts, nch - 1});
+                push_products(chunk * (nch - 1), nj);
+                nparts += nch - 1;
+            }
+        ntasks = (int)jobs.size();
+        auto is_helper = [&](int t) { return jobs[t].np < 0; };
+        auto is_diag = [&](int t) { return jobs[t].np >= 0 && jobs[t].i == jobs[t].k; };
+        auto nprod_of = [&](int t) { return (dptr[t + 1] - dptr[t]) / 2; };
+        // every dependency of job t: product tiles, its helpers (the np jobs right before it), the diagonal tile
+        auto for_deps = [&](int t, const std::function<void(int)> &f) {
+            for (int q = dptr[t]; q < dptr[t + 1]; ++q) if (dep[q] >= 0) f(dep[q]);
+            if (!is_helper(t)) {
+                for (int h = 1; h <= jobs[t].np; ++h) f(t - h);
+                if (jobs[t].i != jobs[t].k) f(own[(size_t)jobs[t].k * nT + jobs[t].k]);
+            }
+        };
         if (!getenv("DBAT_HIP_DF_COLMAJOR")) {
             // Task order = the order in which workgroups take them.  Any topological order is
             // deadlock free (a dependency always has a smaller number, so it is owned by a running
             // workgroup); column-major order, however, hands out ALL tiles of the first blocks of
             // the dissection before the first tile of the others, and the few hundred resident
             // workgroups then sit in the dependent chains of a few leaves while the other leaves
-            // have not started.  Order by the earliest time a task can start (list schedule with
-            // rough costs after the last input: 17 us for a diagonal tile, 6 us for the others):
-            // all leaves advance together and the separators follow when their inputs exist.
-            std::vector<int> tix((size_t)(nT + 1) * nT, -1);
-            for (int t = 0; t < ntasks; ++t) tix[(size_t)tasks[t].i * nT + tasks[t].k] = t;
+            // have not started.  Candidate orders are tried on a model of the kernel (measured
+            // costs, us: bench/chol_trace.py, bench/chol_path.py) and the best one is taken.
+            const double c_prod = getenv("DBAT_HIP_DF_CPROD") ? atof(getenv("DBAT_HIP_DF_CPROD")) : 2.5, c_diag = 13.5, c_off = 4.5, c_hop = 2.0, c_add = 1.5, c_help = 2.0;
+            auto tail_of = [&](int t) { return is_helper(t) ? c_help : (is_diag(t) ? c_diag : c_off); };
+            // (1) earliest start: every input the moment it exists, unlimited workgroups
             std::vector<double> est(ntasks, 0.0), fin(ntasks, 0.0);
-            for (int t = 0; t < ntasks; ++t) {              // column-major: dependencies come earlier
-                const int i = tasks[t].i, k = tasks[t].k;
+            for (int t = 0; t < ntasks; ++t) {
                 double e = 0.0;
-                int nprod = 0;
-                for (int j = 0; j < k; ++j)
-                    if (has(i, j) && has(k, j)) {
-                        ++nprod;
-                        e = std::max(e, std::max(fin[tix[(size_t)i * nT + j]], fin[tix[(size_t)k * nT + j]]));
-                    }
-                if (i != k) e = std::max(e, fin[tix[(size_t)k * nT + k]]);
+                for_deps(t, [&](int d) { e = std::max(e, fin[d]); });
                 est[t] = e;
-                fin[t] = e + (i == k ? 17.0 : 6.0) + (nprod ? 0.0 : -2.0);   // after the last input: its product, then potf2 / the L^-1 product, stores, flag
+                fin[t] = e + c_hop + (nprod_of(t) ? c_prod : 0.0) + tail_of(t);
+            }
+            // (2) bottom level: the longest way from a task to the end of the factorisation
+            std::vector<double> blev(ntasks, 0.0);
+            for (int t = ntasks - 1; t >= 0; --t) {
+                blev[t] += c_hop + c_prod + tail_of(t);
+                for_deps(t, [&](int d) { blev[d] = std::max(blev[d], blev[t]); });
+            }
+            // The kernel as a list schedule: `workers` resident workgroups take the tasks in order; a
+            // workgroup consumes its inputs in its fixed order, every product after both tiles exist.
+            const int workers = std::max(1, std::min(grid, 256));      // 400 registers per lane: one workgroup per CU
+            auto simulate = [&](const std::vector<int> &ord) {
+                std::vector<double> done(ntasks, 0.0);
+                std::priority_queue<double, std::vector<double>, std::greater<double>> freeat;
+                for (int w = 0; w < workers; ++w) freeat.push(0.0);
+                double last = 0.0;
+                for (int t : ord) {
+                    double tc = freeat.top(); freeat.pop();
+                    for (int q = dptr[t]; q + 1 < dptr[t + 1]; q += 2) {
+                        double av = done[dep[q]];
+                        if (dep[q + 1] >= 0) av = std::max(av, done[dep[q + 1]]);
+                        tc = std::max(tc, av + c_hop) + c_prod;
+                    }
+                    if (!is_helper(t)) {
+                        for (int h = jobs[t].np; h >= 1; --h) tc = std::max(tc, done[t - h] + c_hop) + c_add;
+                        if (jobs[t].i != jobs[t].k) tc = std::max(tc, done[own[(size_t)jobs[t].k * nT + jobs[t].k]] + c_hop);
+                    }
+                    tc += tail_of(t);
+                    done[t] = tc; last = std::max(last, tc);
+                    freeat.push(tc);
+                }
+                return last;
+            };
+            // Candidates, all topological (Kahn's algorithm: a task is eligible once its dependencies are
+            // placed; among the eligible ones the smallest key goes first).  Keys: earliest start minus
+            // beta x bottom level -- beta = 0: in the order the inputs appear; large beta: critical path
+            // first -- and earliest start minus the task's own serial work (long sums get their
+            // workgroup early).  The model ranks them; the best simulated one is taken.
+            std::vector<int> indeg0(ntasks, 0), sptr(ntasks + 1, 0), succ;
+            for (int t = 0; t < ntasks; ++t) for_deps(t, [&](int d) { ++indeg0[t]; ++sptr[d + 1]; });
+            for (int t = 0; t < ntasks; ++t) sptr[t + 1] += sptr[t];
+            succ.resize(sptr[ntasks]);
+            {
+                std::vector<int> fill(sptr.begin(), sptr.end() - 1);
+                for (int t = 0; t < ntasks; ++t) for_deps(t, [&](int d) { succ[fill[d]++] = t; });
+            }
+            auto kahn = [&](const std::vector<double> &key) {
+                std::vector<int> ord(ntasks), indeg(indeg0);
+                typedef std::pair<double, int> KI;
+                std::priority_queue<KI, std::vector<KI>, std::greater<KI>> pq;
+                for (int t = 0; t < ntasks; ++t) if (!indeg[t]) pq.push(KI(key[t], t));
+                size_t n_out = 0;
+                while (!pq.empty()) {
+                    const int t = pq.top().second; pq.pop();
+                    ord[n_out++] = t;
+                    for (int q = sptr[t]; q < sptr[t + 1]; ++q) if (--indeg[succ[q]] == 0) pq.push(KI(key[succ[q]], succ[q]));
+                }
+                return ord;
+            };
+            const double betas[] = {0.0, 0.25, 0.5, 1.0, 2.0, 4.0, 1e6};
+            const int ncand = (int)(sizeof(betas) / sizeof(betas[0])) + 1;
+            std::vector<int> best_ord;
+            double tbest = 1e300;
+            int best = -1;
+            std::vector<double> key(ntasks), tcs(ncand);
+            const int forced = getenv("DBAT_HIP_DF_ORDER") ? atoi(getenv("DBAT_HIP_DF_ORDER")) : -1;
+            for (int c = 0; c < ncand; ++c) {
+                if (c + 1 < ncand) for (int t = 0; t < ntasks; ++t) key[t] = est[t] - betas[c] * blev[t];
+                else for (int t = 0; t < ntasks; ++t) key[t] = est[t] - c_prod * nprod_of(t);
+                std::vector<int> ord = kahn(key);
+                tcs[c] = simulate(ord);
+                if (forced == c || (forced < 0 && tcs[c] < tbest)) { tbest = tcs[c]; best = c; best_ord.swap(ord); }
             }
             if (getenv("DBAT_HIP_PLAN_STATS")) {
                 double cp = 0.0;
                 for (int t = 0; t < ntasks; ++t) cp = std::max(cp, fin[t]);
-                fprintf(stderr, "[chol] %d tasks, critical path of the factorisation by the schedule's cost model: %.0f us (= %.1f diagonal + off-diagonal steps)\n",
-                        ntasks, cp, cp / 23.0);
+                fprintf(stderr, "[chol] %d tasks (%d helpers of long sums), %lld products, critical path %.0f us; simulated with %d workgroups, key = earliest start - beta x bottom level:",
+                        ntasks, nparts, n_products, cp, workers);
+                for (int c = 0; c + 1 < ncand; ++c) fprintf(stderr, " beta %g: %.0f us,", betas[c], tcs[c]);
+                fprintf(stderr, " earliest start - own work: %.0f us -> candidate %d\n", tcs[ncand - 1], best);
             }
-            std::vector<int> ord(ntasks);
-            for (int t = 0; t < ntasks; ++t) ord[t] = t;
-            std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return est[a] < est[b]; });
-            std::vector<DfTask> sorted(ntasks);
-            for (int t = 0; t < ntasks; ++t) sorted[t] = tasks[ord[t]];
-            tasks.swap(sorted);
+            // a final task addresses its helpers by slot, not by position: any topological order will do
+            std::vector<DfJob> sorted(ntasks);
+            for (int t = 0; t < ntasks; ++t) sorted[t] = jobs[best_ord[t]];
+            jobs.swap(sorted);
         }
-        h_tasks = tasks;
+        h_tasks = jobs;
         if (getenv("DBAT_HIP_DF_TRACE") && hipMalloc(&d_trace, (size_t)(ntasks + nT) * 16 * sizeof(long long)) != hipSuccess) d_trace = nullptr;
-        n_products = 0;
-        for (const DfTask &tk : tasks)
-            for (int w = 0; w <= (tk.k >> 6); ++w) {
-                uint64_t m = rowbits[(size_t)tk.i * W + w] & rowbits[(size_t)tk.k * W + w];
-                if (w == (tk.k >> 6)) m &= (1ull << (tk.k & 63)) - 1;
-                n_products += __builtin_popcountll(m);
-            }
         std::vector<int> bptr(nT + 1, 0), bidx;
         for (int j = 0; j < nT; ++j) {
             for (int i = nT - 1; i > j; --i)
                 if (has(i, j)) bidx.push_back(i);
             bptr[j + 1] = (int)bidx.size();
         }
-        if (!up(d_tasks, tasks) || !up(d_bk_ptr, bptr) || !up(d_bk_idx, bidx) || !up(d_rowbits, rowbits) || !up(d_toff, toff))
+        if (!up(d_tasks, jobs) || !up(d_bk_ptr, bptr) || !up(d_bk_idx, bidx) || !up(d_rowbits, rowbits) || !up(d_toff, toff))
             return false;
-        if (hipMalloc(&d_flags, (size_t)(nT + 1) * nT * sizeof(int)) != hipSuccess) return false;
+        if (hipMalloc(&d_flags, ((size_t)(nT + 1) * nT + (size_t)nparts) * sizeof(int)) != hipSuccess) return false;   // tiles, then helper slots
+        if (nparts > 0 && hipMalloc(&d_parts, (size_t)nparts * 4096 * sizeof(double)) != hipSuccess) return false;
         if (hipMalloc(&d_ctl, 2 * sizeof(int)) != hipSuccess) return false;
-        (void)hipMemset(d_flags, 0, (size_t)(nT + 1) * nT * sizeof(int));
+        (void)hipMemset(d_flags, 0, ((size_t)(nT + 1) * nT + (size_t)nparts) * sizeof(int));
         if (const char *g = getenv("DBAT_HIP_DF_GRID")) grid = std::min(std::max(atoi(g), 1), 4096);
         epoch = 0;
         return true;
@@ -798,7 +1034,7 @@ struct DataflowChol {
         if (d_trace) (void)hipMemsetAsync(d_trace, 0, (size_t)(ntasks + nT) * 16 * sizeof(long long), stream);
         ++epoch;
         DfView V;
-        V.toff = d_toff; V.rowbits = d_rowbits; V.W = W;
+        V.toff = d_toff; V.rowbits = d_rowbits; V.W = W; V.no_l2 = getenv("DBAT_HIP_DF_L2") ? 0 : 1;     // measured: no gain from the L2 path
         double *qflag;
         if (permuted) {      // the gather also resets info, the task counter and the q flags (every tile row has its diagonal tile)
             hipLaunchKernelGGL(k_gather_tiles, dim3(ntiles), dim3(256), 0, stream, A, lda, n_nat, nT, d_iperm, d_tile_ij, d_tiles,
@@ -812,7 +1048,7 @@ struct DataflowChol {
         }
         hipLaunchKernelGGL(k_chol_df, dim3(std::min(grid, ntasks + nT)), dim3(256), 0, stream, V, n, nT, d_tasks, ntasks,
                            d_flags, d_ctl, epoch, linv_work, info_dev, d_trace, d_bk_ptr, d_bk_idx, qflag, q_out, ldiag,
-                           qscale, dz_out);
+                           qscale, dz_out, d_parts);
     }
 };
 

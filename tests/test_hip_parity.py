@@ -1140,6 +1140,30 @@ def test_run_to_run_repeatability(hip, name, sig, monkeypatch):
         h.close()
 
 
+@pytest.mark.parametrize('name,selfcal', [('small', False), ('small', True), ('C1', False)])
+def test_cholesky_split_sums_and_orders(hip, name, selfcal, monkeypatch):
+    """The dataflow Cholesky cuts long left-looking sums into helper tasks (partial sums in scratch
+    tiles, chol_df.hpp DfJob) and picks one of several topological task orders.  Forced here on small
+    systems -- every sum of more than two products split into pieces of two, each candidate order --
+    the step must agree with the default schedule to rounding."""
+    from dbat_amd import synth
+    s, _ = synth.make_scene(name, selfcal=selfcal) if selfcal else synth.make_scene(name)
+    def step():
+        h = hip.Handle(s)
+        try:
+            p, st = h.linearize_solve(h.serialize(), 0.0, True)
+            assert not st['singular']
+            return p
+        finally:
+            h.close()
+    ref = step()
+    monkeypatch.setenv('DBAT_HIP_DF_SPLIT', '2')
+    monkeypatch.setenv('DBAT_HIP_DF_CHUNK', '2')
+    for order in ('0', '4', '6', '7'):
+        monkeypatch.setenv('DBAT_HIP_DF_ORDER', order)
+        assert relerr(step(), ref) < 1e-9, order
+
+
 @pytest.mark.parametrize('rays,selfcal', [(12, False), (13, False), (11, True)])
 def test_signature_group_kernel_five_row_blocks(hip, rays, selfcal, monkeypatch):
     """Chunks with 11 ... 13 cameras per point need five 16-row blocks (the four-wave instantiations
