@@ -10,11 +10,18 @@ rows = np.loadtxt(sys.argv[1], delimiter=',', dtype=np.int64)
 ti, tk = rows[:, 1], rows[:, 2]
 T = rows[:, 3:19].astype(float) * 0.01
 jlo, jhi = rows[:, 19], rows[:, 20]                 # the task's own products: j in [jlo, jhi)
+mode = rows[:, 21] if rows.shape[1] > 21 else np.zeros(len(rows), int)   # 1: sum only (T published), 2: diagonal task that finishes that tile
 helper = ti <= -2                                   # pieces of long sums: i = -(ti + 2)
 t0 = T[:, 0][T[:, 0] > 0].min()
 fact = (ti >= 0) | helper
 ri = np.where(helper, -(ti + 2), ti)                # tile row of every factor task
-idx = {(int(i), int(k)): n for n, (i, k) in enumerate(zip(ti, tk)) if i >= 0}
+idx = {(int(i), int(k)): n for n, (i, k) in enumerate(zip(ti, tk)) if i >= 0}      # tile -> the task that PUBLISHES it
+sumtask = {}
+for n in np.flatnonzero((ti >= 0) & (mode == 1)):
+    sumtask[int(tk[n])] = n
+    idx[(int(ti[n]), int(tk[n]))] = None           # filled below: published by the diagonal task of the column
+for key in [kk for kk, v in idx.items() if v is None]:
+    idx[key] = idx[(key[1], key[1])]
 helpers = {}
 for n in np.flatnonzero(helper):
     helpers.setdefault((int(ri[n]), int(tk[n])), []).append(n)
@@ -48,7 +55,8 @@ while True:
     deps = [idx[(k, j)] for j in js] + [idx[(i, j)] for j in js if i != k]
     if not helper[n]:
         deps += helpers.get((i, k), [])
-        if i != k: deps.append(idx[(k, k)])
+        if i != k and mode[n] == 0: deps.append(idx[(k, k)])
+        if mode[n] == 2: deps.append(sumtask[k])
     if not deps:
         chain.append((int(ti[n]), k, nprod[n], start[n], 0.0, done[n] - start[n], 0.0)); break
     d = max(deps, key=lambda m: done[m])

@@ -50,7 +50,11 @@ struct DfTask { int i, k; };
 // L^-1 product.  np < 0: a helper: the products j in [jlo, jhi) of tile (i,k) into partial slot
 // `part` -- the sums of the dense rows (IO unknowns, right-hand side: one product per tile column
 // of the whole system) are cut into pieces that run side by side.
-struct DfJob { int i, k, jlo, jhi, part, np; };
+// mode: 0 plain; 1: tile (i,k) is the FIRST tile below the diagonal of its column (the next link of
+// the dependent chain): its task only sums, publishes T = A - sum in the tile and is done -- the
+// diagonal task of column k (mode 2, p = that tile row) multiplies it by L^-T right after its own
+// factorisation, so the chain does not pass through a second workgroup (store, flag, load of L^-1).
+struct DfJob { int i, k, jlo, jhi, part, np, mode, p; };
 
 // Tiles that one workgroup writes and others read inside the same launch move
 // with agent-scope relaxed atomics (sc1 loads/stores that bypass the per-XCD
@@ -409,7 +413,7 @@ __global__ __launch_bounds__(256) void k_chol_df(DfView V, int n, int nT, const 
                                                  const int *__restrict__ bk_idx, double *__restrict__ q_out,
                                                  double *__restrict__ q_nat, double *__restrict__ ldiag,
                                                  const double *__restrict__ qscale, double *__restrict__ dz_out,
-                                                 double *__restrict__ parts) {
+                                                 double *__restrict__ parts, int nparts) {
     constexpr int NB = 64, LD = DF_LD;
     __shared__ double smem[2 * NB * LD];                // Pm | Qm, or the augmented block of df_potf2
     double *Pm = smem, *Qm = smem + NB * LD;
@@ -438,6 +442,7 @@ __global__ __launch_bounds__(256) void k_chol_df(DfView V, int n, int nT, const 
         const bool helper = jb.np < 0;                  // a piece of a long sum (see DfJob)
         const int jend = helper ? jb.jhi : k;           // products j in [jb.jlo, jend)
         int *pflags = flags + (int64_t)(nT + 1) * nT;   // flags of the helpers' partial sums
+        int *tflags = pflags + nparts;                  // per column: T of its sum-only task (DfJob mode 1) is in the tile
         const int nr = i == nT ? 1 : min(NB, n - NB * i);
         const int64_t col0 = (int64_t)NB * k;
         const int nc = min(NB, n - NB * k);
@@ -574,6 +579,21 @@ __global__ __launch_bounds__(256) void k_chol_df(DfView V, int n, int nT, const 
             __syncthreads();                            // s_ok is rewritten in the next round
         }
         if (trace && t == 0) trace[task * 16 + 1] = wall_clock64();
+        if (jb.mode == 1) {                             // sum only: T -> the tile; the diagonal task of the column finishes it
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = 16 * ty + (tx >> 4) + 4 * e, r = 16 * rt + (tx & 15);
+                    if (r < nr && c < nc) st_coh(Tik + (int64_t)c * V.ld + r, -acc[rt][e]);
+                }
+            if (trace && t == 0) trace[task * 16 + 3] = wall_clock64();
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            if (t == 0) __hip_atomic_store(tflags + k, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (trace && t == 0) trace[task * 16 + 4] = wall_clock64();
+            continue;
+        }
         double *Linv = linv_all + (size_t)k * NB * NB;
         if (i == k) {
             // T(r, c) = -acc -> augmented block, ragged part = identity, upper triangle = 0
@@ -589,6 +609,54 @@ __global__ __launch_bounds__(256) void k_chol_df(DfView V, int n, int nT, const 
             if (trace && t == 0) trace[task * 16 + 14] = (long long)__builtin_readcyclecounter();
             df_potf2(smem, nc, (int)col0, info, trace ? trace + task * 16 : nullptr);
             if (trace && t == 0) trace[task * 16 + 15] = (long long)__builtin_readcyclecounter();
+            if (ldiag && ty == 0 && tx < nc) {          // the pivots, by natural index (k_prior_jv takes their extremes)
+                const int zn = V.iperm ? V.iperm[col0 + tx] : (int)(col0 + tx);
+                if (zn >= 0) ldiag[zn] = smem[tx * DF_TLD + tx];
+            }
+            if (jb.mode == 2) {
+                __syncthreads();                        // the pivots have been read: the L rows may go
+                // The next link of the chain, here instead of in a second workgroup: L(p,k) = T(p,k) L^-T with
+                // T from the column's sum-only task (published long ago as a rule) and L^-T where df_potf2
+                // left it.  The L rows of the augmented block are free in the compact layout (the diagonal
+                // tile is not stored): T goes there, smem[m*DF_TLD + r] = T(r, m).
+                const int p = jb.p;
+                const int nrp = p == nT ? 1 : min(NB, n - NB * p);
+                double *Tpk = V.base + V.toff[(int64_t)p * nT + k];
+                // (no prefetch across df_potf2: registers written by in-flight inline-asm loads must not be
+                // moved by the compiler, and under df_potf2's register pressure they are)
+                if (t == 0) s_ok = df_spin(tflags + k, epoch, abort_flag);
+                __syncthreads();
+                if (!s_ok) { if (t == 0) *info = -1; return; }
+                df_load_tile16<DF_TLD>(Tpk, V.ld, smem, tx, ty, false);
+                __syncthreads();
+                // X(r, c) = sum_{m <= c} T(r, m) Linv(c, m), Linv(c, m) = smem[c*DF_TLD + 64 + m].  Wave w takes
+                // the rows r in [16w, 16w+16) and all four column blocks cb, k-steps m < 16(cb+1) only
+                // (L^-1 is lower triangular): 40 instead of 64 products per wave, evenly.
+                chol_d4 x[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+                const double *pq = smem + (tx >> 4) * DF_TLD + 16 * ty + (tx & 15);          // T(r = 16w + lane%16, m = 4kk + lane/16)
+                const double *pl = smem + (tx & 15) * DF_TLD + 64 + (tx >> 4);               // Linv(c = 16cb + lane%16, m = 4kk + lane/16)
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) {
+                    const double b = pq[4 * kk * DF_TLD];
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb)
+                        if (kk < 4 * (cb + 1)) {
+                            const double a = pl[16 * cb * DF_TLD + 4 * kk];
+                            x[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, x[cb], 0, 0, 0);
+                        }
+                }
+                // x[cb][e] = X(c = 16cb + (lane>>4) + 4e, r = 16w + (lane&15))
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int c = 16 * cb + (tx >> 4) + 4 * e, r = 16 * ty + (tx & 15);
+                        if (r < nrp && c < nc) st_coh(Tpk + (int64_t)c * V.ld + r, x[cb][e]);
+                    }
+                __builtin_amdgcn_s_waitcnt(0);
+                __syncthreads();                        // L(p,k) is out: the chain goes on while L^-1 is stored
+                if (t == 0) __hip_atomic_store(flags + (int64_t)p * nT + k, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             // L -> tile (lower triangle), L^-1 -> Linv[c*64 + i] = Linv(i, c) = smem[i][64 + c]
 #pragma unroll 4
             for (int c = ty; c < NB; c += 4) {
@@ -596,10 +664,6 @@ __global__ __launch_bounds__(256) void k_chol_df(DfView V, int n, int nT, const 
                 // in the compact-tile layout nothing reads the diagonal tile again (the solves use L^-1)
                 if (!V.iperm && tx < nc && c < nc && tx >= c) st_coh(Tik + (int64_t)c * V.ld + tx, smem[c * DF_TLD + tx]);
                 st_coh(Linv + c * NB + tx, (tx < nc && c < nc && (c >> 4) <= (tx >> 4)) ? smem[tx * DF_TLD + 64 + c] : 0.0);   // L^-1 is lower triangular
-            }
-            if (ldiag && ty == 0 && tx < nc) {          // the pivots, by natural index (k_diag_minmax)
-                const int zn = V.iperm ? V.iperm[col0 + tx] : (int)(col0 + tx);
-                if (zn >= 0) ldiag[zn] = smem[tx * DF_TLD + tx];
             }
         } else {
             // T(r, c) = -acc  ->  Qm[c][r]
@@ -631,7 +695,9 @@ __global__ __launch_bounds__(256) void k_chol_df(DfView V, int n, int nT, const 
         if (trace && t == 0) trace[task * 16 + 3] = wall_clock64();
         __builtin_amdgcn_s_waitcnt(0);                      // this wave's tile stores have reached the coherence point
         __syncthreads();
-        if (t == 0) __hip_atomic_store(flags + (int64_t)i * nT + k, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == 0) {
+            __hip_atomic_store(flags + (int64_t)i * nT + k, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (trace && t == 0) trace[task * 16 + 4] = wall_clock64();
     }
 }
@@ -695,7 +761,7 @@ struct DataflowChol {
         d_flags = d_ctl = d_bk_ptr = d_bk_idx = d_iperm = nullptr; d_toff = nullptr; d_rowbits = nullptr;
         d_tasks = nullptr; d_tile_ij = nullptr; d_tiles = d_qperm = d_parts = nullptr;
     }
-    // per-task timestamps of the last solve (100 MHz ticks): task, i, k, t[0..15], jlo, jhi per line
+    // per-task timestamps of the last solve (100 MHz ticks): task, i, k, t[0..15], jlo, jhi, mode per line
     void dump_trace(hipStream_t stream, const char *path) const {
         if (!d_trace) return;
         std::vector<long long> h((size_t)(ntasks + nT) * 16);
@@ -708,7 +774,8 @@ struct DataflowChol {
             const int i = t < ntasks ? (h_tasks[t].np < 0 ? -(h_tasks[t].i + 2) : h_tasks[t].i) : -1, k = t < ntasks ? h_tasks[t].k : nT - 1 - (t - ntasks);
             fprintf(f, "%d,%d,%d", t, i, k);
             for (int q = 0; q < 16; ++q) fprintf(f, ",%lld", h[(size_t)t * 16 + q]);
-            fprintf(f, ",%d,%d\n", t < ntasks ? h_tasks[t].jlo : 0, t < ntasks ? (h_tasks[t].np < 0 ? h_tasks[t].jhi : h_tasks[t].k) : 0);   // its products: j in [jlo, jhi)
+            fprintf(f, ",%d,%d,%d\n", t < ntasks ? h_tasks[t].jlo : 0, t < ntasks ? (h_tasks[t].np < 0 ? h_tasks[t].jhi : h_tasks[t].k) : 0,
+                    t < ntasks ? h_tasks[t].mode : 0);   // its products: j in [jlo, jhi); mode (DfJob)
         }
         fclose(f);
     }
@@ -730,9 +797,12 @@ struct DataflowChol {
         std::vector<int> dptr(1, 0), dep;                       // per job: the two tiles of every product (ascending j)
         std::vector<int> js;
         nparts = 0; n_products = 0;
-        for (int k = 0; k < nT; ++k)
-            for (int i = k; i <= nT; ++i) {
-                if (!has(i, k)) continue;
+        const bool merge = permuted && !getenv("DBAT_HIP_DF_NOMERGE");     // compact tiles only (see k_chol_df)
+        std::vector<int> sumjob(nT, -1);                        // column -> the sum-only job of its first sub-diagonal tile
+        for (int k = 0; k < nT; ++k) {
+            int par = -1;
+            if (merge) for (int i = k + 1; i <= nT && par < 0; ++i) if (has(i, k)) par = i;
+            auto emit = [&](int i) {
                 js.clear();
                 for (int j = 0; j < k; ++j) if (has(i, j) && has(k, j)) js.push_back(j);
                 n_products += (long long)js.size();
@@ -743,14 +813,23 @@ struct DataflowChol {
                     dptr.push_back((int)dep.size());
                 };
                 for (int c = 0; c + 1 < nch; ++c) {             // helpers
-                    jobs.push_back(DfJob{i, k, js[chunk * c], js[chunk * (c + 1)], nparts + c, -1});
+                    jobs.push_back(DfJob{i, k, js[chunk * c], js[chunk * (c + 1)], nparts + c, -1, 0, -1});
                     push_products(chunk * c, chunk * (c + 1));
                 }
-                own[(size_t)i * nT + k] = (int)jobs.size();
-                jobs.push_back(DfJob{i, k, nch > 1 ? js[chunk * (nch - 1)] : 0, k, nparts, nch - 1});
+                const int me = (int)jobs.size();
+                const int mode = i == par ? 1 : (i == k && par >= 0 ? 2 : 0);
+                jobs.push_back(DfJob{i, k, nch > 1 ? js[chunk * (nch - 1)] : 0, k, nparts, nch - 1, mode, i == k ? par : -1});
                 push_products(chunk * (nch - 1), nj);
                 nparts += nch - 1;
-            }
+                return me;
+            };
+            // the sum-only task first: the diagonal task depends on it (job numbers stay topological)
+            if (par >= 0) sumjob[k] = emit(par);
+            own[(size_t)k * nT + k] = emit(k);
+            if (par >= 0) own[(size_t)par * nT + k] = own[(size_t)k * nT + k];      // L(par,k) is published by the diagonal task
+            for (int i = k + 1; i <= nT; ++i)
+                if (has(i, k) && i != par) own[(size_t)i * nT + k] = emit(i);
+        }
         ntasks = (int)jobs.size();
         auto is_helper = [&](int t) { return jobs[t].np < 0; };
         auto is_diag = [&](int t) { return jobs[t].np >= 0 && jobs[t].i == jobs[t].k; };
@@ -760,7 +839,8 @@ struct DataflowChol {
             for (int q = dptr[t]; q < dptr[t + 1]; ++q) if (dep[q] >= 0) f(dep[q]);
             if (!is_helper(t)) {
                 for (int h = 1; h <= jobs[t].np; ++h) f(t - h);
-                if (jobs[t].i != jobs[t].k) f(own[(size_t)jobs[t].k * nT + jobs[t].k]);
+                if (jobs[t].mode == 0 && jobs[t].i != jobs[t].k) f(own[(size_t)jobs[t].k * nT + jobs[t].k]);
+                if (jobs[t].mode == 2) f(sumjob[jobs[t].k]);
             }
         };
         if (!getenv("DBAT_HIP_DF_COLMAJOR")) {
@@ -772,7 +852,7 @@ struct DataflowChol {
             // have not started.  Candidate orders are tried on a model of the kernel (measured
             // costs, us: bench/chol_trace.py, bench/chol_path.py) and the best one is taken.
             const double c_prod = getenv("DBAT_HIP_DF_CPROD") ? atof(getenv("DBAT_HIP_DF_CPROD")) : 2.5, c_diag = 13.5, c_off = 4.5, c_hop = 2.0, c_add = 1.5, c_help = 2.0;
-            auto tail_of = [&](int t) { return is_helper(t) ? c_help : (is_diag(t) ? c_diag : c_off); };
+            auto tail_of = [&](int t) { return is_helper(t) || jobs[t].mode == 1 ? c_help : (is_diag(t) ? c_diag + (jobs[t].mode == 2 ? 2.5 : 0.0) : c_off); };
             // (1) earliest start: every input the moment it exists, unlimited workgroups
             std::vector<double> est(ntasks, 0.0), fin(ntasks, 0.0);
             for (int t = 0; t < ntasks; ++t) {
@@ -804,7 +884,8 @@ struct DataflowChol {
                     }
                     if (!is_helper(t)) {
                         for (int h = jobs[t].np; h >= 1; --h) tc = std::max(tc, done[t - h] + c_hop) + c_add;
-                        if (jobs[t].i != jobs[t].k) tc = std::max(tc, done[own[(size_t)jobs[t].k * nT + jobs[t].k]] + c_hop);
+                        if (jobs[t].mode == 0 && jobs[t].i != jobs[t].k) tc = std::max(tc, done[own[(size_t)jobs[t].k * nT + jobs[t].k]] + c_hop);
+                        if (jobs[t].mode == 2) tc = std::max(tc, done[sumjob[jobs[t].k]] + c_hop - c_diag);    // T is only wanted after the factorisation
                     }
                     tc += tail_of(t);
                     done[t] = tc; last = std::max(last, tc);
@@ -875,10 +956,10 @@ struct DataflowChol {
         }
         if (!up(d_tasks, jobs) || !up(d_bk_ptr, bptr) || !up(d_bk_idx, bidx) || !up(d_rowbits, rowbits) || !up(d_toff, toff))
             return false;
-        if (hipMalloc(&d_flags, ((size_t)(nT + 1) * nT + (size_t)nparts) * sizeof(int)) != hipSuccess) return false;   // tiles, then helper slots
+        if (hipMalloc(&d_flags, ((size_t)(nT + 1) * nT + (size_t)nparts + (size_t)nT) * sizeof(int)) != hipSuccess) return false;   // tiles, helper slots, T of the sum-only tasks
         if (nparts > 0 && hipMalloc(&d_parts, (size_t)nparts * 4096 * sizeof(double)) != hipSuccess) return false;
         if (hipMalloc(&d_ctl, 2 * sizeof(int)) != hipSuccess) return false;
-        (void)hipMemset(d_flags, 0, ((size_t)(nT + 1) * nT + (size_t)nparts) * sizeof(int));
+        (void)hipMemset(d_flags, 0, ((size_t)(nT + 1) * nT + (size_t)nparts + (size_t)nT) * sizeof(int));
         if (const char *g = getenv("DBAT_HIP_DF_GRID")) grid = std::min(std::max(atoi(g), 1), 4096);
         epoch = 0;
         return true;
@@ -1048,7 +1129,7 @@ struct DataflowChol {
         }
         hipLaunchKernelGGL(k_chol_df, dim3(std::min(grid, ntasks + nT)), dim3(256), 0, stream, V, n, nT, d_tasks, ntasks,
                            d_flags, d_ctl, epoch, linv_work, info_dev, d_trace, d_bk_ptr, d_bk_idx, qflag, q_out, ldiag,
-                           qscale, dz_out, d_parts);
+                           qscale, dz_out, d_parts, nparts);
     }
 };
 
