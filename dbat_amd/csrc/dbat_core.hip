@@ -317,7 +317,8 @@ struct Core {
                     && getenv("DBAT_HIP_TILE_BMAX") == nullptr;
         if (use_sig) {
 #define SET_SIG(M) SET_LDS((k_build_sig<M, 4, 6>), sig_lds_bytes(4, false)); SET_LDS((k_build_sig<M, 5, 6>), sig_lds_bytes(5, false)); \
-                   SET_LDS((k_build_sig<M, 4, 14>), sig_lds_bytes(4, true)); SET_LDS((k_build_sig<M, 5, 14>), sig_lds_bytes(5, true))
+                   SET_LDS((k_build_sig<M, 4, 14>), sig_lds_bytes(4, true)); SET_LDS((k_build_sig<M, 5, 14>), sig_lds_bytes(5, true)); \
+                   SET_LDS((k_build_sig<M, 4, 14, 1>), sig_lds_bytes(4, true)); SET_LDS((k_build_sig<M, 5, 14, 1>), sig_lds_bytes(5, true))
             SET_SIG(2); SET_SIG(3); SET_SIG(4); SET_SIG(5);
 #undef SET_SIG
         }
@@ -473,12 +474,20 @@ struct Core {
 #undef L_CAMN
             mark(0);                                 // events around the tile kernel alone (bench roofline)
 #define L_TILE3(M, DUMMY) LAUNCHK((k_build_tile3<M, TILE3_PC, TILE3_NBUF>), dim3((unsigned)ntiles), dim3(768), lds_tile3, stream, d, zz, cams.p, lambda, scale, S, g_red, Vinv.p, gp.p, jn2p.p, partial.p, pivmm.p)
-#define L_SIG(M, RBV) LAUNCHK((k_build_sig<M, (RBV) % 8, (RBV) / 8>), dim3((unsigned)ntiles), dim3(64 * sig_waves((RBV) % 8, (RBV) / 8 > 6)), sig_lds_bytes((RBV) % 8, (RBV) / 8 > 6), stream, d, zz, cams.p, lambda, scale, S, g_red, Vinv.p, gp.p, jn2p.p, partial.p, pivmm.p, sg_chunk.p, sg_tile_chunk0.p, sg_lc.p, sg_uv.p, P.uniform_w ? (const double *)nullptr : sg_w.p)
+#define L_SIG(M, RBV) LAUNCHK((k_build_sig<M, (RBV) % 8, (RBV) / 8>), dim3((unsigned)(ntiles - n_ios)), dim3(64 * sig_waves((RBV) % 8, (RBV) / 8 > 6)), sig_lds_bytes((RBV) % 8, (RBV) / 8 > 6), stream, d, zz, cams.p, lambda, scale, S, g_red, Vinv.p, gp.p, jn2p.p, partial.p, pivmm.p, sg_chunk.p, sg_tile_chunk0.p, sg_lc.p, sg_uv.p, P.uniform_w ? (const double *)nullptr : sg_w.p, (int)n_ios)
+#define L_SIGS(M, RBV) LAUNCHK((k_build_sig<M, (RBV) % 8, (RBV) / 8, 1>), dim3((unsigned)n_ios), dim3(64 * sig_waves((RBV) % 8, (RBV) / 8 > 6)), sig_lds_bytes((RBV) % 8, (RBV) / 8 > 6), stream, d, zz, cams.p, lambda, scale, S, g_red, Vinv.p, gp.p, jn2p.p, partial.p, pivmm.p, sg_chunk.p, sg_tile_chunk0.p, sg_lc.p, sg_uv.p, P.uniform_w ? (const double *)nullptr : sg_w.p, 0)
+            // self-calibration: the first n_ios tiles of tile_order have one IO block (their own instantiation)
+            const int64_t n_ios = (use_sig && tile_ncx == 14) ? P.n_tiles_io_simple : 0;
             // (row blocks, camera-side columns) packed into one macro argument: RB + 8 * NCX
             if (use_sig && tile_ncx == 6 && sig_rb == 4) { DISPATCH_MODEL(L_SIG, 4 + 8 * 6) }
             else if (use_sig && tile_ncx == 6) { DISPATCH_MODEL(L_SIG, 5 + 8 * 6) }
-            else if (use_sig && sig_rb == 4) { DISPATCH_MODEL(L_SIG, 4 + 8 * 14) }
-            else if (use_sig) { DISPATCH_MODEL(L_SIG, 5 + 8 * 14) }
+            else if (use_sig && sig_rb == 4) {
+                if (n_ios > 0) { DISPATCH_MODEL(L_SIGS, 4 + 8 * 14) }
+                if (ntiles > n_ios) { DISPATCH_MODEL(L_SIG, 4 + 8 * 14) }
+            } else if (use_sig) {
+                if (n_ios > 0) { DISPATCH_MODEL(L_SIGS, 5 + 8 * 14) }
+                if (ntiles > n_ios) { DISPATCH_MODEL(L_SIG, 5 + 8 * 14) }
+            }
             else if (use_tile3 && tile_ncx == 6) { DISPATCH_MODEL(L_TILE3, 0) }
             else if (use_tile2 && tile_ncx == 6) { DISPATCH_MODEL(L_TILE2, 6) }
             else if (use_tile2 && tile_ncx == 14) { DISPATCH_MODEL(L_TILE2, 14) }

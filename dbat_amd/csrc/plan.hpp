@@ -84,6 +84,8 @@ struct Plan {
     std::vector<int32_t> tile_io_start;            // [ntiles+1]
     std::vector<int32_t> tile_iocols;              // IOu indices, ascending inside a tile
     std::vector<uint8_t> tile_cam_io;              // [#tile cams][16]: local IO row of the camera's j-th IO column
+    std::vector<uint8_t> tile_io_simple;           // per tile: all its cameras share one IO block, IO column q = tile IO row q
+    int32_t n_tiles_io_simple = 0;                 // tile_order lists those tiles first
     // signature groups (k_build_sig): consecutive points of a tile that are seen by exactly the
     // same cameras share their rows of the reduced system.  A chunk = at most 64 points of one
     // group; 8 ints per chunk {first point (processing order), #points, #cameras k, first
@@ -634,7 +636,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     std::vector<int32_t> stamp(nc, -1);              // tile id in which a camera was last seen
     std::vector<int32_t> io_stamp(std::max(1, P.nIOu), -1);
     std::vector<int32_t> cur_cams, cur_io;
-    P.tile_io_start.clear(); P.tile_iocols.clear(); P.tile_cam_io.clear();
+    P.tile_io_start.clear(); P.tile_iocols.clear(); P.tile_cam_io.clear(); P.tile_io_simple.clear();
     P.tile_io_start.push_back(0);
     int64_t pos = 0, bstart = 0, tile_first_obs = 0;
     // signature groups of the current tile
@@ -676,14 +678,18 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         for (int64_t o = tile_first_obs; o < end_obs; ++o) P.o_lc[o] = (uint8_t)loc[P.o_cam[o]];
         // IO columns of the tile, ascending; every camera's IO columns -> local IO rows
         std::sort(cur_io.begin(), cur_io.end());
+        bool io_simple = !cur_cams.empty();
         for (int32_t c : cur_cams) {
             uint8_t rows16[16] = {0};
             for (int q = 6; q < P.cam_ncol[c]; ++q) {
                 const int32_t io = P.cam_col[(size_t)c * MAXCOL + q] - 6 * nc;
                 rows16[q - 6] = (uint8_t)(std::lower_bound(cur_io.begin(), cur_io.end(), io) - cur_io.begin());
+                io_simple = io_simple && rows16[q - 6] == q - 6;
             }
+            io_simple = io_simple && P.cam_ncol[c] == P.cam_ncol[cur_cams[0]] && (size_t)(P.cam_ncol[c] - 6) == cur_io.size();
             P.tile_cam_io.insert(P.tile_cam_io.end(), rows16, rows16 + 16);
         }
+        P.tile_io_simple.push_back(io_simple ? 1 : 0);
         for (int32_t io : cur_io) { P.tile_iocols.push_back(io); io_stamp[io] = -1; }
         P.tile_io_start.push_back((int32_t)P.tile_iocols.size());
         cur_io.clear();
@@ -841,6 +847,12 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
             return P.batch_start[P.tile_batch[a + 1]] - P.batch_start[P.tile_batch[a]] >
                    P.batch_start[P.tile_batch[b + 1]] - P.batch_start[P.tile_batch[b]];
         });
+        // self-calibration: the tiles with one IO block first (they run their own instantiation of k_build_sig)
+        P.n_tiles_io_simple = 0;
+        if (P.with_io && (int)P.tile_io_simple.size() == nt && !getenv("DBAT_HIP_SIG_IOS_OFF")) {
+            std::stable_partition(P.tile_order.begin(), P.tile_order.end(), [&](int32_t a) { return P.tile_io_simple[a] != 0; });
+            for (int a = 0; a < nt; ++a) P.n_tiles_io_simple += P.tile_io_simple[a] ? 1 : 0;
+        }
     }
     {   // camera-major copy of the observations (stable counting sort by camera): first the tiled
         // ones (chunks [0, n_cm_chunks_tiled): k_cam_normal), then the rest (heavy / giant points);

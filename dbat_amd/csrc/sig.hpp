@@ -71,7 +71,9 @@ __device__ __forceinline__ double lane_get(double x, int src) {
 // nio further rows of every chunk (after its 6k camera rows, before the row of y): an IO row is
 // shared by the k observations of a point, so its k-columns are summed with ds_add_f64 into the
 // zeroed panel rows.
-template <int MODEL, int RB, int NCX>
+// IOS = 1: self-calibration, tiles whose cameras all share ONE IO block with the identity row map (the
+// plan lists them first in tile_order): the IO rows of a point are summed in pass 1 (see below).
+template <int MODEL, int RB, int NCX, int IOS = 0>
 __global__ __launch_bounds__(64 * sig_waves(RB, (NCX > 6))) void k_build_sig(DevProblem d, const double *__restrict__ z,
                                                    const CamRec *__restrict__ cams, double lambda, int scale,
                                                    double *__restrict__ S, double *__restrict__ g_red,
@@ -81,8 +83,9 @@ __global__ __launch_bounds__(64 * sig_waves(RB, (NCX > 6))) void k_build_sig(Dev
                                                    const int32_t *__restrict__ sg_chunk,
                                                    const int32_t *__restrict__ sg_tile_chunk0,
                                                    const uint8_t *__restrict__ sg_lc, const double *__restrict__ sg_uv,
-                                                   const double *__restrict__ sg_w) {
+                                                   const double *__restrict__ sg_w, int tile_off) {
     constexpr bool IO = NCX > 6;
+    constexpr bool io_simple = IO && IOS != 0;
     constexpr int NBLK = RB * (RB + 1) / 2, PROWS = RB * 16, LDK = SIG_LDK, NW = sig_waves(RB, IO), NT = 64 * NW;
     constexpr int CAMW = IO ? SIG_CAMW_IO : SIG_CAMW;
     extern __shared__ double smem[];
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(64 * sig_waves(RB, (NCX > 6))) void k_build_sig(Dev
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     double *pan = wave_base + (size_t)wave * (PROWS * LDK);                // [PROWS][LDK]
-    const int tile = d.tile_order[blockIdx.x];
+    const int tile = d.tile_order[blockIdx.x + tile_off];
     const int c0 = d.tile_cam_start[tile];
     const int ncam = d.tile_cam_start[tile + 1] - c0;
     const int io0 = IO ? d.tile_io_start[tile] : 0;
@@ -161,6 +164,15 @@ __global__ __launch_bounds__(64 * sig_waves(RB, (NCX > 6))) void k_build_sig(Dev
         // ------------------------------------------------------------ pass 1: lane = object point
         double pR[6] = {0, 0, 0, 0, 0, 0}, pY[3] = {0, 0, 0}, pQ[3] = {0, 0, 0};     // of this lane's point, for pass 2
         unsigned pEst = 0;
+        // Self-calibration, the rule (IOS): all cameras of the tile share one IO block, IO column q = tile
+        // IO row q.  Then the IO rows of a point, Z_io = (sum_j E_io,j' B_j) R, are summed where the
+        // point's observations are visited one after the other anyway -- in pass 1, in the lane's
+        // registers -- instead of by 24 LDS atomics per observation (ten observations on the same
+        // addresses) in pass 2.  Tiles that mix IO blocks run the IOS = 0 instantiation with the atomics.
+        constexpr int NQ = io_simple ? NCX - 6 : 1;
+        double pZio[NQ][3];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) pZio[q][0] = pZio[q][1] = pZio[q][2] = 0.0;
         {
             // a chunk of at most 32 points takes two lanes per point: lane l and lane l + 32 share the
             // cameras (even / odd slots) and add their sums up afterwards
@@ -188,12 +200,27 @@ __global__ __launch_bounds__(64 * sig_waves(RB, (NCX > 6))) void k_build_sig(Dev
                     if (sg_w) w_n = wp[q + (int64_t)jstep * gm];
                 }
                 double r[2], A[2][6], B[2][3], Cf[2][MAXIO];
-                obs_eval<MODEL, true, false>(C, d.nK, d.nP, Q, uu, vv, r, A, B, Cf);    // A is dead code here
+                obs_eval<MODEL, true, io_simple>(C, d.nK, d.nP, Q, uu, vv, r, A, B, Cf);    // A is dead code here
                 r[0] *= w0; r[1] *= w1;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const double m = ((est >> c) & 1u) ? 1.0 : 0.0;
                     B[0][c] *= w0 * m; B[1][c] *= w1 * m;
+                }
+                if constexpr (io_simple) {
+                    {                                // W_io += E_io' B
+                        double Eio[2][NCX];
+                        io_columns<NCX>(C, Cf, w0, w1, Eio);
+                        const int ncol = min(C.ncol, NCX);
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q)
+                            if (6 + q < ncol) {
+                                const double e0 = Eio[0][6 + q], e1 = Eio[1][6 + q];
+                                pZio[q][0] += e0 * B[0][0] + e1 * B[1][0];
+                                pZio[q][1] += e0 * B[0][1] + e1 * B[1][1];
+                                pZio[q][2] += e0 * B[0][2] + e1 * B[1][2];
+                            }
+                    }
                 }
                 if (act) rr += r[0] * r[0] + r[1] * r[1];
                 V[0] += B[0][0] * B[0][0] + B[1][0] * B[1][0];
@@ -211,6 +238,12 @@ __global__ __launch_bounds__(64 * sig_waves(RB, (NCX > 6))) void k_build_sig(Dev
                 for (int c = 0; c < 6; ++c) V[c] += lane_get(V[c], lane ^ 32);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) g[c] += lane_get(g[c], lane ^ 32);
+                if constexpr (io_simple) {
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) pZio[q][c] += lane_get(pZio[q][c], lane ^ 32);
+                }
             }
             const bool writer = act && lane == pi;    // one lane per point writes to HBM
             if (act) {
@@ -265,6 +298,18 @@ __global__ __launch_bounds__(64 * sig_waves(RB, (NCX > 6))) void k_build_sig(Dev
                 pY[2] = r22 * g[2];
                 pQ[0] = Q[0]; pQ[1] = Q[1]; pQ[2] = Q[2];
                 pEst = est;
+                if constexpr (io_simple) {
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {       // Z_io = W_io R
+                        const double w0_ = pZio[q][0], w1_ = pZio[q][1], w2_ = pZio[q][2];
+                        pZio[q][0] = w0_ * r00 + w1_ * r10 + w2_ * r20;
+                        pZio[q][1] = w1_ * r11 + w2_ * r21;
+                        pZio[q][2] = w2_ * r22;
+                    }
+                }
+            } else if constexpr (io_simple) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) pZio[q][0] = pZio[q][1] = pZio[q][2] = 0.0;      // no point in this lane
             }
         }
         lap(2);
@@ -294,8 +339,35 @@ __global__ __launch_bounds__(64 * sig_waves(RB, (NCX > 6))) void k_build_sig(Dev
 #pragma unroll
             for (int a = 0; a < 6; ++a) Zr[a][0] = Zr[a][1] = Zr[a][2] = 0.0;
             double y3[3] = {0, 0, 0};
-            if constexpr (IO) {                      // the IO rows are sums over a point's observations: start from zero
-                for (int q = lane; q < nio * LDK; q += 64) pan[6 * k * LDK + q] = 0.0;
+            if constexpr (IO) {
+                if constexpr (!io_simple) {          // the IO rows are sums over a point's observations: start from zero
+                    for (int q = lane; q < nio * LDK; q += 64) pan[6 * k * LDK + q] = 0.0;
+                } else {
+                    // Z_io of the round's points from the lanes that hold them (pass-1 layout: lane = point;
+                    // lanes without a point hold zeros and clear the previous round's columns)
+                    const int pil = npts <= 32 ? (lane & 31) : lane;
+                    const int irw = pil - p0;
+                    const int lc0 = sy.lc[wave][0];
+                    const int ncol0 = min(reinterpret_cast<const CamRec *>(camw + lc0 * CAMW)->ncol, NCX);
+                    if (lane == pil && irw >= 0 && irw < ppr) {
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q)
+                            if (6 + q < ncol0) {
+                                double *pio = pan + (6 * k + q) * LDK + 3 * irw;
+                                pio[0] = pZio[q][0]; pio[1] = pZio[q][1]; pio[2] = pZio[q][2];
+                            }
+                    }
+                    const int nhold = npts <= 32 ? 32 : 64;           // points that have a lane in the pass-1 layout
+                    if (p0 + ppr > nhold && lane < p0 + ppr - nhold) {   // columns of points nhold, nhold+1, ...: no lane holds them
+                        const int irz = nhold - p0 + lane;
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q)
+                            if (6 + q < ncol0) {
+                                double *pio = pan + (6 * k + q) * LDK + 3 * irz;
+                                pio[0] = 0.0; pio[1] = 0.0; pio[2] = 0.0;
+                            }
+                    }
+                }
             }
             // R | y | Q | est of this lane's point, from the lane that holds it
             const int src = on ? i : lane;
@@ -310,14 +382,14 @@ __global__ __launch_bounds__(64 * sig_waves(RB, (NCX > 6))) void k_build_sig(Dev
                 const double uu = uv_c.x, vv = uv_c.y;
                 const double w0 = sg_w ? w_c.x : C.w[0], w1 = sg_w ? w_c.y : C.w[1];
                 double r[2], A[2][6], B[2][3], Cf[2][MAXIO];
-                obs_eval<MODEL, true, IO>(C, d.nK, d.nP, Q, uu, vv, r, A, B, Cf);
+                obs_eval<MODEL, true, (IO && !io_simple)>(C, d.nK, d.nP, Q, uu, vv, r, A, B, Cf);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const double m = ((est >> c) & 1u) ? 1.0 : 0.0;
                     B[0][c] *= w0 * m; B[1][c] *= w1 * m;
                 }
                 const double r00 = gR[0], r10 = gR[1], r20 = gR[2], r11 = gR[3], r21 = gR[4], r22 = gR[5];
-                if constexpr (IO) {                  // IO columns of this camera -> the chunk's IO rows (LDS atomics)
+                if constexpr (IO && !io_simple) {    // IO columns of this camera -> the chunk's IO rows (LDS atomics)
                     const int ncol = min(C.ncol, NCX);
                     double Eio[2][NCX];
                     io_columns<NCX>(C, Cf, w0, w1, Eio);
@@ -437,7 +509,7 @@ __global__ __launch_bounds__(64 * sig_waves(RB, (NCX > 6))) void k_build_sig(Dev
         if (vt[i] != 0.0) atomic_add_f64(g_red + sy.grow[i], vt[i]);
     double accr[1] = {rr};
     block_sum<1>(accr, sh);
-    if (t == 0) partial[blockIdx.x] = accr[0];
+    if (t == 0) partial[blockIdx.x + tile_off] = accr[0];
     pmin = pmin < 1e300 ? sqrt(pmin) : pmin; pmax = sqrt(pmax);
     for (int off = 32; off > 0; off >>= 1) {
         pmin = fmin(pmin, __shfl_down(pmin, off, 64));

@@ -1140,6 +1140,29 @@ def test_run_to_run_repeatability(hip, name, sig, monkeypatch):
         h.close()
 
 
+@pytest.mark.parametrize('rays,groups', [(6, 1), (10, 1), (6, 4)])
+def test_selfcal_io_rows_summed_per_point(hip, rays, groups, monkeypatch):
+    """Self-calibration: tiles whose cameras share one IO block run the k_build_sig instantiation
+    that sums a point's IO rows in pass 1 (registers) instead of LDS atomics in pass 2.  On a scene
+    with long signature groups (several rounds per chunk, one and two lanes per point, chunks that
+    end in a partial round) its step must agree with the instantiation with the atomics to rounding;
+    with four IO blocks both instantiations run side by side."""
+    from dbat_amd import synth
+    monkeypatch.setenv('DBAT_HIP_SIG', '2')
+    s, _ = synth.make_scene('C1', selfcal=True, rays=rays, groups=groups)
+    def step():
+        h = hip.Handle(s)
+        try:
+            p, st = h.linearize_solve(h.serialize(), 0.0, True)
+            assert not st['singular']
+            return p
+        finally:
+            h.close()
+    p_new = step()
+    monkeypatch.setenv('DBAT_HIP_SIG_IOS_OFF', '1')
+    assert relerr(p_new, step()) < 1e-9
+
+
 @pytest.mark.parametrize('name,selfcal', [('small', False), ('small', True), ('C1', False)])
 def test_cholesky_split_sums_and_orders(hip, name, selfcal, monkeypatch):
     """The dataflow Cholesky cuts long left-looking sums into helper tasks (partial sums in scratch
