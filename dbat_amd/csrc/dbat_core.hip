@@ -93,6 +93,7 @@ struct Core {
     DevBuf<double> io_fixed, px, cam_w, z_prw, z_prv, o_uv, o_w;
     DevBuf<uint8_t> z_est, z_mine, o_lc, o_pidx;
     DevBuf<int32_t> tile_batch, tile_cam_start, tile_cams, tile_io_start, tile_iocols;
+    DevBuf<uint8_t> tile_io_simple;
     DevBuf<uint8_t> tile_cam_io;
     DevBuf<int32_t> sg_chunk, sg_tile_chunk0, sg_gcam;   // signature groups (sig.hpp)
     int64_t sg_nchunks = 0;
@@ -215,6 +216,7 @@ struct Core {
         if (const char *e = getenv("DBAT_HIP_GIANT_THREADS")) { const int v = atoi(e); if (v == 64 || v == 128) giant_threads = v; }
         d.tile_batch = tile_batch.p; d.tile_cam_start = tile_cam_start.p; d.tile_cams = tile_cams.p;
         d.tile_io_start = tile_io_start.p; d.tile_iocols = tile_iocols.p; d.tile_cam_io = tile_cam_io.p;
+        tile_io_simple.upload(P.tile_io_simple); d.tile_io_simple = P.tile_io_simple.empty() ? nullptr : tile_io_simple.p;
         use_sig = P.sg_ok && ntiles > 0 && tile_ncx <= 14;
         if (use_sig) {
             sg_chunk.upload(P.sg_chunk); sg_tile_chunk0.upload(P.sg_tile_chunk0); sg_lc.upload(P.sg_lc); sg_gcam.upload(P.sg_gcam);
@@ -317,8 +319,7 @@ struct Core {
                     && getenv("DBAT_HIP_TILE_BMAX") == nullptr;
         if (use_sig) {
 #define SET_SIG(M) SET_LDS((k_build_sig<M, 4, 6>), sig_lds_bytes(4, false)); SET_LDS((k_build_sig<M, 5, 6>), sig_lds_bytes(5, false)); \
-                   SET_LDS((k_build_sig<M, 4, 14>), sig_lds_bytes(4, true)); SET_LDS((k_build_sig<M, 5, 14>), sig_lds_bytes(5, true)); \
-                   SET_LDS((k_build_sig<M, 4, 14, 1>), sig_lds_bytes(4, true)); SET_LDS((k_build_sig<M, 5, 14, 1>), sig_lds_bytes(5, true))
+                   SET_LDS((k_build_sig<M, 4, 14>), sig_lds_bytes(4, true)); SET_LDS((k_build_sig<M, 5, 14>), sig_lds_bytes(5, true));
             SET_SIG(2); SET_SIG(3); SET_SIG(4); SET_SIG(5);
 #undef SET_SIG
         }
@@ -474,20 +475,12 @@ struct Core {
 #undef L_CAMN
             mark(0);                                 // events around the tile kernel alone (bench roofline)
 #define L_TILE3(M, DUMMY) LAUNCHK((k_build_tile3<M, TILE3_PC, TILE3_NBUF>), dim3((unsigned)ntiles), dim3(768), lds_tile3, stream, d, zz, cams.p, lambda, scale, S, g_red, Vinv.p, gp.p, jn2p.p, partial.p, pivmm.p)
-#define L_SIG(M, RBV) LAUNCHK((k_build_sig<M, (RBV) % 8, (RBV) / 8>), dim3((unsigned)(ntiles - n_ios)), dim3(64 * sig_waves((RBV) % 8, (RBV) / 8 > 6)), sig_lds_bytes((RBV) % 8, (RBV) / 8 > 6), stream, d, zz, cams.p, lambda, scale, S, g_red, Vinv.p, gp.p, jn2p.p, partial.p, pivmm.p, sg_chunk.p, sg_tile_chunk0.p, sg_lc.p, sg_uv.p, P.uniform_w ? (const double *)nullptr : sg_w.p, (int)n_ios)
-#define L_SIGS(M, RBV) LAUNCHK((k_build_sig<M, (RBV) % 8, (RBV) / 8, 1>), dim3((unsigned)n_ios), dim3(64 * sig_waves((RBV) % 8, (RBV) / 8 > 6)), sig_lds_bytes((RBV) % 8, (RBV) / 8 > 6), stream, d, zz, cams.p, lambda, scale, S, g_red, Vinv.p, gp.p, jn2p.p, partial.p, pivmm.p, sg_chunk.p, sg_tile_chunk0.p, sg_lc.p, sg_uv.p, P.uniform_w ? (const double *)nullptr : sg_w.p, 0)
-            // self-calibration: the first n_ios tiles of tile_order have one IO block (their own instantiation)
-            const int64_t n_ios = (use_sig && tile_ncx == 14) ? P.n_tiles_io_simple : 0;
+#define L_SIG(M, RBV) LAUNCHK((k_build_sig<M, (RBV) % 8, (RBV) / 8>), dim3((unsigned)ntiles), dim3(64 * sig_waves((RBV) % 8, (RBV) / 8 > 6)), sig_lds_bytes((RBV) % 8, (RBV) / 8 > 6), stream, d, zz, cams.p, lambda, scale, S, g_red, Vinv.p, gp.p, jn2p.p, partial.p, pivmm.p, sg_chunk.p, sg_tile_chunk0.p, sg_lc.p, sg_uv.p, P.uniform_w ? (const double *)nullptr : sg_w.p)
             // (row blocks, camera-side columns) packed into one macro argument: RB + 8 * NCX
             if (use_sig && tile_ncx == 6 && sig_rb == 4) { DISPATCH_MODEL(L_SIG, 4 + 8 * 6) }
             else if (use_sig && tile_ncx == 6) { DISPATCH_MODEL(L_SIG, 5 + 8 * 6) }
-            else if (use_sig && sig_rb == 4) {
-                if (n_ios > 0) { DISPATCH_MODEL(L_SIGS, 4 + 8 * 14) }
-                if (ntiles > n_ios) { DISPATCH_MODEL(L_SIG, 4 + 8 * 14) }
-            } else if (use_sig) {
-                if (n_ios > 0) { DISPATCH_MODEL(L_SIGS, 5 + 8 * 14) }
-                if (ntiles > n_ios) { DISPATCH_MODEL(L_SIG, 5 + 8 * 14) }
-            }
+            else if (use_sig && sig_rb == 4) { DISPATCH_MODEL(L_SIG, 4 + 8 * 14) }
+            else if (use_sig) { DISPATCH_MODEL(L_SIG, 5 + 8 * 14) }
             else if (use_tile3 && tile_ncx == 6) { DISPATCH_MODEL(L_TILE3, 0) }
             else if (use_tile2 && tile_ncx == 6) { DISPATCH_MODEL(L_TILE2, 6) }
             else if (use_tile2 && tile_ncx == 14) { DISPATCH_MODEL(L_TILE2, 14) }

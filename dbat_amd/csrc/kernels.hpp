@@ -50,6 +50,7 @@ struct DevProblem {
     const int32_t *tile_batch, *tile_cam_start, *tile_cams;
     const int32_t *tile_order;                      // launch index -> tile (longest first)
     const int32_t *tile_io_start, *tile_iocols;     // IO columns (IOu indices) of every tile
+    const uint8_t *tile_io_simple;                  // per tile: one IO block, identity row map (k_build_sig); may be null
     const uint8_t *tile_cam_io;                     // [#tile cams][16] local IO row of a camera's j-th IO column
     // "giant" points: more observations than a batch holds; one workgroup per point
     int ngiant;

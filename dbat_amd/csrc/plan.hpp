@@ -85,7 +85,7 @@ struct Plan {
     std::vector<int32_t> tile_iocols;              // IOu indices, ascending inside a tile
     std::vector<uint8_t> tile_cam_io;              // [#tile cams][16]: local IO row of the camera's j-th IO column
     std::vector<uint8_t> tile_io_simple;           // per tile: all its cameras share one IO block, IO column q = tile IO row q
-    int32_t n_tiles_io_simple = 0;                 // tile_order lists those tiles first
+    int32_t n_tiles_io_simple = 0;
     // signature groups (k_build_sig): consecutive points of a tile that are seen by exactly the
     // same cameras share their rows of the reduced system.  A chunk = at most 64 points of one
     // group; 8 ints per chunk {first point (processing order), #points, #cameras k, first
@@ -847,12 +847,9 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
             return P.batch_start[P.tile_batch[a + 1]] - P.batch_start[P.tile_batch[a]] >
                    P.batch_start[P.tile_batch[b + 1]] - P.batch_start[P.tile_batch[b]];
         });
-        // self-calibration: the tiles with one IO block first (they run their own instantiation of k_build_sig)
         P.n_tiles_io_simple = 0;
-        if (P.with_io && (int)P.tile_io_simple.size() == nt && !getenv("DBAT_HIP_SIG_IOS_OFF")) {
-            std::stable_partition(P.tile_order.begin(), P.tile_order.end(), [&](int32_t a) { return P.tile_io_simple[a] != 0; });
-            for (int a = 0; a < nt; ++a) P.n_tiles_io_simple += P.tile_io_simple[a] ? 1 : 0;
-        }
+        if (getenv("DBAT_HIP_SIG_IOS_OFF")) std::fill(P.tile_io_simple.begin(), P.tile_io_simple.end(), 0);
+        for (uint8_t f : P.tile_io_simple) P.n_tiles_io_simple += f ? 1 : 0;
     }
     {   // camera-major copy of the observations (stable counting sort by camera): first the tiled
         // ones (chunks [0, n_cm_chunks_tiled): k_cam_normal), then the rest (heavy / giant points);

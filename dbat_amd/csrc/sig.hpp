@@ -71,19 +71,20 @@ __device__ __forceinline__ double lane_get(double x, int src) {
 // nio further rows of every chunk (after its 6k camera rows, before the row of y): an IO row is
 // shared by the k observations of a point, so its k-columns are summed with ds_add_f64 into the
 // zeroed panel rows.
-// IOS = 1: self-calibration, tiles whose cameras all share ONE IO block with the identity row map (the
-// plan lists them first in tile_order): the IO rows of a point are summed in pass 1 (see below).
-template <int MODEL, int RB, int NCX, int IOS = 0>
-__global__ __launch_bounds__(64 * sig_waves(RB, (NCX > 6))) void k_build_sig(DevProblem d, const double *__restrict__ z,
-                                                   const CamRec *__restrict__ cams, double lambda, int scale,
-                                                   double *__restrict__ S, double *__restrict__ g_red,
-                                                   double *__restrict__ Vinv, double *__restrict__ gp,
-                                                   double *__restrict__ jn2p,
-                                                   double *__restrict__ partial, unsigned long long *__restrict__ pivmm,
-                                                   const int32_t *__restrict__ sg_chunk,
-                                                   const int32_t *__restrict__ sg_tile_chunk0,
-                                                   const uint8_t *__restrict__ sg_lc, const double *__restrict__ sg_uv,
-                                                   const double *__restrict__ sg_w, int tile_off) {
+// IOS = 1: self-calibration, tiles whose cameras all share ONE IO block with the identity row map:
+// the IO rows of a point are summed in pass 1 (see below).  One launch serves both kinds of tiles
+// (k_build_sig branches per workgroup on the plan's flag), so they share the longest-first order.
+template <int MODEL, int RB, int NCX, int IOS>
+__device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int tile, const double *__restrict__ z,
+                                               const CamRec *__restrict__ cams, double lambda, int scale,
+                                               double *__restrict__ S, double *__restrict__ g_red,
+                                               double *__restrict__ Vinv, double *__restrict__ gp,
+                                               double *__restrict__ jn2p,
+                                               double *__restrict__ partial, unsigned long long *__restrict__ pivmm,
+                                               const int32_t *__restrict__ sg_chunk,
+                                               const int32_t *__restrict__ sg_tile_chunk0,
+                                               const uint8_t *__restrict__ sg_lc, const double *__restrict__ sg_uv,
+                                               const double *__restrict__ sg_w) {
     constexpr bool IO = NCX > 6;
     constexpr bool io_simple = IO && IOS != 0;
     constexpr int NBLK = RB * (RB + 1) / 2, PROWS = RB * 16, LDK = SIG_LDK, NW = sig_waves(RB, IO), NT = 64 * NW;
@@ -98,7 +99,6 @@ __global__ __launch_bounds__(64 * sig_waves(RB, (NCX > 6))) void k_build_sig(Dev
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     double *pan = wave_base + (size_t)wave * (PROWS * LDK);                // [PROWS][LDK]
-    const int tile = d.tile_order[blockIdx.x + tile_off];
     const int c0 = d.tile_cam_start[tile];
     const int ncam = d.tile_cam_start[tile + 1] - c0;
     const int io0 = IO ? d.tile_io_start[tile] : 0;
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(64 * sig_waves(RB, (NCX > 6))) void k_build_sig(Dev
         if (vt[i] != 0.0) atomic_add_f64(g_red + sy.grow[i], vt[i]);
     double accr[1] = {rr};
     block_sum<1>(accr, sh);
-    if (t == 0) partial[blockIdx.x + tile_off] = accr[0];
+    if (t == 0) partial[blockIdx.x] = accr[0];
     pmin = pmin < 1e300 ? sqrt(pmin) : pmin; pmax = sqrt(pmax);
     for (int off = 32; off > 0; off >>= 1) {
         pmin = fmin(pmin, __shfl_down(pmin, off, 64));
@@ -522,6 +522,27 @@ __global__ __launch_bounds__(64 * sig_waves(RB, (NCX > 6))) void k_build_sig(Dev
     lap(7);
     if (prof)
         for (int i = 0; i < 8; ++i) if (tp[i]) atomicAdd(&g_tile2_prof[i], (unsigned long long)tp[i]);
+}
+
+template <int MODEL, int RB, int NCX>
+__global__ __launch_bounds__(64 * sig_waves(RB, (NCX > 6))) void k_build_sig(DevProblem d, const double *__restrict__ z,
+                                                   const CamRec *__restrict__ cams, double lambda, int scale,
+                                                   double *__restrict__ S, double *__restrict__ g_red,
+                                                   double *__restrict__ Vinv, double *__restrict__ gp,
+                                                   double *__restrict__ jn2p,
+                                                   double *__restrict__ partial, unsigned long long *__restrict__ pivmm,
+                                                   const int32_t *__restrict__ sg_chunk,
+                                                   const int32_t *__restrict__ sg_tile_chunk0,
+                                                   const uint8_t *__restrict__ sg_lc, const double *__restrict__ sg_uv,
+                                                   const double *__restrict__ sg_w) {
+    const int tile = d.tile_order[blockIdx.x];
+    if constexpr (NCX > 6) {
+        if (d.tile_io_simple && d.tile_io_simple[tile]) {
+            build_sig_tile<MODEL, RB, NCX, 1>(d, tile, z, cams, lambda, scale, S, g_red, Vinv, gp, jn2p, partial, pivmm, sg_chunk, sg_tile_chunk0, sg_lc, sg_uv, sg_w);
+            return;
+        }
+    }
+    build_sig_tile<MODEL, RB, NCX, 0>(d, tile, z, cams, lambda, scale, S, g_red, Vinv, gp, jn2p, partial, pivmm, sg_chunk, sg_tile_chunk0, sg_lc, sg_uv, sg_w);
 }
 
 // k_backsub_sig: back-substitution dp = -V^-1 (g_p + W' dc) and ||J p||^2 over the image rows for the
