@@ -414,9 +414,15 @@ struct Core {
     }
 
     // ---- K2: f = 0.5 r'r at zz (all ranks' sum).  Optionally store r.
-    double eval_f(const double *zz, double *r_w_out, double *r_unw_out) {
+    // f at x + alpha p (x, p as given; the point goes to out): the trial point and its camera records in one launch
+    double eval_f_step(const double *x, double alpha, const double *pdir, double *out) {
+        if ((int64_t)cdiv(P.NZ, 256) < P.nc) { axpby(1.0, x, alpha, pdir, out); return eval_f(out, nullptr, nullptr); }
+        LAUNCHK(k_axpby_cams, dim3((unsigned)cdiv(P.NZ, 256)), dim3(256), 0, stream, d, 1.0, x, alpha, pdir, out, cams_f.p);
+        return eval_f(out, nullptr, nullptr, true);
+    }
+    double eval_f(const double *zz, double *r_w_out, double *r_unw_out, bool cams_ready = false) {
         // own camera records: the ones of the linearisation point stay valid for the next solve
-        prep_cams(zz, cams_f.p);
+        if (!cams_ready) prep_cams(zz, cams_f.p);
         mark(6);
         // the objective value always comes from the camera-major kernel (one summation order for
         // every value the damping loops compare); the point-major one only when residuals are exported.
@@ -444,7 +450,9 @@ struct Core {
 
     // ---- K1: linearise at zz with damping lambda; builds the reduced system.
     void build_enqueue(const double *zz, double lambda, int scale) {
-        prep_cams(zz);
+        const bool fused_first = !(s_dense_dirty || getenv("DBAT_HIP_DENSE_ALLREDUCE")) && P.NS >= P.nc;
+        if (!fused_first) prep_cams(zz);
+        else cams_at_lin = false;
         // only the envelope of S is ever written or read: zero that (and the vectors behind S); the whole
         // array once, and again after something filled it densely (the inverse of the posterior covariance)
         bool pivmm_set = false;
@@ -453,7 +461,8 @@ struct Core {
             s_dense_dirty = false;
         } else {
             // ... and the vectors behind S, and the pivot extremes {min, max} x {points, cameras}
-            LAUNCHK(k_envelope_op, dim3((unsigned)P.NS), dim3(256), 0, stream, S, ldS, (int)P.NS, env_tail0, col_bend.p, (const double *)nullptr, g_red, pivmm.p);
+            // ... and the camera records at zz, all in the first launch
+            LAUNCHK(k_envelope_cams, dim3((unsigned)P.NS), dim3(256), 0, stream, d, zz, cams.p, S, ldS, (int)P.NS, env_tail0, col_bend.p, g_red, pivmm.p);
             pivmm_set = true;
         }
         if (!pivmm_set) HIPCHK(hipMemcpyAsync(pivmm.p, hpin + 48, 4 * sizeof(double), hipMemcpyHostToDevice, stream));
@@ -526,14 +535,15 @@ struct Core {
         }
         // red_scal[0] = the build kernels' residual sums + the prior rows' squares, red_scal[1] = owned
         // squared column norms of the point columns
-        LAUNCHK(k_build_tail, dim3(grid_zs), dim3(1024), 0, stream, d, zz, partial.p, npart, jn2p.p, gpart.p, gctr.p + 2, red_scal);
+        // (and keeps the copy of zz that the solve works from)
+        LAUNCHK(k_build_tail, dim3(grid_zs), dim3(1024), 0, stream, d, zz, partial.p, npart, jn2p.p, gpart.p, gctr.p + 2, red_scal,
+                zz != zlin.p ? zlin.p : (double *)nullptr);
     }
     void build(const double *zz, double lambda, int scale) {
         build_enqueue(zz, lambda, scale);
         allreduce_system();
         finish_enqueue(zz, lambda, scale);           // also: trace(J'J) of the camera part and red_scal -> mailbox
-        if (zz != zlin.p) HIPCHK(hipMemcpyAsync(zlin.p, zz, P.NZ * 8, hipMemcpyDeviceToDevice, stream));
-        cams_at_lin = true;                          // build_enqueue prepared them at zz
+        cams_at_lin = true;                          // (zlin = zz: k_build_tail)                          // build_enqueue prepared them at zz
         sync();
         // trace(J'J): camera part from jn2c (estimated), point part from red_scal[1]
         f_lin = 0.5 * hpin[32];
@@ -781,8 +791,7 @@ static void loop_gna(Core &c, const dbat_hip_options &o, LoopOut &out) {
         double alpha = 1.0;
         bool found = false;
         while (alpha >= o.alpha_min) {
-            c.axpby(1.0, c.z.p, alpha, c.dz.p, c.zt.p);
-            const double ft = c.eval_f(c.zt.p, nullptr, nullptr);
+            const double ft = c.eval_f_step(c.z.p, alpha, c.dz.p, c.zt.p);
             if (ft < f0 + o.mu * alpha * fp0) { found = true; f = ft; break; }
             alpha /= 2;
         }
@@ -844,8 +853,7 @@ static void loop_lm(Core &c, const dbat_hip_options &o, LoopOut &out) {
             out.damp.push_back(lambda);
             if (o.store_trace) { std::vector<double> x(c.P.n); c.z_to_x(c.z.p, x.data()); if ((int)T.size() <= n) T.resize(n + 1); T[n] = std::move(x); }
             ++n;
-            c.axpby(1.0, c.z.p, 1.0, c.dz.p, c.zt.p);                         // t = x+p
-            const double fNew = c.eval_f(c.zt.p, nullptr, nullptr);
+            const double fNew = c.eval_f_step(c.z.p, 1.0, c.dz.p, c.zt.p);                 // t = x+p
             if (fNew < f) {
                 c.copy(c.z.p, c.zt.p);
                 lambda = lambda / 10;
@@ -927,8 +935,7 @@ static void loop_lmp(Core &c, const dbat_hip_options &o, double delta0, LoopOut 
         out.damp.push_back(delta);
         steps.push_back(step);
         if (step == 0 && term_fun(o, gnJpJp, f)) break;            // :134-140
-        c.axpby(1.0, c.z.p, 1.0, c.dz.p, c.zt.p);
-        const double ft = c.eval_f(c.zt.p, nullptr, nullptr);
+        const double ft = c.eval_f_step(c.z.p, 1.0, c.dz.p, c.zt.p);
         const double predicted = -rJp - 0.5 * JpJp;                // :153
         const double actual = f - ft;
         const double rho = actual / predicted;
@@ -1378,15 +1385,13 @@ int dbat_hip_bench_step(dbat_hip_handle *h, double lambda, int32_t scale_columns
     c.build_enqueue(c.z.p, lambda, scale_columns);
     c.allreduce_system();
     c.finish_enqueue(c.z.p, lambda, scale_columns);
-    HIPCHK(hipMemcpyAsync(c.zlin.p, c.z.p, c.P.NZ * 8, hipMemcpyDeviceToDevice, c.stream));
     HIPCHK(hipEventRecord(c.ev[1], c.stream));
     c.factor_solve_enqueue();
     HIPCHK(hipEventRecord(c.ev[2], c.stream));
     c.backsub_enqueue();
     c.do_allreduce(c.scal.p, 8);
     HIPCHK(hipEventRecord(c.ev[3], c.stream));
-    c.axpby(1.0, c.z.p, 1.0, c.dz.p, c.zt.p);
-    (void)c.eval_f(c.zt.p, nullptr, nullptr);                     // trial-point residual, syncs
+    (void)c.eval_f_step(c.z.p, 1.0, c.dz.p, c.zt.p);              // trial-point residual, syncs
     HIPCHK(hipEventRecord(c.ev[4], c.stream));
     c.sync();
     c.timing = false;

@@ -63,21 +63,22 @@ __device__ __forceinline__ void atomic_add_f64(double *p, double v) {
 }
 
 // ---------------------------------------------------------------- K0 ----
-__global__ void k_cam_prep(DevProblem d, const double *__restrict__ z, CamRec *__restrict__ cams) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= d.nc) return;
+// The record of camera c from the z-vector given by the accessor zv(index) (a plain array, or a
+// trial point x + alpha p that is only being written by the same launch).
+template <class ZV>
+__device__ __forceinline__ void cam_prep_one(const DevProblem &d, ZV zv, int c, CamRec *__restrict__ cams) {
     CamRec r;
     // the six EO values through the column list: a shared element lives in the slot of its leading entry
     const int32_t *ec = d.cam_col + (int64_t)c * MAXCOL;
-    r.c[0] = z[ec[0]]; r.c[1] = z[ec[1]]; r.c[2] = z[ec[2]];
-    const double ang[3] = {z[ec[3]], z[ec[4]], z[ec[5]]};
+    r.c[0] = zv(ec[0]); r.c[1] = zv(ec[1]); r.c[2] = zv(ec[2]);
+    const double ang[3] = {zv(ec[3]), zv(ec[4]), zv(ec[5])};
     cam_rotation(ang, r.Mt, r.dMt);
     double io[MAXIO];
     for (int k = 0; k < MAXIO; ++k) {
         io[k] = 0;
         if (k < d.nIOrows) {
             const int32_t s = d.io_src[(int64_t)c * d.nIOrows + k];
-            io[k] = s >= 0 ? z[6 * (int64_t)d.nc + s] : d.io_fixed[(int64_t)c * d.nIOrows + k];
+            io[k] = s >= 0 ? zv(6 * (int64_t)d.nc + s) : d.io_fixed[(int64_t)c * d.nIOrows + k];
         }
     }
     r.f = io[0]; r.pp[0] = io[1]; r.pp[1] = io[2]; r.b[0] = io[3]; r.b[1] = io[4];
@@ -97,6 +98,10 @@ __global__ void k_cam_prep(DevProblem d, const double *__restrict__ z, CamRec *_
         if (is8) r.eo_est |= 0x100u;
     }
     cams[c] = r;
+}
+__global__ void k_cam_prep(DevProblem d, const double *__restrict__ z, CamRec *__restrict__ cams) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < d.nc) cam_prep_one(d, [z](int64_t i) { return z[i]; }, c, cams);
 }
 
 // block-wide sum of NV values per thread; result valid in thread 0
@@ -250,14 +255,17 @@ __global__ __launch_bounds__(1024) void k_prior_sq(DevProblem d, const double *_
 __global__ __launch_bounds__(1024) void k_build_tail(DevProblem d, const double *__restrict__ z,
                                                      const double *__restrict__ build_partial, int64_t npart,
                                                      const double *__restrict__ jn2p, double *__restrict__ partial,
-                                                     unsigned *__restrict__ ctr, double *__restrict__ out) {
+                                                     unsigned *__restrict__ ctr, double *__restrict__ out,
+                                                     double *__restrict__ zcopy /* null or the copy of z to keep (zlin) */) {
     __shared__ double sh[32];
     double acc[2] = {0.0, 0.0};
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.NZ; i += stride) {
         const double w = d.z_prw[i];
         const bool mine = d.z_mine[i] != 0;
-        if (w > 0 && mine) { const double e = z[i] - d.z_prv[i]; acc[0] += w * e * e; }
+        const double zi = z[i];
+        if (zcopy) zcopy[i] = zi;
+        if (w > 0 && mine) { const double e = zi - d.z_prv[i]; acc[0] += w * e * e; }
         if (i >= d.NS && mine) acc[1] += jn2p[i - d.NS];
     }
     if (grid_sum<2, 1>(acc, sh, partial, ctr, build_partial, npart) && threadIdx.x == 0) { out[0] = acc[0]; out[1] = acc[1]; }
@@ -1950,11 +1958,9 @@ __global__ __launch_bounds__(256) void k_pack_envelope(double *__restrict__ S, i
 // owns the rows [c, col_bend[c]) of the co-visibility band and the dense tail rows
 // [max(tail0, col_bend[c]), NS) -- nothing outside it is ever written by the build kernels or read
 // by the factorisation, and at C4 the dense 30 032^2 array is 7.2 GB.
-__global__ __launch_bounds__(256) void k_envelope_op(double *__restrict__ S, int64_t ldS, int NS, int tail0,
-                                                     const int *__restrict__ col_bend,
-                                                     const double *__restrict__ ds /* null: zero */,
-                                                     double *__restrict__ vec = nullptr /* [3 NS + 8] zeroed with S */,
-                                                     unsigned long long *__restrict__ pivmm = nullptr /* reset */) {
+__device__ __forceinline__ void envelope_body(double *__restrict__ S, int64_t ldS, int NS, int tail0,
+                                              const int *__restrict__ col_bend, const double *__restrict__ ds,
+                                              double *__restrict__ vec, unsigned long long *__restrict__ pivmm) {
     const int c = blockIdx.x;
     if (vec && threadIdx.x < 3) vec[(int64_t)threadIdx.x * NS + c] = 0.0;
     if (c == 0 && vec && threadIdx.x >= 64 && threadIdx.x < 72) vec[(int64_t)3 * NS + (threadIdx.x - 64)] = 0.0;
@@ -1970,6 +1976,22 @@ __global__ __launch_bounds__(256) void k_envelope_op(double *__restrict__ S, int
         const int r = i < nband ? c + i : t0 + (i - nband);
         col[r] = ds ? col[r] * dc * ds[r] : 0.0;
     }
+}
+__global__ __launch_bounds__(256) void k_envelope_op(double *__restrict__ S, int64_t ldS, int NS, int tail0,
+                                                     const int *__restrict__ col_bend,
+                                                     const double *__restrict__ ds /* null: zero */,
+                                                     double *__restrict__ vec = nullptr /* [3 NS + 8] zeroed with S */,
+                                                     unsigned long long *__restrict__ pivmm = nullptr /* reset */) {
+    envelope_body(S, ldS, NS, tail0, col_bend, ds, vec, pivmm);
+}
+// The first launch of a linearisation: envelope of S, the vectors behind it and the pivot extremes
+// cleared, and the camera records at z (block c < nc builds camera c) -- instead of k_cam_prep + this.
+__global__ __launch_bounds__(256) void k_envelope_cams(DevProblem d, const double *__restrict__ z, CamRec *__restrict__ cams,
+                                                       double *__restrict__ S, int64_t ldS, int NS, int tail0,
+                                                       const int *__restrict__ col_bend, double *__restrict__ vec,
+                                                       unsigned long long *__restrict__ pivmm) {
+    if (threadIdx.x == 255 && (int)blockIdx.x < d.nc) cam_prep_one(d, [z](int64_t i) { return z[i]; }, (int)blockIdx.x, cams);
+    envelope_body(S, ldS, NS, tail0, col_bend, nullptr, vec, pivmm);
 }
 
 // min/max of the Cholesky pivots of the reduced system (estimated entries only)
@@ -2319,6 +2341,15 @@ __global__ void k_axpby(int64_t n, double a, const double *__restrict__ x, doubl
                         const double *__restrict__ y2, double *__restrict__ y) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] = a * x[i] + b * y2[i];
+}
+// The same (y must not alias x or y2) and, in the same launch, the camera records at y: block c < nc
+// builds camera c from the entries it computes itself (another block may still be writing them).
+__global__ void k_axpby_cams(DevProblem d, double a, const double *__restrict__ x, double b,
+                             const double *__restrict__ y2, double *__restrict__ y, CamRec *__restrict__ cams) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < d.NZ) y[i] = a * x[i] + b * y2[i];
+    if (threadIdx.x == blockDim.x - 1 && (int)blockIdx.x < d.nc)
+        cam_prep_one(d, [=](int64_t q) { return a * x[q] + b * y2[q]; }, (int)blockIdx.x, cams);
 }
 
 // gradient in z layout: g[0..NS) = g_c, g[NS..) = g_p (0 for fixed / unowned)
