@@ -318,6 +318,9 @@ struct DfView {
     const uint64_t *rowbits;    // [(nT+1)*W]
     int W;
     const int *iperm;           // permuted index -> natural index (nullptr: identity)
+    const double *S;            // != nullptr (compact tiles): the tasks fetch their tile of P S P' from S themselves
+    int64_t ldS;                //   (natural order, lower triangle, right-hand side in row n_nat) instead of a gather launch
+    int n_nat;
     int no_l2;                  // default 1: tiles with agent-scope loads everywhere; DBAT_HIP_DF_L2=1 reads finished tiles through the L2
 };
 
@@ -456,7 +459,19 @@ __global__ __launch_bounds__(256) void k_chol_df(DfView V, int n, int nT, const 
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int c = 16 * ty + (tx >> 4) + 4 * e, r = 16 * rt + (tx & 15);
-                acc[rt][e] = (!helper && r < nr && c < nc) ? -Tik[(int64_t)c * V.ld + r] : 0.0;
+                double v = 0.0;
+                if (!helper && r < nr && c < nc) {
+                    if (V.S) {                          // the tile of P S P' straight from S
+                        const int cn = V.iperm[NB * k + c];
+                        if (i == nT) v = (r == 0 && cn >= 0) ? V.S[(int64_t)cn * V.ldS + V.n_nat] : 0.0;
+                        else {
+                            const int rn = V.iperm[NB * i + r];
+                            if (cn >= 0 && rn >= 0) v = rn >= cn ? V.S[(int64_t)cn * V.ldS + rn] : V.S[(int64_t)rn * V.ldS + cn];
+                            else v = (i == k && r == c) ? 1.0 : 0.0;      // padding rows: identity
+                        }
+                    } else v = Tik[(int64_t)c * V.ld + r];
+                }
+                acc[rt][e] = -v;
             }
         bool alive = true;
         // T -= L(i,j) L(k,j)' over the columns j < k present in both tile rows
@@ -700,6 +715,14 @@ __global__ __launch_bounds__(256) void k_chol_df(DfView V, int n, int nT, const 
         }
         if (trace && t == 0) trace[task * 16 + 4] = wall_clock64();
     }
+}
+
+// What k_chol_df expects to find reset when the tasks fetch their tiles themselves: error code,
+// task counter / abort flag, "not solved yet" in q.
+__global__ void k_df_reset(int *__restrict__ info, int *__restrict__ ctl, unsigned long long *__restrict__ qflag, int nq) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { *info = 0; ctl[0] = 0; ctl[1] = 0; }
+    if (i < nq) qflag[i] = DF_SENTINEL;
 }
 
 // S (natural order, dense column-major lower triangle + right-hand-side row n)
@@ -1093,6 +1116,7 @@ struct DataflowChol {
         ntiles = (int)tile_ij.size();
         if (!up(d_tile_ij, tile_ij) || !up(d_iperm, iperm)) return false;
         if (hipMalloc(&d_tiles, (size_t)ntiles * 4096 * sizeof(double)) != hipSuccess) return false;
+        (void)hipMemset(d_tiles, 0, (size_t)ntiles * 4096 * sizeof(double));     // right-hand-side tiles: only their first row is ever written
         if (hipMalloc(&d_qperm, (size_t)nT * CHOL_NB * sizeof(double)) != hipSuccess) return false;
         if (getenv("DBAT_HIP_PLAN_STATS"))
             fprintf(stderr, "[chol] order %d (%d with block padding, %zu blocks), %d tile rows, %d tiles (%.1f MB), dense lower triangle would be %d tiles\n",
@@ -1117,7 +1141,14 @@ struct DataflowChol {
         DfView V;
         V.toff = d_toff; V.rowbits = d_rowbits; V.W = W; V.no_l2 = getenv("DBAT_HIP_DF_L2") ? 0 : 1;     // measured: no gain from the L2 path
         double *qflag;
-        if (permuted) {      // the gather also resets info, the task counter and the q flags (every tile row has its diagonal tile)
+        V.S = nullptr; V.ldS = lda; V.n_nat = n_nat;
+        if (permuted && !getenv("DBAT_HIP_DF_GATHER")) {
+            // every task fetches its own tile of P S P' from S (the rows of the right-hand-side tiles below
+            // the first stay zero from the set-up): a small reset instead of the gather launch
+            hipLaunchKernelGGL(k_df_reset, dim3((nT * CHOL_NB + 255) / 256), dim3(256), 0, stream, info_dev, d_ctl,
+                               reinterpret_cast<unsigned long long *>(d_qperm), nT * CHOL_NB);
+            V.base = d_tiles; V.ld = 64; V.iperm = d_iperm; qflag = d_qperm; V.S = A;
+        } else if (permuted) {      // the gather also resets info, the task counter and the q flags (every tile row has its diagonal tile)
             hipLaunchKernelGGL(k_gather_tiles, dim3(ntiles), dim3(256), 0, stream, A, lda, n_nat, nT, d_iperm, d_tile_ij, d_tiles,
                                info_dev, d_ctl, reinterpret_cast<unsigned long long *>(d_qperm));
             V.base = d_tiles; V.ld = 64; V.iperm = d_iperm; qflag = d_qperm;

@@ -342,7 +342,15 @@ struct Core {
     }
 
     // ---- helpers
-    void sync() { HIPCHK(hipStreamSynchronize(stream)); }
+    bool lin_pending = false;                        // k_finish's scalars are in the mailbox (or on their way), not read yet
+    void sync() {
+        HIPCHK(hipStreamSynchronize(stream));
+        if (lin_pending) {      // trace(J'J): camera part from jn2c (estimated), point part from red_scal[1]
+            f_lin = 0.5 * hpin[32];
+            trace_jtj = hpin[34] + hpin[33];
+            lin_pending = false;
+        }
+    }
     void mark(int i) { if (timing) HIPCHK(hipEventRecord(kev[i], stream)); }
     // sum of [S | g_red | g_c | diagU | scalars] over the ranks: the envelope of S is packed
     // next to the vectors, one all-reduce, unpacked again
@@ -539,15 +547,15 @@ struct Core {
         LAUNCHK(k_build_tail, dim3(grid_zs), dim3(1024), 0, stream, d, zz, partial.p, npart, jn2p.p, gpart.p, gctr.p + 2, red_scal,
                 zz != zlin.p ? zlin.p : (double *)nullptr);
     }
-    void build(const double *zz, double lambda, int scale) {
+    // lazy: do not wait for the linearisation's scalars (f_lin, trace_jtj): the next sync() of any kind
+    // picks them up.  The damping loops only need them after their first linearisation.
+    void build(const double *zz, double lambda, int scale, bool lazy = false) {
         build_enqueue(zz, lambda, scale);
         allreduce_system();
         finish_enqueue(zz, lambda, scale);           // also: trace(J'J) of the camera part and red_scal -> mailbox
-        cams_at_lin = true;                          // (zlin = zz: k_build_tail)                          // build_enqueue prepared them at zz
-        sync();
-        // trace(J'J): camera part from jn2c (estimated), point part from red_scal[1]
-        f_lin = 0.5 * hpin[32];
-        trace_jtj = hpin[0] + hpin[33];
+        cams_at_lin = true;                          // (zlin = zz: k_build_tail)
+        lin_pending = true;
+        if (!lazy) sync();
         lambda_lin = lambda;
         scale_lin = scale;
         have_lin = true;
@@ -739,6 +747,7 @@ struct Core {
         LAUNCHK(k_jn2, dim3((unsigned)cdiv(P.NZ, 256)), dim3(256), 0, stream, d, jn2c.p, jn2p.p, out);
     }
     void copy(double *dst, const double *src) { HIPCHK(hipMemcpyAsync(dst, src, P.NZ * 8, hipMemcpyDeviceToDevice, stream)); }
+    void accept_trial() { std::swap(z.p, zt.p); }    // z <- the trial point: the buffers change roles (nothing keeps their addresses)
 };
 
 // ============================================================================
@@ -778,7 +787,7 @@ static void loop_gna(Core &c, const dbat_hip_options &o, LoopOut &out) {
     push_trace(c, o, out);
     double f = c.eval_f(c.z.p, nullptr, nullptr);
     while (true) {
-        c.build(c.z.p, 0.0, 1);                                   // :112-116, :166-170
+        c.build(c.z.p, 0.0, 1, true);                             // :112-116, :166-170 (scalars: with the solve's sync)
         out.res.push_back(std::sqrt(2 * f));
         if (n == 0 && !c.P.rank_ok) { out.code = -4; break; }     // :132-142
         double JpJp, rJp, pp;
@@ -796,7 +805,7 @@ static void loop_gna(Core &c, const dbat_hip_options &o, LoopOut &out) {
             alpha /= 2;
         }
         if (!found) alpha = 0.0;
-        else c.copy(c.z.p, c.zt.p);
+        else c.accept_trial();
         out.damp.push_back(alpha);
         push_trace(c, o, out);
         if (alpha == 0.0) { out.code = -3; out.res.push_back(out.res.back()); break; }
@@ -813,7 +822,7 @@ static void loop_gm(Core &c, const dbat_hip_options &o, LoopOut &out) {
     double f = 0;
     while (true) {
         f = c.eval_f(c.z.p, nullptr, nullptr);
-        c.build(c.z.p, 0.0, 0);
+        c.build(c.z.p, 0.0, 0, true);
         out.res.push_back(std::sqrt(2 * f));
         double JpJp, rJp, pp;
         const bool failed = c.solve(JpJp, rJp, pp);               // :79
@@ -845,7 +854,7 @@ static void loop_lm(Core &c, const dbat_hip_options &o, LoopOut &out) {
     std::vector<std::vector<double>> T;
     while (true) {
         while (n <= o.max_iter) {
-            if (c.lambda_lin != lambda) c.build(c.z.p, lambda, 0);            // (JTJ+lambda*I), :119
+            if (c.lambda_lin != lambda) c.build(c.z.p, lambda, 0, true);      // (JTJ+lambda*I), :119
             const bool failed = c.solve(JpJp, rJp, pp);
             out.res.push_back(std::sqrt(2 * f));
             if (n == 0 && !c.P.rank_ok) { out.code = -4; break; }             // :126-135
@@ -855,10 +864,10 @@ static void loop_lm(Core &c, const dbat_hip_options &o, LoopOut &out) {
             ++n;
             const double fNew = c.eval_f_step(c.z.p, 1.0, c.dz.p, c.zt.p);                 // t = x+p
             if (fNew < f) {
-                c.copy(c.z.p, c.zt.p);
+                c.accept_trial();
                 lambda = lambda / 10;
                 if (lambda < lambdaMin) lambda = 0;
-                c.build(c.z.p, lambda, 0);                                    // :189-194
+                c.build(c.z.p, lambda, 0, true);                              // :189-194
                 f = fNew;
                 break;
             } else {
@@ -944,8 +953,8 @@ static void loop_lmp(Core &c, const dbat_hip_options &o, double delta0, LoopOut 
             delta = delta / 2;
             if (delta > npGN) delta = delta / std::exp2(std::ceil(std::log2(delta / npGN)));
         } else {
-            c.copy(c.z.p, c.zt.p);
-            c.build(c.z.p, 0.0, 1);
+            c.accept_trial();
+            c.build(c.z.p, 0.0, 1, true);
             f = ft;
             have_gn = false;
             if (rho >= o.rho_good) delta = delta * 2;

@@ -2053,7 +2053,7 @@ __global__ void k_finish(DevProblem d, const double *__restrict__ z, double lamb
     }
     if (grid_sum<1>(acc, sh, partial, ctr) && threadIdx.x == 0) {
         out[0] = acc[0];
-        if (mailbox) { mailbox[0] = acc[0]; mailbox[32] = red_scal[0]; mailbox[33] = red_scal[1]; }
+        if (mailbox) { mailbox[34] = acc[0]; mailbox[32] = red_scal[0]; mailbox[33] = red_scal[1]; }   // slots no other kernel writes
     }
 }
 
