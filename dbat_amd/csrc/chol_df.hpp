@@ -769,6 +769,7 @@ struct DataflowChol {
     DfJob *d_tasks = nullptr;
     DfTask *d_tile_ij = nullptr;
     int nparts = 0;                                     // partial-sum slots of the helper tasks
+    bool env_l2 = false, env_gather = false;            // DBAT_HIP_DF_L2 / DBAT_HIP_DF_GATHER, read at set-up
     double *d_parts = nullptr;
     double *d_tiles = nullptr, *d_qperm = nullptr;
     long long *d_trace = nullptr;                       // optional per-task timestamps (DBAT_HIP_DF_TRACE=file)
@@ -984,6 +985,7 @@ struct DataflowChol {
         if (hipMalloc(&d_ctl, 2 * sizeof(int)) != hipSuccess) return false;
         (void)hipMemset(d_flags, 0, ((size_t)(nT + 1) * nT + (size_t)nparts + (size_t)nT) * sizeof(int));
         if (const char *g = getenv("DBAT_HIP_DF_GRID")) grid = std::min(std::max(atoi(g), 1), 4096);
+        env_l2 = getenv("DBAT_HIP_DF_L2") != nullptr; env_gather = getenv("DBAT_HIP_DF_GATHER") != nullptr;
         epoch = 0;
         return true;
     }
@@ -1139,10 +1141,10 @@ struct DataflowChol {
         if (d_trace) (void)hipMemsetAsync(d_trace, 0, (size_t)(ntasks + nT) * 16 * sizeof(long long), stream);
         ++epoch;
         DfView V;
-        V.toff = d_toff; V.rowbits = d_rowbits; V.W = W; V.no_l2 = getenv("DBAT_HIP_DF_L2") ? 0 : 1;     // measured: no gain from the L2 path
+        V.toff = d_toff; V.rowbits = d_rowbits; V.W = W; V.no_l2 = env_l2 ? 0 : 1;     // measured: no gain from the L2 path
         double *qflag;
         V.S = nullptr; V.ldS = lda; V.n_nat = n_nat;
-        if (permuted && !getenv("DBAT_HIP_DF_GATHER")) {
+        if (permuted && !env_gather) {
             // every task fetches its own tile of P S P' from S (the rows of the right-hand-side tiles below
             // the first stay zero from the set-up): a small reset instead of the gather launch
             hipLaunchKernelGGL(k_df_reset, dim3((nT * CHOL_NB + 255) / 256), dim3(256), 0, stream, info_dev, d_ctl,

@@ -117,6 +117,9 @@ struct Core {
     // state
     DevBuf<CamRec> cams, cams_f;                     // camera records at the linearisation point / at the last objective evaluation
     bool cams_at_lin = false;                        // cams holds the records of zlin
+    // experiment switches, read once at set-up (never in the per-iteration path)
+    bool env_dense_allreduce = false, env_camn_mfma = false;
+    const char *env_df_trace = nullptr;
     DevBuf<unsigned> gctr;                           // tickets of the in-kernel grid sums (zero between launches)
     DevBuf<double> gpart, rpart;                     // their per-block partial sums; sink of k_residual's (unused) sums
     DevBuf<double> z, zt, dz, zlin, vtmp, vtmp2, xbuf;  // NZ each (xbuf: n)
@@ -202,6 +205,9 @@ struct Core {
         d.o_cam = o_cam.p; d.o_pt = o_pt.p; d.o_uv = o_uv.p; d.o_w = P.uniform_w ? nullptr : o_w.p;
         d.o_seg = o_seg.p; d.o_row = o_row.p; d.batch_start = batch_start.p;
         d.CMAX = P.CMAX; d.ablate = getenv("DBAT_HIP_ABLATE") ? atoi(getenv("DBAT_HIP_ABLATE")) : 0;
+        env_dense_allreduce = getenv("DBAT_HIP_DENSE_ALLREDUCE") != nullptr;
+        env_camn_mfma = getenv("DBAT_HIP_CAMN_MFMA") != nullptr;
+        env_df_trace = getenv("DBAT_HIP_DF_TRACE");
         d.ntiles = (int)ntiles; d.o_lc = o_lc.p; d.o_pidx = o_pidx.p;
         tile_order.upload(P.tile_order); d.tile_order = tile_order.p;
         cm_pt.upload(P.cm_pt); cm_uv.upload(P.cm_uv); cm_w.upload(P.cm_w);
@@ -356,7 +362,7 @@ struct Core {
     // next to the vectors, one all-reduce, unpacked again
     void allreduce_system() {
         if (!multi()) return;
-        if (getenv("DBAT_HIP_DENSE_ALLREDUCE")) { do_allreduce(red.p, red_count); return; }
+        if (env_dense_allreduce) { do_allreduce(red.p, red_count); return; }
         const int64_t nvec = 3 * P.NS + 8;
         if (!pk.p) pk.alloc((size_t)(pk_s_count + nvec));
         LAUNCHK(k_pack_envelope, dim3((unsigned)P.NS), dim3(256), 0, stream, S, ldS, (int)P.NS, env_tail0,
@@ -458,13 +464,13 @@ struct Core {
 
     // ---- K1: linearise at zz with damping lambda; builds the reduced system.
     void build_enqueue(const double *zz, double lambda, int scale) {
-        const bool fused_first = !(s_dense_dirty || getenv("DBAT_HIP_DENSE_ALLREDUCE")) && P.NS >= P.nc;
+        const bool fused_first = !(s_dense_dirty || env_dense_allreduce) && P.NS >= P.nc;
         if (!fused_first) prep_cams(zz);
         else cams_at_lin = false;
         // only the envelope of S is ever written or read: zero that (and the vectors behind S); the whole
         // array once, and again after something filled it densely (the inverse of the posterior covariance)
         bool pivmm_set = false;
-        if (s_dense_dirty || getenv("DBAT_HIP_DENSE_ALLREDUCE")) {
+        if (s_dense_dirty || env_dense_allreduce) {
             HIPCHK(hipMemsetAsync(red.p, 0, red_count * sizeof(double), stream));
             s_dense_dirty = false;
         } else {
@@ -485,7 +491,7 @@ struct Core {
             if (use_tile2 && tile_ncx <= 14 && n_cm_chunks > 0) {
                 // camera side of the tiled observations: J_c'J_c, J_c'r, squared column norms
 #define L_CAMN6(M, dummy) LAUNCHK((k_cam_normal6<M>), dim3((unsigned)n_cm_chunks), dim3(256), 0, stream, d, zz, cams.p, cm_pt.p, cm_uv.p, P.uniform_w ? (const double *)nullptr : cm_w.p, cm_chunk_cam.p, cm_chunk_start.p, S, g_c, g_red, diagU)
-                if (tile_ncx == 6 && !getenv("DBAT_HIP_CAMN_MFMA")) { DISPATCH_MODEL(L_CAMN6, 0) }
+                if (tile_ncx == 6 && !env_camn_mfma) { DISPATCH_MODEL(L_CAMN6, 0) }
                 else if (tile_ncx == 6) { DISPATCH_MODEL(L_CAMN, 6) } else { DISPATCH_MODEL(L_CAMN, 14) }
 #undef L_CAMN6
             }
@@ -584,7 +590,7 @@ struct Core {
                                     hipMemcpyDeviceToDevice, stream));
         }
         HIPCHK(hipGetLastError());                   // launches inside the factorisation helpers
-        if (const char *tp = getenv("DBAT_HIP_DF_TRACE")) (use_perm && !chol_in_place ? dfchol : dfchol_ip).dump_trace(stream, tp);
+        if (env_df_trace) (use_perm && !chol_in_place ? dfchol : dfchol_ip).dump_trace(stream, env_df_trace);
         mark(3);
         // the pivot extremes of the reduced system are taken in k_prior_jv (the tail of the solve)
         if (!unscaled) LAUNCHK(k_unscale, dim3((unsigned)cdiv(P.NS, 256)), dim3(256), 0, stream, P.NS, rhs.p, dscale.p, dz.p);
