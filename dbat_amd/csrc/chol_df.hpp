@@ -7,31 +7,40 @@
 // a task graph inside one launch:
 //
 //   task (i,k), i >= k, one 64 x 64 tile of the envelope, left-looking:
-//       T  = A(i,k) - sum_{j=jlo}^{k-1} L(i,j) L(k,j)'      f64 MFMA, accumulators in registers,
-//                                                           each term as soon as its two tiles exist
+//       T  = A(i,k) - sum_{j<k} L(i,j) L(k,j)'              f64 MFMA, accumulators in registers, each term
+//                                                           as soon as its two tiles exist; the tiles of the
+//                                                           next term are in flight while one multiplies
 //       i == k :  L(k,k) = chol(T), Linv_k = L(k,k)^-1      (df_potf2: 16-column panels in registers,
 //                                                           trailing updates on the matrix cores)
-//       i  > k :  L(i,k) = T Linv_k'                        f64 MFMA
+//                 L(p,k) = T(p,k) Linv_k'                   for the FIRST tile below the diagonal (the next
+//                                                           link of the dependent chain), whose own task
+//                                                           only sums and publishes T (DfJob modes 1, 2)
+//       i  > k :  L(i,k) = T Linv_k'                        f64 MFMA, the other tiles of the column
 //   The sum runs over the columns j whose tiles exist in both tile rows (the
-//   pattern is closed under fill).
+//   pattern is closed under fill).  Sums of more than 128 terms (the dense IO
+//   rows, the right-hand side) are cut into helper tasks that leave partial sums.
 //
 // Two layouts (DfView): IN PLACE -- S where it lies, natural order, pattern =
 // envelope of the camera co-visibility band; PERMUTED -- the cameras in
-// nested-dissection order, P S P' gathered into compact 64 x 64 tiles, pattern
-// from a symbolic tile factorisation.  With the permutation the independent
-// parts of the camera network factor concurrently and only the separators form
-// a dependent chain; in natural (acquisition) order all n/64 panels do.
+// nested-dissection order, the factor in compact 64 x 64 tiles (every task
+// fetches its tile of P S P' from S itself), pattern from a symbolic tile
+// factorisation.  With the permutation the independent parts of the camera
+// network factor concurrently and only the separators form a dependent chain;
+// in natural (acquisition) order all n/64 panels do.
 //
-// Workgroups take tasks from an atomic counter in column-major order, so every
-// dependency of a task has a smaller number and is already owned by a running
-// workgroup: no deadlock for any grid size.  Completion is published per tile
-// by storing the solve's epoch into the tile's flag after the tile's own
-// stores have completed; tiles and flags move with agent-scope (sc1) accesses
-// because the L2 of the eight XCDs are not coherent among themselves.  A spin cap turns any
-// scheduling accident into an error code instead of a hung GPU.
+// Workgroups take tasks from an atomic counter.  The list is in a topological
+// order -- every dependency of a task has a smaller number and is therefore
+// already owned by a running workgroup: no deadlock for any grid size -- chosen
+// among several such orders by a simulation of the kernel as a list schedule
+// (finish_setup).  Completion is published per tile by storing the solve's epoch
+// into the tile's flag after the tile's own stores have completed; tiles and
+// flags move with agent-scope (sc1) accesses because the L2 of the eight XCDs
+// are not coherent among themselves.  A spin cap turns any scheduling accident
+// into an error code instead of a hung GPU.
 //
 // The right-hand side is tile row nT (one valid row, row n of the array): the
-// forward substitution rides along exactly as in chol.hpp.
+// forward substitution rides along exactly as in chol.hpp; the backward
+// substitution follows as one task per panel.
 #pragma once
 #include <cstdio>
 #include <functional>

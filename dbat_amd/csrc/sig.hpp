@@ -552,7 +552,7 @@ __global__ __launch_bounds__(64 * sig_waves(RB, (NCX > 6))) void k_build_sig(Dev
 // observations stay in the lane's registers: no LDS, no atomics, no per-lane camera gathers.
 // One sweep over the k cameras (see the formula below).
 template <int MODEL, int NCX>
-__global__ __launch_bounds__(256) void k_backsub_sig(DevProblem d, const double *__restrict__ z,
+__global__ __launch_bounds__(256, (NCX > 6 ? 3 : 1)) void k_backsub_sig(DevProblem d, const double *__restrict__ z,
                                                      const CamRec *__restrict__ cams,
                                                      const double *__restrict__ Vinv, const double *__restrict__ gp,
                                                      double *__restrict__ dz, double *__restrict__ partial /* [grid][2] */,
