@@ -1,5 +1,6 @@
 // k_build_sig: Schur complement of the tiled object points by SIGNATURE GROUPS
-// (K1, K3 point side, K4, K5 of SURVEY 8(a); fixed interior orientation).
+// (K1, K3 point side, K4, K5 of SURVEY 8(a); fixed interior orientation and, NCX = 14,
+// self-calibration: the tile's IO columns are further rows of every chunk).
 //
 // Object points that are seen by exactly the same k cameras update the same
 // 6k x 6k block of the reduced camera system.  The plan (plan.hpp) orders the
@@ -14,23 +15,29 @@
 // of 4.  Row 6k of the operand holds y_p = R_p' g_p, so the same product also
 // yields -(W V^-1 g_p) for the reduced right-hand side.
 //
-// One workgroup (four waves, one per SIMD) per tile:
+// One workgroup per tile -- eight waves (two per SIMD: one evaluates while the other multiplies) for
+// fixed IO with at most ten cameras per point, four waves with 512 registers for 11 ... 13 cameras
+// and for self-calibration:
 //   * the tile's camera records are staged in LDS once;
 //   * the tile's block of S (at most 21 cameras, lower triangle packed, 64 KB)
 //     lives in LDS; a finished chunk is added to it with ds_add_f64 and the tile
 //     goes to HBM once, with global f64 atomics, as in the other tile kernels;
-//   * a wave takes chunks from the tile's list through an LDS counter.
+//   * a wave takes chunks from the tile's list through an LDS counter (longest first; the next
+//     chunk's descriptor is fetched while the current one is worked on).
 // A chunk in two passes:
-//   pass 1, lane = object point: loop over the k cameras (uniform per chunk:
-//     broadcast reads of the staged record, coalesced (u,v) from the slot-major
-//     copy), residual r and point block B per observation; V = sum B'B (+ prior,
-//     + lambda), g = sum B'r in registers -- no atomics, no cross-lane traffic;
-//     V^-1, its Cholesky factor R, the pivots; V^-1, g and the squared column
-//     norms go to HBM for the back-substitution, R | R'g | Q to LDS;
+//   pass 1, lane = object point (two lanes per point when the chunk has at most 32): loop over the
+//     k cameras (uniform per chunk: broadcast reads of the staged record, coalesced (u,v) from the
+//     slot-major copy), residual r and point block B per observation; V = sum B'B (+ prior,
+//     + lambda), g = sum B'r in registers -- no atomics, no cross-lane traffic; V^-1, its
+//     Cholesky factor R, the pivots; V^-1, g and the squared column norms go to HBM for the
+//     back-substitution, R | R'g | Q stay in the lane's registers (pass 2 fetches them by
+//     ds_bpermute).  Self-calibration, tiles with one IO block: the point's IO rows
+//     Z_io = (sum_j E_io,j' B_j) R are summed here too;
 //   pass 2, lane = observation, rounds of floor(64/k) <= 6 points: camera-side
-//     block E, W = E'B, Z = W R into the wave's operand panel [rows][18 (+2)
-//     k-columns], then ceil(3 n/4) k-steps of the block products.
-// LDS reads of the operands are conflict free (row stride 22 doubles).
+//     block E, W = E'B, Z = W R into the wave's operand panel [rows][18 k-columns],
+//     then ceil(3 n/4) k-steps of the block products (operands of the next k-step are read
+//     while one multiplies).
+// LDS reads of the operands are conflict free (row stride 18 doubles = 2 mod 4).
 #pragma once
 #include "kernels.hpp"
 

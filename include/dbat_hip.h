@@ -285,9 +285,10 @@ int  dbat_hip_forwintersect(dbat_hip_handle *h, const double *x, const uint8_t *
  * residual-only evaluation at the trial point.  x is not advanced, so every
  * step does identical work.  ms[8], from HIP events on the handle's stream:
  * phases { linearize+Schur build, factor+solve, back-substitution, trial
- * residual } then single kernels { the tile kernel k_build_tile2 / k_build_tile
- * alone (k_build when nothing is tiled), k_chol_df incl. the tile gather,
- * k_backsub, k_residual_cm }. */
+ * residual } then single kernels { the Schur kernel alone (k_build_sig, or the
+ * tile kernel k_build_tile3 / k_build_tile2 where the signature groups are too
+ * short, or k_build when nothing is tiled; dbat_hip_build_kernel_name says which),
+ * k_chol_df incl. its flag reset, the back-substitution kernels, k_residual_cm }. */
 int  dbat_hip_bench_step(dbat_hip_handle *h, double lambda, int32_t scale_columns, double *ms);
 /* load x into the handle (device resident) before bench steps */
 int  dbat_hip_set_x(dbat_hip_handle *h, const double *x);
