@@ -265,4 +265,49 @@ DBAT_HD void obs_eval(const CamRec &cam, int nK, int nP, const double Q[3], doub
     }
 }
 
+// Back-substitution, the usual self-calibration (camera-side columns = 6 EO + cc px py K1 K2 K3 P1 P2,
+// CamRec::eo_est bit 8; nK = 3, nP = 2): t = E dc for one observation and its weighted point block B,
+// straight from the pieces of the model -- no 2 x 14 block E and no 2 x 15 block of IO derivatives in
+// registers (k_backsub_sig<., 14> used 233 of them and ran two waves per SIMD).
+// dc[0..5]: step of the camera's EO columns (0 for fixed ones), dc[6..13]: of its eight IO columns.
+template <int MODEL>
+DBAT_HD void obs_step_dot8(const CamRec &cam, const double Q[3], double u, double v, double w0, double w1,
+                           unsigned est, const double *dc, double &t0, double &t1, double B[2][3]) {
+    const double d0 = Q[0] - cam.c[0], d1 = Q[1] - cam.c[1], d2 = Q[2] - cam.c[2];
+    const double X0 = cam.Mt[0] * d0 + cam.Mt[1] * d1 + cam.Mt[2] * d2;
+    const double X1 = cam.Mt[3] * d0 + cam.Mt[4] * d1 + cam.Mt[5] * d2;
+    const double X2 = cam.Mt[6] * d0 + cam.Mt[7] * d1 + cam.Mt[8] * d2;
+    const double iz = 1.0 / X2;
+    const double ph0 = X0 * iz, ph1 = X1 * iz;
+    const double s = -cam.f * iz;
+    double a0 = 0, a1 = 0;                       // A dc (EO part), unweighted
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double m0 = cam.Mt[k], m1 = cam.Mt[3 + k], m2 = cam.Mt[6 + k];
+        const double b0 = s * (m0 - ph0 * m2), b1 = s * (m1 - ph1 * m2);
+        const double m = ((est >> k) & 1u) ? 1.0 : 0.0;
+        B[0][k] = b0 * w0 * m; B[1][k] = b1 * w1 * m;
+        const double mk = ((cam.eo_est >> k) & 1u) ? dc[k] : 0.0;
+        a0 -= b0 * mk; a1 -= b1 * mk;             // A(:,k) = -B(:,k)  (world2cam.m:82)
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {                 // eulerpinhole2.m:100
+        const double *D = cam.dMt[k];
+        const double y0 = D[0] * d0 + D[1] * d1 + D[2] * d2;
+        const double y1 = D[3] * d0 + D[4] * d1 + D[5] * d2;
+        const double y2 = D[6] * d0 + D[7] * d1 + D[8] * d2;
+        const double mk = ((cam.eo_est >> (3 + k)) & 1u) ? dc[3 + k] : 0.0;
+        a0 += s * (y0 - ph0 * y2) * mk;
+        a1 += s * (y1 - ph1 * y2) * mk;
+    }
+    ImgSide im;
+    image_side<MODEL, true>(cam, 3, 2, u, v, im);
+    // IO rows cc | px py | K1 K2 K3 | P1 P2  (obs_eval: C(:,0) = -ph, C(:,1:2) = dU0, C(:,5:7) = dK, C(:,8:9) = dP)
+    a0 += -ph0 * dc[6] + im.dU0[0][0] * dc[7] + im.dU0[0][1] * dc[8] + im.dK[0][0] * dc[9] + im.dK[0][1] * dc[10] + im.dK[0][2] * dc[11]
+        + im.dP[0][0] * dc[12] + im.dP[0][1] * dc[13];
+    a1 += -ph1 * dc[6] + im.dU0[1][0] * dc[7] + im.dU0[1][1] * dc[8] + im.dK[1][0] * dc[9] + im.dK[1][1] * dc[10] + im.dK[1][2] * dc[11]
+        + im.dP[1][0] * dc[12] + im.dP[1][1] * dc[13];
+    t0 = a0 * w0; t1 = a1 * w1;
+}
+
 }  // namespace dbat

@@ -111,6 +111,7 @@ struct Plan {
     std::vector<double> cam_w;                     // [2*nc] per-camera 1/sigma_mm when uniform
     std::vector<int32_t> cam_ncol, cam_col, cam_iorow;   // per camera column lists (MAXCOL / MAXIO strides)
     std::vector<uint32_t> cam_eo_est;
+    bool all_std8 = false;                         // self-calibration: every camera estimates exactly cc px py K1 K2 K3 P1 P2 (nK = 3, nP = 2)
     std::vector<double> px;                        // [2*nc]
     std::vector<int32_t> cam_first;                // lowest camera index sharing an object point with each camera
     std::vector<uint64_t> cam_adj;                 // [nc][cam_adj_words] co-visibility graph (bit c2 of row c1), symmetric
@@ -270,6 +271,14 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         }
         P.cam_ncol[c] = ncol;
         P.ncolmax = std::max(P.ncolmax, ncol);
+    }
+    {   // the usual self-calibration in every camera?  (same test as k_cam_prep's bit 8 of eo_est)
+        static const int std8[8] = {0, 1, 2, 5, 6, 7, 8, 9};
+        P.all_std8 = P.nIOu > 0 && P.nK == 3 && P.nP == 2;
+        for (int c = 0; c < nc && P.all_std8; ++c) {
+            if (P.cam_ncol[c] != 14) { P.all_std8 = false; break; }
+            for (int k = 0; k < 8; ++k) if (P.cam_iorow[(size_t)c * MAXIO + k] != std8[k]) P.all_std8 = false;
+        }
     }
 
     // ---- observations: validate order, weights
@@ -889,10 +898,12 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     // the build kernel pays from about four points per group on, the back-substitution (one lane per
     // point, one wave per chunk) from about eight (C1 / C2: 6 ... 7 points per group)
     P.sg_ok = sg_can && P.sg_npoints >= 4 * P.sg_ngroups;
-    P.sg_backsub_ok = sg_can && P.sg_npoints >= 8 * P.sg_ngroups;
+    // (self-calibration: k_backsub_sig knows the usual eight IO columns only)
+    const bool bs_can = sg_can && (P.ncolmax <= 6 || P.all_std8);
+    P.sg_backsub_ok = bs_can && P.sg_npoints >= 8 * P.sg_ngroups;
     if (const char *e = getenv("DBAT_HIP_SIG")) {     // 0 off, 2 whenever possible
         P.sg_ok = atoi(e) == 0 ? false : (atoi(e) >= 2 ? sg_can : P.sg_ok);
-        P.sg_backsub_ok = atoi(e) == 0 ? false : (atoi(e) >= 2 ? sg_can : P.sg_backsub_ok);
+        P.sg_backsub_ok = atoi(e) == 0 ? false : (atoi(e) >= 2 ? bs_can : P.sg_backsub_ok);
     }
     if (getenv("DBAT_HIP_PLAN_STATS") && P.sg_ngroups > 0)
         fprintf(stderr, "[plan] %lld signature groups, %.1f points/group, %zu chunks, k max %d, sig kernel %s\n",

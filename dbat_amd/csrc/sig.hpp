@@ -559,7 +559,7 @@ __global__ __launch_bounds__(64 * sig_waves(RB, (NCX > 6))) void k_build_sig(Dev
 // observations stay in the lane's registers: no LDS, no atomics, no per-lane camera gathers.
 // One sweep over the k cameras (see the formula below).
 template <int MODEL, int NCX>
-__global__ __launch_bounds__(256, (NCX > 6 ? 3 : 1)) void k_backsub_sig(DevProblem d, const double *__restrict__ z,
+__global__ __launch_bounds__(256) void k_backsub_sig(DevProblem d, const double *__restrict__ z,
                                                      const CamRec *__restrict__ cams,
                                                      const double *__restrict__ Vinv, const double *__restrict__ gp,
                                                      double *__restrict__ dz, double *__restrict__ partial /* [grid][2] */,
@@ -606,11 +606,17 @@ __global__ __launch_bounds__(256, (NCX > 6 ? 3 : 1)) void k_backsub_sig(DevProbl
             const CamRec &C = *reinterpret_cast<const CamRec *>(crec[wv][j]);
             const double2 uv = uvp[q0 + (int64_t)j * gm];
             const double w0 = sg_w ? wp[q0 + (int64_t)j * gm].x : C.w[0], w1 = sg_w ? wp[q0 + (int64_t)j * gm].y : C.w[1];
-            double r[2], E[2][NCX], B[2][3];
-            eval_obs_pre<MODEL, NCX>(d, C, Q, uv.x, uv.y, w0, w1, est, r, E, B);
-            double t0 = 0, t1 = 0;
+            double B[2][3], t0 = 0, t1 = 0;
+            if constexpr (NCX > 6) {
+                // self-calibration: the plan routes a problem here only if every camera has the usual eight IO
+                // columns (Plan::all_std8); anything else takes k_backsub
+                obs_step_dot8<MODEL>(C, Q, uv.x, uv.y, w0, w1, est, dcs[wv][j], t0, t1, B);
+            } else {
+                double r[2], E[2][NCX];
+                eval_obs_pre<MODEL, NCX>(d, C, Q, uv.x, uv.y, w0, w1, est, r, E, B);
 #pragma unroll
-            for (int a = 0; a < NCX; ++a) { const double dc = dcs[wv][j][a]; t0 += E[0][a] * dc; t1 += E[1][a] * dc; }
+                for (int a = 0; a < NCX; ++a) { const double dc = dcs[wv][j][a]; t0 += E[0][a] * dc; t1 += E[1][a] * dc; }
+            }
             tt2 += t0 * t0 + t1 * t1;
             sB[0] += B[0][0] * t0 + B[1][0] * t1;
             sB[1] += B[0][1] * t0 + B[1][1] * t1;
