@@ -270,8 +270,9 @@ DBAT_HD void obs_eval(const CamRec &cam, int nK, int nP, const double Q[3], doub
 // straight from the pieces of the model -- no 2 x 14 block E and no 2 x 15 block of IO derivatives in
 // registers (k_backsub_sig<., 14> used 233 of them and ran two waves per SIMD).
 // dc[0..5]: step of the camera's EO columns (0 for fixed ones), dc[6..13]: of its eight IO columns.
-template <int MODEL>
-DBAT_HD void obs_step_dot8(const CamRec &cam, const double Q[3], double u, double v, double w0, double w1,
+// IO8 = false: fixed interior orientation, the EO part alone.
+template <int MODEL, bool IO8>
+DBAT_HD void obs_step_dot(const CamRec &cam, const double Q[3], double u, double v, double w0, double w1,
                            unsigned est, const double *dc, double &t0, double &t1, double B[2][3]) {
     const double d0 = Q[0] - cam.c[0], d1 = Q[1] - cam.c[1], d2 = Q[2] - cam.c[2];
     const double X0 = cam.Mt[0] * d0 + cam.Mt[1] * d1 + cam.Mt[2] * d2;
@@ -300,6 +301,7 @@ DBAT_HD void obs_step_dot8(const CamRec &cam, const double Q[3], double u, doubl
         a0 += s * (y0 - ph0 * y2) * mk;
         a1 += s * (y1 - ph1 * y2) * mk;
     }
+    if (!IO8) { t0 = a0 * w0; t1 = a1 * w1; return; }      // fixed IO: dc[0..5] only
     ImgSide im;
     image_side<MODEL, true>(cam, 3, 2, u, v, im);
     // IO rows cc | px py | K1 K2 K3 | P1 P2  (obs_eval: C(:,0) = -ph, C(:,1:2) = dU0, C(:,5:7) = dK, C(:,8:9) = dP)

@@ -608,10 +608,11 @@ __global__ __launch_bounds__(256) void k_backsub_sig(DevProblem d, const double 
             const double w0 = sg_w ? wp[q0 + (int64_t)j * gm].x : C.w[0], w1 = sg_w ? wp[q0 + (int64_t)j * gm].y : C.w[1];
             double B[2][3], t0 = 0, t1 = 0;
             if constexpr (NCX > 6) {
-                // self-calibration: the plan routes a problem here only if every camera has the usual eight IO
-                // columns (Plan::all_std8); anything else takes k_backsub
-                obs_step_dot8<MODEL>(C, Q, uv.x, uv.y, w0, w1, est, dcs[wv][j], t0, t1, B);
-            } else {
+                // self-calibration: t = E dc straight from the pieces of the model (no 2 x 14 block E, no IO
+                // derivative block in registers).  The plan routes a problem here only if every camera has
+                // the usual eight IO columns (Plan::all_std8); anything else takes k_backsub
+                obs_step_dot<MODEL, true>(C, Q, uv.x, uv.y, w0, w1, est, dcs[wv][j], t0, t1, B);
+            } else {                                 // (fixed IO: the same trick costs registers here, 156 against 108)
                 double r[2], E[2][NCX];
                 eval_obs_pre<MODEL, NCX>(d, C, Q, uv.x, uv.y, w0, w1, est, r, E, B);
 #pragma unroll
