@@ -17,7 +17,7 @@
 //                                                           only sums and publishes T (DfJob modes 1, 2)
 //       i  > k :  L(i,k) = T Linv_k'                        f64 MFMA, the other tiles of the column
 //   The sum runs over the columns j whose tiles exist in both tile rows (the
-//   pattern is closed under fill).  Sums of more than 128 terms (the dense IO
+//   pattern is closed under fill).  Sums of more than 96 terms (the dense IO
 //   rows, the right-hand side) are cut into helper tasks that leave partial sums.
 //
 // Two layouts (DfView): IN PLACE -- S where it lies, natural order, pattern =
@@ -823,7 +823,7 @@ struct DataflowChol {
     bool finish_setup(const std::vector<uint64_t> &rowbits, const std::vector<int64_t> &toff) {
         auto has = [&](int i, int k) { return (rowbits[(size_t)i * W + (k >> 6)] >> (k & 63)) & 1ull; };
         // ---- jobs, column-major (dependencies come earlier); long sums are cut into helpers
-        const int split_min = getenv("DBAT_HIP_DF_SPLIT") ? std::max(atoi(getenv("DBAT_HIP_DF_SPLIT")), 2) : 128;
+        const int split_min = getenv("DBAT_HIP_DF_SPLIT") ? std::max(atoi(getenv("DBAT_HIP_DF_SPLIT")), 2) : 96;
         const int chunk = getenv("DBAT_HIP_DF_CHUNK") ? std::max(atoi(getenv("DBAT_HIP_DF_CHUNK")), 1) : 32;
         std::vector<DfJob> jobs;
         std::vector<int> own((size_t)(nT + 1) * nT, -1);        // tile -> its owning job
