@@ -16,6 +16,47 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+// a += (m of lane K of the same 16-lane row) * b: DPP row_newbcast on the f64 operation itself
+template <int K, bool FIRST = false>
+__device__ __forceinline__ void fmac_bcast(double &a, double m, double b) {
+    if constexpr (FIRST)     // m, b were just written by VALU instructions the assembler cannot see from here
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(m), "v"(b), "n"(K));
+    else
+        asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(m), "v"(b), "n"(K));
+}
+template <int K, bool FIRST = true>
+struct UpdFrom {
+    static __device__ __forceinline__ void run(double (&a)[16], double m, double nly) {
+        if constexpr (K < 16) { fmac_bcast<K, FIRST>(a[K], m, nly); UpdFrom<K + 1, false>::run(a, m, nly); }
+    }
+};
+__device__ __forceinline__ double swap16_f64(double v) {       // value of lane ^ 16
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_ds_swizzle((int)(b & 0xffffffffll), 0x401F);
+    const int hi = __builtin_amdgcn_ds_swizzle((int)(b >> 32), 0x401F);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <int J>
+struct ElimCol {
+    static __device__ __forceinline__ void run(double (&a)[16], double &piv, int lane) {
+        const double araw = a[J];
+        const double sw = swap16_f64(araw);
+        const double m = (lane & 16) ? sw : araw;    // every 16-lane row holds the diagonal rows' column
+        const double c1 = J < 15 ? readlane_f64(araw, J + 1 < 16 ? J + 1 : 0) : 0.0;
+        const double rn = J < 15 ? readlane_f64(a[J + 1 < 16 ? J + 1 : 0], J + 1 < 16 ? J + 1 : 0) : 0.0;
+        const double y0 = __builtin_amdgcn_rsq(piv);
+        const double e = __builtin_fma(-piv, y0 * y0, 1.0);
+        const double y = __builtin_fma(y0, __builtin_fma(e, 0.375, 0.5) * e, y0);
+        const double y2 = y * y;
+        piv = __builtin_fma(-c1, c1 * y2, rn);
+        const double ly = araw * y2;
+        a[J] = araw * y;
+        if constexpr (J < 15) a[J + 1] = __builtin_fma(-c1, ly, a[J + 1]);
+        UpdFrom<J + 2>::run(a, m, -ly);
+        if constexpr (J < 15) ElimCol<J + 1>::run(a, piv, lane);
+    }
+};
+
 template <int V>
 __device__ __forceinline__ void eliminate(double (&a)[16], double *col /* LDS, [2][16] of this wave */, int lane) {
     if constexpr (V == 0) {
@@ -36,6 +77,9 @@ __device__ __forceinline__ void eliminate(double (&a)[16], double *col /* LDS, [
 #pragma unroll
             for (int k = j + 2; k < 16; ++k) a[k] = __builtin_fma(-readlane_f64(araw, k), ly, a[k]);
         }
+    } else if constexpr (V == 2) {
+        double piv = readlane_f64(a[0], 0);
+        ElimCol<0>::run(a, piv, lane);
     } else {
         // column j of the diagonal rows -> LDS; every lane reads the multipliers back (same address: broadcast)
         double piv = readlane_f64(a[0], 0);
@@ -189,14 +233,15 @@ int main() {
             if (r < 16 && r < c) v = 0.0;
             A[c * 32 + r] = v;
         }
-    double *dA, *dres[2], *sink; unsigned long long *out;
+    double *dA, *dres[3], *sink; unsigned long long *out;
     hipMalloc(&dA, A.size() * 8); hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
-    hipMalloc(&dres[0], A.size() * 8); hipMalloc(&dres[1], A.size() * 8); hipMalloc(&sink, 256 * 8); hipMalloc(&out, 64);
+    hipMalloc(&dres[0], A.size() * 8); hipMalloc(&dres[1], A.size() * 8); hipMalloc(&dres[2], A.size() * 8); hipMalloc(&sink, 256 * 8); hipMalloc(&out, 64);
     const int iters = 2000;
-    std::vector<double> r0(A.size()), r1(A.size());
-    for (int v = 0; v < 2; ++v) {
+    std::vector<double> r0(A.size()), r1(A.size()), r2(A.size());
+    for (int v = 0; v < 3; ++v) {
         for (int rep = 0; rep < 2; ++rep) {
             if (v == 0) hipLaunchKernelGGL(k_elim<0>, dim3(1), dim3(256), 0, 0, dA, iters, out, dres[0]);
+            else if (v == 2) hipLaunchKernelGGL(k_elim<2>, dim3(1), dim3(256), 0, 0, dA, iters, out, dres[2]);
             else hipLaunchKernelGGL(k_elim<1>, dim3(1), dim3(256), 0, 0, dA, iters, out, dres[1]);
             hipDeviceSynchronize();
         }
@@ -206,6 +251,8 @@ int main() {
     }
     hipMemcpy(r0.data(), dres[0], A.size() * 8, hipMemcpyDeviceToHost);
     hipMemcpy(r1.data(), dres[1], A.size() * 8, hipMemcpyDeviceToHost);
+    hipMemcpy(r2.data(), dres[2], A.size() * 8, hipMemcpyDeviceToHost);
+    { double md2 = 0; for (size_t i = 0; i < A.size(); ++i) md2 = fmax(md2, fabs(r0[i] - r2[i])); printf("max |V0 - V2 (DPP row_newbcast)| = %.3g\n", md2); }
     double md = 0, chk = 0;
     for (size_t i = 0; i < A.size(); ++i) { md = fmax(md, fabs(r0[i] - r1[i])); chk += r0[i]; }
     // host check of L: L L' == A on the diagonal block

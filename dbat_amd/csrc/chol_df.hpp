@@ -177,6 +177,55 @@ __device__ __forceinline__ bool df_spin(const int *flag, int epoch, int *abort_f
 // non-positive pivot.
 constexpr int DF_TLD = 130;     // 64 * 130 doubles = the two 64 x 65 operand tiles
 
+// a += (m of lane K of the same 16-lane row) * b: DPP row_newbcast on the f64 operation itself -- one
+// instruction per update where a v_readlane broadcast needs three (bench/potf_micro.hip: 2593 instead of
+// 3092 ticks per 16-column panel, same bits).  FIRST: m and b were just written by instructions the
+// assembler cannot see from inside the asm statement (DPP read-after-write wait states).
+template <int K, bool FIRST>
+__device__ __forceinline__ void df_fmac_bcast(double &a, double m, double b) {
+    if constexpr (FIRST)
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(m), "v"(b), "n"(K));
+    else
+        asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(m), "v"(b), "n"(K));
+}
+template <int K, bool FIRST = true>
+struct DfUpdFrom {
+    static __device__ __forceinline__ void run(double (&a)[16], double m, double nly) {
+        if constexpr (K < 16) { df_fmac_bcast<K, FIRST>(a[K], m, nly); DfUpdFrom<K + 1, false>::run(a, m, nly); }
+    }
+};
+__device__ __forceinline__ double df_swap16(double v) {          // the value of lane ^ 16 (ds_swizzle, no LDS memory)
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_ds_swizzle((int)(b & 0xffffffffll), 0x401F);
+    const int hi = __builtin_amdgcn_ds_swizzle((int)(b >> 32), 0x401F);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// Column J of the 16-column panel elimination (see df_potf2), and the columns after it.
+template <int J>
+struct DfElimCol {
+    static __device__ __forceinline__ void run(double (&a)[16], double &piv, unsigned &badmask, int lane) {
+        badmask |= !(piv > 0.0) ? 1u << J : 0u;
+        const double araw = a[J];
+        // the diagonal rows' column in BOTH 16-lane rows of the wave's 32 live lanes: the multipliers of the
+        // other rows (lanes 16-31) are the diagonal rows' (lanes 0-15) entries
+        const double sw = df_swap16(araw);
+        const double m = (lane & 16) ? sw : araw;
+        constexpr int J1 = J + 1 < 16 ? J + 1 : 0;
+        const double c1 = J < 15 ? readlane_f64(araw, J1) : 0.0;
+        const double rn = J < 15 ? readlane_f64(a[J1], J1) : 0.0;
+        const double y0 = __builtin_amdgcn_rsq(piv);
+        const double e = __builtin_fma(-piv, y0 * y0, 1.0);
+        const double y = __builtin_fma(y0, __builtin_fma(e, 0.375, 0.5) * e, y0);
+        const double y2 = y * y;
+        piv = __builtin_fma(-c1, c1 * y2, rn);
+        const double ly = araw * y2;
+        a[J] = araw * y;
+        if constexpr (J < 15) a[J + 1] = __builtin_fma(-c1, ly, a[J + 1]);
+        DfUpdFrom<J + 2>::run(a, m, -ly);
+        if constexpr (J < 15) DfElimCol<J + 1>::run(a, piv, badmask, lane);
+    }
+};
+
 // Trailing update of df_potf2 after panel p.  Tiles, numbered cb-major: for cb in p+1..3: T row
 // blocks rb = cb..3 (rowbase 16rb), then the identity blocks ib = 0..p (rowbase 64+16ib; ib == p is
 // touched for the first time: starts from zero).  9 / 7 / 4 tiles for p = 0 / 1 / 2; wave w takes
@@ -254,29 +303,13 @@ __device__ __forceinline__ void df_potf2(double *Tm, int nb, int j0, int *info, 
             unsigned badmask = 0;                           // bit j: pivot j of the panel is not positive
             // The wave is alone on its SIMD, so the dependent chain pivot -> 1/sqrt -> next pivot is
             // what a column costs.  It runs on wave-uniform values only: the multipliers c_k = a_j(lane k)
-            // are read BEFORE the column is scaled (their v_readlanes do not wait for 1/sqrt), every
-            // update is a_k -= c_k (a_j / d), and the next pivot d' = a_{j+1}(lane j+1) - c (c / d) is
+            // are taken BEFORE the column is scaled (they do not wait for 1/sqrt; DPP row broadcasts inside the
+            // f64 operation, see df_fmac_bcast), every update is a_k -= c_k (a_j / d), and the next pivot d' = a_{j+1}(lane j+1) - c (c / d) is
             // formed from scalars with the same two operations the lane itself performs (same bits).
             // 1/sqrt: v_rsq_f64 and one third-order step y0 (1 + e/2 + 3e^2/8), e = 1 - d y0^2.
             // (Padding columns of a ragged block are identity columns: their pivots are 1.)
             double piv = readlane_f64(a[0], 0);
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                badmask |= !(piv > 0.0) ? 1u << j : 0u;
-                const double araw = a[j];
-                const double c1 = j < 15 ? readlane_f64(araw, j + 1) : 0.0;
-                const double rn = j < 15 ? readlane_f64(a[j + 1], j + 1) : 0.0;
-                const double y0 = __builtin_amdgcn_rsq(piv);
-                const double e = __builtin_fma(-piv, y0 * y0, 1.0);
-                const double y = __builtin_fma(y0, __builtin_fma(e, 0.375, 0.5) * e, y0);
-                const double y2 = y * y;
-                piv = __builtin_fma(-c1, c1 * y2, rn);
-                const double ly = araw * y2;
-                a[j] = araw * y;
-                if (j < 15) a[j + 1] = __builtin_fma(-c1, ly, a[j + 1]);
-#pragma unroll
-                for (int k = j + 2; k < 16; ++k) a[k] = __builtin_fma(-readlane_f64(araw, k), ly, a[k]);
-            }
+            DfElimCol<0>::run(a, piv, badmask, lane);
             if (tr && t == 0 && p == 1) tr[13] = wall_clock64();
             if (lane >= 16 ? act : w == 0) {
 #pragma unroll
