@@ -349,8 +349,20 @@ struct Core {
 
     // ---- helpers
     bool lin_pending = false;                        // k_finish's scalars are in the mailbox (or on their way), not read yet
+    unsigned long long mb_seq = 0;                   // ticket of the last kernel that reports through mailbox slot 63
+    bool mb_armed = false;                           // ... and such a kernel is the last one enqueued
     void sync() {
-        HIPCHK(hipStreamSynchronize(stream));
+        // The kernel that ends a phase writes this wait's ticket into the mailbox after its results: spin on
+        // it (a few microseconds after the kernel's last store) instead of sleeping in
+        // hipStreamSynchronize; after ~2 ms without the ticket fall back to the driver's wait.
+        bool done = false;
+        if (mb_armed) {
+            volatile unsigned long long *slot = reinterpret_cast<volatile unsigned long long *>(hpin) + 63;
+            for (int spin = 0; spin < 4000000 && !done; ++spin) { done = *slot == mb_seq; if (!done) __builtin_ia32_pause(); }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            mb_armed = false;
+        }
+        if (!done) HIPCHK(hipStreamSynchronize(stream));
         if (lin_pending) {      // trace(J'J): camera part from jn2c (estimated), point part from red_scal[1]
             f_lin = 0.5 * hpin[32];
             trace_jtj = hpin[34] + hpin[33];
@@ -454,10 +466,10 @@ struct Core {
 #undef L_RES
         }
         LAUNCHK(k_prior_sq, dim3(grid_zs), dim3(1024), 0, stream, d, zz, gpart.p, gctr.p + 1, (const double *)partial.p, n_cm_chunks_all,
-                scal.p, multi() ? (double *)nullptr : hpin);
+                scal.p, multi() ? (double *)nullptr : hpin, ++mb_seq);
         double s;
         if (multi()) { do_allreduce(scal.p, 1); read_scal(&s, 1); }
-        else { sync(); s = hpin[0]; }
+        else { mb_armed = true; sync(); s = hpin[0]; }
         ++n_res_evals;
         return 0.5 * s;
     }
@@ -626,7 +638,7 @@ struct Core {
         // extremes of the reduced system; on one rank straight into the pinned mailbox
         LAUNCHK(k_prior_jv, dim3(grid_zs), dim3(1024), 0, stream, d, zlin.p, dz.p, g_c, gp.p, gpart.p, gctr.p + 4,
                 (const double *)(partial.p + 2 * b_first), nb - b_first + ngiant + n_sig_wg, (const double *)ldiag.p, pivmm.p,
-                (const int *)info.p, scal.p, multi() ? (double *)nullptr : hpin);
+                (const int *)info.p, scal.p, multi() ? (double *)nullptr : hpin, ++mb_seq);
     }
     // solve at the current linearisation: p in dz.  Returns true if the
     // factorisation failed outright (non-positive pivot / non-finite step);
@@ -654,6 +666,7 @@ struct Core {
             do_allreduce(scal.p, 8 + nsl);
             read_scal(h.data(), 8 + nsl);
         } else {             // k_prior_jv left everything in the mailbox
+            mb_armed = true;
             sync();
             memcpy(h.data(), hpin, 8 * sizeof(double));
         }
@@ -729,7 +742,7 @@ struct Core {
         if (tile_ncx == 6) { DISPATCH_MODEL(L_JT, 6) } else if (tile_ncx == 14) { DISPATCH_MODEL(L_JT, 14) } else { DISPATCH_MODEL(L_JT, MAXCOL) }
 #undef L_JT
         LAUNCHK(k_prior_jv, dim3(grid_zs), dim3(1024), 0, stream, d, zlin.p, v, g_c, gp.p, gpart.p, gctr.p + 4,
-                (const double *)partial.p, (int64_t)grid_obs, (const double *)nullptr, pivmm.p, (const int *)info.p, scal.p, (double *)nullptr);
+                (const double *)partial.p, (int64_t)grid_obs, (const double *)nullptr, pivmm.p, (const int *)info.p, scal.p, (double *)nullptr, 0ull);
         do_allreduce(scal.p, 8);
         double h[8];
         read_scal(h, 8);

@@ -229,6 +229,14 @@ __global__ __launch_bounds__(256) void k_residual_cm(DevProblem d, const double 
     if (threadIdx.x == 0) partial[blockIdx.x] = acc[0];      // summed by k_prior_sq (thousands of tickets on one address cost more)
 }
 
+// The last word a kernel says to the host: after its results are in the pinned mailbox it stores the
+// ticket of the host's current wait in slot 63 (system-scope release).  The host spins on that slot
+// instead of sleeping in hipStreamSynchronize -- kernels of a stream finish in order, so the ticket
+// of the last one means everything before it is done.
+__device__ __forceinline__ void mailbox_done(double *mailbox, unsigned long long seq) {
+    __atomic_store_n(reinterpret_cast<unsigned long long *>(mailbox) + 63, seq, __ATOMIC_RELEASE);
+}
+
 // prior-observation rows (prior_obs.m:26-43): sum over owned z of w*(z-prior)^2, plus the n_res partial
 // sums res_partial of the residual kernel launched before.  The total goes to out[0] and
 // (mailbox != null) to the host's pinned mailbox.  Few, large blocks: a grid sum costs one
@@ -236,7 +244,8 @@ __global__ __launch_bounds__(256) void k_residual_cm(DevProblem d, const double 
 __global__ __launch_bounds__(1024) void k_prior_sq(DevProblem d, const double *__restrict__ z,
                                                    double *__restrict__ partial, unsigned *__restrict__ ctr,
                                                    const double *__restrict__ res_partial, int64_t n_res,
-                                                   double *__restrict__ out, double *__restrict__ mailbox) {
+                                                   double *__restrict__ out, double *__restrict__ mailbox,
+                                                   unsigned long long seq) {
     __shared__ double sh[16];
     double acc[1] = {0.0};
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -246,7 +255,7 @@ __global__ __launch_bounds__(1024) void k_prior_sq(DevProblem d, const double *_
     }
     if (grid_sum<1, 1>(acc, sh, partial, ctr, res_partial, n_res) && threadIdx.x == 0) {
         out[0] = acc[0];
-        if (mailbox) mailbox[0] = acc[0];
+        if (mailbox) { mailbox[0] = acc[0]; mailbox_done(mailbox, seq); }
     }
 }
 
@@ -2281,7 +2290,8 @@ __global__ __launch_bounds__(1024) void k_prior_jv(DevProblem d, const double *_
                                                   unsigned *__restrict__ ctr, const double *__restrict__ bs_partial,
                                                   int64_t nbs, const double *__restrict__ ldiag,
                                                   unsigned long long *__restrict__ pivmm, const int *__restrict__ info,
-                                                  double *__restrict__ out, double *__restrict__ mailbox) {
+                                                  double *__restrict__ out, double *__restrict__ mailbox,
+                                                  unsigned long long seq) {
     __shared__ double sh[80];
     double acc[5] = {0, 0, 0, 0, 0};                 // [3], [4]: the sums over the image rows, from bs_partial
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -2318,6 +2328,7 @@ __global__ __launch_bounds__(1024) void k_prior_jv(DevProblem d, const double *_
             const int hi = __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             long long w = hi;
             mailbox[44] = __longlong_as_double(w);
+            mailbox_done(mailbox, seq);
         }
     }
 }
