@@ -354,7 +354,7 @@ struct Core {
     void sync() {
         // The kernel that ends a phase writes this wait's ticket into the mailbox after its results: spin on
         // it (a few microseconds after the kernel's last store) instead of sleeping in
-        // hipStreamSynchronize; after ~2 ms without the ticket fall back to the driver's wait.
+        // hipStreamSynchronize; after ~0.1 s without the ticket fall back to the driver's wait.
         bool done = false;
         if (mb_armed) {
             volatile unsigned long long *slot = reinterpret_cast<volatile unsigned long long *>(hpin) + 63;
