@@ -1,5 +1,5 @@
 """Randomised sweep, outside the test-suite: scenes of random shape (cameras, points, rays per point
-2 ... 13, fixed IO / self-calibration with 1, 2 or 4 IO blocks, long and short signature groups) --
+3 ... 13, fixed IO / self-calibration with 1, 2 or 4 IO blocks, long and short signature groups) --
 the device's Gauss-Newton and damped steps against the oracle's sparse solve, signature kernels forced
 on and off.  Prints one line per scene; exits non-zero on the first disagreement.
     python bench/fuzz_step.py [n_scenes] [first_seed]"""
@@ -18,7 +18,7 @@ worst = 0.0
 for sd in range(seed0, seed0 + n_scenes):
     rng = np.random.default_rng(sd)
     cams = int(rng.integers(24, 140))
-    rays = int(rng.integers(2, 14))
+    rays = int(rng.integers(3, 14))               # (two rays per point: barely determined networks, singular now and then)
     points = int(rng.integers(300, 6000))
     selfcal = bool(rng.integers(0, 2))
     groups = int(rng.choice([1, 1, 2, 4])) if selfcal else 1

@@ -687,18 +687,22 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         for (int64_t o = tile_first_obs; o < end_obs; ++o) P.o_lc[o] = (uint8_t)loc[P.o_cam[o]];
         // IO columns of the tile, ascending; every camera's IO columns -> local IO rows
         std::sort(cur_io.begin(), cur_io.end());
-        bool io_simple = !cur_cams.empty();
+        // k_build_sig's per-point IO rows: 1 = one IO block (IO column q = tile IO row q, every camera the same
+        // number of columns), 2 = two blocks of 8 rows each (camera columns q -> base + q, base 0 or 8)
+        bool io_one = !cur_cams.empty(), io_two = !cur_cams.empty() && cur_io.size() == 16;
         for (int32_t c : cur_cams) {
             uint8_t rows16[16] = {0};
             for (int q = 6; q < P.cam_ncol[c]; ++q) {
                 const int32_t io = P.cam_col[(size_t)c * MAXCOL + q] - 6 * nc;
                 rows16[q - 6] = (uint8_t)(std::lower_bound(cur_io.begin(), cur_io.end(), io) - cur_io.begin());
-                io_simple = io_simple && rows16[q - 6] == q - 6;
+                io_one = io_one && rows16[q - 6] == q - 6;
+                io_two = io_two && (rows16[0] == 0 || rows16[0] == 8) && rows16[q - 6] == rows16[0] + (q - 6);
             }
-            io_simple = io_simple && P.cam_ncol[c] == P.cam_ncol[cur_cams[0]] && (size_t)(P.cam_ncol[c] - 6) == cur_io.size();
+            io_one = io_one && P.cam_ncol[c] == P.cam_ncol[cur_cams[0]] && (size_t)(P.cam_ncol[c] - 6) == cur_io.size();
+            io_two = io_two && P.cam_ncol[c] == 14;
             P.tile_cam_io.insert(P.tile_cam_io.end(), rows16, rows16 + 16);
         }
-        P.tile_io_simple.push_back(io_simple ? 1 : 0);
+        P.tile_io_simple.push_back(io_one ? 1 : (io_two ? 2 : 0));
         for (int32_t io : cur_io) { P.tile_iocols.push_back(io); io_stamp[io] = -1; }
         P.tile_io_start.push_back((int32_t)P.tile_iocols.size());
         cur_io.clear();

@@ -39,6 +39,8 @@
 //     while one multiplies).
 // LDS reads of the operands are conflict free (row stride 18 doubles = 2 mod 4).
 #pragma once
+#include <type_traits>
+
 #include "kernels.hpp"
 
 namespace dbat {
@@ -78,8 +80,8 @@ __device__ __forceinline__ double lane_get(double x, int src) {
 // nio further rows of every chunk (after its 6k camera rows, before the row of y): an IO row is
 // shared by the k observations of a point, so its k-columns are summed with ds_add_f64 into the
 // zeroed panel rows.
-// IOS = 1: self-calibration, tiles whose cameras all share ONE IO block with the identity row map:
-// the IO rows of a point are summed in pass 1 (see below).  One launch serves both kinds of tiles
+// IOS = 1, 2: self-calibration, tiles whose cameras belong to one or two IO blocks with the identity row
+// map inside each block: the IO rows of a point are summed in pass 1 (see below).  One launch serves both kinds of tiles
 // (k_build_sig branches per workgroup on the plan's flag), so they share the longest-first order.
 template <int MODEL, int RB, int NCX, int IOS>
 __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int tile, const double *__restrict__ z,
@@ -176,7 +178,8 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
         // point's observations are visited one after the other anyway -- in pass 1, in the lane's
         // registers -- instead of by 24 LDS atomics per observation (ten observations on the same
         // addresses) in pass 2.  Tiles that mix IO blocks run the IOS = 0 instantiation with the atomics.
-        constexpr int NQ = io_simple ? NCX - 6 : 1;
+        constexpr int NQ1 = NCX - 6;                       // IO columns of one camera
+        constexpr int NQ = io_simple ? IOS * NQ1 : 1;       // IO rows of the tile: one or two IO blocks
         double pZio[NQ][3];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) pZio[q][0] = pZio[q][1] = pZio[q][2] = 0.0;
@@ -215,18 +218,23 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
                     B[0][c] *= w0 * m; B[1][c] *= w1 * m;
                 }
                 if constexpr (io_simple) {
-                    {                                // W_io += E_io' B
+                    {                                // W_io += E_io' B, into the rows of the camera's IO block
                         double Eio[2][NCX];
                         io_columns<NCX>(C, Cf, w0, w1, Eio);
                         const int ncol = min(C.ncol, NCX);
+                        auto into = [&](auto off) {
+                            constexpr int OFF = decltype(off)::value;
 #pragma unroll
-                        for (int q = 0; q < NQ; ++q)
-                            if (6 + q < ncol) {
-                                const double e0 = Eio[0][6 + q], e1 = Eio[1][6 + q];
-                                pZio[q][0] += e0 * B[0][0] + e1 * B[1][0];
-                                pZio[q][1] += e0 * B[0][1] + e1 * B[1][1];
-                                pZio[q][2] += e0 * B[0][2] + e1 * B[1][2];
-                            }
+                            for (int q = 0; q < NQ1; ++q)
+                                if (6 + q < ncol) {
+                                    const double e0 = Eio[0][6 + q], e1 = Eio[1][6 + q];
+                                    pZio[OFF + q][0] += e0 * B[0][0] + e1 * B[1][0];
+                                    pZio[OFF + q][1] += e0 * B[0][1] + e1 * B[1][1];
+                                    pZio[OFF + q][2] += e0 * B[0][2] + e1 * B[1][2];
+                                }
+                        };
+                        if (IOS == 2 && sy.camio[lc][0] >= NQ1) into(std::integral_constant<int, (IOS == 2 ? NQ1 : 0)>{});   // (uniform: the camera is)
+                        else into(std::integral_constant<int, 0>{});
                     }
                 }
                 if (act) rr += r[0] * r[0] + r[1] * r[1];
@@ -354,12 +362,10 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
                     // lanes without a point hold zeros and clear the previous round's columns)
                     const int pil = npts <= 32 ? (lane & 31) : lane;
                     const int irw = pil - p0;
-                    const int lc0 = sy.lc[wave][0];
-                    const int ncol0 = min(reinterpret_cast<const CamRec *>(camw + lc0 * CAMW)->ncol, NCX);
                     if (lane == pil && irw >= 0 && irw < ppr) {
 #pragma unroll
                         for (int q = 0; q < NQ; ++q)
-                            if (6 + q < ncol0) {
+                            if (q < nio) {
                                 double *pio = pan + (6 * k + q) * LDK + 3 * irw;
                                 pio[0] = pZio[q][0]; pio[1] = pZio[q][1]; pio[2] = pZio[q][2];
                             }
@@ -369,7 +375,7 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
                         const int irz = nhold - p0 + lane;
 #pragma unroll
                         for (int q = 0; q < NQ; ++q)
-                            if (6 + q < ncol0) {
+                            if (q < nio) {
                                 double *pio = pan + (6 * k + q) * LDK + 3 * irz;
                                 pio[0] = 0.0; pio[1] = 0.0; pio[2] = 0.0;
                             }
@@ -544,8 +550,13 @@ __global__ __launch_bounds__(64 * sig_waves(RB, (NCX > 6))) void k_build_sig(Dev
                                                    const double *__restrict__ sg_w) {
     const int tile = d.tile_order[blockIdx.x];
     if constexpr (NCX > 6) {
-        if (d.tile_io_simple && d.tile_io_simple[tile]) {
+        const int ios = d.tile_io_simple ? d.tile_io_simple[tile] : 0;       // IO blocks of the tile, if it qualifies
+        if (ios == 1) {
             build_sig_tile<MODEL, RB, NCX, 1>(d, tile, z, cams, lambda, scale, S, g_red, Vinv, gp, jn2p, partial, pivmm, sg_chunk, sg_tile_chunk0, sg_lc, sg_uv, sg_w);
+            return;
+        }
+        if (ios == 2) {
+            build_sig_tile<MODEL, RB, NCX, 2>(d, tile, z, cams, lambda, scale, S, g_red, Vinv, gp, jn2p, partial, pivmm, sg_chunk, sg_tile_chunk0, sg_lc, sg_uv, sg_w);
             return;
         }
     }
