@@ -917,7 +917,7 @@ struct DataflowChol {
             // workgroups then sit in the dependent chains of a few leaves while the other leaves
             // have not started.  Candidate orders are tried on a model of the kernel (measured
             // costs, us: bench/chol_trace.py, bench/chol_path.py) and the best one is taken.
-            const double c_prod = getenv("DBAT_HIP_DF_CPROD") ? atof(getenv("DBAT_HIP_DF_CPROD")) : 2.5, c_diag = 13.5, c_off = 4.5, c_hop = 2.0, c_add = 1.5, c_help = 2.0;
+            const double c_prod = 2.5, c_diag = 13.5, c_off = 4.5, c_hop = 2.0, c_add = 1.5, c_help = 2.0;
             auto tail_of = [&](int t) { return is_helper(t) || jobs[t].mode == 1 ? c_help : (is_diag(t) ? c_diag + (jobs[t].mode == 2 ? 2.5 : 0.0) : c_off); };
             // (1) earliest start: every input the moment it exists, unlimited workgroups
             std::vector<double> est(ntasks, 0.0), fin(ntasks, 0.0);
