@@ -7,13 +7,20 @@
 // 2xnIO blocks of its observation from (u,v), the camera record and the
 // object point (F5-F9 of SURVEY.md 8(a)).
 //
-//   k_cam_prep   per camera: rotation, its derivatives, IO fan-out   (K0)
-//   k_residual   residual only, 0.5*r'r                               (K2)
-//   k_build      residual + Jacobian blocks + point blocks V, g_p,
-//                V^-1 and the Schur complement S -= (W V^-1) W'       (K1,K3,K4,K5)
-//   k_finish / k_scale_S   priors, damping, fixed rows, column scaling (F11)
-//   k_backsub    dp = -V^-1 (g_p + W' dc), J*p sums                   (K7,K8,K9)
-//   k_jtimes     ||J v||^2, r'Jv                                      (K8)
+//   k_cam_prep / k_envelope_cams / k_axpby_cams   per camera: rotation, its derivatives, IO fan-out
+//                (K0), alone or riding in the first launch of a linearisation / of a trial point
+//   k_residual_cm, k_residual   residual only, 0.5*r'r (camera-major; point-major for exports)   (K2)
+//   k_cam_normal6, k_cam_normal camera side of the tiled observations: J_c'J_c, J_c'r
+//   k_build, k_build_giant      residual + Jacobian blocks + point blocks V, g_p, V^-1 and the Schur
+//                complement by the column lists (heavy points, shared EO)             (K1,K3,K4,K5)
+//   k_build_tile2, k_build_tile3  the same on the f64 matrix cores by dense 128-row tiles, where the
+//                signature groups are too short for sig.hpp's k_build_sig
+//   k_finish, k_envelope_op     priors, damping, fixed rows, column scaling on the envelope (F11)
+//   k_backsub, k_backsub_giant  dp = -V^-1 (g_p + W' dc), J*p sums                     (K7,K8,K9)
+//   k_build_tail, k_prior_sq, k_prior_jv   the tails of a linearisation / an objective value / a
+//                solve: one launch each, grid sum finished by the last block (grid_sum)
+//   k_jtimes     ||J v||^2, r'Jv                                                       (K8)
+//   k_cov_*, k_forwintersect*   posterior covariance blocks, forward intersection
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -2003,26 +2010,6 @@ __global__ __launch_bounds__(256) void k_envelope_cams(DevProblem d, const doubl
     envelope_body(S, ldS, NS, tail0, col_bend, nullptr, vec, pivmm);
 }
 
-// min/max of the Cholesky pivots of the reduced system (estimated entries only)
-__global__ __launch_bounds__(256) void k_diag_minmax(DevProblem d, const double *__restrict__ ldiag,
-                                                     unsigned long long *__restrict__ pivmm) {
-    double pmin = 1e300, pmax = 0.0;
-    for (int64_t i = threadIdx.x; i < d.NS; i += blockDim.x)
-        if (d.z_est[i]) {
-            double v = ldiag[i];                     // diag(L) by natural index (the factorisation may be permuted)
-            v = v == v ? v : 0.0;
-            pmin = fmin(pmin, v); pmax = fmax(pmax, v);
-        }
-    for (int off = 32; off > 0; off >>= 1) {
-        pmin = fmin(pmin, __shfl_down(pmin, off, 64));
-        pmax = fmax(pmax, __shfl_down(pmax, off, 64));
-    }
-    if ((threadIdx.x & 63) == 0 && pmax > 0.0) {
-        atomicMin(pivmm, (unsigned long long)__double_as_longlong(fmax(pmin, 0.0)));
-        atomicMax(pivmm + 1, (unsigned long long)__double_as_longlong(pmax));
-    }
-}
-
 // ---------------------------------------------------------------- F11 ---
 // Camera/IO side: priors, damping, fixed rows, column scaling factors.
 //   jn2c[i] = diagU[i] + prior weight  (squared column norm of J)
@@ -2082,15 +2069,6 @@ __global__ void k_weight_rows(DevProblem d, const double *__restrict__ r_unw, do
     const double w0 = d.o_w ? d.o_w[2 * k] : d.cam_w[2 * cam], w1 = d.o_w ? d.o_w[2 * k + 1] : d.cam_w[2 * cam + 1];
     r_wgt[2 * row] = r_unw[2 * row] * w0;
     r_wgt[2 * row + 1] = r_unw[2 * row + 1] * w1;
-}
-
-// S(i,j) *= d_i d_j on the lower triangle
-__global__ void k_scale_S(int64_t NS, int64_t ldS, double *__restrict__ S, const double *__restrict__ ds) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // row
-    if (i >= NS) return;
-    const double di = ds[i];
-    for (int64_t j = blockIdx.y; j <= i; j += gridDim.y)                 // column (grid-stride: NS may exceed the y limit)
-        S[j * ldS + i] *= di * ds[j];
 }
 
 __global__ void k_unscale(int64_t NS, const double *__restrict__ q, const double *__restrict__ ds,
