@@ -199,6 +199,24 @@ __global__ __launch_bounds__(256) void k_tile64(int iters, unsigned long long *o
                     acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[rt], 0, 0, 0);
                 }
             }
+        } else if (VAR == 2) {                       // row blocks interleaved (r = 4 j + rt): the four b operands are 32 contiguous bytes
+            const double *pa = Pm + (lane >> 4) * LD + 16 * w + (lane & 15), *pb = Qm + (lane >> 4) * LD + 4 * (lane & 15);
+            double an = pa[0];
+            double2 b01 = *reinterpret_cast<const double2 *>(pb), b23 = *reinterpret_cast<const double2 *>(pb + 2);
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const double a = an;
+                const double2 c01 = b01, c23 = b23;
+                if (kk + 1 < 16) {
+                    an = pa[4 * (kk + 1) * LD];
+                    b01 = *reinterpret_cast<const double2 *>(pb + 4 * (kk + 1) * LD);
+                    b23 = *reinterpret_cast<const double2 *>(pb + 4 * (kk + 1) * LD + 2);
+                }
+                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, c01.x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, c01.y, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, c23.x, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, c23.y, acc[3], 0, 0, 0);
+            }
         } else {                                     // operands of k-step kk+1 on their way while kk multiplies
             const double *pa = Pm + (lane >> 4) * LD + 16 * w + (lane & 15), *pb = Qm + (lane >> 4) * LD + (lane & 15);
             double an = pa[0], bn[4] = {pb[0], pb[16], pb[32], pb[48]};
@@ -266,10 +284,11 @@ int main() {
         }
     (void)md;
     printf("checksum %.12g, |L L' - A| = %.3g\n", chk, err);
-    for (int var = 0; var < 2; ++var) {
+    for (int var = 0; var < 3; ++var) {
         for (int rep = 0; rep < 2; ++rep) {
             if (var == 0) hipLaunchKernelGGL((k_tile64<65, 0>), dim3(1), dim3(256), 0, 0, 2000, out, sink);
-            else hipLaunchKernelGGL((k_tile64<65, 1>), dim3(1), dim3(256), 0, 0, 2000, out, sink);
+            else if (var == 1) hipLaunchKernelGGL((k_tile64<65, 1>), dim3(1), dim3(256), 0, 0, 2000, out, sink);
+            else hipLaunchKernelGGL((k_tile64<66, 2>), dim3(1), dim3(256), 0, 0, 2000, out, sink);
             hipDeviceSynchronize();
         }
         unsigned long long h[8]; hipMemcpy(h, out, 64, hipMemcpyDeviceToHost);
