@@ -25,7 +25,8 @@
 //   * a wave takes chunks from the tile's list through an LDS counter (longest first; the next
 //     chunk's descriptor is fetched while the current one is worked on).
 // A chunk in two passes:
-//   pass 1, lane = object point (two lanes per point when the chunk has at most 32): loop over the
+//   pass 1, lane = object point (two, four or eight lanes per point when the chunk has at most 32, 16
+//     or 8 points): loop over the
 //     k cameras (uniform per chunk: broadcast reads of the staged record, coalesced (u,v) from the
 //     slot-major copy), residual r and point block B per observation; V = sum B'B (+ prior,
 //     + lambda), g = sum B'r in registers -- no atomics, no cross-lane traffic; V^-1, its
@@ -184,11 +185,13 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
 #pragma unroll
         for (int q = 0; q < NQ; ++q) pZio[q][0] = pZio[q][1] = pZio[q][2] = 0.0;
         {
-            // a chunk of at most 32 points takes two lanes per point: lane l and lane l + 32 share the
-            // cameras (even / odd slots) and add their sums up afterwards
-            const bool split = npts <= 32;
-            const int pi = split ? (lane & 31) : lane;
-            const int jh = split ? (lane >> 5) : 0, jstep = split ? 2 : 1;
+            // A short chunk takes several lanes per point: with G = 32, 16 or 8 point slots (the smallest that
+            // holds the chunk) the lanes l, l + G, l + 2G, ... share the point's cameras (slots h, h + 64/G, ...)
+            // and add their sums up afterwards -- the loop over the cameras is a serial chain of evaluations,
+            // so a chunk of 7 points (C1, C2) takes a quarter of the time of a chunk of 64.
+            const int G = npts > 32 ? 64 : (npts > 16 ? 32 : (npts > 8 ? 16 : 8));
+            const int pi = lane & (G - 1);
+            const int jh = lane / G, jstep = 64 / G;
             const bool act = pi < npts;
             const int pt = pt0 + (act ? pi : 0);
             const int64_t zp = d.NS + 3 * (int64_t)pt;
@@ -248,16 +251,16 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
                 g[1] += B[0][1] * r[0] + B[1][1] * r[1];
                 g[2] += B[0][2] * r[0] + B[1][2] * r[1];
             }
-            if (split) {                              // the other half of the point's cameras (uniform branch)
+            for (int m = G; m < 64; m <<= 1) {        // the other lanes of the point (uniform loop: butterfly over the slices)
 #pragma unroll
-                for (int c = 0; c < 6; ++c) V[c] += lane_get(V[c], lane ^ 32);
+                for (int c = 0; c < 6; ++c) V[c] += lane_get(V[c], lane ^ m);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) g[c] += lane_get(g[c], lane ^ 32);
+                for (int c = 0; c < 3; ++c) g[c] += lane_get(g[c], lane ^ m);
                 if constexpr (io_simple) {
 #pragma unroll
                     for (int q = 0; q < NQ; ++q)
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) pZio[q][c] += lane_get(pZio[q][c], lane ^ 32);
+                        for (int c = 0; c < 3; ++c) pZio[q][c] += lane_get(pZio[q][c], lane ^ m);
                 }
             }
             const bool writer = act && lane == pi;    // one lane per point writes to HBM
@@ -360,7 +363,8 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
                 } else {
                     // Z_io of the round's points from the lanes that hold them (pass-1 layout: lane = point;
                     // lanes without a point hold zeros and clear the previous round's columns)
-                    const int pil = npts <= 32 ? (lane & 31) : lane;
+                    const int nhold = npts > 32 ? 64 : (npts > 16 ? 32 : (npts > 8 ? 16 : 8));     // point slots of the pass-1 layout
+                    const int pil = lane & (nhold - 1);
                     const int irw = pil - p0;
                     if (lane == pil && irw >= 0 && irw < ppr) {
 #pragma unroll
@@ -370,7 +374,6 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
                                 pio[0] = pZio[q][0]; pio[1] = pZio[q][1]; pio[2] = pZio[q][2];
                             }
                     }
-                    const int nhold = npts <= 32 ? 32 : 64;           // points that have a lane in the pass-1 layout
                     if (p0 + ppr > nhold && lane < p0 + ppr - nhold) {   // columns of points nhold, nhold+1, ...: no lane holds them
                         const int irz = nhold - p0 + lane;
 #pragma unroll
