@@ -100,13 +100,12 @@ def cpu_baseline(s_main, name_main, budget_s=25.0):
 def launch_ranks(args):
     """Start one rank per GPU (torch.distributed.run) as a child process; the
     parent never initialises a GPU."""
-    import socket
-    with socket.socket() as sk:
-        sk.bind(('127.0.0.1', 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
-           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: the launcher picks its own rendezvous port (no bind-and-close race on a shared box)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--standalone', '--local-addr', '127.0.0.1', '--nnodes=1',
+           '--nproc-per-node', str(args.gpus), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
+    # this pool's host driver supports dmabuf IPC only: without it RCCL's ncclCommInitRank across
+    # processes fails in hipIpcGetMemHandle (the image exports the same value)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     return subprocess.run(cmd, env=env).returncode
 

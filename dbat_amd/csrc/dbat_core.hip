@@ -73,6 +73,13 @@ struct DevBuf {
 };
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield");
+#endif
+}
 
 struct Core {
     Plan P;
@@ -175,7 +182,10 @@ struct Core {
         device = pb.device;
         HIPCHK(hipSetDevice(pb.device));
         HIPCHK(hipStreamCreate(&stream));
-        HIPCHK(hipHostMalloc((void **)&hpin, 64 * sizeof(double), hipHostMallocDefault));
+        // coherent (fine-grained) on purpose: the kernels' stores must become visible to the spinning host
+        // thread without a stream synchronisation, whatever HIP_HOST_COHERENT says
+        HIPCHK(hipHostMalloc((void **)&hpin, 64 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+        memset(hpin, 0, 64 * sizeof(double));        // ticket slot 63 must not match the first wait by accident
         {
             const double big = 1e300;
             memcpy(&hpin[48], &big, 8); hpin[49] = 0.0; memcpy(&hpin[50], &big, 8); hpin[51] = 0.0;   // bit patterns: min = 1e300, max = +0
@@ -285,6 +295,7 @@ struct Core {
         grid_z = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(P.NZ, 256), 2048));
         grid_zs = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(P.NZ, 2048), 256));
         scal.alloc((size_t)16 + 2 * (size_t)P.nranks);
+        HIPCHK(hipMemset(scal.p, 0, ((size_t)16 + 2 * (size_t)P.nranks) * sizeof(double)));   // unused slots travel through the all-reduce
         info.alloc(1);
         pivmm.alloc(4);
         gctr.alloc(16); HIPCHK(hipMemset(gctr.p, 0, 16 * sizeof(unsigned)));
@@ -354,11 +365,18 @@ struct Core {
     void sync() {
         // The kernel that ends a phase writes this wait's ticket into the mailbox after its results: spin on
         // it (a few microseconds after the kernel's last store) instead of sleeping in
-        // hipStreamSynchronize; after ~0.1 s without the ticket fall back to the driver's wait.
+        // hipStreamSynchronize; after 2 ms without the ticket fall back to the driver's wait (a step that
+        // long does not notice the driver's wake-up latency).  A ticket hit skips the driver's wait, so
+        // asynchronous device errors surface at the next real synchronisation: every ABI call that returns
+        // results ends in one (z_to_x / read_scal).
         bool done = false;
         if (mb_armed) {
             volatile unsigned long long *slot = reinterpret_cast<volatile unsigned long long *>(hpin) + 63;
-            for (int spin = 0; spin < 4000000 && !done; ++spin) { done = *slot == mb_seq; if (!done) __builtin_ia32_pause(); }
+            const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+            for (;;) {
+                for (int spin = 0; spin < 512 && !done; ++spin) { done = *slot == mb_seq; if (!done) cpu_relax(); }
+                if (done || std::chrono::steady_clock::now() >= t_end) break;
+            }
             __atomic_thread_fence(__ATOMIC_ACQUIRE);
             mb_armed = false;
         }
@@ -678,6 +696,9 @@ struct Core {
         double pmin = std::min(mm[0], mm[2]), pmax = std::max(mm[1], mm[3]);
         for (int r = 0; r < nsl / 2; ++r) { pmin = std::min(pmin, h[8 + 2 * r]); pmax = std::max(pmax, h[8 + 2 * r + 1]); }
         const bool failed = hinfo != 0 || !std::isfinite(pp) || !std::isfinite(JpJp);
+        // a failed factorisation that ran in place may have left non-finite values in tile parts outside the
+        // column envelope (0 x NaN), which the envelope-only clearing of the next build would not reach
+        if (failed && !(use_perm && !chol_in_place)) s_dense_dirty = true;
         const double ratio = pmax > 0 ? pmin / pmax : 0.0;
         near_singular = failed || !(ratio * ratio >= 2.220446049250313e-16);
         return failed;
@@ -688,13 +709,15 @@ struct Core {
         build(z.p, 0.0, 0);                          // unscaled, undamped reduced system + V^-1 per point
         s_valid = false;
         chol_in_place = true;
+        // the in-place factorisation stores whole 64 x 64 tiles, which straddle the column envelope that the
+        // next build clears: from here on S must be cleared densely -- also when the factorisation fails
+        s_dense_dirty = true;
         factor_solve_enqueue();                      // L in the lower triangle of S
         chol_in_place = false;
         int hinfo = 0;
         HIPCHK(hipMemcpyAsync(&hinfo, info.p, sizeof(hinfo), hipMemcpyDeviceToHost, stream));
         sync();
         if (hinfo != 0) throw DeviceError{"posterior covariance: the reduced normal matrix is not positive definite"};
-        s_dense_dirty = true;                         // inv(S) is dense
         if (rocsolver_dpotri(blas, rocblas_fill_lower, (rocblas_int)P.NS, S, (rocblas_int)ldS, info.p) != rocblas_status_success)
             throw DeviceError{"rocsolver_dpotri failed"};
         have_lin = false;

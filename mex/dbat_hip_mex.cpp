@@ -8,7 +8,7 @@
 // interleaved-complex API, a same-named .m stub that errors when the MEX file
 // is missing (code/test/postcov/icpc_mex.m:14).
 //
-//   [x,code,iters,sigma0,res,damp,aux,T,ru,rw,time] = dbat_hip_mex(P, opt)
+//   [x,code,iters,sigma0,res,damp,aux,T,ru,rw,time,CEO,CIO,COP] = dbat_hip_mex(P, opt)
 //
 // P   struct with the flattened DBAT struct fields built by bundle_hip.m
 // opt struct: damping (0..3), maxIter, convTol, absTerm, singularTest, trace

@@ -1,0 +1,40 @@
+/* Declarations-only stand-in for MATLAB's mex.h -- TEST INFRASTRUCTURE, not a MEX runtime.
+ *
+ * The image has no MATLAB, so mex/dbat_hip_mex.cpp can never be linked here.  This header carries
+ * just the prototypes the gateway uses (interleaved-complex API of R2018a, as the reference's own
+ * MEX file uses them: /root/reference/code/test/postcov/icpc_mex.c:495-611, dumpsparse.c:25-27), so
+ * that tests/test_mex_gateway.py can run the compiler's front end over the gateway
+ * (g++ -fsyntax-only) and catch signature / type errors.  Nothing is defined, nothing links. */
+#ifndef DBAT_TEST_MEX_STUB_H
+#define DBAT_TEST_MEX_STUB_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mxArray_tag mxArray;
+typedef size_t mwSize;
+typedef size_t mwIndex;
+typedef enum { mxREAL = 0, mxCOMPLEX = 1 } mxComplexity;
+typedef enum { mxUNKNOWN_CLASS = 0, mxDOUBLE_CLASS = 6, mxINT32_CLASS = 12, mxUINT8_CLASS = 9 } mxClassID;
+
+bool mxIsStruct(const mxArray *pa);
+mxArray *mxGetField(const mxArray *pa, mwIndex index, const char *fieldname);
+double mxGetScalar(const mxArray *pa);
+void *mxGetData(const mxArray *pa);
+double *mxGetDoubles(const mxArray *pa);
+mxArray *mxCreateDoubleMatrix(mwSize m, mwSize n, mxComplexity flag);
+mxArray *mxCreateDoubleScalar(double value);
+mxArray *mxCreateNumericArray(mwSize ndim, const mwSize *dims, mxClassID classid, mxComplexity flag);
+void mxSetN(mxArray *pa, mwSize n);
+void mxDestroyArray(mxArray *pa);
+void mexErrMsgIdAndTxt(const char *identifier, const char *fmt, ...);
+void mexWarnMsgIdAndTxt(const char *identifier, const char *fmt, ...);
+
+void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,83 @@
+"""The MATLAB side of the boundary, checked without MATLAB (CPU only).
+
+(a) mex/dbat_hip_mex.cpp passes the compiler's front end against a declarations-only mex.h
+    (tests/mex_stub/mex.h; prototypes as used by the reference's own MEX file,
+    code/test/postcov/icpc_mex.c:495-611) and the real include/dbat_hip.h;
+(b) the field names the gateway reads (field(P,"...") / scalar(O,"...")) are exactly the names of
+    the struct literals in matlab/bundle_hip.m, and the output list of the call in bundle_hip.m
+    matches the gateway's documented [x,code,...] order and its highest plhs index.
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GATEWAY = os.path.join(ROOT, 'mex', 'dbat_hip_mex.cpp')
+WRAPPER = os.path.join(ROOT, 'matlab', 'bundle_hip.m')
+
+
+def test_gateway_passes_the_compiler_front_end():
+    cxx = shutil.which('g++') or shutil.which('c++')
+    if cxx is None:
+        pytest.skip('no C++ compiler')
+    r = subprocess.run([cxx, '-std=c++17', '-fsyntax-only', '-Wall', '-Wextra', '-Werror',
+                        '-I' + os.path.join(ROOT, 'tests', 'mex_stub'), '-I' + os.path.join(ROOT, 'include'), GATEWAY],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def _matlab_struct_fields(src, var):
+    """Field names of `var=struct('a',...,'b',...)` (continuation lines joined)."""
+    m = re.search(r"^%s=struct\((.*?)\);" % re.escape(var), src.replace('...\n', ' '), re.M | re.S)
+    assert m, 'no struct literal for %s' % var
+    body = m.group(1)
+    # top-level 'name', value pairs: a name is a quoted identifier directly followed by a comma at depth 0
+    names, depth, i = [], 0, 0
+    expect_name = True
+    while i < len(body):
+        ch = body[i]
+        if ch in '([{':
+            depth += 1
+        elif ch in ')]}':
+            depth -= 1
+        elif ch == ',' and depth == 0:
+            expect_name = not expect_name
+        elif ch == "'" and depth == 0 and expect_name:
+            j = body.index("'", i + 1)
+            names.append(body[i + 1:j])
+            i = j
+        elif ch == "'":                      # a string inside a value: skip it
+            i = body.index("'", i + 1)
+        i += 1
+    return names
+
+
+def test_field_names_and_output_order_agree():
+    cpp = open(GATEWAY).read()
+    m = open(WRAPPER).read()
+    read_P = set(re.findall(r'(?:field|scalar)\(P,\s*"(\w+)"\)', cpp))
+    read_O = set(re.findall(r'(?:field|scalar)\(O,\s*"(\w+)"\)', cpp))
+    P_fields = _matlab_struct_fields(m, 'P')
+    O_fields = _matlab_struct_fields(m, 'opt')
+    assert len(P_fields) == len(set(P_fields)) and len(O_fields) == len(set(O_fields))
+    assert read_P == set(P_fields), (sorted(read_P - set(P_fields)), sorted(set(P_fields) - read_P))
+    assert read_O == set(O_fields), (sorted(read_O - set(O_fields)), sorted(set(O_fields) - read_O))
+    # outputs: the call in bundle_hip.m, the gateway's documented list, and the plhs indices it fills
+    call = re.search(r'^\[([^\]]+)\]=dbat_hip_mex\(P,opt\);', m, re.M)
+    assert call
+    outs_m = [v.strip() for v in call.group(1).split(',')]
+    doc = re.search(r'//\s*\[([^\]]+)\]\s*=\s*dbat_hip_mex\(P, opt\)', cpp)
+    assert doc
+    outs_cpp = [v.strip() for v in doc.group(1).split(',')]
+    alias = {'sigma0': 's0', 'CEO': 'CEOb', 'CIO': 'CIOu', 'COP': 'COPb'}
+    assert [alias.get(v, v) for v in outs_cpp] == outs_m
+    plhs = sorted({int(i) for i in re.findall(r'plhs\[(\d+)\]\s*=', cpp)})
+    assert plhs == list(range(len(outs_m))), (plhs, outs_m)
+    # every output beyond the first is guarded by the matching nlhs test (MATLAB always accepts plhs[0])
+    for i in plhs[1:]:
+        guards = [int(g) for g in re.findall(r'if \(nlhs > (\d+)\)[^\n;]*plhs\[%d\]\s*=' % i, cpp)]
+        outer = [int(g) for g in re.findall(r'if \(nlhs > (\d+)\) \{', cpp)]
+        assert any(g == i for g in guards) or any(g <= i for g in outer), i   # nlhs > i <=> plhs[i] may be set
