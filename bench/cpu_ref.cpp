@@ -720,4 +720,22 @@ int32_t cpuref_lm_step(cpuref_handle *h, const double *x, double lambda, double 
     return ok ? 0 : -2;
 }
 
+// |J v|^2, r'J v and v'v with the explicit Jacobian and residual of the last cpuref_lm_step (the
+// termination test's norm(J*p), levenberg_marquardt.m:162; the slope r'Jp of the line search).  Not part
+// of the timed step: the parity tests compare the GPU's scalars of one linearise+solve with it.
+int32_t cpuref_step_norms(const cpuref_handle *h, const double *v, double *out3) {
+    if (!h || !v || !out3) return -1;
+    const Ref &R = h->R;
+    std::vector<double> Jv((size_t)2 * R.no, 0.0);
+    double vv = 0;
+    for (int64_t j = 0; j < R.n; ++j) {              // column sweep (serial: columns share rows)
+        vv += v[j] * v[j];
+        for (int64_t k = R.Jp[j]; k < R.Jp[j + 1]; ++k) Jv[R.Ji[k]] += R.Jx[k] * v[j];
+    }
+    double a = 0, b = 0;
+    for (size_t i = 0; i < Jv.size(); ++i) { a += Jv[i] * Jv[i]; b += Jv[i] * R.r[i]; }
+    out3[0] = a; out3[1] = b; out3[2] = vv;
+    return 0;
+}
+
 }  // extern "C"

@@ -36,6 +36,8 @@ def load():
         lib.cpuref_serialize.argtypes = [C.c_void_p, C.c_void_p]
         lib.cpuref_lm_step.restype = C.c_int32
         lib.cpuref_lm_step.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
+        lib.cpuref_step_norms.restype = C.c_int32
+        lib.cpuref_step_norms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = lib
     return _lib
 
@@ -87,6 +89,14 @@ class CpuRef:
         out = dict(code=int(rc), f=st[0], f_trial=st[1], trace=st[2], lam=st[3],
                    ms=dict(zip(self.PHASES, st[4:12].tolist())))
         return p, out
+
+    def step_norms(self, v):
+        """(|J v|^2, r'J v, v'v) with J and r of the last lm_step."""
+        v = np.ascontiguousarray(v, np.float64)
+        out = np.zeros(3)
+        if load().cpuref_step_norms(self._h, v.ctypes.data, out.ctypes.data) != 0:
+            raise RuntimeError('cpuref_step_norms failed')
+        return float(out[0]), float(out[1]), float(out[2])
 
     def close(self):
         if self._h:

@@ -80,6 +80,8 @@ SYMBOLS = {
     'dbat_hip_plan_structural_rank_ok': (C.c_int, [C.POINTER(Problem), C.POINTER(C.c_int32)]),
     'dbat_hip_plan_point_owner': (C.c_int, [C.POINTER(Problem), _ip]),
     'dbat_hip_plan_serialize': (C.c_int, [C.POINTER(Problem), _dp]),
+    'dbat_hip_plan_layout_stats': (C.c_int, [C.POINTER(Problem), C.POINTER(C.c_int64)]),
+    'dbat_hip_plan_domain_map': (C.c_int, [C.POINTER(Problem), _ip, C.POINTER(C.c_int32)]),
     'dbat_hip_create': (C.c_int, [C.POINTER(Problem), C.POINTER(_H)]),
     'dbat_hip_destroy': (None, [_H]),
     'dbat_hip_num_params': (C.c_int64, [_H]),
@@ -448,6 +450,29 @@ def plan_point_owner(s, shard_count):
     owner = np.full(s.OP.val.shape[1], -1, np.int32)
     check(lib.dbat_hip_plan_point_owner(C.byref(p), owner.ctypes.data_as(_ip)))
     return owner
+
+
+def plan_layout_stats(s, shard_rank=0, shard_count=1):
+    """Host-only: which layout (tiles, signature groups, chunk lengths) the plan gives the problem."""
+    lib = load()
+    p, keep = problem_from_struct(s, 0, shard_rank, shard_count)
+    a = (C.c_int64 * 16)()
+    check(lib.dbat_hip_plan_layout_stats(C.byref(p), a))
+    v = [int(x) for x in a]
+    return dict(n_tiles=v[0], n_batches=v[1], n_batches_tiled=v[2], n_groups=v[3], n_group_points=v[4], n_chunks=v[5],
+                chunks_by_length={'1-8': v[6], '9-16': v[7], '17-32': v[8], '33-64': v[9]}, chunks_multi_round=v[10],
+                k_max=v[11], rows_max=v[12], build_sig=bool(v[13]), backsub_sig=bool(v[14]))
+
+
+def plan_domain_map(s, shard_count):
+    """Host-only: (cam_owner, subtree) -- the rank whose domain every image belongs to (-1: top separator) under
+    domain sharding with shard_count ranks, and whether the problem is sharded that way at all."""
+    lib = load()
+    p, keep = problem_from_struct(s, 0, 0, shard_count)
+    owner = np.full(s.EO.val.shape[1], -1, np.int32)
+    sub = C.c_int32(0)
+    check(lib.dbat_hip_plan_domain_map(C.byref(p), owner.ctypes.data_as(_ip), C.byref(sub)))
+    return owner, bool(sub.value)
 
 
 def plan_serialize(s):

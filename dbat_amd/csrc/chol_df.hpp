@@ -47,6 +47,7 @@
 #include <queue>
 
 #include "chol.hpp"
+#include "nd.hpp"
 
 namespace dbat {
 
@@ -63,6 +64,10 @@ struct DfTask { int i, k; };
 // the dependent chain): its task only sums, publishes T = A - sum in the tile and is done -- the
 // diagonal task of column k (mode 2, p = that tile row) multiplies it by L^-T right after its own
 // factorisation, so the chain does not pass through a second workgroup (store, flag, load of L^-1).
+// mode 4 (multi-GPU, phase A): tile (i,k) of a TOP separator column: this rank's share of its Schur complement,
+// T_r = A_r(i,k) - sum over the columns j of the rank's OWN domain, is left in the tile and summed over the
+// ranks before the top separators are factored (phase B, every rank).  | 8: no identity on the padding rows
+// (they are contributed by rank 0 only).
 struct DfJob { int i, k, jlo, jhi, part, np, mode, p; };
 
 // Tiles that one workgroup writes and others read inside the same launch move
@@ -458,23 +463,24 @@ __global__ __launch_bounds__(256) void k_chol_df(DfView V, int n, int nT, const 
                                                  const int *__restrict__ bk_idx, double *__restrict__ q_out,
                                                  double *__restrict__ q_nat, double *__restrict__ ldiag,
                                                  const double *__restrict__ qscale, double *__restrict__ dz_out,
-                                                 double *__restrict__ parts, int nparts) {
+                                                 double *__restrict__ parts, int nparts,
+                                                 const int *__restrict__ bk_list, int nbk, int ctr_slot) {
     constexpr int NB = 64, LD = DF_LD;
     __shared__ double smem[2 * NB * LD];                // Pm | Qm, or the augmented block of df_potf2
     double *Pm = smem, *Qm = smem + NB * LD;
     __shared__ int s_task, s_ok;
     const int t = threadIdx.x, tx = t & 63, ty = t >> 6;
-    int *counter = ctl, *abort_flag = ctl + 1;
+    int *counter = ctl + ctr_slot, *abort_flag = ctl + 1;     // (slot 0, or 2 for the second launch of a solve)
     const bool l2 = V.iperm != nullptr && !V.no_l2;     // compact tiles: finished tiles through the L2 (see ld_l2_16)
     for (;;) {
         if (t == 0) s_task = atomicAdd(counter, 1);
         __syncthreads();
         const int task = s_task;
         if (task >= ntasks) {
-            // backward substitution, panels last to first (q_out == nullptr: factor only)
-            if (q_out == nullptr || task >= ntasks + nT) return;
+            // backward substitution, the panels of bk_list (last to first; q_out == nullptr: factor only)
+            if (q_out == nullptr || task >= ntasks + nbk) return;
             if (trace && t == 0) trace[task * 16 + 0] = wall_clock64();
-            if (!df_backward(smem, V, n, nT, nT - 1 - (task - ntasks), bk_ptr, bk_idx, flags, epoch, abort_flag,
+            if (!df_backward(smem, V, n, nT, bk_list[task - ntasks], bk_ptr, bk_idx, flags, epoch, abort_flag,
                              linv_all, q_out, q_nat, qscale, dz_out)) {
                 if (t == 0) *info = -1;
                 return;
@@ -485,7 +491,7 @@ __global__ __launch_bounds__(256) void k_chol_df(DfView V, int n, int nT, const 
         const DfJob jb = tasks[task];
         const int i = jb.i, k = jb.k;
         const bool helper = jb.np < 0;                  // a piece of a long sum (see DfJob)
-        const int jend = helper ? jb.jhi : k;           // products j in [jb.jlo, jend)
+        const int jend = jb.jhi;                        // products j in [jb.jlo, jend) (owner of a whole sum: jhi = k)
         int *pflags = flags + (int64_t)(nT + 1) * nT;   // flags of the helpers' partial sums
         int *tflags = pflags + nparts;                  // per column: T of its sum-only task (DfJob mode 1) is in the tile
         const int nr = i == nT ? 1 : min(NB, n - NB * i);
@@ -509,7 +515,7 @@ __global__ __launch_bounds__(256) void k_chol_df(DfView V, int n, int nT, const 
                         else {
                             const int rn = V.iperm[NB * i + r];
                             if (cn >= 0 && rn >= 0) v = rn >= cn ? V.S[(int64_t)cn * V.ldS + rn] : V.S[(int64_t)rn * V.ldS + cn];
-                            else v = (i == k && r == c) ? 1.0 : 0.0;      // padding rows: identity
+                            else v = (i == k && r == c && !(jb.mode & 8)) ? 1.0 : 0.0;      // padding rows: identity
                         }
                     } else v = Tik[(int64_t)c * V.ld + r];
                 }
@@ -636,6 +642,17 @@ __global__ __launch_bounds__(256) void k_chol_df(DfView V, int n, int nT, const 
             __syncthreads();                            // s_ok is rewritten in the next round
         }
         if (trace && t == 0) trace[task * 16 + 1] = wall_clock64();
+        if (jb.mode & 4) {                              // this rank's share of a top separator tile: T_r -> the tile, nothing else
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = 16 * ty + (tx >> 4) + 4 * e, r = 16 * rt + (tx & 15);
+                    if (r < nr && c < nc) Tik[(int64_t)c * V.ld + r] = -acc[rt][e];
+                }
+            __syncthreads();
+            continue;
+        }
         if (jb.mode == 1) {                             // sum only: T -> the tile; the diagonal task of the column finishes it
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt)
@@ -763,7 +780,7 @@ __global__ __launch_bounds__(256) void k_chol_df(DfView V, int n, int nT, const 
 // task counter / abort flag, "not solved yet" in q.
 __global__ void k_df_reset(int *__restrict__ info, int *__restrict__ ctl, unsigned long long *__restrict__ qflag, int nq) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) { *info = 0; ctl[0] = 0; ctl[1] = 0; }
+    if (i == 0) { *info = 0; ctl[0] = 0; ctl[1] = 0; ctl[2] = 0; }
     if (i < nq) qflag[i] = DF_SENTINEL;
 }
 
@@ -775,7 +792,7 @@ __global__ __launch_bounds__(256) void k_gather_tiles(const double *__restrict__
                                                       int *__restrict__ ctl, unsigned long long *__restrict__ qflag) {
     const DfTask tk = tile_ij[blockIdx.x];
     // what k_chol_df expects to find reset: error code, task counter / abort flag, "not solved yet" in q
-    if (blockIdx.x == 0 && threadIdx.x < 3) { if (threadIdx.x == 0) *info = 0; else ctl[threadIdx.x - 1] = 0; }
+    if (blockIdx.x == 0 && threadIdx.x < 4) { if (threadIdx.x == 0) *info = 0; else ctl[threadIdx.x - 1] = 0; }
     if (tk.i == tk.k && threadIdx.x < 64) qflag[64 * tk.k + threadIdx.x] = DF_SENTINEL;
     double *T = tiles + (size_t)blockIdx.x * 4096;
     for (int idx = threadIdx.x; idx < 4096; idx += 256) {
@@ -808,7 +825,14 @@ struct DataflowChol {
     int *d_flags = nullptr, *d_ctl = nullptr, *d_bk_ptr = nullptr, *d_bk_idx = nullptr, *d_iperm = nullptr;
     int64_t *d_toff = nullptr;
     uint64_t *d_rowbits = nullptr;
-    DfJob *d_tasks = nullptr;
+    DfJob *d_tasks = nullptr, *d_tasksB = nullptr;      // task list (one rank: everything; several: this rank's domain) / the top separators
+    int ntasksB = 0, nbk = 0;
+    int *d_bk_list = nullptr;                           // panels of the backward substitution in task order
+    uint64_t *d_rowbits_top = nullptr;                  // rowbits restricted to the top columns (second launch)
+    bool two_phase = false;                             // several ranks: domain + shares, all-reduce of the top tiles, top
+    int64_t top_tile0 = 0, n_top_tiles = 0;             // the tiles of the top columns are the last n_top_tiles of d_tiles
+    std::vector<double> sim_critical_us, sim_schedule_us;   // per task list: critical path / simulated list schedule (model, us)
+    std::vector<DfJob> h_tasksB;
     DfTask *d_tile_ij = nullptr;
     int nparts = 0;                                     // partial-sum slots of the helper tasks
     bool env_l2 = false, env_gather = false;            // DBAT_HIP_DF_L2 / DBAT_HIP_DF_GATHER, read at set-up
@@ -822,10 +846,12 @@ struct DataflowChol {
     size_t linv_doubles() const { return (size_t)std::max(nT, 1) * CHOL_NB * CHOL_NB; }
 
     void release() {
-        void *ps[] = {d_flags, d_ctl, d_bk_ptr, d_bk_idx, d_iperm, d_toff, d_rowbits, d_tasks, d_tile_ij, d_tiles, d_qperm, d_parts};
+        void *ps[] = {d_flags, d_ctl, d_bk_ptr, d_bk_idx, d_iperm, d_toff, d_rowbits, d_tasks, d_tile_ij, d_tiles, d_qperm, d_parts,
+                      d_tasksB, d_bk_list, d_rowbits_top};
         for (void *p : ps) if (p) (void)hipFree(p);
         d_flags = d_ctl = d_bk_ptr = d_bk_idx = d_iperm = nullptr; d_toff = nullptr; d_rowbits = nullptr;
         d_tasks = nullptr; d_tile_ij = nullptr; d_tiles = d_qperm = d_parts = nullptr;
+        d_tasksB = nullptr; d_bk_list = nullptr; d_rowbits_top = nullptr;
     }
     // per-task timestamps of the last solve (100 MHz ticks): task, i, k, t[0..15], jlo, jhi, mode per line
     void dump_trace(hipStream_t stream, const char *path) const {
@@ -853,52 +879,83 @@ struct DataflowChol {
     }
     // common part: nz[i] = bitset of columns k <= i with a structurally non-zero tile (i, k), i = 0..nT
     // (row nT = right-hand side, all columns), fill included
-    bool finish_setup(const std::vector<uint64_t> &rowbits, const std::vector<int64_t> &toff) {
+    // One task list (see DfJob).  PHASE 0: the whole factorisation (one rank).  Several ranks (col_owner: the
+    // rank whose domain a tile column belongs to, -1 = top separator / IO): PHASE 1 = the columns of this rank's
+    // domain and its share of every top tile (mode 4); PHASE 2 = the top columns, products over top columns only.
+    struct JobList { std::vector<DfJob> jobs; std::vector<int> dptr, dep, own, sumjob; };
+    void build_jobs(int phase, const std::vector<uint64_t> &rowbits, const std::vector<int> &col_owner, int rank, JobList &L) {
         auto has = [&](int i, int k) { return (rowbits[(size_t)i * W + (k >> 6)] >> (k & 63)) & 1ull; };
-        // ---- jobs, column-major (dependencies come earlier); long sums are cut into helpers
         const int split_min = getenv("DBAT_HIP_DF_SPLIT") ? std::max(atoi(getenv("DBAT_HIP_DF_SPLIT")), 2) : 96;
         const int chunk = getenv("DBAT_HIP_DF_CHUNK") ? std::max(atoi(getenv("DBAT_HIP_DF_CHUNK")), 1) : 32;
-        std::vector<DfJob> jobs;
-        std::vector<int> own((size_t)(nT + 1) * nT, -1);        // tile -> its owning job
-        std::vector<int> dptr(1, 0), dep;                       // per job: the two tiles of every product (ascending j)
-        std::vector<int> js;
-        nparts = 0; n_products = 0;
         const bool merge = permuted && !getenv("DBAT_HIP_DF_NOMERGE");     // compact tiles only (see k_chol_df)
-        std::vector<int> sumjob(nT, -1);                        // column -> the sum-only job of its first sub-diagonal tile
+        auto top = [&](int k) { return phase != 0 && col_owner[k] < 0; };
+        auto mine = [&](int k) { return phase == 0 || col_owner[k] == rank; };
+        int dom_lo = nT, dom_hi = 0;                            // this rank's domain: a contiguous range of tile columns
+        if (phase == 1) for (int k = 0; k < nT; ++k) if (col_owner[k] == rank) { dom_lo = std::min(dom_lo, k); dom_hi = k + 1; }
+        if (dom_hi <= dom_lo) dom_lo = dom_hi = 0;
+        L.jobs.clear(); L.dptr.assign(1, 0); L.dep.clear();
+        L.own.assign((size_t)(nT + 1) * nT, -1); L.sumjob.assign(nT, -1);
+        std::vector<int> js;
         for (int k = 0; k < nT; ++k) {
-            int par = -1;
-            if (merge) for (int i = k + 1; i <= nT && par < 0; ++i) if (has(i, k)) par = i;
-            auto emit = [&](int i) {
-                js.clear();
-                for (int j = 0; j < k; ++j) if (has(i, j) && has(k, j)) js.push_back(j);
+            // emit the job(s) of tile (i,k) with the products js; returns the owner job
+            auto emit = [&](int i, int mode, int par, int jhi_owner) {
                 n_products += (long long)js.size();
                 const int nj = (int)js.size();
                 const int nch = nj > split_min ? (nj + chunk - 1) / chunk : 1;
                 auto push_products = [&](int q0, int q1) {
-                    for (int q = q0; q < q1; ++q) { dep.push_back(own[(size_t)k * nT + js[q]]); dep.push_back(i != k ? own[(size_t)i * nT + js[q]] : -1); }
-                    dptr.push_back((int)dep.size());
+                    for (int q = q0; q < q1; ++q) { L.dep.push_back(L.own[(size_t)k * nT + js[q]]); L.dep.push_back(i != k ? L.own[(size_t)i * nT + js[q]] : -1); }
+                    L.dptr.push_back((int)L.dep.size());
                 };
                 for (int c = 0; c + 1 < nch; ++c) {             // helpers
-                    jobs.push_back(DfJob{i, k, js[chunk * c], js[chunk * (c + 1)], nparts + c, -1, 0, -1});
+                    L.jobs.push_back(DfJob{i, k, js[chunk * c], js[chunk * (c + 1)], nparts + c, -1, 0, -1});
                     push_products(chunk * c, chunk * (c + 1));
                 }
-                const int me = (int)jobs.size();
-                const int mode = i == par ? 1 : (i == k && par >= 0 ? 2 : 0);
-                jobs.push_back(DfJob{i, k, nch > 1 ? js[chunk * (nch - 1)] : 0, k, nparts, nch - 1, mode, i == k ? par : -1});
+                const int me = (int)L.jobs.size();
+                L.jobs.push_back(DfJob{i, k, nch > 1 ? js[chunk * (nch - 1)] : (nj ? js[0] : jhi_owner), jhi_owner, nparts, nch - 1, mode, i == k ? par : -1});   // (no products: an empty range)
                 push_products(chunk * (nch - 1), nj);
                 nparts += nch - 1;
                 return me;
             };
+            if (phase == 1 && top(k)) {                         // this rank's share of the top tiles of column k
+                for (int i = k; i <= nT; ++i) {
+                    if (!has(i, k)) continue;
+                    js.clear();
+                    for (int j = dom_lo; j < std::min(dom_hi, k); ++j) if (has(i, j) && has(k, j)) js.push_back(j);
+                    emit(i, rank == 0 ? 4 : 12, -1, std::min(dom_hi, k));
+                }
+                continue;
+            }
+            if (phase == 1 ? !mine(k) : (phase == 2 && !top(k))) continue;
+            auto products = [&](int i) {
+                js.clear();
+                for (int j = 0; j < k; ++j) if (has(i, j) && has(k, j) && (phase != 2 || top(j))) js.push_back(j);
+            };
+            int par = -1;
+            if (merge) for (int i = k + 1; i <= nT && par < 0; ++i) if (has(i, k)) par = i;
             // the sum-only task first: the diagonal task depends on it (job numbers stay topological)
-            if (par >= 0) sumjob[k] = emit(par);
-            own[(size_t)k * nT + k] = emit(k);
-            if (par >= 0) own[(size_t)par * nT + k] = own[(size_t)k * nT + k];      // L(par,k) is published by the diagonal task
+            if (par >= 0) { products(par); L.sumjob[k] = emit(par, 1, -1, k); }
+            products(k);
+            L.own[(size_t)k * nT + k] = emit(k, par >= 0 ? 2 : 0, par, k);
+            if (par >= 0) L.own[(size_t)par * nT + k] = L.own[(size_t)k * nT + k];      // L(par,k) is published by the diagonal task
             for (int i = k + 1; i <= nT; ++i)
-                if (has(i, k) && i != par) own[(size_t)i * nT + k] = emit(i);
+                if (has(i, k) && i != par) { products(i); L.own[(size_t)i * nT + k] = emit(i, 0, -1, k); }
         }
-        ntasks = (int)jobs.size();
+    }
+    // Task order = the order in which workgroups take them.  Any topological order is
+    // deadlock free (a dependency always has a smaller number, so it is owned by a running
+    // workgroup); column-major order, however, hands out ALL tiles of the first blocks of
+    // the dissection before the first tile of the others, and the few hundred resident
+    // workgroups then sit in the dependent chains of a few leaves while the other leaves
+    // have not started.  Candidate orders are tried on a model of the kernel (measured
+    // costs, us: bench/chol_trace.py, bench/chol_path.py) and the best one is taken.
+    void order_jobs(JobList &L, const char *what) {
+        std::vector<DfJob> &jobs = L.jobs;
+        const std::vector<int> &dptr = L.dptr, &dep = L.dep, &own = L.own, &sumjob = L.sumjob;
+        const int nt = (int)jobs.size();
+        if (nt == 0 || getenv("DBAT_HIP_DF_COLMAJOR")) return;
         auto is_helper = [&](int t) { return jobs[t].np < 0; };
-        auto is_diag = [&](int t) { return jobs[t].np >= 0 && jobs[t].i == jobs[t].k; };
+        auto is_share = [&](int t) { return (jobs[t].mode & 4) != 0; };
+        auto is_diag = [&](int t) { return jobs[t].np >= 0 && jobs[t].i == jobs[t].k && !is_share(t); };
         auto nprod_of = [&](int t) { return (dptr[t + 1] - dptr[t]) / 2; };
         // every dependency of job t: product tiles, its helpers (the np jobs right before it), the diagonal tile
         auto for_deps = [&](int t, const std::function<void(int)> &f) {
@@ -909,124 +966,152 @@ struct DataflowChol {
                 if (jobs[t].mode == 2) f(sumjob[jobs[t].k]);
             }
         };
-        if (!getenv("DBAT_HIP_DF_COLMAJOR")) {
-            // Task order = the order in which workgroups take them.  Any topological order is
-            // deadlock free (a dependency always has a smaller number, so it is owned by a running
-            // workgroup); column-major order, however, hands out ALL tiles of the first blocks of
-            // the dissection before the first tile of the others, and the few hundred resident
-            // workgroups then sit in the dependent chains of a few leaves while the other leaves
-            // have not started.  Candidate orders are tried on a model of the kernel (measured
-            // costs, us: bench/chol_trace.py, bench/chol_path.py) and the best one is taken.
-            const double c_prod = 2.5, c_diag = 13.5, c_off = 4.5, c_hop = 2.0, c_add = 1.5, c_help = 2.0;
-            auto tail_of = [&](int t) { return is_helper(t) || jobs[t].mode == 1 ? c_help : (is_diag(t) ? c_diag + (jobs[t].mode == 2 ? 2.5 : 0.0) : c_off); };
-            // (1) earliest start: every input the moment it exists, unlimited workgroups
-            std::vector<double> est(ntasks, 0.0), fin(ntasks, 0.0);
-            for (int t = 0; t < ntasks; ++t) {
-                double e = 0.0;
-                for_deps(t, [&](int d) { e = std::max(e, fin[d]); });
-                est[t] = e;
-                fin[t] = e + c_hop + (nprod_of(t) ? c_prod : 0.0) + tail_of(t);
-            }
-            // (2) bottom level: the longest way from a task to the end of the factorisation
-            std::vector<double> blev(ntasks, 0.0);
-            for (int t = ntasks - 1; t >= 0; --t) {
-                blev[t] += c_hop + c_prod + tail_of(t);
-                for_deps(t, [&](int d) { blev[d] = std::max(blev[d], blev[t]); });
-            }
-            // The kernel as a list schedule: `workers` resident workgroups take the tasks in order; a
-            // workgroup consumes its inputs in its fixed order, every product after both tiles exist.
-            const int workers = std::max(1, std::min(grid, 256));      // 400 registers per lane: one workgroup per CU
-            auto simulate = [&](const std::vector<int> &ord) {
-                std::vector<double> done(ntasks, 0.0);
-                std::priority_queue<double, std::vector<double>, std::greater<double>> freeat;
-                for (int w = 0; w < workers; ++w) freeat.push(0.0);
-                double last = 0.0;
-                for (int t : ord) {
-                    double tc = freeat.top(); freeat.pop();
-                    for (int q = dptr[t]; q + 1 < dptr[t + 1]; q += 2) {
-                        double av = done[dep[q]];
-                        if (dep[q + 1] >= 0) av = std::max(av, done[dep[q + 1]]);
-                        tc = std::max(tc, av + c_hop) + c_prod;
-                    }
-                    if (!is_helper(t)) {
-                        for (int h = jobs[t].np; h >= 1; --h) tc = std::max(tc, done[t - h] + c_hop) + c_add;
-                        if (jobs[t].mode == 0 && jobs[t].i != jobs[t].k) tc = std::max(tc, done[own[(size_t)jobs[t].k * nT + jobs[t].k]] + c_hop);
-                        if (jobs[t].mode == 2) tc = std::max(tc, done[sumjob[jobs[t].k]] + c_hop - c_diag);    // T is only wanted after the factorisation
-                    }
-                    tc += tail_of(t);
-                    done[t] = tc; last = std::max(last, tc);
-                    freeat.push(tc);
-                }
-                return last;
-            };
-            // Candidates, all topological (Kahn's algorithm: a task is eligible once its dependencies are
-            // placed; among the eligible ones the smallest key goes first).  Keys: earliest start minus
-            // beta x bottom level -- beta = 0: in the order the inputs appear; large beta: critical path
-            // first -- and earliest start minus the task's own serial work (long sums get their
-            // workgroup early).  The model ranks them; the best simulated one is taken.
-            std::vector<int> indeg0(ntasks, 0), sptr(ntasks + 1, 0), succ;
-            for (int t = 0; t < ntasks; ++t) for_deps(t, [&](int d) { ++indeg0[t]; ++sptr[d + 1]; });
-            for (int t = 0; t < ntasks; ++t) sptr[t + 1] += sptr[t];
-            succ.resize(sptr[ntasks]);
-            {
-                std::vector<int> fill(sptr.begin(), sptr.end() - 1);
-                for (int t = 0; t < ntasks; ++t) for_deps(t, [&](int d) { succ[fill[d]++] = t; });
-            }
-            auto kahn = [&](const std::vector<double> &key) {
-                std::vector<int> ord(ntasks), indeg(indeg0);
-                typedef std::pair<double, int> KI;
-                std::priority_queue<KI, std::vector<KI>, std::greater<KI>> pq;
-                for (int t = 0; t < ntasks; ++t) if (!indeg[t]) pq.push(KI(key[t], t));
-                size_t n_out = 0;
-                while (!pq.empty()) {
-                    const int t = pq.top().second; pq.pop();
-                    ord[n_out++] = t;
-                    for (int q = sptr[t]; q < sptr[t + 1]; ++q) if (--indeg[succ[q]] == 0) pq.push(KI(key[succ[q]], succ[q]));
-                }
-                return ord;
-            };
-            const double betas[] = {0.0, 0.25, 0.5, 1.0, 2.0, 4.0, 1e6};
-            const int ncand = (int)(sizeof(betas) / sizeof(betas[0])) + 1;
-            std::vector<int> best_ord;
-            double tbest = 1e300;
-            int best = -1;
-            std::vector<double> key(ntasks), tcs(ncand);
-            const int forced = getenv("DBAT_HIP_DF_ORDER") ? atoi(getenv("DBAT_HIP_DF_ORDER")) : -1;
-            for (int c = 0; c < ncand; ++c) {
-                if (c + 1 < ncand) for (int t = 0; t < ntasks; ++t) key[t] = est[t] - betas[c] * blev[t];
-                else for (int t = 0; t < ntasks; ++t) key[t] = est[t] - c_prod * nprod_of(t);
-                std::vector<int> ord = kahn(key);
-                tcs[c] = simulate(ord);
-                if (forced == c || (forced < 0 && tcs[c] < tbest)) { tbest = tcs[c]; best = c; best_ord.swap(ord); }
-            }
-            if (getenv("DBAT_HIP_PLAN_STATS")) {
-                double cp = 0.0;
-                for (int t = 0; t < ntasks; ++t) cp = std::max(cp, fin[t]);
-                fprintf(stderr, "[chol] %d tasks (%d helpers of long sums), %lld products, critical path %.0f us; simulated with %d workgroups, key = earliest start - beta x bottom level:",
-                        ntasks, nparts, n_products, cp, workers);
-                for (int c = 0; c + 1 < ncand; ++c) fprintf(stderr, " beta %g: %.0f us,", betas[c], tcs[c]);
-                fprintf(stderr, " earliest start - own work: %.0f us -> candidate %d\n", tcs[ncand - 1], best);
-            }
-            // a final task addresses its helpers by slot, not by position: any topological order will do
-            std::vector<DfJob> sorted(ntasks);
-            for (int t = 0; t < ntasks; ++t) sorted[t] = jobs[best_ord[t]];
-            jobs.swap(sorted);
+        const double c_prod = 2.5, c_diag = 13.5, c_off = 4.5, c_hop = 2.0, c_add = 1.5, c_help = 2.0;
+        auto tail_of = [&](int t) { return is_helper(t) || is_share(t) || jobs[t].mode == 1 ? c_help : (is_diag(t) ? c_diag + (jobs[t].mode == 2 ? 2.5 : 0.0) : c_off); };
+        // (1) earliest start: every input the moment it exists, unlimited workgroups
+        std::vector<double> est(nt, 0.0), fin(nt, 0.0);
+        for (int t = 0; t < nt; ++t) {
+            double e = 0.0;
+            for_deps(t, [&](int d) { e = std::max(e, fin[d]); });
+            est[t] = e;
+            fin[t] = e + c_hop + (nprod_of(t) ? c_prod : 0.0) + tail_of(t);
         }
-        h_tasks = jobs;
-        if (getenv("DBAT_HIP_DF_TRACE") && hipMalloc(&d_trace, (size_t)(ntasks + nT) * 16 * sizeof(long long)) != hipSuccess) d_trace = nullptr;
+        // (2) bottom level: the longest way from a task to the end of the factorisation
+        std::vector<double> blev(nt, 0.0);
+        for (int t = nt - 1; t >= 0; --t) {
+            blev[t] += c_hop + c_prod + tail_of(t);
+            for_deps(t, [&](int d) { blev[d] = std::max(blev[d], blev[t]); });
+        }
+        // The kernel as a list schedule: `workers` resident workgroups take the tasks in order; a
+        // workgroup consumes its inputs in its fixed order, every product after both tiles exist.
+        const int workers = std::max(1, std::min(grid, 256));      // 400 registers per lane: one workgroup per CU
+        auto simulate = [&](const std::vector<int> &ord) {
+            std::vector<double> done(nt, 0.0);
+            std::priority_queue<double, std::vector<double>, std::greater<double>> freeat;
+            for (int w = 0; w < workers; ++w) freeat.push(0.0);
+            double last = 0.0;
+            for (int t : ord) {
+                double tc = freeat.top(); freeat.pop();
+                for (int q = dptr[t]; q + 1 < dptr[t + 1]; q += 2) {
+                    double av = done[dep[q]];
+                    if (dep[q + 1] >= 0) av = std::max(av, done[dep[q + 1]]);
+                    tc = std::max(tc, av + c_hop) + c_prod;
+                }
+                if (!is_helper(t)) {
+                    for (int h = jobs[t].np; h >= 1; --h) tc = std::max(tc, done[t - h] + c_hop) + c_add;
+                    if (jobs[t].mode == 0 && jobs[t].i != jobs[t].k) tc = std::max(tc, done[own[(size_t)jobs[t].k * nT + jobs[t].k]] + c_hop);
+                    if (jobs[t].mode == 2) tc = std::max(tc, done[sumjob[jobs[t].k]] + c_hop - c_diag);    // T is only wanted after the factorisation
+                }
+                tc += tail_of(t);
+                done[t] = tc; last = std::max(last, tc);
+                freeat.push(tc);
+            }
+            return last;
+        };
+        // Candidates, all topological (Kahn's algorithm: a task is eligible once its dependencies are
+        // placed; among the eligible ones the smallest key goes first).  Keys: earliest start minus
+        // beta x bottom level -- beta = 0: in the order the inputs appear; large beta: critical path
+        // first -- and earliest start minus the task's own serial work (long sums get their
+        // workgroup early).  The model ranks them; the best simulated one is taken.
+        std::vector<int> indeg0(nt, 0), sptr(nt + 1, 0), succ;
+        for (int t = 0; t < nt; ++t) for_deps(t, [&](int d) { ++indeg0[t]; ++sptr[d + 1]; });
+        for (int t = 0; t < nt; ++t) sptr[t + 1] += sptr[t];
+        succ.resize(sptr[nt]);
+        {
+            std::vector<int> fill(sptr.begin(), sptr.end() - 1);
+            for (int t = 0; t < nt; ++t) for_deps(t, [&](int d) { succ[fill[d]++] = t; });
+        }
+        auto kahn = [&](const std::vector<double> &key) {
+            std::vector<int> ord(nt), indeg(indeg0);
+            typedef std::pair<double, int> KI;
+            std::priority_queue<KI, std::vector<KI>, std::greater<KI>> pq;
+            for (int t = 0; t < nt; ++t) if (!indeg[t]) pq.push(KI(key[t], t));
+            size_t n_out = 0;
+            while (!pq.empty()) {
+                const int t = pq.top().second; pq.pop();
+                ord[n_out++] = t;
+                for (int q = sptr[t]; q < sptr[t + 1]; ++q) if (--indeg[succ[q]] == 0) pq.push(KI(key[succ[q]], succ[q]));
+            }
+            return ord;
+        };
+        const double betas[] = {0.0, 0.25, 0.5, 1.0, 2.0, 4.0, 1e6};
+        const int ncand = (int)(sizeof(betas) / sizeof(betas[0])) + 1;
+        std::vector<int> best_ord;
+        double tbest = 1e300;
+        int best = -1;
+        std::vector<double> key(nt), tcs(ncand);
+        const int forced = getenv("DBAT_HIP_DF_ORDER") ? atoi(getenv("DBAT_HIP_DF_ORDER")) : -1;
+        for (int c = 0; c < ncand; ++c) {
+            if (c + 1 < ncand) for (int t = 0; t < nt; ++t) key[t] = est[t] - betas[c] * blev[t];
+            else for (int t = 0; t < nt; ++t) key[t] = est[t] - c_prod * nprod_of(t);
+            std::vector<int> ord = kahn(key);
+            tcs[c] = simulate(ord);
+            if (forced == c || (forced < 0 && tcs[c] < tbest)) { tbest = tcs[c]; best = c; best_ord.swap(ord); }
+        }
+        double cp = 0.0;
+        for (int t = 0; t < nt; ++t) cp = std::max(cp, fin[t]);
+        sim_critical_us.push_back(cp); sim_schedule_us.push_back(tbest);
+        if (getenv("DBAT_HIP_PLAN_STATS")) {
+            fprintf(stderr, "[chol %s] %d tasks, critical path %.0f us; simulated with %d workgroups, key = earliest start - beta x bottom level:",
+                    what, nt, cp, workers);
+            for (int c = 0; c + 1 < ncand; ++c) fprintf(stderr, " beta %g: %.0f us,", betas[c], tcs[c]);
+            fprintf(stderr, " earliest start - own work: %.0f us -> candidate %d\n", tcs[ncand - 1], best);
+        }
+        // a final task addresses its helpers by slot, not by position: any topological order will do
+        std::vector<DfJob> sorted(nt);
+        for (int t = 0; t < nt; ++t) sorted[t] = jobs[best_ord[t]];
+        jobs.swap(sorted);
+    }
+    // common part: nz[i] = bitset of columns k <= i with a structurally non-zero tile (i, k), i = 0..nT
+    // (row nT = right-hand side, all columns), fill included.  col_owner (empty: one rank): see build_jobs.
+    bool finish_setup(const std::vector<uint64_t> &rowbits, const std::vector<int64_t> &toff,
+                      const std::vector<int> &col_owner = std::vector<int>(), int rank = 0) {
+        auto has = [&](int i, int k) { return (rowbits[(size_t)i * W + (k >> 6)] >> (k & 63)) & 1ull; };
+        if (const char *g = getenv("DBAT_HIP_DF_GRID")) grid = std::min(std::max(atoi(g), 1), 4096);
+        nparts = 0; n_products = 0;
+        two_phase = !col_owner.empty();
+        sim_critical_us.clear(); sim_schedule_us.clear();
+        JobList L;
+        std::vector<int> bkl;                                   // panels of the backward substitution, in task order
+        std::vector<uint64_t> rowbits_top;
+        if (!two_phase) {
+            build_jobs(0, rowbits, col_owner, rank, L);
+            order_jobs(L, "all");
+            h_tasks = L.jobs; ntasks = (int)L.jobs.size();
+            for (int j = nT - 1; j >= 0; --j) bkl.push_back(j);
+        } else {
+            build_jobs(1, rowbits, col_owner, rank, L);
+            order_jobs(L, "domain");
+            h_tasks = L.jobs; ntasks = (int)L.jobs.size();
+            JobList B;
+            build_jobs(2, rowbits, col_owner, rank, B);
+            order_jobs(B, "top");
+            h_tasksB = B.jobs; ntasksB = (int)B.jobs.size();
+            if (!up(d_tasksB, h_tasksB)) return false;
+            // the top columns first (every rank), then this rank's domain: a dependency always has a smaller number
+            for (int j = nT - 1; j >= 0; --j) if (col_owner[j] < 0) bkl.push_back(j);
+            for (int j = nT - 1; j >= 0; --j) if (col_owner[j] == rank) bkl.push_back(j);
+            rowbits_top = rowbits;                              // the products of the second launch: top columns only
+            for (int i = 0; i <= nT; ++i)
+                for (int k = 0; k < nT; ++k)
+                    if (col_owner[k] >= 0) rowbits_top[(size_t)i * W + (k >> 6)] &= ~(1ull << (k & 63));
+            if (!up(d_rowbits_top, rowbits_top)) return false;
+        }
+        nbk = (int)bkl.size();
+        if (getenv("DBAT_HIP_DF_TRACE") && !two_phase && hipMalloc(&d_trace, (size_t)(ntasks + nT) * 16 * sizeof(long long)) != hipSuccess) d_trace = nullptr;
         std::vector<int> bptr(nT + 1, 0), bidx;
         for (int j = 0; j < nT; ++j) {
             for (int i = nT - 1; i > j; --i)
                 if (has(i, j)) bidx.push_back(i);
             bptr[j + 1] = (int)bidx.size();
         }
-        if (!up(d_tasks, jobs) || !up(d_bk_ptr, bptr) || !up(d_bk_idx, bidx) || !up(d_rowbits, rowbits) || !up(d_toff, toff))
+        if (!up(d_tasks, h_tasks) || !up(d_bk_ptr, bptr) || !up(d_bk_idx, bidx) || !up(d_rowbits, rowbits) || !up(d_toff, toff) || !up(d_bk_list, bkl))
             return false;
         if (hipMalloc(&d_flags, ((size_t)(nT + 1) * nT + (size_t)nparts + (size_t)nT) * sizeof(int)) != hipSuccess) return false;   // tiles, helper slots, T of the sum-only tasks
         if (nparts > 0 && hipMalloc(&d_parts, (size_t)nparts * 4096 * sizeof(double)) != hipSuccess) return false;
-        if (hipMalloc(&d_ctl, 2 * sizeof(int)) != hipSuccess) return false;
+        if (hipMalloc(&d_ctl, 4 * sizeof(int)) != hipSuccess) return false;
         (void)hipMemset(d_flags, 0, ((size_t)(nT + 1) * nT + (size_t)nparts + (size_t)nT) * sizeof(int));
-        if (const char *g = getenv("DBAT_HIP_DF_GRID")) grid = std::min(std::max(atoi(g), 1), 4096);
+        (void)hipMemset(d_ctl, 0, 4 * sizeof(int));
         env_l2 = getenv("DBAT_HIP_DF_L2") != nullptr; env_gather = getenv("DBAT_HIP_DF_GATHER") != nullptr;
         epoch = 0;
         return true;
@@ -1047,54 +1132,13 @@ struct DataflowChol {
         return finish_setup(rb, toff);
     }
     // adj: symmetric co-visibility bitsets of the nc cameras (adj_words 64-bit words per camera);
-    // xyz: 3 coordinates per camera (projection centres) for the geometric bisection;
-    // unknowns: 6 per camera, then nio dense IO unknowns.
-    bool setup_permuted(int nc, int nio, const uint64_t *adj, int adj_words, const double *xyz) {
+    // nd: the nested-dissection order of the cameras (nd.hpp; with nd.nparts > 1 its blocks carry the rank
+    // that owns them); unknowns: 6 per camera, then nio dense IO unknowns.
+    bool setup_permuted(int nc, int nio, const uint64_t *adj, int adj_words, const NdTree &nd, int rank) {
         release();
         permuted = true;
         n_nat = 6 * nc + nio;
-        auto adjacent = [&](int a, int b) { return (adj[(size_t)a * adj_words + (b >> 6)] >> (b & 63)) & 1ull; };
-        // ---- nested dissection by recursive coordinate bisection; separator = the cameras of the
-        // lower half that see a camera of the upper half
-        std::vector<int> order; order.reserve(nc);
-        std::vector<int> block_end;                     // order.size() after every leaf / separator block
-        const int leaf = std::max(8, getenv("DBAT_HIP_ND_LEAF") ? atoi(getenv("DBAT_HIP_ND_LEAF")) : 32);
-        std::function<void(std::vector<int> &)> nd = [&](std::vector<int> &cams) {
-            if ((int)cams.size() <= leaf) {
-                std::sort(cams.begin(), cams.end());
-                for (int c : cams) order.push_back(c);
-                block_end.push_back((int)order.size());
-                return;
-            }
-            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-            for (int c : cams) for (int d = 0; d < 3; ++d) { lo[d] = std::min(lo[d], xyz[3 * c + d]); hi[d] = std::max(hi[d], xyz[3 * c + d]); }
-            int ax = 0;
-            for (int d = 1; d < 3; ++d) if (hi[d] - lo[d] > hi[ax] - lo[ax]) ax = d;
-            std::vector<int> s(cams);
-            std::stable_sort(s.begin(), s.end(), [&](int a, int b) { return xyz[3 * a + ax] < xyz[3 * b + ax]; });
-            const size_t half = s.size() / 2;
-            std::vector<int> A(s.begin(), s.begin() + half), B(s.begin() + half, s.end()), Sep, A2;
-            for (int a : A) {
-                bool touch = false;
-                for (int b : B) if (adjacent(a, b)) { touch = true; break; }
-                (touch ? Sep : A2).push_back(a);
-            }
-            if (Sep.size() * 2 >= cams.size() || A2.empty()) {     // no useful separator: one dense block
-                std::sort(cams.begin(), cams.end());
-                for (int c : cams) order.push_back(c);
-                block_end.push_back((int)order.size());
-                return;
-            }
-            nd(A2); nd(B);
-            std::sort(Sep.begin(), Sep.end());
-            for (int c : Sep) order.push_back(c);
-            if (!Sep.empty()) block_end.push_back((int)order.size());
-        };
-        {
-            std::vector<int> all(nc);
-            for (int c = 0; c < nc; ++c) all[c] = c;
-            if (getenv("DBAT_HIP_ND_OFF")) { order = all; block_end.push_back(nc); } else nd(all);
-        }
+        const std::vector<int> &order = nd.order, &block_end = nd.block_end;
         // every block starts on a tile boundary (padding rows = identity): otherwise the tile that
         // straddles two independent blocks chains them together
         std::vector<int> rowpos(nc);                    // first row of every camera in the factorised order
@@ -1148,16 +1192,35 @@ struct DataflowChol {
                         if (rows[b] < nT) setbit(rows[a], rows[b]);
             }
         }
-        // ---- compact tile storage, column-major over the pattern
+        // ---- several ranks: the rank that owns every tile column (a block starts on a tile boundary, so a tile
+        // column lies in one block); -1: top separator, IO unknowns
+        std::vector<int> col_owner;
+        if (nd.nparts > 1) {
+            col_owner.assign(nT, -1);
+            size_t b = 0;
+            for (int q = 0; q < nc; ++q) {
+                while (b < block_end.size() && block_end[b] <= q) ++b;
+                const int ow = b < nd.block_owner.size() ? nd.block_owner[b] : -1;
+                for (int t = rowpos[order[q]] / CHOL_NB; t <= (rowpos[order[q]] + 5) / CHOL_NB; ++t) col_owner[t] = ow;
+            }
+        }
+        // ---- compact tile storage, column-major over the pattern; the tiles of the top columns last and
+        // contiguous (what the ranks sum between the two launches)
         std::vector<int64_t> toff((size_t)(nT + 1) * nT, -1);
         std::vector<DfTask> tile_ij;
-        for (int k = 0; k < nT; ++k)
-            for (int i = k; i <= nT; ++i)
-                if ((rb[(size_t)i * W + (k >> 6)] >> (k & 63)) & 1ull) {
-                    toff[(size_t)i * nT + k] = (int64_t)tile_ij.size() * 4096;
-                    tile_ij.push_back(DfTask{i, k});
-                }
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1) top_tile0 = (int64_t)tile_ij.size();
+            for (int k = 0; k < nT; ++k) {
+                if ((!col_owner.empty() && col_owner[k] < 0) != (pass == 1)) continue;
+                for (int i = k; i <= nT; ++i)
+                    if ((rb[(size_t)i * W + (k >> 6)] >> (k & 63)) & 1ull) {
+                        toff[(size_t)i * nT + k] = (int64_t)tile_ij.size() * 4096;
+                        tile_ij.push_back(DfTask{i, k});
+                    }
+            }
+        }
         ntiles = (int)tile_ij.size();
+        n_top_tiles = ntiles - top_tile0;
         if (!up(d_tile_ij, tile_ij) || !up(d_iperm, iperm)) return false;
         if (hipMalloc(&d_tiles, (size_t)ntiles * 4096 * sizeof(double)) != hipSuccess) return false;
         (void)hipMemset(d_tiles, 0, (size_t)ntiles * 4096 * sizeof(double));     // right-hand-side tiles: only their first row is ever written
@@ -1171,7 +1234,13 @@ struct DataflowChol {
                 fprintf(stderr, " %d", block_end[b] - (b ? block_end[b - 1] : 0));
             fprintf(stderr, "\n");
         }
-        return finish_setup(rb, toff);
+        if (getenv("DBAT_HIP_PLAN_STATS") && !col_owner.empty()) {
+            int ntop = 0, nmine = 0;
+            for (int k = 0; k < nT; ++k) { ntop += col_owner[k] < 0; nmine += col_owner[k] == rank; }
+            fprintf(stderr, "[chol] rank %d of %d: %d tile columns in its domain, %d top columns, %lld top tiles (%.1f MB summed over the ranks per factorisation)\n",
+                    rank, nd.nparts, nmine, ntop, (long long)n_top_tiles, n_top_tiles * 32768.0 / 1e6);
+        }
+        return finish_setup(rb, toff, col_owner, rank);
     }
     // Factor and solve S q = b (b' in row n of S, lower triangle of S, leading dimension lda).
     // q -> q_out (natural order).  In-place mode leaves L in S; permuted mode leaves S untouched.
@@ -1198,13 +1267,42 @@ struct DataflowChol {
             V.base = d_tiles; V.ld = 64; V.iperm = d_iperm; qflag = d_qperm;
         } else {
             (void)hipMemsetAsync(info_dev, 0, sizeof(int), stream);
-            (void)hipMemsetAsync(d_ctl, 0, 2 * sizeof(int), stream);
+            (void)hipMemsetAsync(d_ctl, 0, 4 * sizeof(int), stream);
             V.base = A; V.ld = lda; V.iperm = nullptr; qflag = q_out;
             (void)hipMemsetAsync(q_out, 0xFF, (size_t)n * sizeof(double), stream);
         }
         hipLaunchKernelGGL(k_chol_df, dim3(std::min(grid, ntasks + nT)), dim3(256), 0, stream, V, n, nT, d_tasks, ntasks,
                            d_flags, d_ctl, epoch, linv_work, info_dev, d_trace, d_bk_ptr, d_bk_idx, qflag, q_out, ldiag,
-                           qscale, dz_out, d_parts, nparts);
+                           qscale, dz_out, d_parts, nparts, d_bk_list, nbk, 0);
+    }
+    // ---- several ranks (two_phase), permuted layout only.  solve_domain: this rank factors the columns of its
+    // own domain from ITS S (complete there: nd.hpp) and leaves its share of every top tile -- A_r minus the
+    // domain's updates -- in the tile; the caller sums the top tiles over the ranks (top_tiles(), one
+    // all-reduce); solve_top: every rank factors the top separators from the sums and runs the backward
+    // substitution for the top and for its own domain.  The steps of the other domains' cameras are not
+    // computed here (their dz entries are left alone): no observation of this rank refers to them.
+    double *top_tiles() const { return d_tiles + top_tile0 * 4096; }
+    int64_t top_tiles_count() const { return n_top_tiles * 4096; }
+    void solve_domain(hipStream_t stream, double *A, int64_t lda, double *linv_work, int *info_dev, double *ldiag) {
+        ++epoch;
+        DfView V;
+        V.toff = d_toff; V.rowbits = d_rowbits; V.W = W; V.no_l2 = 1;
+        V.ldS = lda; V.n_nat = n_nat; V.base = d_tiles; V.ld = 64; V.iperm = d_iperm; V.S = A;
+        hipLaunchKernelGGL(k_df_reset, dim3((nT * CHOL_NB + 255) / 256), dim3(256), 0, stream, info_dev, d_ctl,
+                           reinterpret_cast<unsigned long long *>(d_qperm), nT * CHOL_NB);
+        if (ntasks > 0)
+            hipLaunchKernelGGL(k_chol_df, dim3(std::min(grid, ntasks)), dim3(256), 0, stream, V, n, nT, d_tasks, ntasks,
+                               d_flags, d_ctl, epoch, linv_work, info_dev, (long long *)nullptr, d_bk_ptr, d_bk_idx, (double *)nullptr,
+                               (double *)nullptr, ldiag, (const double *)nullptr, (double *)nullptr, d_parts, nparts, d_bk_list, 0, 0);
+    }
+    void solve_top(hipStream_t stream, int64_t lda, double *q_out, double *linv_work, int *info_dev, double *ldiag,
+                   const double *qscale, double *dz_out) {
+        DfView V;
+        V.toff = d_toff; V.rowbits = d_rowbits_top; V.W = W; V.no_l2 = 1;
+        V.ldS = lda; V.n_nat = n_nat; V.base = d_tiles; V.ld = 64; V.iperm = d_iperm; V.S = nullptr;   // the tiles hold the summed shares
+        hipLaunchKernelGGL(k_chol_df, dim3(std::min(grid, ntasksB + nbk)), dim3(256), 0, stream, V, n, nT, d_tasksB, ntasksB,
+                           d_flags, d_ctl, epoch, linv_work, info_dev, (long long *)nullptr, d_bk_ptr, d_bk_idx, d_qperm, q_out, ldiag,
+                           qscale, dz_out, d_parts, nparts, d_bk_list, nbk, 2);
     }
 };
 

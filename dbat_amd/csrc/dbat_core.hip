@@ -92,7 +92,7 @@ struct Core {
     // build sums, [40..47] pivots / info, [48..51] the pivot reset pattern
     double *hpin = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t kev[8] = {};      // per-kernel brackets, recorded only while timing is on
+    hipEvent_t kev[10] = {};     // per-kernel brackets, recorded only while timing is on ([8], [9]: the all-reduce of the top tiles)
     bool timing = false;
     // static problem data
     DevBuf<int32_t> cam_ncol, cam_col, cam_iorow, io_src, o_cam, o_pt;
@@ -137,6 +137,8 @@ struct Core {
     DataflowChol dfchol;                // persistent task-graph Cholesky, cameras in nested-dissection order (chol_df.hpp)
     DataflowChol dfchol_ip;             // the same in place, natural order (posterior covariance: L must end up in S)
     bool use_df = true, use_perm = true;
+    bool mg_subtree = false;            // several ranks, domain sharding (nd.hpp): local factorisation + all-reduce of the top tiles
+    DevBuf<uint8_t> piv_have;           // ... pivots of the reduced system that this rank computes
     bool chol_in_place = false;         // next factorisation must leave L in S
     int64_t ldS = 0;
     CholEnvelope env;
@@ -274,14 +276,16 @@ struct Core {
             use_perm = use_df && getenv("DBAT_HIP_DF_NOPERM") == nullptr && !P.shared_eo;
             if (!dfchol_ip.setup_inplace(env, ldS)) throw DeviceError{"out of device memory (Cholesky schedule)"};
             if (use_perm) {
-                std::vector<double> xyz((size_t)3 * P.nc);
-                for (int c = 0; c < P.nc; ++c)
-                    for (int k = 0; k < 3; ++k) {
-                        const double v = P.z0[(size_t)6 * c + k];
-                        xyz[(size_t)3 * c + k] = std::isfinite(v) ? v : 0.0;      // only steers the bisection
-                    }
-                if (!dfchol.setup_permuted(P.nc, P.nIOu, P.cam_adj.data(), P.cam_adj_words, xyz.data()))
+                if (!dfchol.setup_permuted(P.nc, P.nIOu, P.cam_adj.data(), P.cam_adj_words, P.nd, P.rank))
                     throw DeviceError{"out of device memory (Cholesky schedule)"};
+            }
+            mg_subtree = P.mg_subtree && use_perm && dfchol.two_phase;
+            if (mg_subtree) {     // pivots this rank computes: its own domain's and the (replicated) top separators' / IO
+                std::vector<uint8_t> have((size_t)P.NS, 0);
+                for (int c = 0; c < P.nc; ++c)
+                    if (P.nd.cam_owner[c] < 0 || P.nd.cam_owner[c] == P.rank) for (int k = 0; k < 6; ++k) have[(size_t)6 * c + k] = 1;
+                for (int64_t z = 6 * (int64_t)P.nc; z < P.NS; ++z) have[z] = 1;
+                piv_have.upload(have);
             }
             linv.alloc(std::max({BlockChol::linv_doubles((int)P.NS), dfchol_ip.linv_doubles(),
                                  use_perm ? dfchol.linv_doubles() : (size_t)0}));
@@ -294,8 +298,8 @@ struct Core {
         grid_obs = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(nobs, 256), env_grid_obs()));
         grid_z = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(P.NZ, 256), 2048));
         grid_zs = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(P.NZ, 2048), 256));
-        scal.alloc((size_t)16 + 2 * (size_t)P.nranks);
-        HIPCHK(hipMemset(scal.p, 0, ((size_t)16 + 2 * (size_t)P.nranks) * sizeof(double)));   // unused slots travel through the all-reduce
+        scal.alloc((size_t)16 + 4 * (size_t)P.nranks);
+        HIPCHK(hipMemset(scal.p, 0, ((size_t)16 + 4 * (size_t)P.nranks) * sizeof(double)));   // unused slots travel through the all-reduce
         info.alloc(1);
         pivmm.alloc(4);
         gctr.alloc(16); HIPCHK(hipMemset(gctr.p, 0, 16 * sizeof(unsigned)));
@@ -365,14 +369,16 @@ struct Core {
     void sync() {
         // The kernel that ends a phase writes this wait's ticket into the mailbox after its results: spin on
         // it (a few microseconds after the kernel's last store) instead of sleeping in
-        // hipStreamSynchronize; after 2 ms without the ticket fall back to the driver's wait (a step that
-        // long does not notice the driver's wake-up latency).  A ticket hit skips the driver's wait, so
+        // hipStreamSynchronize; after 20 ms without the ticket fall back to the driver's wait (a wait that
+        // long does not notice the driver's wake-up latency; the bound must cover a whole enqueued LM step --
+        // 1.9 ms at C3, 15 ms at C4 -- because the host runs ahead of the stream: with 2 ms the C3 step
+        // measured 2.32 instead of 1.88 ms).  A ticket hit skips the driver's wait, so
         // asynchronous device errors surface at the next real synchronisation: every ABI call that returns
         // results ends in one (z_to_x / read_scal).
         bool done = false;
         if (mb_armed) {
             volatile unsigned long long *slot = reinterpret_cast<volatile unsigned long long *>(hpin) + 63;
-            const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+            const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
             for (;;) {
                 for (int spin = 0; spin < 512 && !done; ++spin) { done = *slot == mb_seq; if (!done) cpu_relax(); }
                 if (done || std::chrono::steady_clock::now() >= t_end) break;
@@ -585,10 +591,22 @@ struct Core {
     }
     // lazy: do not wait for the linearisation's scalars (f_lin, trace_jtj): the next sync() of any kind
     // picks them up.  The damping loops only need them after their first linearisation.
+    // Several ranks.  Replicated mode: the envelope of S and the vectors are summed BEFORE k_finish; every rank
+    // then holds, finishes and factors the whole system.  Domain mode (mg_subtree): S and the right-hand side
+    // stay this rank's share -- complete for its own domain --, only the vectors [g_c | diagU | sums] are
+    // summed here (the column scaling needs the complete column norms); k_finish adds the prior / damping /
+    // fixed-element terms where this rank owns the column; the top separators are summed inside the
+    // factorisation (factor_solve_enqueue).
+    void allreduce_vectors() {
+        if (!multi()) return;
+        do_allreduce(g_c, 2 * P.NS + 8);             // [g_c | diagU | red_scal], contiguous behind g_red
+    }
     void build(const double *zz, double lambda, int scale, bool lazy = false) {
         build_enqueue(zz, lambda, scale);
-        allreduce_system();
+        if (mg_subtree) allreduce_vectors();
+        else allreduce_system();
         finish_enqueue(zz, lambda, scale);           // also: trace(J'J) of the camera part and red_scal -> mailbox
+        if (mg_subtree && replicate_next && multi()) allreduce_matrix();   // (posterior covariance: the whole system on every rank)
         cams_at_lin = true;                          // (zlin = zz: k_build_tail)
         lin_pending = true;
         if (!lazy) sync();
@@ -598,9 +616,17 @@ struct Core {
         s_valid = true;
         ++n_lin;
     }
+    bool replicate_next = false;     // domain mode: the next build sums the whole matrix after k_finish (in-place factorisation)
+    // sum of the envelope of S (incl. the right-hand-side row) over the ranks, after k_finish
+    void allreduce_matrix() {
+        if (!pk.p) pk.alloc((size_t)(pk_s_count + 3 * P.NS + 8));
+        LAUNCHK(k_pack_envelope, dim3((unsigned)P.NS), dim3(256), 0, stream, S, ldS, (int)P.NS, env_tail0, col_bend.p, col_off.p, pk.p, 1);
+        do_allreduce(pk.p, pk_s_count);
+        LAUNCHK(k_pack_envelope, dim3((unsigned)P.NS), dim3(256), 0, stream, S, ldS, (int)P.NS, env_tail0, col_bend.p, col_off.p, pk.p, 0);
+    }
     void finish_enqueue(const double *zz, double lambda, int scale) {
         LAUNCHK(k_finish, dim3((unsigned)cdiv(P.NS, 256)), dim3(256), 0, stream, d, zz, lambda, scale, S, g_c, g_red, diagU, jn2c.p, dscale.p,
-                gpart.p, gctr.p + 3, (const double *)red_scal, scal.p, hpin);
+                gpart.p, gctr.p + 3, (const double *)red_scal, scal.p, hpin, mg_subtree && multi() ? (const uint8_t *)z_mine.p : (const uint8_t *)nullptr);
         if (scale)      // D S D on the envelope
             LAUNCHK(k_envelope_op, dim3((unsigned)P.NS), dim3(256), 0, stream, S, ldS, (int)P.NS, env_tail0, col_bend.p, (const double *)dscale.p);
     }
@@ -611,7 +637,15 @@ struct Core {
         // Cholesky + both substitutions; q -> rhs.  One persistent dataflow kernel (chol_df.hpp)
         // (the dataflow kernel also writes the step of the unscaled system dc = D q)
         bool unscaled = true;
-        if (use_perm && !chol_in_place) dfchol.solve(stream, S, ldS, rhs.p, linv.p, info.p, ldiag.p, dscale.p, dz.p);
+        if (use_perm && !chol_in_place && mg_subtree && multi()) {
+            // this rank's domain and its share of the top separators; the shares summed over the ranks (one
+            // all-reduce of the top tiles); the top separators and the backward substitution on every rank
+            dfchol.solve_domain(stream, S, ldS, linv.p, info.p, ldiag.p);
+            mark(8);
+            do_allreduce(dfchol.top_tiles(), dfchol.top_tiles_count());
+            mark(9);
+            dfchol.solve_top(stream, ldS, rhs.p, linv.p, info.p, ldiag.p, dscale.p, dz.p);
+        } else if (use_perm && !chol_in_place) dfchol.solve(stream, S, ldS, rhs.p, linv.p, info.p, ldiag.p, dscale.p, dz.p);
         else if (use_df) dfchol_ip.solve(stream, S, ldS, rhs.p, linv.p, info.p, ldiag.p, dscale.p, dz.p);
         else {
             unscaled = false;
@@ -656,7 +690,8 @@ struct Core {
         // extremes of the reduced system; on one rank straight into the pinned mailbox
         LAUNCHK(k_prior_jv, dim3(grid_zs), dim3(1024), 0, stream, d, zlin.p, dz.p, g_c, gp.p, gpart.p, gctr.p + 4,
                 (const double *)(partial.p + 2 * b_first), nb - b_first + ngiant + n_sig_wg, (const double *)ldiag.p, pivmm.p,
-                (const int *)info.p, scal.p, multi() ? (double *)nullptr : hpin, ++mb_seq);
+                (const int *)info.p, scal.p, multi() ? (double *)nullptr : hpin, ++mb_seq,
+                mg_subtree && multi() ? (const uint8_t *)piv_have.p : (const uint8_t *)nullptr);
     }
     // solve at the current linearisation: p in dz.  Returns true if the
     // factorisation failed outright (non-positive pivot / non-finite step);
@@ -672,15 +707,16 @@ struct Core {
         backsub_enqueue();
         int hinfo = 0;
         unsigned long long hmm[4];
-        // one all-reduce per solve: the 8 scalar sums and, behind them, one {min,max} slot per rank
-        // with this rank's point-block pivots (the extremes travel through the sum)
-        const int nsl = multi() ? 2 * P.nranks : 0;
+        // one all-reduce per solve: the 8 scalar sums (slot 7: a failed factorisation on any rank) and, behind
+        // them, two {min,max} slots per rank with this rank's pivots of the point blocks and of the part of
+        // the reduced system it factored (the extremes travel through the sum)
+        const int nsl = multi() ? 4 * P.nranks : 0;
         std::vector<double> h((size_t)8 + nsl);
         if (nsl) {
             HIPCHK(hipMemcpyAsync(hpin + 40, pivmm.p, sizeof(hmm), hipMemcpyDeviceToHost, stream));
             HIPCHK(hipMemcpyAsync(hpin + 44, info.p, sizeof(hinfo), hipMemcpyDeviceToHost, stream));
             HIPCHK(hipMemsetAsync(scal.p + 8, 0, (size_t)nsl * sizeof(double), stream));
-            HIPCHK(hipMemcpyAsync(scal.p + 8 + 2 * P.rank, pivmm.p, 2 * sizeof(double), hipMemcpyDeviceToDevice, stream));
+            HIPCHK(hipMemcpyAsync(scal.p + 8 + 4 * P.rank, pivmm.p, 4 * sizeof(double), hipMemcpyDeviceToDevice, stream));
             do_allreduce(scal.p, 8 + nsl);
             read_scal(h.data(), 8 + nsl);
         } else {             // k_prior_jv left everything in the mailbox
@@ -695,7 +731,7 @@ struct Core {
         memcpy(mm, hmm, sizeof(mm));
         double pmin = std::min(mm[0], mm[2]), pmax = std::max(mm[1], mm[3]);
         for (int r = 0; r < nsl / 2; ++r) { pmin = std::min(pmin, h[8 + 2 * r]); pmax = std::max(pmax, h[8 + 2 * r + 1]); }
-        const bool failed = hinfo != 0 || !std::isfinite(pp) || !std::isfinite(JpJp);
+        const bool failed = hinfo != 0 || (nsl && h[7] > 0) || !std::isfinite(pp) || !std::isfinite(JpJp);
         // a failed factorisation that ran in place may have left non-finite values in tile parts outside the
         // column envelope (0 x NaN), which the envelope-only clearing of the next build would not reach
         if (failed && !(use_perm && !chol_in_place)) s_dense_dirty = true;
@@ -706,7 +742,9 @@ struct Core {
     // ---- posterior covariance blocks at z (bundle_cov.m): s0^2 * blocks of inv(J'J)
     std::vector<double> cop_tmp;
     void posterior_cov(double s0, double *hCEO, double *hCIO, double *hCOP, double *hSinv) {
-        build(z.p, 0.0, 0);                          // unscaled, undamped reduced system + V^-1 per point
+        replicate_next = true;                       // (domain sharding: the whole system on every rank for this one)
+        try { build(z.p, 0.0, 0); } catch (...) { replicate_next = false; throw; }   // unscaled, undamped reduced system + V^-1 per point
+        replicate_next = false;
         s_valid = false;
         chol_in_place = true;
         // the in-place factorisation stores whole 64 x 64 tiles, which straddle the column envelope that the
@@ -1093,6 +1131,36 @@ int dbat_hip_plan_point_owner(const dbat_hip_problem *prob, int32_t *owner) {
     API_CATCH
 }
 
+int dbat_hip_plan_domain_map(const dbat_hip_problem *prob, int32_t *cam_owner, int32_t *subtree) {
+    API_TRY
+    if (!prob || !cam_owner) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
+    Plan P;
+    if (!build_plan(*prob, P, false)) { g_err = P.err; return DBAT_HIP_EINVAL; }
+    for (int c = 0; c < P.nc; ++c) cam_owner[c] = P.mg_subtree ? P.nd.cam_owner[c] : -1;
+    if (subtree) *subtree = P.mg_subtree ? 1 : 0;
+    return DBAT_HIP_OK;
+    API_CATCH
+}
+
+int dbat_hip_plan_layout_stats(const dbat_hip_problem *prob, int64_t *st) {
+    API_TRY
+    if (!prob || !st) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
+    Plan P;
+    if (!build_plan(*prob, P, true)) { g_err = P.err; return DBAT_HIP_EINVAL; }
+    for (int i = 0; i < 16; ++i) st[i] = 0;
+    st[0] = P.CMAX && P.nb_tiled > 0 ? (int64_t)P.tile_batch.size() - 1 : 0;
+    st[1] = (int64_t)P.batch_start.size() - 1; st[2] = P.nb_tiled;
+    st[3] = P.sg_ngroups; st[4] = P.sg_npoints; st[5] = (int64_t)P.sg_chunk.size() / 8;
+    for (size_t q = 0; q < P.sg_chunk.size() / 8; ++q) {
+        const int npts = P.sg_chunk[8 * q + 1], k = P.sg_chunk[8 * q + 2];
+        st[6 + (npts > 32 ? 3 : (npts > 16 ? 2 : (npts > 8 ? 1 : 0)))]++;
+        if (npts > std::min(6, 64 / std::max(k, 1))) st[10]++;      // SIG_PPR points per round of pass 2
+    }
+    st[11] = P.sg_kmax; st[12] = P.sg_rows_max; st[13] = P.sg_ok ? 1 : 0; st[14] = P.sg_backsub_ok ? 1 : 0;
+    return DBAT_HIP_OK;
+    API_CATCH
+}
+
 int dbat_hip_plan_serialize(const dbat_hip_problem *prob, double *x0) {
     API_TRY
     if (!prob || !x0) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
@@ -1434,7 +1502,7 @@ int dbat_hip_bench_step(dbat_hip_handle *h, double lambda, int32_t scale_columns
     c.timing = true;
     HIPCHK(hipEventRecord(c.ev[0], c.stream));
     c.build_enqueue(c.z.p, lambda, scale_columns);
-    c.allreduce_system();
+    if (c.mg_subtree) c.allreduce_vectors(); else c.allreduce_system();
     c.finish_enqueue(c.z.p, lambda, scale_columns);
     HIPCHK(hipEventRecord(c.ev[1], c.stream));
     c.factor_solve_enqueue();

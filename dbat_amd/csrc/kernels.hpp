@@ -2021,28 +2021,36 @@ __global__ void k_finish(DevProblem d, const double *__restrict__ z, double lamb
                          const double *__restrict__ diagU, double *__restrict__ jn2c,
                          double *__restrict__ dscale, double *__restrict__ partial, unsigned *__restrict__ ctr,
                          const double *__restrict__ red_scal, double *__restrict__ out,
-                         double *__restrict__ mailbox) {
+                         double *__restrict__ mailbox, const uint8_t *__restrict__ mine = nullptr) {
+    // mine (several ranks, domain sharding): S and g_red hold THIS rank's share of the reduced system and are
+    // summed over the ranks later (the top separators) or never (the rank's own domain): the terms that enter
+    // once -- prior, damping, the unit diagonal of a fixed element -- are added where the rank owns the column.
+    // g_c and diagU are complete on every rank (summed before this kernel), and so are jn2c and dscale.
     __shared__ double sh[8];
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     double acc[1] = {0.0};                           // trace(J'J), camera/IO part: estimated columns
     if (i < d.NS) {
+        const bool own = !mine || mine[i];
         const double pw = d.z_prw[i];
         double add = 0, g = g_red[i], jn2 = diagU[i];
         if (pw > 0) {
+            // (the prior residual needs this rank's z[i] to be current: true for the owner; g_c is only ever
+            // read at owned entries, the others' share of this term is dropped with them)
             const double e = pw * (z[i] - d.z_prv[i]);
-            add += pw; g += e; jn2 += pw; g_c[i] += e; g_red[i] = g;
+            jn2 += pw; g_c[i] += e;
+            if (own) { add += pw; g += e; g_red[i] = g; }
         }
         jn2c[i] = jn2;
         const bool est = d.z_est[i] != 0;
         double ds = 1.0;
         if (est) {
-            add += lambda;
+            if (own) add += lambda;
             if (scale && jn2 > 0) ds = 1.0 / sqrt(jn2);
             S[i * d.ldS + i] += add;
             S[i * d.ldS + d.NS] = -ds * g;
             acc[0] = jn2;
         } else {
-            S[i * d.ldS + i] = 1.0;
+            S[i * d.ldS + i] = own ? 1.0 : 0.0;
             S[i * d.ldS + d.NS] = 0.0;
         }
         dscale[i] = ds;
@@ -2269,13 +2277,13 @@ __global__ __launch_bounds__(1024) void k_prior_jv(DevProblem d, const double *_
                                                   int64_t nbs, const double *__restrict__ ldiag,
                                                   unsigned long long *__restrict__ pivmm, const int *__restrict__ info,
                                                   double *__restrict__ out, double *__restrict__ mailbox,
-                                                  unsigned long long seq) {
+                                                  unsigned long long seq, const uint8_t *__restrict__ piv_have = nullptr) {
     __shared__ double sh[80];
     double acc[5] = {0, 0, 0, 0, 0};                 // [3], [4]: the sums over the image rows, from bs_partial
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     double pmin = 1e300, pmax = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.NZ; i += stride) {
-        if (ldiag && i < d.NS && d.z_est[i]) {
+        if (ldiag && i < d.NS && d.z_est[i] && (!piv_have || piv_have[i])) {      // (piv_have: the pivots this rank computed)
             double p = ldiag[i];                     // diag(L) by natural index (the factorisation may be permuted)
             p = p == p ? p : 0.0;
             pmin = fmin(pmin, p); pmax = fmax(pmax, p);
@@ -2299,6 +2307,9 @@ __global__ __launch_bounds__(1024) void k_prior_jv(DevProblem d, const double *_
     }
     if (grid_sum<5, 2, 3>(acc, sh, partial, ctr, bs_partial, nbs, 2) && threadIdx.x == 0) {
         out[0] = acc[3]; out[1] = acc[4]; out[4] = acc[0]; out[5] = acc[1]; out[6] = acc[2];
+        // a failed factorisation on ANY rank must be seen by all of them (out is summed over the ranks)
+        out[7] = info && __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 1.0 : 0.0;
+        out[2] = 0.0; out[3] = 0.0;
         if (mailbox) {
             mailbox[0] = acc[3]; mailbox[1] = acc[4]; mailbox[4] = acc[0]; mailbox[5] = acc[1]; mailbox[6] = acc[2];
             for (int q = 0; q < 4; ++q)

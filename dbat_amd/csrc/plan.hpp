@@ -22,6 +22,7 @@
 
 #include "../../include/dbat_hip.h"
 #include "model.hpp"
+#include "nd.hpp"
 
 namespace dbat {
 
@@ -116,6 +117,11 @@ struct Plan {
     std::vector<int32_t> cam_first;                // lowest camera index sharing an object point with each camera
     std::vector<uint64_t> cam_adj;                 // [nc][cam_adj_words] co-visibility graph (bit c2 of row c1), symmetric
     int cam_adj_words = 0;
+    // nested dissection of the co-visibility graph (nd.hpp): elimination order of the reduced system and,
+    // with several ranks, the domain of every rank (mg_subtree: object points follow their cameras' domain,
+    // the domains factor locally and only the top separators' Schur complement is summed over the ranks)
+    NdTree nd;
+    bool mg_subtree = false;
     int max_k = 0;                                 // max observations of one point
     bool shared_eo = false;                        // EO.struct.block shares elements between images (camera stations):
                                                    // every shared element is ONE unknown in the slot of its leading
@@ -441,6 +447,19 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
             }
         }
     }
+    // ---- nested dissection (nd.hpp); with several ranks its first levels are the ranks' domains
+    {
+        const bool nd_off = getenv("DBAT_HIP_ND_OFF") != nullptr;
+        const bool permuted_ok = !P.shared_eo && !getenv("DBAT_HIP_DF_NOPERM") && !getenv("DBAT_HIP_BLOCKCHOL") && !getenv("DBAT_HIP_DENSE_CHOL");
+        P.mg_subtree = P.nranks > 1 && permuted_ok && !nd_off && !getenv("DBAT_HIP_MG_REPLICATED");
+        std::vector<double> xyz((size_t)3 * nc), wcam(nc);
+        for (int c = 0; c < nc; ++c) {
+            for (int k = 0; k < 3; ++k) { const double v = pb.EO_val[(size_t)6 * c + k]; xyz[(size_t)3 * c + k] = std::isfinite(v) ? v : 0.0; }   // only steers the bisection
+            wcam[c] = (double)n_cam[c];
+        }
+        const int leaf = std::max(8, getenv("DBAT_HIP_ND_LEAF") ? atoi(getenv("DBAT_HIP_ND_LEAF")) : 32);
+        nd_build(nc, P.cam_adj.data(), P.cam_adj_words, xyz.data(), wcam.data(), P.mg_subtree ? P.nranks : 1, leaf, nd_off, P.nd);
+    }
     // Points that fit a tile of the MFMA Schur kernel (at most CMAX cameras and
     // IOT estimated IO columns) are processed first; "heavy" points (e.g. control
     // points seen in very many images) follow and go through k_build.
@@ -592,6 +611,28 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
             return key[a] < key[b];
         });
     }
+    if (P.mg_subtree) {
+        // Domain sharding: a point goes to the rank whose domain holds its interior cameras (nd.hpp: all
+        // of them lie in ONE domain); points that only see top-separator cameras go wherever the load is
+        // lowest.  The processing order becomes owner-major (the order inside a rank stays the curve's), so
+        // a rank's points are one contiguous range of it.
+        std::vector<int32_t> owner(np, -1);
+        std::vector<int64_t> load(P.nranks, 0);
+        for (int p = 0; p < np; ++p)
+            for (int j = 0; j < k_pt[p] && owner[p] < 0; ++j) owner[p] = P.nd.cam_owner[pb.ip_cam[by_pt[pstart[p] + j]]];
+        for (int p = 0; p < np; ++p) if (owner[p] >= 0) load[owner[p]] += k_pt[p];
+        for (int p = 0; p < np; ++p)
+            if (owner[p] < 0) {
+                int best = 0;
+                for (int r = 1; r < P.nranks; ++r) if (load[r] < load[best]) best = r;
+                owner[p] = best; load[best] += k_pt[p];
+            }
+        std::stable_sort(P.porder.begin(), P.porder.end(), [&](int32_t a, int32_t b) { return owner[a] < owner[b]; });
+        P.pt_lo = np; P.pt_hi = 0;
+        for (int i = 0; i < np; ++i)
+            if (owner[P.porder[i]] == P.rank) { P.pt_lo = std::min<int64_t>(P.pt_lo, i); P.pt_hi = i + 1; }
+        if (P.pt_hi < P.pt_lo) P.pt_lo = P.pt_hi = 0;
+    } else
     // shard = contiguous range of the processing order balanced by observation count
     {
         std::vector<int64_t> cum(np + 1, 0);
@@ -623,9 +664,17 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         for (auto &v : P.x2z) v = zperm(v);
         for (auto &v : P.prior_z) v = zperm(v);
     }
-    // z_mine: EO/IO counted by rank 0, OP by the owning shard
+    // z_mine: who counts an entry in the sums over z (and supplies it to the gathered result).  OP: the
+    // owning shard.  EO/IO: rank 0 -- with domain sharding the EO of a domain's cameras belongs to that
+    // domain's rank (nobody else ever computes their step), the top separators' and the IO to rank 0
     P.z_mine.assign(P.NZ, 0);
-    if (P.rank == 0) for (int64_t z = 0; z < P.NS; ++z) P.z_mine[z] = 1;
+    if (P.mg_subtree) {
+        for (int c = 0; c < nc; ++c) {
+            const int ow = P.nd.cam_owner[c] < 0 ? 0 : P.nd.cam_owner[c];
+            if (ow == P.rank) for (int k = 0; k < 6; ++k) P.z_mine[(size_t)6 * c + k] = 1;
+        }
+        if (P.rank == 0) for (int64_t z = 6 * (int64_t)nc; z < P.NS; ++z) P.z_mine[z] = 1;
+    } else if (P.rank == 0) for (int64_t z = 0; z < P.NS; ++z) P.z_mine[z] = 1;
     for (int64_t i = P.pt_lo; i < P.pt_hi; ++i)
         for (int d = 0; d < 3; ++d) P.z_mine[P.NS + 3 * i + d] = 1;
     if (!with_obs) return true;

@@ -263,6 +263,15 @@ int  dbat_hip_comm_allreduce_host(dbat_hip_handle *h, double *buf, int64_t count
 typedef int (*dbat_hip_allreduce_fn)(void *user, void *buf_dev, int64_t count, void *stream);
 int  dbat_hip_set_allreduce(dbat_hip_handle *h, dbat_hip_allreduce_fn fn, void *user);
 
+/* Host only: the domain of every image under domain sharding with prob->shard_count ranks (nested dissection of
+ * the co-visibility graph, csrc/nd.hpp): cam_owner[n_images] = the rank whose domain the image belongs to, or -1
+ * for an image of a top separator (replicated on every rank).  An object point is owned by the rank whose domain
+ * holds its interior images (dbat_hip_plan_point_owner); the invariant the scheme rests on -- no point sees
+ * interior images of two domains -- is checked by tests/test_parallel_cpu.py.  *subtree = 1 if this problem
+ * is sharded that way (0: contiguous point ranges, the whole reduced system summed and factored by every rank:
+ * one rank, shared EO blocks, or the environment asked for it). */
+int  dbat_hip_plan_domain_map(const dbat_hip_problem *prob, int32_t *cam_owner, int32_t *subtree);
+
 /* mask[n_params]: 1 where this handle's shard owns the x entry (its object
  * points; rank 0 also owns IO and EO).  Host only; results returned by the
  * library are already complete on every rank. */
@@ -297,6 +306,14 @@ int  dbat_hip_set_x(dbat_hip_handle *h, const double *x);
  * info[3]=obs in this shard info[4]=points in this shard info[5]=batch size
  * info[6]=max camera-side columns per observation info[7]=#tiles */
 int  dbat_hip_info(const dbat_hip_handle *h, int64_t *info /*[8]*/);
+
+/* Host only (no GPU): statistics of the layout the plan gives this problem (this shard), so that a test
+ * can tell which code path of the signature kernel a scene exercises.  st[16]:
+ * [0] tiles [1] batches [2] tiled batches [3] signature groups [4] their points [5] chunks
+ * [6..9] chunks of 1-8 / 9-16 / 17-32 / 33-64 points (8, 4, 2, 1 lanes per point in pass 1)
+ * [10] chunks that need more than one round of pass 2 [11] most cameras per chunk
+ * [12] most rows of a chunk [13] 1 = k_build_sig selected [14] 1 = k_backsub_sig selected [15] 0 */
+int  dbat_hip_plan_layout_stats(const dbat_hip_problem *prob, int64_t *st /*[16]*/);
 
 /* name of the kernel that builds the Schur complement of the tiled points in this handle
  * (the dominant kernel of a step; the one the bench's roofline entry is about) */

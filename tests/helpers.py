@@ -502,3 +502,37 @@ def dump_problem(s, path):
         f.write(hdr.tobytes())
         for k in order:
             f.write(keep[k].tobytes())
+
+
+def oracle_lm_reordered(s, seed=1, max_iter=20, conv_tol=1e-6):
+    """The oracle's Levenberg-Marquardt loop (levenberg_marquardt.m:52-250) on the SAME problem with
+    the rows of r and J visited in a different order: every sum over the rows (r'r, J'J, J'r) then
+    rounds differently, nothing else changes.  Returns (x, code, iters, rr, lambdas).
+
+    Used to decide where an iteration count is a property of the problem and where it is rounding
+    noise of the reference algorithm itself (tests/test_hip_parity.py::check_history)."""
+    import copy
+    import dbat_oracle as o
+    s = copy.deepcopy(s)
+    for nm in ('IO', 'EO', 'OP'):
+        pr = getattr(s.prior, nm)
+        pr.use = np.asarray(pr.use, bool) & np.asarray(getattr(s.bundle.est, nm), bool)
+    s = o.buildserialindices(s)
+    x0 = o.serialize(s)
+    w = o.buildweightvector(s)
+    perm = np.random.default_rng(seed).permutation(len(w))
+
+    def res_fun(x, jac):
+        if not jac:
+            return o.brown_euler_cam4(x, s, False)[perm]
+        r, J = o.brown_euler_cam4(x, s, True)
+        return r[perm], J.tocsr()[perm].tocsc()
+
+    x, code, n, final, T, rr, lam = o.levenberg_marquardt(res_fun, x0, w[perm], max_iter, o.term_relative(conv_tol),
+                                                          -1e-10, -1e-10)
+    return x, code, n, rr, lam
+
+
+def lm_count_is_stable(s, ito, seeds=(1, 2)):
+    """True if the oracle's LM iteration count `ito` does not depend on the summation order."""
+    return all(oracle_lm_reordered(s, seed)[2] == ito for seed in seeds)

@@ -189,3 +189,35 @@ def test_plan_under_sanitizers(tmp_path):
     assert len(lines) == 4 * len(paths) and not any('rejected' in l for l in lines), r.stdout
     first = [l for l in lines if 'p0.bin rank 0/1' in l][0]
     assert 'chunks' in first and '(300 pts)' in first
+
+
+def test_plan_layout_stats_long_groups():
+    """Host-only layout statistics (dbat_hip_plan_layout_stats): the scene of
+    tests/test_fullsize_parity.py::test_long_signature_groups_vs_oracle reaches the chunk lengths of
+    the benchmark scenes in 79 of its 100 chunks ('tiny': 3 of 33, 'small': 32 of 424, C1: 28 of 1706)."""
+    from dbat_amd import _hip, synth
+    s, _ = synth.make_scene('tiny', cams=12, points=4000, rays=10)
+    st = _hip.plan_layout_stats(s)
+    assert st['n_group_points'] == 4000 and sum(st['chunks_by_length'].values()) == st['n_chunks']
+    assert st['chunks_by_length']['33-64'] >= 50 and st['chunks_multi_round'] >= 50
+    assert st['k_max'] == 10 and st['rows_max'] == 61 and st['build_sig'] and st['backsub_sig']
+    s, _ = synth.make_scene('tiny')
+    st = _hip.plan_layout_stats(s)
+    assert st['chunks_by_length']['33-64'] <= 3 and st['n_group_points'] == 300      # (3 of its 33 chunks)
+
+
+def test_lm_count_stability_helper():
+    """helpers.oracle_lm_reordered: the oracle's LM loop with the rows of r and J in another order
+    converges to the same x; its iteration COUNT is stable on some problems and rounding noise on
+    others (the fact check_history builds on)."""
+    import dbat_oracle as o
+    from helpers import synth_struct, oracle_lm_reordered, lm_count_is_stable, relerr
+    s, _ = synth_struct('tiny', 'imagevar')
+    ro, ok, ito, s0, E = o.bundle(s, 'lm')
+    x, code, n, rr, lam = oracle_lm_reordered(s, 1)
+    assert code == 0 and relerr(x, E.x) < 1e-9
+    assert lm_count_is_stable(s, ito)
+    s, _ = synth_struct('tiny', 'plain')
+    ro, ok, ito, s0, E = o.bundle(s, 'lm')
+    counts = {oracle_lm_reordered(s, sd)[2] for sd in (1, 2, 3)} | {ito}
+    assert len(counts) > 1, counts       # fixed IO, well conditioned -- and still not a property of the problem

@@ -16,7 +16,7 @@ import scipy.sparse as sp
 
 import dbat_oracle as o
 from helpers import (camcal_struct, camcal_expected, check_camcal_against_report, synth_struct,
-                     relerr, roma_struct, roma_expected, check_roma_against_result)
+                     relerr, roma_struct, roma_expected, check_roma_against_result, lm_count_is_stable)
 
 pytestmark = pytest.mark.gpu
 
@@ -56,18 +56,20 @@ def noise_tail_start(res):
     return len(res)
 
 
-def check_history(E, Eo, iters, ito, damping, ill_conditioned=False):
-    """Iteration histories must match; for 'lm' only up to the point where the
-    reference algorithm itself is driven by rounding noise.
+def check_history(E, Eo, iters, ito, damping, s=None):
+    """Iteration histories must match; for 'lm' the COUNT only where it is a property of the problem.
 
     levenberg_marquardt.m terminates only after an ACCEPTED undamped step
     (:177,:217); once converged, "fNew<f" compares objective values that
     differ by less than their rounding error, so the number of trailing
-    trials is arithmetic noise in the reference itself (the oracle's own count
-    changes with the summation order).  With self-calibration the unscaled
-    LM normal matrix (levenberg_marquardt.m:119) has rcond < eps, so even the
-    count of trailing trials is not compared (ill_conditioned); the iterates up to
-    the noise tail are, at the same tolerance as everywhere else."""
+    trials can be arithmetic noise in the reference itself: the oracle's own
+    count changes when the rows of r and J are merely summed in another order
+    (helpers.oracle_lm_reordered: tiny-plain 7 / 4 / 21 iterations, camcal
+    model 4 6 / 7 / 6).  The count is therefore asserted exactly where the
+    oracle's count survives two such re-orderings (helpers.lm_count_is_stable)
+    -- self-calibrating or not -- and the iterates, residual norms and lambdas
+    are compared up to the noise tail everywhere, at the tolerance used
+    everywhere else."""
     if damping != 'lm':
         assert iters == ito
         assert len(E.res) == len(Eo.res) and relerr(E.res, Eo.res) < 1e-8
@@ -81,9 +83,8 @@ def check_history(E, Eo, iters, ito, damping, ill_conditioned=False):
     assert relerr(E.res[:k], Eo.res[:k]) < tol
     lam, lamo = E.damping.__dict__['lambda'], Eo.damping.__dict__['lambda']
     assert relerr(lam[:k], lamo[:k]) < tol
-    no_tail = lambda r: noise_tail_start(r) >= len(r) - 1
-    if no_tail(Eo.res) and no_tail(E.res) and not ill_conditioned:
-        assert iters == ito
+    if s is not None and lm_count_is_stable(s, ito):
+        assert iters == ito, 'LM iteration count %d, oracle %d (stable under re-ordered summation)' % (iters, ito)
 
 
 def oracle_setup(s):
@@ -184,7 +185,7 @@ def test_camcal_known_answer_hip(hip, model, damping):
     assert ok and E.code == 0
     check_camcal_against_report(res, s0, E, exp)
     ro, oko, ito, s0o, Eo = o.bundle(camcal_struct(model), damping)
-    check_history(E, Eo, iters, ito, damping, ill_conditioned=True)
+    check_history(E, Eo, iters, ito, damping, s=camcal_struct(model))
     assert relerr(E.x, Eo.x) < TOL_X
     assert abs(s0 - s0o) < 1e-9 * s0o
     if damping != 'lm':
@@ -207,7 +208,7 @@ def test_synthetic_bundle_parity(hip, variant, damping):
     # differ by less than their rounding error, so the number of trailing
     # rejected trials is arithmetic noise in the reference algorithm itself.
     # Compare the iteration history up to that point.
-    check_history(E, Eo, iters, ito, damping, ill_conditioned=(variant in ('selfcal', 'groups4')))
+    check_history(E, Eo, iters, ito, damping, s=s)
     if damping == 'gna':
         assert np.array_equal(E.damping.alpha, Eo.damping.alpha)
     if damping == 'lmp':
@@ -246,7 +247,7 @@ def test_small_scene_all_dampings(hip):
         res, ok, iters, s0, E = bundle(s, damping)
         ro, oko, ito, s0o, Eo = o.bundle(s, damping)
         assert ok and oko
-        check_history(E, Eo, iters, ito, damping)
+        check_history(E, Eo, iters, ito, damping, s=s)
         assert relerr(E.x, Eo.x) < TOL_X
         assert 0.4 < s0 < 0.6           # noise 0.5 px, IP.std 1 px
 
@@ -551,11 +552,12 @@ def _full_size_properties(name, damping):
         assert np.sqrt(st['JpJp']) <= 1e-5 * np.sqrt(2 * st['f'])
     finally:
         h.close()
-    # truth recovered up to what the network determines: with fixed IO to the noise level (< 1 m over
-    # the 100 m block); with self-calibration of a nadir block over nearly flat terrain the camera
-    # constant and the flying height (40 m) are strongly correlated, a few per cent of it remain open
-    selfcal = bool(np.any(s.bundle.est.IO))
-    assert np.abs(res.EO.val[:3] - truth['EO'][:3]).max() < (0.05 * 40.0 if selfcal else 1.0)
+    # truth recovered: fixed IO to the noise level here (estimate and truth differ by the datum -- camera 0 sits
+    # at its noisy initial position -- hence metres, not sigmas).  Self-calibration against the truth, in the
+    # truth's datum and in units of the posterior sigma: tests/test_fullsize_parity.py (C2 and C4), which also
+    # pins why the camera constants of a 0.5 px run sit 0.04 mm (C2) / 0.45 mm (C4) above the generator's values
+    if not bool(np.any(s.bundle.est.IO)):
+        assert np.abs(res.EO.val[:3] - truth['EO'][:3]).max() < 1.0
     other = 'gna' if damping != 'gna' else 'lmp'
     r2, ok2, it2, s02, E2 = bundle(s, other, store_trace=False)
     assert ok2 and abs(s02 - s0) < 1e-7 * s0
@@ -582,10 +584,9 @@ def test_C4_full_size_properties(hip):
     that layout is the 'groups4' variant of the cases above)."""
     res, E = _full_size_properties('C4', 'lm')
     assert E.numParams == 30000 - 7 + 32 + 15_000_000 and E.numObs == 100_000_000
-    # four independent IO blocks: four distinct camera constants near the perturbed truth
-    cc = np.unique(np.round(res.IO.val[0], 12))
-    # (within the +-1 % of the generator plus the few per cent that camera constant and flying height share)
-    assert len(cc) == 4 and np.all(np.abs(cc / 24.3581 - 1) < 0.04)
+    # four independent IO blocks: four distinct camera constants (their values against the four true constants:
+    # tests/test_fullsize_parity.py::test_truth_within_posterior_sigma)
+    assert len(np.unique(np.round(res.IO.val[0], 12))) == 4
 
 
 @pytest.mark.parametrize('variant', ['plain', 'selfcal'])
@@ -812,7 +813,7 @@ def test_camcal_demo_pipeline_hip(hip, model, damping):
     res, ok, iters, s0, E = bundle(s, damping)
     ro, oko, ito, s0o, Eo = o.bundle(s, damping)
     assert ok and oko and E.code == 0
-    check_history(E, Eo, iters, ito, damping)
+    check_history(E, Eo, iters, ito, damping, s=s)
     assert relerr(E.x, Eo.x) < TOL_X
     assert relerr(E.trace, Eo.trace) < 1e-6
     check_camcal_against_report(res, s0, E, exp)
@@ -1019,7 +1020,7 @@ def test_signature_group_kernel(hip, name, variant, monkeypatch):
             res, ok, iters, s0, E = bundle(s, damping)
             ro, oko, ito, s0o, Eo = o.bundle(s, damping)
             assert ok and oko and relerr(E.x, Eo.x) < TOL_X
-            check_history(E, Eo, iters, ito, damping, ill_conditioned=variant in ('selfcal', 'groups4'))
+            check_history(E, Eo, iters, ito, damping, s=s)
 
 
 @pytest.mark.parametrize('knob', ['DBAT_HIP_TILE3=0', 'DBAT_HIP_TILE_BMAX=3'])

@@ -1,0 +1,164 @@
+"""Several ranks on ONE GPU (threads + an all-reduce through the host): the domain-sharded path --
+csrc/nd.hpp, the two-phase factorisation of csrc/chol_df.hpp (own domain + shares of the top
+separators, all-reduce of the top tiles, top separators + backward substitution) -- against the
+one-rank result, for 2, 3 and 4 ranks, all dampings, fixed and self-calibrated IO (dense IO rows =
+part of the top), prior observations, ranks whose domain is empty, the signature kernels forced on,
+and the replicated fall-back.  (tests/test_parallel_cpu.py: the same scheme in NumPy over gloo.)"""
+import threading
+
+import numpy as np
+import pytest
+
+from helpers import relerr, synth_struct
+from test_hip_parity import _ThreadComm
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from dbat_amd import _hip
+    import torch
+    assert torch.cuda.is_available(), 'gpu tests need a GPU'
+    _hip.load()
+    return _hip
+
+
+class _CountingComm(_ThreadComm):
+    """... and counts what travels: (count, bytes) per collective."""
+
+    def __init__(self, rank, world, shared):
+        super().__init__(rank, world, shared)
+        self.sizes = []
+
+    def allreduce_ptr(self, ptr, count, stream):
+        self.sizes.append(int(count))
+        return super().allreduce_ptr(ptr, count, stream)
+
+
+def _run_ranks(s, world, fn):
+    shared = {'buf': [None] * world, 'bar': threading.Barrier(world)}
+    out, err = [None] * world, []
+    comms = [_CountingComm(r, world, shared) for r in range(world)]
+
+    def run(rank):
+        try:
+            out[rank] = fn(comms[rank])
+        except Exception as e:   # noqa: BLE001
+            import traceback
+            err.append(traceback.format_exc())
+            shared['bar'].abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(900) for t in th]
+    assert not err, err[0]
+    return out, comms
+
+
+def _scene(kind):
+    from dbat_amd import synth
+    if kind == 'c1':                       # 100 cameras: two domains of 30 at world 2; at world 4 two of the four are empty
+        return synth.make_scene('C1')[0]
+    if kind == 'c1-selfcal':
+        return synth.make_scene('C1', selfcal=True)[0]
+    if kind == 'grid-selfcal4':            # 15 x 15 cameras, six rays: four non-empty domains; four IO blocks
+        return synth.make_scene('C1', cams=225, points=6000, rays=6, selfcal=True, groups=4)[0]
+    if kind == 'small-priors':             # 40 cameras, EO / OP prior observations, fixed points, non-uniform weights
+        return synth_struct('small', 'priors')[0]
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize('world', [2, 3, 4])
+@pytest.mark.parametrize('kind,damping', [('c1', 'gna'), ('c1', 'lm'), ('c1', 'lmp'), ('c1', 'gm'),
+                                          ('c1-selfcal', 'gna'), ('c1-selfcal', 'lm'), ('grid-selfcal4', 'gna'),
+                                          ('grid-selfcal4', 'lmp'), ('small-priors', 'gna'), ('small-priors', 'lm')])
+def test_domain_shards_match_single(hip, kind, damping, world):
+    from dbat_amd import bundle
+    s = _scene(kind)
+    cam_owner, subtree = hip.plan_domain_map(s, world)
+    assert subtree
+    ref = bundle(s, damping)
+    out, comms = _run_ranks(s, world, lambda comm: bundle(s, damping, comm=comm))
+    for rank in range(world):
+        res, ok, iters, s0, E = out[rank]
+        assert ok == ref[1] and E.code == ref[4].code
+        assert relerr(E.x, ref[4].x) < 1e-8, (rank, relerr(E.x, ref[4].x))
+        assert abs(s0 - ref[3]) < 1e-9 * ref[3]
+        if damping != 'lm':
+            assert iters == ref[2]
+            assert relerr(E.res, ref[4].res) < 1e-9
+        assert relerr(res.post.res.IP, ref[0].post.res.IP) < 1e-6
+    # what travelled: never the whole reduced system
+    NS = 6 * s.EO.val.shape[1] + (len(np.unique(s.IO.struct.block[0])) * 8 if np.any(s.bundle.est.IO) else 0)
+    big = [c for c in comms[0].sizes if c > 2 * NS + 8 + 4096]
+    ntop = int(np.count_nonzero(cam_owner < 0)) * 6 + (NS - 6 * s.EO.val.shape[1])
+    assert big, 'no all-reduce of top tiles seen'
+    if np.count_nonzero(cam_owner >= 0) > 0:
+        assert max(big) < 0.75 * NS * NS / 2 or ntop > 0.8 * NS, (max(big), NS, ntop)
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_domain_shards_step_scalars_and_covariance(hip, world):
+    """linearize_solve on every rank: the complete step and the same scalars (f, ||J p||^2, g'p, ||p||^2,
+    trace(J'J)) as one rank; gradient and column norms complete on every rank; the posterior covariance blocks
+    (computed from the whole system summed over the ranks) as one rank's."""
+    s = _scene('grid-selfcal4')
+    h = hip.Handle(s)
+    try:
+        x0 = h.serialize()
+        p1, st1 = h.linearize_solve(x0, 0.0, True)
+        g1, n1 = h.gradient(), h.colnorms()
+        q1, st2 = h.linearize_solve(x0, 1e-3 * st1['trace'] / h.n, False)
+        C1 = h.posterior_cov(x0, 1.0)
+    finally:
+        h.close()
+
+    def work(comm):
+        hh = hip.Handle(s, shard_rank=comm.rank, shard_count=comm.world_size)
+        try:
+            hh.set_allreduce(comm.allreduce_ptr)
+            p, st = hh.linearize_solve(x0, 0.0, True)
+            g, n = hh.gradient(), hh.colnorms()
+            q, stq = hh.linearize_solve(x0, 1e-3 * st1['trace'] / hh.n, False)
+            C = hh.posterior_cov(x0, 1.0)
+            return p, st, g, n, q, stq, C
+        finally:
+            hh.close()
+
+    out, comms = _run_ranks(s, world, work)
+    for p, st, g, n, q, stq, C in out:
+        assert relerr(p, p1) < 1e-9 and relerr(q, q1) < 1e-9
+        for k in ('f', 'JpJp', 'rJp', 'pp', 'trace'):
+            assert abs(st[k] - st1[k]) <= 1e-9 * abs(st1[k]), k
+            assert abs(stq[k] - st2[k]) <= 1e-9 * abs(st2[k]), k
+        assert relerr(g, g1) < 1e-11 and relerr(n, n1) < 1e-11
+        for a, b in zip(C, C1):
+            assert relerr(a, b) < 1e-8
+
+
+def test_domain_shards_failure_is_seen_by_every_rank(hip):
+    """A rank-deficient domain (no datum: seven-dimensional null space) fails inside ONE rank's local
+    factorisation or in the top separators; every rank must return the same code (-2), none may hang."""
+    from dbat_amd import bundle
+    s = _scene('c1')
+    s.bundle.est.EO[:] = True
+    ref = bundle(s, 'gna')
+    assert ref[4].code == -2
+    out, _ = _run_ranks(s, 2, lambda comm: bundle(s, 'gna', comm=comm))
+    assert all(o[4].code == -2 and not o[1] for o in out)
+
+
+@pytest.mark.parametrize('env', ['DBAT_HIP_MG_REPLICATED=1', 'DBAT_HIP_SIG=2', 'DBAT_HIP_SIG=0'])
+def test_domain_shards_variants(hip, env, monkeypatch):
+    """The replicated fall-back (contiguous point ranges, envelope of the whole system summed, every rank factors
+    everything) and the domain scheme under the signature kernels forced on / off."""
+    from dbat_amd import bundle
+    name, val = env.split('=')
+    s = _scene('c1')
+    ref = bundle(s, 'gna')
+    monkeypatch.setenv(name, val)
+    assert hip.plan_domain_map(s, 2)[1] == (name != 'DBAT_HIP_MG_REPLICATED')
+    out, comms = _run_ranks(s, 2, lambda comm: bundle(s, 'gna', comm=comm))
+    for res, ok, iters, s0, E in out:
+        assert ok and iters == ref[2] and relerr(E.x, ref[4].x) < 1e-8
