@@ -118,6 +118,10 @@ def main():
     ap.add_argument('--config', default='C3')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-solve', action='store_true', help='skip the timed dbat_hip_solve("lm") run')
+    ap.add_argument('--emulate-ranks', type=int, default=0, metavar='R',
+                    help='one GPU plays rank 0 of R (its share of the points, its domain of the reduced system, the '
+                         'collectives replaced by no-ops): per-rank phase times for the scaling estimate of DESIGN.md 6; '
+                         'the numbers of the step are meaningless then and "value" is null')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -151,10 +155,13 @@ def main():
     t_gen = time.perf_counter() - t_gen
     nc, npnt, no = s.EO.val.shape[1], s.OP.val.shape[1], s.IP.val.shape[1]
     t_plan = time.perf_counter()
-    h = _hip.Handle(s, device=local, shard_rank=rank, shard_count=world)
+    emu = args.emulate_ranks if world == 1 and args.emulate_ranks > 1 else 0
+    h = _hip.Handle(s, device=local, shard_rank=rank, shard_count=emu or world)
     t_plan = time.perf_counter() - t_plan
     if comm is not None:
         comm.attach(h)                       # ncclCommInitRank inside the library
+    if emu:
+        h.set_allreduce(lambda ptr, count, stream: 0)       # the sums over the ranks: not performed
     info = h.info()
     x0 = h.serialize()
     h.set_x(x0)
@@ -172,9 +179,12 @@ def main():
         h.bench_step(lam, False)
     barrier()
     t0 = time.perf_counter()
-    ms = np.zeros(8)
+    ms = np.zeros(12)
+    t_each = []
     for _ in range(args.steps):
-        ms += h.bench_step(lam, False)
+        t1 = time.perf_counter()
+        ms += h.bench_step(lam, False)                       # (returns after the step's last kernel: it reads back f)
+        t_each.append(time.perf_counter() - t1)
     barrier()
     dt = time.perf_counter() - t0
     if comm is not None:
@@ -186,7 +196,7 @@ def main():
     # the shipped loop: a real dbat_hip_solve('lm') from x0 (host control flow, scalar
     # read-backs and all), outside the timed region above
     solve = None
-    if not args.no_solve:
+    if not args.no_solve and not emu:
         opt = _hip.default_options('lm')
         opt.store_trace = 0
         barrier()
@@ -257,25 +267,46 @@ def main():
         for k, v in hbm.items():
             v['GBs'] = gb(v['algorithmic_bytes'], k_ms[k])
             v['frac_of_8TBs'] = v['GBs'] / HBM_PEAK_GBS if v['GBs'] else None
+        # whole step against SURVEY 8(d)'s per-iteration figures (dense S written and read once, dense Cholesky):
+        # the lower bound max(bytes / 8 TB/s, flops / 78.6 TF) over the measured step
+        bytes_iter = 40.0 * no + 48.0 * npnt + 96.0 * nc + 16.0 * NS * NS
+        flops_iter = float(np.sum(108.0 * kp + 216.0 * kp * kp)) + NS ** 3 / 3.0
+        t_lb = max(bytes_iter / (HBM_PEAK_GBS * 1e9), flops_iter / (FP64_PEAK_TFLOPS * 1e12))
+        te = np.sort(np.asarray(t_each)) * 1e3
+        roof_step = {'bytes_iter': bytes_iter, 'flops_iter': flops_iter, 'lower_bound_ms': t_lb * 1e3,
+                     'frac': t_lb / (dt / args.steps), 'bound': 'mfma' if flops_iter / (FP64_PEAK_TFLOPS * 1e12) > bytes_iter / (HBM_PEAK_GBS * 1e9) else 'hbm',
+                     'note': 'SURVEY 8(d): dense NS^2 S traffic and dense NS^3/3 Cholesky flops; the sparse factorisation does '
+                             '%.3g flops (roofline_factorisation), so a fraction above 1 is possible and means structure was used' % flops_chol}
+        multi = None
+        if world > 1 or emu:
+            multi = {'ranks': emu or world, 'emulated_on_one_gpu': bool(emu), 'domain_sharding': bool(info['domain_sharding']),
+                     'allreduce_bytes': 8 * (info['reduced_doubles_per_factorisation'] + info['vector_doubles_per_linearisation'] + 8 + 4 * (emu or world) + 1),
+                     'allreduce_bytes_reduced_system': 8 * info['reduced_doubles_per_factorisation'],
+                     'allreduce_bytes_vectors': 8 * info['vector_doubles_per_linearisation'],
+                     'collectives_per_step': 4, 'top_separator_cams': info['n_top_cams'],
+                     'ms_factor_domain': ms[8], 'ms_allreduce': ms[9], 'ms_replicated': ms[10],
+                     'tasks_domain': info['tasks_domain'], 'tasks_top': info['tasks_top'],
+                     'obs_this_rank': no_s, 'pts_this_rank': np_s}
         out = {
-            'metric': 'LM iterations/sec', 'value': args.steps / dt, 'unit': 'it/s',
+            'metric': 'LM iterations/sec', 'value': None if emu else args.steps / dt, 'unit': 'it/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong',
+            'ms_per_step': dt / args.steps * 1e3, 'ms_per_step_min_median_max': [float(te[0]), float(te[len(te) // 2]), float(te[-1])],
+            'higher_is_better': True, 'scaling': 'strong',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': '%s: %d cams / %d pts / %d obs, %s, LM step (J\'J build + Schur '
                                    'solve + back-substitution + trial residual)'
                                    % (args.config, nc, npnt, no,
                                       'self-calibrating' if info['ncolmax'] > 6 else 'fixed IO'),
                        'reduced_system_order': NS, 'n_params': h.n, 'parallelism': 'points/%d' % world,
-                       'collective': 'RCCL all-reduce in libdbat_hip.so' if comm is not None else None,
+                       'collective': ('RCCL all-reduce in libdbat_hip.so: %s' % ('top-separator tiles + vectors (domain sharding)' if info['domain_sharding'] else 'envelope of the reduced system')) if comm is not None else None,
                        'n_tiles': info['n_tiles'], 'n_batches': info['n_batches'], 'batch': info['BT']},
             'ms_build_schur': ms[0], 'ms_factor_solve': ms[1], 'ms_backsub': ms[2],
             'ms_trial_residual': ms[3], 'kernel_ms': k_ms,
-            'roofline': roof, 'roofline_factorisation': roof_chol, 'hbm_kernels': hbm,
+            'roofline': roof, 'roofline_factorisation': roof_chol, 'roofline_step': roof_step, 'hbm_kernels': hbm, 'multi_gpu': multi,
             'solve_lm': solve, 'solve_it_s': solve['it_per_s'] if solve else None,
             'host_s': {'scene_generation': t_gen, 'plan_and_upload': t_plan},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not emu:
             out['cpu_baseline'] = cpu_baseline(s, args.config)
         else:
             out['cpu_baseline'] = None

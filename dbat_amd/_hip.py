@@ -401,7 +401,7 @@ class Handle:
         check(self.lib.dbat_hip_set_x(self.h, dptr(x)))
 
     def bench_step(self, lam=0.0, scale=False):
-        ms = np.zeros(8)
+        ms = np.zeros(12)
         check(self.lib.dbat_hip_bench_step(self.h, float(lam), int(bool(scale)), dptr(ms)))
         return ms
 
@@ -412,9 +412,11 @@ class Handle:
         return dict(zip(keys, [int(v) for v in a]))
 
     def info(self):
-        a = (C.c_int64 * 8)()
+        a = (C.c_int64 * 16)()
         check(self.lib.dbat_hip_info(self.h, a))
-        keys = ('NS', 'n_batches', 'max_k', 'n_obs_shard', 'n_pts_shard', 'BT', 'ncolmax', 'n_tiles')
+        keys = ('NS', 'n_batches', 'max_k', 'n_obs_shard', 'n_pts_shard', 'BT', 'ncolmax', 'n_tiles',
+                'domain_sharding', 'reduced_doubles_per_factorisation', 'vector_doubles_per_linearisation',
+                'n_top_cams', 'factor_tile_rows', 'tasks_domain', 'tasks_top')
         return dict(zip(keys, [int(v) for v in a]))
 
 

@@ -589,6 +589,29 @@ struct Core {
         LAUNCHK(k_build_tail, dim3(grid_zs), dim3(1024), 0, stream, d, zz, partial.p, npart, jn2p.p, gpart.p, gctr.p + 2, red_scal,
                 zz != zlin.p ? zlin.p : (double *)nullptr);
     }
+    // A linearisation at z that a damping loop has asked for but nobody has needed yet.  levenberg_marquardt.m
+    // (:189-194) and levenberg_marquardt_powell.m linearise at every ACCEPTED point before they test for
+    // termination; after the last accepted step that Jacobian is only returned (final.weighted.J), never
+    // used for a step.  Here it is built when the next solve -- or a caller who wants the gradient, the
+    // column norms or J v -- asks for it, and not at all otherwise: one build kernel chain less per solve
+    // (C3: 6 -> 5 linearisations for 4 LM iterations).  The iterates are the same, bit for bit.
+    bool pend_build = false;
+    double pend_lambda = 0;
+    int pend_scale = 0;
+    void request_build(double lambda, int scale) {
+        pend_build = true; pend_lambda = lambda; pend_scale = scale;
+        lambda_lin = lambda; scale_lin = scale;
+    }
+    void ensure_build() {
+        if (!pend_build) return;
+        build(z.p, pend_lambda, pend_scale, true);
+    }
+    // the loop is over: the linearisation POINT is z (residuals, sigma0), whether or not its Jacobian was built
+    void settle_lin_point() {
+        if (!pend_build) return;
+        copy(zlin.p, z.p);
+        cams_at_lin = false; s_valid = false; have_lin = true;
+    }
     // lazy: do not wait for the linearisation's scalars (f_lin, trace_jtj): the next sync() of any kind
     // picks them up.  The damping loops only need them after their first linearisation.
     // Several ranks.  Replicated mode: the envelope of S and the vectors are summed BEFORE k_finish; every rank
@@ -602,6 +625,7 @@ struct Core {
         do_allreduce(g_c, 2 * P.NS + 8);             // [g_c | diagU | red_scal], contiguous behind g_red
     }
     void build(const double *zz, double lambda, int scale, bool lazy = false) {
+        pend_build = false;
         build_enqueue(zz, lambda, scale);
         if (mg_subtree) allreduce_vectors();
         else allreduce_system();
@@ -700,6 +724,7 @@ struct Core {
     // pivots of the point blocks and of the reduced system.
     bool near_singular = false;
     bool solve(double &JpJp, double &rJp, double &pp) {
+        ensure_build();
         if (!s_valid) build(zlin.p, lambda_lin, scale_lin);   // the factorisation overwrote S
         s_valid = false;
         factor_solve_enqueue();
@@ -947,7 +972,7 @@ static void loop_lm(Core &c, const dbat_hip_options &o, LoopOut &out) {
                 c.accept_trial();
                 lambda = lambda / 10;
                 if (lambda < lambdaMin) lambda = 0;
-                c.build(c.z.p, lambda, 0, true);                              // :189-194
+                c.request_build(lambda, 0);                                   // :189-194 (built when the next solve needs it)
                 f = fNew;
                 break;
             } else {
@@ -968,6 +993,7 @@ static void loop_lm(Core &c, const dbat_hip_options &o, LoopOut &out) {
     out.res.push_back(std::sqrt(2 * f));                                      // :242
     out.iters = n;
     out.f_final = f;
+    c.settle_lin_point();
 }
 
 // lsa/levenberg_marquardt_powell.m:60-230, dogleg :232-335
@@ -1034,7 +1060,7 @@ static void loop_lmp(Core &c, const dbat_hip_options &o, double delta0, LoopOut 
             if (delta > npGN) delta = delta / std::exp2(std::ceil(std::log2(delta / npGN)));
         } else {
             c.accept_trial();
-            c.build(c.z.p, 0.0, 1, true);
+            c.request_build(0.0, 1);
             f = ft;
             have_gn = false;
             if (rho >= o.rho_good) delta = delta * 2;
@@ -1055,6 +1081,7 @@ static void loop_lmp(Core &c, const dbat_hip_options &o, double delta0, LoopOut 
     out.aux.insert(out.aux.end(), steps.begin(), steps.end());
     out.iters = n;
     out.f_final = f;
+    c.settle_lin_point();
 }
 
 }  // namespace dbat
@@ -1332,6 +1359,7 @@ int dbat_hip_gradient(dbat_hip_handle *h, double *g) {
     if (!h || !g || !h->core->have_lin) { g_err = "no linearisation"; return DBAT_HIP_EINVAL; }
     Core &c = *h->core;
     DeviceGuard dev_guard(c.device);
+    c.ensure_build();                                 // (a linearisation the damping loop left to whoever needs it)
     c.gradient(c.vtmp.p);
     c.z_to_x(c.vtmp.p, g);
     return DBAT_HIP_OK;
@@ -1343,6 +1371,7 @@ int dbat_hip_colnorms(dbat_hip_handle *h, double *Jn) {
     if (!h || !Jn || !h->core->have_lin) { g_err = "no linearisation"; return DBAT_HIP_EINVAL; }
     Core &c = *h->core;
     DeviceGuard dev_guard(c.device);
+    c.ensure_build();                                 // (a linearisation the damping loop left to whoever needs it)
     c.colnorm2(c.vtmp.p);
     c.z_to_x(c.vtmp.p, Jn);
     for (int64_t i = 0; i < c.P.n; ++i) Jn[i] = std::sqrt(Jn[i]);
@@ -1355,6 +1384,7 @@ int dbat_hip_jtimes_sqnorm(dbat_hip_handle *h, const double *v, double *sqnorm) 
     if (!h || !v || !sqnorm || !h->core->have_lin) { g_err = "no linearisation"; return DBAT_HIP_EINVAL; }
     Core &c = *h->core;
     DeviceGuard dev_guard(c.device);
+    c.ensure_build();                                 // (a linearisation the damping loop left to whoever needs it)
     HIPCHK(hipMemsetAsync(c.vtmp.p, 0, c.P.NZ * 8, c.stream));
     if (c.P.n) {
         HIPCHK(hipMemcpyAsync(c.xbuf.p, v, c.P.n * 8, hipMemcpyHostToDevice, c.stream));
@@ -1526,6 +1556,13 @@ int dbat_hip_bench_step(dbat_hip_handle *h, double lambda, int32_t scale_columns
             HIPCHK(hipEventElapsedTime(&t, c.kev[2 * i], c.kev[2 * i + 1]));
             ms[4 + i] = t;
         }
+        ms[8] = ms[9] = ms[10] = ms[11] = 0.0;
+        if (c.mg_subtree && c.multi() && c.use_perm) {      // domain sharding: the three parts of the factorisation
+            float t = 0;
+            HIPCHK(hipEventElapsedTime(&t, c.kev[2], c.kev[8])); ms[8] = t;       // own domain + shares of the top tiles
+            HIPCHK(hipEventElapsedTime(&t, c.kev[8], c.kev[9])); ms[9] = t;       // all-reduce of the top tiles
+            HIPCHK(hipEventElapsedTime(&t, c.kev[9], c.kev[3])); ms[10] = t;      // top separators + backward substitution
+        }
     }
     return DBAT_HIP_OK;
     API_CATCH
@@ -1600,6 +1637,12 @@ int dbat_hip_info(const dbat_hip_handle *h, int64_t *info) {
     const Core &c = *h->core;
     info[0] = c.P.NS; info[1] = c.nb; info[2] = c.P.max_k; info[3] = c.nobs;
     info[4] = c.P.pt_hi - c.P.pt_lo; info[5] = c.P.BT; info[6] = c.P.ncolmax; info[7] = c.ntiles;
+    info[8] = c.mg_subtree ? 1 : 0;
+    info[9] = c.mg_subtree ? c.dfchol.top_tiles_count() : (c.P.nranks > 1 ? c.pk_s_count : 0);   // doubles summed in / before the factorisation
+    info[10] = c.P.nranks > 1 ? (c.mg_subtree ? 2 * c.P.NS + 8 : 3 * c.P.NS + 8) : 0;          // ... and as vectors per linearisation
+    info[11] = c.mg_subtree ? c.P.nd.n_top_cams : 0;
+    info[12] = c.use_perm ? c.dfchol.nT : 0;
+    info[13] = c.mg_subtree ? c.dfchol.ntasks : 0; info[14] = c.mg_subtree ? c.dfchol.ntasksB : 0; info[15] = 0;
     return DBAT_HIP_OK;
 }
 

@@ -297,15 +297,22 @@ int  dbat_hip_forwintersect(dbat_hip_handle *h, const double *x, const uint8_t *
  * residual } then single kernels { the Schur kernel alone (k_build_sig, or the
  * tile kernel k_build_tile3 / k_build_tile2 where the signature groups are too
  * short, or k_build when nothing is tiled; dbat_hip_build_kernel_name says which),
- * k_chol_df incl. its flag reset, the back-substitution kernels, k_residual_cm }. */
+ * k_chol_df incl. its flag reset, the back-substitution kernels, k_residual_cm },
+ * then (several ranks, domain sharding; else 0) { factorisation of the rank's own domain
+ * + its shares of the top tiles, the all-reduce of the top tiles as the stream sees it,
+ * top separators + backward substitution, 0 }.  ms[12]. */
 int  dbat_hip_bench_step(dbat_hip_handle *h, double lambda, int32_t scale_columns, double *ms);
 /* load x into the handle (device resident) before bench steps */
 int  dbat_hip_set_x(dbat_hip_handle *h, const double *x);
 /* sizes of the internal layout, for roofline accounting:
  * info[0]=NS (reduced system order) info[1]=#batches info[2]=max obs per point
  * info[3]=obs in this shard info[4]=points in this shard info[5]=batch size
- * info[6]=max camera-side columns per observation info[7]=#tiles */
-int  dbat_hip_info(const dbat_hip_handle *h, int64_t *info /*[8]*/);
+ * info[6]=max camera-side columns per observation info[7]=#tiles
+ * several ranks: info[8]=1 domain sharding (0: replicated factorisation) info[9]=doubles of the reduced
+ * system summed per factorisation (top tiles / the envelope) info[10]=doubles summed as vectors per
+ * linearisation info[11]=images in the top separators info[12]=tile rows of the factor
+ * info[13], info[14]=tasks of the two launches of the factorisation; info[15]=0 */
+int  dbat_hip_info(const dbat_hip_handle *h, int64_t *info /*[16]*/);
 
 /* Host only (no GPU): statistics of the layout the plan gives this problem (this shard), so that a test
  * can tell which code path of the signature kernel a scene exercises.  st[16]:

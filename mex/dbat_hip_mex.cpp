@@ -110,7 +110,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
         // posterior covariance blocks (bundle_cov.m 'CEO','CIO','COP') at the result:
         // plhs[11] 6 x 6 x nImages, plhs[12] nIOu x nIOu (IO unknowns in x order), plhs[13] 3 x 3 x nOP
         const mwSize dE[3] = {6, 6, (mwSize)pb.n_images}, dP[3] = {3, 3, (mwSize)pb.n_points};
-        int64_t inf[8];
+        int64_t inf[16];
         dbat_hip_info(h, inf);
         const mwSize nIOu = (mwSize)(inf[0] - 6 * (int64_t)pb.n_images);
         plhs[11] = mxCreateNumericArray(3, dE, mxDOUBLE_CLASS, mxREAL);
