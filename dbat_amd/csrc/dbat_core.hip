@@ -168,7 +168,7 @@ struct Core {
     bool s_valid = false;      // S holds an unfactorised reduced system
     bool s_dense_dirty = true; // S may hold non-zeros outside its envelope (fresh allocation, dense inverse)
     // counters
-    int n_res_evals = 0, n_lin = 0, n_solves = 0;
+    int n_res_evals = 0, n_lin = 0, n_solves = 0, n_trace_only = 0;
 
     ~Core() {
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
@@ -624,9 +624,16 @@ struct Core {
         if (!multi()) return;
         do_allreduce(g_c, 2 * P.NS + 8);             // [g_c | diagU | red_scal], contiguous behind g_red
     }
-    void build(const double *zz, double lambda, int scale, bool lazy = false) {
+    // trace_only: the linearisation is wanted for trace(J'J) alone (Levenberg-Marquardt's lambda0): the signature
+    // kernel stops after the per-point sums (squared column norms), the reduced system is NOT formed -- a third of
+    // a build.  The handle has no linearisation afterwards (lambda_lin = NaN: the loop builds the damped system).
+    void build(const double *zz, double lambda, int scale, bool lazy = false, bool trace_only = false) {
         pend_build = false;
-        build_enqueue(zz, lambda, scale);
+        trace_only = trace_only && use_sig && ntiles > 0;
+        const int ablate0 = d.ablate;
+        if (trace_only) d.ablate |= 64;
+        try { build_enqueue(zz, lambda, scale); } catch (...) { d.ablate = ablate0; throw; }
+        d.ablate = ablate0;
         if (mg_subtree) allreduce_vectors();
         else allreduce_system();
         finish_enqueue(zz, lambda, scale);           // also: trace(J'J) of the camera part and red_scal -> mailbox
@@ -634,11 +641,11 @@ struct Core {
         cams_at_lin = true;                          // (zlin = zz: k_build_tail)
         lin_pending = true;
         if (!lazy) sync();
-        lambda_lin = lambda;
+        lambda_lin = trace_only ? NAN : lambda;
         scale_lin = scale;
-        have_lin = true;
-        s_valid = true;
-        ++n_lin;
+        have_lin = !trace_only;
+        s_valid = !trace_only;
+        if (!trace_only) ++n_lin; else ++n_trace_only;
     }
     bool replicate_next = false;     // domain mode: the next build sums the whole matrix after k_finish (in-place factorisation)
     // sum of the envelope of S (incl. the right-hand-side row) over the ranks, after k_finish
@@ -942,11 +949,19 @@ static void loop_gm(Core &c, const dbat_hip_options &o, LoopOut &out) {
     out.f_final = f;
 }
 
+// lambda0 (and lambdaMin) given as fractions of trace(J'J)/n with lambda0 >= lambdaMin > 0: the undamped system of
+// the first linearisation is never solved, only its trace is used
+static bool lambda0_needs_trace(const dbat_hip_options &o) {
+    const double l0 = std::fabs(o.lambda0), lm = std::fabs(o.lambda_min);
+    return o.lambda0 < 0 && o.lambda_min < 0 && l0 >= lm && l0 > 0;
+}
+
 // lsa/levenberg_marquardt.m:52-250
 static void loop_lm(Core &c, const dbat_hip_options &o, LoopOut &out) {
     int n = 0;
     double f = c.eval_f(c.z.p, nullptr, nullptr);
-    c.build(c.z.p, 0.0, 0);                                       // :76-82
+    // :76-82.  J at x0 is needed for trace(J'J) here; the first step solves (J'J + lambda0 I), built below
+    c.build(c.z.p, 0.0, 0, false, lambda0_needs_trace(o));
     const double nx = (double)c.P.n;
     double lambda0 = o.lambda0, lambdaMin = o.lambda_min;
     if (lambda0 < 0) lambda0 = std::fabs(lambda0) * c.trace_jtj / nx;       // :88-90
@@ -1405,7 +1420,7 @@ int dbat_hip_solve(dbat_hip_handle *h, const dbat_hip_options *opt, double *x, d
     if (opt->store_trace && !trace) { g_err = "store_trace without a trace buffer"; return DBAT_HIP_EINVAL; }
     Core &c = *h->core;
     DeviceGuard dev_guard(c.device);
-    c.n_res_evals = c.n_lin = c.n_solves = 0;
+    c.n_res_evals = c.n_lin = c.n_solves = c.n_trace_only = 0;
     c.x_to_z(x, c.z.p);
     c.lambda_lin = NAN;
     LoopOut out;

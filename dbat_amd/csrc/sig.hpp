@@ -331,6 +331,9 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
             }
         }
         lap(2);
+        // trace(J'J) only (the first linearisation of levenberg_marquardt.m:76-95 serves lambda0 = c trace / n and
+        // nothing else): the squared column norms of the points are out, the Schur complement is not wanted
+        if (d.ablate & 64) continue;
         // ------------------------------------------------------------ pass 2: lane = observation
         mfma_d4 acc[NBLK];
 #pragma unroll

@@ -207,17 +207,21 @@ def test_plan_layout_stats_long_groups():
 
 
 def test_lm_count_stability_helper():
-    """helpers.oracle_lm_reordered: the oracle's LM loop with the rows of r and J in another order
-    converges to the same x; its iteration COUNT is stable on some problems and rounding noise on
-    others (the fact check_history builds on)."""
+    """Why the parity tests do not assert Levenberg-Marquardt's iteration COUNT (check_history): in the
+    reference's loop (levenberg_marquardt.m:166,217) the last accept/reject decisions `fNew < f` compare
+    objective values that differ by rounding noise -- relative margins of 1e-13 ... 1e-16 in every case the
+    GPU tests use -- so the count changes when the rows of r and J are merely summed in another order, while
+    the converged x does not.  helpers.lm_count_is_stable asserts the count only where the margins are large."""
     import dbat_oracle as o
-    from helpers import synth_struct, oracle_lm_reordered, lm_count_is_stable, relerr
-    s, _ = synth_struct('tiny', 'imagevar')
-    ro, ok, ito, s0, E = o.bundle(s, 'lm')
-    x, code, n, rr, lam = oracle_lm_reordered(s, 1)
-    assert code == 0 and relerr(x, E.x) < 1e-9
-    assert lm_count_is_stable(s, ito)
+    from helpers import synth_struct, oracle_lm_reordered, lm_decision_margins, lm_count_is_stable, relerr
     s, _ = synth_struct('tiny', 'plain')
     ro, ok, ito, s0, E = o.bundle(s, 'lm')
-    counts = {oracle_lm_reordered(s, sd)[2] for sd in (1, 2, 3)} | {ito}
+    n, margin, term = lm_decision_margins(s)
+    assert n == ito and margin < 1e-12 and term > 1.5
+    assert not lm_count_is_stable(s, ito)
+    counts = {ito}
+    for sd in (1, 2, 3):
+        x, code, n2, rr, lam = oracle_lm_reordered(s, sd)
+        assert code == 0 and relerr(x, E.x) < 1e-9
+        counts.add(n2)
     assert len(counts) > 1, counts       # fixed IO, well conditioned -- and still not a property of the problem
