@@ -103,6 +103,7 @@ SYMBOLS = {
     'dbat_hip_set_allreduce': (C.c_int, [_H, ALLREDUCE_FN, C.c_void_p]),
     'dbat_hip_owned_mask': (C.c_int, [_H, _bp]),
     'dbat_hip_forwintersect': (C.c_int, [_H, _dp, _bp, _dp]),
+    'dbat_hip_resect': (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_int64), _dp, _dp, C.POINTER(C.c_int64), _ip, _dp, _dp]),
     'dbat_hip_bench_step': (C.c_int, [_H, C.c_double, C.c_int32, _dp]),
     'dbat_hip_set_x': (C.c_int, [_H, _dp]),
     'dbat_hip_info': (C.c_int, [_H, C.POINTER(C.c_int64)]),
@@ -452,6 +453,22 @@ def plan_point_owner(s, shard_count):
     owner = np.full(s.OP.val.shape[1], -1, np.int32)
     check(lib.dbat_hip_plan_point_owner(C.byref(p), owner.ctypes.data_as(_ip)))
     return owner
+
+
+def resect_poses(pt_start, X, xn, tri_start, tri, device=0):
+    """dbat_hip_resect: best 3 x 4 camera matrix (n, 3, 4) and rms (n) per camera from its candidate triangles."""
+    lib = load()
+    n = len(pt_start) - 1
+    ps = np.ascontiguousarray(pt_start, np.int64)
+    ts = np.ascontiguousarray(tri_start, np.int64)
+    Xf = np.ascontiguousarray(np.asarray(X, float).flatten('F'))
+    xf = np.ascontiguousarray(np.asarray(xn, float).flatten('F'))
+    tf = np.ascontiguousarray(np.asarray(tri, np.int32).reshape(-1))
+    P, rms = np.empty(12 * n), np.empty(n)
+    i64p = C.POINTER(C.c_int64)
+    check(lib.dbat_hip_resect(int(device), n, ps.ctypes.data_as(i64p), dptr(Xf), dptr(xf), ts.ctypes.data_as(i64p),
+                              tf.ctypes.data_as(_ip), dptr(P), dptr(rms)))
+    return P.reshape(n, 4, 3).transpose(0, 2, 1), rms
 
 
 def plan_layout_stats(s, shard_rank=0, shard_count=1):

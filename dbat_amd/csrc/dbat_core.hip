@@ -18,6 +18,7 @@
 #include "kernels.hpp"
 #include "sig.hpp"
 #include "plan.hpp"
+#include "resect.hpp"
 
 namespace dbat {
 
@@ -1621,6 +1622,37 @@ int dbat_hip_forwintersect(dbat_hip_handle *h, const double *x, const uint8_t *s
         const int64_t r = P.pt_rank[p];
         for (int k = 0; k < 3; ++k) OP[3 * p + k] = seen[r] ? tmp[3 * r + k] : nan;
     }
+    return DBAT_HIP_OK;
+    API_CATCH
+}
+
+int dbat_hip_resect(int32_t device, int32_t n_images, const int64_t *pt_start, const double *X, const double *xn,
+                    const int64_t *tri_start, const int32_t *tri, double *P, double *rms) {
+    API_TRY
+    if (n_images < 0 || !pt_start || !tri_start || !P || !rms) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_err = "no HIP device: the dbat_hip core has no CPU path"; return DBAT_HIP_EDEVICE; }
+    if (device < 0 || device >= ndev) { g_err = "bad device index"; return DBAT_HIP_EINVAL; }
+    if (n_images == 0) return DBAT_HIP_OK;
+    const int64_t npt = pt_start[n_images], ntri = tri_start[n_images];
+    for (int c = 0; c < n_images; ++c)
+        if (pt_start[c + 1] < pt_start[c] || tri_start[c + 1] < tri_start[c]) { g_err = "ranges must ascend"; return DBAT_HIP_EINVAL; }
+    for (int c = 0; c < n_images; ++c)
+        for (int64_t t = 3 * tri_start[c]; t < 3 * tri_start[c + 1]; ++t)
+            if (tri[t] < 0 || tri[t] >= pt_start[c + 1] - pt_start[c]) { g_err = "triangle index outside the camera's points"; return DBAT_HIP_EINVAL; }
+    if ((npt > 0 && (!X || !xn)) || (ntri > 0 && !tri)) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
+    DeviceGuard dev_guard(device);
+    DevBuf<int64_t> dps, dts;
+    DevBuf<double> dX, dx, dP, dr;
+    DevBuf<int32_t> dtri;
+    dps.upload(std::vector<int64_t>(pt_start, pt_start + n_images + 1));
+    dts.upload(std::vector<int64_t>(tri_start, tri_start + n_images + 1));
+    dX.upload(std::vector<double>(X, X + 3 * npt)); dx.upload(std::vector<double>(xn, xn + 2 * npt));
+    dtri.upload(std::vector<int32_t>(tri, tri + 3 * ntri));
+    dP.alloc((size_t)12 * n_images); dr.alloc((size_t)n_images);
+    LAUNCHK(k_resect, dim3((unsigned)n_images), dim3(64), 0, (hipStream_t)nullptr, n_images, dps.p, dX.p, dx.p, dts.p, dtri.p, 1, dP.p, dr.p);
+    HIPCHK(hipMemcpy(P, dP.p, (size_t)12 * n_images * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(rms, dr.p, (size_t)n_images * sizeof(double), hipMemcpyDeviceToHost));
     return DBAT_HIP_OK;
     API_CATCH
 }

@@ -425,16 +425,17 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
                             atomic_add_f64(pio + 2, wa2 * r22);
                         }
                 }
+                // Z = W R = E' (B R): the 2 x 3 block B R once per observation (12 operations), then one 2-term
+                // product per element of Z (36) -- instead of W = E'B (36) followed by W R (36)
+                const double br00 = B[0][0] * r00 + B[0][1] * r10 + B[0][2] * r20, br01 = B[0][1] * r11 + B[0][2] * r21, br02 = B[0][2] * r22;
+                const double br10 = B[1][0] * r00 + B[1][1] * r10 + B[1][2] * r20, br11 = B[1][1] * r11 + B[1][2] * r21, br12 = B[1][2] * r22;
 #pragma unroll
                 for (int a = 0; a < 6; ++a) {
                     const double m = ((eo_est >> a) & 1u) ? 1.0 : 0.0;
                     const double e0 = A[0][a] * w0 * m, e1 = A[1][a] * w1 * m;
-                    const double wa0 = e0 * B[0][0] + e1 * B[1][0];
-                    const double wa1 = e0 * B[0][1] + e1 * B[1][1];
-                    const double wa2 = e0 * B[0][2] + e1 * B[1][2];
-                    Zr[a][0] = wa0 * r00 + wa1 * r10 + wa2 * r20;
-                    Zr[a][1] = wa1 * r11 + wa2 * r21;
-                    Zr[a][2] = wa2 * r22;
+                    Zr[a][0] = e0 * br00 + e1 * br10;
+                    Zr[a][1] = e0 * br01 + e1 * br11;
+                    Zr[a][2] = e0 * br02 + e1 * br12;
                 }
                 y3[0] = gY[0]; y3[1] = gY[1]; y3[2] = gY[2];
             }

@@ -224,6 +224,62 @@ def resect(s0, cams='all', cpId=None, n=1, v=0.0, chkId=None):
     return s, rms, fail
 
 
+def resect_hip(s0, cams='all', cpId=None, n=1, v=0.0, chkId=None, device=0):
+    """resect() with the per-camera work on the GPU (dbat_hip_resect: one wave per camera solves the
+    quartics of the candidate triangles and scores the poses against the check points).  The host keeps
+    what resect.m does with MATLAB built-ins around it: lens correction, the choice of the triangles,
+    camera centre and Euler angles from the winning 3 x 4 matrix.  Same arguments and results."""
+    from . import _hip
+    from .dbatstruct import copy_struct
+    s = copy_struct(s0)
+    nc = s0.EO.val.shape[1]
+    cams = list(range(nc)) if isinstance(cams, str) and cams == 'all' else list(cams)
+    cpId = np.asarray(cpId)
+    chkId = s0.OP.id if chkId is None else np.asarray(chkId)
+    keepId = np.union1d(cpId, chkId)
+    xy = lenscorr1(s0)
+    pt_start, tri_start, Xs, xs, tris = [0], [0], [], [], []
+    for ci in cams:
+        IO = s0.IO.val[:, ci]
+        rows = np.flatnonzero(s0.IP.cam == ci)
+        ids = s0.OP.id[s0.IP.pt[rows]]
+        is_cp = np.isin(ids, cpId)
+        if np.count_nonzero(is_cp) > 3:
+            T, A = largesttriangle(xy[:, rows[is_cp]])
+            take = (np.arange(len(A)) < n) & (A >= v * A[0])
+            tryId = ids[is_cp][T[take]]
+        elif np.count_nonzero(is_cp) == 3:
+            tryId = ids[is_cp][None, :]
+        else:
+            tryId = np.zeros((0, 3), int)
+        keep = np.isin(ids, keepId)
+        pt2 = xy[:, rows[keep]]
+        xs.append(np.stack([(pt2[0] - IO[1]) / -IO[0], (pt2[1] - IO[2]) / -IO[0]]))   # K\homogeneous(pt2)
+        Xs.append(s0.OP.val[:, s0.IP.pt[rows[keep]]])
+        visId = ids[keep]
+        for useId in tryId:          # pm_resect_3pt takes the three points in the order they are seen (use mask)
+            tris.append(np.flatnonzero(np.isin(visId, useId)))
+        pt_start.append(pt_start[-1] + int(np.count_nonzero(keep)))
+        tri_start.append(len(tris))
+    for t in tris:
+        if len(t) != 3:
+            raise ValueError('Can only use 3 points for resection')
+    P, rms = _hip.resect_poses(pt_start, np.concatenate(Xs, 1) if Xs else np.zeros((3, 0)),
+                               np.concatenate(xs, 1) if xs else np.zeros((2, 0)), tri_start,
+                               np.array(tris, np.int32).reshape(-1, 3), device=device)
+    fail = False
+    rms = np.where(np.isfinite(rms), rms, np.nan)
+    for k, ci in enumerate(cams):
+        if np.all(np.isfinite(P[k])):
+            nv = np.linalg.svd(P[k])[2][-1]          # euclidean(null(P)), as resect() above
+            s.EO.val[:3, ci] = nv[:3] / nv[3]
+            s.EO.val[3:6, ci] = derotmat3d(P[k][:, :3])
+        else:
+            fail = True
+            s.EO.val[:6, ci] = np.nan
+    return s, rms, fail
+
+
 def _rot(ang):
     so, co = np.sin(ang[0]), np.cos(ang[0])
     sp, cp = np.sin(ang[1]), np.cos(ang[1])

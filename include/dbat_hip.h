@@ -287,6 +287,22 @@ int  dbat_hip_owned_mask(const dbat_hip_handle *h, uint8_t *mask);
  * rays becomes NaN.  Collective on a sharded handle. */
 int  dbat_hip_forwintersect(dbat_hip_handle *h, const double *x, const uint8_t *skip, double *OP);
 
+/* [s,rms,fail] = resect(s0, cams, cpId, n, v, chkId) (photogrammetry/resect.m:42-131) with the per-camera work on
+ * the device: for every camera the candidate triangles of control points are solved by the three-point resection of
+ * pm_resect_3pt.m:27-147 (Grunert's quartic, up to four poses each, camera behind the image plane as resect.m:105
+ * asks for) and scored by the rms reprojection error over the camera's check points; the best pose wins, a later
+ * triangle only if strictly better.  No handle: the inputs are what resect.m has after its MATLAB-side preparation.
+ *   pt_start  [n_images+1]  range of every camera's check points in X / xn
+ *   X         [3*total]     object coordinates of the check points, per camera
+ *   xn        [2*total]     their lens-corrected, normalised image coordinates K \ [x; y; 1] (resect.m:95-99)
+ *   tri_start [n_images+1]  range of every camera's candidate triangles in tri
+ *   tri       [3*total]     three indices into the camera's point range per triangle, in trial order
+ *   P         [12*n_images] out: best 3 x 4 camera matrix (column-major), NaN if the camera has no pose
+ *   rms       [n_images]    out: its rms error, Inf if none
+ * Returns DBAT_HIP_EDEVICE without a HIP device (no CPU path). */
+int  dbat_hip_resect(int32_t device, int32_t n_images, const int64_t *pt_start, const double *X, const double *xn,
+                     const int64_t *tri_start, const int32_t *tri, double *P, double *rms);
+
 /* ---- measurement hooks -------------------------------------------------- */
 
 /* One benchmark step = one Levenberg-Marquardt iteration's device work at
