@@ -208,6 +208,8 @@ def main():
                  'residual_evals': int(res.n_residual_evals), 'solves': int(res.n_solves),
                  'time_s': float(res.time_s), 'wall_s': t_solve, 'sigma0': float(res.sigma0),
                  'it_per_s': res.iters / res.time_s if res.time_s > 0 else None,
+                 'trace_only_linearizations': int(res.n_trace_only),
+                 'stage_s': dict(zip(('linearise', 'factor_solve', 'backsub', 'residual', 'other'), [float(v) for v in res.stage_s])),
                  'ms_per_linearization': res.time_s / max(res.n_linearizations, 1) * 1e3}
 
     if rank == 0:

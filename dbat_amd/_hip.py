@@ -65,6 +65,7 @@ class Result(C.Structure):
         ('code', C.c_int32), ('iters', C.c_int32), ('n_res', C.c_int32), ('n_damp', C.c_int32),
         ('n_trace', C.c_int32), ('sigma0', C.c_double), ('time_s', C.c_double),
         ('n_residual_evals', C.c_int32), ('n_linearizations', C.c_int32), ('n_solves', C.c_int32),
+        ('n_trace_only', C.c_int32), ('stage_s', C.c_double * 5),
     ]
 
 

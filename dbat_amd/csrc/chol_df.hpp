@@ -368,7 +368,7 @@ struct DfView {
     const double *S;            // != nullptr (compact tiles): the tasks fetch their tile of P S P' from S themselves
     int64_t ldS;                //   (natural order, lower triangle, right-hand side in row n_nat) instead of a gather launch
     int n_nat;
-    int no_l2;                  // default 1: tiles with agent-scope loads everywhere; DBAT_HIP_DF_L2=1 reads finished tiles through the L2
+    int no_l2;                  // 1: tiles with agent-scope loads everywhere (0 would read finished tiles through the L2: no gain measured)
 };
 
 // Backward substitution task of panel j:  q_j = Linv_j' (y_j - sum_{i>j} L(i,j)' q_i).
@@ -784,33 +784,6 @@ __global__ void k_df_reset(int *__restrict__ info, int *__restrict__ ctl, unsign
     if (i < nq) qflag[i] = DF_SENTINEL;
 }
 
-// S (natural order, dense column-major lower triangle + right-hand-side row n)
-// -> the non-zero tiles of P S P' in compact storage.  One workgroup per tile.
-__global__ __launch_bounds__(256) void k_gather_tiles(const double *__restrict__ S, int64_t ldS, int n_nat, int nT,
-                                                      const int *__restrict__ iperm, const DfTask *__restrict__ tile_ij,
-                                                      double *__restrict__ tiles, int *__restrict__ info,
-                                                      int *__restrict__ ctl, unsigned long long *__restrict__ qflag) {
-    const DfTask tk = tile_ij[blockIdx.x];
-    // what k_chol_df expects to find reset: error code, task counter / abort flag, "not solved yet" in q
-    if (blockIdx.x == 0 && threadIdx.x < 4) { if (threadIdx.x == 0) *info = 0; else ctl[threadIdx.x - 1] = 0; }
-    if (tk.i == tk.k && threadIdx.x < 64) qflag[64 * tk.k + threadIdx.x] = DF_SENTINEL;
-    double *T = tiles + (size_t)blockIdx.x * 4096;
-    for (int idx = threadIdx.x; idx < 4096; idx += 256) {
-        const int c = idx >> 6, r = idx & 63;
-        const int C = 64 * tk.k + c;
-        const int cn = iperm[C];                        // < 0: padding column (blocks start on tile boundaries)
-        double v = 0.0;
-        if (tk.i == nT) { if (r == 0 && cn >= 0) v = S[(int64_t)cn * ldS + n_nat]; }
-        else {
-            const int R = 64 * tk.i + r;
-            const int rn = iperm[R];
-            if (cn >= 0 && rn >= 0) v = rn >= cn ? S[(int64_t)cn * ldS + rn] : S[(int64_t)rn * ldS + cn];
-            else if (R == C) v = 1.0;
-        }
-        T[idx] = v;
-    }
-}
-
 // Host side: schedule (tile pattern, task list, tables) and launch.
 //   setup_inplace   factor S where it lies, natural order, envelope pattern
 //   setup_permuted  nested-dissection order of the cameras + symbolic tile
@@ -835,7 +808,7 @@ struct DataflowChol {
     std::vector<DfJob> h_tasksB;
     DfTask *d_tile_ij = nullptr;
     int nparts = 0;                                     // partial-sum slots of the helper tasks
-    bool env_l2 = false, env_gather = false;            // DBAT_HIP_DF_L2 / DBAT_HIP_DF_GATHER, read at set-up
+    bool env_l2 = false;                                // finished tiles through the L2: measured in round 2, no gain (kept off)
     double *d_parts = nullptr;
     double *d_tiles = nullptr, *d_qperm = nullptr;
     long long *d_trace = nullptr;                       // optional per-task timestamps (DBAT_HIP_DF_TRACE=file)
@@ -887,7 +860,7 @@ struct DataflowChol {
         auto has = [&](int i, int k) { return (rowbits[(size_t)i * W + (k >> 6)] >> (k & 63)) & 1ull; };
         const int split_min = getenv("DBAT_HIP_DF_SPLIT") ? std::max(atoi(getenv("DBAT_HIP_DF_SPLIT")), 2) : 96;
         const int chunk = getenv("DBAT_HIP_DF_CHUNK") ? std::max(atoi(getenv("DBAT_HIP_DF_CHUNK")), 1) : 32;
-        const bool merge = permuted && !getenv("DBAT_HIP_DF_NOMERGE");     // compact tiles only (see k_chol_df)
+        const bool merge = permuted;                            // compact tiles only (see k_chol_df)
         auto top = [&](int k) { return phase != 0 && col_owner[k] < 0; };
         auto mine = [&](int k) { return phase == 0 || col_owner[k] == rank; };
         int dom_lo = nT, dom_hi = 0;                            // this rank's domain: a contiguous range of tile columns
@@ -952,7 +925,7 @@ struct DataflowChol {
         std::vector<DfJob> &jobs = L.jobs;
         const std::vector<int> &dptr = L.dptr, &dep = L.dep, &own = L.own, &sumjob = L.sumjob;
         const int nt = (int)jobs.size();
-        if (nt == 0 || getenv("DBAT_HIP_DF_COLMAJOR")) return;
+        if (nt == 0) return;
         auto is_helper = [&](int t) { return jobs[t].np < 0; };
         auto is_share = [&](int t) { return (jobs[t].mode & 4) != 0; };
         auto is_diag = [&](int t) { return jobs[t].np >= 0 && jobs[t].i == jobs[t].k && !is_share(t); };
@@ -1112,7 +1085,7 @@ struct DataflowChol {
         if (hipMalloc(&d_ctl, 4 * sizeof(int)) != hipSuccess) return false;
         (void)hipMemset(d_flags, 0, ((size_t)(nT + 1) * nT + (size_t)nparts + (size_t)nT) * sizeof(int));
         (void)hipMemset(d_ctl, 0, 4 * sizeof(int));
-        env_l2 = getenv("DBAT_HIP_DF_L2") != nullptr; env_gather = getenv("DBAT_HIP_DF_GATHER") != nullptr;
+        env_l2 = false;
         epoch = 0;
         return true;
     }
@@ -1255,16 +1228,12 @@ struct DataflowChol {
         V.toff = d_toff; V.rowbits = d_rowbits; V.W = W; V.no_l2 = env_l2 ? 0 : 1;     // measured: no gain from the L2 path
         double *qflag;
         V.S = nullptr; V.ldS = lda; V.n_nat = n_nat;
-        if (permuted && !env_gather) {
+        if (permuted) {
             // every task fetches its own tile of P S P' from S (the rows of the right-hand-side tiles below
             // the first stay zero from the set-up): a small reset instead of the gather launch
             hipLaunchKernelGGL(k_df_reset, dim3((nT * CHOL_NB + 255) / 256), dim3(256), 0, stream, info_dev, d_ctl,
                                reinterpret_cast<unsigned long long *>(d_qperm), nT * CHOL_NB);
             V.base = d_tiles; V.ld = 64; V.iperm = d_iperm; qflag = d_qperm; V.S = A;
-        } else if (permuted) {      // the gather also resets info, the task counter and the q flags (every tile row has its diagonal tile)
-            hipLaunchKernelGGL(k_gather_tiles, dim3(ntiles), dim3(256), 0, stream, A, lda, n_nat, nT, d_iperm, d_tile_ij, d_tiles,
-                               info_dev, d_ctl, reinterpret_cast<unsigned long long *>(d_qperm));
-            V.base = d_tiles; V.ld = 64; V.iperm = d_iperm; qflag = d_qperm;
         } else {
             (void)hipMemsetAsync(info_dev, 0, sizeof(int), stream);
             (void)hipMemsetAsync(d_ctl, 0, 4 * sizeof(int), stream);

@@ -126,7 +126,7 @@ struct Core {
     DevBuf<CamRec> cams, cams_f;                     // camera records at the linearisation point / at the last objective evaluation
     bool cams_at_lin = false;                        // cams holds the records of zlin
     // experiment switches, read once at set-up (never in the per-iteration path)
-    bool env_dense_allreduce = false, env_camn_mfma = false;
+
     const char *env_df_trace = nullptr;
     DevBuf<unsigned> gctr;                           // tickets of the in-kernel grid sums (zero between launches)
     DevBuf<double> gpart, rpart;                     // their per-block partial sums; sink of k_residual's (unused) sums
@@ -134,10 +134,10 @@ struct Core {
     DevBuf<double> red;      // [S | g_red | g_c | diagU | scal(8)]
     DevBuf<double> jn2c, dscale, rhs, Vinv, gp, jn2p, partial, scal;
     DevBuf<int> info;
-    DevBuf<double> ywork, linv, ldiag;
+    DevBuf<double> linv, ldiag;
     DataflowChol dfchol;                // persistent task-graph Cholesky, cameras in nested-dissection order (chol_df.hpp)
     DataflowChol dfchol_ip;             // the same in place, natural order (posterior covariance: L must end up in S)
-    bool use_df = true, use_perm = true;
+    bool use_perm = true;
     bool mg_subtree = false;            // several ranks, domain sharding (nd.hpp): local factorisation + all-reduce of the top tiles
     DevBuf<uint8_t> piv_have;           // ... pivots of the reduced system that this rank computes
     bool chol_in_place = false;         // next factorisation must leave L in S
@@ -174,6 +174,7 @@ struct Core {
     ~Core() {
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         for (auto &e : kev) if (e) (void)hipEventDestroy(e);
+        for (auto &e : st_ev) if (e) (void)hipEventDestroy(e);
         dfchol.release(); dfchol_ip.release();
         if (hpin) (void)hipHostFree(hpin);
         if (nccl) (void)ncclCommDestroy(nccl);
@@ -218,8 +219,6 @@ struct Core {
         d.o_cam = o_cam.p; d.o_pt = o_pt.p; d.o_uv = o_uv.p; d.o_w = P.uniform_w ? nullptr : o_w.p;
         d.o_seg = o_seg.p; d.o_row = o_row.p; d.batch_start = batch_start.p;
         d.CMAX = P.CMAX; d.ablate = getenv("DBAT_HIP_ABLATE") ? atoi(getenv("DBAT_HIP_ABLATE")) : 0;
-        env_dense_allreduce = getenv("DBAT_HIP_DENSE_ALLREDUCE") != nullptr;
-        env_camn_mfma = getenv("DBAT_HIP_CAMN_MFMA") != nullptr;
         env_df_trace = getenv("DBAT_HIP_DF_TRACE");
         d.ntiles = (int)ntiles; d.o_lc = o_lc.p; d.o_pidx = o_pidx.p;
         tile_order.upload(P.tile_order); d.tile_order = tile_order.p;
@@ -253,12 +252,12 @@ struct Core {
         red_count = s_count + 3 * P.NS + 8;
         red.alloc(red_count);
         S = red.p; g_red = S + s_count; g_c = g_red + P.NS; diagU = g_c + P.NS; red_scal = diagU + P.NS;
-        ywork.alloc(P.NS); ldiag.alloc(P.NS);
+        ldiag.alloc(P.NS);
         {   // envelope of the reduced system from the camera co-visibility graph; IO rows are dense
             std::vector<int> first((size_t)P.NS, 0);
             for (int c = 0; c < P.nc; ++c)
                 for (int k = 0; k < 6; ++k) first[(size_t)6 * c + k] = 6 * P.cam_first[c];
-            if (getenv("DBAT_HIP_DENSE_CHOL") || P.shared_eo) env.build_dense((int)P.NS);   // shared EO: columns couple beyond the co-visibility band
+            if (P.shared_eo) env.build_dense((int)P.NS);   // shared EO: columns couple beyond the co-visibility band
             else env.build((int)P.NS, 6 * P.nc, first);
             {   // packed layout of the envelope for the all-reduce
                 const int NSi = (int)P.NS;
@@ -273,8 +272,9 @@ struct Core {
                 pk_s_count = co[NSi];
                 col_bend.upload(cb); col_off.upload(co);
             }
-            use_df = getenv("DBAT_HIP_BLOCKCHOL") == nullptr;       // the multi-launch BlockChol stays for A/B runs
-            use_perm = use_df && getenv("DBAT_HIP_DF_NOPERM") == nullptr && !P.shared_eo;
+            // nested-dissection order + compact tiles; in place (natural order, envelope pattern) where the factor
+            // must end up in S (posterior covariance) and for shared EO blocks (no camera-wise dissection)
+            use_perm = !P.shared_eo;
             if (!dfchol_ip.setup_inplace(env, ldS)) throw DeviceError{"out of device memory (Cholesky schedule)"};
             if (use_perm) {
                 if (!dfchol.setup_permuted(P.nc, P.nIOu, P.cam_adj.data(), P.cam_adj_words, P.nd, P.rank))
@@ -288,8 +288,7 @@ struct Core {
                 for (int64_t z = 6 * (int64_t)P.nc; z < P.NS; ++z) have[z] = 1;
                 piv_have.upload(have);
             }
-            linv.alloc(std::max({BlockChol::linv_doubles((int)P.NS), dfchol_ip.linv_doubles(),
-                                 use_perm ? dfchol.linv_doubles() : (size_t)0}));
+            linv.alloc(std::max(dfchol_ip.linv_doubles(), use_perm ? dfchol.linv_doubles() : (size_t)0));
         }
         jn2c.alloc(P.NS); dscale.alloc(P.NS); rhs.alloc(P.NS);
         Vinv.alloc((size_t)6 * P.np); gp.alloc((size_t)3 * P.np); jn2p.alloc((size_t)3 * P.np);
@@ -329,16 +328,12 @@ struct Core {
             if (P.with_io) {
                 SET_LDS((k_build_tile2<2, 14, TILE2_PC, TILE2_NBUF>), lds_tile2); SET_LDS((k_build_tile2<3, 14, TILE2_PC, TILE2_NBUF>), lds_tile2);
                 SET_LDS((k_build_tile2<4, 14, TILE2_PC, TILE2_NBUF>), lds_tile2); SET_LDS((k_build_tile2<5, 14, TILE2_PC, TILE2_NBUF>), lds_tile2);
-            } else {
-                SET_LDS((k_build_tile2<2, 6, TILE2_PC, TILE2_NBUF>), lds_tile2); SET_LDS((k_build_tile2<3, 6, TILE2_PC, TILE2_NBUF>), lds_tile2);
-                SET_LDS((k_build_tile2<4, 6, TILE2_PC, TILE2_NBUF>), lds_tile2); SET_LDS((k_build_tile2<5, 6, TILE2_PC, TILE2_NBUF>), lds_tile2);
             }
         }
         lds_tile3 = ((size_t)TILE3_NBUF * 3 * TILE3_PC * TILE_LD + (size_t)256 * 9 + (size_t)256 * 9 + TILE_LD) * sizeof(double);
-        // fixed IO: the variant with two producer groups (DBAT_HIP_TILE3=0 selects k_build_tile2);
-        // it holds at most 64 batch offsets per tile, the plan's default cap is 48
-        use_tile3 = use_tile2 && !P.with_io && !(getenv("DBAT_HIP_TILE3") && atoi(getenv("DBAT_HIP_TILE3")) == 0)
-                    && getenv("DBAT_HIP_TILE_BMAX") == nullptr;
+        // fixed IO: the variant with two producer groups (it holds at most 64 batch offsets per tile, the plan's
+        // cap is 48); self-calibration: k_build_tile2
+        use_tile3 = use_tile2 && !P.with_io;
         if (use_sig) {
 #define SET_SIG(M) SET_LDS((k_build_sig<M, 4, 6>), sig_lds_bytes(4, false)); SET_LDS((k_build_sig<M, 5, 6>), sig_lds_bytes(5, false)); \
                    SET_LDS((k_build_sig<M, 4, 14>), sig_lds_bytes(4, true)); SET_LDS((k_build_sig<M, 5, 14>), sig_lds_bytes(5, true));
@@ -395,11 +390,34 @@ struct Core {
         }
     }
     void mark(int i) { if (timing) HIPCHK(hipEventRecord(kev[i], stream)); }
+    // ---- stage timers of a solve (dbat_hip_result.stage_s): an event where a stage is enqueued; the stream
+    // time between consecutive events goes to the stage of the first.  Events come from a pool that grows
+    // with the longest loop seen; nothing is read back before the loop has ended.
+    std::vector<hipEvent_t> st_ev;
+    std::vector<int> st_id;
+    bool st_on = false;
+    void stage(int id) {
+        if (!st_on) return;
+        if (st_id.size() == st_ev.size()) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); st_ev.push_back(e); }
+        HIPCHK(hipEventRecord(st_ev[st_id.size()], stream));
+        st_id.push_back(id);
+    }
+    void stages_begin() { st_id.clear(); st_on = true; stage(4); }
+    void stages_end(double *out5) {
+        stage(4);
+        st_on = false;
+        HIPCHK(hipStreamSynchronize(stream));
+        for (int i = 0; i < 5; ++i) out5[i] = 0.0;
+        for (size_t i = 0; i + 1 < st_id.size(); ++i) {
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, st_ev[i], st_ev[i + 1]));
+            out5[st_id[i]] += 1e-3 * ms;
+        }
+    }
     // sum of [S | g_red | g_c | diagU | scalars] over the ranks: the envelope of S is packed
     // next to the vectors, one all-reduce, unpacked again
     void allreduce_system() {
         if (!multi()) return;
-        if (env_dense_allreduce) { do_allreduce(red.p, red_count); return; }
         const int64_t nvec = 3 * P.NS + 8;
         if (!pk.p) pk.alloc((size_t)(pk_s_count + nvec));
         LAUNCHK(k_pack_envelope, dim3((unsigned)P.NS), dim3(256), 0, stream, S, ldS, (int)P.NS, env_tail0,
@@ -450,6 +468,7 @@ struct Core {
     }
     void z_to_x(const double *z_dev, double *x_host) {     // collective on a sharded handle
         if (!P.n) return;
+        stage(4);
         z_dev = gathered(z_dev);
         LAUNCHK(k_gather_x, dim3((unsigned)cdiv(P.n, 256)), dim3(256), 0, stream, P.n, x2z.p, z_dev, xbuf.p);
         HIPCHK(hipMemcpyAsync(x_host, xbuf.p, P.n * 8, hipMemcpyDeviceToHost, stream));
@@ -467,11 +486,13 @@ struct Core {
     // ---- K2: f = 0.5 r'r at zz (all ranks' sum).  Optionally store r.
     // f at x + alpha p (x, p as given; the point goes to out): the trial point and its camera records in one launch
     double eval_f_step(const double *x, double alpha, const double *pdir, double *out) {
+        stage(3);
         if ((int64_t)cdiv(P.NZ, 256) < P.nc) { axpby(1.0, x, alpha, pdir, out); return eval_f(out, nullptr, nullptr); }
         LAUNCHK(k_axpby_cams, dim3((unsigned)cdiv(P.NZ, 256)), dim3(256), 0, stream, d, 1.0, x, alpha, pdir, out, cams_f.p);
         return eval_f(out, nullptr, nullptr, true);
     }
     double eval_f(const double *zz, double *r_w_out, double *r_unw_out, bool cams_ready = false) {
+        stage(3);
         // own camera records: the ones of the linearisation point stay valid for the next solve
         if (!cams_ready) prep_cams(zz, cams_f.p);
         mark(6);
@@ -501,13 +522,14 @@ struct Core {
 
     // ---- K1: linearise at zz with damping lambda; builds the reduced system.
     void build_enqueue(const double *zz, double lambda, int scale) {
-        const bool fused_first = !(s_dense_dirty || env_dense_allreduce) && P.NS >= P.nc;
+        stage(0);
+        const bool fused_first = !s_dense_dirty && P.NS >= P.nc;
         if (!fused_first) prep_cams(zz);
         else cams_at_lin = false;
         // only the envelope of S is ever written or read: zero that (and the vectors behind S); the whole
         // array once, and again after something filled it densely (the inverse of the posterior covariance)
         bool pivmm_set = false;
-        if (s_dense_dirty || env_dense_allreduce) {
+        if (s_dense_dirty) {
             HIPCHK(hipMemsetAsync(red.p, 0, red_count * sizeof(double), stream));
             s_dense_dirty = false;
         } else {
@@ -528,8 +550,7 @@ struct Core {
             if (use_tile2 && tile_ncx <= 14 && n_cm_chunks > 0) {
                 // camera side of the tiled observations: J_c'J_c, J_c'r, squared column norms
 #define L_CAMN6(M, dummy) LAUNCHK((k_cam_normal6<M>), dim3((unsigned)n_cm_chunks), dim3(256), 0, stream, d, zz, cams.p, cm_pt.p, cm_uv.p, P.uniform_w ? (const double *)nullptr : cm_w.p, cm_chunk_cam.p, cm_chunk_start.p, S, g_c, g_red, diagU)
-                if (tile_ncx == 6 && !env_camn_mfma) { DISPATCH_MODEL(L_CAMN6, 0) }
-                else if (tile_ncx == 6) { DISPATCH_MODEL(L_CAMN, 6) } else { DISPATCH_MODEL(L_CAMN, 14) }
+                if (tile_ncx == 6) { DISPATCH_MODEL(L_CAMN6, 0) } else { DISPATCH_MODEL(L_CAMN, 14) }
 #undef L_CAMN6
             }
 #undef L_CAMN
@@ -542,7 +563,6 @@ struct Core {
             else if (use_sig && sig_rb == 4) { DISPATCH_MODEL(L_SIG, 4 + 8 * 14) }
             else if (use_sig) { DISPATCH_MODEL(L_SIG, 5 + 8 * 14) }
             else if (use_tile3 && tile_ncx == 6) { DISPATCH_MODEL(L_TILE3, 0) }
-            else if (use_tile2 && tile_ncx == 6) { DISPATCH_MODEL(L_TILE2, 6) }
             else if (use_tile2 && tile_ncx == 14) { DISPATCH_MODEL(L_TILE2, 14) }
             else throw DeviceError{"internal: tiles without a tile kernel"};
             mark(1);
@@ -665,10 +685,10 @@ struct Core {
 
     // ---- K6: Cholesky of the reduced system; returns 0 or the failing pivot
     int factor_solve_enqueue() {
+        stage(1);
         mark(2);
         // Cholesky + both substitutions; q -> rhs.  One persistent dataflow kernel (chol_df.hpp)
         // (the dataflow kernel also writes the step of the unscaled system dc = D q)
-        bool unscaled = true;
         if (use_perm && !chol_in_place && mg_subtree && multi()) {
             // this rank's domain and its share of the top separators; the shares summed over the ranks (one
             // all-reduce of the top tiles); the top separators and the backward substitution on every rank
@@ -678,23 +698,17 @@ struct Core {
             mark(9);
             dfchol.solve_top(stream, ldS, rhs.p, linv.p, info.p, ldiag.p, dscale.p, dz.p);
         } else if (use_perm && !chol_in_place) dfchol.solve(stream, S, ldS, rhs.p, linv.p, info.p, ldiag.p, dscale.p, dz.p);
-        else if (use_df) dfchol_ip.solve(stream, S, ldS, rhs.p, linv.p, info.p, ldiag.p, dscale.p, dz.p);
-        else {
-            unscaled = false;
-            BlockChol::solve(blas, stream, S, ldS, (int)P.NS, rhs.p, ywork.p, linv.p, info.p, env);
-            HIPCHK(hipMemcpy2DAsync(ldiag.p, sizeof(double), S, (ldS + 1) * sizeof(double), sizeof(double), (size_t)P.NS,
-                                    hipMemcpyDeviceToDevice, stream));
-        }
+        else dfchol_ip.solve(stream, S, ldS, rhs.p, linv.p, info.p, ldiag.p, dscale.p, dz.p);
         HIPCHK(hipGetLastError());                   // launches inside the factorisation helpers
         if (env_df_trace) (use_perm && !chol_in_place ? dfchol : dfchol_ip).dump_trace(stream, env_df_trace);
         mark(3);
         // the pivot extremes of the reduced system are taken in k_prior_jv (the tail of the solve)
-        if (!unscaled) LAUNCHK(k_unscale, dim3((unsigned)cdiv(P.NS, 256)), dim3(256), 0, stream, P.NS, rhs.p, dscale.p, dz.p);
         ++n_solves;
         return 0;
     }
     // ---- K7: back-substitution; sums {||Jp||^2, r'Jp, ||p||^2}
     void backsub_enqueue() {
+        stage(2);
         mark(4);
         // the points of the signature chunks by k_backsub_sig (one wave per chunk), the other batches by
         // k_backsub; partial: [nb batches][2] (the tiled batches' slots stay zero), giants, sig workgroups
@@ -1426,6 +1440,7 @@ int dbat_hip_solve(dbat_hip_handle *h, const dbat_hip_options *opt, double *x, d
     c.lambda_lin = NAN;
     LoopOut out;
     const auto t0 = std::chrono::steady_clock::now();
+    c.stages_begin();
     switch (opt->damping) {
         case DBAT_HIP_DAMP_GM: loop_gm(c, *opt, out); break;
         case DBAT_HIP_DAMP_GNA: loop_gna(c, *opt, out); break;
@@ -1442,6 +1457,7 @@ int dbat_hip_solve(dbat_hip_handle *h, const dbat_hip_options *opt, double *x, d
     }
     c.sync();
     result->time_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    c.stages_end(result->stage_s);
     result->code = out.code; result->iters = out.iters;
     c.z_to_x(c.z.p, x);
     const int cap_res = opt->max_iter + 3, cap_d = 2 * opt->max_iter + 4;
@@ -1461,6 +1477,7 @@ int dbat_hip_solve(dbat_hip_handle *h, const dbat_hip_options *opt, double *x, d
     const double dof = (double)(c.P.m - c.P.n);
     result->sigma0 = std::sqrt(2 * out.f_final / dof);            // bundle.m:476-483
     result->n_residual_evals = c.n_res_evals; result->n_linearizations = c.n_lin; result->n_solves = c.n_solves;
+    result->n_trace_only = c.n_trace_only;
     return DBAT_HIP_OK;
     API_CATCH
 }
@@ -1661,7 +1678,7 @@ int dbat_hip_chol_stats(const dbat_hip_handle *h, int64_t *st) {
     if (!h || !st) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
     const Core &c = *h->core;
     const DataflowChol &f = c.use_perm ? c.dfchol : c.dfchol_ip;
-    st[0] = f.n; st[1] = f.ntasks; st[2] = f.n_products; st[3] = f.nT; st[4] = c.use_perm ? 1 : 0; st[5] = c.use_df ? 1 : 0;
+    st[0] = f.n; st[1] = f.ntasks; st[2] = f.n_products; st[3] = f.nT; st[4] = c.use_perm ? 1 : 0; st[5] = 1;
     return DBAT_HIP_OK;
 }
 

@@ -450,7 +450,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     // ---- nested dissection (nd.hpp); with several ranks its first levels are the ranks' domains
     {
         const bool nd_off = getenv("DBAT_HIP_ND_OFF") != nullptr;
-        const bool permuted_ok = !P.shared_eo && !getenv("DBAT_HIP_DF_NOPERM") && !getenv("DBAT_HIP_BLOCKCHOL") && !getenv("DBAT_HIP_DENSE_CHOL");
+        const bool permuted_ok = !P.shared_eo;
         P.mg_subtree = P.nranks > 1 && permuted_ok && !nd_off && !getenv("DBAT_HIP_MG_REPLICATED");
         std::vector<double> xyz((size_t)3 * nc), wcam(nc);
         for (int c = 0; c < nc; ++c) {
@@ -551,8 +551,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         std::sort(axis, axis + 3, [&](int a, int b) { return hi[a] - lo[a] > hi[b] - lo[b]; });
         double ext = hi[axis[0]] - lo[axis[0]];
         if (!(ext > 0)) ext = 1;
-        const char *od = getenv("DBAT_HIP_ORDER_DIMS");               // 2 or 3: override the flatness rule
-        const int dims = od ? std::min(3, std::max(2, atoi(od))) : ((hi[axis[2]] - lo[axis[2]]) < 0.2 * ext ? 2 : 3);
+        const int dims = (hi[axis[2]] - lo[axis[2]]) < 0.2 * ext ? 2 : 3;
         P.order_dims = dims;
         auto spread = [](uint64_t v) {      // 21 bits -> every third bit
             v &= 0x1FFFFF;
@@ -590,7 +589,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         while (((int64_t)512 << cell_bits) < nobs_pts && cell_bits < 60) ++cell_bits;
         // the code interleaves `order_dims` of three bit lanes into the top 62 bits of the key
         const int eff_bits = (cell_bits * 3 + P.order_dims - 1) / P.order_dims;
-        const int low_bits = getenv("DBAT_HIP_SIG_SORT_OFF") ? 0 : std::max(0, 62 - eff_bits);
+        const int low_bits = std::max(0, 62 - eff_bits);
         std::vector<uint64_t> sig(np, 0);
         if (low_bits > 0)
             for (int p = 0; p < np; ++p) {
@@ -792,7 +791,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     int64_t shard_obs = 0;
     for (int64_t i = P.pt_lo; i < P.pt_hi; ++i) shard_obs += k_pt[P.porder[i]];
     const int bmax_auto = (int)std::min<int64_t>(48, std::max<int64_t>(4, (shard_obs / std::max(1, P.BT) + 511) / 512));
-    const int tile_bmax = std::max(1, env_int0("DBAT_HIP_TILE_BMAX", bmax_auto));
+    const int tile_bmax = bmax_auto;
     for (int64_t i = P.pt_lo; i < P.pt_hi; ++i) {
         const int32_t p = P.porder[i];
         const int k = k_pt[p];

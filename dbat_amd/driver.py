@@ -124,6 +124,8 @@ def bundle(s, *args, device=None, comm=None, store_trace=True):
             E.damping = NS(name='lmp', delta=damp, rho=rho, delta0=float(np.linalg.norm(x0)),
                            rhoBad=opt.rho_bad, rhoGood=opt.rho_good, step=step)
         E.res, E.trace, E.time = rr, T, res.time_s
+        # where it went (hipEvent stage timers of the library), the E.time of bundle.m:287-294 by stage
+        E.timeStages = dict(zip(('linearise', 'factor_solve', 'backsub', 'residual', 'other'), [float(v) for v in res.stage_s]))
         E.code, E.usedIters = int(res.code), int(res.iters)
         E.counters = NS(residual_evals=res.n_residual_evals, linearizations=res.n_linearizations,
                         solves=res.n_solves)

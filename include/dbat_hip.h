@@ -124,6 +124,14 @@ typedef struct dbat_hip_result {
     int32_t n_residual_evals;   /* residual-only evaluations (line search / trial points) */
     int32_t n_linearizations;   /* residual+Jacobian+normal-equation builds */
     int32_t n_solves;           /* reduced-system factorisations */
+    int32_t n_trace_only;       /* linearisations taken for trace(J'J) alone (LM's first: no reduced system formed) */
+    /* Where the time went (the E.time of bundle.m:287-294, by stage): seconds of the handle's stream between
+     * hipEvents recorded where a stage is enqueued -- each interval runs to the next stage's first kernel, so
+     * it includes whatever wait for the host follows the stage.  [0] linearisation (residual + Jacobian blocks
+     * + J'J + Schur complement), [1] factorisation + solve of the reduced system, [2] back-substitution +
+     * step norms, [3] residual-only evaluations (line search / trial points), [4] everything else inside the
+     * loop (iterate gathers for the trace, set-up copies). */
+    double  stage_s[5];
 } dbat_hip_result;
 
 const char *dbat_hip_last_error(void);

@@ -58,7 +58,9 @@ opt=struct('damping',dampNo,'maxIter',maxIter,'convTol',convTol,'absTerm',absTer
 % --- result packaging, bundle.m:341-358,449-491
 if isempty(s.bundle.serial) || isempty(s.bundle.deserial), s=buildserialindices(s); end
 E=struct('maxIter',maxIter,'convTol',convTol,'absTerm',absTerm,'singularTest',singularTest,...
-         'chirality',false,'res',res,'trace',T,'time',time,'code',code,'usedIters',iters);
+         'chirality',false,'res',res,'trace',T,'time',time(1),'code',code,'usedIters',iters);
+% where the time went on the device (hipEvent stage timers), bundle.m:287-294
+E.timeStages=struct('linearise',time(2),'factorSolve',time(3),'backsub',time(4),'residual',time(5),'other',time(6));
 switch damping
   case {'none','gm'}, E.damping=struct('name','gm');
   case 'gna', E.damping=struct('name','gna','alpha',damp,'mu',0.1,'alphaMin',1e-9);

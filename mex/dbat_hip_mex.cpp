@@ -105,7 +105,10 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
         if (r.code != -4) dbat_hip_final_residuals(h, mxGetDoubles(plhs[8]), mxGetDoubles(rw));
         if (nlhs > 9) plhs[9] = rw; else mxDestroyArray(rw);
     }
-    if (nlhs > 10) plhs[10] = mxCreateDoubleScalar(r.time_s);
+    if (nlhs > 10) {            // [total, linearise, factor+solve, back-substitution, residual evaluations, other] seconds
+        const double tm[6] = {r.time_s, r.stage_s[0], r.stage_s[1], r.stage_s[2], r.stage_s[3], r.stage_s[4]};
+        plhs[10] = vec(tm, 6);
+    }
     if (nlhs > 11) {
         // posterior covariance blocks (bundle_cov.m 'CEO','CIO','COP') at the result:
         // plhs[11] 6 x 6 x nImages, plhs[12] nIOu x nIOu (IO unknowns in x order), plhs[13] 3 x 3 x nOP

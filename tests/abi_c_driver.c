@@ -49,6 +49,7 @@ static void layout(void) {
     FIELD(dbat_hip_result, n_damp); FIELD(dbat_hip_result, n_trace); FIELD(dbat_hip_result, sigma0);
     FIELD(dbat_hip_result, time_s); FIELD(dbat_hip_result, n_residual_evals);
     FIELD(dbat_hip_result, n_linearizations); FIELD(dbat_hip_result, n_solves);
+    FIELD(dbat_hip_result, n_trace_only); FIELD(dbat_hip_result, stage_s);
     printf("}}, \"abi_version\": %d, \"unique_id_bytes\": %d}\n", DBAT_HIP_ABI_VERSION, DBAT_HIP_UNIQUE_ID_BYTES);
 }
 

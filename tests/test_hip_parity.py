@@ -1026,39 +1026,50 @@ def test_signature_group_kernel(hip, name, variant, monkeypatch):
             check_history(E, Eo, iters, ito, damping, s=s)
 
 
-@pytest.mark.parametrize('knob', ['DBAT_HIP_TILE3=0', 'DBAT_HIP_TILE_BMAX=3'])
-def test_fixed_io_single_producer_group_kernel(hip, knob, monkeypatch):
-    """Fixed-IO problems run k_build_tile3 (two producer groups) by default;
-    k_build_tile2 remains behind DBAT_HIP_TILE3=0 and when the tile length is
-    overridden: same step and the same bundle result as the oracle, and the
-    same step as the default kernel to rounding."""
+@pytest.mark.parametrize('variant', ['plain', 'selfcal'])
+def test_tile_kernels_without_signature_groups(hip, variant, monkeypatch):
+    """The tile kernels that take a scene whose signature groups are too short (real projects: irregular
+    visibility): k_build_tile3 (fixed IO, two producer groups) and k_build_tile2 (self-calibration), forced here
+    by DBAT_HIP_SIG=0 on a scene the signature kernel would take: step and bundle result as the oracle's."""
     from dbat_amd import bundle
-    monkeypatch.setenv('DBAT_HIP_SIG', '0')              # the tile kernels (the signature kernel would take this scene)
-    s, truth = synth_struct('small', 'plain')
+    monkeypatch.setenv('DBAT_HIP_SIG', '0')
+    s, truth = synth_struct('small', variant)
     so, x0, w = oracle_setup(s)
     R = np.sqrt(w)
     r_o, K = o.brown_euler_cam4(x0, so, jac=True)
     p_o, *_ = o._scaled_gn((sp.diags(R) @ K).tocsc(), R * r_o)
     h = hip.Handle(s)
     try:
-        assert h.build_kernel_name() == 'k_build_tile3'
-        p_default, _ = h.linearize_solve(x0, 0.0, True)
-    finally:
-        h.close()
-    name, val = knob.split('=')
-    monkeypatch.setenv(name, val)
-    h = hip.Handle(s)
-    try:
-        assert h.build_kernel_name() == 'k_build_tile2'
+        assert h.build_kernel_name() == ('k_build_tile3' if variant == 'plain' else 'k_build_tile2')
         p_h, st = h.linearize_solve(x0, 0.0, True)
     finally:
         h.close()
-    assert relerr(p_h, p_o) < TOL_STEP and relerr(p_default, p_o) < TOL_STEP
-    assert relerr(p_h, p_default) < 1e-10
+    assert relerr(p_h, p_o) < TOL_STEP
     res, ok, iters, s0, E = bundle(s, 'lm')
-    monkeypatch.delenv(name)
     ro, oko, ito, s0o, Eo = o.bundle(s, 'lm')
     assert ok and oko and relerr(E.x, Eo.x) < TOL_X
+
+
+def test_stage_timers_of_a_solve(hip):
+    """dbat_hip_result.stage_s (E.timeStages): hipEvent stage timers of the damping loop add up to the loop's
+    wall time (minus the host work before the first launch), every stage of an LM solve is visited, and LM's first
+    linearisation is taken for its trace alone."""
+    from dbat_amd import bundle
+    s, _ = synth_struct('small', 'plain')
+    res, ok, iters, s0, E = bundle(s, 'lm', store_trace=False)
+    assert ok
+    st = E.timeStages
+    assert set(st) == {'linearise', 'factor_solve', 'backsub', 'residual', 'other'}
+    assert all(v >= 0 for v in st.values()) and min(st['linearise'], st['factor_solve'], st['backsub'], st['residual']) > 0
+    assert 0.5 * E.time < sum(st.values()) <= 1.05 * E.time + 1e-3
+    h = hip.Handle(s)
+    try:
+        opt = hip.default_options('lm')
+        opt.store_trace = 0
+        x, r, rr, damp, aux, T = h.solve(h.serialize(), opt)
+        assert r.n_trace_only == 1 and r.n_linearizations == r.n_solves      # one build per solve; the last accepted point is not linearised
+    finally:
+        h.close()
 
 
 @pytest.mark.parametrize('damping', ['gna', 'lm'])
