@@ -93,6 +93,7 @@ SYMBOLS = {
     'dbat_hip_residual': (C.c_int, [_H, _dp, _dp, _dp]),
     'dbat_hip_jacobian_blocks': (C.c_int, [_H, _dp, _dp, _dp, _dp]),
     'dbat_hip_linearize_solve': (C.c_int, [_H, _dp, C.c_double, C.c_int32, _dp, _dp]),
+    'dbat_hip_jacobian_csc': (C.c_int, [_H, _dp, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), _dp]),
     'dbat_hip_gradient': (C.c_int, [_H, _dp]),
     'dbat_hip_colnorms': (C.c_int, [_H, _dp]),
     'dbat_hip_jtimes_sqnorm': (C.c_int, [_H, _dp, _dp]),
@@ -284,6 +285,20 @@ class Handle:
         check(self.lib.dbat_hip_jacobian_blocks(self.h, dptr(x), dptr(JEO), dptr(JOP), dptr(JIO)))
         return (JEO.reshape(no, 6, 2).transpose(0, 2, 1), JOP.reshape(no, 3, 2).transpose(0, 2, 1),
                 JIO.reshape(no, R, 2).transpose(0, 2, 1))
+
+    def jacobian_csc(self, x, weighted=True):
+        """J at x as scipy.sparse.csc_matrix (m x n): E.final.weighted.J / unweighted.J of bundle.m:341-350."""
+        import scipy.sparse as sp
+        x = np.ascontiguousarray(x, float)
+        nnz = C.c_int64(0)
+        check(self.lib.dbat_hip_jacobian_csc(self.h, dptr(x), int(bool(weighted)), C.byref(nnz), None, None, None))
+        colptr = np.zeros(self.n + 1, np.int64)
+        rowidx = np.zeros(max(nnz.value, 1), np.int64)
+        val = np.zeros(max(nnz.value, 1))
+        i64 = C.POINTER(C.c_int64)
+        check(self.lib.dbat_hip_jacobian_csc(self.h, dptr(x), int(bool(weighted)), C.byref(nnz), colptr.ctypes.data_as(i64),
+                                             rowidx.ctypes.data_as(i64), dptr(val)))
+        return sp.csc_matrix((val[:nnz.value], rowidx[:nnz.value], colptr), shape=(self.m, self.n))
 
     def linearize_solve(self, x, lam=0.0, scale=True):
         x = np.ascontiguousarray(x, float)

@@ -1364,6 +1364,85 @@ int dbat_hip_jacobian_blocks(dbat_hip_handle *h, const double *x, double *JEO, d
     API_CATCH
 }
 
+int dbat_hip_jacobian_csc(dbat_hip_handle *h, const double *x, int32_t weighted, int64_t *nnz_out,
+                          int64_t *colptr, int64_t *rowidx, double *val) {
+    API_TRY
+    if (!h || !x || !nnz_out) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
+    Core &c = *h->core;
+    const Plan &P = c.P;
+    if (P.nranks > 1) { g_err = "dbat_hip_jacobian_csc: one-rank handles only"; return DBAT_HIP_EUNSUPPORTED; }
+    std::vector<int64_t> z2x((size_t)P.NZ, -1);
+    for (int64_t i = 0; i < P.n; ++i) z2x[P.x2z[i]] = i;
+    // columns of one observation: EO (6), IO (the camera's estimated IO columns), OP (3); -1 = no unknown
+    const int R = P.nIOrows;
+    auto cols_of = [&](int64_t o, int64_t *eo, int64_t *io, int *iorow, int &nio, int64_t *op) {
+        const int cam = P.o_cam[o];
+        for (int k = 0; k < 6; ++k) { const int32_t zc = P.cam_col[(size_t)cam * MAXCOL + k]; eo[k] = (P.cam_eo_est[cam] >> k) & 1u ? z2x[zc] : -1; }
+        nio = P.cam_ncol[cam] - 6;
+        for (int q = 0; q < nio; ++q) { io[q] = z2x[P.cam_col[(size_t)cam * MAXCOL + 6 + q]]; iorow[q] = P.cam_iorow[(size_t)cam * MAXIO + q]; }
+        for (int k = 0; k < 3; ++k) op[k] = z2x[P.NS + 3 * (int64_t)P.o_pt[o] + k];
+    };
+    const int64_t nobs = (int64_t)P.o_cam.size();
+    std::vector<int64_t> cnt((size_t)P.n + 1, 0);
+    int64_t eo[6], io[MAXIO], op[3];
+    int iorow[MAXIO], nio;
+    for (int64_t o = 0; o < nobs; ++o) {
+        cols_of(o, eo, io, iorow, nio, op);
+        for (int k = 0; k < 6; ++k) if (eo[k] >= 0) cnt[eo[k] + 1] += 2;
+        for (int q = 0; q < nio; ++q) if (io[q] >= 0) cnt[io[q] + 1] += 2;
+        for (int k = 0; k < 3; ++k) if (op[k] >= 0) cnt[op[k] + 1] += 2;
+    }
+    for (int64_t zi : P.prior_z) cnt[z2x[zi] + 1] += 1;
+    for (int64_t i = 0; i < P.n; ++i) cnt[i + 1] += cnt[i];
+    *nnz_out = cnt[P.n];
+    if (!colptr) return DBAT_HIP_OK;
+    if (!rowidx || !val) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
+    DeviceGuard dev_guard(c.device);
+    c.x_to_z(x, c.zt.p);
+    c.prep_cams(c.zt.p);
+    const int64_t no = std::max<int64_t>(P.no, 1);
+    DevBuf<double> a, b, cc;
+    a.alloc(12 * no); b.alloc(6 * no); cc.alloc(2 * (int64_t)R * no);
+    if (c.nobs > 0) {
+#define L_JB(M, dummy) LAUNCHK((k_jac_blocks<M>), dim3((unsigned)cdiv(c.nobs, 256)), dim3(256), 0, c.stream, c.d, c.zt.p, c.cams.p, a.p, b.p, cc.p)
+        switch (P.model) { case 2: L_JB(2, 0); break; case 3: L_JB(3, 0); break; case 4: L_JB(4, 0); break; default: L_JB(5, 0); break; }
+#undef L_JB
+    }
+    std::vector<double> JEO((size_t)12 * no), JOP((size_t)6 * no), JIO((size_t)2 * R * no);
+    HIPCHK(hipMemcpyAsync(JEO.data(), a.p, JEO.size() * 8, hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipMemcpyAsync(JOP.data(), b.p, JOP.size() * 8, hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipMemcpyAsync(JIO.data(), cc.p, JIO.size() * 8, hipMemcpyDeviceToHost, c.stream));
+    c.sync();
+    for (int64_t i = 0; i <= P.n; ++i) colptr[i] = cnt[i];
+    std::vector<int64_t> fill(cnt.begin(), cnt.end() - 1);
+    // observations in REFERENCE row order (ascending IP column), so that the rows of a column ascend
+    std::vector<int64_t> by_row((size_t)nobs);
+    for (int64_t o = 0; o < nobs; ++o) by_row[P.o_row[o]] = o;
+    for (int64_t k = 0; k < nobs; ++k) {
+        const int64_t o = by_row[k];
+        const int cam = P.o_cam[o];
+        double w0 = 1.0, w1 = 1.0;
+        if (weighted) { w0 = P.uniform_w ? P.cam_w[2 * cam] : P.o_w[2 * o]; w1 = P.uniform_w ? P.cam_w[2 * cam + 1] : P.o_w[2 * o + 1]; }
+        cols_of(o, eo, io, iorow, nio, op);
+        auto put = [&](int64_t col, double v0, double v1) {
+            int64_t &f = fill[col];
+            rowidx[f] = 2 * k; val[f] = v0 * w0; rowidx[f + 1] = 2 * k + 1; val[f + 1] = v1 * w1;
+            f += 2;
+        };
+        for (int q = 0; q < 6; ++q) if (eo[q] >= 0) put(eo[q], JEO[12 * k + 2 * q], JEO[12 * k + 2 * q + 1]);
+        for (int q = 0; q < nio; ++q) if (io[q] >= 0) put(io[q], JIO[2 * (int64_t)R * k + 2 * iorow[q]], JIO[2 * (int64_t)R * k + 2 * iorow[q] + 1]);
+        for (int q = 0; q < 3; ++q) if (op[q] >= 0) put(op[q], JOP[6 * k + 2 * q], JOP[6 * k + 2 * q + 1]);
+    }
+    int64_t row = 2 * P.no;
+    for (int64_t zi : P.prior_z) {                       // prior rows: selection rows of I (prior_obs.m:45-72)
+        int64_t &f = fill[z2x[zi]];
+        rowidx[f] = row++; val[f] = weighted ? std::sqrt(P.z_prw[zi]) : 1.0;
+        ++f;
+    }
+    return DBAT_HIP_OK;
+    API_CATCH
+}
+
 int dbat_hip_linearize_solve(dbat_hip_handle *h, const double *x, double lambda, int32_t scale_columns,
                              double *p, double *stats) {
     API_TRY

@@ -60,14 +60,15 @@ def _parse_args(args):
     return o
 
 
-def bundle(s, *args, device=None, comm=None, store_trace=True):
+def bundle(s, *args, device=None, comm=None, store_trace=True, jacobian=False):
     """[s,ok,iters,s0,E] = bundle(s[,maxIter][,damping][,'trace'][,tol]
     [,'absterm'][,'singulartest'|'nosingulartest'][,veto][,'pmdof'][,'dofverb'])
 
     `comm` (dbat_amd.parallel.Comm) shards the object points over the ranks of
     a torch.distributed group, one GPU per rank; every rank returns the full
     result.  `store_trace=False` drops E.trace (n x iterations) for very large
-    problems.
+    problems.  `jacobian=True` also returns E.final.weighted.J and E.final.unweighted.J
+    (scipy CSC, bundle.m:341-350) -- on request only, the solver never forms J.
     """
     o = _parse_args(args)
     if o['veto']:
@@ -161,6 +162,9 @@ def bundle(s, *args, device=None, comm=None, store_trace=True):
             ofs += len(pos)
             setattr(s.post.res, nm, flat.reshape(arr.shape, order='F'))
         E.final = NS(unweighted=NS(r=ru), weighted=NS(r=rw))
+        if jacobian and world == 1 and E.code != -4:
+            E.final.weighted.J = h.jacobian_csc(x, True)
+            E.final.unweighted.J = h.jacobian_csc(x, False)
         p_extra = 0
         if o['pmDof']:                                               # bundle.m:467-471
             seen_pt = np.zeros(s.OP.val.shape[1], bool); seen_pt[s.IP.pt] = True

@@ -221,6 +221,17 @@ int  dbat_hip_colnorms(dbat_hip_handle *h, double *Jn);
 /* ||J*v||^2 at the last linearisation point (Jp, dog-leg g'J'Jg: lmp.m:304-311) */
 int  dbat_hip_jtimes_sqnorm(dbat_hip_handle *h, const double *v, double *sqnorm);
 
+/* J = [image rows; IO prior rows; EO prior rows; OP prior rows] at x as a compressed-sparse-column matrix of
+ * n_residuals x n_params -- what [r,J]=resFun(x) returns (brown_euler_cam4.m:163-182, multi_res.m:300-313) and
+ * bundle() hands on as E.final.weighted.J / E.final.unweighted.J (bundle.m:341-350; bundle_cov.m:18-23,68 reads
+ * it for 'CXX' / 'COPF').  On request only: the solver itself never forms J.  The 2x6 / 2x3 / 2xnIO blocks come
+ * from the device (the kernel of dbat_hip_jacobian_blocks), the assembly is a counting sort on the host.
+ * weighted != 0: rows scaled by 1/sigma (chol(W) J, gauss_newton_armijo.m:104,116).
+ * Two calls: with colptr == NULL only *nnz is set; then colptr [n_params+1] (int64), rowidx [nnz] (int64, ascending
+ * inside a column), val [nnz].  One-rank handles only (DBAT_HIP_EUNSUPPORTED on a sharded one). */
+int  dbat_hip_jacobian_csc(dbat_hip_handle *h, const double *x, int32_t weighted, int64_t *nnz,
+                           int64_t *colptr, int64_t *rowidx, double *val);
+
 /* ---- the damping loops (host control flow, device arithmetic) ----------- */
 
 /* [x,code,n,final,T,rr,extra] = <solver>(resFun,vetoFun,x0,W,maxIter,termFun,...)

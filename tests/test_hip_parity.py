@@ -1050,6 +1050,32 @@ def test_tile_kernels_without_signature_groups(hip, variant, monkeypatch):
     assert ok and oko and relerr(E.x, Eo.x) < TOL_X
 
 
+@pytest.mark.parametrize('name', ['camcal3', 'tiny-selfcal', 'tiny-imagevar', 'tiny-priors', 'tiny-groups4', 'small-priors'])
+def test_jacobian_csc_matches_oracle(hip, name):
+    """dbat_hip_jacobian_csc: the whole J (image rows + prior rows) as a CSC matrix in the reference's row and
+    column order, weighted and unweighted, against the oracle's sparse J (multi_res.m:300-313, prior_obs.m)."""
+    s = dict(cases())[name]()
+    so, x0, w = oracle_setup(s)
+    rng = np.random.default_rng(3)
+    x = x0 + 1e-5 * rng.standard_normal(len(x0)) * np.maximum(1e-3, np.abs(x0))
+    r_o, K = o.brown_euler_cam4(x, so, jac=True)
+    h = hip.Handle(s)
+    try:
+        Ju, Jw = h.jacobian_csc(x, False), h.jacobian_csc(x, True)
+    finally:
+        h.close()
+    K = K.tocsc(); K.sort_indices()
+    assert Ju.shape == K.shape and Ju.has_sorted_indices
+    assert abs(Ju - K).max() <= TOL_BLOCK * abs(K).max()
+    assert abs(Jw - sp.diags(np.sqrt(w)) @ K).max() <= TOL_BLOCK * abs(sp.diags(np.sqrt(w)) @ K).max()
+    assert Ju.nnz <= K.nnz + 1 and (Ju != 0).sum() >= (K != 0).sum() - 1          # same pattern (explicit zeros aside)
+    from dbat_amd import bundle
+    res, ok, iters, s0, E = bundle(s, 'gna', jacobian=True)
+    assert E.final.weighted.J.shape == (E.numObs, E.numParams)
+    g = E.final.weighted.J.T @ E.final.weighted.r
+    assert np.linalg.norm(g) <= 1e-4 * np.linalg.norm(E.final.weighted.J.data) * np.linalg.norm(E.final.weighted.r)   # a stationary point
+
+
 def test_stage_timers_of_a_solve(hip):
     """dbat_hip_result.stage_s (E.timeStages): hipEvent stage timers of the damping loop add up to the loop's
     wall time (minus the host work before the first launch), every stage of an LM solve is visited, and LM's first
