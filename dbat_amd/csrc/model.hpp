@@ -89,8 +89,12 @@ struct ImgSide {
     double dP[2][MAXP];
 };
 
-template <int MODEL, bool JAC>
-DBAT_HD void image_side(const CamRec &cam, int nK, int nP, double u, double v, ImgSide &o) {
+// NKC, NPC >= 0: the numbers of radial / tangential coefficients are compile-time constants (the loops below
+// unroll into straight-line code: no uniform branches between the dependent chains of two observations that the
+// scheduler could otherwise interleave); < 0: run-time values nK, nP.
+template <int MODEL, bool JAC, int NKC, int NPC>
+DBAT_HD void image_side_impl(const CamRec &cam, int nK_, int nP_, double u, double v, ImgSide &o) {
+    const int nK = NKC >= 0 ? NKC : nK_, nP = NPC >= 0 ? NPC : nP_;
     // scale2, aniscale2([1;-1]), (aniscale2b for model 5), xlat2(-u0)
     const double s0 = cam.sz * u, s1 = -cam.sz * v;
     double x0, x1;
@@ -104,6 +108,7 @@ DBAT_HD void image_side(const CamRec &cam, int nK, int nP, double u, double v, I
     double rs = 0, drs = 0, pw = 1.0;            // rs = sum Kn_j rho^j ; drs = sum j Kn_j rho^(j-1)
     double rpow[MAXK + 1];
     rpow[0] = 1.0;
+#pragma unroll
     for (int j = 0; j < MAXK; ++j) {
         if (j < nK) {
             const double kn = -cam.K[j];
@@ -120,6 +125,7 @@ DBAT_HD void image_side(const CamRec &cam, int nK, int nP, double u, double v, I
         ts0 = pn0 * rho + 2 * pTu * a0;
         ts1 = pn1 * rho + 2 * pTu * a1;
         double q = 1.0;
+#pragma unroll
         for (int j = 2; j < MAXP; ++j)
             if (j < nP) {
                 const double pn = -cam.P[j];
@@ -163,6 +169,7 @@ DBAT_HD void image_side(const CamRec &cam, int nK, int nP, double u, double v, I
         o.dU0[1][0] = TL10; o.dU0[1][1] = TL11;
     }
     // dv/dK = T * a * rho^j   (brown_rad.m:76-79 ; sign: -K passed, v = lhs - l)
+#pragma unroll
     for (int j = 0; j < MAXK; ++j) {
         if (j < nK) {
             const double k0 = a0 * rpow[j + 1], k1 = a1 * rpow[j + 1];
@@ -179,6 +186,7 @@ DBAT_HD void image_side(const CamRec &cam, int nK, int nP, double u, double v, I
         o.dP[0][0] = T00 * p00 + T01 * p01; o.dP[0][1] = T00 * p01 + T01 * p11;
         o.dP[1][0] = p01;                   o.dP[1][1] = p11;
         double q = 1.0;
+#pragma unroll
         for (int j = 2; j < MAXP; ++j)
             if (j < nP) {
                 q *= rho;
@@ -199,6 +207,14 @@ DBAT_HD void image_side(const CamRec &cam, int nK, int nP, double u, double v, I
         o.dB[0][0] = -TL00 * s0; o.dB[0][1] = -l1;
         o.dB[1][0] = -TL10 * s0; o.dB[1][1] = 0;
     }
+}
+
+// the usual lens (K1-K3, P1-P2: every camera of the synthetic configurations, the roma camera, PhotoModeler's
+// default) takes the straight-line instantiation; one wave-uniform test
+template <int MODEL, bool JAC>
+DBAT_HD void image_side(const CamRec &cam, int nK, int nP, double u, double v, ImgSide &o) {
+    if (nK == 3 && nP == 2) image_side_impl<MODEL, JAC, 3, 2>(cam, nK, nP, u, v, o);
+    else image_side_impl<MODEL, JAC, -1, -1>(cam, nK, nP, u, v, o);
 }
 
 // Full observation: residual r[2] (unweighted, mm) and Jacobian blocks

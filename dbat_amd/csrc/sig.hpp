@@ -200,9 +200,57 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
             double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
             const int64_t q0 = uv0 + gi0 + (act ? pi : 0);
             const double2 *uvp = reinterpret_cast<const double2 *>(sg_uv), *wp = reinterpret_cast<const double2 *>(sg_w);
+            // V += B'B, g += B'r of one observation (weighted, fixed coordinates masked)
+            auto accumulate = [&](const double (&r)[2], const double (&B)[2][3]) {
+                if (act) rr += r[0] * r[0] + r[1] * r[1];
+                V[0] += B[0][0] * B[0][0] + B[1][0] * B[1][0];
+                V[1] += B[0][0] * B[0][1] + B[1][0] * B[1][1];
+                V[2] += B[0][0] * B[0][2] + B[1][0] * B[1][2];
+                V[3] += B[0][1] * B[0][1] + B[1][1] * B[1][1];
+                V[4] += B[0][1] * B[0][2] + B[1][1] * B[1][2];
+                V[5] += B[0][2] * B[0][2] + B[1][2] * B[1][2];
+                g[0] += B[0][0] * r[0] + B[1][0] * r[1];
+                g[1] += B[0][1] * r[0] + B[1][1] * r[1];
+                g[2] += B[0][2] * r[0] + B[1][2] * r[1];
+            };
+            const int kk = (d.ablate & 4) ? 1 : k;
+            if constexpr (!IO) {
+                // Fixed IO: TWO cameras per trip.  One evaluation is a dependent chain of ~120 f64 operations and the
+                // SIMD holds two waves, so a single chain leaves the issue slots half empty (r03a_c3_summary.md: 40 %
+                // of the wave cycles issue-stalled); two independent chains interleave.  The accumulators of pass 2
+                // are not live here, so the registers are there.  A lane whose second camera does not exist repeats
+                // its first with zero weights (lanes of a short chunk start at different cameras).
+                auto ld = [&](int jj, double2 &uvx, double2 &wx) {
+                    if (jj < k) { uvx = uvp[q0 + (int64_t)jj * gm]; if (sg_w) wx = wp[q0 + (int64_t)jj * gm]; }
+                };
+                double2 ua = double2{0, 0}, ub = double2{0, 0}, wa = double2{0, 0}, wb = double2{0, 0};
+                ld(jh, ua, wa); ld(jh + jstep, ub, wb);
+                for (int j = jh; j < kk; j += 2 * jstep) {
+                    const bool vb = j + jstep < kk;
+                    const int j2 = vb ? j + jstep : j;
+                    const CamRec &CA = *reinterpret_cast<const CamRec *>(camw + sy.lc[wave][j] * CAMW);
+                    const CamRec &CB = *reinterpret_cast<const CamRec *>(camw + sy.lc[wave][j2] * CAMW);
+                    const double2 ca = ua, cb = vb ? ub : ua, cwa = wa, cwb = vb ? wb : wa;
+                    ld(j + 2 * jstep, ua, wa); ld(j + 3 * jstep, ub, wb);      // the next trip's image coordinates
+                    const double wa0 = sg_w ? cwa.x : CA.w[0], wa1 = sg_w ? cwa.y : CA.w[1];
+                    const double zb = vb ? 1.0 : 0.0;
+                    const double wb0 = (sg_w ? cwb.x : CB.w[0]) * zb, wb1 = (sg_w ? cwb.y : CB.w[1]) * zb;
+                    double rA[2], AA[2][6], BA[2][3], CfA[2][MAXIO], rB[2], AB[2][6], BB[2][3], CfB[2][MAXIO];
+                    obs_eval<MODEL, true, false>(CA, d.nK, d.nP, Q, ca.x, ca.y, rA, AA, BA, CfA);    // A is dead code here
+                    obs_eval<MODEL, true, false>(CB, d.nK, d.nP, Q, cb.x, cb.y, rB, AB, BB, CfB);
+                    rA[0] *= wa0; rA[1] *= wa1; rB[0] *= wb0; rB[1] *= wb1;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const double m = ((est >> c) & 1u) ? 1.0 : 0.0;
+                        BA[0][c] *= wa0 * m; BA[1][c] *= wa1 * m; BB[0][c] *= wb0 * m; BB[1][c] *= wb1 * m;
+                    }
+                    accumulate(rA, BA);
+                    accumulate(rB, BB);
+                }
+            } else {
             double2 uv_n = double2{0, 0}, w_n = double2{0, 0};
             if (jh < k) { uv_n = uvp[q0 + (int64_t)jh * gm]; if (sg_w) w_n = wp[q0 + (int64_t)jh * gm]; }
-            for (int j = jh; j < ((d.ablate & 4) ? 1 : k); j += jstep) {
+            for (int j = jh; j < kk; j += jstep) {
                 const int lc = sy.lc[wave][j];
                 const CamRec &C = *reinterpret_cast<const CamRec *>(camw + lc * CAMW);
                 const int64_t q = q0 + (int64_t)j * gm;
@@ -240,16 +288,8 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
                         else into(std::integral_constant<int, 0>{});
                     }
                 }
-                if (act) rr += r[0] * r[0] + r[1] * r[1];
-                V[0] += B[0][0] * B[0][0] + B[1][0] * B[1][0];
-                V[1] += B[0][0] * B[0][1] + B[1][0] * B[1][1];
-                V[2] += B[0][0] * B[0][2] + B[1][0] * B[1][2];
-                V[3] += B[0][1] * B[0][1] + B[1][1] * B[1][1];
-                V[4] += B[0][1] * B[0][2] + B[1][1] * B[1][2];
-                V[5] += B[0][2] * B[0][2] + B[1][2] * B[1][2];
-                g[0] += B[0][0] * r[0] + B[1][0] * r[1];
-                g[1] += B[0][1] * r[0] + B[1][1] * r[1];
-                g[2] += B[0][2] * r[0] + B[1][2] * r[1];
+                accumulate(r, B);
+            }
             }
             for (int m = G; m < 64; m <<= 1) {        // the other lanes of the point (uniform loop: butterfly over the slices)
 #pragma unroll
