@@ -33,14 +33,20 @@ def hip():
     return _hip
 
 
-@pytest.mark.parametrize('name', ['C2', 'C3'])
+@pytest.mark.parametrize('name', ['C2', 'C3', 'C4'])
 def test_full_size_step_vs_independent_full_matrix_solve(hip, name):
-    """One linearise + solve at x0 at FULL size: the step p, f = r'r/2, ||J p||^2, g'p and trace(J'J)
-    of dbat_hip_linearize_solve (Schur complement on the GPU, the kernels the bench times) against
-    bench/cpu_ref.cpp's step of the full sparse normal matrix.  1e-8 on p with the damping of the
-    small-scene tests (1e-4 trace/n); with the bench's own 1e-10 trace/n the stated bar (1e-6)."""
+    """One linearise + solve at x0 at FULL size (C2, C3, and C4 with its 15 M unknowns and four IO blocks): the step
+    p, f = r'r/2, ||J p||^2, g'p and trace(J'J) of dbat_hip_linearize_solve (Schur complement on the GPU, the
+    kernels the bench times) against bench/cpu_ref.cpp's step of the full sparse normal matrix.  1e-8 on p with
+    the damping of the small-scene tests (1e-4 trace/n); with the bench's own 1e-10 trace/n the stated bar (1e-6)."""
     import cpu_ref
     from dbat_amd import synth
+    if name == 'C4':
+        # explicit J with 1.7e9 non-zeros, its J'J and the factor: ~60 GB and about two minutes on the GPU box's
+        # 256 host threads (measured: p to 1.5e-13 / 1.3e-10 of the CPU solve)
+        import psutil
+        if psutil.virtual_memory().total < 200e9:
+            pytest.skip('the full-matrix CPU solve of C4 needs ~60 GB of host memory')
     s, _ = synth.make_scene(name)
     c = cpu_ref.CpuRef(s)
     h = hip.Handle(s)
