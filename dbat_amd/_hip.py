@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdbat_hip.so')
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 DAMP = {'none': 0, 'gm': 0, 'gna': 1, 'lm': 2, 'lmp': 3}
 
 OK, EINVAL, EUNSUPPORTED, EDEVICE, ENOMEM = 0, -101, -102, -103, -104

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DBAT_HIP_ABI_VERSION 1
+#define DBAT_HIP_ABI_VERSION 2   /* 2: dbat_hip_result grew (stage_s, n_trace_only); dbat_hip_info [16]; dbat_hip_bench_step ms[12] */
 
 /* error returns */
 #define DBAT_HIP_OK            0
