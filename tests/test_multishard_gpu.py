@@ -141,6 +141,26 @@ def test_domain_shards_step_scalars_and_covariance(hip, world):
             assert relerr(a, b) < 1e-8
 
 
+@pytest.mark.parametrize('name,world', [('roma', 2), ('roma', 3), ('camcal', 2)])
+def test_domain_shards_real_projects(hip, name, world):
+    """Real data under domain sharding: the roma script project (60 images with irregular visibility, 26 321
+    points, five IO parameters estimated: tile kernels instead of signature groups, dense IO rows in the top) and
+    the camcal project (21 images that all see each other: no domain can be cut, everything is 'top' -- the
+    degenerate case) give every rank the one-rank result."""
+    from dbat_amd import bundle
+    from helpers import roma_struct, camcal_struct
+    s = roma_struct() if name == 'roma' else camcal_struct(3)
+    cam_owner, subtree = hip.plan_domain_map(s, world)
+    assert subtree
+    if name == 'camcal':
+        assert np.all(cam_owner < 0)
+    ref = bundle(s, 'gna', store_trace=False)
+    out, comms = _run_ranks(s, world, lambda comm: bundle(s, 'gna', comm=comm, store_trace=False))
+    for res, ok, iters, s0, E in out:
+        assert ok == ref[1] and iters == ref[2]
+        assert relerr(E.x, ref[4].x) < 1e-8 and abs(s0 - ref[3]) < 1e-9 * ref[3]
+
+
 def test_domain_shards_failure_is_seen_by_every_rank(hip):
     """A rank-deficient domain (no datum: seven-dimensional null space) fails inside ONE rank's local
     factorisation or in the top separators; every rank must return the same code (-2), none may hang."""
