@@ -135,6 +135,13 @@ def main():
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the dbat_hip core has no CPU path)')
+    # DBAT_BENCH_HOST_ALLREDUCE=1: the sums over the ranks go through host memory and the control-plane group
+    # (gloo) instead of RCCL, and the ranks share the GPUs that exist -- the whole multi-process path (launcher,
+    # rendezvous, one plan per rank, domain sharding, barriers, max over the ranks) on a box with fewer GPUs than
+    # ranks.  A functional check: its numbers are not scaling numbers, and the JSON says so.
+    host_ar = os.environ.get('DBAT_BENCH_HOST_ALLREDUCE') == '1'
+    if host_ar:
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     comm = None
     if world > 1 or os.environ.get('DBAT_BENCH_FORCE_COMM') == '1':
@@ -158,7 +165,9 @@ def main():
     emu = args.emulate_ranks if world == 1 and args.emulate_ranks > 1 else 0
     h = _hip.Handle(s, device=local, shard_rank=rank, shard_count=emu or world)
     t_plan = time.perf_counter() - t_plan
-    if comm is not None:
+    if comm is not None and host_ar:
+        comm.attach_host(h)
+    elif comm is not None:
         comm.attach(h)                       # ncclCommInitRank inside the library
     if emu:
         h.set_allreduce(lambda ptr, count, stream: 0)       # the sums over the ranks: not performed
@@ -300,7 +309,7 @@ def main():
                                    % (args.config, nc, npnt, no,
                                       'self-calibrating' if info['ncolmax'] > 6 else 'fixed IO'),
                        'reduced_system_order': NS, 'n_params': h.n, 'parallelism': 'points/%d' % world,
-                       'collective': ('RCCL all-reduce in libdbat_hip.so: %s' % ('top-separator tiles + vectors (domain sharding)' if info['domain_sharding'] else 'envelope of the reduced system')) if comm is not None else None,
+                       'collective': ('%s: %s' % ('all-reduce through host memory (gloo; ranks share GPUs: functional check, not a scaling number)' if host_ar else 'RCCL all-reduce in libdbat_hip.so', 'top-separator tiles + vectors (domain sharding)' if info['domain_sharding'] else 'envelope of the reduced system')) if comm is not None else None,
                        'n_tiles': info['n_tiles'], 'n_batches': info['n_batches'], 'batch': info['BT']},
             'ms_build_schur': ms[0], 'ms_factor_solve': ms[1], 'ms_backsub': ms[2],
             'ms_trial_residual': ms[3], 'kernel_ms': k_ms,

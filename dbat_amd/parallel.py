@@ -27,8 +27,11 @@ class _DevMem:
 class Comm:
     """Thin wrapper of a torch.distributed process group."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, via_host=False):
+        """via_host: attach() gives a handle its sums through host memory (attach_host) instead of an RCCL
+        communicator -- ranks that share a GPU, groups without RCCL."""
         import torch.distributed as dist
+        self.via_host = bool(via_host)
         if not dist.is_initialized():
             raise RuntimeError('torch.distributed is not initialised')
         self.dist = dist
@@ -49,6 +52,8 @@ class Comm:
     def attach(self, handle):
         """Give `handle` (this rank's shard) its RCCL communicator.  Collective."""
         from . import _hip
+        if self.via_host:
+            return self.attach_host(handle)
         box = [_hip.comm_unique_id() if self.rank == 0 else None]
         src = self.dist.get_global_rank(self.group, 0) if self.group is not None else 0
         self.dist.broadcast_object_list(box, src=src, group=self.group)
@@ -72,6 +77,29 @@ class Comm:
         with torch.cuda.stream(ext):
             self.allreduce_tensor(t)
         return 0
+
+    def allreduce_ptr_host(self, ptr, count, stream):
+        """The same sum through host memory (device -> host, all-reduce of the group's backend on the host copy,
+        host -> device), ordered on `stream`: for groups without RCCL between the ranks' buffers -- several
+        processes that share one GPU (the one-GPU test box), gloo."""
+        import torch
+        dev = torch.device('cuda', torch.cuda.current_device() if self.device is None else self.device)
+        t = torch.as_tensor(_DevMem(ptr, count), device=dev)
+        if t.data_ptr() != ptr:
+            raise RuntimeError('the buffer does not live on %s' % dev)
+        ext = torch.cuda.ExternalStream(stream, device=dev) if stream else torch.cuda.current_stream(dev)
+        with torch.cuda.stream(ext):
+            c = t.cpu()                      # waits for the stream's work on the buffer
+            self.allreduce_tensor(c)
+            t.copy_(c)
+            ext.synchronize()
+        return 0
+
+    def attach_host(self, handle):
+        """Give `handle` its sums over the ranks through host memory (allreduce_ptr_host) instead of an RCCL
+        communicator."""
+        self._hook = lambda ptr, count, stream: self.allreduce_ptr_host(ptr, count, stream)
+        handle.set_allreduce(self._hook)
 
     def allreduce_numpy(self, a):
         """Sum-all-reduce a host array (final gather of the sharded result)."""

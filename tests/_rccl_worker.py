@@ -1,6 +1,8 @@
-"""Two-rank GPU worker (launched by test_two_ranks_rccl_match_single): each rank
+"""Multi-rank GPU worker (launched by test_two_ranks_rccl_match_single): each rank
 runs bundle() on its shard of the object points with the RCCL communicator
-inside libdbat_hip.so and compares with the one-GPU run on the same device."""
+inside libdbat_hip.so and compares with the one-GPU run on the same device.
+DBAT_TEST_HOST_ALLREDUCE=1 (test_processes_share_one_gpu_through_the_host): the ranks share GPU 0 and sum
+through host memory over gloo -- the same processes, launcher and domain sharding on a one-GPU box."""
 import os
 import sys
 
@@ -19,10 +21,11 @@ from helpers import synth_struct, relerr  # noqa: E402
 
 
 def main():
-    local = int(os.environ['LOCAL_RANK'])
+    via_host = os.environ.get('DBAT_TEST_HOST_ALLREDUCE') == '1'
+    local = 0 if via_host else int(os.environ['LOCAL_RANK'])
     torch.cuda.set_device(local)
     dist.init_process_group('gloo')
-    comm = Comm()
+    comm = Comm(via_host=via_host)
     assert comm.device == local
     s, _ = synth_struct('small', 'priors')
     for damping in ('gna', 'lm', 'lmp'):

@@ -509,6 +509,47 @@ def test_two_ranks_rccl_match_single(hip):
     assert r.stdout.count('RANK_OK') == 2
 
 
+@pytest.mark.parametrize('world', [2, 3])
+def test_processes_share_one_gpu_through_the_host(hip, world):
+    """The multi-process path on a one-GPU box: `world` processes (torch.distributed.run, tests/_rccl_worker.py) share
+    GPU 0, every rank plans and runs its own domain of the dissection, and the sums over the ranks go through
+    host memory over gloo (parallel.Comm.attach_host) instead of RCCL.  Every rank's bundle() equals the
+    one-process result for GNA, LM and LMP."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--standalone', '--local-addr', '127.0.0.1', '--nnodes=1',
+           '--nproc-per-node', str(world), os.path.join(root, 'tests', '_rccl_worker.py')]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', DBAT_TEST_HOST_ALLREDUCE='1')
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count('RANK_OK') == world
+
+
+def test_bench_two_processes_on_one_gpu(hip):
+    """`python bench.py --gpus 2` end to end on a one-GPU box (DBAT_BENCH_HOST_ALLREDUCE=1: both ranks on GPU 0, sums
+    through the host): the launcher, one plan per rank, the barriers and the max over the ranks, the JSON line
+    of rank 0 -- and the LM solve inside it ends where the one-process run ends."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, 'bench.py'), '--config', 'C1', '--steps', '3', '--warmup', '1', '--no-cpu-baseline']
+    one = subprocess.run(base, capture_output=True, text=True, timeout=900, cwd=root)
+    assert one.returncode == 0, one.stderr[-3000:]
+    two = subprocess.run(base + ['--gpus', '2'], capture_output=True, text=True, timeout=900, cwd=root,
+                         env=dict(os.environ, DBAT_BENCH_HOST_ALLREDUCE='1'))
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-3000:]
+    j1, j2 = json.loads(one.stdout.strip().splitlines()[-1]), json.loads(two.stdout.strip().splitlines()[-1])
+    assert j2['n_gpus'] == 2 and j2['multi_gpu']['ranks'] == 2 and j2['multi_gpu']['domain_sharding']
+    assert j2['multi_gpu']['obs_this_rank'] < 0.6 * 100000
+    assert 'host memory' in j2['config']['collective']
+    assert j2['solve_lm']['code'] == 0 and j1['solve_lm']['code'] == 0
+    assert abs(j2['solve_lm']['sigma0'] - j1['solve_lm']['sigma0']) < 1e-8 * j1['solve_lm']['sigma0']
+
+
 def test_rccl_allreduce_on_raw_device_pointer(hip):
     """parallel.Comm.allreduce_ptr (the callback the core invokes) on a raw
     device pointer and a non-default HIP stream, over the nccl (= RCCL)
