@@ -10,6 +10,7 @@
 // The first NS = 6*nc+nIOu entries of z are the columns of the reduced
 // (camera + IO) system; the OP part is eliminated by the Schur complement.
 #pragma once
+#include <chrono>
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -173,6 +174,15 @@ inline void serialize_block(int rows, int cols, const int32_t *block, const uint
 }
 
 inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
+    // DBAT_HIP_PLAN_STATS=2: wall time of every section of the plan (stderr)
+    const bool plan_clock = getenv("DBAT_HIP_PLAN_STATS") && atoi(getenv("DBAT_HIP_PLAN_STATS")) >= 2;
+    auto plan_t0 = std::chrono::steady_clock::now();
+    auto lapt = [&](const char *what) {
+        if (!plan_clock) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[plan clock] %-60s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - plan_t0).count());
+        plan_t0 = now;
+    };
     if (pb.abi_version != DBAT_HIP_ABI_VERSION) return fail(P, "ABI version mismatch");
     if (pb.n_images <= 0 || pb.n_points <= 0 || pb.n_obs < 0) return fail(P, "empty problem");
     if (pb.dist_model < 2 || pb.dist_model > 5)
@@ -199,6 +209,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         for (int j = 0; j < P.nP; ++j) { if (!e[5 + P.nK + j]) gap = true; else if (gap) return fail(P, "Illegal cP vector"); }
         if (P.nP >= 2 && (e[5 + P.nK] != e[5 + P.nK + 1])) return fail(P, "Illegal cP vector");
     }
+    lapt("est / prior masks; bundle.m:137-154");
     // ---- serial indices
     std::vector<int32_t> distIO, distEO;
     std::vector<int64_t> leadIO, leadEO;
@@ -253,6 +264,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         if (!(P.z_prw[z] > 0) || !std::isfinite(P.z_prw[z])) return fail(P, "prior observation with zero/invalid std");
     P.m = 2 * P.no + P.n_prior[0] + P.n_prior[1] + P.n_prior[2];
 
+    lapt("serial indices");
     // ---- per-camera column lists
     P.px.assign(pb.px_size, pb.px_size + (size_t)2 * nc);
     P.cam_ncol.assign(nc, 6); P.cam_col.assign((size_t)nc * MAXCOL, -1);
@@ -287,6 +299,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         }
     }
 
+    lapt("per-camera column lists");
     // ---- observations: validate order, weights
     std::vector<int32_t> k_pt(np, 0), n_cam(nc, 0);
     for (int64_t o = 0; o < P.no; ++o) {
@@ -317,6 +330,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     for (int64_t o = 0; o < P.no; ++o)
         if (!(pb.ip_std[2 * o] > 0) || !(pb.ip_std[2 * o + 1] > 0)) return fail(P, "IP.std must be positive");
 
+    lapt("observations: validate order, weights");
     // ---- structural rank test (sprank(J), gauss_newton_armijo.m:132-142).  First the cheap
     // necessary conditions on the natural parameter groups; the exact matching follows below.
     P.rank_ok = P.m >= P.n;
@@ -339,12 +353,14 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
             if (rows[k] == 0 && !(P.z_prw[6 * (int64_t)nc + k] > 0)) P.rank_ok = false;
     }
 
+    lapt("structural rank test (sprank(J), gauss_newton_armijo.m:132");
     // ---- processing order of the object points
     std::vector<int64_t> pstart(np + 1, 0);
     for (int p = 0; p < np; ++p) pstart[p + 1] = pstart[p] + k_pt[p];
     std::vector<int64_t> fill(pstart.begin(), pstart.end() - 1);
     std::vector<int64_t> by_pt(P.no);
     for (int64_t o = 0; o < P.no; ++o) by_pt[fill[pb.ip_pt[o]]++] = o;   // image-major scan => cams ascending per point
+    lapt("processing order of the object points");
     // ---- exact structural rank (sprank(J) < n  =>  code -4): when the counting conditions
     // above hold, a maximum matching of the unknowns to the rows of J decides.  An unknown
     // with a prior observation owns that row.  The others are matched to image rows (two per
@@ -447,6 +463,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
             }
         }
     }
+    lapt("exact structural rank (sprank(J) < n  =>  code -4): when t");
     // ---- nested dissection (nd.hpp); with several ranks its first levels are the ranks' domains
     {
         const bool nd_off = getenv("DBAT_HIP_ND_OFF") != nullptr;
@@ -460,6 +477,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         const int leaf = std::max(8, getenv("DBAT_HIP_ND_LEAF") ? atoi(getenv("DBAT_HIP_ND_LEAF")) : 32);
         nd_build(nc, P.cam_adj.data(), P.cam_adj_words, xyz.data(), wcam.data(), P.mg_subtree ? P.nranks : 1, leaf, nd_off, P.nd);
     }
+    lapt("nested dissection");
     // Points that fit a tile of the MFMA Schur kernel (at most CMAX cameras and
     // IOT estimated IO columns) are processed first; "heavy" points (e.g. control
     // points seen in very many images) follow and go through k_build.
@@ -493,6 +511,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
             if (ns > Plan::IOT) heavy[p] = 1;
         }
     }
+    lapt("tile-fit classification of the points");
     // Key = Morton code of the point's initial coordinates in the principal axes of the
     // point cloud: points that are close in object space are seen by the same cameras, so
     // neighbouring points touch the same blocks of the reduced system (tiles below).  A
@@ -632,6 +651,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
             if (owner[P.porder[i]] == P.rank) { P.pt_lo = std::min<int64_t>(P.pt_lo, i); P.pt_hi = i + 1; }
         if (P.pt_hi < P.pt_lo) P.pt_lo = P.pt_hi = 0;
     } else
+    lapt("processing order (keys, sort)");
     // shard = contiguous range of the processing order balanced by observation count
     {
         std::vector<int64_t> cum(np + 1, 0);
@@ -645,6 +665,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         P.pt_lo = cut(P.rank); P.pt_hi = cut(P.rank + 1);
         if (P.pt_hi < P.pt_lo) P.pt_hi = P.pt_lo;
     }
+    lapt("shards");
     // the point part of z follows the processing order: permute everything that was laid out by point id
     P.pt_rank.assign(np, 0);
     for (int i = 0; i < np; ++i) P.pt_rank[P.porder[i]] = i;
@@ -678,6 +699,8 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         for (int d = 0; d < 3; ++d) P.z_mine[P.NS + 3 * i + d] = 1;
     if (!with_obs) return true;
 
+    lapt("nested dissection (nd.hpp); with several ranks its first l");
+    lapt("permutation of the point arrays, z_mine");
     // ---- batches of whole points, at most BT observations each; tiles of
     // batches touching at most CMAX cameras (fixed-IO path only)
     P.batch_start.clear(); P.batch_start.push_back(0);
@@ -786,6 +809,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     int32_t tile_id = 0;
     int pidx = 0;
     bool in_heavy = false;
+    lapt("batches, tiles, signature groups");
     // batches per tile: long tiles amortise the flush of the tile into S, but a small
     // problem must still break into enough tiles to occupy the 256 CUs twice over
     int64_t shard_obs = 0;
@@ -943,6 +967,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         // a chunk ends where the next one starts (same camera + CM_CHUNK, the next camera's first
         // observation, or the end of its part)
     }
+    lapt("tile bookkeeping");
     // k_build_sig takes the tiled points when every one of them fits its five row blocks, the
     // interior orientation is fixed and the groups are long enough to fill a wave's lanes
     // every chunk's rows (6k + the IO columns of its tile + the right-hand-side row) fit five 16-row blocks
@@ -971,6 +996,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
                 nbt.size(), nbt.front(), nbt[nbt.size() / 2], s / nbt.size(), nbt[nbt.size() * 9 / 10],
                 nbt[nbt.size() * 99 / 100], nbt.back(), (double)P.tile_cams.size() / nbt.size());
     }
+    lapt("kernel choice");
     return true;
 }
 
