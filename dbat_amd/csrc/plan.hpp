@@ -360,7 +360,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     std::vector<int64_t> fill(pstart.begin(), pstart.end() - 1);
     std::vector<int64_t> by_pt(P.no);
     for (int64_t o = 0; o < P.no; ++o) by_pt[fill[pb.ip_pt[o]]++] = o;   // image-major scan => cams ascending per point
-    lapt("processing order of the object points");
+    lapt("observations by point (counting sort)");
     // ---- exact structural rank (sprank(J) < n  =>  code -4): when the counting conditions
     // above hold, a maximum matching of the unknowns to the rows of J decides.  An unknown
     // with a prior observation owns that row.  The others are matched to image rows (two per
@@ -651,7 +651,6 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
             if (owner[P.porder[i]] == P.rank) { P.pt_lo = std::min<int64_t>(P.pt_lo, i); P.pt_hi = i + 1; }
         if (P.pt_hi < P.pt_lo) P.pt_lo = P.pt_hi = 0;
     } else
-    lapt("processing order (keys, sort)");
     // shard = contiguous range of the processing order balanced by observation count
     {
         std::vector<int64_t> cum(np + 1, 0);
@@ -665,7 +664,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         P.pt_lo = cut(P.rank); P.pt_hi = cut(P.rank + 1);
         if (P.pt_hi < P.pt_lo) P.pt_hi = P.pt_lo;
     }
-    lapt("shards");
+    lapt("processing order (keys, sort), shards");
     // the point part of z follows the processing order: permute everything that was laid out by point id
     P.pt_rank.assign(np, 0);
     for (int i = 0; i < np; ++i) P.pt_rank[P.porder[i]] = i;
@@ -699,7 +698,6 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         for (int d = 0; d < 3; ++d) P.z_mine[P.NS + 3 * i + d] = 1;
     if (!with_obs) return true;
 
-    lapt("nested dissection (nd.hpp); with several ranks its first l");
     lapt("permutation of the point arrays, z_mine");
     // ---- batches of whole points, at most BT observations each; tiles of
     // batches touching at most CMAX cameras (fixed-IO path only)

@@ -56,6 +56,19 @@ def test_domain_map_invariant_and_balance():
         assert 0 < np.count_nonzero(cam_owner < 0) < 0.75 * len(cam_owner)
     cam_owner, subtree = _hip.plan_domain_map(s, 1)
     assert not subtree and np.all(cam_owner == -1)
+    # scenes of random shape (bench/fuzz_multishard.py runs the same family through the GPU): every point's owner is
+    # the domain of its interior cameras, for even and odd numbers of ranks
+    rng = np.random.default_rng(11)
+    for _ in range(6):
+        cams, rays, points = int(rng.integers(30, 300)), int(rng.integers(3, 11)), int(rng.integers(500, 6000))
+        selfcal = bool(rng.integers(0, 2))
+        s, _t = synth.make_scene('C1' if rng.integers(0, 2) else 'small', seed=int(rng.integers(1, 10 ** 6)), cams=cams,
+                                 points=points, rays=rays, selfcal=selfcal, groups=2 if selfcal else 1)
+        for w in (2, 3, 5):
+            cam_owner, subtree = _hip.plan_domain_map(s, w)
+            owner = _hip.plan_point_owner(s, w)
+            co = cam_owner[s.IP.cam]
+            assert np.all((co < 0) | (co == owner[s.IP.pt])), (cams, rays, points, w)
 
 
 def test_point_owner_partitions_points():
