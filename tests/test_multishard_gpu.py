@@ -141,6 +141,53 @@ def test_domain_shards_step_scalars_and_covariance(hip, world):
             assert relerr(a, b) < 1e-8
 
 
+@pytest.mark.parametrize('seed', [5, 8, 12, 17, 26, 29])
+def test_domain_shards_random_scenes(hip, seed, monkeypatch):
+    """Scenes of random shape (cameras, points, rays, self-calibration with 1 ... 4 IO blocks, 2 ... 8 ranks, signature
+    kernels on / off) from bench/fuzz_multishard.py's family -- these seeds are the ones a broken point-shard range
+    once showed up on: every rank's Gauss-Newton and damped step and the step scalars as one rank's."""
+    from dbat_amd import synth
+    rng = np.random.default_rng(7000 + seed)
+    cams, rays, points = int(rng.integers(30, 400)), int(rng.integers(3, 12)), int(rng.integers(500, 12000))
+    selfcal = bool(rng.integers(0, 2))
+    groups = int(rng.choice([1, 1, 2, 4])) if selfcal else 1
+    world = int(rng.choice([2, 2, 3, 4, 5, 8]))
+    sig = str(rng.choice(['0', '2', '']))
+    if sig:
+        monkeypatch.setenv('DBAT_HIP_SIG', sig)
+    base = 'C1' if rng.integers(0, 2) else 'small'
+    s = synth.make_scene(base, seed=2000 + seed, cams=cams, points=points, rays=rays, selfcal=selfcal, groups=groups)[0]
+    cam_owner, subtree = hip.plan_domain_map(s, world)
+    owner = hip.plan_point_owner(s, world)
+    co = cam_owner[s.IP.cam]
+    assert subtree and np.all((co < 0) | (co == owner[s.IP.pt]))
+    h = hip.Handle(s)
+    try:
+        x0 = h.serialize()
+        p1, st1 = h.linearize_solve(x0, 0.0, True)
+        lam = 1e-4 * st1['trace'] / h.n
+        q1, st2 = h.linearize_solve(x0, lam, False)
+    finally:
+        h.close()
+
+    def work(comm):
+        hh = hip.Handle(s, shard_rank=comm.rank, shard_count=comm.world_size)
+        try:
+            hh.set_allreduce(comm.allreduce_ptr)
+            p, st = hh.linearize_solve(x0, 0.0, True)
+            q, stq = hh.linearize_solve(x0, lam, False)
+            return p, st, q, stq
+        finally:
+            hh.close()
+
+    out, _comms = _run_ranks(s, world, work)
+    for p, st, q, stq in out:
+        assert relerr(p, p1) < 1e-7 and relerr(q, q1) < 1e-9, (world, relerr(p, p1), relerr(q, q1))
+        for k in ('f', 'JpJp', 'rJp', 'pp', 'trace'):
+            assert abs(st[k] - st1[k]) <= 1e-8 * abs(st1[k]), k
+            assert abs(stq[k] - st2[k]) <= 1e-8 * abs(st2[k]), k
+
+
 @pytest.mark.parametrize('name,world', [('roma', 2), ('roma', 3), ('camcal', 2)])
 def test_domain_shards_real_projects(hip, name, world):
     """Real data under domain sharding: the roma script project (60 images with irregular visibility, 26 321
