@@ -305,7 +305,7 @@ class Handle:
         p, st = np.empty(self.n), np.empty(8)
         check(self.lib.dbat_hip_linearize_solve(self.h, dptr(x), float(lam), int(bool(scale)),
                                                 dptr(p), dptr(st)))
-        return p, dict(f=st[0], JpJp=st[1], rJp=st[2], pp=st[3], trace=st[4], singular=bool(st[5]))
+        return p, dict(f=st[0], JpJp=st[1], rJp=st[2], pp=st[3], trace=st[4], singular=bool(st[5]), rcond=st[6], chol_info=int(st[7]))
 
     def gradient(self):
         g = np.empty(self.n)

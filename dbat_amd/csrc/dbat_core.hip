@@ -745,6 +745,9 @@ struct Core {
     // CHOLMOD's estimate rcond = (min diag(L) / max diag(L))^2 < eps over the
     // pivots of the point blocks and of the reduced system.
     bool near_singular = false;
+    double rcond_est = 0.0;      // (min pivot / max pivot)^2 of the last solve; 0 after a failed factorisation
+    int chol_info = 0;           // k_chol_df's info of the last solve: > 0 first non-positive pivot, -1 dataflow abort
+    double piv_last[4] = {0, 0, 0, 0};   // {min, max} pivot of the point blocks, {min, max} of the reduced system
     bool solve(double &JpJp, double &rJp, double &pp) {
         ensure_build();
         if (!s_valid) build(zlin.p, lambda_lin, scale_lin);   // the factorisation overwrote S
@@ -784,6 +787,12 @@ struct Core {
         if (failed && !(use_perm && !chol_in_place)) s_dense_dirty = true;
         const double ratio = pmax > 0 ? pmin / pmax : 0.0;
         near_singular = failed || !(ratio * ratio >= 2.220446049250313e-16);
+        rcond_est = failed ? 0.0 : ratio * ratio;
+        chol_info = hinfo;
+        for (int q = 0; q < 4; ++q) piv_last[q] = mm[q];
+        if (getenv("DBAT_HIP_PIVOT_STATS"))
+            fprintf(stderr, "[solve] pivots of the point blocks %.3e ... %.3e, of the reduced system %.3e ... %.3e, info %d, rcond estimate %.3e\n",
+                    mm[0], mm[1], mm[2], mm[3], hinfo, rcond_est);
         return failed;
     }
     // ---- posterior covariance blocks at z (bundle_cov.m): s0^2 * blocks of inv(J'J)
@@ -1457,7 +1466,7 @@ int dbat_hip_linearize_solve(dbat_hip_handle *h, const double *x, double lambda,
     if (p) c.z_to_x(c.dz.p, p);
     if (stats) {
         stats[0] = c.f_lin; stats[1] = JpJp; stats[2] = rJp; stats[3] = pp;
-        stats[4] = c.trace_jtj; stats[5] = singular ? 1.0 : 0.0; stats[6] = 0; stats[7] = 0;
+        stats[4] = c.trace_jtj; stats[5] = singular ? 1.0 : 0.0; stats[6] = c.rcond_est; stats[7] = (double)c.chol_info;
     }
     return DBAT_HIP_OK;
     API_CATCH

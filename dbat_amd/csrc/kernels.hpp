@@ -424,6 +424,44 @@ __device__ __forceinline__ double fast_rcp(double x) {
     return r * (2.0 - x * r);
 }
 
+// Elimination of an object point's 3 x 3 block V (symmetric storage a00 a01 a02 a11 a12 a22), stably: V = U D U'
+// with U UNIT UPPER triangular (the last coordinate is eliminated first), hence V^-1 = R R' with
+// R = U^-T D^-1/2 LOWER triangular -- the Cholesky factor of V^-1, obtained from V itself and not from an
+// explicitly formed inverse.  Z = W R then gives the point's Schur term Z Z' = W V^-1 W' with the backward error
+// of a Cholesky factorisation of the full normal matrix (a small RELATIVE perturbation of V).  The adjugate
+// inverse used until round 3 loses cond(V) eps there: a point seen under a narrow angle next to a camera with
+// very large derivatives could push a pivot of the reduced system below zero while the full factorisation
+// (MATLAB's, the oracle's) still goes through (bench/fuzz_solve.py, start values far from the solution).
+// R = {r00, r10, r20, r11, r21, r22}; inv = R R' (for the back-substitution).  V not positive definite: NaN.
+__device__ __forceinline__ void point_block_factor(const double (&V)[6], double (&R)[6], double (&inv)[6]) {
+    const double s2 = fast_rcp(sqrt(V[5])), i2 = s2 * s2;
+    const double u12 = V[4] * i2, u02 = V[2] * i2;
+    const double d1 = V[3] - u12 * V[4];
+    const double s1 = fast_rcp(sqrt(d1)), i1 = s1 * s1;
+    const double u01 = (V[1] - u02 * V[4]) * i1;
+    const double d0 = V[0] - u01 * u01 * d1 - u02 * V[2];
+    const double s0 = fast_rcp(sqrt(d0));
+    R[0] = s0; R[1] = -u01 * s0; R[2] = (u01 * u12 - u02) * s0;
+    R[3] = s1; R[4] = -u12 * s1; R[5] = s2;
+    inv[0] = R[0] * R[0]; inv[1] = R[0] * R[1]; inv[2] = R[0] * R[2];
+    inv[3] = R[1] * R[1] + R[3] * R[3]; inv[4] = R[1] * R[2] + R[3] * R[4];
+    inv[5] = R[2] * R[2] + R[4] * R[4] + R[5] * R[5];
+}
+// The point arrays keep R (six doubles per point, where V^-1 used to be): p = -V^-1 s = -R (R' s), through the factor
+__device__ __forceinline__ void point_block_solve_neg(const double *__restrict__ R, double s0, double s1, double s2,
+                                                      double &p0, double &p1, double &p2) {
+    const double y0 = R[0] * s0 + R[1] * s1 + R[2] * s2, y1 = R[3] * s1 + R[4] * s2, y2 = R[5] * s2;
+    p0 = -(R[0] * y0);
+    p1 = -(R[1] * y0 + R[3] * y1);
+    p2 = -(R[2] * y0 + R[4] * y1 + R[5] * y2);
+}
+// ... and V^-1 = R R' itself (posterior covariance of the object points)
+__device__ __forceinline__ void point_block_inverse(const double *__restrict__ R, double (&inv)[6]) {
+    inv[0] = R[0] * R[0]; inv[1] = R[0] * R[1]; inv[2] = R[0] * R[2];
+    inv[3] = R[1] * R[1] + R[3] * R[3]; inv[4] = R[1] * R[2] + R[3] * R[4];
+    inv[5] = R[2] * R[2] + R[4] * R[4] + R[5] * R[5];
+}
+
 template <int MODEL, bool WITH_IO>
 __device__ __forceinline__ void eval_obs_cols(const DevProblem &d, const CamRec &C, const double *z,
                                               int64_t o, int pt, double r[2],
@@ -435,7 +473,7 @@ __device__ __forceinline__ void eval_obs_cols(const DevProblem &d, const CamRec 
 // One workgroup per batch; lane t <-> observation batch_start[b]+t.
 // Outputs: S (lower triangle, NS x NS column-major, atomically accumulated),
 // g_c (J_c' r), g_red (g_c - W V^-1 g_p), diagU (sum of squared camera-side
-// Jacobian columns), per point Vinv[6], gp[3], jn2[3] (squared column norms),
+// Jacobian columns), per point R[6] (V^-1 = R R': point_block_factor; the array is still called Vinv), gp[3], jn2[3] (squared column norms),
 // r_w (weighted residuals), partial sums of r'r.
 template <int MODEL, bool WITH_IO>
 __global__ __launch_bounds__(256) void k_build(DevProblem d, const double *__restrict__ z,
@@ -452,7 +490,7 @@ __global__ __launch_bounds__(256) void k_build(DevProblem d, const double *__res
     const int strideW = d.ncolmax * 3;
     double *Wl = smem;                               // [BT][strideW]
     double *red = Wl + (size_t)BT * strideW;         // [BT][9]  B'B (6) | B'r (3)
-    double *pinfo = red + (size_t)BT * 9;            // [BT][9]  Vinv (6) | gp (3)
+    double *pinfo = red + (size_t)BT * 9;            // [BT][9]  R (6: V^-1 = R R') | y = R' g (3)
     __shared__ double sh[8];
 
     const int t = threadIdx.x;
@@ -504,8 +542,8 @@ __global__ __launch_bounds__(256) void k_build(DevProblem d, const double *__res
             jn2p[3 * (int64_t)pt + k] = V[dix[k]];
             if (d.z_est[zp + k]) V[dix[k]] += lambda; else V[dix[k]] = 1.0;
         }
-        double inv[6];
-        inv3_sym(V, inv);
+        double inv[6], Rpb[6];
+        point_block_factor(V, Rpb, inv);
         {   // diag of chol(V): the leading pivots of the full normal-matrix factor
             const double d0 = sqrt(V[0]), l10 = V[1] / d0, l20 = V[2] / d0;
             const double d1 = sqrt(V[3] - l10 * l10), l21 = (V[4] - l20 * l10) / d1;
@@ -522,12 +560,15 @@ __global__ __launch_bounds__(256) void k_build(DevProblem d, const double *__res
         }
         double *pi = pinfo + (size_t)t * 9;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) { pi[k] = inv[k]; Vinv[6 * (int64_t)pt + k] = inv[k]; }
+        for (int k = 0; k < 6; ++k) { pi[k] = Rpb[k]; Vinv[6 * (int64_t)pt + k] = Rpb[k]; }
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { pi[6 + k] = g[k]; gp[3 * (int64_t)pt + k] = g[k]; }
+        for (int k = 0; k < 3; ++k) gp[3 * (int64_t)pt + k] = g[k];
+        pi[6] = Rpb[0] * g[0] + Rpb[1] * g[1] + Rpb[2] * g[2];      // y = R' g
+        pi[7] = Rpb[3] * g[1] + Rpb[4] * g[2];
+        pi[8] = Rpb[5] * g[2];
     }
     __syncthreads();
-    // ---- W = E'B, Y = W V^-1, reduced right-hand side
+    // ---- W = E'B, Z = W R (V^-1 = R R': point_block_factor), reduced right-hand side -Z y
     double Vi[6] = {0, 0, 0, 0, 0, 0}, gpt[3] = {0, 0, 0};
     double W[WITH_IO ? 1 : 6][3], Y[WITH_IO ? 1 : 6][3];
     if (active) {
@@ -542,10 +583,11 @@ __global__ __launch_bounds__(256) void k_build(DevProblem d, const double *__res
                 const double w0 = E[0][a] * B[0][0] + E[1][a] * B[1][0];
                 const double w1 = E[0][a] * B[0][1] + E[1][a] * B[1][1];
                 const double w2 = E[0][a] * B[0][2] + E[1][a] * B[1][2];
-                wl[3 * a] = w0; wl[3 * a + 1] = w1; wl[3 * a + 2] = w2;
+                // Z = W R; the scratch rows and Y hold Z: the point's Schur term is the Gram matrix Z Z'
                 const double y0 = w0 * Vi[0] + w1 * Vi[1] + w2 * Vi[2];
-                const double y1 = w0 * Vi[1] + w1 * Vi[3] + w2 * Vi[4];
-                const double y2 = w0 * Vi[2] + w1 * Vi[4] + w2 * Vi[5];
+                const double y1 = w1 * Vi[3] + w2 * Vi[4];
+                const double y2 = w2 * Vi[5];
+                wl[3 * a] = y0; wl[3 * a + 1] = y1; wl[3 * a + 2] = y2;
                 if constexpr (!WITH_IO) { W[a][0] = w0; W[a][1] = w1; W[a][2] = w2; Y[a][0] = y0; Y[a][1] = y1; Y[a][2] = y2; }
                 const int col = C->col[a];
                 const double ga = E[0][a] * r[0] + E[1][a] * r[1];
@@ -583,10 +625,7 @@ __global__ __launch_bounds__(256) void k_build(DevProblem d, const double *__res
             for (int a = 0; a < NCX; ++a) {
                 if (a >= ncol) break;
                 const int gcol = C->col[a];
-                const double w0 = wi[3 * a], w1 = wi[3 * a + 1], w2 = wi[3 * a + 2];
-                const double y0 = w0 * Vi[0] + w1 * Vi[1] + w2 * Vi[2];
-                const double y1 = w0 * Vi[1] + w1 * Vi[3] + w2 * Vi[4];
-                const double y2 = w0 * Vi[2] + w1 * Vi[4] + w2 * Vi[5];
+                const double y0 = wi[3 * a], y1 = wi[3 * a + 1], y2 = wi[3 * a + 2];      // (the scratch rows hold Z)
                 double ea0 = 0, ea1 = 0;
 #pragma unroll
                 for (int q = 0; q < NCX; ++q) if (q == a) { ea0 = E[0][q]; ea1 = E[1][q]; }
@@ -704,8 +743,8 @@ __global__ __launch_bounds__(256) void k_build_giant(DevProblem d, const double 
             jn2p[3 * (int64_t)pt + q] = jn[q];
             if (d.z_est[zp + q]) V[dix[q]] += lambda; else V[dix[q]] = 1.0;
         }
-        double inv[6];
-        inv3_sym(V, inv);
+        double inv[6], Rpb[6];
+        point_block_factor(V, Rpb, inv);
         const double d0 = sqrt(V[0]), l10 = V[1] / d0, l20 = V[2] / d0;
         const double d1 = sqrt(V[3] - l10 * l10), l21 = (V[4] - l20 * l10) / d1;
         const double d2 = sqrt(V[5] - l20 * l20 - l21 * l21);
@@ -716,8 +755,11 @@ __global__ __launch_bounds__(256) void k_build_giant(DevProblem d, const double 
                 v = v == v ? v : 0.0;
                 pmin = fmin(pmin, v); pmax = fmax(pmax, v);
             }
-        for (int q = 0; q < 6; ++q) { pin[q] = inv[q]; Vinv[6 * (int64_t)pt + q] = inv[q]; }
-        for (int q = 0; q < 3; ++q) { pin[6 + q] = g[q]; gp[3 * (int64_t)pt + q] = g[q]; }
+        for (int q = 0; q < 6; ++q) { pin[q] = Rpb[q]; Vinv[6 * (int64_t)pt + q] = Rpb[q]; }
+        for (int q = 0; q < 3; ++q) gp[3 * (int64_t)pt + q] = g[q];
+        pin[6] = Rpb[0] * g[0] + Rpb[1] * g[1] + Rpb[2] * g[2];     // y = R' g
+        pin[7] = Rpb[3] * g[1] + Rpb[4] * g[2];
+        pin[8] = Rpb[5] * g[2];
         if (pmax > 0.0) {
             atomicMin(pivmm, (unsigned long long)__double_as_longlong(pmin));
             atomicMax(pivmm + 1, (unsigned long long)__double_as_longlong(pmax));
@@ -725,18 +767,25 @@ __global__ __launch_bounds__(256) void k_build_giant(DevProblem d, const double 
     }
     __threadfence_block();
     __syncthreads();                                 // pin and the W scratch of the whole point are visible
-    const double v0 = pin[0], v1 = pin[1], v2 = pin[2], v3 = pin[3], v4 = pin[4], v5 = pin[5];
-    const double g0 = pin[6], g1 = pin[7], g2 = pin[8];
+    const double v0 = pin[0], v1 = pin[1], v2 = pin[2], v3 = pin[3], v4 = pin[4], v5 = pin[5];      // R: V^-1 = R R'
+    const double g0 = pin[6], g1 = pin[7], g2 = pin[8];                                               // y = R' g
+    for (int i = t; i < k; i += BT) {                // the scratch rows W -> Z = W R: the Schur term is the Gram matrix Z Z'
+        const int nci = WITH_IO ? cams[d.o_cam[o0 + i]].ncol : 6;
+        double *wi = Wg + (size_t)i * strideW;
+        for (int a = 0; a < nci; ++a) {
+            const double w0 = wi[3 * a], w1 = wi[3 * a + 1], w2 = wi[3 * a + 2];
+            wi[3 * a] = w0 * v0 + w1 * v1 + w2 * v2; wi[3 * a + 1] = w1 * v3 + w2 * v4; wi[3 * a + 2] = w2 * v5;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
     for (int i = t; i < k; i += BT) {                // ---- pass 2
         const CamRec &Ci = cams[d.o_cam[o0 + i]];
         const int nci = WITH_IO ? Ci.ncol : 6;
         const double *wi = Wg + (size_t)i * strideW;
         for (int a = 0; a < nci; ++a) {
             const int gcol = Ci.col[a];
-            const double w0 = wi[3 * a], w1 = wi[3 * a + 1], w2 = wi[3 * a + 2];
-            const double y0 = w0 * v0 + w1 * v1 + w2 * v2;
-            const double y1 = w0 * v1 + w1 * v3 + w2 * v4;
-            const double y2 = w0 * v2 + w1 * v4 + w2 * v5;
+            const double y0 = wi[3 * a], y1 = wi[3 * a + 1], y2 = wi[3 * a + 2];
             atomic_add_f64(g_red + gcol, -(y0 * g0 + y1 * g1 + y2 * g2));
             // partners: fixed IO -> cameras ascend inside a point, j >= i covers the lower triangle;
             // with IO columns every ordered pair whose row is not above the column
@@ -790,10 +839,8 @@ __global__ __launch_bounds__(256) void k_backsub_giant(DevProblem d, const doubl
     block_sum<3>(s, sh);
     if (t == 0) {
         for (int q = 0; q < 3; ++q) s[q] += gp[3 * (int64_t)pt + q];
-        const double *vi = Vinv + 6 * (int64_t)pt;
-        const double p0 = -(vi[0] * s[0] + vi[1] * s[1] + vi[2] * s[2]);
-        const double p1 = -(vi[1] * s[0] + vi[3] * s[1] + vi[4] * s[2]);
-        const double p2 = -(vi[2] * s[0] + vi[4] * s[1] + vi[5] * s[2]);
+        double p0, p1, p2;
+        point_block_solve_neg(Vinv + 6 * (int64_t)pt, s[0], s[1], s[2], p0, p1, p2);
         const int64_t zp = d.NS + 3 * (int64_t)pt;
         dps[0] = d.z_est[zp] ? p0 : 0.0; dps[1] = d.z_est[zp + 1] ? p1 : 0.0; dps[2] = d.z_est[zp + 2] ? p2 : 0.0;
         dz[zp] = dps[0]; dz[zp + 1] = dps[1]; dz[zp + 2] = dps[2];
@@ -1207,18 +1254,10 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
                     jn2p[3 * (int64_t)pt + k] = jn[k];
                     if ((est >> k) & 1u) V[dix[k]] += lambda; else V[dix[k]] = 1.0;
                 }
-                double inv[6];
-                {   // adjugate inverse and the SQUARED pivots of chol(V) (the square roots are taken
-                    // once per wave at the end of the kernel)
-                    const double c00 = V[3] * V[5] - V[4] * V[4];
-                    const double c01 = V[2] * V[4] - V[1] * V[5];
-                    const double c02 = V[1] * V[4] - V[2] * V[3];
-                    const double det = V[0] * c00 + V[1] * c01 + V[2] * c02;
-                    const double id = fast_rcp(det);
-                    inv[0] = c00 * id; inv[1] = c01 * id; inv[2] = c02 * id;
-                    inv[3] = (V[0] * V[5] - V[2] * V[2]) * id;
-                    inv[4] = (V[1] * V[2] - V[0] * V[4]) * id;
-                    inv[5] = (V[0] * V[3] - V[1] * V[1]) * id;
+                double inv[6], Rpb[6];
+                {   // the block's factor (point_block_factor) and the SQUARED pivots of chol(V) (the square roots are
+                    // taken once per wave at the end of the kernel)
+                    point_block_factor(V, Rpb, inv);
                     const double r0 = fast_rcp(V[0]);
                     const double d1s = V[3] - V[1] * V[1] * r0;
                     const double tt = V[4] - V[2] * V[1] * r0;
@@ -1234,15 +1273,14 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
                 }
                 double *pi = pinv + (size_t)pidx * 15;
 #pragma unroll
-                for (int k = 0; k < 6; ++k) { pi[k] = inv[k]; Vinv[6 * (int64_t)pt + k] = inv[k]; }
+                for (int k = 0; k < 6; ++k) { pi[k] = Rpb[k]; Vinv[6 * (int64_t)pt + k] = Rpb[k]; }
 #pragma unroll
-                for (int k = 0; k < 3; ++k) { pi[6 + k] = g[k]; gp[3 * (int64_t)pt + k] = g[k]; }
+                for (int k = 0; k < 3; ++k) gp[3 * (int64_t)pt + k] = g[k];
+                pi[6] = Rpb[0] * g[0] + Rpb[1] * g[1] + Rpb[2] * g[2];      // y = R' g
+                pi[7] = Rpb[3] * g[1] + Rpb[4] * g[2];
+                pi[8] = Rpb[5] * g[2];
                 {   // V^-1 = R R', R lower triangular
-                    const double r00 = sqrt(inv[0]), ir00 = fast_rcp(r00);
-                    const double r10 = inv[1] * ir00, r20 = inv[2] * ir00;
-                    const double r11 = sqrt(inv[3] - r10 * r10);
-                    const double r21 = (inv[4] - r20 * r10) * fast_rcp(r11);
-                    const double r22 = sqrt(inv[5] - r20 * r20 - r21 * r21);
+                    const double r00 = Rpb[0], r10 = Rpb[1], r20 = Rpb[2], r11 = Rpb[3], r21 = Rpb[4], r22 = Rpb[5];
                     pi[9] = r00; pi[10] = r10; pi[11] = r20; pi[12] = r11; pi[13] = r21; pi[14] = r22;
                 }
             }
@@ -1278,9 +1316,9 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
                     const double w0 = E[0][a] * B[0][0] + E[1][a] * B[1][0];
                     const double w1 = E[0][a] * B[0][1] + E[1][a] * B[1][1];
                     const double w2 = E[0][a] * B[0][2] + E[1][a] * B[1][2];
-                    const double y0 = w0 * v0 + w1 * v1 + w2 * v2;
-                    const double y1 = w0 * v1 + w1 * v3 + w2 * v4;
-                    const double y2 = w0 * v2 + w1 * v4 + w2 * v5;
+                    const double y0 = w0 * v0 + w1 * v1 + w2 * v2;               // z = w R, and -(W V^-1 g) = -z (R' g)
+                    const double y1 = w1 * v3 + w2 * v4;
+                    const double y2 = w2 * v5;
                     atomic_add_f64(vt + lrow(a), -(y0 * g0 + y1 * g1 + y2 * g2));
                 }
             }
@@ -1298,8 +1336,8 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
                             const double w1 = e0 * B[0][1] + e1 * B[1][1];
                             const double w2 = e0 * B[0][2] + e1 * B[1][2];
                             const double y0 = w0 * v0 + w1 * v1 + w2 * v2;
-                            const double y1 = w0 * v1 + w1 * v3 + w2 * v4;
-                            const double y2 = w0 * v2 + w1 * v4 + w2 * v5;
+                            const double y1 = w1 * v3 + w2 * v4;
+                            const double y2 = w2 * v5;
                             gr = -(y0 * g0 + y1 * g1 + y2 * g2);
                         }
                         const double s_r = wave_sum_f64(gr);
@@ -1594,17 +1632,9 @@ __global__ __launch_bounds__(768) void k_build_tile3(DevProblem d, const double 
                     jn2p[3 * (int64_t)pt + k] = jn[k];
                     if ((est >> k) & 1u) V[dix[k]] += lambda; else V[dix[k]] = 1.0;
                 }
-                double inv[6];
+                double inv[6], Rpb[6];
                 {
-                    const double c00 = V[3] * V[5] - V[4] * V[4];
-                    const double c01 = V[2] * V[4] - V[1] * V[5];
-                    const double c02 = V[1] * V[4] - V[2] * V[3];
-                    const double det = V[0] * c00 + V[1] * c01 + V[2] * c02;
-                    const double id = fast_rcp(det);
-                    inv[0] = c00 * id; inv[1] = c01 * id; inv[2] = c02 * id;
-                    inv[3] = (V[0] * V[5] - V[2] * V[2]) * id;
-                    inv[4] = (V[1] * V[2] - V[0] * V[4]) * id;
-                    inv[5] = (V[0] * V[3] - V[1] * V[1]) * id;
+                    point_block_factor(V, Rpb, inv);
                     const double r0 = fast_rcp(V[0]);
                     const double d1s = V[3] - V[1] * V[1] * r0;
                     const double tt = V[4] - V[2] * V[1] * r0;
@@ -1620,18 +1650,15 @@ __global__ __launch_bounds__(768) void k_build_tile3(DevProblem d, const double 
                 }
                 double *pi = pinvg + (size_t)pidx * PW;
 #pragma unroll
-                for (int k = 0; k < 6; ++k) Vinv[6 * (int64_t)pt + k] = inv[k];
+                for (int k = 0; k < 6; ++k) Vinv[6 * (int64_t)pt + k] = Rpb[k];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) gp[3 * (int64_t)pt + k] = g[k];
-                pi[0] = inv[0] * g[0] + inv[1] * g[1] + inv[2] * g[2];        // h = V^-1 g
-                pi[1] = inv[1] * g[0] + inv[3] * g[1] + inv[4] * g[2];
-                pi[2] = inv[2] * g[0] + inv[4] * g[1] + inv[5] * g[2];
-                {   // V^-1 = R R', R lower triangular
-                    const double r00 = sqrt(inv[0]), ir00 = fast_rcp(r00);
-                    const double r10 = inv[1] * ir00, r20 = inv[2] * ir00;
-                    const double r11 = sqrt(inv[3] - r10 * r10);
-                    const double r21 = (inv[4] - r20 * r10) * fast_rcp(r11);
-                    const double r22 = sqrt(inv[5] - r20 * r20 - r21 * r21);
+                {   // V^-1 = R R', R lower triangular; h = V^-1 g = R (R' g), through the factor (see point_block_factor)
+                    const double r00 = Rpb[0], r10 = Rpb[1], r20 = Rpb[2], r11 = Rpb[3], r21 = Rpb[4], r22 = Rpb[5];
+                    const double y0 = r00 * g[0] + r10 * g[1] + r20 * g[2], y1 = r11 * g[1] + r21 * g[2], y2 = r22 * g[2];
+                    pi[0] = r00 * y0;
+                    pi[1] = r10 * y0 + r11 * y1;
+                    pi[2] = r20 * y0 + r21 * y1 + r22 * y2;
                     pi[3] = r00; pi[4] = r10; pi[5] = r20; pi[6] = r11; pi[7] = r21; pi[8] = r22;
                 }
             }
@@ -1815,8 +1842,7 @@ __global__ __launch_bounds__(256) void k_cov_points(DevProblem d, const double *
         ncol = WITH_IO ? C->ncol : 6;
         double r[2], E[2][NCX], B[2][3];
         eval_obs_cols<MODEL, WITH_IO>(d, *C, z, o, pt, r, E, B);
-#pragma unroll
-        for (int q = 0; q < 6; ++q) vi[q] = Vinv[6 * (int64_t)pt + q];
+        point_block_inverse(Vinv + 6 * (int64_t)pt, vi);
         double *yl = Yl + (size_t)t * strideW;
 #pragma unroll
         for (int a = 0; a < NCX; ++a)
@@ -1886,8 +1912,7 @@ __global__ __launch_bounds__(256) void k_cov_giant(DevProblem d, const double *_
     double *Yg = d.giant_W + (o0 - d.giant_start[0]) * strideW;
     const int pt = d.o_pt[o0];
     double vi[6];
-#pragma unroll
-    for (int q = 0; q < 6; ++q) vi[q] = Vinv[6 * (int64_t)pt + q];
+    point_block_inverse(Vinv + 6 * (int64_t)pt, vi);
     for (int i = t; i < k; i += BT) {
         const int64_t o = o0 + i;
         const CamRec &C = cams[d.o_cam[o]];
@@ -2129,10 +2154,8 @@ __global__ __launch_bounds__(256) void k_backsub(DevProblem d, const double *__r
     if (active && t == seg_start) {
         double s[3] = {gp[3 * (int64_t)pt], gp[3 * (int64_t)pt + 1], gp[3 * (int64_t)pt + 2]};
         for (int j = 0; j < seg_len; ++j) { s[0] += red[3 * (t + j)]; s[1] += red[3 * (t + j) + 1]; s[2] += red[3 * (t + j) + 2]; }
-        const double *vi = Vinv + 6 * (int64_t)pt;
-        const double p0 = -(vi[0] * s[0] + vi[1] * s[1] + vi[2] * s[2]);
-        const double p1 = -(vi[1] * s[0] + vi[3] * s[1] + vi[4] * s[2]);
-        const double p2 = -(vi[2] * s[0] + vi[4] * s[1] + vi[5] * s[2]);
+        double p0, p1, p2;
+        point_block_solve_neg(Vinv + 6 * (int64_t)pt, s[0], s[1], s[2], p0, p1, p2);
         const int64_t zp = d.NS + 3 * (int64_t)pt;
         const double q0 = d.z_est[zp] ? p0 : 0.0, q1 = d.z_est[zp + 1] ? p1 : 0.0, q2 = d.z_est[zp + 2] ? p2 : 0.0;
         dz[zp] = q0; dz[zp + 1] = q1; dz[zp + 2] = q2;

@@ -314,16 +314,8 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
                     if (writer) jn2p[3 * (int64_t)pt + c] = jn[c];
                     if ((est >> c) & 1u) V[dix[c]] += lambda; else V[dix[c]] = 1.0;
                 }
-                double inv[6];
-                const double c00 = V[3] * V[5] - V[4] * V[4];
-                const double c01 = V[2] * V[4] - V[1] * V[5];
-                const double c02 = V[1] * V[4] - V[2] * V[3];
-                const double det = V[0] * c00 + V[1] * c01 + V[2] * c02;
-                const double id = fast_rcp(det);
-                inv[0] = c00 * id; inv[1] = c01 * id; inv[2] = c02 * id;
-                inv[3] = (V[0] * V[5] - V[2] * V[2]) * id;
-                inv[4] = (V[1] * V[2] - V[0] * V[4]) * id;
-                inv[5] = (V[0] * V[3] - V[1] * V[1]) * id;
+                double inv[6], Rpb[6];
+                point_block_factor(V, Rpb, inv);          // V^-1 = R R', R lower triangular, straight from V
                 {   // pivots of the point block (CHOLMOD's rcond estimate)
                     const double r0 = fast_rcp(V[0]);
                     const double d1s = V[3] - V[1] * V[1] * r0;
@@ -340,16 +332,11 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
                 }
                 if (writer) {
 #pragma unroll
-                    for (int c = 0; c < 6; ++c) Vinv[6 * (int64_t)pt + c] = inv[c];
+                    for (int c = 0; c < 6; ++c) Vinv[6 * (int64_t)pt + c] = Rpb[c];     // the factor: V^-1 = R R'
 #pragma unroll
                     for (int c = 0; c < 3; ++c) gp[3 * (int64_t)pt + c] = g[c];
                 }
-                // V^-1 = R R', R lower triangular
-                const double r00 = sqrt(inv[0]), ir00 = fast_rcp(r00);
-                const double r10 = inv[1] * ir00, r20 = inv[2] * ir00;
-                const double r11 = sqrt(inv[3] - r10 * r10);
-                const double r21 = (inv[4] - r20 * r10) * fast_rcp(r11);
-                const double r22 = sqrt(inv[5] - r20 * r20 - r21 * r21);
+                const double r00 = Rpb[0], r10 = Rpb[1], r20 = Rpb[2], r11 = Rpb[3], r21 = Rpb[4], r22 = Rpb[5];
                 pR[0] = r00; pR[1] = r10; pR[2] = r20; pR[3] = r11; pR[4] = r21; pR[5] = r22;
                 pY[0] = r00 * g[0] + r10 * g[1] + r20 * g[2];                  // y = R' g
                 pY[1] = r11 * g[1] + r21 * g[2];
@@ -689,10 +676,8 @@ __global__ __launch_bounds__(256) void k_backsub_sig(DevProblem d, const double 
         }
         {
             const double s0 = gp[3 * (int64_t)pt] + sB[0], s1 = gp[3 * (int64_t)pt + 1] + sB[1], s2 = gp[3 * (int64_t)pt + 2] + sB[2];
-            const double *vi = Vinv + 6 * (int64_t)pt;
-            const double p0 = -(vi[0] * s0 + vi[1] * s1 + vi[2] * s2);
-            const double p1 = -(vi[1] * s0 + vi[3] * s1 + vi[4] * s2);
-            const double p2 = -(vi[2] * s0 + vi[4] * s1 + vi[5] * s2);
+            double p0, p1, p2;
+            point_block_solve_neg(Vinv + 6 * (int64_t)pt, s0, s1, s2, p0, p1, p2);
             const double d0 = (est & 1u) ? p0 : 0.0, d1 = (est & 2u) ? p1 : 0.0, d2 = (est & 4u) ? p2 : 0.0;
             if (act) {
                 dz[zp] = d0; dz[zp + 1] = d1; dz[zp + 2] = d2;

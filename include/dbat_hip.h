@@ -210,7 +210,9 @@ int  dbat_hip_jacobian_blocks(dbat_hip_handle *h, const double *x,
  *   scale_columns=0 : p = (J'*J + lambda*I) \ (-J'*r)   (levenberg_marquardt.m:119; gauss_markov.m:79)
  * computed by Schur-complement elimination of the object-point blocks.
  * p [n] in x order.  stats[8] = { f=0.5 r'r, ||J p||^2, r'Jp, ||p||^2,
- * trace(J'J), singular flag, 0, 0 }.  Jp/stats may be NULL. */
+ * trace(J'J), singular flag, the estimate (min pivot / max pivot)^2 the flag is taken from (CHOLMOD's rcond;
+ * 0 after a failed factorisation), the factorisation's info (> 0: first non-positive pivot, index in
+ * the factorised order) }.  Jp/stats may be NULL. */
 int  dbat_hip_linearize_solve(dbat_hip_handle *h, const double *x, double lambda,
                               int32_t scale_columns, double *p, double *stats);
 

@@ -509,6 +509,54 @@ def test_two_ranks_rccl_match_single(hip):
     assert r.stdout.count('RANK_OK') == 2
 
 
+@pytest.mark.parametrize('path', ['tile3', 'sig', 'column-list'])
+def test_ill_conditioned_point_blocks(hip, path, monkeypatch):
+    """Start values far from the solution (bench/fuzz_solve.py, seed 137: exterior orientations off by metres and
+    tenths of a radian): object points seen under narrow angles (cond(V) up to 7e8) beside an image whose derivatives
+    are a thousand times the others'.  cond(J'J) is 8e9 -- well inside double precision, the oracle's Cholesky of the
+    full normal matrix goes through -- but the Schur complement only survives if the point blocks are eliminated
+    through their FACTOR (kernels.hpp point_block_factor: V^-1 = R R', Z = W R, h = R (R' g)): with the adjugate
+    inverse of rounds 1-3 the reduced system lost a pivot (code -2 at iteration 0 where the reference converges in 15
+    iterations) and products with the explicit inverse cost five digits of the step.  Every build path."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(9000 + 137)
+    rng.choice(['plain', 'selfcal', 'imagevar', 'priors', 'groups4']); rng.choice(['tiny', 'tiny', 'small'])
+    s, truth = synth_struct('tiny', 'plain', seed=3000 + 137)
+    push = float(rng.choice([0.0, 1.0, 3.0, 10.0, 30.0])) * 12
+    assert push == 120.0
+    nc, npnt = s.EO.val.shape[1], s.OP.val.shape[1]
+    s.EO.val[0:3] += push * rng.normal(0, 0.05, (3, nc))
+    s.EO.val[3:6] += push * rng.normal(0, 0.002, (3, nc))
+    s.OP.val += push * rng.normal(0, 0.05, (3, npnt))
+    so, x0, w = oracle_setup(s)
+    Rw = np.sqrt(w)
+    r_o, K = o.brown_euler_cam4(x0, so, jac=True)
+    J = (sp.diags(Rw) @ K).tocsc()
+    p_o, sing, Jn, *_ = o._scaled_gn(J, Rw * r_o)
+    assert not sing
+    p_qr = np.linalg.lstsq((J @ sp.diags(1.0 / Jn)).toarray(), -(Rw * r_o), rcond=None)[0] / Jn      # no normal equations at all
+    assert relerr(p_o, p_qr) < 5e-6
+    monkeypatch.setenv(*{'tile3': ('DBAT_HIP_SIG', '0'), 'sig': ('DBAT_HIP_SIG', '2'), 'column-list': ('DBAT_HIP_CMAX', '0')}[path])
+    h = hip.Handle(s)
+    try:
+        assert h.build_kernel_name() == {'tile3': 'k_build_tile3', 'sig': 'k_build_sig', 'column-list': 'k_build'}[path]
+        p, st = h.linearize_solve(x0, 0.0, True)
+        assert st['chol_info'] == 0 and not st['singular'] and 1e-10 < st['rcond'] < 1e-7
+        assert relerr(p, p_qr) < 1e-6, relerr(p, p_qr)           # measured 2 ... 4e-8 on all three paths
+        lam = 1e-10 * st['trace'] / h.n
+        q, st2 = h.linearize_solve(x0, lam, False)
+        q_o, _ = o.normal_solve(((J.T @ J) + lam * sp.identity(J.shape[1])).tocsc(), -(J.T @ (Rw * r_o)))
+        assert st2['chol_info'] == 0 and relerr(q, q_o) < 1e-5
+    finally:
+        h.close()
+    if path == 'sig':
+        from dbat_amd import bundle
+        res, ok, iters, s0, E = bundle(s, 'gna')
+        ro, oko, ito, s0o, Eo = o.bundle(s, 'gna')
+        assert ok and oko and E.code == 0 and iters == ito == 15
+        assert relerr(E.x, Eo.x) < 1e-6
+
+
 @pytest.mark.parametrize('world', [2, 3])
 def test_processes_share_one_gpu_through_the_host(hip, world):
     """The multi-process path on a one-GPU box: `world` processes (torch.distributed.run, tests/_rccl_worker.py) share
