@@ -1,0 +1,108 @@
+"""Randomised sweep of the paths that regular synthetic scenes never reach, outside the test-suite: irregular
+visibility (random observations dropped, down to two rays per point), control points seen in many or all images
+(heavy points through the column-list kernel, giant points through k_build_giant / k_backsub_giant), cameras per
+tile, batch length and giant-kernel width forced small, signature kernels on / off -- the device's Gauss-Newton and
+damped steps, step scalars, gradient and (small scenes) the posterior covariance blocks against the oracle.
+    python bench/fuzz_irregular.py [n_scenes] [first_seed]"""
+import os, sys
+R_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R_); sys.path.insert(0, os.path.join(R_, 'oracle')); sys.path.insert(0, os.path.join(R_, 'tests'))
+import numpy as np, scipy.sparse as sp
+import dbat_oracle as o
+from dbat_amd import synth, _hip
+from test_hip_parity import oracle_setup
+
+relerr = lambda a, b: float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+KNOBS = ('DBAT_HIP_SIG', 'DBAT_HIP_CMAX', 'DBAT_HIP_BT', 'DBAT_HIP_GIANT_THREADS')
+
+
+def main():
+    n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    nbad, worst = 0, 0.0
+    for sd in range(seed0, seed0 + n_scenes):
+        rng = np.random.default_rng(11000 + sd)
+        cams = int(rng.integers(12, 150)); rays = int(rng.integers(4, 12)); points = int(rng.integers(150, 3000))
+        selfcal = bool(rng.integers(0, 2)); groups = int(rng.choice([1, 1, 2])) if selfcal else 1
+        s, truth = synth.make_scene('small', seed=5000 + sd, cams=cams, points=points, rays=rays, selfcal=selfcal, groups=groups)
+        s.IO.val[5:10] = 0.0; truth['IO'][5:10] = 0.0        # distortion-free: projections far outside the format stay defined
+        nc = s.EO.val.shape[1]
+        px = float(np.ravel(s.IO.sensor.pxSize)[0])
+        cam, pt = np.asarray(s.IP.cam), np.asarray(s.IP.pt)
+        # control points: seen by many (or all) images
+        ncp = int(rng.integers(0, 4))
+        frac = float(rng.choice([0.3, 0.6, 1.0]))
+        add_c, add_p = [], []
+        for p in rng.choice(points, size=ncp, replace=False):
+            have = set(cam[pt == p].tolist())
+            for c in range(nc):
+                if c not in have and rng.random() < frac: add_c.append(c); add_p.append(int(p))
+        cam = np.r_[cam, np.array(add_c, int)]; pt = np.r_[pt, np.array(add_p, int)]
+        # drop observations at random, keeping at least two rays per point
+        drop = float(rng.choice([0.0, 0.2, 0.5]))
+        keep = rng.random(len(cam)) >= drop
+        cnt = np.bincount(pt[keep], minlength=points)
+        for p in np.nonzero(cnt < 2)[0]: keep[pt == p] = True
+        cam, pt = cam[keep], pt[keep]
+        order = np.lexsort((pt, cam)); cam, pt = cam[order], pt[order]
+        uv, depth = synth.project(truth['IO'], truth['EO'], truth['OP'], cam, pt, px, nK=3, nP=2)
+        s.IP.val = uv + rng.normal(0, 0.5, uv.shape); s.IP.std = np.ones_like(uv)
+        s.IP.cam, s.IP.pt = cam, pt
+        env = {}
+        if rng.integers(0, 2): env['DBAT_HIP_SIG'] = str(rng.choice(['0', '2']))
+        if rng.integers(0, 2): env['DBAT_HIP_CMAX'] = str(rng.choice(['0', '4', '6', '10']))
+        if rng.integers(0, 2):
+            env['DBAT_HIP_BT'] = str(rng.choice(['64', '128']))
+            env['DBAT_HIP_GIANT_THREADS'] = str(rng.choice(['64', '128', '256']))
+        for k in KNOBS: os.environ.pop(k, None)
+        os.environ.update(env)
+        line = 'seed %3d: %3d cams %4d pts %2d rays, %d obs (max %3d per point), selfcal=%d groups=%d, drop %.1f, %s |' % (
+            sd, cams, points, rays, len(cam), int(np.bincount(pt).max()), selfcal, groups, drop, ' '.join('%s=%s' % (k[9:], v) for k, v in env.items()) or 'defaults')
+        try:
+            so, x0, w = oracle_setup(s)
+            Rw = np.sqrt(w)
+            r_o, K = o.brown_euler_cam4(x0, so, jac=True)
+            J = (sp.diags(Rw) @ K).tocsc()
+            p_o, sing, *_ = o._scaled_gn(J, Rw * r_o)
+            JTJ = (J.T @ J).tocsc()
+            lam = 1e-4 * JTJ.diagonal().sum() / J.shape[1]
+            q_o, _ = o.normal_solve((JTJ + lam * sp.identity(J.shape[1])).tocsc(), -(J.T @ (Rw * r_o)))
+            h = _hip.Handle(s)
+            try:
+                inf = h.info()
+                p, st = h.linearize_solve(x0, 0.0, True)
+                g = h.gradient()
+                q, st2 = h.linearize_solve(x0, lam, False)
+                e = [relerr(p, p_o), relerr(q, q_o), relerr(g, J.T @ (Rw * r_o))]
+                Jp = J @ p_o
+                if sing:      # rank-deficient after the thinning (the oracle's rcond test fires): both must say so, the steps mean nothing
+                    line += ' %s: singular in the oracle, device flag %s' % (h.build_kernel_name(), st['singular'])
+                    if not st['singular']: raise AssertionError('the device does not flag the singular system')
+                    print(line, flush=True)
+                    continue
+                ok = e[0] < 1e-6 and e[1] < 1e-7 and e[2] < 1e-9 and abs(st['JpJp'] - Jp @ Jp) <= 1e-6 * (Jp @ Jp) and not st['singular']
+                line += ' %s, %d tiles, %d batches: GN %.1e LM %.1e grad %.1e' % (h.build_kernel_name(), inf['n_tiles'], inf['n_batches'], e[0], e[1], e[2])
+                worst = max(worst, e[0], e[1])
+                if J.shape[1] <= 4000:                      # posterior covariance: must exist wherever the oracle's Cholesky of J'J does
+                    try:
+                        np.linalg.cholesky(JTJ.toarray()); o_ok = True
+                    except np.linalg.LinAlgError:
+                        o_ok = False
+                    try:
+                        C = h.posterior_cov(x0, 1.0); d_ok = all(np.all(np.isfinite(c)) for c in C)
+                    except _hip.DbatHipError as ex:
+                        d_ok = False
+                    line += ' cov %s (oracle chol %s, cond %.1e)' % ('ok' if d_ok else 'FAILS', 'ok' if o_ok else 'fails', np.linalg.cond(JTJ.toarray()))
+                    ok = ok and (d_ok or not o_ok)
+                if not ok: raise AssertionError('tolerance')
+            finally:
+                h.close()
+        except AssertionError as ex:
+            nbad += 1; line += '  <-- DISAGREES (%s)' % ex
+        print(line, flush=True)
+    print('worst relative difference of a step over %d scenes: %.2e; %d disagreements' % (n_scenes, worst, nbad))
+    sys.exit(1 if nbad else 0)
+
+
+if __name__ == '__main__':
+    main()
