@@ -16,48 +16,56 @@ relerr = lambda a, b: float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30
 KNOBS = ('DBAT_HIP_SIG', 'DBAT_HIP_CMAX', 'DBAT_HIP_BT', 'DBAT_HIP_GIANT_THREADS')
 
 
+def irregular_scene(sd):
+    """Scene number sd of the family: (s, env, description)."""
+    rng = np.random.default_rng(11000 + sd)
+    cams = int(rng.integers(12, 150)); rays = int(rng.integers(4, 12)); points = int(rng.integers(150, 3000))
+    selfcal = bool(rng.integers(0, 2)); groups = int(rng.choice([1, 1, 2])) if selfcal else 1
+    s, truth = synth.make_scene('small', seed=5000 + sd, cams=cams, points=points, rays=rays, selfcal=selfcal, groups=groups)
+    s.IO.val[5:10] = 0.0; truth['IO'][5:10] = 0.0        # distortion-free: projections far outside the format stay defined
+    nc = s.EO.val.shape[1]
+    px = float(np.ravel(s.IO.sensor.pxSize)[0])
+    cam, pt = np.asarray(s.IP.cam), np.asarray(s.IP.pt)
+    # control points: seen by many (or all) images
+    ncp = int(rng.integers(0, 4))
+    frac = float(rng.choice([0.3, 0.6, 1.0]))
+    add_c, add_p = [], []
+    for p in rng.choice(points, size=ncp, replace=False):
+        have = set(cam[pt == p].tolist())
+        for c in range(nc):
+            if c not in have and rng.random() < frac: add_c.append(c); add_p.append(int(p))
+    cam = np.r_[cam, np.array(add_c, int)]; pt = np.r_[pt, np.array(add_p, int)]
+    # drop observations at random, keeping at least two rays per point
+    drop = float(rng.choice([0.0, 0.2, 0.5]))
+    keep = rng.random(len(cam)) >= drop
+    cnt = np.bincount(pt[keep], minlength=points)
+    for p in np.nonzero(cnt < 2)[0]: keep[pt == p] = True
+    cam, pt = cam[keep], pt[keep]
+    order = np.lexsort((pt, cam)); cam, pt = cam[order], pt[order]
+    uv, depth = synth.project(truth['IO'], truth['EO'], truth['OP'], cam, pt, px, nK=3, nP=2)
+    s.IP.val = uv + rng.normal(0, 0.5, uv.shape); s.IP.std = np.ones_like(uv)
+    s.IP.cam, s.IP.pt = cam, pt
+    env = {}
+    if rng.integers(0, 2): env['DBAT_HIP_SIG'] = str(rng.choice(['0', '2']))
+    if rng.integers(0, 2): env['DBAT_HIP_CMAX'] = str(rng.choice(['0', '4', '6', '10']))
+    if rng.integers(0, 2):
+        env['DBAT_HIP_BT'] = str(rng.choice(['64', '128']))
+        env['DBAT_HIP_GIANT_THREADS'] = str(rng.choice(['64', '128', '256']))
+    desc = '%3d cams %4d pts %2d rays, %d obs (max %3d per point), selfcal=%d groups=%d, drop %.1f, %s' % (
+        cams, points, rays, len(cam), int(np.bincount(pt).max()), selfcal, groups, drop, ' '.join('%s=%s' % (k[9:], v) for k, v in env.items()) or 'defaults')
+    return s, env, desc
+
+
 def main():
     n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 24
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     nbad, worst = 0, 0.0
     for sd in range(seed0, seed0 + n_scenes):
-        rng = np.random.default_rng(11000 + sd)
-        cams = int(rng.integers(12, 150)); rays = int(rng.integers(4, 12)); points = int(rng.integers(150, 3000))
-        selfcal = bool(rng.integers(0, 2)); groups = int(rng.choice([1, 1, 2])) if selfcal else 1
-        s, truth = synth.make_scene('small', seed=5000 + sd, cams=cams, points=points, rays=rays, selfcal=selfcal, groups=groups)
-        s.IO.val[5:10] = 0.0; truth['IO'][5:10] = 0.0        # distortion-free: projections far outside the format stay defined
+        s, env, desc = irregular_scene(sd)
         nc = s.EO.val.shape[1]
-        px = float(np.ravel(s.IO.sensor.pxSize)[0])
-        cam, pt = np.asarray(s.IP.cam), np.asarray(s.IP.pt)
-        # control points: seen by many (or all) images
-        ncp = int(rng.integers(0, 4))
-        frac = float(rng.choice([0.3, 0.6, 1.0]))
-        add_c, add_p = [], []
-        for p in rng.choice(points, size=ncp, replace=False):
-            have = set(cam[pt == p].tolist())
-            for c in range(nc):
-                if c not in have and rng.random() < frac: add_c.append(c); add_p.append(int(p))
-        cam = np.r_[cam, np.array(add_c, int)]; pt = np.r_[pt, np.array(add_p, int)]
-        # drop observations at random, keeping at least two rays per point
-        drop = float(rng.choice([0.0, 0.2, 0.5]))
-        keep = rng.random(len(cam)) >= drop
-        cnt = np.bincount(pt[keep], minlength=points)
-        for p in np.nonzero(cnt < 2)[0]: keep[pt == p] = True
-        cam, pt = cam[keep], pt[keep]
-        order = np.lexsort((pt, cam)); cam, pt = cam[order], pt[order]
-        uv, depth = synth.project(truth['IO'], truth['EO'], truth['OP'], cam, pt, px, nK=3, nP=2)
-        s.IP.val = uv + rng.normal(0, 0.5, uv.shape); s.IP.std = np.ones_like(uv)
-        s.IP.cam, s.IP.pt = cam, pt
-        env = {}
-        if rng.integers(0, 2): env['DBAT_HIP_SIG'] = str(rng.choice(['0', '2']))
-        if rng.integers(0, 2): env['DBAT_HIP_CMAX'] = str(rng.choice(['0', '4', '6', '10']))
-        if rng.integers(0, 2):
-            env['DBAT_HIP_BT'] = str(rng.choice(['64', '128']))
-            env['DBAT_HIP_GIANT_THREADS'] = str(rng.choice(['64', '128', '256']))
         for k in KNOBS: os.environ.pop(k, None)
         os.environ.update(env)
-        line = 'seed %3d: %3d cams %4d pts %2d rays, %d obs (max %3d per point), selfcal=%d groups=%d, drop %.1f, %s |' % (
-            sd, cams, points, rays, len(cam), int(np.bincount(pt).max()), selfcal, groups, drop, ' '.join('%s=%s' % (k[9:], v) for k, v in env.items()) or 'defaults')
+        line = 'seed %3d: %s |' % (sd, desc)
         try:
             so, x0, w = oracle_setup(s)
             Rw = np.sqrt(w)

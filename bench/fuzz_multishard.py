@@ -6,7 +6,7 @@ one-rank result.  Prints one line per scene; exits non-zero on the first disagre
     python bench/fuzz_multishard.py [n_scenes] [first_seed]"""
 import os, sys, threading
 R_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, R_); sys.path.insert(0, os.path.join(R_, 'oracle')); sys.path.insert(0, os.path.join(R_, 'tests'))
+sys.path.insert(0, R_); sys.path.insert(0, os.path.join(R_, 'oracle')); sys.path.insert(0, os.path.join(R_, 'tests')); sys.path.insert(0, os.path.join(R_, 'bench'))
 import numpy as np
 from dbat_amd import synth, _hip
 from test_hip_parity import _ThreadComm
@@ -51,7 +51,15 @@ def main():
         if sig: os.environ['DBAT_HIP_SIG'] = sig
         else: os.environ.pop('DBAT_HIP_SIG', None)
         base = 'C1' if rng.integers(0, 2) else 'small'
-        s, _ = synth.make_scene(base, seed=2000 + sd, cams=cams, points=points, rays=rays, selfcal=selfcal, groups=groups)
+        if os.environ.get('FUZZ_IRREGULAR'):          # bench/fuzz_irregular.py's family: thinned visibility, control points in many images, forced kernel paths
+            from fuzz_irregular import irregular_scene, KNOBS
+            s, env, desc = irregular_scene(sd)
+            for k in KNOBS: os.environ.pop(k, None)
+            os.environ.update(env)
+            base, cams, points, rays = 'irr', s.EO.val.shape[1], s.OP.val.shape[1], 0
+            sig = env.get('DBAT_HIP_SIG', '')
+        else:
+            s, _ = synth.make_scene(base, seed=2000 + sd, cams=cams, points=points, rays=rays, selfcal=selfcal, groups=groups)
         cam_owner, subtree = _hip.plan_domain_map(s, world)
         h = _hip.Handle(s)
         try:
