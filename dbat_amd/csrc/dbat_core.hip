@@ -132,6 +132,8 @@ struct Core {
     DevBuf<double> gpart, rpart;                     // their per-block partial sums; sink of k_residual's (unused) sums
     DevBuf<double> z, zt, dz, zlin, vtmp, vtmp2, xbuf;  // NZ each (xbuf: n)
     DevBuf<double> red;      // [S | g_red | g_c | diagU | scal(8)]
+    // Vinv: six doubles per object point -- since round 3 the FACTOR R of the point block's inverse (V^-1 = R R',
+    // kernels.hpp point_block_factor), not the inverse; gp: B'r per point; jn2p: squared column norms of the point columns
     DevBuf<double> jn2c, dscale, rhs, Vinv, gp, jn2p, partial, scal;
     DevBuf<int> info;
     DevBuf<double> linv, ldiag;
