@@ -1124,14 +1124,25 @@ struct DataflowChol {
         permuted = true;
         n_nat = 6 * nc + nio;
         const std::vector<int> &order = nd.order, &block_end = nd.block_end;
-        // every block starts on a tile boundary (padding rows = identity): otherwise the tile that
-        // straddles two independent blocks chains them together
+        // A block starts on a tile boundary (padding rows = identity) where the tile that straddled the boundary
+        // would chain two INDEPENDENT blocks together, or two owners (several ranks).  A separator directly follows
+        // the last block of the part it was cut from and depends on it anyway: its rows go on in that block's last
+        // tile -- one link less in the dependent chain per level of the dissection (DBAT_HIP_ND_PAD_ALL=1: as before).
         std::vector<int> rowpos(nc);                    // first row of every camera in the factorised order
         int off = 0;
         {
+            const bool pad_all = getenv("DBAT_HIP_ND_PAD_ALL") != nullptr;
             size_t b = 0; int q0 = 0;
             for (int q = 0; q < nc; ++q) {
-                if (q == q0) off = (off + CHOL_NB - 1) / CHOL_NB * CHOL_NB;
+                if (q == q0) {
+                    // ... but only where that saves a tile: the separator's rows and the ragged tail before them fit
+                    // into fewer tiles together than apart (otherwise the separator merely loses its alignment)
+                    const int sep_rows = 6 * (block_end[b] - q0), used = off % CHOL_NB;
+                    const bool saves = used > 0 && (used + sep_rows + CHOL_NB - 1) / CHOL_NB < 1 + (sep_rows + CHOL_NB - 1) / CHOL_NB;
+                    const bool joins = !pad_all && saves && b > 0 && b < nd.block_sep.size() && nd.block_sep[b] &&
+                                       nd.block_owner[b] == nd.block_owner[b - 1];
+                    if (!joins) off = (off + CHOL_NB - 1) / CHOL_NB * CHOL_NB;
+                }
                 rowpos[order[q]] = off; off += 6;
                 while (b < block_end.size() && block_end[b] <= q + 1) { q0 = q + 1; ++b; }
             }

@@ -29,6 +29,7 @@ struct NdTree {
     std::vector<int> order;         // position -> camera
     std::vector<int> block_end;     // order.size() after every block (leaf or separator), in elimination order
     std::vector<int> block_owner;   // per block: the rank whose domain it belongs to, -1: a top separator
+    std::vector<uint8_t> block_sep; // per block: a separator -- it directly follows the last block of the part it was cut from
     std::vector<int> cam_owner;     // per camera: rank, -1: top separator
     int n_top_cams = 0;
 };
@@ -43,10 +44,10 @@ inline void nd_build(int nc, const uint64_t *adj, int adj_words, const double *x
     T.order.reserve(nc);
     T.cam_owner.assign(nc, 0);
     auto adjacent = [&](int a, int b) { return (adj[(size_t)a * adj_words + (b >> 6)] >> (b & 63)) & 1ull; };
-    auto emit = [&](std::vector<int> &cams, int owner) {
+    auto emit = [&](std::vector<int> &cams, int owner, bool sep = false) {
         std::sort(cams.begin(), cams.end());
         for (int c : cams) { T.order.push_back(c); T.cam_owner[c] = owner; if (owner < 0) ++T.n_top_cams; }
-        if (!cams.empty()) { T.block_end.push_back((int)T.order.size()); T.block_owner.push_back(owner); }
+        if (!cams.empty()) { T.block_end.push_back((int)T.order.size()); T.block_owner.push_back(owner); T.block_sep.push_back(sep ? 1 : 0); }
     };
     // part0 .. part0+np-1: the ranks this set of cameras is divided among
     std::function<void(std::vector<int> &, int, int)> nd = [&](std::vector<int> &cams, int part0, int np) {
@@ -93,7 +94,7 @@ inline void nd_build(int nc, const uint64_t *adj, int adj_words, const double *x
         }
         nd(A2, part0, np > 1 ? npa : 1);
         nd(B, np > 1 ? part0 + npa : part0, np > 1 ? npb : 1);
-        emit(Sep, np > 1 ? -1 : part0);
+        emit(Sep, np > 1 ? -1 : part0, true);
     };
     std::vector<int> all(nc);
     for (int c = 0; c < nc; ++c) all[c] = c;
