@@ -100,7 +100,21 @@ def main():
                         C = h.posterior_cov(x0, 1.0); d_ok = all(np.all(np.isfinite(c)) for c in C)
                     except _hip.DbatHipError as ex:
                         d_ok = False
-                    line += ' cov %s (oracle chol %s, cond %.1e)' % ('ok' if d_ok else 'FAILS', 'ok' if o_ok else 'fails', np.linalg.cond(JTJ.toarray()))
+                    cerr = float('nan')
+                    if d_ok and o_ok:
+                        # the 6 x 6 camera and 3 x 3 point blocks of inv(J'J) through the x index of every EO / OP entry
+                        # (rows / columns of parameters that are not estimated: zero on the device)
+                        N = np.linalg.inv(JTJ.toarray())
+                        IOix, EOix, OPix = h.index_maps()
+                        cerr = 0.0
+                        for blk, ix in ((C[0], EOix), (C[2], OPix)):
+                            for i in range(0, ix.shape[1], max(1, ix.shape[1] // 40)):
+                                idx = ix[:, i]; m = idx >= 0
+                                if not m.any(): continue
+                                ref = N[np.ix_(idx[m], idx[m])]
+                                cerr = max(cerr, float(np.abs(blk[i][np.ix_(m, m)] - ref).max() / np.abs(ref).max()))
+                        d_ok = cerr < 1e-6
+                    line += ' cov %s %.0e (oracle chol %s, cond %.1e)' % ('ok' if d_ok else 'FAILS', cerr, 'ok' if o_ok else 'fails', np.linalg.cond(JTJ.toarray()))
                     ok = ok and (d_ok or not o_ok)
                 if not ok: raise AssertionError('tolerance')
             finally:
