@@ -110,7 +110,7 @@ struct Ref {
 
 static void cam_record(const Ref &R, const double *IOv, const double *EOv, int c, CamRec &cr) {
     cr.c[0] = EOv[6 * c]; cr.c[1] = EOv[6 * c + 1]; cr.c[2] = EOv[6 * c + 2];
-    cam_rotation(EOv + 6 * c + 3, cr.Mt, cr.dMt);
+    cam_rotation(EOv + 6 * c + 3, cr.Mt, cr.sk, cr.ck);
     const double *io = IOv + (size_t)R.nIOrows * c;
     cr.f = io[0]; cr.pp[0] = io[1]; cr.pp[1] = io[2]; cr.b[0] = io[3]; cr.b[1] = io[4];
     for (int k = 0; k < MAXK; ++k) cr.K[k] = k < R.nK ? io[5 + k] : 0.0;

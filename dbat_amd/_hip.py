@@ -13,6 +13,10 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdbat_hip.so')
+# measurement only (bench/ tools): DBAT_AMD_LIB=prof loads libdbat_hip_prof.so, the same sources built with
+# -DDBAT_HIP_PROFILING (make -C dbat_amd/csrc prof) -- the only build that reads DBAT_HIP_ABLATE, _DF_TRACE, ...
+if os.environ.get('DBAT_AMD_LIB') == 'prof':
+    LIB_PATH = os.path.join(_HERE, 'libdbat_hip_prof.so')
 
 ABI_VERSION = 2
 DAMP = {'none': 0, 'gm': 0, 'gna': 1, 'lm': 2, 'lmp': 3}

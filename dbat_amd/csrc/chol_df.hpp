@@ -42,6 +42,7 @@
 // forward substitution rides along exactly as in chol.hpp; the backward
 // substitution follows as one task per panel.
 #pragma once
+#include "env.hpp"
 #include <cstdio>
 #include <functional>
 #include <queue>
@@ -870,8 +871,8 @@ struct DataflowChol {
     struct JobList { std::vector<DfJob> jobs; std::vector<int> dptr, dep, own, sumjob; };
     void build_jobs(int phase, const std::vector<uint64_t> &rowbits, const std::vector<int> &col_owner, int rank, JobList &L) {
         auto has = [&](int i, int k) { return (rowbits[(size_t)i * W + (k >> 6)] >> (k & 63)) & 1ull; };
-        const int split_min = getenv("DBAT_HIP_DF_SPLIT") ? std::max(atoi(getenv("DBAT_HIP_DF_SPLIT")), 2) : 96;
-        const int chunk = getenv("DBAT_HIP_DF_CHUNK") ? std::max(atoi(getenv("DBAT_HIP_DF_CHUNK")), 1) : 32;
+        const int split_min = std::max(env_int("DBAT_HIP_DF_SPLIT", 96), 2);
+        const int chunk = std::max(env_int("DBAT_HIP_DF_CHUNK", 32), 1);
         const bool merge = permuted;                            // compact tiles only (see k_chol_df)
         auto top = [&](int k) { return phase != 0 && col_owner[k] < 0; };
         auto mine = [&](int k) { return phase == 0 || col_owner[k] == rank; };
@@ -1025,7 +1026,7 @@ struct DataflowChol {
         double tbest = 1e300;
         int best = -1;
         std::vector<double> key(nt), tcs(ncand);
-        const int forced = getenv("DBAT_HIP_DF_ORDER") ? atoi(getenv("DBAT_HIP_DF_ORDER")) : -1;
+        const int forced = env_int("DBAT_HIP_DF_ORDER", -1);
         for (int c = 0; c < ncand; ++c) {
             if (c + 1 < ncand) for (int t = 0; t < nt; ++t) key[t] = est[t] - betas[c] * blev[t];
             else for (int t = 0; t < nt; ++t) key[t] = est[t] - c_prod * nprod_of(t);
@@ -1036,7 +1037,7 @@ struct DataflowChol {
         double cp = 0.0;
         for (int t = 0; t < nt; ++t) cp = std::max(cp, fin[t]);
         sim_critical_us.push_back(cp); sim_schedule_us.push_back(tbest);
-        if (getenv("DBAT_HIP_PLAN_STATS")) {
+        if (env_on("DBAT_HIP_PLAN_STATS")) {
             fprintf(stderr, "[chol %s] %d tasks, critical path %.0f us; simulated with %d workgroups, key = earliest start - beta x bottom level:",
                     what, nt, cp, workers);
             for (int c = 0; c + 1 < ncand; ++c) fprintf(stderr, " beta %g: %.0f us,", betas[c], tcs[c]);
@@ -1052,7 +1053,7 @@ struct DataflowChol {
     bool finish_setup(const std::vector<uint64_t> &rowbits, const std::vector<int64_t> &toff,
                       const std::vector<int> &col_owner = std::vector<int>(), int rank = 0) {
         auto has = [&](int i, int k) { return (rowbits[(size_t)i * W + (k >> 6)] >> (k & 63)) & 1ull; };
-        if (const char *g = getenv("DBAT_HIP_DF_GRID")) grid = std::min(std::max(atoi(g), 1), 4096);
+        if (const char *g = env_get("DBAT_HIP_DF_GRID")) grid = std::min(std::max(atoi(g), 1), 4096);
         nparts = 0; n_products = 0;
         two_phase = !col_owner.empty();
         sim_critical_us.clear(); sim_schedule_us.clear();
@@ -1083,7 +1084,7 @@ struct DataflowChol {
             if (!up(d_rowbits_top, rowbits_top)) return false;
         }
         nbk = (int)bkl.size();
-        if (getenv("DBAT_HIP_DF_TRACE") && !two_phase && hipMalloc(&d_trace, (size_t)(ntasks + nT) * 16 * sizeof(long long)) != hipSuccess) d_trace = nullptr;
+        if (env_on("DBAT_HIP_DF_TRACE") && !two_phase && hipMalloc(&d_trace, (size_t)(ntasks + nT) * 16 * sizeof(long long)) != hipSuccess) d_trace = nullptr;
         std::vector<int> bptr(nT + 1, 0), bidx;
         for (int j = 0; j < nT; ++j) {
             for (int i = nT - 1; i > j; --i)
@@ -1131,7 +1132,7 @@ struct DataflowChol {
         std::vector<int> rowpos(nc);                    // first row of every camera in the factorised order
         int off = 0;
         {
-            const bool pad_all = getenv("DBAT_HIP_ND_PAD_ALL") != nullptr;
+            const bool pad_all = env_on("DBAT_HIP_ND_PAD_ALL");
             size_t b = 0; int q0 = 0;
             for (int q = 0; q < nc; ++q) {
                 if (q == q0) {
@@ -1141,7 +1142,7 @@ struct DataflowChol {
                     const bool saves = used > 0 && (used + sep_rows + CHOL_NB - 1) / CHOL_NB < 1 + (sep_rows + CHOL_NB - 1) / CHOL_NB;
                     // ... or the separator is short (two tiles at most): its alignment is worth less than the rows the
                     // padding would add to the chain (measured: C1 0.196 -> 0.176 ms, C2 0.692 -> 0.681; longer ones: C2 loses)
-                    const int join_small = getenv("DBAT_HIP_ND_JOIN_SMALL") ? atoi(getenv("DBAT_HIP_ND_JOIN_SMALL")) : 2 * CHOL_NB;
+                    const int join_small = env_int("DBAT_HIP_ND_JOIN_SMALL", 2 * CHOL_NB);
                     const bool joins = !pad_all && (saves || (used > 0 && sep_rows <= join_small)) && b > 0 && b < nd.block_sep.size() && nd.block_sep[b] &&
                                        nd.block_owner[b] == nd.block_owner[b - 1];
                     if (!joins) off = (off + CHOL_NB - 1) / CHOL_NB * CHOL_NB;
@@ -1224,16 +1225,16 @@ struct DataflowChol {
         if (hipMalloc(&d_tiles, (size_t)ntiles * 4096 * sizeof(double)) != hipSuccess) return false;
         (void)hipMemset(d_tiles, 0, (size_t)ntiles * 4096 * sizeof(double));     // right-hand-side tiles: only their first row is ever written
         if (hipMalloc(&d_qperm, (size_t)nT * CHOL_NB * sizeof(double)) != hipSuccess) return false;
-        if (getenv("DBAT_HIP_PLAN_STATS"))
+        if (env_on("DBAT_HIP_PLAN_STATS"))
             fprintf(stderr, "[chol] order %d (%d with block padding, %zu blocks), %d tile rows, %d tiles (%.1f MB), dense lower triangle would be %d tiles\n",
                     n_nat, n, block_end.size(), nT, ntiles, ntiles * 32768.0 / 1e6, nT * (nT + 1) / 2 + nT);
-        if (getenv("DBAT_HIP_PLAN_STATS")) {
+        if (env_on("DBAT_HIP_PLAN_STATS")) {
             fprintf(stderr, "[chol] cameras per block, last (root separator) first:");
             for (size_t b = block_end.size(); b-- > 0 && block_end.size() - b <= 24;)
                 fprintf(stderr, " %d", block_end[b] - (b ? block_end[b - 1] : 0));
             fprintf(stderr, "\n");
         }
-        if (getenv("DBAT_HIP_PLAN_STATS") && !col_owner.empty()) {
+        if (env_on("DBAT_HIP_PLAN_STATS") && !col_owner.empty()) {
             int ntop = 0, nmine = 0;
             for (int k = 0; k < nT; ++k) { ntop += col_owner[k] < 0; nmine += col_owner[k] == rank; }
             fprintf(stderr, "[chol] rank %d of %d: %d tile columns in its domain, %d top columns, %lld top tiles (%.1f MB summed over the ranks per factorisation)\n",

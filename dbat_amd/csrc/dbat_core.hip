@@ -25,6 +25,7 @@ namespace dbat {
 static thread_local std::string g_err;
 
 struct DeviceError { std::string msg; };
+struct UsageError { std::string msg; };
 
 #define HIPCHK(expr)                                                                       \
     do {                                                                                   \
@@ -82,6 +83,14 @@ static inline void cpu_relax() {
 #endif
 }
 
+#define DISPATCH_MODEL(KERNEL, ...)                                                          \
+    switch (P.model) {                                                                       \
+        case 2: KERNEL(2, __VA_ARGS__); break;                                               \
+        case 3: KERNEL(3, __VA_ARGS__); break;                                               \
+        case 4: KERNEL(4, __VA_ARGS__); break;                                               \
+        default: KERNEL(5, __VA_ARGS__); break;                                              \
+    }
+
 struct Core {
     Plan P;
     DevProblem d{};
@@ -99,6 +108,8 @@ struct Core {
     DevBuf<int32_t> cam_ncol, cam_col, cam_iorow, io_src, o_cam, o_pt;
     DevBuf<uint32_t> cam_eo_est, o_seg;
     DevBuf<double> io_fixed, px, cam_w, z_prw, z_prv, o_uv, o_w;
+    DevBuf<double> o_rhs;               // fixed IO: the corrected image coordinates (k_uv_to_rhs), what d.o_uv points at
+    bool uv_pre = false;
     DevBuf<uint8_t> z_est, z_mine, o_lc, o_pidx;
     DevBuf<int32_t> tile_batch, tile_cam_start, tile_cams, tile_io_start, tile_iocols;
     DevBuf<uint8_t> tile_io_simple;
@@ -220,8 +231,8 @@ struct Core {
         d.z_est = z_est.p; d.z_mine = z_mine.p; d.z_prw = z_prw.p; d.z_prv = z_prv.p;
         d.o_cam = o_cam.p; d.o_pt = o_pt.p; d.o_uv = o_uv.p; d.o_w = P.uniform_w ? nullptr : o_w.p;
         d.o_seg = o_seg.p; d.o_row = o_row.p; d.batch_start = batch_start.p;
-        d.CMAX = P.CMAX; d.ablate = getenv("DBAT_HIP_ABLATE") ? atoi(getenv("DBAT_HIP_ABLATE")) : 0;
-        env_df_trace = getenv("DBAT_HIP_DF_TRACE");
+        d.CMAX = P.CMAX; d.ablate = env_int("DBAT_HIP_ABLATE", 0); d.trace_only = 0;
+        env_df_trace = env_get("DBAT_HIP_DF_TRACE");
         d.ntiles = (int)ntiles; d.o_lc = o_lc.p; d.o_pidx = o_pidx.p;
         tile_order.upload(P.tile_order); d.tile_order = tile_order.p;
         cm_pt.upload(P.cm_pt); cm_uv.upload(P.cm_uv); cm_w.upload(P.cm_w);
@@ -233,7 +244,7 @@ struct Core {
             giant_W.alloc((size_t)(P.giant_start.back() - P.giant_start.front()) * P.ncolmax * 3);
         }
         d.ngiant = (int)ngiant; d.giant_start = giant_start.p; d.giant_W = giant_W.p;
-        if (const char *e = getenv("DBAT_HIP_GIANT_THREADS")) { const int v = atoi(e); if (v == 64 || v == 128) giant_threads = v; }
+        if (const char *e = env_get("DBAT_HIP_GIANT_THREADS")) { const int v = atoi(e); if (v == 64 || v == 128) giant_threads = v; }
         d.tile_batch = tile_batch.p; d.tile_cam_start = tile_cam_start.p; d.tile_cams = tile_cams.p;
         d.tile_io_start = tile_io_start.p; d.tile_iocols = tile_iocols.p; d.tile_cam_io = tile_cam_io.p;
         tile_io_simple.upload(P.tile_io_simple); d.tile_io_simple = P.tile_io_simple.empty() ? nullptr : tile_io_simple.p;
@@ -317,12 +328,32 @@ struct Core {
         set_lds_limits();
         HIPCHK(hipMemcpy(z.p, P.z0.data(), P.NZ * 8, hipMemcpyHostToDevice));
         HIPCHK(hipMemset(dz.p, 0, P.NZ * 8));
+        HIPCHK(hipMemset(zt.p, 0, P.NZ * 8));          // (entries of other ranks' domains are never written)
+        precompute_image_side();
         HIPCHK(hipDeviceSynchronize());
+    }
+
+    // Fixed interior orientation: the image side of every observation once per handle (kernels.hpp k_uv_to_rhs).
+    // The point-major copy keeps the measured coordinates beside it (Jacobian export, forward intersection); the
+    // camera-major and the slot-major copies are converted in place.
+    void precompute_image_side() {
+        uv_pre = !P.with_io;
+        d.o_uv_raw = o_uv.p; d.uv_pre = uv_pre ? 1 : 0;
+        if (!uv_pre || nobs == 0) return;
+        prep_cams(z.p, cams_f.p);                    // interior orientation: the fixed values
+        o_rhs.alloc((size_t)2 * nobs);
+#define L_RHS(M, dummy)                                                                                              \
+        LAUNCHK((k_uv_to_rhs<M>), dim3((unsigned)cdiv(nobs, 256)), dim3(256), 0, stream, d.nK, d.nP, cams_f.p, nobs, o_cam.p, o_uv.p, o_rhs.p); \
+        if (n_cm_chunks_all > 0) LAUNCHK((k_uv_to_rhs_cm<M>), dim3((unsigned)n_cm_chunks_all), dim3(256), 0, stream, d.nK, d.nP, cams_f.p, cm_chunk_cam.p, cm_chunk_start.p, cm_uv.p); \
+        if (use_sig && sg_nchunks > 0) LAUNCHK((k_uv_to_rhs_sig<M>), dim3((unsigned)sg_nchunks), dim3(64), 0, stream, d.nK, d.nP, cams_f.p, sg_chunk.p, sg_gcam.p, sg_uv.p)
+        DISPATCH_MODEL(L_RHS, 0)
+#undef L_RHS
+        d.o_uv = o_rhs.p;
     }
 
     // grid of the grid-stride observation kernels: one resident round (k_residual: 6 waves/SIMD
     // of 4-wave workgroups on 256 CUs)
-    static int env_grid_obs() { const char *e = getenv("DBAT_HIP_GRID_OBS"); return e ? std::min(std::max(1, atoi(e)), 1 << 20) : 1536; }
+    static int env_grid_obs() { return std::min(std::max(1, env_int("DBAT_HIP_GRID_OBS", 1536)), 1 << 20); }
     // kernels that use more than 64 KB of dynamic LDS must opt in
     void set_lds_limits() {
 #define SET_LDS(K, BYTES) HIPCHK(hipFuncSetAttribute((const void *)(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)))
@@ -477,14 +508,6 @@ struct Core {
         sync();
     }
 
-#define DISPATCH_MODEL(KERNEL, ...)                                                          \
-    switch (P.model) {                                                                       \
-        case 2: KERNEL(2, __VA_ARGS__); break;                                               \
-        case 3: KERNEL(3, __VA_ARGS__); break;                                               \
-        case 4: KERNEL(4, __VA_ARGS__); break;                                               \
-        default: KERNEL(5, __VA_ARGS__); break;                                              \
-    }
-
     // ---- K2: f = 0.5 r'r at zz (all ranks' sum).  Optionally store r.
     // f at x + alpha p (x, p as given; the point goes to out): the trial point and its camera records in one launch
     double eval_f_step(const double *x, double alpha, const double *pdir, double *out) {
@@ -503,14 +526,14 @@ struct Core {
         // Both kernels finish their grid sums themselves; the second one adds the prior rows and hands
         // the total to the pinned mailbox (one rank) or to scal[0] for the all-reduce.
         if (n_cm_chunks_all > 0) {
-#define L_RESCM(M, dummy) LAUNCHK((k_residual_cm<M>), dim3((unsigned)n_cm_chunks_all), dim3(256), 0, stream, d, zz, cams_f.p, cm_pt.p, cm_uv.p, P.uniform_w ? (const double *)nullptr : cm_w.p, cm_chunk_cam.p, cm_chunk_start.p, partial.p)
-            DISPATCH_MODEL(L_RESCM, 0)
+#define L_RESCM(M, PRE) LAUNCHK((k_residual_cm<M, PRE>), dim3((unsigned)n_cm_chunks_all), dim3(256), 0, stream, d, zz, cams_f.p, cm_pt.p, cm_uv.p, P.uniform_w ? (const double *)nullptr : cm_w.p, cm_chunk_cam.p, cm_chunk_start.p, partial.p)
+            if (uv_pre) { DISPATCH_MODEL(L_RESCM, true) } else { DISPATCH_MODEL(L_RESCM, false) }
 #undef L_RESCM
         }
         mark(7);
         if (r_w_out || r_unw_out) {
-#define L_RES(M, dummy) LAUNCHK((k_residual<M>), dim3(grid_obs), dim3(256), 0, stream, d, zz, cams_f.p, rpart.p, r_w_out, r_unw_out)
-            DISPATCH_MODEL(L_RES, 0)
+#define L_RES(M, PRE) LAUNCHK((k_residual<M, PRE>), dim3(grid_obs), dim3(256), 0, stream, d, zz, cams_f.p, rpart.p, r_w_out, r_unw_out)
+            if (uv_pre) { DISPATCH_MODEL(L_RES, true) } else { DISPATCH_MODEL(L_RES, false) }
 #undef L_RES
         }
         LAUNCHK(k_prior_sq, dim3(grid_zs), dim3(1024), 0, stream, d, zz, gpart.p, gctr.p + 1, (const double *)partial.p, n_cm_chunks_all,
@@ -653,10 +676,9 @@ struct Core {
     void build(const double *zz, double lambda, int scale, bool lazy = false, bool trace_only = false) {
         pend_build = false;
         trace_only = trace_only && use_sig && ntiles > 0;
-        const int ablate0 = d.ablate;
-        if (trace_only) d.ablate |= 64;
-        try { build_enqueue(zz, lambda, scale); } catch (...) { d.ablate = ablate0; throw; }
-        d.ablate = ablate0;
+        d.trace_only = trace_only ? 1 : 0;             // an argument of this launch (DevProblem travels by value)
+        try { build_enqueue(zz, lambda, scale); } catch (...) { d.trace_only = 0; throw; }
+        d.trace_only = 0;
         if (mg_subtree) allreduce_vectors();
         else allreduce_system();
         finish_enqueue(zz, lambda, scale);           // also: trace(J'J) of the camera part and red_scal -> mailbox
@@ -687,6 +709,10 @@ struct Core {
 
     // ---- K6: Cholesky of the reduced system; returns 0 or the failing pivot
     int factor_solve_enqueue() {
+        // a schedule built for domain sharding publishes the top separators only after the sum over the ranks
+        if (mg_subtree && !multi())
+            throw UsageError{"this handle is one of several shards: attach a communicator (dbat_hip_comm_init) or an all-reduce "
+                             "callback (dbat_hip_set_allreduce) before linearising or solving"};
         stage(1);
         mark(2);
         // Cholesky + both substitutions; q -> rhs.  One persistent dataflow kernel (chol_df.hpp)
@@ -747,6 +773,7 @@ struct Core {
     // CHOLMOD's estimate rcond = (min diag(L) / max diag(L))^2 < eps over the
     // pivots of the point blocks and of the reduced system.
     bool near_singular = false;
+    const bool pivot_stats = env_on("DBAT_HIP_PIVOT_STATS");
     double rcond_est = 0.0;      // (min pivot / max pivot)^2 of the last solve; 0 after a failed factorisation
     int chol_info = 0;           // k_chol_df's info of the last solve: > 0 first non-positive pivot, -1 dataflow abort
     double piv_last[4] = {0, 0, 0, 0};   // {min, max} pivot of the point blocks, {min, max} of the reduced system
@@ -792,7 +819,7 @@ struct Core {
         rcond_est = failed ? 0.0 : ratio * ratio;
         chol_info = hinfo;
         for (int q = 0; q < 4; ++q) piv_last[q] = mm[q];
-        if (getenv("DBAT_HIP_PIVOT_STATS"))
+        if (pivot_stats)
             fprintf(stderr, "[solve] pivots of the point blocks %.3e ... %.3e, of the reduced system %.3e ... %.3e, info %d, rcond estimate %.3e\n",
                     mm[0], mm[1], mm[2], mm[3], hinfo, rcond_est);
         return failed;
@@ -1140,6 +1167,7 @@ struct dbat_hip_handle {
 #define API_CATCH                                                                       \
     }                                                                                   \
     catch (const DeviceError &e) { g_err = e.msg; return DBAT_HIP_EDEVICE; }            \
+    catch (const UsageError &e) { g_err = e.msg; return DBAT_HIP_EINVAL; }              \
     catch (const std::bad_alloc &) { g_err = "out of host memory"; return DBAT_HIP_ENOMEM; } \
     catch (const std::exception &e) { g_err = e.what(); return DBAT_HIP_EINVAL; }
 
@@ -1162,7 +1190,7 @@ int dbat_hip_plan(const dbat_hip_problem *prob, int64_t *n_params, int64_t *n_re
     API_TRY
     if (!prob) { g_err = "null problem"; return DBAT_HIP_EINVAL; }
     Plan P;
-    if (!build_plan(*prob, P, getenv("DBAT_HIP_PLAN_STATS") != nullptr)) { g_err = P.err; return DBAT_HIP_EINVAL; }
+    if (!build_plan(*prob, P, env_on("DBAT_HIP_PLAN_STATS"))) { g_err = P.err; return DBAT_HIP_EINVAL; }
     if (n_params) *n_params = P.n;
     if (n_residuals) *n_residuals = P.m;
     if (n_io) *n_io = P.nIO;
@@ -1531,6 +1559,7 @@ int dbat_hip_solve(dbat_hip_handle *h, const dbat_hip_options *opt, double *x, d
     LoopOut out;
     const auto t0 = std::chrono::steady_clock::now();
     c.stages_begin();
+    struct StageGuard { Core &c; ~StageGuard() { c.st_on = false; } } stage_guard{c};     // (a loop that throws must not leave the timers on)
     switch (opt->damping) {
         case DBAT_HIP_DAMP_GM: loop_gm(c, *opt, out); break;
         case DBAT_HIP_DAMP_GNA: loop_gna(c, *opt, out); break;
@@ -1741,13 +1770,14 @@ int dbat_hip_resect(int32_t device, int32_t n_images, const int64_t *pt_start, c
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_err = "no HIP device: the dbat_hip core has no CPU path"; return DBAT_HIP_EDEVICE; }
     if (device < 0 || device >= ndev) { g_err = "bad device index"; return DBAT_HIP_EINVAL; }
     if (n_images == 0) return DBAT_HIP_OK;
-    const int64_t npt = pt_start[n_images], ntri = tri_start[n_images];
+    if (pt_start[0] != 0 || tri_start[0] != 0) { g_err = "ranges must start at 0"; return DBAT_HIP_EINVAL; }
     for (int c = 0; c < n_images; ++c)
         if (pt_start[c + 1] < pt_start[c] || tri_start[c + 1] < tri_start[c]) { g_err = "ranges must ascend"; return DBAT_HIP_EINVAL; }
+    const int64_t npt = pt_start[n_images], ntri = tri_start[n_images];
+    if ((npt > 0 && (!X || !xn)) || (ntri > 0 && !tri)) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
     for (int c = 0; c < n_images; ++c)
         for (int64_t t = 3 * tri_start[c]; t < 3 * tri_start[c + 1]; ++t)
             if (tri[t] < 0 || tri[t] >= pt_start[c + 1] - pt_start[c]) { g_err = "triangle index outside the camera's points"; return DBAT_HIP_EINVAL; }
-    if ((npt > 0 && (!X || !xn)) || (ntri > 0 && !tri)) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
     DeviceGuard dev_guard(device);
     DevBuf<int64_t> dps, dts;
     DevBuf<double> dX, dx, dP, dr;
@@ -1808,7 +1838,7 @@ int dbat_hip_debug_model_eval_host(int32_t model, int32_t nK, int32_t nP, const 
     if (model < 2 || model > 5 || nK < 0 || nK > MAXK || nP < 0 || nP > MAXP) { g_err = "bad model"; return DBAT_HIP_EINVAL; }
     CamRec c{};
     c.c[0] = EO6[0]; c.c[1] = EO6[1]; c.c[2] = EO6[2];
-    cam_rotation(EO6 + 3, c.Mt, c.dMt);
+    cam_rotation(EO6 + 3, c.Mt, c.sk, c.ck);
     c.f = IO[0]; c.pp[0] = IO[1]; c.pp[1] = IO[2]; c.b[0] = IO[3]; c.b[1] = IO[4];
     for (int k = 0; k < nK; ++k) c.K[k] = IO[5 + k];
     for (int k = 0; k < nP; ++k) c.P[k] = IO[5 + nK + k];

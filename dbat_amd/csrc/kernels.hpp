@@ -45,14 +45,17 @@ struct DevProblem {
     const double *z_prw, *z_prv;
     // observations (processing order)
     const int32_t *o_cam, *o_pt;
-    const double *o_uv;
+    const double *o_uv;             // image coordinates -- or, uv_pre, the corrected coordinates rhs (k_uv_to_rhs)
+    const double *o_uv_raw;         // always the measured (u, v): Jacobian export, forward intersection
+    int uv_pre;                     // fixed interior orientation: o_uv, cm_uv, sg_uv hold rhs
     const double *o_w;              // may be null (uniform)
     const uint32_t *o_seg;
     const int64_t *o_row;
     const int64_t *batch_start;
     // tiles (fixed-IO path): runs of batches touching at most CMAX cameras
     int CMAX, ntiles;
-    int ablate;                     // profiling only (DBAT_HIP_ABLATE): bit0 skip MFMA, bit1 skip P3 atomics, bit2 skip eval
+    int ablate;                     // measurement builds only (DBAT_HIP_ABLATE, read through DBAT_ABLATE): phases off, phase clocks
+    int trace_only;                 // this linearisation serves trace(J'J) alone (levenberg_marquardt.m:88-95): no Schur complement
     const uint8_t *o_lc, *o_pidx;
     const int32_t *tile_batch, *tile_cam_start, *tile_cams;
     const int32_t *tile_order;                      // launch index -> tile (longest first)
@@ -64,6 +67,13 @@ struct DevProblem {
     const int64_t *giant_start;                     // [ngiant+1] first observation (processing order)
     double *giant_W;                                // scratch [n giant observations][3*ncolmax]  W = E'B
 };
+
+// ablation bits exist in measurement builds only (-DDBAT_HIP_PROFILING); the product build compiles them out
+#ifdef DBAT_HIP_PROFILING
+#define DBAT_ABLATE(d, bits) (((d).ablate & (bits)) != 0)
+#else
+#define DBAT_ABLATE(d, bits) (0)
+#endif
 
 __device__ __forceinline__ void atomic_add_f64(double *p, double v) {
     unsafeAtomicAdd(p, v);          // global_atomic_add_f64 / ds_add_f64 on gfx950
@@ -79,7 +89,7 @@ __device__ __forceinline__ void cam_prep_one(const DevProblem &d, ZV zv, int c, 
     const int32_t *ec = d.cam_col + (int64_t)c * MAXCOL;
     r.c[0] = zv(ec[0]); r.c[1] = zv(ec[1]); r.c[2] = zv(ec[2]);
     const double ang[3] = {zv(ec[3]), zv(ec[4]), zv(ec[5])};
-    cam_rotation(ang, r.Mt, r.dMt);
+    cam_rotation(ang, r.Mt, r.sk, r.ck);
     double io[MAXIO];
     for (int k = 0; k < MAXIO; ++k) {
         io[k] = 0;
@@ -109,6 +119,50 @@ __device__ __forceinline__ void cam_prep_one(const DevProblem &d, ZV zv, int c, 
 __global__ void k_cam_prep(DevProblem d, const double *__restrict__ z, CamRec *__restrict__ cams) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < d.nc) cam_prep_one(d, [z](int64_t i) { return z[i]; }, c, cams);
+}
+
+// Fixed interior orientation: rhs = T_post * brown(T_pre(x(u, v))) of an observation (model.hpp image_side) depends on
+// (u, v) and the camera's interior orientation only -- not on anything that is estimated -- so it is computed ONCE per
+// handle and the kernels of the iteration read rhs where they would read (u, v) (obs_eval<.., PRE>): the residual is
+// lhs - rhs with the same arithmetic as before, the Jacobian blocks A, B never needed (u, v).  Three copies of the
+// image coordinates exist: point-major (cam[] = o_cam), camera-major (one camera per chunk), slot-major of the
+// signature groups (sig.hpp; one camera per slot of a chunk).
+template <int MODEL>
+__global__ __launch_bounds__(256) void k_uv_to_rhs(int nK, int nP, const CamRec *__restrict__ cams, int64_t n,
+                                                   const int32_t *__restrict__ cam, const double *__restrict__ uv,
+                                                   double *__restrict__ rhs) {
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n) return;
+    ImgSide im;
+    image_side<MODEL, false>(cams[cam[o]], nK, nP, uv[2 * o], uv[2 * o + 1], im);
+    rhs[2 * o] = im.rhs[0]; rhs[2 * o + 1] = im.rhs[1];
+}
+template <int MODEL>
+__global__ __launch_bounds__(256) void k_uv_to_rhs_cm(int nK, int nP, const CamRec *__restrict__ cams,
+                                                      const int32_t *__restrict__ chunk_cam,
+                                                      const int64_t *__restrict__ chunk_start, double *__restrict__ cm_uv) {
+    const CamRec &C = cams[chunk_cam[blockIdx.x]];
+    for (int64_t q = chunk_start[blockIdx.x] + threadIdx.x; q < chunk_start[blockIdx.x + 1]; q += 256) {
+        ImgSide im;
+        image_side<MODEL, false>(C, nK, nP, cm_uv[2 * q], cm_uv[2 * q + 1], im);
+        cm_uv[2 * q] = im.rhs[0]; cm_uv[2 * q + 1] = im.rhs[1];
+    }
+}
+template <int MODEL>
+__global__ __launch_bounds__(64) void k_uv_to_rhs_sig(int nK, int nP, const CamRec *__restrict__ cams,
+                                                      const int32_t *__restrict__ sg_chunk,
+                                                      const int32_t *__restrict__ sg_gcam, double *__restrict__ sg_uv) {
+    const int32_t *cd = sg_chunk + 8 * (int64_t)blockIdx.x;
+    const int npts = cd[1], k = cd[2], gm = cd[4], gi0 = cd[5], uv0 = cd[6];
+    for (int j = 0; j < k; ++j) {
+        const CamRec &C = cams[sg_gcam[16 * (int64_t)blockIdx.x + j]];
+        for (int i = threadIdx.x; i < npts; i += 64) {
+            const int64_t q = uv0 + (int64_t)j * gm + gi0 + i;
+            ImgSide im;
+            image_side<MODEL, false>(C, nK, nP, sg_uv[2 * q], sg_uv[2 * q + 1], im);
+            sg_uv[2 * q] = im.rhs[0]; sg_uv[2 * q + 1] = im.rhs[1];
+        }
+    }
 }
 
 // block-wide sum of NV values per thread; result valid in thread 0
@@ -181,7 +235,7 @@ __device__ __forceinline__ bool grid_sum(double (&v)[NV], double *sh /* >= NV*nw
 // ---------------------------------------------------------------- K2 ----
 // Residual only.  partial[blockIdx] = sum of squared weighted residuals.
 // r_w (weighted, processing order) and r_unw (mm, reference row order) optional.
-template <int MODEL>
+template <int MODEL, bool PRE>
 __global__ __launch_bounds__(256) void k_residual(DevProblem d, const double *__restrict__ z,
                                                   const CamRec *__restrict__ cams,
                                                   double *__restrict__ partial,
@@ -196,7 +250,7 @@ __global__ __launch_bounds__(256) void k_residual(DevProblem d, const double *__
         const double Q[3] = {q[0], q[1], q[2]};
         double r[2];
         double(*nil6)[6] = nullptr; double(*nil3)[3] = nullptr; double(*nilc)[MAXIO] = nullptr;
-        obs_eval<MODEL, false, false>(C, d.nK, d.nP, Q, d.o_uv[2 * o], d.o_uv[2 * o + 1], r, nil6, nil3, nilc);
+        obs_eval<MODEL, false, false, PRE>(C, d.nK, d.nP, Q, d.o_uv[2 * o], d.o_uv[2 * o + 1], r, nil6, nil3, nilc);
         if (r_unw) { const int64_t row = d.o_row[o]; r_unw[2 * row] = r[0]; r_unw[2 * row + 1] = r[1]; }
         const double w0 = d.o_w ? d.o_w[2 * o] : C.w[0], w1 = d.o_w ? d.o_w[2 * o + 1] : C.w[1];
         r[0] *= w0; r[1] *= w1;
@@ -210,7 +264,7 @@ __global__ __launch_bounds__(256) void k_residual(DevProblem d, const double *__
 // Residual only, camera-major: one workgroup per chunk of one camera's observations (camera
 // record uniform, (u,v) and point index coalesced).  partial[blockIdx] = sum of squared
 // weighted residuals.  Used for every objective value the damping loops compare.
-template <int MODEL>
+template <int MODEL, bool PRE>
 __global__ __launch_bounds__(256) void k_residual_cm(DevProblem d, const double *__restrict__ z,
                                                      const CamRec *__restrict__ cams,
                                                      const int32_t *__restrict__ cm_pt,
@@ -227,7 +281,7 @@ __global__ __launch_bounds__(256) void k_residual_cm(DevProblem d, const double 
         const double Q[3] = {p[0], p[1], p[2]};
         double r[2];
         double(*nil6)[6] = nullptr; double(*nil3)[3] = nullptr; double(*nilc)[MAXIO] = nullptr;
-        obs_eval<MODEL, false, false>(C, d.nK, d.nP, Q, cm_uv[2 * q], cm_uv[2 * q + 1], r, nil6, nil3, nilc);
+        obs_eval<MODEL, false, false, PRE>(C, d.nK, d.nP, Q, cm_uv[2 * q], cm_uv[2 * q + 1], r, nil6, nil3, nilc);
         const double w0 = cm_w ? cm_w[2 * q] : C.w[0], w1 = cm_w ? cm_w[2 * q + 1] : C.w[1];
         r[0] *= w0; r[1] *= w1;
         acc[0] += r[0] * r[0] + r[1] * r[1];
@@ -354,7 +408,7 @@ __device__ __forceinline__ void eval_obs_cols_n(const DevProblem &d, const CamRe
     const double Q[3] = {q[0], q[1], q[2]};
     double A[2][6];
     double Cf[2][MAXIO];                       // untouched (and optimised away) when !WITH_IO
-    obs_eval<MODEL, true, WITH_IO>(C, d.nK, d.nP, Q, d.o_uv[2 * o], d.o_uv[2 * o + 1], r, A, B, Cf);
+    obs_eval<MODEL, true, WITH_IO, !WITH_IO>(C, d.nK, d.nP, Q, d.o_uv[2 * o], d.o_uv[2 * o + 1], r, A, B, Cf);   // fixed IO: rhs is precomputed
     const double w0 = d.o_w ? d.o_w[2 * o] : C.w[0], w1 = d.o_w ? d.o_w[2 * o + 1] : C.w[1];
     r[0] *= w0; r[1] *= w1;
     const uint8_t *pe = d.z_est + d.NS + 3 * (int64_t)pt;
@@ -381,7 +435,7 @@ __device__ __forceinline__ void eval_obs_pre(const DevProblem &d, const CamRec &
     constexpr bool WITH_IO = NCX > 6;
     double A[2][6];
     double Cf[2][MAXIO];
-    obs_eval<MODEL, true, WITH_IO>(C, d.nK, d.nP, Q, u, v, r, A, B, Cf);
+    obs_eval<MODEL, true, WITH_IO, !WITH_IO>(C, d.nK, d.nP, Q, u, v, r, A, B, Cf);   // fixed IO: (u, v) hold rhs
     r[0] *= w0; r[1] *= w1;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -1146,7 +1200,7 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
     for (int s = 0; s < 9; ++s) acc[s] = mfma_d4{0, 0, 0, 0};
     double pmin = 1e300, pmax = 0.0, rr = 0.0;
     __syncthreads();
-    const bool prof = (d.ablate & 32) && lane == 0 && wave == 0;
+    const bool prof = DBAT_ABLATE(d, 32) && lane == 0 && wave == 0;
     long long tp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = prof ? wall_clock64() : 0;
     auto lap = [&](int i) { if (prof) { const long long now = wall_clock64(); tp[i] += now - tlast; tlast = now; } };
     if (producer) {
@@ -1311,7 +1365,7 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
                 g0 = pi[6]; g1 = pi[7]; g2 = pi[8];
 #pragma unroll
                 for (int a = 0; a < NCX; ++a) {
-                    if (a >= ncol || (d.ablate & 2)) continue;       // ablate: profiling only
+                    if (a >= ncol || DBAT_ABLATE(d, 2)) continue;       // ablate: profiling only
                     if (IO && a >= 6 && io_uniform) continue;        // summed over the wave below
                     const double w0 = E[0][a] * B[0][0] + E[1][a] * B[1][0];
                     const double w1 = E[0][a] * B[0][1] + E[1][a] * B[1][1];
@@ -1323,7 +1377,7 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
                 }
             }
             if constexpr (IO) {
-                if (io_uniform && !(d.ablate & 2)) {
+                if (io_uniform && !DBAT_ABLATE(d, 2)) {
                     const int ncw = __builtin_amdgcn_readfirstlane(ncol);
 #pragma unroll
                     for (int a = 6; a < NCX; ++a) {
@@ -1401,7 +1455,7 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
             lap(6);
             int ksteps = __hip_atomic_load(&sy.ks[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (ksteps < 0) break;
-            if (d.ablate & 8) ksteps = 0;                // profiling: hand-over without the matrix work
+            if DBAT_ABLATE(d, 8) ksteps = 0;                // profiling: hand-over without the matrix work
             const double *Zt = pan + s * PANEL;
             if (full_tile) {
                 switch (wave) {
@@ -2062,8 +2116,8 @@ __global__ void k_finish(DevProblem d, const double *__restrict__ z, double lamb
             // (the prior residual needs this rank's z[i] to be current: true for the owner; g_c is only ever
             // read at owned entries, the others' share of this term is dropped with them)
             const double e = pw * (z[i] - d.z_prv[i]);
-            jn2 += pw; g_c[i] += e;
-            if (own) { add += pw; g += e; g_red[i] = g; }
+            jn2 += pw;
+            if (own) { g_c[i] += e; add += pw; g += e; g_red[i] = g; }
         }
         jn2c[i] = jn2;
         const bool est = d.z_est[i] != 0;
@@ -2227,7 +2281,7 @@ __global__ __launch_bounds__(256) void k_forwintersect(DevProblem d, const CamRe
         pt = d.o_pt[o];
         const uint32_t sg = d.o_seg[o];
         seg_start = sg & 0xFFFF; seg_len = sg >> 16;
-        fwd_ray_terms(cams[d.o_cam[o]], d.nK, d.nP, d.o_uv[2 * o], d.o_uv[2 * o + 1], smem + 9 * t);
+        fwd_ray_terms(cams[d.o_cam[o]], d.nK, d.nP, d.o_uv_raw[2 * o], d.o_uv_raw[2 * o + 1], smem + 9 * t);
     }
     __syncthreads();
     if (t < nobs && t == seg_start) {
@@ -2247,7 +2301,7 @@ __global__ __launch_bounds__(256) void k_forwintersect_giant(DevProblem d, const
     double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int64_t o = o0 + t; o < o1; o += blockDim.x) {
         double q[9];
-        fwd_ray_terms(cams[d.o_cam[o]], d.nK, d.nP, d.o_uv[2 * o], d.o_uv[2 * o + 1], q);
+        fwd_ray_terms(cams[d.o_cam[o]], d.nK, d.nP, d.o_uv_raw[2 * o], d.o_uv_raw[2 * o + 1], q);
 #pragma unroll
         for (int i = 0; i < 9; ++i) a[i] += q[i];
     }
@@ -2420,7 +2474,7 @@ __global__ __launch_bounds__(256) void k_jac_blocks(DevProblem d, const double *
     const double *q = z + d.NS + 3 * (int64_t)pt;
     const double Q[3] = {q[0], q[1], q[2]};
     double r[2], A[2][6], B[2][3], Cf[2][MAXIO];
-    obs_eval<MODEL, true, true>(C, d.nK, d.nP, Q, d.o_uv[2 * o], d.o_uv[2 * o + 1], r, A, B, Cf);
+    obs_eval<MODEL, true, true>(C, d.nK, d.nP, Q, d.o_uv_raw[2 * o], d.o_uv_raw[2 * o + 1], r, A, B, Cf);
     const int64_t k = d.o_row[o];
     if (JEO) for (int c = 0; c < 6; ++c) { JEO[12 * k + 2 * c] = A[0][c]; JEO[12 * k + 2 * c + 1] = A[1][c]; }
     if (JOP) for (int c = 0; c < 3; ++c) { JOP[6 * k + 2 * c] = B[0][c]; JOP[6 * k + 2 * c + 1] = B[1][c]; }

@@ -24,7 +24,7 @@ constexpr int MAXCOL = 6 + MAXIO;  // camera-side columns of one observation
 // Per-camera record, rebuilt from the parameter vector before every pass.
 struct CamRec {
     double Mt[9];        // world->camera rotation M' (row-major), M = R1(om)R2(ph)R3(ka)
-    double dMt[3][9];    // d(M')/d(omega,phi,kappa)
+    double sk, ck;       // sin / cos of kappa: all that the angle derivatives need besides M' (angle_terms below)
     double c[3];         // camera centre
     double f;            // camera constant cc
     double pp[2];        // principal point
@@ -41,18 +41,17 @@ struct CamRec {
 
 #define DBAT_HD __host__ __device__ __forceinline__
 
-// eulerrotmat.m:81,109-124 (seq 123, moving axes) and the transposition of
-// eulerpinhole2.m:54-60.
-DBAT_HD void cam_rotation(const double ang[3], double Mt[9], double dMt[3][9]) {
+// eulerrotmat.m:81 (seq 123, moving axes) and the transposition of eulerpinhole2.m:54-60: M' with
+// M = R1(omega) R2(phi) R3(kappa).  The derivative matrices of eulerrotmat.m:109-124 (dM/d omega = P1 M,
+// dM/d phi = R1 R2 P2 R3, dM/d kappa = M P3) are never formed: their products with a vector follow from M'
+// itself and (sin kappa, cos kappa) -- angle_terms below.
+DBAT_HD void cam_rotation(const double ang[3], double Mt[9], double &sk_out, double &ck_out) {
     const double so = sin(ang[0]), co = cos(ang[0]);
     const double sp = sin(ang[1]), cp = cos(ang[1]);
     const double sk = sin(ang[2]), ck = cos(ang[2]);
     const double R1[9] = {1, 0, 0, 0, co, -so, 0, so, co};
     const double R2[9] = {cp, 0, sp, 0, 1, 0, -sp, 0, cp};
     const double R3[9] = {ck, -sk, 0, sk, ck, 0, 0, 0, 1};
-    const double G1[9] = {0, 0, 0, 0, 0, -1, 0, 1, 0};
-    const double G2[9] = {0, 0, 1, 0, 0, 0, -1, 0, 0};
-    const double G3[9] = {0, -1, 0, 1, 0, 0, 0, 0, 0};
     auto mul = [](const double *a, const double *b, double *c) {
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j < 3; ++j) {
@@ -61,21 +60,39 @@ DBAT_HD void cam_rotation(const double ang[3], double Mt[9], double dMt[3][9]) {
                 c[3 * i + j] = s;
             }
     };
-    double R12[9], M[9], t[9], t2[9], d1[9], d2[9], d3[9];
+    double R12[9], M[9];
     mul(R1, R2, R12);
     mul(R12, R3, M);
-    mul(G1, M, d1);            // dA1 = P1*M
-    mul(R12, G2, t);
-    mul(t, R3, d2);            // dA2 = M1*M2*P2*M3
-    mul(M, G3, d3);            // dA3 = M*P3
-    (void)t2;
     for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) {
-            Mt[3 * i + j] = M[3 * j + i];
-            dMt[0][3 * i + j] = d1[3 * j + i];
-            dMt[1][3 * i + j] = d2[3 * j + i];
-            dMt[2][3 * i + j] = d3[3 * j + i];
-        }
+        for (int j = 0; j < 3; ++j) Mt[3 * i + j] = M[3 * j + i];
+    sk_out = sk; ck_out = ck;
+}
+
+// y_k = d(M')/d(angle_k) * d for the three Euler angles (eulerpinhole2.m:100 with eulerrotmat.m:109-124), from
+// X = M'd:  dM/d omega = P1 M      =>  y_omega = M' (P1' d) = M' (0, d2, -d1)
+//           dM/d phi = R1 R2 P2 R3 =>  y_phi = R3' P2' R3 X = (-ck X2, sk X2, ck X0 - sk X1)
+//           dM/d kappa = M P3      =>  y_kappa = P3' X = (X1, -X0, 0)
+// (P1, P2, P3: the generators of the rotations about x, y, z).  19 operations and two constants where the
+// three 3 x 3 derivative matrices cost 27 constants and 27 operations per observation.
+DBAT_HD void angle_terms(const CamRec &cam, double d0, double d1, double d2, double X0, double X1, double X2,
+                         double (&y)[3][3]) {
+    (void)d0;
+    y[0][0] = cam.Mt[1] * d2 - cam.Mt[2] * d1;
+    y[0][1] = cam.Mt[4] * d2 - cam.Mt[5] * d1;
+    y[0][2] = cam.Mt[7] * d2 - cam.Mt[8] * d1;
+    y[1][0] = -cam.ck * X2; y[1][1] = cam.sk * X2; y[1][2] = cam.ck * X0 - cam.sk * X1;
+    y[2][0] = X1; y[2][1] = -X0; y[2][2] = 0.0;
+}
+
+// 1/x: v_rcp_f64 and two Newton steps on the device (5 operations; the IEEE division sequence takes 12)
+DBAT_HD double recip(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(x);
+    r = r * (2.0 - x * r);
+    return r * (2.0 - x * r);
+#else
+    return 1.0 / x;
+#endif
 }
 
 // Image-side part: rhs and its derivatives.  a = pre-distortion coordinates.
@@ -221,17 +238,21 @@ DBAT_HD void image_side(const CamRec &cam, int nK, int nP, double u, double v, I
 //   A[2][6]  wrt EO = [centre(3) angles(3)]   (dQ0, dA)
 //   B[2][3]  wrt OP                           (dQ)
 //   C[2][nIOrows] wrt IO rows [cc px py as sk K.. P..] (only if WITH_IO)
-template <int MODEL, bool JAC, bool WITH_IO>
+//   PRE: (u, v) already hold rhs -- the corrected image coordinates of a problem whose interior orientation
+//   is fixed do not change between iterations and are computed once (k_uv_to_rhs, kernels.hpp)
+template <int MODEL, bool JAC, bool WITH_IO, bool PRE = false>
 DBAT_HD void obs_eval(const CamRec &cam, int nK, int nP, const double Q[3], double u, double v,
                       double r[2], double A[2][6], double B[2][3], double C[2][MAXIO]) {
+    static_assert(!(PRE && WITH_IO), "precomputed image side: fixed interior orientation only");
     const double d0 = Q[0] - cam.c[0], d1 = Q[1] - cam.c[1], d2 = Q[2] - cam.c[2];
     const double X0 = cam.Mt[0] * d0 + cam.Mt[1] * d1 + cam.Mt[2] * d2;
     const double X1 = cam.Mt[3] * d0 + cam.Mt[4] * d1 + cam.Mt[5] * d2;
     const double X2 = cam.Mt[6] * d0 + cam.Mt[7] * d1 + cam.Mt[8] * d2;
-    const double iz = 1.0 / X2;
+    const double iz = recip(X2);
     const double ph0 = X0 * iz, ph1 = X1 * iz;
     ImgSide im;
-    image_side<MODEL, JAC && WITH_IO>(cam, nK, nP, u, v, im);
+    if (PRE) { im.rhs[0] = u; im.rhs[1] = v; }
+    else image_side<MODEL, JAC && WITH_IO>(cam, nK, nP, u, v, im);
     const double nf = -cam.f;
     r[0] = nf * ph0 - im.rhs[0];
     r[1] = nf * ph1 - im.rhs[1];
@@ -244,13 +265,11 @@ DBAT_HD void obs_eval(const CamRec &cam, int nK, int nP, const double Q[3], doub
         B[0][k] = b0;  B[1][k] = b1;
         A[0][k] = -b0; A[1][k] = -b1;              // world2cam.m:82  dP0 = -M
     }
-    for (int k = 0; k < 3; ++k) {                  // eulerpinhole2.m:100
-        const double *D = cam.dMt[k];
-        const double y0 = D[0] * d0 + D[1] * d1 + D[2] * d2;
-        const double y1 = D[3] * d0 + D[4] * d1 + D[5] * d2;
-        const double y2 = D[6] * d0 + D[7] * d1 + D[8] * d2;
-        A[0][3 + k] = s * (y0 - ph0 * y2);
-        A[1][3 + k] = s * (y1 - ph1 * y2);
+    double y[3][3];
+    angle_terms(cam, d0, d1, d2, X0, X1, X2, y);   // eulerpinhole2.m:100
+    for (int k = 0; k < 3; ++k) {
+        A[0][3 + k] = s * (y[k][0] - ph0 * y[k][2]);
+        A[1][3 + k] = s * (y[k][1] - ph1 * y[k][2]);
     }
     if (WITH_IO) {
         C[0][0] = -ph0; C[1][0] = -ph1;            // dv/df = -vec(PH)
@@ -294,7 +313,7 @@ DBAT_HD void obs_step_dot(const CamRec &cam, const double Q[3], double u, double
     const double X0 = cam.Mt[0] * d0 + cam.Mt[1] * d1 + cam.Mt[2] * d2;
     const double X1 = cam.Mt[3] * d0 + cam.Mt[4] * d1 + cam.Mt[5] * d2;
     const double X2 = cam.Mt[6] * d0 + cam.Mt[7] * d1 + cam.Mt[8] * d2;
-    const double iz = 1.0 / X2;
+    const double iz = recip(X2);
     const double ph0 = X0 * iz, ph1 = X1 * iz;
     const double s = -cam.f * iz;
     double a0 = 0, a1 = 0;                       // A dc (EO part), unweighted
@@ -307,15 +326,13 @@ DBAT_HD void obs_step_dot(const CamRec &cam, const double Q[3], double u, double
         const double mk = ((cam.eo_est >> k) & 1u) ? dc[k] : 0.0;
         a0 -= b0 * mk; a1 -= b1 * mk;             // A(:,k) = -B(:,k)  (world2cam.m:82)
     }
+    double y[3][3];
+    angle_terms(cam, d0, d1, d2, X0, X1, X2, y);  // eulerpinhole2.m:100
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {                 // eulerpinhole2.m:100
-        const double *D = cam.dMt[k];
-        const double y0 = D[0] * d0 + D[1] * d1 + D[2] * d2;
-        const double y1 = D[3] * d0 + D[4] * d1 + D[5] * d2;
-        const double y2 = D[6] * d0 + D[7] * d1 + D[8] * d2;
+    for (int k = 0; k < 3; ++k) {
         const double mk = ((cam.eo_est >> (3 + k)) & 1u) ? dc[3 + k] : 0.0;
-        a0 += s * (y0 - ph0 * y2) * mk;
-        a1 += s * (y1 - ph1 * y2) * mk;
+        a0 += s * (y[k][0] - ph0 * y[k][2]) * mk;
+        a1 += s * (y[k][1] - ph1 * y[k][2]) * mk;
     }
     if (!IO8) { t0 = a0 * w0; t1 = a1 * w1; return; }      // fixed IO: dc[0..5] only
     ImgSide im;

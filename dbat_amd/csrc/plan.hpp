@@ -10,6 +10,7 @@
 // The first NS = 6*nc+nIOu entries of z are the columns of the reduced
 // (camera + IO) system; the OP part is eliminated by the Schur complement.
 #pragma once
+#include "env.hpp"
 #include <chrono>
 #include <algorithm>
 #include <cmath>
@@ -175,7 +176,7 @@ inline void serialize_block(int rows, int cols, const int32_t *block, const uint
 
 inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     // DBAT_HIP_PLAN_STATS=2: wall time of every section of the plan (stderr)
-    const bool plan_clock = getenv("DBAT_HIP_PLAN_STATS") && atoi(getenv("DBAT_HIP_PLAN_STATS")) >= 2;
+    const bool plan_clock = env_int("DBAT_HIP_PLAN_STATS", 0) >= 2;
     auto plan_t0 = std::chrono::steady_clock::now();
     auto lapt = [&](const char *what) {
         if (!plan_clock) return;
@@ -184,6 +185,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         plan_t0 = now;
     };
     if (pb.abi_version != DBAT_HIP_ABI_VERSION) return fail(P, "ABI version mismatch");
+    { std::string env_err; if (!env_validate(env_err)) return fail(P, env_err.c_str()); }
     if (pb.n_images <= 0 || pb.n_points <= 0 || pb.n_obs < 0) return fail(P, "empty problem");
     if (pb.dist_model < 2 || pb.dist_model > 5)
         return fail(P, "lens distortion model must be 2..5 (brown_euler_cam4.m:122-130)");
@@ -369,7 +371,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     // along an augmenting path.  J is never formed: the rows of an EO or IO column are the
     // contiguous observation ranges of its cameras, those of an OP column the observations
     // of its point.
-    if (P.rank_ok && !getenv("DBAT_HIP_SPRANK_OFF") && !P.shared_eo) {     // (shared EO: the counting conditions only)
+    if (P.rank_ok && !env_on("DBAT_HIP_SPRANK_OFF") && !P.shared_eo) {     // (shared EO: the counting conditions only)
         const int64_t ncol_all = P.NZ;
         std::vector<int64_t> cam_obs0(nc + 1, 0);
         for (int c = 0; c < nc; ++c) cam_obs0[c + 1] = cam_obs0[c] + n_cam[c];
@@ -466,28 +468,26 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     lapt("exact structural rank (sprank(J) < n  =>  code -4): when t");
     // ---- nested dissection (nd.hpp); with several ranks its first levels are the ranks' domains
     {
-        const bool nd_off = getenv("DBAT_HIP_ND_OFF") != nullptr;
+        const bool nd_off = env_on("DBAT_HIP_ND_OFF");
         const bool permuted_ok = !P.shared_eo;
-        P.mg_subtree = P.nranks > 1 && permuted_ok && !nd_off && !getenv("DBAT_HIP_MG_REPLICATED");
+        P.mg_subtree = P.nranks > 1 && permuted_ok && !nd_off && !env_on("DBAT_HIP_MG_REPLICATED");
         std::vector<double> xyz((size_t)3 * nc), wcam(nc);
         for (int c = 0; c < nc; ++c) {
             for (int k = 0; k < 3; ++k) { const double v = pb.EO_val[(size_t)6 * c + k]; xyz[(size_t)3 * c + k] = std::isfinite(v) ? v : 0.0; }   // only steers the bisection
             wcam[c] = (double)n_cam[c];
         }
-        const int leaf = std::max(8, getenv("DBAT_HIP_ND_LEAF") ? atoi(getenv("DBAT_HIP_ND_LEAF")) : 32);
+        const int leaf = std::max(8, env_int("DBAT_HIP_ND_LEAF", 32));
         nd_build(nc, P.cam_adj.data(), P.cam_adj_words, xyz.data(), wcam.data(), P.mg_subtree ? P.nranks : 1, leaf, nd_off, P.nd);
     }
     lapt("nested dissection");
     // Points that fit a tile of the MFMA Schur kernel (at most CMAX cameras and
     // IOT estimated IO columns) are processed first; "heavy" points (e.g. control
     // points seen in very many images) follow and go through k_build.
-    auto env_int0 = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
-    P.CMAX = env_int0("DBAT_HIP_CMAX", P.with_io ? 18 : 21);
+    P.CMAX = env_int("DBAT_HIP_CMAX", P.with_io ? 18 : 21);
     if (P.shared_eo) P.CMAX = 0;                    // the tile kernels address camera rows as 6*camera + k
     if (P.CMAX < 0 || P.CMAX > (P.with_io ? 18 : 21)) P.CMAX = P.with_io ? 18 : 21;   // 6*CMAX (+IOT) <= 128 rows of the MFMA tile
     if (P.ncolmax > 14) P.CMAX = 0;                  // the tile kernels hold at most 8 IO columns per camera: untiled (k_build)
     {   // batch size: whole points, at most BT observations
-        auto env_int = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
         P.BT = env_int("DBAT_HIP_BT", 256);
         if (P.BT != 128 && P.BT != 256) P.BT = 256;
         if ((size_t)P.BT * P.ncolmax * 3 * 8 + (size_t)P.BT * 18 * 8 > 150 * 1024) P.BT = 128;
@@ -931,7 +931,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
                    P.batch_start[P.tile_batch[b + 1]] - P.batch_start[P.tile_batch[b]];
         });
         P.n_tiles_io_simple = 0;
-        if (getenv("DBAT_HIP_SIG_IOS_OFF")) std::fill(P.tile_io_simple.begin(), P.tile_io_simple.end(), 0);
+        if (env_on("DBAT_HIP_SIG_IOS_OFF")) std::fill(P.tile_io_simple.begin(), P.tile_io_simple.end(), 0);
         for (uint8_t f : P.tile_io_simple) P.n_tiles_io_simple += f ? 1 : 0;
     }
     {   // camera-major copy of the observations (stable counting sort by camera): first the tiled
@@ -976,15 +976,15 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     // (self-calibration: k_backsub_sig knows the usual eight IO columns only)
     const bool bs_can = sg_can && (P.ncolmax <= 6 || P.all_std8);
     P.sg_backsub_ok = bs_can && P.sg_npoints >= 8 * P.sg_ngroups;
-    if (const char *e = getenv("DBAT_HIP_SIG")) {     // 0 off, 2 whenever possible
+    if (const char *e = env_get("DBAT_HIP_SIG")) {     // 0 off, 2 whenever possible
         P.sg_ok = atoi(e) == 0 ? false : (atoi(e) >= 2 ? sg_can : P.sg_ok);
         P.sg_backsub_ok = atoi(e) == 0 ? false : (atoi(e) >= 2 ? bs_can : P.sg_backsub_ok);
     }
-    if (getenv("DBAT_HIP_PLAN_STATS") && P.sg_ngroups > 0)
+    if (env_on("DBAT_HIP_PLAN_STATS") && P.sg_ngroups > 0)
         fprintf(stderr, "[plan] %lld signature groups, %.1f points/group, %zu chunks, k max %d, sig kernel %s\n",
                 (long long)P.sg_ngroups, (double)P.sg_npoints / P.sg_ngroups, P.sg_chunk.size() / 8, P.sg_kmax,
                 P.sg_ok ? "on" : "off");
-    if (getenv("DBAT_HIP_PLAN_STATS") && P.tile_batch.size() > 1) {      // tile size distribution
+    if (env_on("DBAT_HIP_PLAN_STATS") && P.tile_batch.size() > 1) {      // tile size distribution
         std::vector<int> nbt;
         for (size_t i = 0; i + 1 < P.tile_batch.size(); ++i) nbt.push_back(P.tile_batch[i + 1] - P.tile_batch[i]);
         std::sort(nbt.begin(), nbt.end());

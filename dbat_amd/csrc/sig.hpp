@@ -40,6 +40,7 @@
 //     while one multiplies).
 // LDS reads of the operands are conflict free (row stride 18 doubles = 2 mod 4).
 #pragma once
+#include <cstddef>
 #include <type_traits>
 
 #include "kernels.hpp"
@@ -50,7 +51,7 @@ constexpr int SIG_LDK = 18;          // k-columns per panel row: 6 points of a r
 constexpr int SIG_PPR = 6;           // points per round of pass 2
 constexpr int SIG_KMAXR = 13;        // cameras per group at most (Plan::SG_KMAX)
 constexpr int SIG_NW = 8;            // waves per workgroup (two per SIMD: one evaluates while the other multiplies)
-constexpr int SIG_CAMW = 58;         // doubles of a CamRec that the fixed-IO evaluation reads (.. w[2]) + eo_est
+constexpr int SIG_CAMW = (int)(offsetof(CamRec, ncol) / 8) + 1;   // doubles of a CamRec that the fixed-IO evaluation reads (.. w[2]) + eo_est
 constexpr int SIG_CAMW_IO = (int)((sizeof(CamRec) + 7) / 8);   // self-calibration: the whole record (column lists)
 constexpr int SIG_STILE = 8064;      // 126*127/2 = 8001 packed lower triangle of the tile, padded
 
@@ -75,6 +76,59 @@ __device__ __forceinline__ double lane_get(double x, int src) {
     const int lo = __builtin_amdgcn_ds_bpermute(4 * src, (int)(b & 0xffffffffll));
     const int hi = __builtin_amdgcn_ds_bpermute(4 * src, (int)(b >> 32));
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Fixed interior orientation: the image side of an observation (the corrected image coordinates rhs) does not change
+// between iterations and is precomputed (k_uv_to_rhs), the Jacobian blocks A, B do not depend on (u, v) at all.
+// Pass 1 -- residual and WEIGHTED point block (res_euler_brown_*.m with eulerpinhole2.m, pinhole.m:54-66): 38 operations.
+__device__ __forceinline__ void sig_eval_rB(const CamRec &C, const double (&Q)[3], double rhs0, double rhs1, double w0,
+                                            double w1, double (&r)[2], double (&B)[2][3]) {
+    const double d0 = Q[0] - C.c[0], d1 = Q[1] - C.c[1], d2 = Q[2] - C.c[2];
+    const double X0 = C.Mt[0] * d0 + C.Mt[1] * d1 + C.Mt[2] * d2;
+    const double X1 = C.Mt[3] * d0 + C.Mt[4] * d1 + C.Mt[5] * d2;
+    const double X2 = C.Mt[6] * d0 + C.Mt[7] * d1 + C.Mt[8] * d2;
+    const double iz = recip(X2);
+    const double ph0 = X0 * iz, ph1 = X1 * iz;
+    const double nf = -C.f, s = nf * iz, s0 = s * w0, s1 = s * w1;
+    r[0] = (nf * ph0 - rhs0) * w0;
+    r[1] = (nf * ph1 - rhs1) * w1;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        B[0][k] = s0 * (C.Mt[k] - ph0 * C.Mt[6 + k]);
+        B[1][k] = s1 * (C.Mt[3 + k] - ph1 * C.Mt[6 + k]);
+    }
+}
+// Pass 2 -- Z = E' (B R) of one observation, E = weighted camera block [dQ0 | dA], R = the (row-masked) factor of the
+// point's V^-1: 6 x 3 values, about 100 operations (angle_terms: no derivative matrices).
+__device__ __forceinline__ void sig_eval_Z(const CamRec &C, const double (&Q)[3], double w0, double w1,
+                                           const double (&R)[6], double (&Z)[6][3]) {
+    const double d0 = Q[0] - C.c[0], d1 = Q[1] - C.c[1], d2 = Q[2] - C.c[2];
+    const double X0 = C.Mt[0] * d0 + C.Mt[1] * d1 + C.Mt[2] * d2;
+    const double X1 = C.Mt[3] * d0 + C.Mt[4] * d1 + C.Mt[5] * d2;
+    const double X2 = C.Mt[6] * d0 + C.Mt[7] * d1 + C.Mt[8] * d2;
+    const double iz = recip(X2);
+    const double ph0 = X0 * iz, ph1 = X1 * iz;
+    const double s = -C.f * iz, s0 = s * w0, s1 = s * w1;
+    double t0[3], t1[3];                             // B = [s0 t0 ; s1 t1]
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { t0[k] = C.Mt[k] - ph0 * C.Mt[6 + k]; t1[k] = C.Mt[3 + k] - ph1 * C.Mt[6 + k]; }
+    const double r00 = R[0], r10 = R[1], r20 = R[2], r11 = R[3], r21 = R[4], r22 = R[5];
+    const double br0[3] = {s0 * (t0[0] * r00 + t0[1] * r10 + t0[2] * r20), s0 * (t0[1] * r11 + t0[2] * r21), s0 * (t0[2] * r22)};
+    const double br1[3] = {s1 * (t1[0] * r00 + t1[1] * r10 + t1[2] * r20), s1 * (t1[1] * r11 + t1[2] * r21), s1 * (t1[2] * r22)};
+    double y[3][3];
+    angle_terms(C, d0, d1, d2, X0, X1, X2, y);
+    double e0[6], e1[6];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        e0[k] = -(s0 * t0[k]); e1[k] = -(s1 * t1[k]);                 // world2cam.m:82  dQ0 = -dQ
+        e0[3 + k] = s0 * (y[k][0] - ph0 * y[k][2]); e1[3 + k] = s1 * (y[k][1] - ph1 * y[k][2]);
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        Z[a][0] = e0[a] * br0[0] + e1[a] * br1[0];
+        Z[a][1] = e0[a] * br0[1] + e1[a] * br1[1];
+        Z[a][2] = e0[a] * br0[2] + e1[a] * br1[2];
+    }
 }
 
 // NCX = 6: fixed IO.  NCX = 14: self-calibration -- the estimated IO columns of the tile's cameras are
@@ -128,7 +182,7 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
     if constexpr (IO) { for (int i = t; i < 16 * ncam; i += NT) sy.camio[i >> 4][i & 15] = d.tile_cam_io[(size_t)c0 * 16 + i]; }
     if (t == 0) { sy.next_chunk = ch0; sy.abort_ = 0; }
     // DBAT_HIP_ABLATE & 32: phase clocks of wave 0 (100 MHz ticks), summed over the tiles into g_tile2_prof
-    const bool prof = (d.ablate & 32) && t == 0;
+    const bool prof = DBAT_ABLATE(d, 32) && t == 0;
     long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = prof ? wall_clock64() : 0;
     auto lap = [&](int i) { if (prof) { const long long now = wall_clock64(); tp[i] += now - tlast; tlast = now; } };
     __syncthreads();
@@ -213,7 +267,7 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
                 g[1] += B[0][1] * r[0] + B[1][1] * r[1];
                 g[2] += B[0][2] * r[0] + B[1][2] * r[1];
             };
-            const int kk = (d.ablate & 4) ? 1 : k;
+            const int kk = DBAT_ABLATE(d, 4) ? 1 : k;
             if constexpr (!IO) {
                 // Fixed IO: TWO cameras per trip.  One evaluation is a dependent chain of ~120 f64 operations and the
                 // SIMD holds two waves, so a single chain leaves the issue slots half empty (r03a_c3_summary.md: 40 %
@@ -235,15 +289,10 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
                     const double wa0 = sg_w ? cwa.x : CA.w[0], wa1 = sg_w ? cwa.y : CA.w[1];
                     const double zb = vb ? 1.0 : 0.0;
                     const double wb0 = (sg_w ? cwb.x : CB.w[0]) * zb, wb1 = (sg_w ? cwb.y : CB.w[1]) * zb;
-                    double rA[2], AA[2][6], BA[2][3], CfA[2][MAXIO], rB[2], AB[2][6], BB[2][3], CfB[2][MAXIO];
-                    obs_eval<MODEL, true, false>(CA, d.nK, d.nP, Q, ca.x, ca.y, rA, AA, BA, CfA);    // A is dead code here
-                    obs_eval<MODEL, true, false>(CB, d.nK, d.nP, Q, cb.x, cb.y, rB, AB, BB, CfB);
-                    rA[0] *= wa0; rA[1] *= wa1; rB[0] *= wb0; rB[1] *= wb1;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const double m = ((est >> c) & 1u) ? 1.0 : 0.0;
-                        BA[0][c] *= wa0 * m; BA[1][c] *= wa1 * m; BB[0][c] *= wb0 * m; BB[1][c] *= wb1 * m;
-                    }
+                    // (the coordinates a point does not estimate are masked once per point, after the sums)
+                    double rA[2], BA[2][3], rB[2], BB[2][3];
+                    sig_eval_rB(CA, Q, ca.x, ca.y, wa0, wa1, rA, BA);
+                    sig_eval_rB(CB, Q, cb.x, cb.y, wb0, wb1, rB, BB);
                     accumulate(rA, BA);
                     accumulate(rB, BB);
                 }
@@ -304,6 +353,13 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
                 }
             }
             const bool writer = act && lane == pi;    // one lane per point writes to HBM
+            if constexpr (!IO) {
+                if (est != 7u) {                      // fixed coordinates: B(:, c) = 0
+                    const double m0 = (est & 1u) ? 1.0 : 0.0, m1 = (est & 2u) ? 1.0 : 0.0, m2 = (est & 4u) ? 1.0 : 0.0;
+                    V[0] *= m0; V[1] *= m0 * m1; V[2] *= m0 * m2; V[3] *= m1; V[4] *= m1 * m2; V[5] *= m2;
+                    g[0] *= m0; g[1] *= m1; g[2] *= m2;
+                }
+            }
             if (act) {
                 double jn[3];
 #pragma unroll
@@ -338,6 +394,15 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
                 }
                 const double r00 = Rpb[0], r10 = Rpb[1], r20 = Rpb[2], r11 = Rpb[3], r21 = Rpb[4], r22 = Rpb[5];
                 pR[0] = r00; pR[1] = r10; pR[2] = r20; pR[3] = r11; pR[4] = r21; pR[5] = r22;
+                if constexpr (!IO) {
+                    // pass 2 multiplies B R with B unmasked: row c of R is zeroed for a coordinate that is not estimated
+                    // (column c of B then never contributes)
+                    if (est != 7u) {
+                        if (!(est & 1u)) pR[0] = 0.0;
+                        if (!(est & 2u)) { pR[1] = 0.0; pR[3] = 0.0; }
+                        if (!(est & 4u)) { pR[2] = 0.0; pR[4] = 0.0; pR[5] = 0.0; }
+                    }
+                }
                 pY[0] = r00 * g[0] + r10 * g[1] + r20 * g[2];                  // y = R' g
                 pY[1] = r11 * g[1] + r21 * g[2];
                 pY[2] = r22 * g[2];
@@ -360,7 +425,7 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
         lap(2);
         // trace(J'J) only (the first linearisation of levenberg_marquardt.m:76-95 serves lambda0 = c trace / n and
         // nothing else): the squared column norms of the points are out, the Schur complement is not wanted
-        if (d.ablate & 64) continue;
+        if (d.trace_only) continue;
         // ------------------------------------------------------------ pass 2: lane = observation
         mfma_d4 acc[NBLK];
 #pragma unroll
@@ -422,8 +487,22 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
             for (int c = 0; c < 6; ++c) gR[c] = lane_get(pR[c], src);
 #pragma unroll
             for (int c = 0; c < 3; ++c) { gY[c] = lane_get(pY[c], src); gQ[c] = lane_get(pQ[c], src); }
-            const unsigned est = (unsigned)__builtin_amdgcn_ds_bpermute(4 * src, (int)pEst);
-            if (on && !(d.ablate & 2)) {
+            unsigned est = 7u;
+            if constexpr (IO) est = (unsigned)__builtin_amdgcn_ds_bpermute(4 * src, (int)pEst);
+            if constexpr (!IO) {
+                if (on && !DBAT_ABLATE(d, 2)) {
+                    const double Q[3] = {gQ[0], gQ[1], gQ[2]};
+                    const double w0 = sg_w ? w_c.x : C.w[0], w1 = sg_w ? w_c.y : C.w[1];
+                    sig_eval_Z(C, Q, w0, w1, gR, Zr);
+                    if (eo_est != 63u) {
+#pragma unroll
+                        for (int a = 0; a < 6; ++a)
+                            if (!((eo_est >> a) & 1u)) { Zr[a][0] = 0.0; Zr[a][1] = 0.0; Zr[a][2] = 0.0; }
+                    }
+                    y3[0] = gY[0]; y3[1] = gY[1]; y3[2] = gY[2];
+                }
+            } else
+            if (on && !DBAT_ABLATE(d, 2)) {
                 const double Q[3] = {gQ[0], gQ[1], gQ[2]};
                 const double uu = uv_c.x, vv = uv_c.y;
                 const double w0 = sg_w ? w_c.x : C.w[0], w1 = sg_w ? w_c.y : C.w[1];
@@ -477,7 +556,7 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
             lap(3);
             // 18 k-columns = 4 1/2 k-steps: all operands of the round are read first, then the products
             // run back to back; the last step's lanes 32..63 would read k-columns 18, 19 (the next row)
-            const int ksteps = (d.ablate & 1) ? 0 : (3 * min(ppr, npts - p0) + 3) >> 2;
+            const int ksteps = DBAT_ABLATE(d, 1) ? 0 : (3 * min(ppr, npts - p0) + 3) >> 2;
             const double *zr = pan + (lane & 15) * LDK + (lane >> 4);
             // operands of k-step ks+1 are read while the products of k-step ks run
             auto load_ops = [&](int ks, double (&o)[RB]) {
@@ -530,7 +609,7 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
 #pragma unroll
                     for (int r2 = 0; r2 <= r1; ++r2) {
                         double v = acc[r1 * (r1 + 1) / 2 + r2][e];
-                        bool take = v != 0.0 && !(d.ablate & 8);
+                        bool take = v != 0.0 && !DBAT_ABLATE(d, 8);
                         if (r2 == r1) { const int lcol = 16 * r2 + (lane & 15); take = take && lcol <= lr && lcol < r6k; }
                         if (take) atomic_add_f64(row + tcm[r2], yrow ? -v : v);
                     }
@@ -549,7 +628,7 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
         const int64_t gcol = sy.grow[tc];
         for (int tr = tc + lane; tr < nrows; tr += 64) {
             const double v = stile[tr * (tr + 1) / 2 + tc];
-            if (v != 0.0 && !(d.ablate & 16)) atomic_add_f64(S + gcol * d.ldS + sy.grow[tr], -v);
+            if (v != 0.0 && !DBAT_ABLATE(d, 16)) atomic_add_f64(S + gcol * d.ldS + sy.grow[tr], -v);
         }
     }
     for (int i = t; i < nrows; i += NT)

@@ -86,6 +86,8 @@ def bundle(s, *args, device=None, comm=None, store_trace=True, jacobian=False):
             print('Setting %s parameters to fixed' % nm)
             pr.use = pr.use & est
     rank, world = (comm.rank, comm.world_size) if comm is not None else (0, 1)
+    if jacobian and world > 1:
+        raise BadInput('bundle(..., jacobian=True): the explicit Jacobian (E.final.*.J) is built by one-rank handles only')
     if device is None:
         # a rank of a multi-GPU run works on the device its process selected
         device = getattr(comm, 'device', None) if comm is not None else 0
@@ -162,7 +164,7 @@ def bundle(s, *args, device=None, comm=None, store_trace=True, jacobian=False):
             ofs += len(pos)
             setattr(s.post.res, nm, flat.reshape(arr.shape, order='F'))
         E.final = NS(unweighted=NS(r=ru), weighted=NS(r=rw))
-        if jacobian and world == 1 and E.code != -4:
+        if jacobian and E.code != -4:
             E.final.weighted.J = h.jacobian_csc(x, True)
             E.final.unweighted.J = h.jacobian_csc(x, False)
         p_extra = 0

@@ -135,8 +135,8 @@ def set_script_defaults(s):
     return s
 
 
-def forwintersect(s):
+def forwintersect(s, device=0):
     """Initial object points by forward intersection of every point
-    (photogrammetry/forwintersect.m:27-46); see dbat_amd.initial."""
+    (photogrammetry/forwintersect.m:27-46), on the device: dbat_amd.initial.forwintersect."""
     from .initial import forwintersect as fwd
-    return fwd(s, 'all')
+    return fwd(s, 'all', device=device)

@@ -90,12 +90,13 @@ def camcal_demo_struct(model=3, export='camcal-pmexport.txt'):
     reference's committed report also pins the iteration count and the first
     residual norm."""
     from dbat_amd import initial as I
+    import initial_oracle as IO_
     s = I.clearop(I.cleareo(camcal_struct(model, export)))
     assert np.isnan(s.EO.val).all() and np.isnan(s.OP.val[:, ~s.prior.OP.isCtrl]).all()
     cpId = s.OP.id[s.prior.OP.isCtrl]
-    s1, rms, fail = I.resect(s, 'all', cpId, 1, 0, cpId)
+    s1, rms, fail = IO_.resect(s, 'all', cpId, 1, 0, cpId)
     assert not fail
-    return I.forwintersect(s1, 'all', True)
+    return IO_.forwintersect(s1, 'all', True)
 
 
 def camcal_expected():
@@ -261,6 +262,17 @@ def relerr(a, b):
     return np.linalg.norm((a - b).ravel()) / (d if d > 0 else 1.0)
 
 
+def script_forwintersect(s):
+    """The script operation forward_intersection: on the device where there is one (the product path,
+    dbat_amd.loadtables.forwintersect -> dbat_hip_forwintersect), by the oracle's restatement on the CPU box."""
+    import torch
+    if torch.cuda.is_available():
+        from dbat_amd import loadtables as T
+        return T.forwintersect(s)
+    import initial_oracle
+    return initial_oracle.forwintersect(s, 'all')
+
+
 def roma_struct():
     """data/script/romabundledemo/romabundledemo.xml: loaded camera and EO,
     OP by forward intersection, estimate cc, pp, K1, K2 (no aspect, skew, P,
@@ -275,7 +287,7 @@ def roma_struct():
     sensor = (ci['image'][0] * h / ci['image'][1], h)          # sensor 'auto,24', aspect 1
     io = T.camera_io(ci['cc'], ci['pp'], ci['K'], ci['P'])
     s = T.struct_from_tables(io, sensor, ci['image'], eo, mk, 'im,id,x,y', 1.0, distModel=ci['model'])
-    s = T.forwintersect(s)
+    s = script_forwintersect(s)
     s.bundle.est.IO[[0, 1, 2, 5, 6]] = True
     s.EO.name = exp['image_paths']
     s.proj = type(s.post)(objUnit='m', x0desc='')
@@ -295,6 +307,7 @@ def prague_struct(label):
     that model 2 replicates (bundle.m:49-51); oracle and library evaluate it as
     model 2.  Returns (s, path of the committed report)."""
     from dbat_amd import initial as I
+    import initial_oracle as IO_
     site, stub, weighted = PRAGUE[label]
     prob = L.loadpm(_golden_path('prague-%s-%s-pmexport.txt' % (site, stub)))
     s = L.prob2dbatstruct(prob, distModel=1)
@@ -309,9 +322,9 @@ def prague_struct(label):
     s.proj = type(s.post)(objUnit='m', x0desc='')
     s = I.clearop(I.cleareo(s))
     cpId = s.OP.id[s.prior.OP.isCtrl]
-    s, rms, fail = I.resect(s, 'all', cpId, 1, 0, cpId)
+    s, rms, fail = IO_.resect(s, 'all', cpId, 1, 0, cpId)
     assert not fail
-    return I.forwintersect(s, 'all', True), os.path.join(GOLDEN, 'prague-%s-%s-dbatreport.txt' % (site, stub))
+    return IO_.forwintersect(s, 'all', True), os.path.join(GOLDEN, 'prague-%s-%s-dbatreport.txt' % (site, stub))
 
 
 def sxb_prior_eo_struct(use_prior_eo):
@@ -320,6 +333,7 @@ def sxb_prior_eo_struct(use_prior_eo):
     prior observations (0.05 m) of four of the five camera positions from
     ref/fake-camera-positions.txt (misc/setprioreo.m).  Returns (s, report)."""
     from dbat_amd import initial as I
+    import initial_oracle as IO_
     prob = L.loadpm(_golden_path('prague-sxb-wsmart-with-orient-pmexport.txt'))
     s = L.prob2dbatstruct(prob, distModel=1)               # the demo's model; evaluated as model 2 (bundle.m:49-51)
     s.bundle.est.IO[:] = False
@@ -340,9 +354,9 @@ def sxb_prior_eo_struct(use_prior_eo):
             s.bundle.est.EO[:3, i] = sd != 0
     s = I.clearop(I.cleareo(s))
     cpId = s.OP.id[s.prior.OP.isCtrl]
-    s, rms, fail = I.resect(s, 'all', cpId, 1, 0, cpId)
+    s, rms, fail = IO_.resect(s, 'all', cpId, 1, 0, cpId)
     assert not fail
-    return I.forwintersect(s, 'all', True), os.path.join(
+    return IO_.forwintersect(s, 'all', True), os.path.join(
         GOLDEN, 'prague-sxb-%sprior-eo-dbatreport.txt' % ('' if use_prior_eo else 'no-'))
 
 
@@ -359,6 +373,7 @@ def sxb_struct():
     false, eo true, op default), spatial_resection, forward_intersection
     (script/parseops.m:36-43)."""
     from dbat_amd import initial as I
+    import initial_oracle as IO_
     from dbat_amd import loadtables as T
     exp = sxb_expected()
     cam = exp['camera']
@@ -376,9 +391,9 @@ def sxb_struct():
     s = T.set_script_defaults(s)
     s.proj = type(s.post)(objUnit='m', x0desc='')
     cpId = s.OP.id[s.prior.OP.isCtrl]
-    s, rms, fail = I.resect(s, 'all', cpId, 1, 0, cpId)
+    s, rms, fail = IO_.resect(s, 'all', cpId, 1, 0, cpId)
     assert not fail
-    return I.forwintersect(s, 'all', True)
+    return IO_.forwintersect(s, 'all', True)
 
 
 def check_sxb_against_report(res, s0, E, iters, exp):
@@ -413,7 +428,7 @@ def roma_demo_struct(variant):
     io = T.camera_io(cam['cc'], (cam['px'], cam['py']), [cam['K1'], cam['K2'], cam['K3']], [cam['P1'], cam['P2']],
                      aspect=1.0 - cam['as'])
     s = T.struct_from_tables(io, (36.0, 24.0), (5616, 3744), eo, mk, 'im,id,x,y', 1.0, distModel=3)
-    s = T.forwintersect(s)
+    s = script_forwintersect(s)
     if variant != 'fixed':
         s.bundle.est.IO[:] = True                              # setcamest 'all','not','sk'
         s.bundle.est.IO[4] = False

@@ -37,6 +37,24 @@ def test_no_cpu_fallback_without_gpu():
     assert e.value.code == _hip.EDEVICE
 
 
+def test_unknown_or_measurement_environment_switch_is_refused(monkeypatch):
+    """csrc/env.hpp: a DBAT_HIP_* variable that is not a switch of the library (a typo, a knob of an older round),
+    or a measurement switch (ablation bits make the results wrong by design) given to the product build, fails the
+    plan loudly instead of being ignored."""
+    s, _ = synth_struct('tiny')
+    assert _hip.plan(s)['n'] > 0
+    for name, needle in (('DBAT_HIP_SIGG', 'unknown environment variable DBAT_HIP_SIGG'),
+                         ('DBAT_HIP_ABLATE', 'measurement switch'), ('DBAT_HIP_DF_ORDER', 'measurement switch'),
+                         ('DBAT_HIP_BLOCKCHOL', 'unknown environment variable')):
+        monkeypatch.setenv(name, '1')
+        with pytest.raises(_hip.DbatHipError) as e:
+            _hip.plan(s)
+        assert e.value.code == _hip.EINVAL and needle in str(e.value)
+        monkeypatch.delenv(name)
+    monkeypatch.setenv('DBAT_HIP_SIG', '0')           # a product switch
+    assert _hip.plan(s)['n'] > 0
+
+
 def test_default_options_match_bundle_m():
     # bundle.m:78-86, 281-283, 301-304, 321-322
     for d in ('gm', 'gna', 'lm', 'lmp'):

