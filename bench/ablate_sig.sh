@@ -1,7 +1,7 @@
 #!/bin/bash
 # time k_build_sig with parts switched off (results are wrong, only the kernel time matters)
 for a in 0 1 2 3 4 7 8 16 31; do
-  DBAT_HIP_ABLATE=$a python bench.py --no-cpu-baseline --no-solve --steps 10 --warmup 2 2>/dev/null | python -c "
+  DBAT_AMD_LIB=prof DBAT_HIP_ABLATE=$a python bench.py --no-cpu-baseline --no-solve --steps 10 --warmup 2 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):

@@ -3,5 +3,5 @@
 cd $GRAFT_REPO_ROOT
 C=${1:-C3}
 python bench.py --config $C --steps 10 --warmup 2 --no-cpu-baseline --no-solve 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print(d['value'], d['kernel_ms'])"
-DBAT_HIP_DF_TRACE=/tmp/df_trace.csv python bench.py --config $C --steps 2 --warmup 1 --no-cpu-baseline --no-solve > /dev/null 2>&1
+DBAT_AMD_LIB=prof DBAT_HIP_DF_TRACE=/tmp/df_trace.csv python bench.py --config $C --steps 2 --warmup 1 --no-cpu-baseline --no-solve > /dev/null 2>&1
 python bench/chol_trace.py /tmp/df_trace.csv

@@ -96,6 +96,7 @@ struct Core {
     DevProblem d{};
     hipStream_t stream = nullptr;
     int device = 0;
+    int n_cu = 256;                  // compute units: launch size of the persistent tile kernel
     rocblas_handle blas = nullptr;
     // pinned host mailbox for the scalar read-backs of the damping loops (a copy to pageable memory is
     // staged and costs a blit kernel of ~18 us each, seven per LM step): [0..31] scalars, [32..35]
@@ -198,6 +199,11 @@ struct Core {
     void init(const dbat_hip_problem &pb) {
         device = pb.device;
         HIPCHK(hipSetDevice(pb.device));
+        {
+            hipDeviceProp_t prop;
+            HIPCHK(hipGetDeviceProperties(&prop, pb.device));
+            n_cu = std::max(1, prop.multiProcessorCount);
+        }
         HIPCHK(hipStreamCreate(&stream));
         // coherent (fine-grained) on purpose: the kernels' stores must become visible to the spinning host
         // thread without a stream synchronisation, whatever HIP_HOST_COHERENT says
@@ -581,7 +587,7 @@ struct Core {
 #undef L_CAMN
             mark(0);                                 // events around the tile kernel alone (bench roofline)
 #define L_TILE3(M, DUMMY) LAUNCHK((k_build_tile3<M, TILE3_PC, TILE3_NBUF>), dim3((unsigned)ntiles), dim3(768), lds_tile3, stream, d, zz, cams.p, lambda, scale, S, g_red, Vinv.p, gp.p, jn2p.p, partial.p, pivmm.p)
-#define L_SIG(M, RBV) LAUNCHK((k_build_sig<M, (RBV) % 8, (RBV) / 8>), dim3((unsigned)ntiles), dim3(64 * sig_waves((RBV) % 8, (RBV) / 8 > 6)), sig_lds_bytes((RBV) % 8, (RBV) / 8 > 6), stream, d, zz, cams.p, lambda, scale, S, g_red, Vinv.p, gp.p, jn2p.p, partial.p, pivmm.p, sg_chunk.p, sg_tile_chunk0.p, sg_lc.p, sg_uv.p, P.uniform_w ? (const double *)nullptr : sg_w.p)
+#define L_SIG(M, RBV) LAUNCHK((k_build_sig<M, (RBV) % 8, (RBV) / 8>), dim3((unsigned)std::min<int64_t>(ntiles, n_cu)), dim3(64 * sig_waves((RBV) % 8, (RBV) / 8 > 6)), sig_lds_bytes((RBV) % 8, (RBV) / 8 > 6), stream, d, zz, cams.p, lambda, scale, S, g_red, Vinv.p, gp.p, jn2p.p, partial.p, pivmm.p, sg_chunk.p, sg_tile_chunk0.p, sg_lc.p, sg_uv.p, P.uniform_w ? (const double *)nullptr : sg_w.p, gctr.p + 5)
             // (row blocks, camera-side columns) packed into one macro argument: RB + 8 * NCX
             if (use_sig && tile_ncx == 6 && sig_rb == 4) { DISPATCH_MODEL(L_SIG, 4 + 8 * 6) }
             else if (use_sig && tile_ncx == 6) { DISPATCH_MODEL(L_SIG, 5 + 8 * 6) }

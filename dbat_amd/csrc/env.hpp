@@ -33,6 +33,8 @@ static const EnvSwitch kEnvSwitches[] = {
     {"DBAT_HIP_ND_LEAF", false, "leaf size of the dissection"},
     {"DBAT_HIP_ND_PAD_ALL", false, "every block of the dissection on a tile boundary"},
     {"DBAT_HIP_ND_JOIN_SMALL", false, "separators up to that many rows join their child's last tile"},
+    {"DBAT_HIP_DF_SPLIT", false, "factorisation: helper tasks for sums longer than this many products (default 96)"},
+    {"DBAT_HIP_DF_CHUNK", false, "factorisation: products per helper task (default 32)"},
     {"DBAT_HIP_SPRANK_OFF", false, "structural rank from the counting conditions only"},
     {"DBAT_HIP_PLAN_THREADS", false, "threads of the host plan (default: hardware concurrency, at most 32)"},
     {"DBAT_HIP_PLAN_STATS", false, "1: print layout statistics, 2: also the wall time of every section of the plan"},
@@ -40,8 +42,6 @@ static const EnvSwitch kEnvSwitches[] = {
     {"DBAT_HIP_ABLATE", true, "k_build_sig / tile kernels: switch phases off (results are wrong), phase clocks"},
     {"DBAT_HIP_DF_TRACE", true, "per-task clocks of the factorisation, written to this file"},
     {"DBAT_HIP_DF_ORDER", true, "one of the candidate task orders instead of the simulated best"},
-    {"DBAT_HIP_DF_SPLIT", true, "helper tasks for sums longer than this many products"},
-    {"DBAT_HIP_DF_CHUNK", true, "products per helper task"},
     {"DBAT_HIP_DF_GRID", true, "workgroups of the factorisation"},
     {"DBAT_HIP_GRID_OBS", true, "launch size of the observation-parallel kernels"},
 };

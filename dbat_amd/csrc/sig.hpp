@@ -60,6 +60,7 @@ struct SigLds {                      // static part
     int grow[128];                   // row of the reduced system of every row of the tile
     int lc[SIG_NW][16];              // tile-local camera of every slot of the wave's chunk
     short tmap[SIG_NW][80];          // tile row of every row of the wave's chunk
+    int toff[SIG_NW][80];            // ... and the offset of that row in the packed lower triangle of the tile
     unsigned char camio[21][16];     // self-calibration: tile IO row of a camera's q-th IO column
 };
 
@@ -139,7 +140,7 @@ __device__ __forceinline__ void sig_eval_Z(const CamRec &C, const double (&Q)[3]
 // map inside each block: the IO rows of a point are summed in pass 1 (see below).  One launch serves both kinds of tiles
 // (k_build_sig branches per workgroup on the plan's flag), so they share the longest-first order.
 template <int MODEL, int RB, int NCX, int IOS>
-__device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int tile, const double *__restrict__ z,
+__device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int tile, const int part_slot, const double *__restrict__ z,
                                                const CamRec *__restrict__ cams, double lambda, int scale,
                                                double *__restrict__ S, double *__restrict__ g_red,
                                                double *__restrict__ Vinv, double *__restrict__ gp,
@@ -162,6 +163,9 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
     __shared__ double sh[16];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    // DBAT_HIP_ABLATE & 32 (measurement build): phase clocks of wave 0 (100 MHz ticks), summed over the tiles into g_tile2_prof
+    const bool prof = DBAT_ABLATE(d, 32) && t == 0;
+    long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = prof ? wall_clock64() : 0;
     double *pan = wave_base + (size_t)wave * (PROWS * LDK);                // [PROWS][LDK]
     const int c0 = d.tile_cam_start[tile];
     const int ncam = d.tile_cam_start[tile + 1] - c0;
@@ -169,6 +173,14 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
     const int nio = IO ? d.tile_io_start[tile + 1] - io0 : 0;      // IO rows of the tile (and of each of its chunks)
     const int nrows = 6 * ncam + nio;
     const int ch0 = sg_tile_chunk0[tile], ch1 = sg_tile_chunk0[tile + 1];
+    // the first chunk of every wave is fixed (no ticket), and its descriptor is requested before anything else:
+    // the load travels while the tile is cleared and the camera records are staged
+    int ch = ch0 + wave;
+    int nd = 0, nlc = 0;                             // lane l < 8: word l of the next descriptor; l < 16: its camera list
+    if (ch < ch1) {
+        if (lane < 8) nd = sg_chunk[8 * (int64_t)ch + lane];
+        if (lane < 16) nlc = sg_lc[16 * (int64_t)ch + lane];
+    }
     for (int i = t; i < SIG_STILE + 128; i += NT) stile[i] = 0.0;
     for (int i = t; i < NW * (PROWS * LDK); i += NT) wave_base[i] = 0.0;
     for (int i = t; i < ncam * CAMW; i += NT) {
@@ -180,10 +192,8 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
     if (t < 6 * ncam) sy.grow[t] = 6 * d.tile_cams[c0 + t / 6] + t % 6;
     else if (t < nrows) sy.grow[t] = 6 * d.nc + d.tile_iocols[io0 + t - 6 * ncam];
     if constexpr (IO) { for (int i = t; i < 16 * ncam; i += NT) sy.camio[i >> 4][i & 15] = d.tile_cam_io[(size_t)c0 * 16 + i]; }
-    if (t == 0) { sy.next_chunk = ch0; sy.abort_ = 0; }
-    // DBAT_HIP_ABLATE & 32: phase clocks of wave 0 (100 MHz ticks), summed over the tiles into g_tile2_prof
-    const bool prof = DBAT_ABLATE(d, 32) && t == 0;
-    long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = prof ? wall_clock64() : 0;
+    if (t == 0) { sy.next_chunk = ch0 + NW; sy.abort_ = 0; }
+    for (int i = t; i < NW * 80; i += NT) { sy.tmap[i / 80][i % 80] = 0; sy.toff[i / 80][i % 80] = 0; }
     auto lap = [&](int i) { if (prof) { const long long now = wall_clock64(); tp[i] += now - tlast; tlast = now; } };
     __syncthreads();
     lap(0);
@@ -195,12 +205,6 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
         if (lane == 0) c = atomicAdd(&sy.next_chunk, 1);
         return __builtin_amdgcn_readfirstlane(c);
     };
-    int ch = grab();
-    int nd = 0, nlc = 0;                             // lane l < 8: word l of the next descriptor; l < 16: its camera list
-    if (ch < ch1) {
-        if (lane < 8) nd = sg_chunk[8 * (int64_t)ch + lane];
-        if (lane < 16) nlc = sg_lc[16 * (int64_t)ch + lane];
-    }
     while (ch < ch1) {
         const int pt0 = __builtin_amdgcn_readlane(nd, 0), npts = __builtin_amdgcn_readlane(nd, 1);
         const int k = __builtin_amdgcn_readlane(nd, 2);
@@ -210,12 +214,17 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
         {   // tile row of the chunk's rows 0 .. 6k-1 (row 6k is the right-hand side)
             const int kq = lane / 6;
             const int lcq = __builtin_amdgcn_ds_bpermute(4 * (kq < k ? kq : 0), nlc);
-            if (lane < 6 * k) sy.tmap[wave][lane] = (short)(6 * lcq + (lane - 6 * kq));
+            const int tr1 = 6 * lcq + (lane - 6 * kq);
+            if (lane < 6 * k) { sy.tmap[wave][lane] = (short)tr1; sy.toff[wave][lane] = tr1 * (tr1 + 1) / 2; }
             // (ds_bpermute returns 0 from lanes outside EXEC: both exchanges run with the whole wave)
             const int kq2 = (lane + 64) / 6;
             const int lcq2 = __builtin_amdgcn_ds_bpermute(4 * (kq2 < k ? kq2 : 0), nlc);
-            if (lane + 64 < 6 * k) sy.tmap[wave][lane + 64] = (short)(6 * lcq2 + (lane + 64 - 6 * kq2));
-            if (lane < nio) sy.tmap[wave][6 * k + lane] = (short)(6 * ncam + lane);      // IO rows follow the camera rows
+            const int tr2 = 6 * lcq2 + (lane + 64 - 6 * kq2);
+            if (lane + 64 < 6 * k) { sy.tmap[wave][lane + 64] = (short)tr2; sy.toff[wave][lane + 64] = tr2 * (tr2 + 1) / 2; }
+            if (lane < nio) {                        // IO rows follow the camera rows
+                const int tr3 = 6 * ncam + lane;
+                sy.tmap[wave][6 * k + lane] = (short)tr3; sy.toff[wave][6 * k + lane] = tr3 * (tr3 + 1) / 2;
+            }
         }
         ch = grab();
         if (ch < ch1) {
@@ -251,6 +260,8 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
             const int64_t zp = d.NS + 3 * (int64_t)pt;
             double Q[3] = {z[zp], z[zp + 1], z[zp + 2]};
             const unsigned est = (d.z_est[zp] ? 1u : 0u) | (d.z_est[zp + 1] ? 2u : 0u) | (d.z_est[zp + 2] ? 4u : 0u);
+            const double prw[3] = {d.z_prw[zp], d.z_prw[zp + 1], d.z_prw[zp + 2]};     // (used after the sums: requested with the point)
+            const double prv[3] = {d.z_prv[zp], d.z_prv[zp + 1], d.z_prv[zp + 2]};
             double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
             const int64_t q0 = uv0 + gi0 + (act ? pi : 0);
             const double2 *uvp = reinterpret_cast<const double2 *>(sg_uv), *wp = reinterpret_cast<const double2 *>(sg_w);
@@ -274,27 +285,40 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
                 // of the wave cycles issue-stalled); two independent chains interleave.  The accumulators of pass 2
                 // are not live here, so the registers are there.  A lane whose second camera does not exist repeats
                 // its first with zero weights (lanes of a short chunk start at different cameras).
-                auto ld = [&](int jj, double2 &uvx, double2 &wx) {
-                    if (jj < k) { uvx = uvp[q0 + (int64_t)jj * gm]; if (sg_w) wx = wp[q0 + (int64_t)jj * gm]; }
-                };
-                double2 ua = double2{0, 0}, ub = double2{0, 0}, wa = double2{0, 0}, wb = double2{0, 0};
-                ld(jh, ua, wa); ld(jh + jstep, ub, wb);
-                for (int j = jh; j < kk; j += 2 * jstep) {
-                    const bool vb = j + jstep < kk;
-                    const int j2 = vb ? j + jstep : j;
-                    const CamRec &CA = *reinterpret_cast<const CamRec *>(camw + sy.lc[wave][j] * CAMW);
-                    const CamRec &CB = *reinterpret_cast<const CamRec *>(camw + sy.lc[wave][j2] * CAMW);
-                    const double2 ca = ua, cb = vb ? ub : ua, cwa = wa, cwb = vb ? wb : wa;
-                    ld(j + 2 * jstep, ua, wa); ld(j + 3 * jstep, ub, wb);      // the next trip's image coordinates
-                    const double wa0 = sg_w ? cwa.x : CA.w[0], wa1 = sg_w ? cwa.y : CA.w[1];
-                    const double zb = vb ? 1.0 : 0.0;
-                    const double wb0 = (sg_w ? cwb.x : CB.w[0]) * zb, wb1 = (sg_w ? cwb.y : CB.w[1]) * zb;
-                    // (the coordinates a point does not estimate are masked once per point, after the sums)
-                    double rA[2], BA[2][3], rB[2], BB[2][3];
-                    sig_eval_rB(CA, Q, ca.x, ca.y, wa0, wa1, rA, BA);
-                    sig_eval_rB(CB, Q, cb.x, cb.y, wb0, wb1, rB, BB);
-                    accumulate(rA, BA);
-                    accumulate(rB, BB);
+                // All the image coordinates of the lane's share are requested up front (a trip of two evaluations takes
+                // a few hundred cycles, a load that misses the L2 a few thousand: fetching one trip ahead left every trip
+                // waiting), so the chunk pays ONE memory latency here, together with the point and its prior above.
+                constexpr int NT1 = (SIG_KMAXR + 1) / 2;                 // trips of two cameras
+                double2 uvl[2 * NT1];
+#pragma unroll
+                for (int tq = 0; tq < 2 * NT1; ++tq) {
+                    const int jj = jh + tq * jstep;
+                    uvl[tq] = double2{0, 0};
+                    if (jj < k) uvl[tq] = uvp[q0 + (int64_t)jj * gm];
+                }
+#pragma unroll
+                for (int tq = 0; tq < NT1; ++tq) {
+                    const int j = jh + 2 * tq * jstep;
+                    if (j < kk) {
+                        const bool vb = j + jstep < kk;
+                        const int j2 = vb ? j + jstep : j;
+                        const CamRec &CA = *reinterpret_cast<const CamRec *>(camw + sy.lc[wave][j] * CAMW);
+                        const CamRec &CB = *reinterpret_cast<const CamRec *>(camw + sy.lc[wave][j2] * CAMW);
+                        const double2 ca = uvl[2 * tq], cb = vb ? uvl[2 * tq + 1] : uvl[2 * tq];
+                        double wa0 = CA.w[0], wa1 = CA.w[1], wb0 = CB.w[0], wb1 = CB.w[1];
+                        if (sg_w) {                  // (observations with their own standard deviations: the rare case)
+                            const double2 cwa = wp[q0 + (int64_t)j * gm], cwb = wp[q0 + (int64_t)j2 * gm];
+                            wa0 = cwa.x; wa1 = cwa.y; wb0 = cwb.x; wb1 = cwb.y;
+                        }
+                        const double zb = vb ? 1.0 : 0.0;
+                        wb0 *= zb; wb1 *= zb;
+                        // (the coordinates a point does not estimate are masked once per point, after the sums)
+                        double rA[2], BA[2][3], rB[2], BB[2][3];
+                        sig_eval_rB(CA, Q, ca.x, ca.y, wa0, wa1, rA, BA);
+                        sig_eval_rB(CB, Q, cb.x, cb.y, wb0, wb1, rB, BB);
+                        accumulate(rA, BA);
+                        accumulate(rB, BB);
+                    }
                 }
             } else {
             double2 uv_n = double2{0, 0}, w_n = double2{0, 0};
@@ -364,8 +388,8 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
                 double jn[3];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const double pw = d.z_prw[zp + c];
-                    if (pw > 0) { V[dix[c]] += pw; g[c] += pw * (Q[c] - d.z_prv[zp + c]); }
+                    const double pw = prw[c];
+                    if (pw > 0) { V[dix[c]] += pw; g[c] += pw * (Q[c] - prv[c]); }
                     jn[c] = V[dix[c]];
                     if (writer) jn2p[3 * (int64_t)pt + c] = jn[c];
                     if ((est >> c) & 1u) V[dix[c]] += lambda; else V[dix[c]] = 1.0;
@@ -594,9 +618,10 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
             int tcm[RB];
 #pragma unroll
             for (int r2 = 0; r2 < RB; ++r2) tcm[r2] = sy.tmap[wave][min(16 * r2 + (lane & 15), 79)];
-            // Rows beyond the row of y and k-columns beyond the round were zero in the panel, so the
-            // accumulators are exactly 0.0 there: `v != 0` is the only test the blocks below the diagonal
-            // need; the diagonal blocks also drop their upper triangle and the (y, y) element.
+            // Rows beyond the row of y were zero in the panel, so the accumulators are exactly 0.0 there and their row
+            // map entries are those of an earlier chunk (or the zeros of the set-up): the blocks below the diagonal add
+            // every element, without a test -- a zero lands on some valid element of the tile.  The diagonal blocks drop
+            // their upper triangle and the (y, y) element.
 #pragma unroll
             for (int r1 = 0; r1 < RB; ++r1) {
                 if (r1 >= rbk) break;
@@ -604,14 +629,16 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
                 for (int e = 0; e < 4; ++e) {
                     const int lr = 16 * r1 + (lane >> 4) + 4 * e;
                     const bool yrow = lr == r6k;
-                    const int tr = sy.tmap[wave][min(lr, 79)];
-                    double *row = stile + (yrow ? SIG_STILE : tr * (tr + 1) / 2);
+                    double *row = stile + (yrow ? SIG_STILE : sy.toff[wave][min(lr, 79)]);
+                    if (!DBAT_ABLATE(d, 8)) {
 #pragma unroll
-                    for (int r2 = 0; r2 <= r1; ++r2) {
-                        double v = acc[r1 * (r1 + 1) / 2 + r2][e];
-                        bool take = v != 0.0 && !DBAT_ABLATE(d, 8);
-                        if (r2 == r1) { const int lcol = 16 * r2 + (lane & 15); take = take && lcol <= lr && lcol < r6k; }
-                        if (take) atomic_add_f64(row + tcm[r2], yrow ? -v : v);
+                        for (int r2 = 0; r2 < r1; ++r2) {
+                            const double v = acc[r1 * (r1 + 1) / 2 + r2][e];
+                            atomic_add_f64(row + tcm[r2], yrow ? -v : v);
+                        }
+                        const double v = acc[r1 * (r1 + 1) / 2 + r1][e];
+                        const int lcol = 16 * r1 + (lane & 15);
+                        if (lcol <= lr && lcol < r6k && v != 0.0) atomic_add_f64(row + tcm[r1], yrow ? -v : v);
                     }
                 }
             }
@@ -623,19 +650,35 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
     __syncthreads();
     lap(6);
     // ---------------------------------------------------------------- tile -> HBM
-#pragma unroll 4
-    for (int tc = wave; tc < nrows; tc += NW) {      // one column per wave: consecutive lanes, consecutive rows
-        const int64_t gcol = sy.grow[tc];
-        for (int tr = tc + lane; tr < nrows; tr += 64) {
-            const double v = stile[tr * (tr + 1) / 2 + tc];
-            if (v != 0.0 && !DBAT_ABLATE(d, 16)) atomic_add_f64(S + gcol * d.ldS + sy.grow[tr], -v);
+    // one column per wave and trip: consecutive lanes, consecutive rows (neighbouring addresses in S).  All the
+    // LDS reads of the wave's columns are issued first (the accumulators are dead: the registers are there), then the
+    // atomics -- one LDS latency per tile instead of one per column
+    {
+        constexpr int NCOLW = (128 + NW - 1) / NW;   // columns per wave at most
+        double v0[NCOLW], v1[NCOLW];
+#pragma unroll
+        for (int q = 0; q < NCOLW; ++q) {
+            const int tc = wave + q * NW, tr = tc + lane;
+            v0[q] = (tc < nrows && tr < nrows) ? stile[tr * (tr + 1) / 2 + tc] : 0.0;
+            v1[q] = (tc < nrows && tr + 64 < nrows) ? stile[(tr + 64) * (tr + 65) / 2 + tc] : 0.0;
+        }
+        if (!DBAT_ABLATE(d, 16)) {
+#pragma unroll
+            for (int q = 0; q < NCOLW; ++q) {
+                const int tc = wave + q * NW, tr = tc + lane;
+                if (tc < nrows) {
+                    const int64_t gcol = sy.grow[tc] * d.ldS;
+                    if (v0[q] != 0.0) atomic_add_f64(S + gcol + sy.grow[tr], -v0[q]);
+                    if (v1[q] != 0.0) atomic_add_f64(S + gcol + sy.grow[tr + 64], -v1[q]);
+                }
+            }
         }
     }
     for (int i = t; i < nrows; i += NT)
         if (vt[i] != 0.0) atomic_add_f64(g_red + sy.grow[i], vt[i]);
     double accr[1] = {rr};
     block_sum<1>(accr, sh);
-    if (t == 0) partial[blockIdx.x] = accr[0];
+    if (t == 0) partial[part_slot] = accr[0];
     pmin = pmin < 1e300 ? sqrt(pmin) : pmin; pmax = sqrt(pmax);
     for (int off = 32; off > 0; off >>= 1) {
         pmin = fmin(pmin, __shfl_down(pmin, off, 64));
@@ -650,6 +693,11 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
         for (int i = 0; i < 8; ++i) if (tp[i]) atomicAdd(&g_tile2_prof[i], (unsigned long long)tp[i]);
 }
 
+// PERSISTENT: the launch has one workgroup per CU (the tile's LDS allows no more), and every workgroup takes tiles
+// from a ticket counter, longest first, until none is left -- a tile is 150 us of work, and a workgroup that is
+// dispatched for one tile only pays the dispatch and the release of 150 KB of LDS every time (round 4: about 14 us
+// per tile between the end of one workgroup and the first instruction of the next).  Every workgroup draws exactly one
+// ticket beyond the last tile; the one that draws the very last ticket of the launch puts the counter back to zero.
 template <int MODEL, int RB, int NCX>
 __global__ __launch_bounds__(64 * sig_waves(RB, (NCX > 6))) void k_build_sig(DevProblem d, const double *__restrict__ z,
                                                    const CamRec *__restrict__ cams, double lambda, int scale,
@@ -660,20 +708,28 @@ __global__ __launch_bounds__(64 * sig_waves(RB, (NCX > 6))) void k_build_sig(Dev
                                                    const int32_t *__restrict__ sg_chunk,
                                                    const int32_t *__restrict__ sg_tile_chunk0,
                                                    const uint8_t *__restrict__ sg_lc, const double *__restrict__ sg_uv,
-                                                   const double *__restrict__ sg_w) {
-    const int tile = d.tile_order[blockIdx.x];
-    if constexpr (NCX > 6) {
-        const int ios = d.tile_io_simple ? d.tile_io_simple[tile] : 0;       // IO blocks of the tile, if it qualifies
-        if (ios == 1) {
-            build_sig_tile<MODEL, RB, NCX, 1>(d, tile, z, cams, lambda, scale, S, g_red, Vinv, gp, jn2p, partial, pivmm, sg_chunk, sg_tile_chunk0, sg_lc, sg_uv, sg_w);
+                                                   const double *__restrict__ sg_w, unsigned *__restrict__ tile_ctr) {
+    __shared__ unsigned s_ticket;
+    for (;;) {
+        if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(tile_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned ti = s_ticket;
+        if (ti >= (unsigned)d.ntiles) {
+            if (threadIdx.x == 0 && ti == (unsigned)d.ntiles + gridDim.x - 1)
+                __hip_atomic_store(tile_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
-        if (ios == 2) {
-            build_sig_tile<MODEL, RB, NCX, 2>(d, tile, z, cams, lambda, scale, S, g_red, Vinv, gp, jn2p, partial, pivmm, sg_chunk, sg_tile_chunk0, sg_lc, sg_uv, sg_w);
-            return;
-        }
+        const int tile = d.tile_order[ti];
+        int ios = 0;
+        if constexpr (NCX > 6) ios = d.tile_io_simple ? d.tile_io_simple[tile] : 0;       // IO blocks of the tile, if it qualifies
+        if (NCX > 6 && ios == 1)
+            build_sig_tile<MODEL, RB, NCX, (NCX > 6 ? 1 : 0)>(d, tile, (int)ti, z, cams, lambda, scale, S, g_red, Vinv, gp, jn2p, partial, pivmm, sg_chunk, sg_tile_chunk0, sg_lc, sg_uv, sg_w);
+        else if (NCX > 6 && ios == 2)
+            build_sig_tile<MODEL, RB, NCX, (NCX > 6 ? 2 : 0)>(d, tile, (int)ti, z, cams, lambda, scale, S, g_red, Vinv, gp, jn2p, partial, pivmm, sg_chunk, sg_tile_chunk0, sg_lc, sg_uv, sg_w);
+        else
+            build_sig_tile<MODEL, RB, NCX, 0>(d, tile, (int)ti, z, cams, lambda, scale, S, g_red, Vinv, gp, jn2p, partial, pivmm, sg_chunk, sg_tile_chunk0, sg_lc, sg_uv, sg_w);
+        __syncthreads();                             // the tile's LDS is free again (and s_ticket may be redrawn)
     }
-    build_sig_tile<MODEL, RB, NCX, 0>(d, tile, z, cams, lambda, scale, S, g_red, Vinv, gp, jn2p, partial, pivmm, sg_chunk, sg_tile_chunk0, sg_lc, sg_uv, sg_w);
 }
 
 // k_backsub_sig: back-substitution dp = -V^-1 (g_p + W' dc) and ||J p||^2 over the image rows for the

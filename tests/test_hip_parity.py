@@ -9,6 +9,7 @@ Tolerances (north_star: parameter updates and converged parameters within
   converged x                                        : 1e-8 relative (bar 1e-6)
 """
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -1295,11 +1296,10 @@ def test_selfcal_io_rows_summed_per_point(hip, rays, groups, monkeypatch):
 
 
 @pytest.mark.parametrize('name,selfcal', [('small', False), ('small', True), ('C1', False)])
-def test_cholesky_split_sums_and_orders(hip, name, selfcal, monkeypatch):
+def test_cholesky_split_sums(hip, name, selfcal, monkeypatch):
     """The dataflow Cholesky cuts long left-looking sums into helper tasks (partial sums in scratch
-    tiles, chol_df.hpp DfJob) and picks one of several topological task orders.  Forced here on small
-    systems -- every sum of more than two products split into pieces of two, each candidate order --
-    the step must agree with the default schedule to rounding."""
+    tiles, chol_df.hpp DfJob).  Forced here on small systems -- every sum of more than two products
+    split into pieces of two -- the step must agree with the default schedule to rounding."""
     from dbat_amd import synth
     s, _ = synth.make_scene(name, selfcal=selfcal) if selfcal else synth.make_scene(name)
     def step():
@@ -1313,9 +1313,51 @@ def test_cholesky_split_sums_and_orders(hip, name, selfcal, monkeypatch):
     ref = step()
     monkeypatch.setenv('DBAT_HIP_DF_SPLIT', '2')
     monkeypatch.setenv('DBAT_HIP_DF_CHUNK', '2')
-    for order in ('0', '4', '6', '7'):
-        monkeypatch.setenv('DBAT_HIP_DF_ORDER', order)
-        assert relerr(step(), ref) < 1e-9, order
+    assert relerr(step(), ref) < 1e-9
+
+
+def test_cholesky_task_orders_in_the_measurement_build(hip):
+    """Every candidate order of the factorisation's task list is a topological order and must give the same
+    step.  DBAT_HIP_DF_ORDER is a measurement switch (csrc/env.hpp): the product library refuses it, so the
+    orders are forced in a child process that loads libdbat_hip_prof.so (the same sources, -DDBAT_HIP_PROFILING)."""
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prof = os.path.join(ROOT, 'dbat_amd', 'libdbat_hip_prof.so')
+    if not os.path.exists(prof):
+        pytest.skip('libdbat_hip_prof.so not built (make -C dbat_amd/csrc prof)')
+    code = (
+        "import os, sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from dbat_amd import _hip, synth\n"
+        "s, _ = synth.make_scene('small', selfcal=True)\n"
+        "def step():\n"
+        "    h = _hip.Handle(s)\n"
+        "    try:\n"
+        "        p, st = h.linearize_solve(h.serialize(), 0.0, True)\n"
+        "        assert not st['singular']\n"
+        "        return p\n"
+        "    finally:\n"
+        "        h.close()\n"
+        "ref = step()\n"
+        "os.environ['DBAT_HIP_DF_SPLIT'] = '2'; os.environ['DBAT_HIP_DF_CHUNK'] = '2'\n"
+        "for order in ('0', '4', '6', '7'):\n"
+        "    os.environ['DBAT_HIP_DF_ORDER'] = order\n"
+        "    e = np.linalg.norm(step() - ref) / np.linalg.norm(ref)\n"
+        "    assert e < 1e-9, (order, e)\n"
+        "print('ORDERS_OK')\n" % ROOT)
+    env = dict(os.environ, DBAT_AMD_LIB='prof')
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'ORDERS_OK' in r.stdout, r.stderr[-2000:]
+    # ... and the product library refuses the switch
+    os.environ['DBAT_HIP_DF_ORDER'] = '4'
+    try:
+        from dbat_amd import synth
+        with pytest.raises(hip.DbatHipError) as e:
+            hip.Handle(synth.make_scene('tiny')[0])
+        assert 'measurement switch' in str(e.value)
+    finally:
+        del os.environ['DBAT_HIP_DF_ORDER']
 
 
 @pytest.mark.parametrize('rays,selfcal', [(12, False), (13, False), (11, True)])
