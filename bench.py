@@ -9,6 +9,10 @@ in HBM before the timed region.
 
     python bench.py --gpus N --steps K --warmup W [--config C3]
 
+--config roma | roma-selfcal | camcal: the reference's own demo projects (bench/real_scenes.py, fixtures under
+tests/golden) -- the scenes DBAT's only published timings are quoted on; the line then also carries the
+shipped dbat_hip_solve with the demo's damping next to the published MATLAB figure.
+
 N > 1: one rank per GPU.  Under torch.distributed.run (WORLD_SIZE set) this
 process is one of the ranks; started plainly, it launches
 `python -m torch.distributed.run --nproc-per-node N` itself before anything
@@ -43,7 +47,7 @@ def cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(s_main, name_main, budget_s=25.0):
+def cpu_baseline(s_main, name_main, budget_s=25.0, others=('C1', 'C2')):
     """The reference algorithm as written (explicit sparse J, J'*J, sparse
     Cholesky of the FULL normal matrix, levenberg_marquardt.m:81-82,119) in
     C++/OpenMP on all host cores -- bench/cpu_ref.cpp, checked against the
@@ -58,17 +62,20 @@ def cpu_baseline(s_main, name_main, budget_s=25.0):
         try:
             x = c.serialize()
             p, st = c.lm_step(x, -1e-10)           # untimed: first touch of every buffer
-            n_it, t_all, ms = 0, 0.0, {}
+            n_it, t_all, ms, t_it = 0, 0.0, {}, []
             while n_it < max_it and (n_it == 0 or t_all < budget):
                 t0 = time.perf_counter()
                 p, st = c.lm_step(x, -1e-10)
-                t_all += time.perf_counter() - t0
+                t_it.append(time.perf_counter() - t0)
+                t_all += t_it[-1]
                 for k, v in st['ms'].items():
                     ms[k] = ms.get(k, 0.0) + v
                 if st['code'] == 0 and st['f_trial'] < st['f']:
                     x = x + p
                 n_it += 1
+            t_it.sort()
             return {'it_per_s': n_it / t_all, 'iterations': n_it, 'threads': c.threads, 'n_params': c.n,
+                    'it_per_s_slowest_median_fastest': [1.0 / t_it[-1], 1.0 / t_it[len(t_it) // 2], 1.0 / t_it[0]],
                     'setup_s': c.setup_ms * 1e-3, 'nnz': c.nnz,
                     'ms_per_phase': {k: v / n_it for k, v in ms.items()}}
         finally:
@@ -76,7 +83,7 @@ def cpu_baseline(s_main, name_main, budget_s=25.0):
 
     out = {}
     t_start = time.perf_counter()
-    for name in ('C1', 'C2'):
+    for name in others:
         if name == name_main:
             continue
         out[name] = run(synth.make_scene(name)[0], 20, 4.0)
@@ -91,6 +98,7 @@ def cpu_baseline(s_main, name_main, budget_s=25.0):
                   'product, supernodal Cholesky of the full %d x %d normal matrix, trial residual) on the '
                   'bench scene %s itself (%d obs), %d threads'
                   % (main['iterations'], main['n_params'], main['n_params'], name_main, no, main['threads']),
+        'value_slowest_median_fastest': main['it_per_s_slowest_median_fastest'],
         'obs_per_s': main['it_per_s'] * no, 'configs': out,
         'reference_published': 'DBAT MATLAB R2020a (other machine, core count unknown): roma 1.04 s/it at 181k rows, '
                                'St-Pierre 5.9 s/it at 394k rows (SURVEY 6)',
@@ -158,7 +166,14 @@ def main():
     from dbat_amd import _hip, synth
 
     t_gen = time.perf_counter()
-    s, _ = synth.make_scene(args.config)
+    published = None
+    real = args.config in ('roma', 'roma-selfcal', 'camcal')
+    if real:
+        sys.path.insert(0, os.path.join(ROOT, 'bench'))
+        import real_scenes
+        s, published = real_scenes.make(args.config)       # (initial values on the device: needs the GPU)
+    else:
+        s, _ = synth.make_scene(args.config)
     t_gen = time.perf_counter() - t_gen
     nc, npnt, no = s.EO.val.shape[1], s.OP.val.shape[1], s.IP.val.shape[1]
     t_plan = time.perf_counter()
@@ -221,6 +236,27 @@ def main():
                  'stage_s': dict(zip(('linearise', 'factor_solve', 'backsub', 'residual', 'other'), [float(v) for v in res.stage_s])),
                  'ms_per_linearization': res.time_s / max(res.n_linearizations, 1) * 1e3}
 
+    # the reference's demo run: the shipped loop with the demo's damping from the demo's start values
+    solve_ref = None
+    if real and not emu and not args.no_solve:
+        opt = _hip.default_options(published['damping'])
+        opt.store_trace = 0
+        best = None
+        for _ in range(3):                                   # (a 10 ms solve: the first run pays the allocations of its loop)
+            barrier()
+            xs, res, rr, damp, aux, T = h.solve(x0, opt)
+            if best is None or res.time_s < best.time_s:
+                best = res
+        res = best
+        solve_ref = {'damping': published['damping'], 'code': int(res.code), 'iterations': int(res.iters), 'time_s': float(res.time_s),
+                     'sigma0': float(res.sigma0), 'it_per_s': res.iters / res.time_s if res.time_s > 0 else None,
+                     'linearizations': int(res.n_linearizations), 'residual_evals': int(res.n_residual_evals),
+                     'stage_s': dict(zip(('linearise', 'factor_solve', 'backsub', 'residual', 'other'), [float(v) for v in res.stage_s])),
+                     'published': published,
+                     'published_it_per_s': published['iterations'] / published['bundle_s'],
+                     'speedup_vs_published_matlab': (published['bundle_s'] / published['iterations']) / (res.time_s / max(res.iters, 1)),
+                     'note': 'published: DBAT MATLAB R2020a on another machine, CPU and core count not recorded (SURVEY 6): context, not vs_baseline'}
+
     if rank == 0:
         NS = info['NS']
         # Algorithmic work per launch; obs/points are this
@@ -254,6 +290,13 @@ def main():
             roof = {'kernel': kname, 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS,
                     'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'traffic': traffic}
         roof['traffic_source'] = traffic_src
+        # what the matrix pipe really executed: the kernel uses the symmetry of Z Z' (lower triangle by 16 x 16 blocks)
+        ex_flops = 2048.0 * info['tile_kernel_mfma']
+        roof['executed_flops'] = ex_flops
+        roof['executed_TFLOPs'] = ex_flops / t_build / 1e12 if t_build > 0 else None
+        roof['executed_frac'] = ex_flops / t_build / 1e12 / FP64_PEAK_TFLOPS if t_build > 0 else None
+        roof['note'] = ('achieved / frac: ALGORITHMIC flops sum_p(108 k + 216 k^2) (the full product Y W\', SURVEY 8(d)) per launch; '
+                        'executed_*: the v_mfma_f64_16x16x4_f64 instructions the kernel issues (x 2048) -- comparable with SQ_VALU_MFMA_BUSY')
         roof['algorithmic_flops'] = flops_schur
         roof['algorithmic_bytes'] = bytes_build
         roof['hbm_GBs_on_algorithmic_bytes'] = bytes_build / t_build / 1e9
@@ -284,7 +327,13 @@ def main():
         flops_iter = float(np.sum(108.0 * kp + 216.0 * kp * kp)) + NS ** 3 / 3.0
         t_lb = max(bytes_iter / (HBM_PEAK_GBS * 1e9), flops_iter / (FP64_PEAK_TFLOPS * 1e12))
         te = np.sort(np.asarray(t_each)) * 1e3
+        # ... and against the work that is really executed (sparse factorisation, symmetric Schur products)
+        flops_exec = ex_flops + flops_chol
+        bytes_exec = 40.0 * no + 48.0 * npnt + 96.0 * nc + 16.0 * cs['tile_tasks'] * 64 * 64
+        t_lb_exec = max(bytes_exec / (HBM_PEAK_GBS * 1e9), flops_exec / (FP64_PEAK_TFLOPS * 1e12))
         roof_step = {'bytes_iter': bytes_iter, 'flops_iter': flops_iter, 'lower_bound_ms': t_lb * 1e3,
+                     'executed_flops_iter': flops_exec, 'executed_bytes_iter': bytes_exec,
+                     'executed_lower_bound_ms': t_lb_exec * 1e3, 'executed_frac': t_lb_exec / (dt / args.steps),
                      'frac': t_lb / (dt / args.steps), 'bound': 'mfma' if flops_iter / (FP64_PEAK_TFLOPS * 1e12) > bytes_iter / (HBM_PEAK_GBS * 1e9) else 'hbm',
                      'note': 'SURVEY 8(d): dense NS^2 S traffic and dense NS^3/3 Cholesky flops; the sparse factorisation does '
                              '%.3g flops (roofline_factorisation), so a fraction above 1 is possible and means structure was used' % flops_chol}
@@ -303,7 +352,7 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'ms_per_step_min_median_max': [float(te[0]), float(te[len(te) // 2]), float(te[-1])],
             'higher_is_better': True, 'scaling': 'strong',
-            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'f64', 'data': ('the reference\'s demo project (fixtures under tests/golden)' if real else 'synthetic'),
             'config': {'workload': '%s: %d cams / %d pts / %d obs, %s, LM step (J\'J build + Schur '
                                    'solve + back-substitution + trial residual)'
                                    % (args.config, nc, npnt, no,
@@ -314,11 +363,14 @@ def main():
             'ms_build_schur': ms[0], 'ms_factor_solve': ms[1], 'ms_backsub': ms[2],
             'ms_trial_residual': ms[3], 'kernel_ms': k_ms,
             'roofline': roof, 'roofline_factorisation': roof_chol, 'roofline_step': roof_step, 'hbm_kernels': hbm, 'multi_gpu': multi,
-            'solve_lm': solve, 'solve_it_s': solve['it_per_s'] if solve else None,
+            'solve_lm': solve, 'solve_it_s': solve['it_per_s'] if solve else None, 'solve_reference_demo': solve_ref,
             'host_s': {'scene_generation': t_gen, 'plan_and_upload': t_plan},
         }
         if world == 1 and not args.no_cpu_baseline and not emu:
-            out['cpu_baseline'] = cpu_baseline(s, args.config)
+            try:
+                out['cpu_baseline'] = cpu_baseline(s, args.config, others=() if real else ('C1', 'C2'))
+            except ValueError as e:                          # (a scene the C++ port does not model)
+                out['cpu_baseline'] = {'value': None, 'kind': 'port', 'note': str(e)}
         else:
             out['cpu_baseline'] = None
     # RCCL writes a version banner through C stdio, which is block-buffered when stdout is a

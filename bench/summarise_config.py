@@ -18,7 +18,10 @@ src, prefix, cfg, out = sys.argv[1:5]
 title = sys.argv[5] if len(sys.argv) > 5 else ''
 WORK = {'C1': '100 cams / 10 000 pts / 100 000 obs, fixed IO', 'C2': '1000 cams / 100 000 pts / 1 000 000 obs, self-calibrating',
         'C3': '1000 cams / 1 000 000 pts / 10 000 000 obs, fixed IO',
-        'C4': '5000 cams / 5 000 000 pts / 50 000 000 obs, 4 independent self-calibrated IO blocks'}
+        'C4': '5000 cams / 5 000 000 pts / 50 000 000 obs, 4 independent self-calibrated IO blocks',
+        'roma': "DBAT's romabundledemo: 60 images / 26 321 pts / 90 561 obs, fixed IO (irregular visibility: tile kernels)",
+        'roma-selfcal': "DBAT's romabundledemo_selfcal: 60 images / 26 321 pts / 90 561 obs, 9 IO unknowns",
+        'camcal': "DBAT's camcaldemo: 21 images / 100 pts / 2 074 obs, 9 IO unknowns"}
 
 
 def short(name):

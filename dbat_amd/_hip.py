@@ -17,6 +17,8 @@ LIB_PATH = os.path.join(_HERE, 'libdbat_hip.so')
 # -DDBAT_HIP_PROFILING (make -C dbat_amd/csrc prof) -- the only build that reads DBAT_HIP_ABLATE, _DF_TRACE, ...
 if os.environ.get('DBAT_AMD_LIB') == 'prof':
     LIB_PATH = os.path.join(_HERE, 'libdbat_hip_prof.so')
+elif os.environ.get('DBAT_AMD_LIB', '').endswith('.so'):          # (a development build to compare with)
+    LIB_PATH = os.environ['DBAT_AMD_LIB']
 
 ABI_VERSION = 2
 DAMP = {'none': 0, 'gm': 0, 'gna': 1, 'lm': 2, 'lmp': 3}
@@ -118,6 +120,7 @@ SYMBOLS = {
     'dbat_hip_posterior_cov': (C.c_int, [_H, _dp, C.c_double, _dp, _dp, _dp, _dp]),
 }
 DEBUG_SYMBOLS = {
+    'dbat_hip_debug_plan_digest': (C.c_int, [C.POINTER(Problem), C.POINTER(C.c_uint64), C.c_int32, C.c_char_p, C.c_int32]),
     'dbat_hip_debug_model_eval_host': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, C.c_double,
                                                  _dp, _dp, _dp, _dp, _dp, _dp]),
 }
@@ -437,7 +440,7 @@ class Handle:
         check(self.lib.dbat_hip_info(self.h, a))
         keys = ('NS', 'n_batches', 'max_k', 'n_obs_shard', 'n_pts_shard', 'BT', 'ncolmax', 'n_tiles',
                 'domain_sharding', 'reduced_doubles_per_factorisation', 'vector_doubles_per_linearisation',
-                'n_top_cams', 'factor_tile_rows', 'tasks_domain', 'tasks_top')
+                'n_top_cams', 'factor_tile_rows', 'tasks_domain', 'tasks_top', 'tile_kernel_mfma')
         return dict(zip(keys, [int(v) for v in a]))
 
 
@@ -501,6 +504,18 @@ def plan_layout_stats(s, shard_rank=0, shard_count=1):
     return dict(n_tiles=v[0], n_batches=v[1], n_batches_tiled=v[2], n_groups=v[3], n_group_points=v[4], n_chunks=v[5],
                 chunks_by_length={'1-8': v[6], '9-16': v[7], '17-32': v[8], '33-64': v[9]}, chunks_multi_round=v[10],
                 k_max=v[11], rows_max=v[12], build_sig=bool(v[13]), backsub_sig=bool(v[14]))
+
+
+def plan_digest(s, shard_rank=0, shard_count=1):
+    """Host-only (debug): {field: hash} of the whole host plan of this shard -- equal digests mean identical plans."""
+    lib = load()
+    p, keep = problem_from_struct(s, 0, shard_rank, shard_count)
+    out = (C.c_uint64 * 96)()
+    names = C.create_string_buffer(4096)
+    n = lib.dbat_hip_debug_plan_digest(C.byref(p), out, 96, names, 4096)
+    if n < 0:
+        check(n)
+    return dict(zip(names.value.decode().split(','), [int(v) for v in out[:n]]))
 
 
 def plan_domain_map(s, shard_count):

@@ -67,7 +67,8 @@ struct DevBuf {
         n = count;
         if (count) HIPCHK(hipMalloc((void **)&p, count * sizeof(T)));
     }
-    void upload(const std::vector<T> &v) {
+    template <class A>
+    void upload(const std::vector<T, A> &v) {
         alloc(v.size());
         if (!v.empty()) HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     }
@@ -197,6 +198,14 @@ struct Core {
     }
 
     void init(const dbat_hip_problem &pb) {
+        const bool init_clock = env_int("DBAT_HIP_PLAN_STATS", 0) >= 2;
+        auto t_init = std::chrono::steady_clock::now();
+        auto lapi = [&](const char *what) {
+            if (!init_clock) return;
+            const auto now = std::chrono::steady_clock::now();
+            fprintf(stderr, "[create clock] %-60s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_init).count());
+            t_init = now;
+        };
         device = pb.device;
         HIPCHK(hipSetDevice(pb.device));
         {
@@ -228,7 +237,7 @@ struct Core {
         x2z.upload(P.x2z);
         o_lc.upload(P.o_lc); o_pidx.upload(P.o_pidx); tile_batch.upload(P.tile_batch); tile_cam_start.upload(P.tile_cam_start); tile_cams.upload(P.tile_cams);
         tile_io_start.upload(P.tile_io_start); tile_iocols.upload(P.tile_iocols); tile_cam_io.upload(P.tile_cam_io);
-        tile_ncx = P.shared_eo ? MAXCOL : (P.ncolmax <= 6 ? 6 : (P.ncolmax <= 14 ? 14 : MAXCOL));
+        tile_ncx = P.shared_eo ? MAXCOL : (P.ncolmax <= 6 ? 6 : (P.ncolmax <= 14 ? 14 : (P.ncolmax <= 15 ? 15 : MAXCOL)));
         ntiles = (P.CMAX && P.nb_tiled > 0) ? (int64_t)P.tile_batch.size() - 1 : 0;
         d.nc = P.nc; d.np = P.np; d.nIOrows = P.nIOrows; d.nK = P.nK; d.nP = P.nP; d.nIOu = P.nIOu;
         d.ncolmax = P.ncolmax; d.BT = P.BT; d.NS = P.NS; d.NZ = P.NZ; d.nobs = nobs; d.nb = nb;
@@ -262,6 +271,7 @@ struct Core {
             if (!P.uniform_w) sg_w.upload(P.sg_w);
             sig_rb = P.sg_rows_max <= 64 ? 4 : 5;
         }
+        lapi("stream, events, uploads of the plan");
         cams.alloc(P.nc); cams_f.alloc(P.nc);
         z.alloc(P.NZ); zt.alloc(P.NZ); dz.alloc(P.NZ); zlin.alloc(P.NZ); vtmp.alloc(P.NZ); vtmp2.alloc(P.NZ);
         xbuf.alloc(std::max<int64_t>(P.n, 1));
@@ -309,6 +319,7 @@ struct Core {
             }
             linv.alloc(std::max(dfchol_ip.linv_doubles(), use_perm ? dfchol.linv_doubles() : (size_t)0));
         }
+        lapi("envelope, schedules of the factorisation");
         jn2c.alloc(P.NS); dscale.alloc(P.NS); rhs.alloc(P.NS);
         Vinv.alloc((size_t)6 * P.np); gp.alloc((size_t)3 * P.np); jn2p.alloc((size_t)3 * P.np);
         HIPCHK(hipMemset(Vinv.p, 0, (size_t)6 * P.np * 8));
@@ -329,7 +340,7 @@ struct Core {
         // wave-specialised tile kernel: 256-observation batches, 16-point chunks, 2 panels
         tile2_pc = TILE2_PC;
         lds_tile2 = ((size_t)TILE2_NBUF * 3 * tile2_pc * TILE_LD + (size_t)256 * 9 + (size_t)128 * 15 + TILE_LD) * sizeof(double);
-        use_tile2 = P.BT == 256 && P.ncolmax <= 14;      // (the plan does not tile anything else)
+        use_tile2 = P.BT == 256 && P.ncolmax <= 15;      // (the plan does not tile anything else)
         partial.alloc((size_t)4 * std::max<int64_t>(std::max<int64_t>(std::max<int64_t>(nb + ntiles + ngiant + (int64_t)P.sg_chunk.size() / 8, n_cm_chunks_all), 2048), 1));
         set_lds_limits();
         HIPCHK(hipMemcpy(z.p, P.z0.data(), P.NZ * 8, hipMemcpyHostToDevice));
@@ -337,6 +348,7 @@ struct Core {
         HIPCHK(hipMemset(zt.p, 0, P.NZ * 8));          // (entries of other ranks' domains are never written)
         precompute_image_side();
         HIPCHK(hipDeviceSynchronize());
+        lapi("work arrays, image side");
     }
 
     // Fixed interior orientation: the image side of every observation once per handle (kernels.hpp k_uv_to_rhs).
@@ -367,6 +379,8 @@ struct Core {
             if (P.with_io) {
                 SET_LDS((k_build_tile2<2, 14, TILE2_PC, TILE2_NBUF>), lds_tile2); SET_LDS((k_build_tile2<3, 14, TILE2_PC, TILE2_NBUF>), lds_tile2);
                 SET_LDS((k_build_tile2<4, 14, TILE2_PC, TILE2_NBUF>), lds_tile2); SET_LDS((k_build_tile2<5, 14, TILE2_PC, TILE2_NBUF>), lds_tile2);
+                SET_LDS((k_build_tile2<2, 15, TILE2_PC, TILE2_NBUF>), lds_tile2); SET_LDS((k_build_tile2<3, 15, TILE2_PC, TILE2_NBUF>), lds_tile2);
+                SET_LDS((k_build_tile2<4, 15, TILE2_PC, TILE2_NBUF>), lds_tile2); SET_LDS((k_build_tile2<5, 15, TILE2_PC, TILE2_NBUF>), lds_tile2);
             }
         }
         lds_tile3 = ((size_t)TILE3_NBUF * 3 * TILE3_PC * TILE_LD + (size_t)256 * 9 + (size_t)256 * 9 + TILE_LD) * sizeof(double);
@@ -395,6 +409,32 @@ struct Core {
         SET_LDS((k_build<2, true>), lds_build); SET_LDS((k_build<3, true>), lds_build);
         SET_LDS((k_build<4, true>), lds_build); SET_LDS((k_build<5, true>), lds_build);
 #undef SET_LDS
+    }
+
+    // v_mfma_f64_16x16x4_f64 instructions (2048 flops each) that one launch of the tile kernel executes: the symmetric
+    // products it really runs, for the roofline entry beside the algorithmic (full product) count
+    int64_t tile_kernel_mfma() const {
+        if (!(ntiles > 0 && P.nb_tiled > 0)) return 0;
+        int64_t n = 0;
+        if (use_sig) {
+            for (int64_t t = 0; t < ntiles; ++t) {
+                const int nio = tile_ncx > 6 ? P.tile_io_start[t + 1] - P.tile_io_start[t] : 0;
+                for (int64_t q = P.sg_tile_chunk0[t]; q < P.sg_tile_chunk0[t + 1]; ++q) {
+                    const int npts = P.sg_chunk[8 * q + 1], k = P.sg_chunk[8 * q + 2];
+                    const int ppr = std::min(SIG_PPR, 64 / std::max(k, 1)), rbk = (6 * k + nio + 1 + 15) >> 4;
+                    for (int p0 = 0; p0 < npts; p0 += ppr) n += (int64_t)((3 * std::min(ppr, npts - p0) + 3) >> 2) * (rbk * (rbk + 1) / 2);
+                }
+            }
+            return n;
+        }
+        // dense 128-row tiles: 36 lower-triangle blocks per k-step, chunks of PC points of every batch
+        const int pc = (use_tile3 && tile_ncx == 6) ? TILE3_PC : tile2_pc;
+        for (int64_t b = 0; b < P.nb_tiled; ++b) {
+            const int64_t o1 = P.batch_start[b + 1];
+            const int npts = o1 > P.batch_start[b] ? (int)P.o_pidx[o1 - 1] + 1 : 0;
+            for (int p0 = 0; p0 < npts; p0 += pc) n += (int64_t)((3 * std::min(pc, npts - p0) + 3) >> 2) * 36;
+        }
+        return n;
     }
 
     // ---- helpers
@@ -578,10 +618,10 @@ struct Core {
             npart = ntiles;
 #define L_TILE2(M, NCXV) LAUNCHK((k_build_tile2<M, NCXV, TILE2_PC, TILE2_NBUF>), dim3((unsigned)ntiles), dim3(512), lds_tile2, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, partial.p, pivmm.p)
 #define L_CAMN(M, NCXV) LAUNCHK((k_cam_normal<M, NCXV>), dim3((unsigned)n_cm_chunks), dim3(256), 0, stream, d, zz, cams.p, cm_pt.p, cm_uv.p, P.uniform_w ? (const double *)nullptr : cm_w.p, cm_chunk_cam.p, cm_chunk_start.p, S, g_c, g_red, diagU)
-            if (use_tile2 && tile_ncx <= 14 && n_cm_chunks > 0) {
+            if (use_tile2 && tile_ncx <= 15 && n_cm_chunks > 0) {
                 // camera side of the tiled observations: J_c'J_c, J_c'r, squared column norms
 #define L_CAMN6(M, dummy) LAUNCHK((k_cam_normal6<M>), dim3((unsigned)n_cm_chunks), dim3(256), 0, stream, d, zz, cams.p, cm_pt.p, cm_uv.p, P.uniform_w ? (const double *)nullptr : cm_w.p, cm_chunk_cam.p, cm_chunk_start.p, S, g_c, g_red, diagU)
-                if (tile_ncx == 6) { DISPATCH_MODEL(L_CAMN6, 0) } else { DISPATCH_MODEL(L_CAMN, 14) }
+                if (tile_ncx == 6) { DISPATCH_MODEL(L_CAMN6, 0) } else if (tile_ncx == 14) { DISPATCH_MODEL(L_CAMN, 14) } else { DISPATCH_MODEL(L_CAMN, 15) }
 #undef L_CAMN6
             }
 #undef L_CAMN
@@ -595,6 +635,7 @@ struct Core {
             else if (use_sig) { DISPATCH_MODEL(L_SIG, 5 + 8 * 14) }
             else if (use_tile3 && tile_ncx == 6) { DISPATCH_MODEL(L_TILE3, 0) }
             else if (use_tile2 && tile_ncx == 14) { DISPATCH_MODEL(L_TILE2, 14) }
+            else if (use_tile2 && tile_ncx == 15) { DISPATCH_MODEL(L_TILE2, 15) }
             else throw DeviceError{"internal: tiles without a tile kernel"};
             mark(1);
 #undef L_TILE2
@@ -757,7 +798,7 @@ struct Core {
         }
         if (nb > b_first) {
 #define L_BACK(M, NCXV) LAUNCHK((k_backsub<M, NCXV>), dim3((unsigned)(nb - b_first)), dim3(P.BT), lds_back, stream, d, zlin.p, cams.p, Vinv.p, gp.p, dz.p, partial.p, (int)b_first)
-            if (tile_ncx == 6) { DISPATCH_MODEL(L_BACK, 6) } else if (tile_ncx == 14) { DISPATCH_MODEL(L_BACK, 14) } else { DISPATCH_MODEL(L_BACK, MAXCOL) }
+            if (tile_ncx == 6) { DISPATCH_MODEL(L_BACK, 6) } else if (tile_ncx == 14) { DISPATCH_MODEL(L_BACK, 14) } else if (tile_ncx == 15) { DISPATCH_MODEL(L_BACK, 15) } else { DISPATCH_MODEL(L_BACK, MAXCOL) }
 #undef L_BACK
         }
         if (ngiant > 0) {
@@ -891,7 +932,7 @@ struct Core {
     void jtimes(const double *v, double &JvJv, double &rJv, double &vv) {
         if (!cams_at_lin) { prep_cams(zlin.p); cams_at_lin = true; }
 #define L_JT(M, NCXV) LAUNCHK((k_jtimes<M, NCXV>), dim3(grid_obs), dim3(256), 0, stream, d, zlin.p, cams.p, v, partial.p)
-        if (tile_ncx == 6) { DISPATCH_MODEL(L_JT, 6) } else if (tile_ncx == 14) { DISPATCH_MODEL(L_JT, 14) } else { DISPATCH_MODEL(L_JT, MAXCOL) }
+        if (tile_ncx == 6) { DISPATCH_MODEL(L_JT, 6) } else if (tile_ncx == 14) { DISPATCH_MODEL(L_JT, 14) } else if (tile_ncx == 15) { DISPATCH_MODEL(L_JT, 15) } else { DISPATCH_MODEL(L_JT, MAXCOL) }
 #undef L_JT
         LAUNCHK(k_prior_jv, dim3(grid_zs), dim3(1024), 0, stream, d, zlin.p, v, g_c, gp.p, gpart.p, gctr.p + 4,
                 (const double *)partial.p, (int64_t)grid_obs, (const double *)nullptr, pivmm.p, (const int *)info.p, scal.p, (double *)nullptr, 0ull);
@@ -1284,6 +1325,8 @@ int dbat_hip_create(const dbat_hip_problem *prob, dbat_hip_handle **out) {
     }
     auto h = std::make_unique<dbat_hip_handle>();
     h->core = std::make_unique<Core>();
+    const bool create_clock = env_int("DBAT_HIP_PLAN_STATS", 0) >= 2;
+    const auto t_create0 = std::chrono::steady_clock::now();
     if (!build_plan(*prob, h->core->P, true)) {
         g_err = h->core->P.err;
         return g_err.find("not supported") != std::string::npos || g_err.find("more observations") != std::string::npos
@@ -1292,7 +1335,12 @@ int dbat_hip_create(const dbat_hip_problem *prob, dbat_hip_handle **out) {
     {
         if (prob->device < 0 || prob->device >= ndev) { g_err = "bad device index"; return DBAT_HIP_EINVAL; }
         DeviceGuard dev_guard(prob->device);
+        const auto t_create1 = std::chrono::steady_clock::now();
         h->core->init(*prob);
+        if (create_clock)
+            fprintf(stderr, "[create clock] host plan %.1f ms, device set-up (uploads, schedule of the factorisation, image side) %.1f ms\n",
+                    std::chrono::duration<double, std::milli>(t_create1 - t_create0).count(),
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create1).count());
     }
     *out = h.release();
     return DBAT_HIP_OK;
@@ -1815,7 +1863,7 @@ int dbat_hip_build_kernel_name(const dbat_hip_handle *h, char *buf, int32_t buf_
     if (c.ntiles > 0 && c.P.nb_tiled > 0) {
         if (c.use_sig) nm = "k_build_sig";
         else if (c.use_tile3 && c.tile_ncx == 6) nm = "k_build_tile3";
-        else if (c.use_tile2 && c.tile_ncx <= 14) nm = "k_build_tile2";
+        else if (c.use_tile2 && c.tile_ncx <= 15) nm = "k_build_tile2";
         else nm = "k_build";
     }
     snprintf(buf, (size_t)buf_len, "%s", nm);
@@ -1832,8 +1880,49 @@ int dbat_hip_info(const dbat_hip_handle *h, int64_t *info) {
     info[10] = c.P.nranks > 1 ? (c.mg_subtree ? 2 * c.P.NS + 8 : 3 * c.P.NS + 8) : 0;          // ... and as vectors per linearisation
     info[11] = c.mg_subtree ? c.P.nd.n_top_cams : 0;
     info[12] = c.use_perm ? c.dfchol.nT : 0;
-    info[13] = c.mg_subtree ? c.dfchol.ntasks : 0; info[14] = c.mg_subtree ? c.dfchol.ntasksB : 0; info[15] = 0;
+    info[13] = c.mg_subtree ? c.dfchol.ntasks : 0; info[14] = c.mg_subtree ? c.dfchol.ntasksB : 0;
+    info[15] = c.tile_kernel_mfma();
     return DBAT_HIP_OK;
+}
+
+
+/* Digest of the host plan (debug / CPU tests only: the plan must be identical bit for bit whatever the number of
+ * threads that built it).  out[k] = FNV-1a hash of the k-th field of Plan in the order of plan_digest_names(). */
+#define DBAT_PLAN_FIELDS(X)                                                                                           \
+    X(x2z) X(io_src) X(io_fixed) X(z_est) X(z_prw) X(z_prv) X(z_mine) X(z0) X(prior_z) X(porder) X(pt_rank) X(o_cam)    \
+    X(o_pt) X(o_uv) X(o_w) X(o_seg) X(o_row) X(batch_start) X(o_lc) X(o_pidx) X(tile_batch) X(tile_cam_start)           \
+    X(tile_order) X(tile_cams) X(cm_pt) X(cm_uv) X(cm_w) X(cm_chunk_cam) X(cm_chunk_start) X(giant_start)               \
+    X(tile_io_start) X(tile_iocols) X(tile_cam_io) X(tile_io_simple) X(sg_chunk) X(sg_tile_chunk0) X(sg_lc) X(sg_gcam)  \
+    X(sg_uv) X(sg_w) X(cam_w) X(cam_ncol) X(cam_col) X(cam_iorow) X(cam_eo_est) X(px) X(cam_first) X(cam_adj)
+int dbat_hip_debug_plan_digest(const dbat_hip_problem *prob, uint64_t *out, int32_t n_out, char *names, int32_t names_len) {
+    API_TRY
+    if (!prob || !out) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
+    Plan P;
+    if (!build_plan(*prob, P, true)) { g_err = P.err; return DBAT_HIP_EINVAL; }
+    auto fnv = [](const void *p, size_t n) {
+        uint64_t h = 1469598103934665603ull;
+        const unsigned char *b = (const unsigned char *)p;
+        for (size_t i = 0; i < n; ++i) h = (h ^ b[i]) * 1099511628211ull;
+        return h ^ (uint64_t)n;
+    };
+    std::vector<uint64_t> hs;
+    std::string nm;
+#define X(F) hs.push_back(fnv(P.F.data(), P.F.size() * sizeof(P.F[0]))); nm += #F ",";
+    DBAT_PLAN_FIELDS(X)
+#undef X
+    hs.push_back(fnv(P.nd.order.data(), P.nd.order.size() * sizeof(int))); nm += "nd.order,";
+    hs.push_back(fnv(P.nd.block_end.data(), P.nd.block_end.size() * sizeof(int))); nm += "nd.block_end,";
+    hs.push_back(fnv(P.nd.cam_owner.data(), P.nd.cam_owner.size() * sizeof(int))); nm += "nd.cam_owner,";
+    const int64_t sc[] = {P.n, P.m, P.NS, P.NZ, P.nIOu, P.pt_lo, P.pt_hi, P.CMAX, P.nb_tiled, P.n_cm_chunks_tiled, P.sg_kmax, P.sg_rows_max,
+                          P.sg_ngroups, P.sg_npoints, P.sg_ok, P.sg_backsub_ok, P.BT, P.ncolmax, P.with_io, P.uniform_w, P.all_std8, P.max_k,
+                          P.shared_eo, P.rank_ok, P.order_dims, P.mg_subtree, P.n_tiles_io_simple, P.n_prior[0], P.n_prior[1], P.n_prior[2]};
+    hs.push_back(fnv(sc, sizeof(sc))); nm += "scalars";
+    if ((int)hs.size() > n_out) { g_err = "digest buffer too small"; return DBAT_HIP_EINVAL; }
+    for (size_t i = 0; i < hs.size(); ++i) out[i] = hs[i];
+    for (int i = (int)hs.size(); i < n_out; ++i) out[i] = 0;
+    if (names && names_len > 0) snprintf(names, (size_t)names_len, "%s", nm.c_str());
+    return (int)hs.size();
+    API_CATCH
 }
 
 /* Host evaluation of the per-observation model (debug / CPU unit tests of

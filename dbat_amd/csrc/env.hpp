@@ -37,6 +37,7 @@ static const EnvSwitch kEnvSwitches[] = {
     {"DBAT_HIP_DF_CHUNK", false, "factorisation: products per helper task (default 32)"},
     {"DBAT_HIP_SPRANK_OFF", false, "structural rank from the counting conditions only"},
     {"DBAT_HIP_PLAN_THREADS", false, "threads of the host plan (default: hardware concurrency, at most 32)"},
+    {"DBAT_HIP_PLAN_GRAIN", false, "elements per thread below which a pass of the host plan is not split (tests: 1)"},
     {"DBAT_HIP_PLAN_STATS", false, "1: print layout statistics, 2: also the wall time of every section of the plan"},
     {"DBAT_HIP_PIVOT_STATS", false, "print the pivot extremes and the rcond estimate of every solve"},
     {"DBAT_HIP_ABLATE", true, "k_build_sig / tile kernels: switch phases off (results are wrong), phase clocks"},

@@ -643,11 +643,70 @@ __global__ __launch_bounds__(256) void k_build(DevProblem d, const double *__res
                 const double y2 = w2 * Vi[5];
                 wl[3 * a] = y0; wl[3 * a + 1] = y1; wl[3 * a + 2] = y2;
                 if constexpr (!WITH_IO) { W[a][0] = w0; W[a][1] = w1; W[a][2] = w2; Y[a][0] = y0; Y[a][1] = y1; Y[a][2] = y2; }
+                if (WITH_IO && a >= 6) continue;     // IO columns: below, summed over the wave where the lanes share them
                 const int col = C->col[a];
                 const double ga = E[0][a] * r[0] + E[1][a] * r[1];
                 atomic_add_f64(g_c + col, ga);
                 atomic_add_f64(g_red + col, ga - (y0 * gpt[0] + y1 * gpt[1] + y2 * gpt[2]));
                 atomic_add_f64(diagU + col, E[0][a] * E[0][a] + E[1][a] * E[1][a]);
+            }
+        }
+    }
+    // An estimated IO parameter is usually shared by many images (one camera: by all of them), so every observation
+    // of the batch adds to the SAME elements -- 2 000 observations of the camcal demo queue up on nine addresses
+    // of g_c and on the 45 of the IO x IO block (11.7 ms per linearisation in round 3, where 0.1 would do).  In
+    // converged control flow the lanes compare their targets: if all of them agree, the wave adds up first
+    // (DPP row sums, no LDS) and one lane issues the atomic; otherwise every lane goes its own way as before.
+    auto add_shared = [&](double *base, int64_t idx, bool valid, double val) {
+        const unsigned long long vm = __ballot(valid);
+        if (!vm) return;
+        const int fl = __ffsll((long long)vm) - 1;
+        const int64_t idx0 = __shfl(idx, fl, 64);
+        if (__ballot(valid && idx != idx0) == 0) {
+            const double sum = wave_sum_f64(valid ? val : 0.0);
+            if ((int)(threadIdx.x & 63) == fl) atomic_add_f64(base + idx0, sum);
+        } else if (valid) atomic_add_f64(base + idx, val);
+    };
+    if constexpr (WITH_IO) {
+#pragma unroll
+        for (int a = 6; a < NCX; ++a) {
+            if (__ballot(active && a < ncol) == 0) break;
+            const bool valid = active && a < ncol;
+            double ea0 = 0, ea1 = 0;
+#pragma unroll
+            for (int q = 6; q < NCX; ++q) if (q == a) { ea0 = E[0][q]; ea1 = E[1][q]; }
+            const double *wl = Wl + (size_t)t * strideW;
+            const int64_t col = valid ? C->col[a] : 0;
+            const double ga = valid ? ea0 * r[0] + ea1 * r[1] : 0.0;
+            const double gr = valid ? ga - (wl[3 * a] * gpt[0] + wl[3 * a + 1] * gpt[1] + wl[3 * a + 2] * gpt[2]) : 0.0;
+            add_shared(g_c, col, valid, ga);
+            add_shared(g_red, col, valid, gr);
+            add_shared(diagU, col, valid, ea0 * ea0 + ea1 * ea1);
+        }
+    }
+    // Shared IO columns again: if every observation of a point sees the SAME IO columns (one camera, or one IO block
+    // per point), the pair terms that involve an IO column collapse -- with ZU = sum_j Z_io,j over the point's
+    // observations, sum_j Y_i W_j'(EO x IO) = Z_eo,i ZU' and sum_i sum_j (IO x IO) = ZU ZU': 54 atomics per
+    // observation and 45 per point instead of 54 k and 45 k^2.  The point's leader finds out (its observations compare
+    // their column lists with its own) and sums ZU into its own scratch row.
+    __shared__ int same_io[256];
+    bool blocksum = false;
+    if constexpr (WITH_IO) {
+        if (t < BT) same_io[t] = 1;
+        __syncthreads();
+        if (active && t != seg_start) {
+            const CamRec *CL = cams + d.o_cam[o0 + seg_start];
+            bool same = CL->ncol == ncol;
+            for (int a = 6; a < NCX; ++a) if (a < ncol && same) same = CL->col[a] == C->col[a];
+            if (!same) same_io[seg_start] = 0;
+        }
+        __syncthreads();
+        blocksum = active && ncol > 6 && same_io[seg_start] != 0;
+        if (blocksum && t == seg_start) {
+            double *wl = Wl + (size_t)t * strideW;
+            for (int jj = seg_start + 1; jj < seg_start + seg_len; ++jj) {
+                const double *wj = Wl + (size_t)jj * strideW;
+                for (int q = 18; q < 3 * ncol; ++q) wl[q] += wj[q];
             }
         }
     }
@@ -676,18 +735,28 @@ __global__ __launch_bounds__(256) void k_build(DevProblem d, const double *__res
             }
         } else {
             const double *wi = Wl + (size_t)t * strideW;
+            const double *zu = Wl + (size_t)seg_start * strideW;      // (block sums: the leader's IO part holds ZU)
             for (int a = 0; a < NCX; ++a) {
-                if (a >= ncol) break;
+                if (a >= ncol || (blocksum && a >= 6)) break;
                 const int gcol = C->col[a];
                 const double y0 = wi[3 * a], y1 = wi[3 * a + 1], y2 = wi[3 * a + 2];      // (the scratch rows hold Z)
                 double ea0 = 0, ea1 = 0;
 #pragma unroll
                 for (int q = 0; q < NCX; ++q) if (q == a) { ea0 = E[0][q]; ea1 = E[1][q]; }
+                if (blocksum) {                          // EO column a x the point's IO columns, once
+#pragma unroll
+                    for (int b = 6; b < NCX; ++b) {
+                        if (b >= ncol) break;
+                        atomic_add_f64(S + (int64_t)gcol * d.ldS + C->col[b],
+                                       ea0 * E[0][b] + ea1 * E[1][b] - (y0 * zu[3 * b] + y1 * zu[3 * b + 1] + y2 * zu[3 * b + 2]));
+                    }
+                }
                 for (int jj = seg_start; jj < seg_start + seg_len; ++jj) {
                     const CamRec *Cj = cams + d.o_cam[o0 + jj];
                     const double *wj = Wl + (size_t)jj * strideW;
-                    const int ncj = Cj->ncol;
+                    const int ncj = blocksum ? 6 : Cj->ncol;
                     for (int b = 0; b < ncj; ++b) {
+                        if (a >= 6 && b >= 6) break;     // IO x IO: below
                         const int grow = Cj->col[b];
                         if (grow < gcol) continue;
                         double val = -(y0 * wj[3 * b] + y1 * wj[3 * b + 1] + y2 * wj[3 * b + 2]);
@@ -699,6 +768,49 @@ __global__ __launch_bounds__(256) void k_build(DevProblem d, const double *__res
                         }
                         atomic_add_f64(S + (int64_t)gcol * d.ldS + grow, val);
                     }
+                }
+            }
+        }
+    }
+    if constexpr (WITH_IO) {
+        // IO x IO elements of the pair terms (and of E'E on the diagonal pair), all lanes in step: own IO column a,
+        // partner j of the point, partner's IO column b
+        // (a lane of a block-sum point takes part once, j = 0: its own E_io'E_io, and -- the leader -- ZU ZU')
+        int maxlen = active ? (blocksum ? 1 : seg_len) : 0;
+        for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
+        const double *wi = Wl + (size_t)t * strideW;
+        const bool leader = t == seg_start;
+        for (int a = 6; a < NCX; ++a) {
+            if (__ballot(active && a < ncol) == 0) break;
+            const bool va = active && a < ncol;
+            const int64_t gcol = va ? C->col[a] : 0;
+            double ea0 = 0, ea1 = 0;
+#pragma unroll
+            for (int q = 6; q < NCX; ++q) if (q == a) { ea0 = E[0][q]; ea1 = E[1][q]; }
+            // block sums: the pair term comes from the leader alone, who holds ZU in its scratch row
+            const bool pairs = va && (!blocksum || leader);
+            const double y0 = pairs ? wi[3 * a] : 0.0, y1 = pairs ? wi[3 * a + 1] : 0.0, y2 = pairs ? wi[3 * a + 2] : 0.0;
+            for (int j = 0; j < maxlen; ++j) {
+                const bool vj = va && j < (blocksum ? 1 : seg_len);
+                const int jj = (vj && !blocksum) ? seg_start + j : t;
+                const CamRec *Cj = cams + ((vj && !blocksum) ? d.o_cam[o0 + jj] : cam);
+                const double *wj = Wl + (size_t)jj * strideW;
+                const int ncj = vj ? Cj->ncol : 0;
+                for (int b = 6; b < NCX; ++b) {
+                    if (__ballot(vj && b < ncj) == 0) break;
+                    const int64_t grow = (vj && b < ncj) ? Cj->col[b] : -1;
+                    const bool valid = vj && b < ncj && grow >= gcol;
+                    double val = 0.0;
+                    if (valid) {
+                        val = -(y0 * wj[3 * b] + y1 * wj[3 * b + 1] + y2 * wj[3 * b + 2]);
+                        if (jj == t) {
+                            double eb0 = 0, eb1 = 0;
+#pragma unroll
+                            for (int q = 6; q < NCX; ++q) if (q == b) { eb0 = E[0][q]; eb1 = E[1][q]; }
+                            val += ea0 * eb0 + ea1 * eb1;
+                        }
+                    }
+                    add_shared(S, gcol * d.ldS + grow, valid, val);
                 }
             }
         }

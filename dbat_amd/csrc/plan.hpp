@@ -11,6 +11,8 @@
 // (camera + IO) system; the OP part is eliminated by the Schur complement.
 #pragma once
 #include "env.hpp"
+#include "par.hpp"
+#include <atomic>
 #include <chrono>
 #include <algorithm>
 #include <cmath>
@@ -53,16 +55,16 @@ struct Plan {
     std::vector<int32_t> pt_rank;                  // point -> position in the processing order; the object points
                                                    // sit in z in THAT order (neighbouring observations then
                                                    // gather neighbouring coordinates), o_pt holds ranks
-    std::vector<int32_t> o_cam, o_pt;
-    std::vector<double> o_uv;                      // 2 per obs
-    std::vector<double> o_w;                       // 2 per obs (1/sigma_mm) or empty if uniform
-    std::vector<uint32_t> o_seg;                   // (seg_start | seg_len<<16) within batch
-    std::vector<int64_t> o_row;                    // IP column (reference order)
+    uvec<int32_t> o_cam, o_pt;
+    uvec<double> o_uv;                      // 2 per obs
+    uvec<double> o_w;                       // 2 per obs (1/sigma_mm) or empty if uniform
+    uvec<uint32_t> o_seg;                   // (seg_start | seg_len<<16) within batch
+    uvec<int64_t> o_row;                    // IP column (reference order)
     std::vector<int64_t> batch_start;              // [nb+1]
     // tiles: runs of batches whose observations touch at most CMAX cameras; the
     // Schur complement of a tile is accumulated in LDS and flushed once
-    std::vector<uint8_t> o_lc;                     // local camera index of every observation
-    std::vector<uint8_t> o_pidx;                   // ordinal of the observation's point inside its batch
+    uvec<uint8_t> o_lc;                     // local camera index of every observation
+    uvec<uint8_t> o_pidx;                   // ordinal of the observation's point inside its batch
     std::vector<int32_t> tile_batch;               // [ntiles+1] first batch of every tile
     std::vector<int32_t> tile_cam_start;           // [ntiles+1]
     std::vector<int32_t> tile_order;               // launch order: longest tiles first (shorter tail)
@@ -73,9 +75,9 @@ struct Plan {
     // camera over the tiled part; k_residual_cm over everything): chunks of one camera's
     // observations, at most CM_CHUNK each
     static constexpr int CM_CHUNK = 2048;
-    std::vector<int32_t> cm_pt;                    // object point
-    std::vector<double> cm_uv;                     // 2 per observation
-    std::vector<double> cm_w;                      // 2 per observation or empty if uniform
+    uvec<int32_t> cm_pt;                    // object point
+    uvec<double> cm_uv;                     // 2 per observation
+    uvec<double> cm_w;                      // 2 per observation or empty if uniform
     std::vector<int32_t> cm_chunk_cam;             // camera of every chunk
     std::vector<int64_t> cm_chunk_start;           // [nchunks+1]
     int64_t n_cm_chunks_tiled = 0;                 // chunks of tiled observations come first
@@ -100,8 +102,8 @@ struct Plan {
     std::vector<int32_t> sg_tile_chunk0;           // [ntiles+1]
     std::vector<uint8_t> sg_lc;                    // [nchunks][16] tile-local camera index of every slot
     std::vector<int32_t> sg_gcam;                  // [nchunks][16] the same cameras by their global index
-    std::vector<double> sg_uv;                     // slot-major copy of o_uv: group g, slot j, point i at 2*(obs0_g + j*m_g + i)
-    std::vector<double> sg_w;                      // the same for o_w (empty if uniform)
+    uvec<double> sg_uv;                     // slot-major copy of o_uv: group g, slot j, point i at 2*(obs0_g + j*m_g + i)
+    uvec<double> sg_w;                      // the same for o_w (empty if uniform)
     int sg_kmax = 0;                               // largest k among the tiled points
     int sg_rows_max = 0;                           // most rows of a chunk: 6k + IO columns of its tile + 1
     int64_t sg_ngroups = 0, sg_npoints = 0;
@@ -244,6 +246,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     for (size_t e = 0; e < (size_t)3 * np; ++e) { P.z0[P.NS + e] = pb.OP_val[e]; P.z_est[P.NS + e] = estOP[e]; }
     // x order: IO leading (column-major), EO est (column-major), OP est (column-major)
     P.x2z.clear();
+    P.x2z.reserve((size_t)P.NZ);
     for (int k = 0; k < P.nIOu; ++k) P.x2z.push_back(6 * (int64_t)nc + k);
     for (size_t e = 0; e < (size_t)6 * nc; ++e) if (eo_lead[e]) P.x2z.push_back((int64_t)e);
     for (size_t e = 0; e < (size_t)3 * np; ++e) if (estOP[e]) P.x2z.push_back(P.NS + (int64_t)e);
@@ -302,35 +305,57 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     }
 
     lapt("per-camera column lists");
-    // ---- observations: validate order, weights
+    // ---- observations: validate order, weights (parallel over ranges of the IP columns; the first offence in
+    // column order is the one reported, as a single pass would)
+    const Par par{Par::default_threads()};
     std::vector<int32_t> k_pt(np, 0), n_cam(nc, 0);
-    for (int64_t o = 0; o < P.no; ++o) {
-        const int32_t c = pb.ip_cam[o], p = pb.ip_pt[o];
-        if (c < 0 || c >= nc || p < 0 || p >= np) return fail(P, "IP.cam / IP.pt out of range");
-        if (o > 0) {
-            const int32_t c0 = pb.ip_cam[o - 1], p0 = pb.ip_pt[o - 1];
-            if (c < c0 || (c == c0 && p <= p0))
-                return fail(P, "IP columns must be image-major with ascending OP index (prob2dbatstruct.m:349-365)");
-        }
-        k_pt[p]++; n_cam[c]++;
-    }
-    P.max_k = 0;
-    for (int p = 0; p < np; ++p) P.max_k = std::max(P.max_k, k_pt[p]);
-    // uniform sigma per camera?  sigma_mm = IP.std .* pxSize(:,cam)  (buildweightmatrix.m:20)
-    P.uniform_w = true;
-    P.cam_w.assign((size_t)2 * nc, 0.0);
     {
-        std::vector<uint8_t> have(nc, 0);
-        for (int64_t o = 0; o < P.no && P.uniform_w; ++o) {
-            const int32_t c = pb.ip_cam[o];
-            const double wu = 1.0 / (pb.ip_std[2 * o] * P.px[2 * c]);
-            const double wv = 1.0 / (pb.ip_std[2 * o + 1] * P.px[2 * c + 1]);
-            if (!have[c]) { have[c] = 1; P.cam_w[2 * c] = wu; P.cam_w[2 * c + 1] = wv; }
-            else if (P.cam_w[2 * c] != wu || P.cam_w[2 * c + 1] != wv) P.uniform_w = false;
+        std::atomic<int64_t> first_range{INT64_MAX}, first_order{INT64_MAX}, first_std{INT64_MAX};
+        auto lower = [](std::atomic<int64_t> &a, int64_t v) { int64_t c = a.load(); while (v < c && !a.compare_exchange_weak(c, v)) {} };
+        par.run(P.no, [&](int64_t lo, int64_t hi, int) {
+            int32_t run_cam = -1; int32_t run_n = 0;
+            for (int64_t o = lo; o < hi; ++o) {
+                const int32_t c = pb.ip_cam[o], p = pb.ip_pt[o];
+                if (c < 0 || c >= nc || p < 0 || p >= np) { lower(first_range, o); break; }
+                if (o > 0) {
+                    const int32_t c0 = pb.ip_cam[o - 1], p0 = pb.ip_pt[o - 1];
+                    if (c < c0 || (c == c0 && p <= p0)) lower(first_order, o);
+                }
+                if (!(pb.ip_std[2 * o] > 0) || !(pb.ip_std[2 * o + 1] > 0)) lower(first_std, o);
+                __atomic_fetch_add(&k_pt[p], 1, __ATOMIC_RELAXED);
+                if (c != run_cam) { if (run_n) __atomic_fetch_add(&n_cam[run_cam], run_n, __ATOMIC_RELAXED); run_cam = c; run_n = 0; }
+                ++run_n;
+            }
+            if (run_n) __atomic_fetch_add(&n_cam[run_cam], run_n, __ATOMIC_RELAXED);
+        });
+        const int64_t fr = first_range.load(), fo = first_order.load();
+        if (fr <= fo && fr != INT64_MAX) return fail(P, "IP.cam / IP.pt out of range");
+        if (fo != INT64_MAX) return fail(P, "IP columns must be image-major with ascending OP index (prob2dbatstruct.m:349-365)");
+        P.max_k = 0;
+        for (int p = 0; p < np; ++p) P.max_k = std::max(P.max_k, k_pt[p]);
+        // uniform sigma per camera?  sigma_mm = IP.std .* pxSize(:,cam)  (buildweightmatrix.m:20).  The columns are
+        // image-major: a camera's first observation is the start of its range.
+        std::vector<int64_t> cam_obs_first(nc + 1, 0);
+        for (int c = 0; c < nc; ++c) cam_obs_first[c + 1] = cam_obs_first[c] + n_cam[c];
+        std::atomic<int64_t> first_diff{INT64_MAX};
+        par.run(P.no, [&](int64_t lo, int64_t hi, int) {
+            for (int64_t o = lo; o < hi; ++o) {
+                const int32_t c = pb.ip_cam[o];
+                const int64_t f = cam_obs_first[c];
+                const double wu = 1.0 / (pb.ip_std[2 * o] * P.px[2 * c]), wv = 1.0 / (pb.ip_std[2 * o + 1] * P.px[2 * c + 1]);
+                const double fu = 1.0 / (pb.ip_std[2 * f] * P.px[2 * c]), fv = 1.0 / (pb.ip_std[2 * f + 1] * P.px[2 * c + 1]);
+                if (wu != fu || wv != fv) { lower(first_diff, o); break; }
+            }
+        });
+        const int64_t fd = first_diff.load();
+        P.uniform_w = fd == INT64_MAX;
+        P.cam_w.assign((size_t)2 * nc, 0.0);
+        for (int c = 0; c < nc; ++c) {               // (cameras first seen before the first differing observation, as a single pass leaves it)
+            const int64_t f = cam_obs_first[c];
+            if (n_cam[c] > 0 && f < fd) { P.cam_w[2 * c] = 1.0 / (pb.ip_std[2 * f] * P.px[2 * c]); P.cam_w[2 * c + 1] = 1.0 / (pb.ip_std[2 * f + 1] * P.px[2 * c + 1]); }
         }
+        if (first_std.load() != INT64_MAX) return fail(P, "IP.std must be positive");
     }
-    for (int64_t o = 0; o < P.no; ++o)
-        if (!(pb.ip_std[2 * o] > 0) || !(pb.ip_std[2 * o + 1] > 0)) return fail(P, "IP.std must be positive");
 
     lapt("observations: validate order, weights");
     // ---- structural rank test (sprank(J), gauss_newton_armijo.m:132-142).  First the cheap
@@ -359,9 +384,19 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     // ---- processing order of the object points
     std::vector<int64_t> pstart(np + 1, 0);
     for (int p = 0; p < np; ++p) pstart[p + 1] = pstart[p] + k_pt[p];
-    std::vector<int64_t> fill(pstart.begin(), pstart.end() - 1);
-    std::vector<int64_t> by_pt(P.no);
-    for (int64_t o = 0; o < P.no; ++o) by_pt[fill[pb.ip_pt[o]]++] = o;   // image-major scan => cams ascending per point
+    // by_pt: the IP columns of every point, ascending (image-major scan => cameras ascend inside a point); cbp: their
+    // cameras.  A stable counting sort in parallel: every thread owns a range of POINTS and scans all columns.
+    uvec<int64_t> by_pt(P.no);
+    uvec<int32_t> cbp(P.no);
+    par.run(np, [&](int64_t plo, int64_t phi, int) {
+        std::vector<int32_t> cur((size_t)(phi - plo), 0);
+        for (int64_t o = 0; o < P.no; ++o) {
+            const int32_t p = pb.ip_pt[o];
+            if (p < plo || p >= phi) continue;
+            const int64_t q = pstart[p] + cur[p - plo]++;
+            by_pt[q] = o; cbp[q] = pb.ip_cam[o];
+        }
+    }, 1 << 15);
     lapt("observations by point (counting sort)");
     // ---- exact structural rank (sprank(J) < n  =>  code -4): when the counting conditions
     // above hold, a maximum matching of the unknowns to the rows of J decides.  An unknown
@@ -371,7 +406,65 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     // along an augmenting path.  J is never formed: the rows of an EO or IO column are the
     // contiguous observation ranges of its cameras, those of an OP column the observations
     // of its point.
-    if (P.rank_ok && !env_on("DBAT_HIP_SPRANK_OFF") && !P.shared_eo) {     // (shared EO: the counting conditions only)
+    // The healthy network first, in parallel: every object point claims as many rows among its OWN observations as
+    // it has unknowns without a prior (rows of different points are disjoint: a bitmap of taken rows and an atomic
+    // OR per claim are all it takes; the observations are tried from a point-dependent start, so that the claims spread
+    // over the point's cameras), then the IO and EO columns take the first rows that are still free in their cameras.
+    // If everybody is served that IS a perfect matching, hence sprank = n.  Anything else is left to the exact
+    // matching below, from scratch: the answer is the existence of a perfect matching either way.
+    bool sprank_settled = false;
+    if (P.rank_ok && !env_on("DBAT_HIP_SPRANK_OFF") && !P.shared_eo) {
+        std::vector<int64_t> cam_obs0(nc + 1, 0);
+        for (int c = 0; c < nc; ++c) cam_obs0[c + 1] = cam_obs0[c] + n_cam[c];
+        std::vector<uint64_t> taken((size_t)(2 * P.no + 63) / 64 + 1, 0);
+        auto wanted = [&](int64_t col) -> bool { return P.z_est[col] && !(P.z_prw[col] > 0); };
+        std::atomic<int> short_pts{0};
+        par.run(np, [&](int64_t plo, int64_t phi, int) {
+            for (int64_t p = plo; p < phi; ++p) {
+                int want = 0;
+                for (int d = 0; d < 3; ++d) want += wanted(P.NS + 3 * p + d) ? 1 : 0;
+                const int k = k_pt[p];
+                for (int dd = 0; dd < 2 * k && want > 0; ++dd) {         // one row per observation first, then the second rows
+                    const int j = (int)((p + dd) % k);
+                    const int64_t row = 2 * by_pt[pstart[p] + j] + (dd >= k ? 1 : 0);
+                    __atomic_fetch_or(&taken[row >> 6], 1ull << (row & 63), __ATOMIC_RELAXED);
+                    --want;
+                }
+                if (want > 0) { short_pts.fetch_add(1); return; }
+            }
+        });
+        bool cheap_ok = short_pts.load() == 0;
+        auto claim = [&](int c, int64_t &row) -> bool {                  // the next free row of camera c at or after `row`
+            while (row < 2 * cam_obs0[c + 1] && ((taken[row >> 6] >> (row & 63)) & 1)) ++row;
+            if (row >= 2 * cam_obs0[c + 1]) return false;
+            taken[row >> 6] |= 1ull << (row & 63);
+            return true;
+        };
+        if (cheap_ok) {      // IO columns: a free row of the first of their cameras that has one
+            std::vector<uint8_t> io_done(std::max(1, P.nIOu), 0);
+            int64_t io_left = 0;
+            for (int k = 0; k < P.nIOu; ++k) { io_done[k] = !wanted(6 * (int64_t)nc + k); io_left += !io_done[k]; }
+            for (int c = 0; c < nc && io_left > 0; ++c) {
+                int64_t row = 2 * cam_obs0[c];
+                for (int r = 0; r < R && io_left > 0; ++r) {
+                    const int32_t k = distIO[(size_t)c * R + r];
+                    if (k < 0 || io_done[k]) continue;
+                    if (!claim(c, row)) break;
+                    io_done[k] = 1; --io_left;
+                }
+            }
+            cheap_ok = io_left == 0;
+        }
+        for (int c = 0; c < nc && cheap_ok; ++c) {
+            int64_t row = 2 * cam_obs0[c];
+            for (int d = 0; d < 6 && cheap_ok; ++d)
+                if (wanted(6 * (int64_t)c + d)) cheap_ok = claim(c, row);
+        }
+        sprank_settled = cheap_ok;
+    }
+    lapt("structural rank: cheap assignment in parallel");
+    if (plan_clock) fprintf(stderr, "[plan clock] cheap assignment settled the structural rank: %s\n", sprank_settled ? "yes" : "no");
+    if (P.rank_ok && !sprank_settled && !env_on("DBAT_HIP_SPRANK_OFF") && !P.shared_eo) {     // (shared EO: the counting conditions only)
         const int64_t ncol_all = P.NZ;
         std::vector<int64_t> cam_obs0(nc + 1, 0);
         for (int c = 0; c < nc; ++c) cam_obs0[c + 1] = cam_obs0[c] + n_cam[c];
@@ -439,33 +532,44 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         for (int64_t col = io_end; col < ncol_all && P.rank_ok; ++col) if (wanted(col) && !match_column(col)) P.rank_ok = false;
     }
 
-    // camera co-visibility: the envelope of the reduced system (chol.hpp)
+    lapt("structural rank: exact matching (only when the cheap assignment fails)");
+    // camera co-visibility: the envelope of the reduced system (chol.hpp) and the full graph -- the pattern of the
+    // reduced system (ordering + symbolic factorisation of the tile Cholesky, chol_df.hpp).  Every thread collects
+    // the points of its range in its own copy (min / bit-or: exact, order-free), the copies are merged.
     P.cam_first.resize(nc);
     for (int c = 0; c < nc; ++c) P.cam_first[c] = c;
-    for (int p = 0; p < np; ++p) {
-        if (!k_pt[p]) continue;
-        const int32_t c0 = pb.ip_cam[by_pt[pstart[p]]];          // cameras ascend inside a point
-        for (int j = 1; j < k_pt[p]; ++j) {
-            const int32_t c = pb.ip_cam[by_pt[pstart[p] + j]];
-            if (c0 < P.cam_first[c]) P.cam_first[c] = c0;
-        }
-    }
-    // full co-visibility graph of the cameras: the pattern of the reduced system
-    // (ordering + symbolic factorisation of the tile Cholesky, chol_df.hpp)
     P.cam_adj_words = (nc + 63) / 64;
     P.cam_adj.assign((size_t)nc * P.cam_adj_words, 0);
-    for (int p = 0; p < np; ++p) {
-        const int k = k_pt[p];
-        for (int a = 0; a < k; ++a) {
-            const int32_t ca = pb.ip_cam[by_pt[pstart[p] + a]];
-            uint64_t *row = P.cam_adj.data() + (size_t)ca * P.cam_adj_words;
-            for (int b = 0; b < k; ++b) {
-                const int32_t cb = pb.ip_cam[by_pt[pstart[p] + b]];
-                row[cb >> 6] |= 1ull << (cb & 63);
+    {
+        const size_t aw = (size_t)nc * P.cam_adj_words;
+        const int nr = (int)std::min<int64_t>(par.ranges(np, 1 << 14), std::max<int64_t>(1, (int64_t)(256u << 20) / (int64_t)std::max<size_t>(aw * 8, 1)));
+        std::vector<std::vector<uint64_t>> adj_t(nr);
+        std::vector<std::vector<int32_t>> first_t(nr);
+        const Par par_adj{nr};
+        par_adj.run(np, [&](int64_t plo, int64_t phi, int tid) {
+            std::vector<uint64_t> &adj = adj_t[tid];
+            std::vector<int32_t> &first = first_t[tid];
+            adj.assign(aw, 0); first.resize(nc);
+            for (int c = 0; c < nc; ++c) first[c] = c;
+            for (int64_t p = plo; p < phi; ++p) {
+                const int k = k_pt[p];
+                if (!k) continue;
+                const int32_t *cp = cbp.data() + pstart[p];
+                const int32_t c0 = cp[0];                                 // cameras ascend inside a point
+                for (int j = 1; j < k; ++j) if (c0 < first[cp[j]]) first[cp[j]] = c0;
+                for (int a = 0; a < k; ++a) {
+                    uint64_t *row = adj.data() + (size_t)cp[a] * P.cam_adj_words;
+                    for (int b = 0; b < k; ++b) row[cp[b] >> 6] |= 1ull << (cp[b] & 63);
+                }
             }
+        }, 1);
+        for (int t = 0; t < nr; ++t) {
+            if (adj_t[t].empty()) continue;
+            for (size_t i = 0; i < aw; ++i) P.cam_adj[i] |= adj_t[t][i];
+            for (int c = 0; c < nc; ++c) P.cam_first[c] = std::min(P.cam_first[c], first_t[t][c]);
         }
     }
-    lapt("exact structural rank (sprank(J) < n  =>  code -4): when t");
+    lapt("camera co-visibility graph");
     // ---- nested dissection (nd.hpp); with several ranks its first levels are the ranks' domains
     {
         const bool nd_off = env_on("DBAT_HIP_ND_OFF");
@@ -486,7 +590,8 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     P.CMAX = env_int("DBAT_HIP_CMAX", P.with_io ? 18 : 21);
     if (P.shared_eo) P.CMAX = 0;                    // the tile kernels address camera rows as 6*camera + k
     if (P.CMAX < 0 || P.CMAX > (P.with_io ? 18 : 21)) P.CMAX = P.with_io ? 18 : 21;   // 6*CMAX (+IOT) <= 128 rows of the MFMA tile
-    if (P.ncolmax > 14) P.CMAX = 0;                  // the tile kernels hold at most 8 IO columns per camera: untiled (k_build)
+    if (P.ncolmax > 15) P.CMAX = 0;                  // the tile kernels hold at most 9 IO columns per camera (DBAT's usual self-calibration:
+                                                     // cc, pp, aspect, K1-K3, P1-P2); beyond that: untiled (k_build)
     {   // batch size: whole points, at most BT observations
         P.BT = env_int("DBAT_HIP_BT", 256);
         if (P.BT != 128 && P.BT != 256) P.BT = 256;
@@ -500,7 +605,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         if (P.with_io) {
             int32_t seen[Plan::IOT + 1]; int ns = 0;
             for (int j = 0; j < k_pt[p] && ns <= Plan::IOT; ++j) {
-                const int32_t c = pb.ip_cam[by_pt[pstart[p] + j]];
+                const int32_t c = cbp[pstart[p] + j];
                 for (int q = 6; q < P.cam_ncol[c] && ns <= Plan::IOT; ++q) {
                     const int32_t io = P.cam_col[(size_t)c * MAXCOL + q];
                     bool f = false;
@@ -581,19 +686,21 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
             v = (v | v << 2) & 0x1249249249249249ull;
             return v;
         };
-        for (int p = 0; p < np; ++p) {
-            uint64_t k = 0;
-            for (int d = 0; d < dims; ++d) {
-                double v = (coord(p, axis[d]) - lo[axis[d]]) / ext;
-                if (!(v >= 0)) v = 0;
-                if (v > 1) v = 1;
-                k |= spread((uint64_t)(v * 2097151.0)) << d;
+        par.run(np, [&](int64_t plo, int64_t phi, int) {
+            for (int64_t p = plo; p < phi; ++p) {
+                uint64_t k = 0;
+                for (int d = 0; d < dims; ++d) {
+                    double v = (coord((int)p, axis[d]) - lo[axis[d]]) / ext;
+                    if (!(v >= 0)) v = 0;
+                    if (v > 1) v = 1;
+                    k |= spread((uint64_t)(v * 2097151.0)) << d;
+                }
+                // tiled points, then heavy points, then giant points; unobserved points last
+                key[p] = !k_pt[p] ? ~0ull
+                         : giant[p] ? ((k >> 2) | (3ull << 62))
+                         : heavy[p] ? ((k >> 2) | (1ull << 63)) : (k >> 1);
             }
-            // tiled points, then heavy points, then giant points; unobserved points last
-            key[p] = !k_pt[p] ? ~0ull
-                     : giant[p] ? ((k >> 2) | (3ull << 62))
-                     : heavy[p] ? ((k >> 2) | (1ull << 63)) : (k >> 1);
-        }
+        });
     }
     P.porder.resize(np);
     std::iota(P.porder.begin(), P.porder.end(), 0);
@@ -609,25 +716,34 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         // the code interleaves `order_dims` of three bit lanes into the top 62 bits of the key
         const int eff_bits = (cell_bits * 3 + P.order_dims - 1) / P.order_dims;
         const int low_bits = std::max(0, 62 - eff_bits);
-        std::vector<uint64_t> sig(np, 0);
-        if (low_bits > 0)
-            for (int p = 0; p < np; ++p) {
-                // first four cameras (16 bits each) lead, so that groups with neighbouring camera sets stay close
-                uint64_t lead = 0, h = 1469598103934665603ull;
-                for (int j = 0; j < k_pt[p]; ++j) {
-                    const uint64_t c = (uint64_t)pb.ip_cam[by_pt[pstart[p] + j]];
-                    if (j < 3) lead |= (c & 0xFFFF) << (48 - 16 * j);
-                    h = (h ^ c) * 1099511628211ull;
+        // one record per point: (cell of the curve, camera signature inside a cell of tiled points, key, point) -- a
+        // strict total order whose last member reproduces the stable sort by the first three
+        struct Rec { uint64_t cell, sig, key; int32_t p; };
+        std::vector<Rec> recs(np);
+        par.run(np, [&](int64_t plo, int64_t phi, int) {
+            for (int64_t p = plo; p < phi; ++p) {
+                uint64_t sg = 0;
+                const bool in_cell = low_bits > 0 && key[p] < (1ull << 62);
+                if (in_cell) {
+                    // first four cameras (16 bits each) lead, so that groups with neighbouring camera sets stay close
+                    uint64_t lead = 0, h = 1469598103934665603ull;
+                    for (int j = 0; j < k_pt[p]; ++j) {
+                        const uint64_t c = (uint64_t)cbp[pstart[p] + j];
+                        if (j < 3) lead |= (c & 0xFFFF) << (48 - 16 * j);
+                        h = (h ^ c) * 1099511628211ull;
+                    }
+                    sg = lead | (h & 0xFFFF);
                 }
-                sig[p] = lead | (h & 0xFFFF);
+                recs[p] = Rec{in_cell ? key[p] >> low_bits : key[p], sg, key[p], (int32_t)p};
             }
-        auto cell = [&](int32_t a) { return low_bits > 0 && key[a] < (1ull << 62) ? key[a] >> low_bits : key[a]; };
-        std::stable_sort(P.porder.begin(), P.porder.end(), [&](int32_t a, int32_t b) {
-            const uint64_t ca = cell(a), cb = cell(b);
-            if (ca != cb) return ca < cb;
-            if (low_bits > 0 && key[a] < (1ull << 62) && sig[a] != sig[b]) return sig[a] < sig[b];
-            return key[a] < key[b];
         });
+        par.sort(recs, [](const Rec &a, const Rec &b) {
+            if (a.cell != b.cell) return a.cell < b.cell;
+            if (a.sig != b.sig) return a.sig < b.sig;
+            if (a.key != b.key) return a.key < b.key;
+            return a.p < b.p;
+        });
+        par.run(np, [&](int64_t lo_, int64_t hi_, int) { for (int64_t i = lo_; i < hi_; ++i) P.porder[i] = recs[i].p; });
     }
     if (P.mg_subtree) {
         // Domain sharding: a point goes to the rank whose domain holds its interior cameras (nd.hpp: all
@@ -637,7 +753,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         std::vector<int32_t> owner(np, -1);
         std::vector<int64_t> load(P.nranks, 0);
         for (int p = 0; p < np; ++p)
-            for (int j = 0; j < k_pt[p] && owner[p] < 0; ++j) owner[p] = P.nd.cam_owner[pb.ip_cam[by_pt[pstart[p] + j]]];
+            for (int j = 0; j < k_pt[p] && owner[p] < 0; ++j) owner[p] = P.nd.cam_owner[cbp[pstart[p] + j]];
         for (int p = 0; p < np; ++p) if (owner[p] >= 0) load[owner[p]] += k_pt[p];
         for (int p = 0; p < np; ++p)
             if (owner[p] < 0) {
@@ -645,11 +761,16 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
                 for (int r = 1; r < P.nranks; ++r) if (load[r] < load[best]) best = r;
                 owner[p] = best; load[best] += k_pt[p];
             }
-        std::stable_sort(P.porder.begin(), P.porder.end(), [&](int32_t a, int32_t b) { return owner[a] < owner[b]; });
-        P.pt_lo = np; P.pt_hi = 0;
-        for (int i = 0; i < np; ++i)
-            if (owner[P.porder[i]] == P.rank) { P.pt_lo = std::min<int64_t>(P.pt_lo, i); P.pt_hi = i + 1; }
-        if (P.pt_hi < P.pt_lo) P.pt_lo = P.pt_hi = 0;
+        {   // stable sort by owner: a counting sort
+            std::vector<int64_t> cnt((size_t)P.nranks + 1, 0);
+            for (int p = 0; p < np; ++p) ++cnt[(size_t)owner[p] + 1];
+            for (int r = 0; r < P.nranks; ++r) cnt[r + 1] += cnt[r];
+            P.pt_lo = cnt[P.rank]; P.pt_hi = cnt[P.rank + 1];
+            std::vector<int32_t> sorted(np);
+            for (int i = 0; i < np; ++i) sorted[cnt[owner[P.porder[i]]]++] = P.porder[i];
+            P.porder.swap(sorted);
+        }
+        if (P.pt_hi <= P.pt_lo) P.pt_lo = P.pt_hi = 0;
     } else
     // shard = contiguous range of the processing order balanced by observation count
     {
@@ -676,11 +797,13 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         };
         std::vector<double> a(P.z0), b(P.z_prw), c(P.z_prv);
         std::vector<uint8_t> e(P.z_est);
-        for (int64_t zi = P.NS; zi < P.NZ; ++zi) {
-            const int64_t q = zperm(zi);
-            P.z0[q] = a[zi]; P.z_prw[q] = b[zi]; P.z_prv[q] = c[zi]; P.z_est[q] = e[zi];
-        }
-        for (auto &v : P.x2z) v = zperm(v);
+        par.run(np, [&](int64_t plo, int64_t phi, int) {        // (whole points per thread: z_est is a byte array)
+            for (int64_t zi = P.NS + 3 * plo; zi < P.NS + 3 * phi; ++zi) {
+                const int64_t q = zperm(zi);
+                P.z0[q] = a[zi]; P.z_prw[q] = b[zi]; P.z_prv[q] = c[zi]; P.z_est[q] = e[zi];
+            }
+        });
+        par.run((int64_t)P.x2z.size(), [&](int64_t lo_, int64_t hi_, int) { for (int64_t i = lo_; i < hi_; ++i) P.x2z[i] = zperm(P.x2z[i]); });
         for (auto &v : P.prior_z) v = zperm(v);
     }
     // z_mine: who counts an entry in the sums over z (and supplies it to the gathered result).  OP: the
@@ -700,15 +823,53 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
 
     lapt("permutation of the point arrays, z_mine");
     // ---- batches of whole points, at most BT observations each; tiles of
-    // batches touching at most CMAX cameras (fixed-IO path only)
+    // batches touching at most CMAX cameras (fixed-IO path only).
+    // Two stages.  DECISIONS (one thread; it only reads the camera lists of the points): where every point's
+    // observations start, batch / tile / signature-group boundaries, the chunk list.  COPIES (all threads): the
+    // per-observation arrays in processing order, the tile-local camera indices, the slot-major and the camera-major
+    // copies of the image coordinates -- everything that is proportional to the number of observations.
     P.batch_start.clear(); P.batch_start.push_back(0);
     P.giant_start.clear();
-    int64_t nobs_shard = 0;
-    for (int64_t i = P.pt_lo; i < P.pt_hi; ++i) nobs_shard += k_pt[P.porder[i]];
+    // Where a point's observations start does not depend on any decision: a prefix sum over the processing order.
+    // So the arrays that only depend on it are copied FIRST, by all threads -- and the decisions then read the
+    // cameras of the points as one contiguous stream (P.o_cam) instead of chasing the points through memory.
+    const int64_t n_sh = P.pt_hi - P.pt_lo;
+    uvec<int32_t> kk((size_t)n_sh);                  // observations of the point at processing index pt_lo + is
+    uvec<uint8_t> pfl((size_t)n_sh);                 // 1: giant, 2: heavy
+    uvec<int64_t> pt_pos((size_t)n_sh + 1);          // first observation
+    par.run(n_sh, [&](int64_t lo_, int64_t hi_, int) {
+        for (int64_t is = lo_; is < hi_; ++is) {
+            const int32_t p = P.porder[P.pt_lo + is];
+            kk[is] = k_pt[p]; pfl[is] = (uint8_t)((giant[p] ? 1 : 0) | (heavy[p] ? 2 : 0));
+        }
+    });
+    pt_pos[0] = 0;
+    for (int64_t is = 0; is < n_sh; ++is) pt_pos[is + 1] = pt_pos[is] + kk[is];
+    const int64_t nobs_shard = pt_pos[n_sh];
     P.o_cam.resize(nobs_shard); P.o_pt.resize(nobs_shard); P.o_uv.resize(2 * nobs_shard);
-    P.o_seg.resize(nobs_shard); P.o_row.resize(nobs_shard); P.o_lc.assign(nobs_shard, 0);
-    P.o_pidx.assign(nobs_shard, 0);
+    P.o_seg.resize(nobs_shard); P.o_row.resize(nobs_shard); P.o_lc.resize(nobs_shard);
+    P.o_pidx.resize(nobs_shard);
     if (!P.uniform_w) P.o_w.resize(2 * nobs_shard);
+    par.run(n_sh, [&](int64_t lo_, int64_t hi_, int) {
+        for (int64_t is = lo_; is < hi_; ++is) {
+            int64_t q = pt_pos[is];
+            const int32_t p = P.porder[P.pt_lo + is];
+            const int k = kk[is];
+            const int32_t rk = P.pt_rank[p];
+            for (int j = 0; j < k; ++j, ++q) {
+                const int64_t o = by_pt[pstart[p] + j];
+                const int32_t c = cbp[pstart[p] + j];
+                P.o_cam[q] = c; P.o_pt[q] = rk;
+                P.o_uv[2 * q] = pb.ip_val[2 * o]; P.o_uv[2 * q + 1] = pb.ip_val[2 * o + 1];
+                P.o_row[q] = o;
+                if (!P.uniform_w) {
+                    P.o_w[2 * q] = 1.0 / (pb.ip_std[2 * o] * P.px[2 * c]);
+                    P.o_w[2 * q + 1] = 1.0 / (pb.ip_std[2 * o + 1] * P.px[2 * c + 1]);
+                }
+            }
+        }
+    }, 1024);
+    lapt("copies: observations in processing order");
     P.tile_batch.clear(); P.tile_cam_start.clear(); P.tile_cams.clear();
     P.tile_batch.push_back(0); P.tile_cam_start.push_back(0);
     std::vector<int32_t> stamp(nc, -1);              // tile id in which a camera was last seen
@@ -717,10 +878,14 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     P.tile_io_start.clear(); P.tile_iocols.clear(); P.tile_cam_io.clear(); P.tile_io_simple.clear();
     P.tile_io_start.push_back(0);
     int64_t pos = 0, bstart = 0, tile_first_obs = 0;
+    // what the later copies need to know about a point of the shard (index i - pt_lo)
+    uvec<uint32_t> pt_seg((size_t)n_sh);             // segment word (0: a giant point)
+    uvec<uint8_t> pt_pidx((size_t)n_sh);             // ordinal inside its batch
+    std::vector<int64_t> tile_obs0;                  // [ntiles + 1] observation range of every tile
+    struct GroupRec { int64_t pos0, npts; int k; };
+    std::vector<GroupRec> groups;                    // signature groups (slot-major copy of their image coordinates)
     // signature groups of the current tile
     P.sg_chunk.clear(); P.sg_tile_chunk0.assign(1, 0); P.sg_lc.clear(); P.sg_gcam.clear(); P.sg_kmax = 0; P.sg_rows_max = 0; P.sg_ngroups = 0; P.sg_npoints = 0;
-    P.sg_uv.assign(P.o_uv.size(), 0.0);
-    if (!P.uniform_w) P.sg_w.assign(P.o_w.size(), 0.0); else P.sg_w.clear();
     std::vector<int32_t> sg_gc;                      // global camera of every sg_lc entry (converted when the tile closes)
     size_t sg_lc_tile0 = 0;
     std::vector<int32_t> g_cams;                     // cameras of the open group
@@ -737,12 +902,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
             P.sg_chunk.insert(P.sg_chunk.end(), ch, ch + 8);
             for (int j = 0; j < 16; ++j) sg_gc.push_back(j < k ? g_cams[j] : -1);      // 16 camera slots per chunk
         }
-        for (int64_t i = 0; i < g_npts; ++i)         // slot-major copy of the group's image coordinates
-            for (int j = 0; j < k; ++j) {
-                const int64_t src = g_pos0 + i * k + j, dst = g_pos0 + (int64_t)j * g_npts + i;
-                P.sg_uv[2 * dst] = P.o_uv[2 * src]; P.sg_uv[2 * dst + 1] = P.o_uv[2 * src + 1];
-                if (!P.uniform_w) { P.sg_w[2 * dst] = P.o_w[2 * src]; P.sg_w[2 * dst + 1] = P.o_w[2 * src + 1]; }
-            }
+        groups.push_back(GroupRec{g_pos0, g_npts, k});
         P.sg_kmax = std::max(P.sg_kmax, k);
         ++P.sg_ngroups; P.sg_npoints += g_npts;
         g_npts = 0; g_cams.clear();
@@ -753,7 +913,8 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         std::sort(cur_cams.begin(), cur_cams.end());
         std::vector<int32_t> &loc = stamp;            // reuse as cam -> local index (restored below)
         for (size_t l = 0; l < cur_cams.size(); ++l) loc[cur_cams[l]] = (int32_t)l;
-        for (int64_t o = tile_first_obs; o < end_obs; ++o) P.o_lc[o] = (uint8_t)loc[P.o_cam[o]];
+        if (tile_obs0.empty()) tile_obs0.push_back(tile_first_obs);
+        tile_obs0.push_back(end_obs);                 // (o_lc of the tile's observations: in the copy stage)
         // IO columns of the tile, ascending; every camera's IO columns -> local IO rows
         std::sort(cur_io.begin(), cur_io.end());
         // k_build_sig's per-point IO rows: 1 = one IO block (IO column q = tile IO row q, every camera the same
@@ -810,15 +971,16 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     lapt("batches, tiles, signature groups");
     // batches per tile: long tiles amortise the flush of the tile into S, but a small
     // problem must still break into enough tiles to occupy the 256 CUs twice over
-    int64_t shard_obs = 0;
-    for (int64_t i = P.pt_lo; i < P.pt_hi; ++i) shard_obs += k_pt[P.porder[i]];
+    const int64_t shard_obs = nobs_shard;
     const int bmax_auto = (int)std::min<int64_t>(48, std::max<int64_t>(4, (shard_obs / std::max(1, P.BT) + 511) / 512));
     const int tile_bmax = bmax_auto;
     for (int64_t i = P.pt_lo; i < P.pt_hi; ++i) {
-        const int32_t p = P.porder[i];
-        const int k = k_pt[p];
+        const int64_t is = i - P.pt_lo;
+        const int k = kk[is];
+        pt_seg[is] = 0; pt_pidx[is] = 0;
         if (k == 0) continue;
-        if (giant[p]) {
+        const int32_t *cp = P.o_cam.data() + pos;    // (pos == pt_pos[is])
+        if (pfl[is] & 1) {
             if (P.giant_start.empty()) {
                 // first giant point: close the last batch (and tile); what follows is outside the batches
                 if (pos > bstart) { P.batch_start.push_back(pos); bstart = pos; }
@@ -829,22 +991,12 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
                     P.nb_tiled = (int64_t)P.batch_start.size() - 1;
                 }
             }
-            P.giant_start.push_back(pos);
-            for (int j = 0; j < k; ++j, ++pos) {
-                const int64_t o = by_pt[pstart[p] + j];
-                const int32_t c = pb.ip_cam[o];
-                P.o_cam[pos] = c; P.o_pt[pos] = P.pt_rank[p];
-                P.o_uv[2 * pos] = pb.ip_val[2 * o]; P.o_uv[2 * pos + 1] = pb.ip_val[2 * o + 1];
-                P.o_seg[pos] = 0; P.o_row[pos] = o;
-                if (!P.uniform_w) {
-                    P.o_w[2 * pos] = 1.0 / (pb.ip_std[2 * o] * P.px[2 * c]);
-                    P.o_w[2 * pos + 1] = 1.0 / (pb.ip_std[2 * o + 1] * P.px[2 * c + 1]);
-                }
-            }
+            P.giant_start.push_back(pos);            // (segment word 0, ordinal 0)
+            pos += k;
             bstart = pos;
             continue;
         }
-        if (P.CMAX && heavy[p] && !in_heavy) {
+        if (P.CMAX && (pfl[is] & 2) && !in_heavy) {
             // first heavy point: close the last tile; the remaining batches are not tiled
             if (pos > bstart) { P.batch_start.push_back(pos); bstart = pos; }
             for (int32_t c : cur_cams) stamp[c] = -1;
@@ -856,7 +1008,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
             int fresh = 0, fresh_io = 0;
             int32_t fio[Plan::IOT + 1];
             for (int j = 0; j < k; ++j) {
-                const int32_t c = pb.ip_cam[by_pt[pstart[p] + j]];
+                const int32_t c = cp[j];
                 if (stamp[c] == tile_id) continue;
                 ++fresh;
                 for (int q = 6; q < P.cam_ncol[c]; ++q) {
@@ -885,33 +1037,28 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         if (pos == bstart) pidx = 0;
         if (P.CMAX && !in_heavy) {                   // same cameras as the previous point of the tile: same group
             bool same = g_npts > 0 && (int)g_cams.size() == k && g_npts < (1 << 20);
-            for (int j = 0; same && j < k; ++j) same = g_cams[j] == pb.ip_cam[by_pt[pstart[p] + j]];
+            for (int j = 0; same && j < k; ++j) same = g_cams[j] == cp[j];
             if (!same) {
                 close_group();
                 g_pos0 = pos; g_rank0 = i;
-                for (int j = 0; j < k; ++j) g_cams.push_back(pb.ip_cam[by_pt[pstart[p] + j]]);
+                g_cams.assign(cp, cp + k);
             }
             ++g_npts;
         }
-        const uint32_t seg = (uint32_t)(pos - bstart) | ((uint32_t)k << 16);
-        for (int j = 0; j < k; ++j, ++pos) {
-            const int64_t o = by_pt[pstart[p] + j];
-            const int32_t c = pb.ip_cam[o];
-            P.o_cam[pos] = c; P.o_pt[pos] = P.pt_rank[p];
-            P.o_uv[2 * pos] = pb.ip_val[2 * o]; P.o_uv[2 * pos + 1] = pb.ip_val[2 * o + 1];
-            P.o_seg[pos] = seg; P.o_row[pos] = o; P.o_pidx[pos] = (uint8_t)pidx;
-            if (!P.uniform_w) {
-                P.o_w[2 * pos] = 1.0 / (pb.ip_std[2 * o] * P.px[2 * c]);
-                P.o_w[2 * pos + 1] = 1.0 / (pb.ip_std[2 * o + 1] * P.px[2 * c + 1]);
-            }
-            if (P.CMAX && !in_heavy && stamp[c] != tile_id) {
-                stamp[c] = tile_id; cur_cams.push_back(c);
-                for (int q = 6; q < P.cam_ncol[c]; ++q) {
-                    const int32_t io = P.cam_col[(size_t)c * MAXCOL + q] - 6 * nc;
-                    if (io_stamp[io] != tile_id) { io_stamp[io] = tile_id; cur_io.push_back(io); }
+        pt_seg[is] = (uint32_t)(pos - bstart) | ((uint32_t)k << 16);
+        pt_pidx[is] = (uint8_t)pidx;
+        if (P.CMAX && !in_heavy)
+            for (int j = 0; j < k; ++j) {
+                const int32_t c = cp[j];
+                if (stamp[c] != tile_id) {
+                    stamp[c] = tile_id; cur_cams.push_back(c);
+                    for (int q = 6; q < P.cam_ncol[c]; ++q) {
+                        const int32_t io = P.cam_col[(size_t)c * MAXCOL + q] - 6 * nc;
+                        if (io_stamp[io] != tile_id) { io_stamp[io] = tile_id; cur_io.push_back(io); }
+                    }
                 }
             }
-        }
+        pos += k;
         ++pidx;
     }
     if (!P.giant_start.empty()) P.giant_start.push_back(pos);
@@ -922,6 +1069,47 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         P.nb_tiled = (int64_t)P.batch_start.size() - 1;
     }
     if (!P.CMAX) P.nb_tiled = 0;
+    lapt("decisions: batches, tiles, signature groups (one thread)");
+    // ---- the copies that depend on the decisions
+    par.run(n_sh, [&](int64_t lo_, int64_t hi_, int) {
+        for (int64_t is = lo_; is < hi_; ++is) {
+            const uint32_t seg = pt_seg[is];
+            const uint8_t pi = pt_pidx[is];
+            for (int64_t q = pt_pos[is]; q < pt_pos[is + 1]; ++q) { P.o_seg[q] = seg; P.o_pidx[q] = pi; P.o_lc[q] = 0; }
+        }
+    }, 1024);
+    {   // tile-local camera index of every tiled observation
+        const int64_t nt_ = (int64_t)tile_obs0.size() - 1;
+        par.run(std::max<int64_t>(nt_, 0), [&](int64_t lo_, int64_t hi_, int) {
+            std::vector<int32_t> loc(nc, 0);
+            for (int64_t t = lo_; t < hi_; ++t) {
+                for (int32_t l = P.tile_cam_start[t]; l < P.tile_cam_start[t + 1]; ++l) loc[P.tile_cams[l]] = l - P.tile_cam_start[t];
+                for (int64_t o = tile_obs0[t]; o < tile_obs0[t + 1]; ++o) P.o_lc[o] = (uint8_t)loc[P.o_cam[o]];
+            }
+        }, 4);
+    }
+    {   // slot-major copy of every signature group's image coordinates (zeros where there is no group)
+        P.sg_uv.resize(P.o_uv.size());
+        if (!P.uniform_w) P.sg_w.resize(P.o_w.size()); else P.sg_w.clear();
+        const int64_t tiled_end = tile_obs0.empty() ? 0 : tile_obs0.back();
+        par.run(nobs_shard - tiled_end, [&](int64_t lo_, int64_t hi_, int) {
+            std::fill(P.sg_uv.begin() + 2 * (tiled_end + lo_), P.sg_uv.begin() + 2 * (tiled_end + hi_), 0.0);
+            if (!P.uniform_w) std::fill(P.sg_w.begin() + 2 * (tiled_end + lo_), P.sg_w.begin() + 2 * (tiled_end + hi_), 0.0);
+        }, 1 << 16);
+        par.run((int64_t)groups.size(), [&](int64_t lo_, int64_t hi_, int) {
+            for (int64_t g = lo_; g < hi_; ++g) {
+                const int64_t g0 = groups[g].pos0, m = groups[g].npts;
+                const int k = groups[g].k;
+                for (int64_t i = 0; i < m; ++i)
+                    for (int j = 0; j < k; ++j) {
+                        const int64_t src = g0 + i * k + j, dst = g0 + (int64_t)j * m + i;
+                        P.sg_uv[2 * dst] = P.o_uv[2 * src]; P.sg_uv[2 * dst + 1] = P.o_uv[2 * src + 1];
+                        if (!P.uniform_w) { P.sg_w[2 * dst] = P.o_w[2 * src]; P.sg_w[2 * dst + 1] = P.o_w[2 * src + 1]; }
+                    }
+            }
+        }, 64);
+    }
+    lapt("copies: segment words, tile-local cameras, slot-major coordinates");
     {   // launch the longest tiles first
         const int nt = (int)P.tile_batch.size() - 1;
         P.tile_order.resize(std::max(nt, 0));
@@ -936,23 +1124,36 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     }
     {   // camera-major copy of the observations (stable counting sort by camera): first the tiled
         // ones (chunks [0, n_cm_chunks_tiled): k_cam_normal), then the rest (heavy / giant points);
-        // k_residual_cm runs over all chunks
+        // k_residual_cm runs over all chunks.  In parallel: the range is cut into blocks, every block counts its
+        // cameras (nc counters per block: small), a prefix over (camera, block) gives every block its place.
         const int64_t ntiled = P.nb_tiled > 0 ? P.batch_start[P.nb_tiled] : 0;
         const int64_t nall = (int64_t)P.o_cam.size();
         P.cm_pt.resize(nall); P.cm_uv.resize(2 * nall);
         if (!P.uniform_w) P.cm_w.resize(2 * nall); else P.cm_w.clear();
         P.cm_chunk_cam.clear(); P.cm_chunk_start.clear();
         auto part = [&](int64_t lo, int64_t hi) {
+            const int nbk = par.ranges(hi - lo, 1 << 15);
+            std::vector<std::vector<int64_t>> cntb(nbk, std::vector<int64_t>((size_t)nc, 0));
+            const Par pk{nbk};
+            pk.run(hi - lo, [&](int64_t a_, int64_t b_, int tid) {
+                std::vector<int64_t> &cn = cntb[tid];
+                for (int64_t o = lo + a_; o < lo + b_; ++o) ++cn[P.o_cam[o]];
+            }, 1);
             std::vector<int64_t> cnt((size_t)nc + 1, 0);
-            for (int64_t o = lo; o < hi; ++o) ++cnt[(size_t)P.o_cam[o] + 1];
-            for (int c = 0; c < nc; ++c) cnt[c + 1] += cnt[c];
-            std::vector<int64_t> fillc(cnt.begin(), cnt.end() - 1);
-            for (int64_t o = lo; o < hi; ++o) {
-                const int64_t q = lo + fillc[P.o_cam[o]]++;
-                P.cm_pt[q] = P.o_pt[o];
-                P.cm_uv[2 * q] = P.o_uv[2 * o]; P.cm_uv[2 * q + 1] = P.o_uv[2 * o + 1];
-                if (!P.uniform_w) { P.cm_w[2 * q] = P.o_w[2 * o]; P.cm_w[2 * q + 1] = P.o_w[2 * o + 1]; }
+            for (int c = 0; c < nc; ++c) {
+                int64_t run = cnt[c];
+                for (int t = 0; t < nbk; ++t) { const int64_t v = cntb[t][c]; cntb[t][c] = run; run += v; }
+                cnt[c + 1] = run;
             }
+            pk.run(hi - lo, [&](int64_t a_, int64_t b_, int tid) {
+                std::vector<int64_t> &fillc = cntb[tid];
+                for (int64_t o = lo + a_; o < lo + b_; ++o) {
+                    const int64_t q = lo + fillc[P.o_cam[o]]++;
+                    P.cm_pt[q] = P.o_pt[o];
+                    P.cm_uv[2 * q] = P.o_uv[2 * o]; P.cm_uv[2 * q + 1] = P.o_uv[2 * o + 1];
+                    if (!P.uniform_w) { P.cm_w[2 * q] = P.o_w[2 * o]; P.cm_w[2 * q + 1] = P.o_w[2 * o + 1]; }
+                }
+            }, 1);
             for (int c = 0; c < nc; ++c)
                 for (int64_t s0 = cnt[c]; s0 < cnt[c + 1]; s0 += Plan::CM_CHUNK) {
                     P.cm_chunk_cam.push_back(c); P.cm_chunk_start.push_back(lo + s0);

@@ -348,7 +348,9 @@ int  dbat_hip_set_x(dbat_hip_handle *h, const double *x);
  * several ranks: info[8]=1 domain sharding (0: replicated factorisation) info[9]=doubles of the reduced
  * system summed per factorisation (top tiles / the envelope) info[10]=doubles summed as vectors per
  * linearisation info[11]=images in the top separators info[12]=tile rows of the factor
- * info[13], info[14]=tasks of the two launches of the factorisation; info[15]=0 */
+ * info[13], info[14]=tasks of the two launches of the factorisation
+ * info[15]=v_mfma_f64_16x16x4_f64 instructions (2048 flops each) one launch of the tile kernel executes (its symmetric
+ * products; the algorithmic count of the roofline is the full product) */
 int  dbat_hip_info(const dbat_hip_handle *h, int64_t *info /*[16]*/);
 
 /* Host only (no GPU): statistics of the layout the plan gives this problem (this shard), so that a test

@@ -181,15 +181,12 @@ def test_c_driver_plan_matches_python_binding(case, tmp_path):
 
 def test_plan_under_sanitizers(tmp_path):
     """plan.hpp (index building, matching, ordering, batches, tiles, signature chunks -- all host
-    code) compiled with -fsanitize=address,undefined and run on dumped problems, one and three
-    shards: no report, and every tiled point is in exactly one signature chunk."""
+    code, threaded since round 4: csrc/par.hpp) compiled with -fsanitize=address,undefined and, separately, with
+    -fsanitize=thread, run on dumped problems with one and with five threads (ranges cut down to single elements,
+    so that the tiny scenes take the threaded paths), one and three shards: no report, and every tiled point is in
+    exactly one signature chunk."""
     import subprocess
     from helpers import dump_problem
-    exe = str(tmp_path / 'asan_plan')
-    subprocess.run(['g++', '-std=c++17', '-g', '-O1', '-fsanitize=address,undefined', '-fno-sanitize-recover=all',
-                    '-fno-omit-frame-pointer', '-D__HIP_PLATFORM_AMD__', '-I/opt/rocm/include',
-                    '-I' + os.path.join(ROOT, 'include'), os.path.join(ROOT, 'tests', 'asan_plan.cpp'), '-o', exe],
-                   check=True, capture_output=True)
     paths = []
     for i, (name, variant) in enumerate([('tiny', 'plain'), ('tiny', 'priors'), ('tiny', 'groups4'), ('tiny', 'imagevar'),
                                          ('small', 'selfcal')]):
@@ -201,12 +198,47 @@ def test_plan_under_sanitizers(tmp_path):
     s.EO.struct.block[0:3, 2] = s.EO.struct.block[0:3, 1]
     paths.append(str(tmp_path / 'shared.bin'))
     dump_problem(s, paths[-1])
-    r = subprocess.run([exe] + paths, capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS='detect_leaks=1'))
-    assert r.returncode == 0 and 'ERROR' not in r.stderr and 'runtime error' not in r.stderr, r.stderr[-3000:]
-    lines = r.stdout.strip().splitlines()
-    assert len(lines) == 4 * len(paths) and not any('rejected' in l for l in lines), r.stdout
+    outs = []
+    for san in ('address,undefined', 'thread'):
+        exe = str(tmp_path / ('plan_' + san.split(',')[0]))
+        subprocess.run(['g++', '-std=c++17', '-g', '-O1', '-pthread', '-fsanitize=' + san, '-fno-sanitize-recover=all',
+                        '-fno-omit-frame-pointer', '-D__HIP_PLATFORM_AMD__', '-I/opt/rocm/include',
+                        '-I' + os.path.join(ROOT, 'include'), os.path.join(ROOT, 'tests', 'asan_plan.cpp'), '-o', exe],
+                       check=True, capture_output=True)
+        for threads in ('1', '5'):
+            env = dict(os.environ, ASAN_OPTIONS='detect_leaks=1', DBAT_HIP_PLAN_THREADS=threads, DBAT_HIP_PLAN_GRAIN='1')
+            r = subprocess.run([exe] + paths, capture_output=True, text=True, env=env)
+            assert r.returncode == 0 and 'ERROR' not in r.stderr and 'runtime error' not in r.stderr and 'WARNING: ThreadSanitizer' not in r.stderr, \
+                (san, threads, r.stderr[-3000:])
+            outs.append(r.stdout)
+    assert all(o_ == outs[0] for o_ in outs)
+    lines = outs[0].strip().splitlines()
+    assert len(lines) == 4 * len(paths) and not any('rejected' in l for l in lines), outs[0]
     first = [l for l in lines if 'p0.bin rank 0/1' in l][0]
     assert 'chunks' in first and '(300 pts)' in first
+
+
+@pytest.mark.parametrize('case', ['tiny-plain', 'tiny-priors', 'tiny-groups4', 'tiny-imagevar', 'small-selfcal', 'camcal', 'C1'])
+def test_plan_identical_for_any_number_of_threads(case, monkeypatch):
+    """The host plan is built by several threads (csrc/par.hpp); its result must not depend on how many: the digest
+    of EVERY array of the plan (dbat_hip_debug_plan_digest) is the same for 1, 2, 3 and 7 threads, with the ranges cut
+    down to single elements, for one rank and for rank 1 of 3."""
+    from dbat_amd import synth
+    if case == 'camcal':
+        s = camcal_struct(3)
+    elif case == 'C1':
+        s = synth.make_scene('C1')[0]
+    else:
+        s = synth_struct(*case.split('-'))[0]
+    monkeypatch.setenv('DBAT_HIP_PLAN_GRAIN', '1' if case != 'C1' else '64')
+    ref = None
+    for threads in ('1', '2', '3', '7'):
+        monkeypatch.setenv('DBAT_HIP_PLAN_THREADS', threads)
+        d = (_hip.plan_digest(s, 0, 1), _hip.plan_digest(s, 1, 3))
+        assert len(d[0]) > 40
+        if ref is None:
+            ref = d
+        assert d == ref, [k for k in ref[0] if d[0][k] != ref[0][k]] + [k for k in ref[1] if d[1][k] != ref[1][k]]
 
 
 def test_plan_layout_stats_long_groups():
