@@ -126,6 +126,8 @@ def main():
     ap.add_argument('--config', default='C3')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-solve', action='store_true', help='skip the timed dbat_hip_solve("lm") run')
+    ap.add_argument('--deterministic', action='store_true',
+                    help='fixed-order sums into the reduced system (dbat_hip_set_deterministic: bit-identical runs); reports what that costs')
     ap.add_argument('--emulate-ranks', type=int, default=0, metavar='R',
                     help='one GPU plays rank 0 of R (its share of the points, its domain of the reduced system, the '
                          'collectives replaced by no-ops): per-rank phase times for the scaling estimate of DESIGN.md 6; '
@@ -186,6 +188,8 @@ def main():
         comm.attach(h)                       # ncclCommInitRank inside the library
     if emu:
         h.set_allreduce(lambda ptr, count, stream: 0)       # the sums over the ranks: not performed
+    if args.deterministic:
+        h.set_deterministic(True)
     info = h.info()
     x0 = h.serialize()
     h.set_x(x0)
@@ -351,7 +355,7 @@ def main():
             'metric': 'LM iterations/sec', 'value': None if emu else args.steps / dt, 'unit': 'it/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'ms_per_step_min_median_max': [float(te[0]), float(te[len(te) // 2]), float(te[-1])],
-            'higher_is_better': True, 'scaling': 'strong',
+            'higher_is_better': True, 'scaling': 'strong', 'deterministic_sums': bool(args.deterministic),
             'vs_baseline': None, 'dtype': 'f64', 'data': ('the reference\'s demo project (fixtures under tests/golden)' if real else 'synthetic'),
             'config': {'workload': '%s: %d cams / %d pts / %d obs, %s, LM step (J\'J build + Schur '
                                    'solve + back-substitution + trial residual)'

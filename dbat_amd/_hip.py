@@ -98,6 +98,7 @@ SYMBOLS = {
     'dbat_hip_structural_rank_ok': (C.c_int, [_H, C.POINTER(C.c_int32)]),
     'dbat_hip_residual': (C.c_int, [_H, _dp, _dp, _dp]),
     'dbat_hip_jacobian_blocks': (C.c_int, [_H, _dp, _dp, _dp, _dp]),
+    'dbat_hip_jacobian_sample': (C.c_int, [_H, _dp, C.c_int64, C.POINTER(C.c_int64), _dp, _dp, _dp, _dp]),
     'dbat_hip_linearize_solve': (C.c_int, [_H, _dp, C.c_double, C.c_int32, _dp, _dp]),
     'dbat_hip_jacobian_csc': (C.c_int, [_H, _dp, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), _dp]),
     'dbat_hip_gradient': (C.c_int, [_H, _dp]),
@@ -108,6 +109,7 @@ SYMBOLS = {
     'dbat_hip_comm_unique_id': (C.c_int, [_bp]),
     'dbat_hip_comm_init': (C.c_int, [_H, _bp]),
     'dbat_hip_comm_allreduce_host': (C.c_int, [_H, _dp, C.c_int64, C.c_int32]),
+    'dbat_hip_set_deterministic': (C.c_int, [_H, C.c_int32]),
     'dbat_hip_set_allreduce': (C.c_int, [_H, ALLREDUCE_FN, C.c_void_p]),
     'dbat_hip_owned_mask': (C.c_int, [_H, _bp]),
     'dbat_hip_forwintersect': (C.c_int, [_H, _dp, _bp, _dp]),
@@ -293,6 +295,18 @@ class Handle:
         return (JEO.reshape(no, 6, 2).transpose(0, 2, 1), JOP.reshape(no, 3, 2).transpose(0, 2, 1),
                 JIO.reshape(no, R, 2).transpose(0, 2, 1))
 
+    def jacobian_sample(self, x, ip_cols):
+        """Residual and Jacobian blocks of the image observations ip_cols (IP columns, 0-based): (r n x 2, JEO n x 2 x 6,
+        JOP n x 2 x 3, JIO n x 2 x nIOrows)."""
+        idx = np.ascontiguousarray(ip_cols, np.int64)
+        n, R = idx.size, 5 + self.prob.nK + self.prob.nP
+        x = np.ascontiguousarray(x, float)
+        r, JEO, JOP, JIO = np.zeros(2 * n), np.zeros(12 * n), np.zeros(6 * n), np.zeros(2 * R * n)
+        check(self.lib.dbat_hip_jacobian_sample(self.h, dptr(x), n, idx.ctypes.data_as(C.POINTER(C.c_int64)), dptr(r), dptr(JEO),
+                                                dptr(JOP), dptr(JIO)))
+        return (r.reshape(n, 2), JEO.reshape(n, 6, 2).transpose(0, 2, 1), JOP.reshape(n, 3, 2).transpose(0, 2, 1),
+                JIO.reshape(n, R, 2).transpose(0, 2, 1))
+
     def jacobian_csc(self, x, weighted=True):
         """J at x as scipy.sparse.csc_matrix (m x n): E.final.weighted.J / unweighted.J of bundle.m:341-350."""
         import scipy.sparse as sp
@@ -357,6 +371,10 @@ class Handle:
         sk = None if skip is None else np.ascontiguousarray(np.asarray(skip, bool).astype(np.uint8))
         check(self.lib.dbat_hip_forwintersect(self.h, dptr(x), None if sk is None else sk.ctypes.data_as(_bp), dptr(out)))
         return out.reshape(3, -1, order='F')
+
+    def set_deterministic(self, on=True):
+        """Fixed-order sums into the reduced system (bit-identical runs); DbatHipError(EUNSUPPORTED) off the signature path."""
+        check(self.lib.dbat_hip_set_deterministic(self.h, int(bool(on))))
 
     def build_kernel_name(self):
         buf = C.create_string_buffer(64)

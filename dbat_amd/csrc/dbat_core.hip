@@ -110,6 +110,10 @@ struct Core {
     DevBuf<int32_t> cam_ncol, cam_col, cam_iorow, io_src, o_cam, o_pt;
     DevBuf<uint32_t> cam_eo_est, o_seg;
     DevBuf<double> io_fixed, px, cam_w, z_prw, z_prv, o_uv, o_w;
+    // deterministic mode (dbat_hip_set_deterministic): ticket counters and the turn of every tile / chunk at them
+    bool deterministic = false;
+    DevBuf<unsigned> det_ctr;           // [nc | nc | 2]
+    DevBuf<int32_t> tile_cam_seq, tile_io_seq, cm_chunk_seq;
     DevBuf<double> o_rhs;               // fixed IO: the corrected image coordinates (k_uv_to_rhs), what d.o_uv points at
     bool uv_pre = false;
     DevBuf<uint8_t> z_est, z_mine, o_lc, o_pidx;
@@ -247,6 +251,8 @@ struct Core {
         d.o_cam = o_cam.p; d.o_pt = o_pt.p; d.o_uv = o_uv.p; d.o_w = P.uniform_w ? nullptr : o_w.p;
         d.o_seg = o_seg.p; d.o_row = o_row.p; d.batch_start = batch_start.p;
         d.CMAX = P.CMAX; d.ablate = env_int("DBAT_HIP_ABLATE", 0); d.trace_only = 0;
+        d.deterministic = 0; d.det_cam_turn = d.det_cm_turn = d.det_io_turn = nullptr;
+        d.tile_cam_seq = d.tile_io_seq = d.cm_chunk_seq = nullptr;
         env_df_trace = env_get("DBAT_HIP_DF_TRACE");
         d.ntiles = (int)ntiles; d.o_lc = o_lc.p; d.o_pidx = o_pidx.p;
         tile_order.upload(P.tile_order); d.tile_order = tile_order.p;
@@ -591,9 +597,48 @@ struct Core {
         return 0.5 * s;
     }
 
+    // Deterministic mode: sums into the reduced system in a fixed order (kernels.hpp DevProblem::deterministic).
+    // Covered: the signature-group path with its camera-side kernels, the factorisation and the back-substitution
+    // (the latter two are order-fixed by construction).  Not covered: heavy / giant points and the tile kernels of
+    // irregular scenes (LDS and global atomics per observation), several ranks.
+    bool deterministic_supported() const {
+        return use_sig && ntiles > 0 && nb == P.nb_tiled && ngiant == 0 && P.nranks == 1 && tile_ncx <= 14;
+    }
+    void set_deterministic(bool on) {
+        if (on && !deterministic_supported())
+            throw UsageError{"deterministic mode covers the signature-group path on one rank (no heavy or giant points, no irregular-visibility tile kernels)"};
+        if (on && !det_ctr.p) {
+            const int nc = P.nc;
+            det_ctr.alloc((size_t)2 * nc + 2);
+            std::vector<int32_t> cs(P.tile_cams.size(), 0), ios((size_t)ntiles, -1), cnt((size_t)nc, 0);
+            int32_t io_n = 0;
+            for (int64_t i = 0; i < ntiles; ++i) {              // launch order
+                const int32_t t = P.tile_order[i];
+                for (int32_t l = P.tile_cam_start[t]; l < P.tile_cam_start[t + 1]; ++l) cs[l] = cnt[P.tile_cams[l]]++;
+                if (tile_ncx > 6 && P.tile_io_start[t + 1] > P.tile_io_start[t]) ios[t] = io_n++;
+            }
+            std::vector<int32_t> qs((size_t)n_cm_chunks_all, 0);
+            if (tile_ncx > 6) { for (int64_t q = 0; q < n_cm_chunks_all; ++q) qs[q] = (int32_t)q; }   // shared IO rows: one global order
+            else {
+                int64_t first = 0;
+                for (int64_t q = 0; q < n_cm_chunks_all; ++q) {
+                    if (q > 0 && P.cm_chunk_cam[q] != P.cm_chunk_cam[q - 1]) first = q;
+                    if (q == n_cm_chunks) first = q;                        // (the untiled part starts over; it is not used here)
+                    qs[q] = (int32_t)(q - first);
+                }
+            }
+            tile_cam_seq.upload(cs); tile_io_seq.upload(ios); cm_chunk_seq.upload(qs);
+        }
+        deterministic = on;
+        d.deterministic = on ? 1 : 0;
+        d.det_cam_turn = det_ctr.p; d.det_cm_turn = det_ctr.p ? det_ctr.p + P.nc : nullptr; d.det_io_turn = det_ctr.p ? det_ctr.p + 2 * (size_t)P.nc : nullptr;
+        d.tile_cam_seq = tile_cam_seq.p; d.tile_io_seq = tile_io_seq.p; d.cm_chunk_seq = cm_chunk_seq.p;
+    }
+
     // ---- K1: linearise at zz with damping lambda; builds the reduced system.
     void build_enqueue(const double *zz, double lambda, int scale) {
         stage(0);
+        if (deterministic) HIPCHK(hipMemsetAsync(det_ctr.p, 0, ((size_t)2 * P.nc + 2) * sizeof(unsigned), stream));
         const bool fused_first = !s_dense_dirty && P.NS >= P.nc;
         if (!fused_first) prep_cams(zz);
         else cams_at_lin = false;
@@ -1457,6 +1502,49 @@ int dbat_hip_jacobian_blocks(dbat_hip_handle *h, const double *x, double *JEO, d
     API_CATCH
 }
 
+int dbat_hip_jacobian_sample(dbat_hip_handle *h, const double *x, int64_t n, const int64_t *ip_col, double *res,
+                             double *JEO, double *JOP, double *JIO) {
+    API_TRY
+    if (!h || !x || n < 0 || (n > 0 && (!ip_col || !res || !JEO || !JOP || !JIO))) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
+    Core &c = *h->core;
+    const Plan &P = c.P;
+    if (P.nranks > 1) { g_err = "dbat_hip_jacobian_sample: one-rank handles only"; return DBAT_HIP_EUNSUPPORTED; }
+    if (n == 0) return DBAT_HIP_OK;
+    // IP column -> position in processing order, for the requested columns only
+    std::vector<int64_t> pos((size_t)n, -1);
+    {
+        std::vector<std::pair<int64_t, int64_t>> want((size_t)n);
+        for (int64_t i = 0; i < n; ++i) {
+            if (ip_col[i] < 0 || ip_col[i] >= P.no) { g_err = "IP column out of range"; return DBAT_HIP_EINVAL; }
+            want[i] = {ip_col[i], i};
+        }
+        std::sort(want.begin(), want.end());
+        const int64_t nobs = (int64_t)P.o_row.size();
+        for (int64_t o = 0; o < nobs; ++o) {
+            auto it = std::lower_bound(want.begin(), want.end(), std::make_pair(P.o_row[o], (int64_t)-1));
+            for (; it != want.end() && it->first == P.o_row[o]; ++it) pos[it->second] = o;
+        }
+    }
+    DeviceGuard dev_guard(c.device);
+    c.x_to_z(x, c.zt.p);
+    c.prep_cams(c.zt.p);
+    DevBuf<int64_t> dpos;
+    dpos.upload(pos);
+    const int R = P.nIOrows;
+    DevBuf<double> dr, a, b, cc;
+    dr.alloc(2 * n); a.alloc(12 * n); b.alloc(6 * n); cc.alloc(2 * (int64_t)R * n);
+#define L_JS(M, dummy) LAUNCHK((k_jac_sample<M>), dim3((unsigned)cdiv(n, 256)), dim3(256), 0, c.stream, c.d, c.zt.p, c.cams.p, n, dpos.p, dr.p, a.p, b.p, cc.p)
+    switch (P.model) { case 2: L_JS(2, 0); break; case 3: L_JS(3, 0); break; case 4: L_JS(4, 0); break; default: L_JS(5, 0); break; }
+#undef L_JS
+    HIPCHK(hipMemcpyAsync(res, dr.p, 2 * n * 8, hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipMemcpyAsync(JEO, a.p, 12 * n * 8, hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipMemcpyAsync(JOP, b.p, 6 * n * 8, hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipMemcpyAsync(JIO, cc.p, 2 * (int64_t)R * n * 8, hipMemcpyDeviceToHost, c.stream));
+    c.sync();
+    return DBAT_HIP_OK;
+    API_CATCH
+}
+
 int dbat_hip_jacobian_csc(dbat_hip_handle *h, const double *x, int32_t weighted, int64_t *nnz_out,
                           int64_t *colptr, int64_t *rowidx, double *val) {
     API_TRY
@@ -1661,6 +1749,20 @@ int dbat_hip_final_residuals(dbat_hip_handle *h, double *r_unweighted, double *r
     Core &c = *h->core;
     DeviceGuard dev_guard(c.device);
     export_residuals(c, c.zlin.p, r_unweighted, r_weighted, nullptr);
+    return DBAT_HIP_OK;
+    API_CATCH
+}
+
+int dbat_hip_set_deterministic(dbat_hip_handle *h, int32_t on) {
+    API_TRY
+    if (!h) { g_err = "null handle"; return DBAT_HIP_EINVAL; }
+    Core &c = *h->core;
+    if (on && !c.deterministic_supported()) {
+        g_err = "deterministic mode covers the signature-group path on one rank (no heavy or giant points, no irregular-visibility tile kernels)";
+        return DBAT_HIP_EUNSUPPORTED;
+    }
+    DeviceGuard dev_guard(c.device);
+    c.set_deterministic(on != 0);
     return DBAT_HIP_OK;
     API_CATCH
 }

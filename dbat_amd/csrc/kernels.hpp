@@ -56,6 +56,15 @@ struct DevProblem {
     int CMAX, ntiles;
     int ablate;                     // measurement builds only (DBAT_HIP_ABLATE, read through DBAT_ABLATE): phases off, phase clocks
     int trace_only;                 // this linearisation serves trace(J'J) alone (levenberg_marquardt.m:88-95): no Schur complement
+    // deterministic mode (dbat_hip_set_deterministic): every sum into S / g_red / g_c / diagU is made in a FIXED order,
+    // so that two runs give the same bits.  Tickets: a tile waits until every one of its cameras has seen all the
+    // earlier tiles (launch order) that contain it; a camera-major chunk waits for the camera's earlier chunks;
+    // whatever touches the shared IO rows goes through one global ticket.
+    int deterministic;
+    unsigned *det_cam_turn, *det_cm_turn, *det_io_turn;   // [nc], [nc], [2] counters, zero at the start of a build
+    const int32_t *tile_cam_seq;    // [#tile cams] what det_cam_turn must show before the tile may add
+    const int32_t *tile_io_seq;     // [ntiles]     ... det_io_turn[0] (-1: the tile has no IO rows)
+    const int32_t *cm_chunk_seq;    // [chunks]     ... det_cm_turn[camera] (fixed IO) / det_io_turn[1] (self-calibration)
     const uint8_t *o_lc, *o_pidx;
     const int32_t *tile_batch, *tile_cam_start, *tile_cams;
     const int32_t *tile_order;                      // launch index -> tile (longest first)
@@ -77,6 +86,15 @@ struct DevProblem {
 
 __device__ __forceinline__ void atomic_add_f64(double *p, double v) {
     unsafeAtomicAdd(p, v);          // global_atomic_add_f64 / ds_add_f64 on gfx950
+}
+
+// deterministic mode: wait until a ticket counter shows `want` (agent scope: the waiting and the signalling workgroup
+// may sit on different XCDs), and hand the turn on after this workgroup's atomics have been performed
+__device__ __forceinline__ void det_wait(const unsigned *ctr, unsigned want) {
+    while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != want) __builtin_amdgcn_s_sleep(2);
+}
+__device__ __forceinline__ void det_pass(unsigned *ctr, unsigned next) {
+    __hip_atomic_store(ctr, next, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---------------------------------------------------------------- K0 ----
@@ -1115,6 +1133,8 @@ __global__ __launch_bounds__(256) void k_cam_normal(DevProblem d, const double *
     __syncthreads();
     const int i = t >> 4, j = t & 15;
     const double g = (Gs[t] + Gs[256 + t]) + (Gs[512 + t] + Gs[768 + t]);
+    // deterministic mode: the IO x IO block is common to all cameras -- one global ticket orders the chunks
+    if (d.deterministic) { if (t == 0) det_wait(d.det_io_turn + 1, (unsigned)d.cm_chunk_seq[blockIdx.x]); __syncthreads(); }
     if (i < ncol && g != 0.0) {
         const int64_t ri = C.col[i];
         if (j < ncol) {
@@ -1127,6 +1147,7 @@ __global__ __launch_bounds__(256) void k_cam_normal(DevProblem d, const double *
             atomic_add_f64(g_red + ri, g);
         }
     }
+    if (d.deterministic) { __threadfence(); __syncthreads(); if (t == 0) det_pass(d.det_io_turn + 1, (unsigned)d.cm_chunk_seq[blockIdx.x] + 1u); }
 }
 
 // Fixed interior orientation: the Gram matrix of [E | r] is 7 x 7 -- 27 useful sums.  On the matrix
@@ -1172,6 +1193,8 @@ __global__ __launch_bounds__(256) void k_cam_normal6(DevProblem d, const double 
         if (lane == 0) Gs[w * 27 + i] = v;
     }
     __syncthreads();
+    // deterministic mode: the chunks of one camera add to its block in their order
+    if (d.deterministic) { if (t == 0) det_wait(d.det_cm_turn + cam, (unsigned)d.cm_chunk_seq[blockIdx.x]); __syncthreads(); }
     if (t < 27) {
         const double g = (Gs[t] + Gs[27 + t]) + (Gs[54 + t] + Gs[81 + t]);
         if (g != 0.0) {
@@ -1189,6 +1212,7 @@ __global__ __launch_bounds__(256) void k_cam_normal6(DevProblem d, const double 
             }
         }
     }
+    if (d.deterministic) { __threadfence(); __syncthreads(); if (t == 0) det_pass(d.det_cm_turn + cam, (unsigned)d.cm_chunk_seq[blockIdx.x] + 1u); }
 }
 
 // ---------------------------------------------------------------- K1t2 --
@@ -2593,6 +2617,32 @@ __global__ __launch_bounds__(256) void k_jac_blocks(DevProblem d, const double *
     if (JIO) for (int c = 0; c < d.nIOrows; ++c) {
         JIO[2 * (int64_t)d.nIOrows * k + 2 * c] = Cf[0][c];
         JIO[2 * (int64_t)d.nIOrows * k + 2 * c + 1] = Cf[1][c];
+    }
+}
+
+
+// ... and for a SAMPLE of the observations (dbat_hip_jacobian_sample): pos[i] = processing-order position of the
+// i-th requested IP column; the results are indexed by i.  Residual unweighted [mm], as k_residual exports it.
+template <int MODEL>
+__global__ __launch_bounds__(256) void k_jac_sample(DevProblem d, const double *__restrict__ z,
+                                                    const CamRec *__restrict__ cams, int64_t n,
+                                                    const int64_t *__restrict__ pos, double *__restrict__ res,
+                                                    double *__restrict__ JEO, double *__restrict__ JOP,
+                                                    double *__restrict__ JIO) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t o = pos[i];
+    const CamRec &C = cams[d.o_cam[o]];
+    const double *q = z + d.NS + 3 * (int64_t)d.o_pt[o];
+    const double Q[3] = {q[0], q[1], q[2]};
+    double r[2], A[2][6], B[2][3], Cf[2][MAXIO];
+    obs_eval<MODEL, true, true>(C, d.nK, d.nP, Q, d.o_uv_raw[2 * o], d.o_uv_raw[2 * o + 1], r, A, B, Cf);
+    res[2 * i] = r[0]; res[2 * i + 1] = r[1];
+    for (int c = 0; c < 6; ++c) { JEO[12 * i + 2 * c] = A[0][c]; JEO[12 * i + 2 * c + 1] = A[1][c]; }
+    for (int c = 0; c < 3; ++c) { JOP[6 * i + 2 * c] = B[0][c]; JOP[6 * i + 2 * c + 1] = B[1][c]; }
+    for (int c = 0; c < d.nIOrows; ++c) {
+        JIO[2 * (int64_t)d.nIOrows * i + 2 * c] = Cf[0][c];
+        JIO[2 * (int64_t)d.nIOrows * i + 2 * c + 1] = Cf[1][c];
     }
 }
 

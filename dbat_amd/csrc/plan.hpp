@@ -199,6 +199,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     P.rank = pb.shard_rank; P.nranks = std::max(1, pb.shard_count);
     if (P.rank < 0 || P.rank >= P.nranks) return fail(P, "bad shard rank");
     const int nc = P.nc, np = P.np, R = P.nIOrows;
+    const Par par{Par::default_threads()};
 
     // ---- est / prior masks; bundle.m:137-154
     std::vector<uint8_t> estIO(pb.est_IO, pb.est_IO + (size_t)R * nc);
@@ -243,13 +244,31 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     P.z0.assign(P.NZ, 0.0);
     for (size_t e = 0; e < (size_t)6 * nc; ++e) { P.z0[e] = pb.EO_val[e]; P.z_est[e] = eo_lead[e]; }
     for (int k = 0; k < P.nIOu; ++k) { P.z0[6 * (int64_t)nc + k] = pb.IO_val[leadIO[k]]; P.z_est[6 * (int64_t)nc + k] = 1; }
-    for (size_t e = 0; e < (size_t)3 * np; ++e) { P.z0[P.NS + e] = pb.OP_val[e]; P.z_est[P.NS + e] = estOP[e]; }
+    par.run((int64_t)3 * np, [&](int64_t lo_, int64_t hi_, int) {
+        for (int64_t e = lo_; e < hi_; ++e) { P.z0[P.NS + e] = pb.OP_val[e]; P.z_est[P.NS + e] = estOP[e]; }
+    });
     // x order: IO leading (column-major), EO est (column-major), OP est (column-major)
     P.x2z.clear();
     P.x2z.reserve((size_t)P.NZ);
     for (int k = 0; k < P.nIOu; ++k) P.x2z.push_back(6 * (int64_t)nc + k);
     for (size_t e = 0; e < (size_t)6 * nc; ++e) if (eo_lead[e]) P.x2z.push_back((int64_t)e);
-    for (size_t e = 0; e < (size_t)3 * np; ++e) if (estOP[e]) P.x2z.push_back(P.NS + (int64_t)e);
+    {   // the estimated OP coordinates in order: counts per range, then every range fills its slice
+        const int nr = par.ranges((int64_t)3 * np, 1 << 16);
+        std::vector<int64_t> cnt((size_t)nr + 1, 0);
+        const Par pr{nr};
+        pr.run((int64_t)3 * np, [&](int64_t lo_, int64_t hi_, int tid) {
+            int64_t c = 0;
+            for (int64_t e = lo_; e < hi_; ++e) c += estOP[e] != 0;
+            cnt[tid + 1] = c;
+        }, 1);
+        const int64_t base = (int64_t)P.x2z.size();
+        for (int t = 0; t < nr; ++t) cnt[t + 1] += cnt[t];
+        P.x2z.resize((size_t)(base + cnt[nr]));
+        pr.run((int64_t)3 * np, [&](int64_t lo_, int64_t hi_, int tid) {
+            int64_t q = base + cnt[tid];
+            for (int64_t e = lo_; e < hi_; ++e) if (estOP[e]) P.x2z[q++] = P.NS + e;
+        }, 1);
+    }
     P.n = (int64_t)P.x2z.size();
     P.nOP = P.n - P.nIO - P.nEO;
     // priors: use & est & leading (bundle.m:137-154, buildserialindices.m:138-139)
@@ -307,7 +326,6 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     lapt("per-camera column lists");
     // ---- observations: validate order, weights (parallel over ranges of the IP columns; the first offence in
     // column order is the one reported, as a single pass would)
-    const Par par{Par::default_threads()};
     std::vector<int32_t> k_pt(np, 0), n_cam(nc, 0);
     {
         std::atomic<int64_t> first_range{INT64_MAX}, first_order{INT64_MAX}, first_std{INT64_MAX};
@@ -599,8 +617,9 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         if (P.BT != 256) P.CMAX = 0;                // the tile kernels are written for four waves of observations
     }
     std::vector<uint8_t> heavy(np, 0), giant(np, 0);
-    for (int p = 0; p < np; ++p) giant[p] = k_pt[p] > P.BT;
-    for (int p = 0; p < np && P.CMAX; ++p) {
+    par.run(np, [&](int64_t plo, int64_t phi, int) {
+    for (int64_t p = plo; p < phi; ++p) giant[p] = k_pt[p] > P.BT;
+    for (int64_t p = plo; p < phi && P.CMAX; ++p) {
         if (k_pt[p] > P.CMAX) { heavy[p] = 1; continue; }
         if (P.with_io) {
             int32_t seen[Plan::IOT + 1]; int ns = 0;
@@ -616,6 +635,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
             if (ns > Plan::IOT) heavy[p] = 1;
         }
     }
+    });
     lapt("tile-fit classification of the points");
     // Key = Morton code of the point's initial coordinates in the principal axes of the
     // point cloud: points that are close in object space are seen by the same cameras, so
@@ -795,8 +815,11 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
             const int64_t e = zi - P.NS;
             return P.NS + 3 * (int64_t)P.pt_rank[e / 3] + e % 3;
         };
-        std::vector<double> a(P.z0), b(P.z_prw), c(P.z_prv);
-        std::vector<uint8_t> e(P.z_est);
+        uvec<double> a((size_t)P.NZ), b((size_t)P.NZ), c((size_t)P.NZ);
+        uvec<uint8_t> e((size_t)P.NZ);
+        par.run(np, [&](int64_t plo, int64_t phi, int) {
+            for (int64_t zi = P.NS + 3 * plo; zi < P.NS + 3 * phi; ++zi) { a[zi] = P.z0[zi]; b[zi] = P.z_prw[zi]; c[zi] = P.z_prv[zi]; e[zi] = P.z_est[zi]; }
+        });
         par.run(np, [&](int64_t plo, int64_t phi, int) {        // (whole points per thread: z_est is a byte array)
             for (int64_t zi = P.NS + 3 * plo; zi < P.NS + 3 * phi; ++zi) {
                 const int64_t q = zperm(zi);

@@ -57,6 +57,7 @@ constexpr int SIG_STILE = 8064;      // 126*127/2 = 8001 packed lower triangle o
 
 struct SigLds {                      // static part
     int next_chunk, abort_;
+    int flush_turn;                  // deterministic mode: the chunk (tile-local index) whose turn it is to add to the tile
     int grow[128];                   // row of the reduced system of every row of the tile
     int lc[SIG_NW][16];              // tile-local camera of every slot of the wave's chunk
     short tmap[SIG_NW][80];          // tile row of every row of the wave's chunk
@@ -192,7 +193,7 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
     if (t < 6 * ncam) sy.grow[t] = 6 * d.tile_cams[c0 + t / 6] + t % 6;
     else if (t < nrows) sy.grow[t] = 6 * d.nc + d.tile_iocols[io0 + t - 6 * ncam];
     if constexpr (IO) { for (int i = t; i < 16 * ncam; i += NT) sy.camio[i >> 4][i & 15] = d.tile_cam_io[(size_t)c0 * 16 + i]; }
-    if (t == 0) { sy.next_chunk = ch0 + NW; sy.abort_ = 0; }
+    if (t == 0) { sy.next_chunk = ch0 + NW; sy.abort_ = 0; sy.flush_turn = 0; }
     for (int i = t; i < NW * 80; i += NT) { sy.tmap[i / 80][i % 80] = 0; sy.toff[i / 80][i % 80] = 0; }
     auto lap = [&](int i) { if (prof) { const long long now = wall_clock64(); tp[i] += now - tlast; tlast = now; } };
     __syncthreads();
@@ -226,6 +227,7 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
                 sy.tmap[wave][6 * k + lane] = (short)tr3; sy.toff[wave][6 * k + lane] = tr3 * (tr3 + 1) / 2;
             }
         }
+        const int ch_cur = ch;
         ch = grab();
         if (ch < ch1) {
             if (lane < 8) nd = sg_chunk[8 * (int64_t)ch + lane];
@@ -613,6 +615,10 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
         // ------------------------------------------------------------ chunk -> tile (LDS atomics)
         // one predicated ds_add_f64 per accumulator element; vt follows stile, so the right-hand-side
         // row (6k) only changes the index and the sign
+        if (d.deterministic) {                        // the chunks add to the tile in their order (they are taken in that order)
+            volatile int *turn = &sy.flush_turn;
+            while (*turn != ch_cur - ch0) __builtin_amdgcn_s_sleep(1);
+        }
         {
             const int r6k = ry;                      // the row of y closes the chunk's rows
             int tcm[RB];
@@ -643,6 +649,10 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
                 }
             }
         }
+        if (d.deterministic) {
+            lds_fence();
+            if (lane == 0) { volatile int *turn = &sy.flush_turn; *turn = ch_cur - ch0 + 1; }
+        }
         __builtin_amdgcn_wave_barrier();
         lap(5);
     }
@@ -650,6 +660,12 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
     __syncthreads();
     lap(6);
     // ---------------------------------------------------------------- tile -> HBM
+    // deterministic mode: this tile's turn at every one of its cameras (and at the shared IO rows)
+    if (d.deterministic) {
+        if (t < ncam) det_wait(d.det_cam_turn + d.tile_cams[c0 + t], (unsigned)d.tile_cam_seq[c0 + t]);
+        if (IO && t == 64 && d.tile_io_seq[tile] >= 0) det_wait(d.det_io_turn, (unsigned)d.tile_io_seq[tile]);
+        __syncthreads();
+    }
     // one column per wave and trip: consecutive lanes, consecutive rows (neighbouring addresses in S).  All the
     // LDS reads of the wave's columns are issued first (the accumulators are dead: the registers are there), then the
     // atomics -- one LDS latency per tile instead of one per column
@@ -676,6 +692,12 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
     }
     for (int i = t; i < nrows; i += NT)
         if (vt[i] != 0.0) atomic_add_f64(g_red + sy.grow[i], vt[i]);
+    if (d.deterministic) {
+        __threadfence();                             // this tile's atomics have been performed
+        __syncthreads();
+        if (t < ncam) det_pass(d.det_cam_turn + d.tile_cams[c0 + t], (unsigned)d.tile_cam_seq[c0 + t] + 1u);
+        if (IO && t == 64 && d.tile_io_seq[tile] >= 0) det_pass(d.det_io_turn, (unsigned)d.tile_io_seq[tile] + 1u);
+    }
     double accr[1] = {rr};
     block_sum<1>(accr, sh);
     if (t == 0) partial[part_slot] = accr[0];

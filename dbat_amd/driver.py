@@ -60,14 +60,15 @@ def _parse_args(args):
     return o
 
 
-def bundle(s, *args, device=None, comm=None, store_trace=True, jacobian=False):
+def bundle(s, *args, device=None, comm=None, store_trace=True, jacobian=False, deterministic=False):
     """[s,ok,iters,s0,E] = bundle(s[,maxIter][,damping][,'trace'][,tol]
     [,'absterm'][,'singulartest'|'nosingulartest'][,veto][,'pmdof'][,'dofverb'])
 
     `comm` (dbat_amd.parallel.Comm) shards the object points over the ranks of
     a torch.distributed group, one GPU per rank; every rank returns the full
     result.  `store_trace=False` drops E.trace (n x iterations) for very large
-    problems.  `jacobian=True` also returns E.final.weighted.J and E.final.unweighted.J
+    problems.  `deterministic=True` sums the reduced system in a fixed order (dbat_hip_set_deterministic:
+    two runs give the same bits; slower; signature-group path only).  `jacobian=True` also returns E.final.weighted.J and E.final.unweighted.J
     (scipy CSC, bundle.m:341-350) -- on request only, the solver never forms J.
     """
     o = _parse_args(args)
@@ -94,6 +95,8 @@ def bundle(s, *args, device=None, comm=None, store_trace=True, jacobian=False):
         device = 0 if device is None else device
     h = _hip.Handle(s, device=device, shard_rank=rank, shard_count=world)
     try:
+        if deterministic:                                            # fixed-order sums: bit-identical runs (parity mode)
+            h.set_deterministic(True)
         if comm is not None and world > 1:
             if hasattr(comm, 'attach'):
                 comm.attach(h)                                       # RCCL communicator inside the library

@@ -223,6 +223,13 @@ int  dbat_hip_colnorms(dbat_hip_handle *h, double *Jn);
 /* ||J*v||^2 at the last linearisation point (Jp, dog-leg g'J'Jg: lmp.m:304-311) */
 int  dbat_hip_jtimes_sqnorm(dbat_hip_handle *h, const double *v, double *sqnorm);
 
+/* The same for a SAMPLE of the image observations -- n IP columns ip_col[i] (0-based, reference order) -- so that
+ * the model of a problem with 10^7 ... 10^8 observations can be checked without exporting 12 doubles for each:
+ * res[2n] the unweighted residual [mm] (multi_res.m:20-55), JEO[12n], JOP[6n], JIO[2*nIOrows*n] laid out as in
+ * dbat_hip_jacobian_blocks but indexed by i.  One-rank handles only. */
+int  dbat_hip_jacobian_sample(dbat_hip_handle *h, const double *x, int64_t n, const int64_t *ip_col, double *res,
+                              double *JEO, double *JOP, double *JIO);
+
 /* J = [image rows; IO prior rows; EO prior rows; OP prior rows] at x as a compressed-sparse-column matrix of
  * n_residuals x n_params -- what [r,J]=resFun(x) returns (brown_euler_cam4.m:163-182, multi_res.m:300-313) and
  * bundle() hands on as E.final.weighted.J / E.final.unweighted.J (bundle.m:341-350; bundle_cov.m:18-23,68 reads
@@ -277,6 +284,14 @@ int  dbat_hip_comm_init(dbat_hip_handle *h, const uint8_t *id /*[128]*/);
  * doubles over the handle's communicator; op 0 = sum, 1 = max, 2 = min
  * (a barrier is a reduce of one double).  Identity without a communicator. */
 int  dbat_hip_comm_allreduce_host(dbat_hip_handle *h, double *buf, int64_t count, int32_t op);
+
+/* Deterministic mode: on != 0 makes every later linearisation of this handle add its contributions to the reduced
+ * system in a FIXED order (tickets per image, per camera-major chunk and one for the shared IO rows), so that two
+ * runs of the same problem give the same bits -- as the reference does by construction, where one MATLAB thread
+ * forms J'J (gauss_newton_armijo.m:166-174).  The atomics of the default mode reorder f64 sums (1e-13 relative).
+ * Costs time (the tile flushes of self-calibrating problems queue up on the IO rows); meant for parity runs.
+ * DBAT_HIP_EUNSUPPORTED unless the handle runs the signature-group path on one rank (no heavy / giant points). */
+int  dbat_hip_set_deterministic(dbat_hip_handle *h, int32_t on);
 
 /* Test hook (gloo on CPU boxes, two shards on one GPU through the host):
  * sum-all-reduce of `count` doubles at device address `buf_dev`, enqueued on

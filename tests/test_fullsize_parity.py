@@ -34,6 +34,53 @@ def hip():
 
 
 @pytest.mark.parametrize('name', ['C2', 'C3', 'C4'])
+def test_full_size_model_sample_vs_oracle(hip, name):
+    """The MODEL at the bench's own sizes (bench/cpu_ref.cpp shares csrc/model.hpp with the
+    device, so the full-size step test above pins the solver, not the residual / Jacobian model).  10 000 image
+    observations drawn from the scene the bench times, at a perturbed point: residual and the 2 x 6 / 2 x 3 /
+    2 x nIO blocks from the device (dbat_hip_jacobian_sample: the obs_eval the kernels inline) against the ORACLE's
+    primitive chain res_euler_brown_{0..3} (cameramodel/res_euler_brown_1.m:84-95,149-178 for the synthetic
+    configurations), camera by camera.  Also: the residual the damping loops use (k_residual_cm, rhs precomputed
+    for fixed IO) gives the same objective value as the exported rows."""
+    from dbat_amd import synth
+    s, _ = synth.make_scene(name)
+    h = hip.Handle(s)
+    try:
+        x0 = h.serialize()
+        rng = np.random.default_rng(77)
+        x = x0 + 1e-5 * rng.standard_normal(len(x0)) * np.maximum(1e-3, np.abs(x0))
+        no = s.IP.val.shape[1]
+        idx = np.sort(rng.choice(no, 10000, replace=False))
+        r, JEO, JOP, JIO = h.jacobian_sample(x, idx)
+        IO, EO, OP = h.deserialize(x)
+        nK, nP = int(s.IO.model.nK), int(s.IO.model.nP)
+        model = int(np.unique(s.IO.model.distModel)[0])
+        cam, pt = s.IP.cam[idx], s.IP.pt[idx]
+        px = np.asarray(s.IO.sensor.pxSize)
+        worst_r = worst_j = 0.0
+        for c in np.unique(cam):
+            m = cam == c
+            io = IO[:, c]
+            v, d = o.res_euler_brown(model, OP[:, pt[m]], EO[:3, c], EO[3:6, c], io[0], s.IP.val[:, idx[m]], px[0, c], io[1:3],
+                                     io[5:5 + nK], io[5 + nK:5 + nK + nP], io[3:5], jac=True)
+            A_o = np.concatenate([d['dQ0'], d['dA']], 2)
+            C_o = np.concatenate([d['dF'], d['dU0'], d['dB'], d['dK'], d['dP']], 2)
+            worst_r = max(worst_r, np.abs(r[m] - v.T).max())
+            sc = max(1.0, np.abs(C_o).max())
+            worst_j = max(worst_j, np.abs(JEO[m] - A_o).max() / max(1.0, np.abs(A_o).max()), np.abs(JOP[m] - d['dQ']).max() / max(1.0, np.abs(d['dQ']).max()),
+                          np.abs(JIO[m] - C_o).max() / sc)
+        assert worst_r < 1e-11 and worst_j < 1e-11, (worst_r, worst_j)
+        # the objective of the damping loops (camera-major kernel, image side precomputed where IO is fixed) against
+        # the exported residual rows of the point-major kernel
+        r_all, f = h.residual(x)
+        w = 1.0 / (np.asarray(s.IP.std) * px[:, s.IP.cam])
+        f_rows = 0.5 * np.sum((r_all[:2 * no].reshape(no, 2).T * w) ** 2)
+        assert abs(f - f_rows) <= 1e-11 * abs(f)
+    finally:
+        h.close()
+
+
+@pytest.mark.parametrize('name', ['C2', 'C3', 'C4'])
 def test_full_size_step_vs_independent_full_matrix_solve(hip, name):
     """One linearise + solve at x0 at FULL size (C2, C3, and C4 with its 15 M unknowns and four IO blocks): the step
     p, f = r'r/2, ||J p||^2, g'p and trace(J'J) of dbat_hip_linearize_solve (Schur complement on the GPU, the

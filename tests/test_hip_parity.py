@@ -1272,6 +1272,44 @@ def test_run_to_run_repeatability(hip, name, sig, monkeypatch):
         h.close()
 
 
+@pytest.mark.parametrize('name,selfcal', [('small', False), ('small', True), ('C1', False), ('C1', True)])
+def test_deterministic_mode_repeats_bit_for_bit(hip, name, selfcal, monkeypatch):
+    """dbat_hip_set_deterministic: every sum into the reduced system in a fixed order (tickets per image, per
+    camera-major chunk, one for the shared IO rows; chunks add to their tile in order) -- what the reference has by
+    construction, where one thread forms J'J (gauss_newton_armijo.m:166-174).  Twenty linearise + solve
+    steps and two whole bundles: the step, sigma0 and the estimate repeat BIT FOR BIT; and the deterministic step agrees
+    with the default one to rounding.  Scenes off the signature path are refused."""
+    from dbat_amd import bundle, synth
+    monkeypatch.setenv('DBAT_HIP_SIG', '2')
+    s, _ = synth.make_scene(name, selfcal=selfcal) if selfcal else synth.make_scene(name)
+    h = hip.Handle(s)
+    try:
+        x0 = h.serialize()
+        p_default, _ = h.linearize_solve(x0, 0.0, True)
+        h.set_deterministic(True)
+        ref = None
+        for i in range(20):
+            p, st = h.linearize_solve(x0, 0.0, True)
+            assert not st['singular']
+            if ref is None:
+                ref = p.copy()
+            assert np.array_equal(p, ref), relerr(p, ref)
+        assert relerr(ref, p_default) < 1e-10
+    finally:
+        h.close()
+    runs = [bundle(s, 'lm', deterministic=True) for _ in range(2)]
+    assert runs[0][1] and np.array_equal(runs[0][4].x, runs[1][4].x) and runs[0][3] == runs[1][3]
+    assert np.array_equal(np.asarray(runs[0][4].res), np.asarray(runs[1][4].res))
+    monkeypatch.setenv('DBAT_HIP_SIG', '0')                  # the tile kernels of irregular scenes: not covered
+    h = hip.Handle(s)
+    try:
+        with pytest.raises(hip.DbatHipError) as e:
+            h.set_deterministic(True)
+        assert e.value.code == hip.EUNSUPPORTED
+    finally:
+        h.close()
+
+
 @pytest.mark.parametrize('rays,groups', [(6, 1), (10, 1), (6, 4)])
 def test_selfcal_io_rows_summed_per_point(hip, rays, groups, monkeypatch):
     """Self-calibration: tiles whose cameras share one IO block run the k_build_sig instantiation
