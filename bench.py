@@ -220,6 +220,14 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     ms /= max(args.steps, 1)
+    # every rank's phase times (ms per step), so that the first real multi-GPU run explains itself: rank 0 prints
+    # them with the bytes each all-reduce carried and the rate that implies
+    per_rank = None
+    if comm is not None and world > 1:
+        tv = torch.tensor(ms, dtype=torch.float64)
+        gl = [torch.zeros_like(tv) for _ in range(world)]
+        torch.distributed.all_gather(gl, tv)
+        per_rank = [[float(v) for v in g] for g in gl]
 
     # the shipped loop: a real dbat_hip_solve('lm') from x0 (host control flow, scalar
     # read-backs and all), outside the timed region above
@@ -351,6 +359,18 @@ def main():
                      'ms_factor_domain': ms[8], 'ms_allreduce': ms[9], 'ms_replicated': ms[10],
                      'tasks_domain': info['tasks_domain'], 'tasks_top': info['tasks_top'],
                      'obs_this_rank': no_s, 'pts_this_rank': np_s}
+            # achieved rate of the collective inside the factorisation (the top-separator tiles): algorithm bandwidth
+            # bytes / time, and bus bandwidth x 2 (R - 1) / R for a ring-equivalent comparison with the 7 x 153 GB/s xGMI links
+            R_ = emu or world
+            if multi['ms_allreduce'] > 0 and not emu:
+                alg = multi['allreduce_bytes_reduced_system'] / (multi['ms_allreduce'] * 1e-3) / 1e9
+                multi['allreduce_algbw_GBs'] = alg
+                multi['allreduce_busbw_GBs'] = alg * 2.0 * (R_ - 1) / R_
+            if per_rank is not None:
+                keys = ('build', 'factor_solve', 'backsub', 'trial_residual', 'tile_kernel', 'k_chol_df', 'k_backsub', 'k_residual_cm',
+                        'factor_domain', 'allreduce_top_tiles', 'factor_top_replicated', 'unused')
+                multi['per_rank_ms'] = [dict(zip(keys, r)) for r in per_rank]
+                multi['slowest_rank_ms'] = {k: max(r[i] for r in per_rank) for i, k in enumerate(keys)}
         out = {
             'metric': 'LM iterations/sec', 'value': None if emu else args.steps / dt, 'unit': 'it/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,

@@ -420,7 +420,7 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
                 }
                 const double r00 = Rpb[0], r10 = Rpb[1], r20 = Rpb[2], r11 = Rpb[3], r21 = Rpb[4], r22 = Rpb[5];
                 pR[0] = r00; pR[1] = r10; pR[2] = r20; pR[3] = r11; pR[4] = r21; pR[5] = r22;
-                if constexpr (!IO) {
+                if constexpr (!IO || io_simple) {
                     // pass 2 multiplies B R with B unmasked: row c of R is zeroed for a coordinate that is not estimated
                     // (column c of B then never contributes)
                     if (est != 7u) {
@@ -514,13 +514,15 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
 #pragma unroll
             for (int c = 0; c < 3; ++c) { gY[c] = lane_get(pY[c], src); gQ[c] = lane_get(pQ[c], src); }
             unsigned est = 7u;
-            if constexpr (IO) est = (unsigned)__builtin_amdgcn_ds_bpermute(4 * src, (int)pEst);
-            if constexpr (!IO) {
+            if constexpr (IO && !io_simple) est = (unsigned)__builtin_amdgcn_ds_bpermute(4 * src, (int)pEst);
+            // fixed IO, and self-calibrating tiles whose IO rows were summed in pass 1: the camera rows of Z need the
+            // blocks A and B only -- they do not depend on (u, v) -- by the lean evaluation
+            if constexpr (!IO || io_simple) {
                 if (on && !DBAT_ABLATE(d, 2)) {
                     const double Q[3] = {gQ[0], gQ[1], gQ[2]};
                     const double w0 = sg_w ? w_c.x : C.w[0], w1 = sg_w ? w_c.y : C.w[1];
                     sig_eval_Z(C, Q, w0, w1, gR, Zr);
-                    if (eo_est != 63u) {
+                    if ((eo_est & 63u) != 63u) {
 #pragma unroll
                         for (int a = 0; a < 6; ++a)
                             if (!((eo_est >> a) & 1u)) { Zr[a][0] = 0.0; Zr[a][1] = 0.0; Zr[a][2] = 0.0; }
