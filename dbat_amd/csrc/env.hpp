@@ -27,6 +27,7 @@ static const EnvSwitch kEnvSwitches[] = {
     {"DBAT_HIP_SIG_IOS_OFF", false, "self-calibration: IO rows by LDS atomics in every tile"},
     {"DBAT_HIP_CMAX", false, "cameras per tile (0: column-list kernel only)"},
     {"DBAT_HIP_BT", false, "observations per batch (128 | 256)"},
+    {"DBAT_HIP_TILE_BMIN", false, "fewest batches a tile may be capped at (default 2)"},
     {"DBAT_HIP_GIANT_THREADS", false, "threads of the giant-point kernels (64 | 128 | 256)"},
     {"DBAT_HIP_MG_REPLICATED", false, "several ranks: envelope summed, replicated factorisation"},
     {"DBAT_HIP_ND_OFF", false, "no nested dissection"},

@@ -102,37 +102,44 @@ __device__ __forceinline__ void det_pass(unsigned *ctr, unsigned next) {
 // trial point x + alpha p that is only being written by the same launch).
 template <class ZV>
 __device__ __forceinline__ void cam_prep_one(const DevProblem &d, ZV zv, int c, CamRec *__restrict__ cams) {
-    CamRec r;
+    // straight into the record in global memory: a local CamRec (400 bytes, indexed by loops) lives in scratch
+    CamRec &r = cams[c];
     // the six EO values through the column list: a shared element lives in the slot of its leading entry
     const int32_t *ec = d.cam_col + (int64_t)c * MAXCOL;
     r.c[0] = zv(ec[0]); r.c[1] = zv(ec[1]); r.c[2] = zv(ec[2]);
     const double ang[3] = {zv(ec[3]), zv(ec[4]), zv(ec[5])};
-    cam_rotation(ang, r.Mt, r.sk, r.ck);
-    double io[MAXIO];
-    for (int k = 0; k < MAXIO; ++k) {
-        io[k] = 0;
-        if (k < d.nIOrows) {
-            const int32_t s = d.io_src[(int64_t)c * d.nIOrows + k];
-            io[k] = s >= 0 ? zv(6 * (int64_t)d.nc + s) : d.io_fixed[(int64_t)c * d.nIOrows + k];
-        }
-    }
-    r.f = io[0]; r.pp[0] = io[1]; r.pp[1] = io[2]; r.b[0] = io[3]; r.b[1] = io[4];
-    for (int k = 0; k < MAXK; ++k) r.K[k] = k < d.nK ? io[5 + k] : 0.0;
-    for (int k = 0; k < MAXP; ++k) r.P[k] = k < d.nP ? io[5 + d.nK + k] : 0.0;
+    double Mt[9], sk, ck;
+    cam_rotation(ang, Mt, sk, ck);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r.Mt[k] = Mt[k];
+    r.sk = sk; r.ck = ck;
+    auto io_at = [&](int k) -> double {
+        if (k >= d.nIOrows) return 0.0;
+        const int32_t s = d.io_src[(int64_t)c * d.nIOrows + k];
+        return s >= 0 ? zv(6 * (int64_t)d.nc + s) : d.io_fixed[(int64_t)c * d.nIOrows + k];
+    };
+    r.f = io_at(0); r.pp[0] = io_at(1); r.pp[1] = io_at(2); r.b[0] = io_at(3); r.b[1] = io_at(4);
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) r.K[k] = k < d.nK ? io_at(5 + k) : 0.0;
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) r.P[k] = k < d.nP ? io_at(5 + d.nK + k) : 0.0;
     r.sz = d.px[2 * c];
     r.w[0] = d.cam_w[2 * c]; r.w[1] = d.cam_w[2 * c + 1];
-    r.ncol = d.cam_ncol[c];
-    for (int k = 0; k < MAXCOL; ++k) r.col[k] = d.cam_col[(int64_t)c * MAXCOL + k];
-    for (int k = 0; k < MAXIO; ++k) r.iorow[k] = d.cam_iorow[(int64_t)c * MAXIO + k];
-    r.eo_est = d.cam_eo_est[c];
-    {   // bit 8: the camera's estimated IO rows are cc, px, py, K1-K3, P1, P2 in this order (the usual
-        // self-calibration): the kernels then pick the IO columns without a select chain
-        static const int std8[8] = {0, 1, 2, 5, 6, 7, 8, 9};
-        bool is8 = r.ncol == 14 && d.nK == 3 && d.nP == 2;
-        for (int k = 0; k < 8 && is8; ++k) is8 = r.iorow[k] == std8[k];
-        if (is8) r.eo_est |= 0x100u;
+    const int ncol = d.cam_ncol[c];
+    r.ncol = ncol;
+#pragma unroll
+    for (int k = 0; k < MAXCOL; ++k) r.col[k] = ec[k];
+    // bit 8: the camera's estimated IO rows are cc, px, py, K1-K3, P1, P2 in this order (the usual
+    // self-calibration): the kernels then pick the IO columns without a select chain
+    constexpr int std8[8] = {0, 1, 2, 5, 6, 7, 8, 9};
+    bool is8 = ncol == 14 && d.nK == 3 && d.nP == 2;
+#pragma unroll
+    for (int k = 0; k < MAXIO; ++k) {
+        const int32_t row = d.cam_iorow[(int64_t)c * MAXIO + k];
+        r.iorow[k] = row;
+        if (k < 8) is8 = is8 && row == std8[k];
     }
-    cams[c] = r;
+    r.eo_est = d.cam_eo_est[c] | (is8 ? 0x100u : 0u);
 }
 __global__ void k_cam_prep(DevProblem d, const double *__restrict__ z, CamRec *__restrict__ cams) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;

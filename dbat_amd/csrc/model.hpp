@@ -49,22 +49,13 @@ DBAT_HD void cam_rotation(const double ang[3], double Mt[9], double &sk_out, dou
     const double so = sin(ang[0]), co = cos(ang[0]);
     const double sp = sin(ang[1]), cp = cos(ang[1]);
     const double sk = sin(ang[2]), ck = cos(ang[2]);
-    const double R1[9] = {1, 0, 0, 0, co, -so, 0, so, co};
-    const double R2[9] = {cp, 0, sp, 0, 1, 0, -sp, 0, cp};
-    const double R3[9] = {ck, -sk, 0, sk, ck, 0, 0, 0, 1};
-    auto mul = [](const double *a, const double *b, double *c) {
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) {
-                double s = 0;
-                for (int k = 0; k < 3; ++k) s += a[3 * i + k] * b[3 * k + j];
-                c[3 * i + j] = s;
-            }
-    };
-    double R12[9], M[9];
-    mul(R1, R2, R12);
-    mul(R12, R3, M);
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) Mt[3 * i + j] = M[3 * j + i];
+    // M = R1 R2 R3 written out (R1 = rot_x(omega), R2 = rot_y(phi), R3 = rot_z(kappa)); M' row-major
+    const double M00 = cp * ck,                  M01 = -cp * sk,                 M02 = sp;
+    const double M10 = co * sk + so * sp * ck,   M11 = co * ck - so * sp * sk,   M12 = -so * cp;
+    const double M20 = so * sk - co * sp * ck,   M21 = so * ck + co * sp * sk,   M22 = co * cp;
+    Mt[0] = M00; Mt[1] = M10; Mt[2] = M20;
+    Mt[3] = M01; Mt[4] = M11; Mt[5] = M21;
+    Mt[6] = M02; Mt[7] = M12; Mt[8] = M22;
     sk_out = sk; ck_out = ck;
 }
 

@@ -995,7 +995,8 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     // batches per tile: long tiles amortise the flush of the tile into S, but a small
     // problem must still break into enough tiles to occupy the 256 CUs twice over
     const int64_t shard_obs = nobs_shard;
-    const int bmax_auto = (int)std::min<int64_t>(48, std::max<int64_t>(4, (shard_obs / std::max(1, P.BT) + 511) / 512));
+    const int bmax_floor = std::max(1, env_int("DBAT_HIP_TILE_BMIN", 2));     // (round 4: 4 -> 2; the reference's roma project: tile kernel 0.136 -> 0.084 ms)
+    const int bmax_auto = (int)std::min<int64_t>(48, std::max<int64_t>(bmax_floor, (shard_obs / std::max(1, P.BT) + 511) / 512));
     const int tile_bmax = bmax_auto;
     for (int64_t i = P.pt_lo; i < P.pt_hi; ++i) {
         const int64_t is = i - P.pt_lo;

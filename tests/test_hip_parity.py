@@ -1354,6 +1354,32 @@ def test_cholesky_split_sums(hip, name, selfcal, monkeypatch):
     assert relerr(step(), ref) < 1e-9
 
 
+@pytest.mark.parametrize('switch,value', [('DBAT_HIP_ND_OFF', '1'), ('DBAT_HIP_ND_LEAF', '8'), ('DBAT_HIP_ND_PAD_ALL', '1'),
+                                          ('DBAT_HIP_ND_JOIN_SMALL', '0'), ('DBAT_HIP_SPRANK_OFF', '1'), ('DBAT_HIP_TILE_BMIN', '1'),
+                                          ('DBAT_HIP_TILE_BMIN', '6'), ('DBAT_HIP_PLAN_STATS', '2'), ('DBAT_HIP_PIVOT_STATS', '1'),
+                                          ('DBAT_HIP_PLAN_THREADS', '3')])
+def test_product_switches_leave_the_result_alone(hip, switch, value, monkeypatch):
+    """csrc/env.hpp: a product switch selects a layout or a schedule (the dissection of the camera network, the tile
+    length, the threads of the host plan) or prints statistics -- the step is the same to rounding whatever its value.
+    (The switches that select kernels have their own tests: SIG, SIG_IOS_OFF, CMAX, BT, GIANT_THREADS, MG_REPLICATED,
+    DF_SPLIT / DF_CHUNK.)  Fixed IO and self-calibration, 'small' (several tiles, a dissection with separators)."""
+    from dbat_amd import synth
+    for selfcal in (False, True):
+        s, _ = synth.make_scene('small', selfcal=selfcal) if selfcal else synth.make_scene('small')
+        def step():
+            h = hip.Handle(s)
+            try:
+                p, st = h.linearize_solve(h.serialize(), 0.0, True)
+                assert not st['singular'] and h.structural_rank_ok()
+                return p
+            finally:
+                h.close()
+        ref = step()
+        monkeypatch.setenv(switch, value)
+        assert relerr(step(), ref) < 1e-9
+        monkeypatch.delenv(switch)
+
+
 def test_cholesky_task_orders_in_the_measurement_build(hip):
     """Every candidate order of the factorisation's task list is a topological order and must give the same
     step.  DBAT_HIP_DF_ORDER is a measurement switch (csrc/env.hpp): the product library refuses it, so the
