@@ -301,15 +301,33 @@ __global__ __launch_bounds__(256) void k_residual_cm(DevProblem d, const double 
     const CamRec &C = cams[chunk_cam[blockIdx.x]];
     const int64_t q0 = chunk_start[blockIdx.x], q1 = chunk_start[blockIdx.x + 1];
     double acc[1] = {0.0};
-    for (int64_t q = q0 + threadIdx.x; q < q1; q += 256) {
-        const double *p = z + d.NS + 3 * (int64_t)cm_pt[q];
-        const double Q[3] = {p[0], p[1], p[2]};
-        double r[2];
-        double(*nil6)[6] = nullptr; double(*nil3)[3] = nullptr; double(*nilc)[MAXIO] = nullptr;
-        obs_eval<MODEL, false, false, PRE>(C, d.nK, d.nP, Q, cm_uv[2 * q], cm_uv[2 * q + 1], r, nil6, nil3, nilc);
-        const double w0 = cm_w ? cm_w[2 * q] : C.w[0], w1 = cm_w ? cm_w[2 * q + 1] : C.w[1];
-        r[0] *= w0; r[1] *= w1;
-        acc[0] += r[0] * r[0] + r[1] * r[1];
+    // a chunk holds at most 2048 observations: eight per thread.  Four at a time: their point indices and image
+    // coordinates are requested together, then the four gathers of the object points -- two memory latencies per
+    // four observations instead of two per observation (the kernel is bound by them, not by its 20 B per observation)
+    const double2 *uvp = reinterpret_cast<const double2 *>(cm_uv), *wp = reinterpret_cast<const double2 *>(cm_w);
+    for (int64_t qb = q0 + threadIdx.x; qb < q1; qb += 4 * 256) {
+        int pt[4]; double2 uv[4], ww[4]; double Q[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t q = qb + 256 * u;
+            const bool on = q < q1;
+            pt[u] = on ? cm_pt[q] : -1;
+            uv[u] = on ? uvp[q] : double2{0, 0};
+            ww[u] = (on && cm_w) ? wp[q] : double2{C.w[0], C.w[1]};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double *p = z + d.NS + 3 * (int64_t)(pt[u] < 0 ? 0 : pt[u]);
+            Q[u][0] = p[0]; Q[u][1] = p[1]; Q[u][2] = p[2];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            double r[2];
+            double(*nil6)[6] = nullptr; double(*nil3)[3] = nullptr; double(*nilc)[MAXIO] = nullptr;
+            obs_eval<MODEL, false, false, PRE>(C, d.nK, d.nP, Q[u], uv[u].x, uv[u].y, r, nil6, nil3, nilc);
+            r[0] *= ww[u].x; r[1] *= ww[u].y;
+            if (pt[u] >= 0) acc[0] += r[0] * r[0] + r[1] * r[1];
+        }
     }
     block_sum<1>(acc, sh);
     if (threadIdx.x == 0) partial[blockIdx.x] = acc[0];      // summed by k_prior_sq (thousands of tickets on one address cost more)
@@ -1179,20 +1197,37 @@ __global__ __launch_bounds__(256) void k_cam_normal6(DevProblem d, const double 
     double G[27];                                    // 21: E'E lower triangle by rows (i >= j), then 6: E'r
 #pragma unroll
     for (int i = 0; i < 27; ++i) G[i] = 0.0;
-    for (int64_t q = q0 + t; q < q1; q += 256) {
-        const int pt = cm_pt[q];
-        const int64_t zp = d.NS + 3 * (int64_t)pt;
-        const double Q[3] = {z[zp], z[zp + 1], z[zp + 2]};
-        const double w0 = cm_w ? cm_w[2 * q] : C.w[0], w1 = cm_w ? cm_w[2 * q + 1] : C.w[1];
-        double r[2], E[2][6], B[2][3];
-        eval_obs_pre<MODEL, 6>(d, C, Q, cm_uv[2 * q], cm_uv[2 * q + 1], w0, w1, 7u, r, E, B);
-        int n = 0;
+    // four observations at a time: their point indices and coordinates are requested together, then the four
+    // gathers of the object points (a chunk has at most eight observations per thread)
+    const double2 *uvp = reinterpret_cast<const double2 *>(cm_uv), *wp = reinterpret_cast<const double2 *>(cm_w);
+    for (int64_t qb = q0 + t; qb < q1; qb += 4 * 256) {
+        int pt[4]; double2 uv[4], ww[4]; double Qv[4][3];
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
+        for (int u = 0; u < 4; ++u) {
+            const int64_t q = qb + 256 * u;
+            const bool on = q < q1;
+            pt[u] = on ? cm_pt[q] : -1;
+            uv[u] = on ? uvp[q] : double2{0, 0};
+            ww[u] = (on && cm_w) ? wp[q] : double2{C.w[0], C.w[1]};
+        }
 #pragma unroll
-            for (int j = 0; j <= i; ++j, ++n) G[n] += E[0][i] * E[0][j] + E[1][i] * E[1][j];
+        for (int u = 0; u < 4; ++u) {
+            const double *p = z + d.NS + 3 * (int64_t)(pt[u] < 0 ? 0 : pt[u]);
+            Qv[u][0] = p[0]; Qv[u][1] = p[1]; Qv[u][2] = p[2];
+        }
 #pragma unroll
-        for (int i = 0; i < 6; ++i) G[21 + i] += E[0][i] * r[0] + E[1][i] * r[1];
+        for (int u = 0; u < 4; ++u) {
+            if (pt[u] < 0) continue;
+            double r[2], E[2][6], B[2][3];
+            eval_obs_pre<MODEL, 6>(d, C, Qv[u], uv[u].x, uv[u].y, ww[u].x, ww[u].y, 7u, r, E, B);
+            int n = 0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j <= i; ++j, ++n) G[n] += E[0][i] * E[0][j] + E[1][i] * E[1][j];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) G[21 + i] += E[0][i] * r[0] + E[1][i] * r[1];
+        }
     }
 #pragma unroll
     for (int i = 0; i < 27; ++i) {
