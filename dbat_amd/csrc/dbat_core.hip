@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <memory>
 #include <string>
+#include <thread>
+#include <atomic>
 #include <vector>
 
 #include "../../include/dbat_hip.h"
@@ -226,10 +228,10 @@ struct Core {
             const double big = 1e300;
             memcpy(&hpin[48], &big, 8); hpin[49] = 0.0; memcpy(&hpin[50], &big, 8); hpin[51] = 0.0;   // bit patterns: min = 1e300, max = +0
         }
-        if (rocblas_create_handle(&blas) != rocblas_status_success) throw DeviceError{"rocblas_create_handle failed"};
-        rocblas_set_stream(blas, stream);
+        lapi("device, stream, pinned mailbox (the first call of a process initialises the HIP runtime: ~0.1 s)");
         for (auto &e : ev) HIPCHK(hipEventCreate(&e));
         for (auto &e : kev) HIPCHK(hipEventCreate(&e));
+        lapi("events");
         nb = (int64_t)P.batch_start.size() - 1;
         nobs = (int64_t)P.o_cam.size();
         cam_ncol.upload(P.cam_ncol); cam_col.upload(P.cam_col); cam_iorow.upload(P.cam_iorow);
@@ -277,7 +279,7 @@ struct Core {
             if (!P.uniform_w) sg_w.upload(P.sg_w);
             sig_rb = P.sg_rows_max <= 64 ? 4 : 5;
         }
-        lapi("stream, events, uploads of the plan");
+        lapi("allocations and uploads of the plan");
         cams.alloc(P.nc); cams_f.alloc(P.nc);
         z.alloc(P.NZ); zt.alloc(P.NZ); dz.alloc(P.NZ); zlin.alloc(P.NZ); vtmp.alloc(P.NZ); vtmp2.alloc(P.NZ);
         xbuf.alloc(std::max<int64_t>(P.n, 1));
@@ -933,6 +935,10 @@ struct Core {
         HIPCHK(hipMemcpyAsync(&hinfo, info.p, sizeof(hinfo), hipMemcpyDeviceToHost, stream));
         sync();
         if (hinfo != 0) throw DeviceError{"posterior covariance: the reduced normal matrix is not positive definite"};
+        if (!blas) {     // (created on first use: rocblas_create_handle costs 0.1 s, and only the posterior covariance needs it)
+            if (rocblas_create_handle(&blas) != rocblas_status_success) throw DeviceError{"rocblas_create_handle failed"};
+            rocblas_set_stream(blas, stream);
+        }
         if (rocsolver_dpotri(blas, rocblas_fill_lower, (rocblas_int)P.NS, S, (rocblas_int)ldS, info.p) != rocblas_status_success)
             throw DeviceError{"rocsolver_dpotri failed"};
         have_lin = false;

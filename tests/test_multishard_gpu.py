@@ -220,6 +220,22 @@ def test_domain_shards_failure_is_seen_by_every_rank(hip):
     assert all(o[4].code == -2 and not o[1] for o in out)
 
 
+def test_shard_without_communicator_is_a_usage_error(hip):
+    """A handle that is one of several domain shards but has neither a communicator nor an all-reduce callback cannot
+    factor (its schedule publishes the top separators only after the sum over the ranks): DBAT_HIP_EINVAL with a
+    message, not a spurious 'singular' (ADVICE r03)."""
+    from dbat_amd import synth
+    s, _ = synth.make_scene('C1')
+    h = hip.Handle(s, shard_rank=0, shard_count=2)
+    try:
+        if h.info()['domain_sharding']:
+            with pytest.raises(hip.DbatHipError) as e:
+                h.linearize_solve(h.serialize(), 0.0, True)
+            assert e.value.code == hip.EINVAL and 'communicator' in str(e.value)
+    finally:
+        h.close()
+
+
 @pytest.mark.parametrize('env', ['DBAT_HIP_MG_REPLICATED=1', 'DBAT_HIP_SIG=2', 'DBAT_HIP_SIG=0'])
 def test_domain_shards_variants(hip, env, monkeypatch):
     """The replicated fall-back (contiguous point ranges, envelope of the whole system summed, every rank factors

@@ -55,6 +55,29 @@ def test_resect_hip_matches_host_on_noisy_scene(n, v):
     assert np.median(da) < 1e-8 and da.max() < 1e-2
 
 
+def test_resect_rejects_bad_ranges_and_null_pointers():
+    """dbat_hip_resect validates before it dereferences: ranges that do not start at 0 or descend, triangle
+    indices outside the image's points, and null arrays with non-empty ranges are DBAT_HIP_EINVAL, not a segfault."""
+    import ctypes as C
+    from dbat_amd import _hip
+    lib = _hip.load()
+    i64p = C.POINTER(C.c_int64)
+    X = np.zeros(3 * 4); xn = np.zeros(2 * 4); P = np.zeros(12); rms = np.zeros(1)
+    tri = np.array([0, 1, 2], np.int32)
+    def call(pt_start, tri_start, Xp=X, xp=xn, trip=tri):
+        ps = np.ascontiguousarray(pt_start, np.int64); ts = np.ascontiguousarray(tri_start, np.int64)
+        return lib.dbat_hip_resect(0, 1, ps.ctypes.data_as(i64p), None if Xp is None else _hip.dptr(Xp),
+                                   None if xp is None else _hip.dptr(xp), ts.ctypes.data_as(i64p),
+                                   None if trip is None else trip.ctypes.data_as(_hip._ip), _hip.dptr(P), _hip.dptr(rms))
+    assert call([0, 4], [0, 1]) == _hip.OK
+    assert call([1, 4], [0, 1]) == _hip.EINVAL and 'start at 0' in _hip.last_error()
+    assert call([0, 4], [1, 1]) == _hip.EINVAL
+    assert call([0, 4], [0, 1], trip=None) == _hip.EINVAL and 'null' in _hip.last_error()
+    assert call([0, 4], [0, 1], Xp=None) == _hip.EINVAL
+    assert call([0, 4], [0, 1], trip=np.array([0, 1, 7], np.int32)) == _hip.EINVAL and 'triangle index' in _hip.last_error()
+    assert call([0, -1], [0, 0]) == _hip.EINVAL
+
+
 def test_camcal_demo_pipeline_with_device_resection():
     """demo/camcaldemo.m:56-107 with resection AND forward intersection on the GPU, then the bundle:
     camcal-dbatreport.txt:39-43 -- 9 iterations, first error 30873.9 (sixth digit: the near-triple root of image
