@@ -253,7 +253,7 @@ struct Core {
         d.o_cam = o_cam.p; d.o_pt = o_pt.p; d.o_uv = o_uv.p; d.o_w = P.uniform_w ? nullptr : o_w.p;
         d.o_seg = o_seg.p; d.o_row = o_row.p; d.batch_start = batch_start.p;
         d.CMAX = P.CMAX; d.ablate = env_int("DBAT_HIP_ABLATE", 0); d.trace_only = 0;
-        d.deterministic = 0; d.det_cam_turn = d.det_cm_turn = d.det_io_turn = nullptr;
+        d.deterministic = 0; d.det_cam_turn = d.det_cm_turn = d.det_io_turn = d.det_timeouts = nullptr;
         d.tile_cam_seq = d.tile_io_seq = d.cm_chunk_seq = nullptr;
         env_df_trace = env_get("DBAT_HIP_DF_TRACE");
         d.ntiles = (int)ntiles; d.o_lc = o_lc.p; d.o_pidx = o_pidx.p;
@@ -611,7 +611,7 @@ struct Core {
             throw UsageError{"deterministic mode covers the signature-group path on one rank (no heavy or giant points, no irregular-visibility tile kernels)"};
         if (on && !det_ctr.p) {
             const int nc = P.nc;
-            det_ctr.alloc((size_t)2 * nc + 2);
+            det_ctr.alloc((size_t)2 * nc + 3);
             std::vector<int32_t> cs(P.tile_cams.size(), 0), ios((size_t)ntiles, -1), cnt((size_t)nc, 0);
             int32_t io_n = 0;
             for (int64_t i = 0; i < ntiles; ++i) {              // launch order
@@ -634,13 +634,14 @@ struct Core {
         deterministic = on;
         d.deterministic = on ? 1 : 0;
         d.det_cam_turn = det_ctr.p; d.det_cm_turn = det_ctr.p ? det_ctr.p + P.nc : nullptr; d.det_io_turn = det_ctr.p ? det_ctr.p + 2 * (size_t)P.nc : nullptr;
+        d.det_timeouts = det_ctr.p ? det_ctr.p + 2 * (size_t)P.nc + 2 : nullptr;
         d.tile_cam_seq = tile_cam_seq.p; d.tile_io_seq = tile_io_seq.p; d.cm_chunk_seq = cm_chunk_seq.p;
     }
 
     // ---- K1: linearise at zz with damping lambda; builds the reduced system.
     void build_enqueue(const double *zz, double lambda, int scale) {
         stage(0);
-        if (deterministic) HIPCHK(hipMemsetAsync(det_ctr.p, 0, ((size_t)2 * P.nc + 2) * sizeof(unsigned), stream));
+        if (deterministic) HIPCHK(hipMemsetAsync(det_ctr.p, 0, ((size_t)2 * P.nc + 3) * sizeof(unsigned), stream));
         const bool fused_first = !s_dense_dirty && P.NS >= P.nc;
         if (!fused_first) prep_cams(zz);
         else cams_at_lin = false;
@@ -896,6 +897,11 @@ struct Core {
             mb_armed = true;
             sync();
             memcpy(h.data(), hpin, 8 * sizeof(double));
+        }
+        if (deterministic) {     // a ticket wait that gave up: the sums are incomplete (never seen; the cap exists so that it would be)
+            unsigned tmo = 0;
+            HIPCHK(hipMemcpy(&tmo, det_ctr.p + 2 * (size_t)P.nc + 2, sizeof(tmo), hipMemcpyDeviceToHost));
+            if (tmo) throw DeviceError{"deterministic mode: a ticket wait timed out"};
         }
         memcpy(hmm, hpin + 40, sizeof(hmm));
         memcpy(&hinfo, hpin + 44, sizeof(hinfo));

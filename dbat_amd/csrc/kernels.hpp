@@ -62,6 +62,7 @@ struct DevProblem {
     // whatever touches the shared IO rows goes through one global ticket.
     int deterministic;
     unsigned *det_cam_turn, *det_cm_turn, *det_io_turn;   // [nc], [nc], [2] counters, zero at the start of a build
+    unsigned *det_timeouts;         // waits that gave up (the host turns a non-zero count into an error)
     const int32_t *tile_cam_seq;    // [#tile cams] what det_cam_turn must show before the tile may add
     const int32_t *tile_io_seq;     // [ntiles]     ... det_io_turn[0] (-1: the tile has no IO rows)
     const int32_t *cm_chunk_seq;    // [chunks]     ... det_cm_turn[camera] (fixed IO) / det_io_turn[1] (self-calibration)
@@ -90,8 +91,13 @@ __device__ __forceinline__ void atomic_add_f64(double *p, double v) {
 
 // deterministic mode: wait until a ticket counter shows `want` (agent scope: the waiting and the signalling workgroup
 // may sit on different XCDs), and hand the turn on after this workgroup's atomics have been performed
-__device__ __forceinline__ void det_wait(const unsigned *ctr, unsigned want) {
-    while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != want) __builtin_amdgcn_s_sleep(2);
+// (every spin is capped -- about a second -- like those of the factorisation: a scheduling accident must end in an error
+// code, DevProblem::det_timeouts, not in a hung GPU)
+__device__ __forceinline__ void det_wait(const unsigned *ctr, unsigned want, unsigned *timeouts) {
+    for (int spins = 0; __hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != want; ++spins) {
+        __builtin_amdgcn_s_sleep(2);
+        if (spins > (1 << 23)) { __hip_atomic_fetch_add(timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+    }
 }
 __device__ __forceinline__ void det_pass(unsigned *ctr, unsigned next) {
     __hip_atomic_store(ctr, next, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -1159,7 +1165,7 @@ __global__ __launch_bounds__(256) void k_cam_normal(DevProblem d, const double *
     const int i = t >> 4, j = t & 15;
     const double g = (Gs[t] + Gs[256 + t]) + (Gs[512 + t] + Gs[768 + t]);
     // deterministic mode: the IO x IO block is common to all cameras -- one global ticket orders the chunks
-    if (d.deterministic) { if (t == 0) det_wait(d.det_io_turn + 1, (unsigned)d.cm_chunk_seq[blockIdx.x]); __syncthreads(); }
+    if (d.deterministic) { if (t == 0) det_wait(d.det_io_turn + 1, (unsigned)d.cm_chunk_seq[blockIdx.x], d.det_timeouts); __syncthreads(); }
     if (i < ncol && g != 0.0) {
         const int64_t ri = C.col[i];
         if (j < ncol) {
@@ -1236,7 +1242,7 @@ __global__ __launch_bounds__(256) void k_cam_normal6(DevProblem d, const double 
     }
     __syncthreads();
     // deterministic mode: the chunks of one camera add to its block in their order
-    if (d.deterministic) { if (t == 0) det_wait(d.det_cm_turn + cam, (unsigned)d.cm_chunk_seq[blockIdx.x]); __syncthreads(); }
+    if (d.deterministic) { if (t == 0) det_wait(d.det_cm_turn + cam, (unsigned)d.cm_chunk_seq[blockIdx.x], d.det_timeouts); __syncthreads(); }
     if (t < 27) {
         const double g = (Gs[t] + Gs[27 + t]) + (Gs[54 + t] + Gs[81 + t]);
         if (g != 0.0) {

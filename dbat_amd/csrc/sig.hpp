@@ -619,7 +619,10 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
         // row (6k) only changes the index and the sign
         if (d.deterministic) {                        // the chunks add to the tile in their order (they are taken in that order)
             volatile int *turn = &sy.flush_turn;
-            while (*turn != ch_cur - ch0) __builtin_amdgcn_s_sleep(1);
+            for (int spins = 0; *turn != ch_cur - ch0; ++spins) {
+                __builtin_amdgcn_s_sleep(1);
+                if (spins > (1 << 23)) { if (lane == 0) __hip_atomic_fetch_add(d.det_timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
         }
         {
             const int r6k = ry;                      // the row of y closes the chunk's rows
@@ -664,8 +667,8 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
     // ---------------------------------------------------------------- tile -> HBM
     // deterministic mode: this tile's turn at every one of its cameras (and at the shared IO rows)
     if (d.deterministic) {
-        if (t < ncam) det_wait(d.det_cam_turn + d.tile_cams[c0 + t], (unsigned)d.tile_cam_seq[c0 + t]);
-        if (IO && t == 64 && d.tile_io_seq[tile] >= 0) det_wait(d.det_io_turn, (unsigned)d.tile_io_seq[tile]);
+        if (t < ncam) det_wait(d.det_cam_turn + d.tile_cams[c0 + t], (unsigned)d.tile_cam_seq[c0 + t], d.det_timeouts);
+        if (IO && t == 64 && d.tile_io_seq[tile] >= 0) det_wait(d.det_io_turn, (unsigned)d.tile_io_seq[tile], d.det_timeouts);
         __syncthreads();
     }
     // one column per wave and trip: consecutive lanes, consecutive rows (neighbouring addresses in S).  All the
