@@ -84,8 +84,14 @@ def main():
                 e = [relerr(p, p_o), relerr(q, q_o), relerr(g, J.T @ (Rw * r_o))]
                 Jp = J @ p_o
                 if sing:      # rank-deficient after the thinning (the oracle's rcond test fires): both must say so, the steps mean nothing
-                    line += ' %s: singular in the oracle, device flag %s' % (h.build_kernel_name(), st['singular'])
-                    if not st['singular']: raise AssertionError('the device does not flag the singular system')
+                    # An exactly singular J'J leaves a last pivot of pure rounding noise, of either sign and around
+                    # eps x the largest: CHOLMOD's test (min / max)^2 < eps is then decided by that noise, in the
+                    # reference as much as here, and the atomic sums make the device's noise differ from run to run
+                    # (seed 6017: flagged in one run, rcond estimate 3 eps in another).  Required of the device: the
+                    # flag, or an estimate within a few eps of the threshold.
+                    line += ' %s: singular in the oracle, device flag %s (rcond estimate %.1e)' % (h.build_kernel_name(), st['singular'], st['rcond'])
+                    if not st['singular'] and not st['rcond'] < 64 * np.finfo(float).eps:
+                        raise AssertionError('the device does not see the singular system')
                     print(line, flush=True)
                     continue
                 ok = e[0] < 1e-6 and e[1] < 1e-7 and e[2] < 1e-9 and abs(st['JpJp'] - Jp @ Jp) <= 1e-6 * (Jp @ Jp) and not st['singular']

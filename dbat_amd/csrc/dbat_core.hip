@@ -768,7 +768,26 @@ struct Core {
     // trace_only: the linearisation is wanted for trace(J'J) alone (Levenberg-Marquardt's lambda0): the signature
     // kernel stops after the per-point sums (squared column norms), the reduced system is NOT formed -- a third of
     // a build.  The handle has no linearisation afterwards (lambda_lin = NaN: the loop builds the damped system).
+    // trace(J'J) at zz by one streaming pass (k_trace_cm): what Levenberg-Marquardt's first linearisation is for.
+    // One rank only (several ranks sum it with the vectors of a build).
+    void trace_only_pass(const double *zz) {
+        stage(0);
+        prep_cams(zz);
+#define L_TRACE(M, NCXV) LAUNCHK((k_trace_cm<M, NCXV>), dim3((unsigned)n_cm_chunks_all), dim3(256), 0, stream, d, zz, cams.p, cm_pt.p, cm_uv.p, P.uniform_w ? (const double *)nullptr : cm_w.p, cm_chunk_cam.p, cm_chunk_start.p, partial.p)
+        if (n_cm_chunks_all > 0) {
+            if (tile_ncx == 6) { DISPATCH_MODEL(L_TRACE, 6) } else if (tile_ncx == 14) { DISPATCH_MODEL(L_TRACE, 14) }
+            else if (tile_ncx == 15) { DISPATCH_MODEL(L_TRACE, 15) } else { DISPATCH_MODEL(L_TRACE, MAXCOL) }
+        }
+#undef L_TRACE
+        LAUNCHK(k_trace_tail, dim3(grid_zs), dim3(1024), 0, stream, d, gpart.p, gctr.p + 6, (const double *)partial.p, n_cm_chunks_all, hpin, ++mb_seq);
+        mb_armed = true; lin_pending = true;
+        sync();
+        pend_build = false;
+        lambda_lin = NAN; have_lin = false; s_valid = false;
+        ++n_trace_only;
+    }
     void build(const double *zz, double lambda, int scale, bool lazy = false, bool trace_only = false) {
+        if (trace_only && !multi() && P.nranks == 1) { trace_only_pass(zz); return; }
         pend_build = false;
         trace_only = trace_only && use_sig && ntiles > 0;
         d.trace_only = trace_only ? 1 : 0;             // an argument of this launch (DevProblem travels by value)

@@ -369,6 +369,55 @@ __global__ __launch_bounds__(1024) void k_prior_sq(DevProblem d, const double *_
     }
 }
 
+// trace(J'J) and nothing else -- levenberg_marquardt.m:76-95 linearises at x0 only to set lambda0 = c trace(J'J) / n.
+// One streaming pass over the camera-major copy: the squared weighted, masked Jacobian columns of every observation
+// (partial[chunk]); k_trace_tail adds the prior weights of the estimated unknowns and hands the total to the mailbox.
+template <int MODEL, int NCX>
+__global__ __launch_bounds__(256) void k_trace_cm(DevProblem d, const double *__restrict__ z,
+                                                  const CamRec *__restrict__ cams,
+                                                  const int32_t *__restrict__ cm_pt,
+                                                  const double *__restrict__ cm_uv, const double *__restrict__ cm_w,
+                                                  const int32_t *__restrict__ chunk_cam,
+                                                  const int64_t *__restrict__ chunk_start,
+                                                  double *__restrict__ partial) {
+    __shared__ double sh[8];
+    const CamRec &C = cams[chunk_cam[blockIdx.x]];
+    const int64_t q0 = chunk_start[blockIdx.x], q1 = chunk_start[blockIdx.x + 1];
+    const int ncol = NCX > 6 ? min(C.ncol, NCX) : 6;
+    double acc[1] = {0.0};
+    for (int64_t q = q0 + threadIdx.x; q < q1; q += 256) {
+        const int64_t zp = d.NS + 3 * (int64_t)cm_pt[q];
+        const double Q[3] = {z[zp], z[zp + 1], z[zp + 2]};
+        const unsigned est = (d.z_est[zp] ? 1u : 0u) | (d.z_est[zp + 1] ? 2u : 0u) | (d.z_est[zp + 2] ? 4u : 0u);
+        const double w0 = cm_w ? cm_w[2 * q] : C.w[0], w1 = cm_w ? cm_w[2 * q + 1] : C.w[1];
+        double r[2], E[2][NCX], B[2][3];
+        eval_obs_pre<MODEL, NCX>(d, C, Q, cm_uv[2 * q], cm_uv[2 * q + 1], w0, w1, est, r, E, B);
+        double s = 0.0;
+#pragma unroll
+        for (int a = 0; a < NCX; ++a) if (a < ncol) s += E[0][a] * E[0][a] + E[1][a] * E[1][a];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) s += B[0][c] * B[0][c] + B[1][c] * B[1][c];
+        acc[0] += s;
+    }
+    block_sum<1>(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc[0];
+}
+__global__ __launch_bounds__(1024) void k_trace_tail(DevProblem d, double *__restrict__ partial, unsigned *__restrict__ ctr,
+                                                     const double *__restrict__ obs_partial, int64_t n_obs_partial,
+                                                     double *__restrict__ mailbox, unsigned long long seq) {
+    __shared__ double sh[16];
+    double acc[1] = {0.0};
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.NZ; i += stride) {
+        const double w = d.z_prw[i];
+        if (w > 0 && d.z_est[i] && d.z_mine[i]) acc[0] += w;
+    }
+    if (grid_sum<1, 1>(acc, sh, partial, ctr, obs_partial, n_obs_partial) && threadIdx.x == 0) {
+        mailbox[32] = 0.0; mailbox[33] = acc[0]; mailbox[34] = 0.0;       // (f of the linearisation point: not computed here)
+        mailbox_done(mailbox, seq);
+    }
+}
+
 // After the build kernels: {sum of their npart residual partials + the prior rows' squares,
 // owned squared column norms of the point columns} -> out[0], out[1].  One launch.
 __global__ __launch_bounds__(1024) void k_build_tail(DevProblem d, const double *__restrict__ z,

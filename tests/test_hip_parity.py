@@ -1188,6 +1188,33 @@ def test_stage_timers_of_a_solve(hip):
         h.close()
 
 
+@pytest.mark.parametrize('case,variant', [('tiny', 'plain'), ('small', 'priors'), ('small', 'selfcal'),
+                                          ('small', 'imagevar'), ('small', 'groups4'), ('C1', 'plain')])
+def test_lm_trace_only_pass(hip, case, variant):
+    """Levenberg-Marquardt's lambda0 = c trace(J'J)/n (levenberg_marquardt.m:88-90) comes from a streaming pass that
+    forms no normal equations (k_trace_cm): the same trace as the full linearisation reports, and the same as the
+    oracle's J'J where that is small."""
+    s, _ = synth_struct(case, variant)
+    h = hip.Handle(s)
+    try:
+        x0 = h.serialize()
+        _, st = h.linearize_solve(x0, 0.0, False)
+        opt = hip.default_options('lm')
+        opt.store_trace = 0
+        opt.max_iter = 1
+        x, r, rr, damp, aux, T = h.solve(x0, opt)
+        assert r.n_trace_only == 1
+        lam0 = damp[0]
+        assert abs(lam0 - abs(opt.lambda0) * st['trace'] / h.n) <= 1e-12 * lam0
+        if case != 'C1':
+            so, x0o, w = oracle_setup(s)
+            _, K = o.brown_euler_cam4(x0o, so, jac=True)
+            tr = float((sp.diags(w) @ K.multiply(K)).sum())
+            assert abs(lam0 - abs(opt.lambda0) * tr / h.n) <= 1e-11 * lam0
+    finally:
+        h.close()
+
+
 @pytest.mark.parametrize('damping', ['gna', 'lm'])
 def test_c_driver_solve_matches_bundle(hip, damping, tmp_path):
     """create -> solve -> final residuals -> destroy from a compiled C caller of the ABI
