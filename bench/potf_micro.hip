@@ -58,6 +58,47 @@ struct ElimCol {
     }
 };
 
+// Variants of the column of V2 (round 4):
+//   X = 1  1/d = t (1 + e + e^2), t = y0^2 (two operations off the dependent chain, one more in total)
+//   X = 2  no scalar copy of the next pivot: it is the updated a[J+1] of lane J+1, fetched after the update
+//          (two v_readlane and two f64 operations fewer per column, a longer chain)
+//   X = 3  both
+//   X & 4  y = y0 (1 + e/2): second order (v_rsq_f64 would have to be good to 2^-27);  X & 8: 1/d = t (1 + e) likewise
+template <int J, int X>
+struct ElimColX {
+    static __device__ __forceinline__ void run(double (&a)[16], double &piv, int lane) {
+        const double araw = a[J];
+        const double sw = swap16_f64(araw);
+        const double m = (lane & 16) ? sw : araw;
+        constexpr int J1 = J + 1 < 16 ? J + 1 : 0;
+        const double y0 = __builtin_amdgcn_rsq(piv);
+        const double t = y0 * y0;
+        const double e = __builtin_fma(-piv, t, 1.0);
+        double y;
+        if constexpr (X & 4) y = __builtin_fma(0.5 * y0, e, y0); else y = __builtin_fma(y0, __builtin_fma(e, 0.375, 0.5) * e, y0);
+        double y2;
+        if constexpr (X & 8) y2 = __builtin_fma(t, e, t);
+        else if constexpr (X & 1) y2 = __builtin_fma(t, __builtin_fma(e, e, e), t); else y2 = y * y;
+        const double ly = araw * y2;
+        if constexpr (X & 2) {
+            if constexpr (J < 15) {
+                fmac_bcast<J1, true>(a[J1], m, -ly);
+                piv = readlane_f64(a[J1], J1);
+            }
+            a[J] = araw * y;
+            UpdFrom<J + 2, false>::run(a, m, -ly);
+        } else {
+            const double c1 = J < 15 ? readlane_f64(araw, J1) : 0.0;
+            const double rn = J < 15 ? readlane_f64(a[J1], J1) : 0.0;
+            piv = __builtin_fma(-c1 * c1, y2, rn);
+            a[J] = araw * y;
+            if constexpr (J < 15) a[J + 1] = __builtin_fma(-c1, ly, a[J + 1]);
+            UpdFrom<J + 2>::run(a, m, -ly);
+        }
+        if constexpr (J < 15) ElimColX<J + 1, X>::run(a, piv, lane);
+    }
+};
+
 template <int V>
 __device__ __forceinline__ void eliminate(double (&a)[16], double *col /* LDS, [2][16] of this wave */, int lane) {
     if constexpr (V == 0) {
@@ -81,6 +122,9 @@ __device__ __forceinline__ void eliminate(double (&a)[16], double *col /* LDS, [
     } else if constexpr (V == 2) {
         double piv = readlane_f64(a[0], 0);
         ElimCol<0>::run(a, piv, lane);
+    } else if constexpr (V >= 3) {
+        double piv = readlane_f64(a[0], 0);
+        ElimColX<0, V - 2>::run(a, piv, lane);
     } else {
         // column j of the diagonal rows -> LDS; every lane reads the multipliers back (same address: broadcast)
         double piv = readlane_f64(a[0], 0);
@@ -243,6 +287,22 @@ __global__ __launch_bounds__(256) void k_tile64(int iters, unsigned long long *o
     if (lane == 0) { out[2 * w] = c1 - c0; out[2 * w + 1] = w1 - w0; }
 }
 
+// accuracy of v_rsq_f64 / v_rcp_f64: max |1 - x y0^2|, max |1 - x r0| over a sweep of x
+__global__ void k_rsq_acc(double *out) {
+    double me = 0, mr = 0;
+    for (int i = threadIdx.x; i < (1 << 22); i += blockDim.x) {
+        const double x = exp2((double)(i % 97) - 48.0) * (1.0 + (double)i * (1.0 / (1 << 22)));
+        const double y0 = __builtin_amdgcn_rsq(x);
+        me = fmax(me, fabs(__builtin_fma(-x, y0 * y0, 1.0)));
+        const double r0 = __builtin_amdgcn_rcp(x);
+        mr = fmax(mr, fabs(__builtin_fma(-x, r0, 1.0)));
+    }
+    __shared__ double sh[2][256];
+    sh[0][threadIdx.x] = me; sh[1][threadIdx.x] = mr;
+    __syncthreads();
+    if (threadIdx.x == 0) { for (int k = 1; k < 256; ++k) { me = fmax(me, sh[0][k]); mr = fmax(mr, sh[1][k]); } out[0] = me; out[1] = mr; }
+}
+
 int main() {
     // SPD 16 x 16 block + 16 more rows
     std::vector<double> A(16 * 32);
@@ -257,12 +317,23 @@ int main() {
     hipMalloc(&dres[0], A.size() * 8); hipMalloc(&dres[1], A.size() * 8); hipMalloc(&dres[2], A.size() * 8); hipMalloc(&sink, 256 * 8); hipMalloc(&out, 64);
     const int iters = 2000;
     std::vector<double> r0(A.size()), r1(A.size()), r2(A.size());
-    for (int v = 0; v < 3; v += 2) {          // (V1, the LDS broadcast, is slower and is not maintained)
+    for (int v = 0; v < 8; ++v) {
+        if (v == 1) continue;                 // (V1, the LDS broadcast, is slower and is not maintained)
         for (int rep = 0; rep < 2; ++rep) {
             if (v == 0) hipLaunchKernelGGL(k_elim<0>, dim3(1), dim3(256), 0, 0, dA, iters, out, dres[0]);
             else if (v == 2) hipLaunchKernelGGL(k_elim<2>, dim3(1), dim3(256), 0, 0, dA, iters, out, dres[2]);
-            else hipLaunchKernelGGL(k_elim<1>, dim3(1), dim3(256), 0, 0, dA, iters, out, dres[1]);
+            else if (v == 3) hipLaunchKernelGGL(k_elim<3>, dim3(1), dim3(256), 0, 0, dA, iters, out, dres[1]);
+            else if (v == 4) hipLaunchKernelGGL(k_elim<4>, dim3(1), dim3(256), 0, 0, dA, iters, out, dres[1]);
+            else if (v == 5) hipLaunchKernelGGL(k_elim<5>, dim3(1), dim3(256), 0, 0, dA, iters, out, dres[1]);
+            else if (v == 6) hipLaunchKernelGGL(k_elim<9>, dim3(1), dim3(256), 0, 0, dA, iters, out, dres[1]);     // X = 7
+            else hipLaunchKernelGGL(k_elim<16>, dim3(1), dim3(256), 0, 0, dA, iters, out, dres[1]);               // X = 14
             hipDeviceSynchronize();
+        }
+        if (v >= 3) {
+            hipMemcpy(r1.data(), dres[1], A.size() * 8, hipMemcpyDeviceToHost);
+            hipMemcpy(r0.data(), dres[0], A.size() * 8, hipMemcpyDeviceToHost);
+            double mdx = 0; for (size_t i = 0; i < A.size(); ++i) mdx = fmax(mdx, fabs(r0[i] - r1[i]));
+            printf("   max |V0 - V%d| = %.3g\n", v, mdx);
         }
         unsigned long long h[8]; hipMemcpy(h, out, 64, hipMemcpyDeviceToHost);
         printf("V%d: %.0f shader ticks, %.3f us per 16-column panel (wave 0), %.1f ticks per column\n", v,
@@ -293,6 +364,11 @@ int main() {
         }
         unsigned long long h[8]; hipMemcpy(h, out, 64, hipMemcpyDeviceToHost);
         printf("64^3 tile product from LDS (64 MFMAs per wave), variant %d: %.0f shader ticks, %.3f us\n", var, (double)h[0] / 2000, (double)h[1] * 0.01 / 2000);
+    }
+    {
+        double *acc; hipMalloc(&acc, 16); hipLaunchKernelGGL(k_rsq_acc, dim3(1), dim3(256), 0, 0, acc); hipDeviceSynchronize();
+        double h[2]; hipMemcpy(h, acc, 16, hipMemcpyDeviceToHost);
+        printf("v_rsq_f64: max |1 - x y0^2| = %.3g (2^%.1f);  v_rcp_f64: max |1 - x r0| = %.3g (2^%.1f)\n", h[0], log2(h[0]), h[1], log2(h[1]));
     }
     const char *names[] = {"16 dependent v_fma_f64", "16 independent v_fma_f64", "8 x (2 v_readlane + v_fma_f64)",
                            "4 dependent (v_rsq_f64 + v_fma_f64)", "16 v_readlane_b32 + adds"};

@@ -227,17 +227,23 @@ struct DfElimCol {
         // other rows (lanes 16-31) are the diagonal rows' (lanes 0-15) entries
         const double m = df_mirror16(araw);
         constexpr int J1 = J + 1 < 16 ? J + 1 : 0;
-        const double c1 = J < 15 ? readlane_f64(araw, J1) : 0.0;
-        const double rn = J < 15 ? readlane_f64(a[J1], J1) : 0.0;
+        // 1/sqrt(d) = y0 (1 + e/2 + 3 e^2/8) and 1/d = y0^2 (1 + e + e^2), e = 1 - d y0^2 (v_rsq_f64 is good to 2^-23: third
+        // order).  Every f64 operation costs its 6.5 ticks of issue whether it depends on the one before or not
+        // (bench/potf_micro.hip), so a column costs what it issues: the next pivot is the updated a[J+1] of lane J+1
+        // itself, read back after the update (one DPP operation + two v_readlane), not a scalar copy of the same
+        // arithmetic (four v_readlane + two operations): 161 -> 134 ticks per column.
         const double y0 = __builtin_amdgcn_rsq(piv);
-        const double e = __builtin_fma(-piv, y0 * y0, 1.0);
+        const double t = y0 * y0;
+        const double e = __builtin_fma(-piv, t, 1.0);
         const double y = __builtin_fma(y0, __builtin_fma(e, 0.375, 0.5) * e, y0);
-        const double y2 = y * y;
-        piv = __builtin_fma(-c1, c1 * y2, rn);
-        const double ly = araw * y2;
+        const double y2 = __builtin_fma(t, __builtin_fma(e, e, e), t);
+        const double nly = -(araw * y2);
+        if constexpr (J < 15) {
+            df_fmac_bcast<J1, true>(a[J1], m, nly);
+            piv = readlane_f64(a[J1], J1);
+        }
         a[J] = araw * y;
-        if constexpr (J < 15) a[J + 1] = __builtin_fma(-c1, ly, a[J + 1]);
-        DfUpdFrom<J + 2>::run(a, m, -ly);
+        DfUpdFrom<J + 2, false>::run(a, m, nly);
         if constexpr (J < 15) DfElimCol<J + 1>::run(a, piv, badmask, lane);
     }
 };
@@ -317,12 +323,10 @@ __device__ __forceinline__ void df_potf2(double *Tm, int nb, int j0, int *info, 
             for (int q = 0; q < 16; ++q) a[q] = (act && ident < 0) ? Tm[(16 * p + q) * LD + row] : (ident == q ? 1.0 : 0.0);
             if (tr && t == 0 && p == 1) tr[5] = wall_clock64();
             unsigned badmask = 0;                           // bit j: pivot j of the panel is not positive
-            // The wave is alone on its SIMD, so the dependent chain pivot -> 1/sqrt -> next pivot is
-            // what a column costs.  It runs on wave-uniform values only: the multipliers c_k = a_j(lane k)
-            // are taken BEFORE the column is scaled (they do not wait for 1/sqrt; DPP row broadcasts inside the
-            // f64 operation, see df_fmac_bcast), every update is a_k -= c_k (a_j / d), and the next pivot d' = a_{j+1}(lane j+1) - c (c / d) is
-            // formed from scalars with the same two operations the lane itself performs (same bits).
-            // 1/sqrt: v_rsq_f64 and one third-order step y0 (1 + e/2 + 3e^2/8), e = 1 - d y0^2.
+            // The wave is alone on its SIMD and every operation costs its issue slot: a column costs what it
+            // issues.  The multipliers c_k = a_j(lane k) are taken BEFORE the column is scaled (DPP row broadcasts
+            // inside the f64 operation, see df_fmac_bcast), every update is a_k -= c_k (a_j / d), and the next
+            // pivot is the updated a_{j+1} of lane j+1 (DfElimCol).
             // (Padding columns of a ragged block are identity columns: their pivots are 1.)
             double piv = readlane_f64(a[0], 0);
             // (all 64 lanes run it although only the lower 32 hold rows: with the upper half out of EXEC the elimination

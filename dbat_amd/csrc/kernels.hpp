@@ -1273,15 +1273,32 @@ __global__ __launch_bounds__(256) void k_cam_normal6(DevProblem d, const double 
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (pt[u] < 0) continue;
-            double r[2], E[2][6], B[2][3];
-            eval_obs_pre<MODEL, 6>(d, C, Qv[u], uv[u].x, uv[u].y, ww[u].x, ww[u].y, 7u, r, E, B);
+            // residual and weighted camera block of the observation, unmasked (the masks of the camera's fixed elements are
+            // applied to the sums), nothing else: the kernel is bound by the vector instructions it issues (obs_eval,
+            // PRE: res_euler_brown_*.m with the image side precomputed, eulerpinhole2.m, pinhole.m:54-66)
+            const double d0 = Qv[u][0] - C.c[0], d1 = Qv[u][1] - C.c[1], d2 = Qv[u][2] - C.c[2];
+            const double X0 = C.Mt[0] * d0 + C.Mt[1] * d1 + C.Mt[2] * d2;
+            const double X1 = C.Mt[3] * d0 + C.Mt[4] * d1 + C.Mt[5] * d2;
+            const double X2 = C.Mt[6] * d0 + C.Mt[7] * d1 + C.Mt[8] * d2;
+            const double iz = recip(X2);
+            const double ph0 = X0 * iz, ph1 = X1 * iz;
+            const double nf = -C.f, sc = nf * iz, s0 = sc * ww[u].x, s1 = sc * ww[u].y;
+            const double r0 = (nf * ph0 - uv[u].x) * ww[u].x, r1 = (nf * ph1 - uv[u].y) * ww[u].y;
+            double y[3][3];
+            angle_terms(C, d0, d1, d2, X0, X1, X2, y);
+            double e0[6], e1[6];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                e0[k] = -s0 * (C.Mt[k] - ph0 * C.Mt[6 + k]);      e1[k] = -s1 * (C.Mt[3 + k] - ph1 * C.Mt[6 + k]);
+                e0[3 + k] = s0 * (y[k][0] - ph0 * y[k][2]);       e1[3 + k] = s1 * (y[k][1] - ph1 * y[k][2]);
+            }
             int n = 0;
 #pragma unroll
             for (int i = 0; i < 6; ++i)
 #pragma unroll
-                for (int j = 0; j <= i; ++j, ++n) G[n] += E[0][i] * E[0][j] + E[1][i] * E[1][j];
+                for (int j = 0; j <= i; ++j, ++n) G[n] = __builtin_fma(e0[i], e0[j], __builtin_fma(e1[i], e1[j], G[n]));
 #pragma unroll
-            for (int i = 0; i < 6; ++i) G[21 + i] += E[0][i] * r[0] + E[1][i] * r[1];
+            for (int i = 0; i < 6; ++i) G[21 + i] = __builtin_fma(e0[i], r0, __builtin_fma(e1[i], r1, G[21 + i]));
         }
     }
 #pragma unroll
@@ -1293,12 +1310,16 @@ __global__ __launch_bounds__(256) void k_cam_normal6(DevProblem d, const double 
     // deterministic mode: the chunks of one camera add to its block in their order
     if (d.deterministic) { if (t == 0) det_wait(d.det_cm_turn + cam, (unsigned)d.cm_chunk_seq[blockIdx.x], d.det_timeouts); __syncthreads(); }
     if (t < 27) {
-        const double g = (Gs[t] + Gs[27 + t]) + (Gs[54 + t] + Gs[81 + t]);
+        double g = (Gs[t] + Gs[27 + t]) + (Gs[54 + t] + Gs[81 + t]);
+        int i = t - 21, j = i;
+        if (t < 21) {
+            i = 0;
+            while ((i + 1) * (i + 2) / 2 <= t) ++i;
+            j = t - i * (i + 1) / 2;
+        }
+        if (!((C.eo_est >> i) & (C.eo_est >> j) & 1u)) g = 0.0;      // a camera element that is not estimated: no row, no column
         if (g != 0.0) {
             if (t < 21) {
-                int i = 0;
-                while ((i + 1) * (i + 2) / 2 <= t) ++i;
-                const int j = t - i * (i + 1) / 2;
                 const int64_t ri = C.col[i], rj = C.col[j];
                 if (i == j) { atomic_add_f64(S + ri * d.ldS + ri, g); atomic_add_f64(diagU + ri, g); }
                 else atomic_add_f64(S + (ri >= rj ? rj * d.ldS + ri : ri * d.ldS + rj), g);

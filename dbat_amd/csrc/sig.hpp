@@ -133,6 +133,40 @@ __device__ __forceinline__ void sig_eval_Z(const CamRec &C, const double (&Q)[3]
     }
 }
 
+// Back-substitution, fixed IO -- t = E dc of one observation and its weighted point block B, without E: the step dc moves
+// the camera-frame point by dX = -M dc[0..2] + sum_a y_a dc[3+a] (world2cam.m:82, angle_terms), and the projection
+// takes that to t = (s0 (dX0 - ph0 dX2), s1 (dX1 - ph1 dX2)).  65 operations where the 2 x 6 block E and its product
+// with dc took about 110 (the kernel is bound by the vector instructions it issues: SQ_INSTS_VALU, profiles/r04_c3_summary.md).
+// dc: 0 for camera elements that are not estimated (masked once per camera); B: not masked by the point's fixed
+// coordinates -- V^-1 decouples them (build: V(c,c) = 1, row and column 0) and their step is set to zero at the end.
+__device__ __forceinline__ void sig_step_dot6(const CamRec &C, const double (&Q)[3], double w0, double w1,
+                                              const double *dc, double &t0, double &t1, double (&B)[2][3]) {
+    const double d0 = Q[0] - C.c[0], d1 = Q[1] - C.c[1], d2 = Q[2] - C.c[2];
+    const double X0 = C.Mt[0] * d0 + C.Mt[1] * d1 + C.Mt[2] * d2;
+    const double X1 = C.Mt[3] * d0 + C.Mt[4] * d1 + C.Mt[5] * d2;
+    const double X2 = C.Mt[6] * d0 + C.Mt[7] * d1 + C.Mt[8] * d2;
+    const double iz = recip(X2);
+    const double ph0 = X0 * iz, ph1 = X1 * iz;
+    const double s = -C.f * iz, s0 = s * w0, s1 = s * w1;
+    double y[3][3];
+    angle_terms(C, d0, d1, d2, X0, X1, X2, y);
+    const double c0 = dc[0], c1 = dc[1], c2 = dc[2], a0 = dc[3], a1 = dc[4], a2 = dc[5];
+    const double n0 = -c0, n1 = -c1, n2 = -c2;       // (wave-uniform: the negations cost nothing per observation)
+    const double e0 = __builtin_fma(C.Mt[0], n0, __builtin_fma(C.Mt[1], n1, __builtin_fma(C.Mt[2], n2,
+                      __builtin_fma(y[0][0], a0, __builtin_fma(y[1][0], a1, y[2][0] * a2)))));
+    const double e1 = __builtin_fma(C.Mt[3], n0, __builtin_fma(C.Mt[4], n1, __builtin_fma(C.Mt[5], n2,
+                      __builtin_fma(y[0][1], a0, __builtin_fma(y[1][1], a1, y[2][1] * a2)))));
+    const double e2 = __builtin_fma(C.Mt[6], n0, __builtin_fma(C.Mt[7], n1, __builtin_fma(C.Mt[8], n2,
+                      __builtin_fma(y[0][2], a0, y[1][2] * a1))));
+    t0 = s0 * (e0 - ph0 * e2);
+    t1 = s1 * (e1 - ph1 * e2);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        B[0][k] = s0 * (C.Mt[k] - ph0 * C.Mt[6 + k]);
+        B[1][k] = s1 * (C.Mt[3 + k] - ph1 * C.Mt[6 + k]);
+    }
+}
+
 // NCX = 6: fixed IO.  NCX = 14: self-calibration -- the estimated IO columns of the tile's cameras are
 // nio further rows of every chunk (after its 6k camera rows, before the row of y): an IO row is
 // shared by the k observations of a point, so its k-columns are summed with ds_add_f64 into the
@@ -794,7 +828,8 @@ __global__ __launch_bounds__(256) void k_backsub_sig(DevProblem d, const double 
         for (int idx = lane; idx < k * NCX; idx += 64) {
             const int c = idx / NCX, a = idx - c * NCX;
             const CamRec &C = *reinterpret_cast<const CamRec *>(crec[wv][c]);
-            dcs[wv][c][a] = a < (NCX > 6 ? min(C.ncol, NCX) : 6) ? dz[C.col[a]] : 0.0;
+            const bool on = a < (NCX > 6 ? min(C.ncol, NCX) : 6) && (NCX > 6 || ((C.eo_est >> a) & 1u));
+            dcs[wv][c][a] = on ? dz[C.col[a]] : 0.0;
         }
         __builtin_amdgcn_wave_barrier();
         const bool act = lane < npts;
@@ -809,33 +844,41 @@ __global__ __launch_bounds__(256) void k_backsub_sig(DevProblem d, const double 
         //   sum_j |t_j + B_j dp|^2 = sum |t_j|^2 + 2 dp' (sum B_j' t_j) + dp' (sum B_j' B_j) dp
         // so |J p|^2 of the point's rows needs no second evaluation of its observations
         double sB[3] = {0, 0, 0}, V0[6] = {0, 0, 0, 0, 0, 0}, tt2 = 0;
+        // (two copies of the sweep, with the weights of the observations or of the camera: a select between a
+        // global and an LDS address inside the loop becomes a flat load)
+        auto sweep = [&](auto per_obs_w) {
         for (int j = 0; j < k; ++j) {
             const CamRec &C = *reinterpret_cast<const CamRec *>(crec[wv][j]);
-            const double2 uv = uvp[q0 + (int64_t)j * gm];
-            const double w0 = sg_w ? wp[q0 + (int64_t)j * gm].x : C.w[0], w1 = sg_w ? wp[q0 + (int64_t)j * gm].y : C.w[1];
+            double2 uv = {0, 0};
+            if constexpr (NCX > 6) uv = uvp[q0 + (int64_t)j * gm];        // (fixed IO: E and B do not depend on the image point)
+            double w0, w1;
+            if constexpr (decltype(per_obs_w)::value) { const double2 ww = wp[q0 + (int64_t)j * gm]; w0 = ww.x; w1 = ww.y; }
+            else { w0 = C.w[0]; w1 = C.w[1]; }
             double B[2][3], t0 = 0, t1 = 0;
             if constexpr (NCX > 6) {
                 // self-calibration: t = E dc straight from the pieces of the model (no 2 x 14 block E, no IO
                 // derivative block in registers).  The plan routes a problem here only if every camera has
                 // the usual eight IO columns (Plan::all_std8); anything else takes k_backsub
                 obs_step_dot<MODEL, true>(C, Q, uv.x, uv.y, w0, w1, est, dcs[wv][j], t0, t1, B);
-            } else {                                 // (fixed IO: the same trick costs registers here, 156 against 108)
-                double r[2], E[2][NCX];
-                eval_obs_pre<MODEL, NCX>(d, C, Q, uv.x, uv.y, w0, w1, est, r, E, B);
-#pragma unroll
-                for (int a = 0; a < NCX; ++a) { const double dc = dcs[wv][j][a]; t0 += E[0][a] * dc; t1 += E[1][a] * dc; }
+            } else {
+                sig_step_dot6(C, Q, w0, w1, dcs[wv][j], t0, t1, B);
             }
-            tt2 += t0 * t0 + t1 * t1;
-            sB[0] += B[0][0] * t0 + B[1][0] * t1;
-            sB[1] += B[0][1] * t0 + B[1][1] * t1;
-            sB[2] += B[0][2] * t0 + B[1][2] * t1;
-            V0[0] += B[0][0] * B[0][0] + B[1][0] * B[1][0];
-            V0[1] += B[0][0] * B[0][1] + B[1][0] * B[1][1];
-            V0[2] += B[0][0] * B[0][2] + B[1][0] * B[1][2];
-            V0[3] += B[0][1] * B[0][1] + B[1][1] * B[1][1];
-            V0[4] += B[0][1] * B[0][2] + B[1][1] * B[1][2];
-            V0[5] += B[0][2] * B[0][2] + B[1][2] * B[1][2];
+            // (two accumulating FMAs per sum: the kernel is bound by the vector instructions it issues)
+#define DBAT_ACC2(acc, a, b, c, e) acc = __builtin_fma(a, b, __builtin_fma(c, e, acc))
+            DBAT_ACC2(tt2, t0, t0, t1, t1);
+            DBAT_ACC2(sB[0], B[0][0], t0, B[1][0], t1);
+            DBAT_ACC2(sB[1], B[0][1], t0, B[1][1], t1);
+            DBAT_ACC2(sB[2], B[0][2], t0, B[1][2], t1);
+            DBAT_ACC2(V0[0], B[0][0], B[0][0], B[1][0], B[1][0]);
+            DBAT_ACC2(V0[1], B[0][0], B[0][1], B[1][0], B[1][1]);
+            DBAT_ACC2(V0[2], B[0][0], B[0][2], B[1][0], B[1][2]);
+            DBAT_ACC2(V0[3], B[0][1], B[0][1], B[1][1], B[1][1]);
+            DBAT_ACC2(V0[4], B[0][1], B[0][2], B[1][1], B[1][2]);
+            DBAT_ACC2(V0[5], B[0][2], B[0][2], B[1][2], B[1][2]);
+#undef DBAT_ACC2
         }
+        };
+        if (sg_w) sweep(std::true_type{}); else sweep(std::false_type{});
         {
             const double s0 = gp[3 * (int64_t)pt] + sB[0], s1 = gp[3 * (int64_t)pt + 1] + sB[1], s2 = gp[3 * (int64_t)pt + 2] + sB[2];
             double p0, p1, p2;
