@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void k_residual(DevProblem d, const double *__
         const double w0 = d.o_w ? d.o_w[2 * o] : C.w[0], w1 = d.o_w ? d.o_w[2 * o + 1] : C.w[1];
         r[0] *= w0; r[1] *= w1;
         if (r_w) { r_w[2 * o] = r[0]; r_w[2 * o + 1] = r[1]; }
-        acc[0] += r[0] * r[0] + r[1] * r[1];
+        acc[0] = fma2(acc[0], r[0], r[0], r[1], r[1]);
     }
     block_sum<1>(acc, sh);
     if (threadIdx.x == 0) partial[blockIdx.x] = acc[0];
@@ -825,7 +825,7 @@ __global__ __launch_bounds__(256) void k_build(DevProblem d, const double *__res
                         double val = -(Y[a][0] * wb0 + Y[a][1] * wb1 + Y[a][2] * wb2);
                         if (jj == t) {
                             if (b < a) continue;
-                            val += E[0][a] * E[0][b] + E[1][a] * E[1][b];
+                            val = fma2(val, E[0][a], E[0][b], E[1][a], E[1][b]);
                         }
                         atomic_add_f64(S + (int64_t)(cbase + a) * d.ldS + (rbase + b), val);
                     }
@@ -862,7 +862,7 @@ __global__ __launch_bounds__(256) void k_build(DevProblem d, const double *__res
                             double eb0 = 0, eb1 = 0;
 #pragma unroll
                             for (int q = 0; q < NCX; ++q) if (q == b) { eb0 = E[0][q]; eb1 = E[1][q]; }
-                            val += ea0 * eb0 + ea1 * eb1;
+                            val = fma2(val, ea0, eb0, ea1, eb1);
                         }
                         atomic_add_f64(S + (int64_t)gcol * d.ldS + grow, val);
                     }
@@ -905,7 +905,7 @@ __global__ __launch_bounds__(256) void k_build(DevProblem d, const double *__res
                             double eb0 = 0, eb1 = 0;
 #pragma unroll
                             for (int q = 6; q < NCX; ++q) if (q == b) { eb0 = E[0][q]; eb1 = E[1][q]; }
-                            val += ea0 * eb0 + ea1 * eb1;
+                            val = fma2(val, ea0, eb0, ea1, eb1);
                         }
                     }
                     add_shared(S, gcol * d.ldS + grow, valid, val);
@@ -959,16 +959,16 @@ __global__ __launch_bounds__(256) void k_build_giant(DevProblem d, const double 
         const int ncol = WITH_IO ? C.ncol : 6;
         double r[2], E[2][NCX], B[2][3];
         eval_obs_cols<MODEL, WITH_IO>(d, C, z, o, pt, r, E, B);
-        rr += r[0] * r[0] + r[1] * r[1];
-        acc[0] += B[0][0] * B[0][0] + B[1][0] * B[1][0];
-        acc[1] += B[0][0] * B[0][1] + B[1][0] * B[1][1];
-        acc[2] += B[0][0] * B[0][2] + B[1][0] * B[1][2];
-        acc[3] += B[0][1] * B[0][1] + B[1][1] * B[1][1];
-        acc[4] += B[0][1] * B[0][2] + B[1][1] * B[1][2];
-        acc[5] += B[0][2] * B[0][2] + B[1][2] * B[1][2];
-        acc[6] += B[0][0] * r[0] + B[1][0] * r[1];
-        acc[7] += B[0][1] * r[0] + B[1][1] * r[1];
-        acc[8] += B[0][2] * r[0] + B[1][2] * r[1];
+        rr = fma2(rr, r[0], r[0], r[1], r[1]);
+        acc[0] = fma2(acc[0], B[0][0], B[0][0], B[1][0], B[1][0]);
+        acc[1] = fma2(acc[1], B[0][0], B[0][1], B[1][0], B[1][1]);
+        acc[2] = fma2(acc[2], B[0][0], B[0][2], B[1][0], B[1][2]);
+        acc[3] = fma2(acc[3], B[0][1], B[0][1], B[1][1], B[1][1]);
+        acc[4] = fma2(acc[4], B[0][1], B[0][2], B[1][1], B[1][2]);
+        acc[5] = fma2(acc[5], B[0][2], B[0][2], B[1][2], B[1][2]);
+        acc[6] = fma2(acc[6], B[0][0], r[0], B[1][0], r[1]);
+        acc[7] = fma2(acc[7], B[0][1], r[0], B[1][1], r[1]);
+        acc[8] = fma2(acc[8], B[0][2], r[0], B[1][2], r[1]);
         double *wl = Wg + (size_t)i * strideW;
         for (int a = 0; a < NCX; ++a) {
             if (a >= ncol) break;
@@ -1096,9 +1096,9 @@ __global__ __launch_bounds__(256) void k_backsub_giant(DevProblem d, const doubl
 #pragma unroll
         for (int a = 0; a < NCX; ++a)
             if (a < ncol) { const double dc = dz[C.col[a]]; tt[0] += E[0][a] * dc; tt[1] += E[1][a] * dc; }
-        s[0] += B[0][0] * tt[0] + B[1][0] * tt[1];
-        s[1] += B[0][1] * tt[0] + B[1][1] * tt[1];
-        s[2] += B[0][2] * tt[0] + B[1][2] * tt[1];
+        s[0] = fma2(s[0], B[0][0], tt[0], B[1][0], tt[1]);
+        s[1] = fma2(s[1], B[0][1], tt[0], B[1][1], tt[1]);
+        s[2] = fma2(s[2], B[0][2], tt[0], B[1][2], tt[1]);
     }
     block_sum<3>(s, sh);
     if (t == 0) {
@@ -1122,7 +1122,7 @@ __global__ __launch_bounds__(256) void k_backsub_giant(DevProblem d, const doubl
             if (a < ncol) { const double dc = dz[C.col[a]]; tt[0] += E[0][a] * dc; tt[1] += E[1][a] * dc; }
         const double j0 = tt[0] + B[0][0] * dps[0] + B[0][1] * dps[1] + B[0][2] * dps[2];
         const double j1 = tt[1] + B[1][0] * dps[0] + B[1][1] * dps[1] + B[1][2] * dps[2];
-        acc[0] += j0 * j0 + j1 * j1;
+        acc[0] = fma2(acc[0], j0, j0, j1, j1);
     }
     block_sum<2>(acc, sh);
     if (t == 0) { partial[2 * blockIdx.x] = acc[0]; partial[2 * blockIdx.x + 1] = acc[1]; }
@@ -1245,6 +1245,7 @@ __global__ __launch_bounds__(256) void k_cam_normal6(DevProblem d, const double 
                                                      double *__restrict__ g_c, double *__restrict__ g_red,
                                                      double *__restrict__ diagU) {
     __shared__ double Gs[4 * 27];
+    __shared__ double Rd[4][14 * 65];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int cam = chunk_cam[blockIdx.x];
     const int64_t q0 = chunk_start[blockIdx.x], q1 = chunk_start[blockIdx.x + 1];
@@ -1301,10 +1302,27 @@ __global__ __launch_bounds__(256) void k_cam_normal6(DevProblem d, const double 
             for (int i = 0; i < 6; ++i) G[21 + i] = __builtin_fma(e0[i], r0, __builtin_fma(e1[i], r1, G[21 + i]));
         }
     }
+    // The 27 sums over the wave's lanes through LDS, 14 at a time: every lane leaves its values, lane l then adds value
+    // l % 16 over the 16 lanes of quarter l / 16, and two exchanges join the quarters -- about 110 instructions where 27
+    // DPP wave sums took 400 (a chunk has eight observations per lane: that was a quarter of the kernel's instructions).
 #pragma unroll
-    for (int i = 0; i < 27; ++i) {
-        const double v = wave_sum_f64(G[i]);
-        if (lane == 0) Gs[w * 27 + i] = v;
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int v = 0; v < 14; ++v)
+            if (14 * h + v < 27) Rd[w][v * 65 + lane] = G[14 * h + v];
+        lds_fence();
+        __builtin_amdgcn_wave_barrier();
+        const int v = lane & 15, q4 = lane >> 4;
+        double sum = 0.0;
+        if (v < 14) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sum += Rd[w][v * 65 + 16 * q4 + i];
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        if (lane < 14 && 14 * h + lane < 27) Gs[w * 27 + 14 * h + lane] = sum;
+        lds_fence();
+        __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
     // deterministic mode: the chunks of one camera add to its block in their order
@@ -1524,7 +1542,7 @@ __global__ __launch_bounds__(512) void k_build_tile2(DevProblem d, const double 
                     ciop[0] = cp[0]; ciop[1] = cp[1]; ciop[2] = cp[2]; ciop[3] = cp[3];
                 }
                 eval_obs_pre<MODEL, NCX>(d, C, Q, uu, vv, w0, w1, est, r, E, B);
-                rr += r[0] * r[0] + r[1] * r[1];
+                rr = fma2(rr, r[0], r[0], r[1], r[1]);
                 // per-point sums of B'B and B'r with LDS atomics (the LDS unit, not the FP64 pipe the
                 // matrix work of the consumer wave on this SIMD is using)
                 double *ps = red + (size_t)(b & 1) * (NPROD / 2) * 9 + (size_t)pidx * 9;
@@ -1910,7 +1928,7 @@ __global__ __launch_bounds__(768) void k_build_tile3(DevProblem d, const double 
                 const CamRec &C = cams[cam];
                 const double w0 = d.o_w ? d.o_w[2 * o] : C.w[0], w1 = d.o_w ? d.o_w[2 * o + 1] : C.w[1];
                 eval_obs_pre<MODEL, NCX>(d, C, Q, uu, vv, w0, w1, est, r, E, B);
-                rr += r[0] * r[0] + r[1] * r[1];
+                rr = fma2(rr, r[0], r[0], r[1], r[1]);
                 double *ps = redg + (size_t)pidx * 9;
                 atomic_add_f64(ps + 0, B[0][0] * B[0][0] + B[1][0] * B[1][0]);
                 atomic_add_f64(ps + 1, B[0][0] * B[0][1] + B[1][0] * B[1][1]);
@@ -2587,7 +2605,7 @@ __global__ __launch_bounds__(256) void k_jtimes(DevProblem d, const double *__re
 #pragma unroll
         for (int a = 0; a < NCX; ++a)
             if (a < ncol) { const double vc = v[C.col[a]]; j0 += E[0][a] * vc; j1 += E[1][a] * vc; }
-        acc[0] += j0 * j0 + j1 * j1;
+        acc[0] = fma2(acc[0], j0, j0, j1, j1);
     }
     block_sum<2>(acc, sh);
     if (threadIdx.x == 0) { partial[2 * blockIdx.x] = acc[0]; partial[2 * blockIdx.x + 1] = acc[1]; }

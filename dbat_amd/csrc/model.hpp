@@ -75,6 +75,12 @@ DBAT_HD void angle_terms(const CamRec &cam, double d0, double d1, double d2, dou
     y[2][0] = X1; y[2][1] = -X0; y[2][2] = 0.0;
 }
 
+// acc + a b + c d as two accumulating FMAs.  (Written `acc += a * b + c * d` the compiler keeps the association of the
+// source: a multiplication, an FMA and an addition; the observation kernels are bound by the vector instructions they issue.)
+DBAT_HD double fma2(double acc, double a, double b, double c, double d) {
+    return __builtin_fma(a, b, __builtin_fma(c, d, acc));
+}
+
 // 1/x: v_rcp_f64 and two Newton steps on the device (5 operations; the IEEE division sequence takes 12)
 DBAT_HD double recip(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -303,16 +303,16 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
             const double2 *uvp = reinterpret_cast<const double2 *>(sg_uv), *wp = reinterpret_cast<const double2 *>(sg_w);
             // V += B'B, g += B'r of one observation (weighted, fixed coordinates masked)
             auto accumulate = [&](const double (&r)[2], const double (&B)[2][3]) {
-                if (act) rr += r[0] * r[0] + r[1] * r[1];
-                V[0] += B[0][0] * B[0][0] + B[1][0] * B[1][0];
-                V[1] += B[0][0] * B[0][1] + B[1][0] * B[1][1];
-                V[2] += B[0][0] * B[0][2] + B[1][0] * B[1][2];
-                V[3] += B[0][1] * B[0][1] + B[1][1] * B[1][1];
-                V[4] += B[0][1] * B[0][2] + B[1][1] * B[1][2];
-                V[5] += B[0][2] * B[0][2] + B[1][2] * B[1][2];
-                g[0] += B[0][0] * r[0] + B[1][0] * r[1];
-                g[1] += B[0][1] * r[0] + B[1][1] * r[1];
-                g[2] += B[0][2] * r[0] + B[1][2] * r[1];
+                if (act) rr = fma2(rr, r[0], r[0], r[1], r[1]);
+                V[0] = fma2(V[0], B[0][0], B[0][0], B[1][0], B[1][0]);
+                V[1] = fma2(V[1], B[0][0], B[0][1], B[1][0], B[1][1]);
+                V[2] = fma2(V[2], B[0][0], B[0][2], B[1][0], B[1][2]);
+                V[3] = fma2(V[3], B[0][1], B[0][1], B[1][1], B[1][1]);
+                V[4] = fma2(V[4], B[0][1], B[0][2], B[1][1], B[1][2]);
+                V[5] = fma2(V[5], B[0][2], B[0][2], B[1][2], B[1][2]);
+                g[0] = fma2(g[0], B[0][0], r[0], B[1][0], r[1]);
+                g[1] = fma2(g[1], B[0][1], r[0], B[1][1], r[1]);
+                g[2] = fma2(g[2], B[0][2], r[0], B[1][2], r[1]);
             };
             const int kk = DBAT_ABLATE(d, 4) ? 1 : k;
             if constexpr (!IO) {
@@ -388,9 +388,9 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
                             for (int q = 0; q < NQ1; ++q)
                                 if (6 + q < ncol) {
                                     const double e0 = Eio[0][6 + q], e1 = Eio[1][6 + q];
-                                    pZio[OFF + q][0] += e0 * B[0][0] + e1 * B[1][0];
-                                    pZio[OFF + q][1] += e0 * B[0][1] + e1 * B[1][1];
-                                    pZio[OFF + q][2] += e0 * B[0][2] + e1 * B[1][2];
+                                    pZio[OFF + q][0] = fma2(pZio[OFF + q][0], e0, B[0][0], e1, B[1][0]);
+                                    pZio[OFF + q][1] = fma2(pZio[OFF + q][1], e0, B[0][1], e1, B[1][1]);
+                                    pZio[OFF + q][2] = fma2(pZio[OFF + q][2], e0, B[0][2], e1, B[1][2]);
                                 }
                         };
                         if (IOS == 2 && sy.camio[lc][0] >= NQ1) into(std::integral_constant<int, (IOS == 2 ? NQ1 : 0)>{});   // (uniform: the camera is)
