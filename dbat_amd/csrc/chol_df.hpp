@@ -207,25 +207,25 @@ __device__ __forceinline__ double df_swap16(double v) {          // the value of
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 // v with the odd 16-lane rows replaced by the even ones (row 1 <- row 0, row 3 <- row 2): the diagonal rows' column
-// mirrored into the lanes of the other rows.  v_permlane16_swap_b32 (gfx950) swaps the odd rows of its first
-// operand with the even rows of its second: a vector instruction, where ds_swizzle went through the LDS crossbar
-// and its lgkmcnt wait once per column of the dependent chain.
-__device__ __forceinline__ double df_mirror16(double v) {
+// mirrored into the lanes of the other rows.  ds_bpermute_b32 with the source lane (lane & ~16): the exchange runs in
+// the LDS pipe and costs the vector pipe no issue slot -- the elimination is bound by what the vector pipe issues
+// (v_permlane16_swap_b32: two swaps, three moves and their wait states per column; bench/potf2_micro.hip).
+__device__ __forceinline__ double df_mirror16(double v, int src4 /* 4 * (lane & ~16) */) {
     const long long b = __double_as_longlong(v);
-    const unsigned lo = (unsigned)(b & 0xffffffffll), hi = (unsigned)(b >> 32);
-    const auto l2 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-    const auto h2 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-    return __longlong_as_double(((long long)h2[0] << 32) | (unsigned int)l2[0]);
+    const int lo = __builtin_amdgcn_ds_bpermute(src4, (int)(b & 0xffffffffll));
+    const int hi = __builtin_amdgcn_ds_bpermute(src4, (int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 // Column J of the 16-column panel elimination (see df_potf2), and the columns after it.
 template <int J>
 struct DfElimCol {
-    static __device__ __forceinline__ void run(double (&a)[16], double &piv, unsigned &badmask, int lane) {
+    // m: the diagonal rows' column J in BOTH 16-lane rows of every half of the wave (df_mirror16 of a[J]) -- the
+    // multipliers of the other rows (lanes 16-31) are the diagonal rows' (lanes 0-15) entries.  The mirror of the NEXT
+    // column is requested as soon as that column is final (right after its update by this one), so that its trip through
+    // the LDS pipe runs under the remaining updates.
+    static __device__ __forceinline__ void run(double (&a)[16], double &piv, unsigned &badmask, double m, int src4) {
         badmask |= !(piv > 0.0) ? 1u << J : 0u;
         const double araw = a[J];
-        // the diagonal rows' column in BOTH 16-lane rows of the wave's 32 live lanes: the multipliers of the
-        // other rows (lanes 16-31) are the diagonal rows' (lanes 0-15) entries
-        const double m = df_mirror16(araw);
         constexpr int J1 = J + 1 < 16 ? J + 1 : 0;
         // 1/sqrt(d) = y0 (1 + e/2 + 3 e^2/8) and 1/d = y0^2 (1 + e + e^2), e = 1 - d y0^2 (v_rsq_f64 is good to 2^-23: third
         // order).  Every f64 operation costs its 6.5 ticks of issue whether it depends on the one before or not
@@ -238,13 +238,16 @@ struct DfElimCol {
         const double y = __builtin_fma(y0, __builtin_fma(e, 0.375, 0.5) * e, y0);
         const double y2 = __builtin_fma(t, __builtin_fma(e, e, e), t);
         const double nly = -(araw * y2);
+        double mn = 0.0;
         if constexpr (J < 15) {
             df_fmac_bcast<J1, true>(a[J1], m, nly);
+            mn = df_mirror16(a[J1], src4);
             piv = readlane_f64(a[J1], J1);
+            __builtin_amdgcn_sched_barrier(0);       // (... and not after the updates, where the scheduler would put them)
         }
         a[J] = araw * y;
         DfUpdFrom<J + 2, false>::run(a, m, nly);
-        if constexpr (J < 15) DfElimCol<J + 1>::run(a, piv, badmask, lane);
+        if constexpr (J < 15) DfElimCol<J + 1>::run(a, piv, badmask, mn, src4);
     }
 };
 
@@ -331,7 +334,8 @@ __device__ __forceinline__ void df_potf2(double *Tm, int nb, int j0, int *info, 
             double piv = readlane_f64(a[0], 0);
             // (all 64 lanes run it although only the lower 32 hold rows: with the upper half out of EXEC the elimination
             // measured 1.44 instead of 1.03 us per panel -- no pass is skipped, and the branch costs)
-            DfElimCol<0>::run(a, piv, badmask, lane);
+            const int src4 = 4 * (lane & ~16);
+            DfElimCol<0>::run(a, piv, badmask, df_mirror16(a[0], src4), src4);
             if (tr && t == 0 && p == 1) tr[13] = wall_clock64();
             if (lane >= 16 ? act : w == 0) {
 #pragma unroll
