@@ -178,6 +178,13 @@ def main():
         s, _ = synth.make_scene(args.config)
     t_gen = time.perf_counter() - t_gen
     nc, npnt, no = s.EO.val.shape[1], s.OP.val.shape[1], s.IP.val.shape[1]
+    # What a process pays ONCE, whatever the problem: loading the library (and rocSOLVER / rocBLAS / RCCL behind it), the
+    # HIP context, the code object -- timed on a 12-camera scene, so that plan_and_upload below is what dbat_hip_create costs
+    # per problem (host plan, uploads, schedule of the factorisation).
+    t_first = time.perf_counter()
+    _h0 = _hip.Handle(synth.make_scene('tiny')[0], device=local)
+    _h0.close()
+    t_first = time.perf_counter() - t_first
     t_plan = time.perf_counter()
     emu = args.emulate_ranks if world == 1 and args.emulate_ranks > 1 else 0
     h = _hip.Handle(s, device=local, shard_rank=rank, shard_count=emu or world)
@@ -388,7 +395,7 @@ def main():
             'ms_trial_residual': ms[3], 'kernel_ms': k_ms,
             'roofline': roof, 'roofline_factorisation': roof_chol, 'roofline_step': roof_step, 'hbm_kernels': hbm, 'multi_gpu': multi,
             'solve_lm': solve, 'solve_it_s': solve['it_per_s'] if solve else None, 'solve_reference_demo': solve_ref,
-            'host_s': {'scene_generation': t_gen, 'plan_and_upload': t_plan},
+            'host_s': {'scene_generation': t_gen, 'library_load_and_first_use': t_first, 'plan_and_upload': t_plan},
         }
         if world == 1 and not args.no_cpu_baseline and not emu:
             try:
