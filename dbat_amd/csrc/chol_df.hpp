@@ -300,7 +300,28 @@ __device__ __forceinline__ void df_trail(double *Tm, int p, int w, int lane) {
         }
 }
 
-__device__ __forceinline__ void df_potf2(double *Tm, int nb, int j0, int *info, long long *tr) {
+// What the chain role (df_chain_role) has a factorisation do on the side -- work whose latency then hides under the
+// panels instead of standing between two links of the chain:
+//   pub_flag        the tile stores this wave issued before the call are awaited under the first panel's elimination and
+//                   the tile's flag is raised after that panel's barrier (a write-through takes 2.5 us);
+//   look1, look2    flags thread 0 reads while panel 2 / panel 3 are eliminated (-> look_out[2] | look_out[0..1]);
+//   tsrc            if look1 was up under panel 2, every thread requests its 16 operand values of the link product
+//                   (T(p,k), element kk at tsrc + 4 kk tld) before panel 3: ordinary agent-scope loads the compiler
+//                   counts, in flight across the panel (tb_loaded).
+struct DfHook {
+    int *pub_flag = nullptr;
+    int epoch = 0;
+    const int *look1 = nullptr, *look2 = nullptr;
+    int *look_out = nullptr;
+    const double *tsrc = nullptr;
+    int64_t tld = 0;
+    bool tb_loaded = false;
+    double tb[16];
+};
+struct DfNoHook {};
+
+template <bool PUB = false, class HOOK = DfNoHook>
+__device__ __forceinline__ void df_potf2(double *Tm, int nb, int j0, int *info, long long *tr, HOOK *H = nullptr) {
     constexpr int LD = DF_TLD;
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -321,6 +342,18 @@ __device__ __forceinline__ void df_potf2(double *Tm, int nb, int j0, int *info, 
                 if (lane < 32 && s - nlowT >= 16 * p) ident = s - nlowT - 16 * p;
             }
             const bool act = lane < 32;
+            int lk1 = 0, lk2 = 0;
+            if constexpr (PUB) {
+                if (p == 3 && H->tsrc && H->look_out[2] == H->epoch) {
+#pragma unroll
+                    for (int kk = 0; kk < 16; ++kk) H->tb[kk] = ld_coh(H->tsrc + (int64_t)(4 * kk) * H->tld);
+                    H->tb_loaded = true;
+                }
+                if (p >= 2 && t == 0) {
+                    if (H->look1 && !H->tb_loaded) lk1 = __hip_atomic_load(H->look1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (H->look2 && p == 3) lk2 = __hip_atomic_load(H->look2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
             double a[16];
 #pragma unroll
             for (int q = 0; q < 16; ++q) a[q] = (act && ident < 0) ? Tm[(16 * p + q) * LD + row] : (ident == q ? 1.0 : 0.0);
@@ -342,8 +375,16 @@ __device__ __forceinline__ void df_potf2(double *Tm, int nb, int j0, int *info, 
                 for (int q = 0; q < 16; ++q) Tm[(16 * p + q) * LD + row] = a[q];
             }
             if (badmask != 0 && t == 0 && *info == 0) *info = j0 + 16 * p + __builtin_ctz(badmask) + 1;
+            if constexpr (PUB) {
+                if (p == 2 && t == 0) H->look_out[2] = lk1;
+                if (p == 3 && t == 0) { H->look_out[0] = H->tb_loaded ? H->epoch : lk1; H->look_out[1] = lk2; }
+            }
         }
+        if constexpr (PUB) { if (p == 0 && H->pub_flag) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         __syncthreads();
+        if constexpr (PUB) {
+            if (p == 0 && H->pub_flag && t == 0) __hip_atomic_store(H->pub_flag, H->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (tr && t == 0) tr[6 + 2 * p] = wall_clock64();
         if (p == 3) break;
         // ---- B: columns cb > p:  Tm[16cb + cc][rowbase + rr] -= sum_m P(rowbase + rr, m) P(16cb + cc, m)
@@ -477,6 +518,238 @@ __device__ __forceinline__ bool df_backward(double *smem, const DfView &V, int n
     return true;
 }
 
+// ---- The dependent chain in its own role.
+// Consecutive diagonal tiles of a separator are a chain: column k+1 cannot start before the link L(k+1,k) exists.
+// Run as ordinary tasks a link costs 19 us (round 4: store -> write-through -> flag -> poll -> load on two parallel
+// paths), of which df_potf2 is 8.7.  Here the first workgroups that arrive take the CHAIN ROLE: they factor diagonal
+// tiles only, and one that has factored column k keeps L(k+1,k) in LDS and goes on with column k+1 --
+//     T(k+1,k+1) = T'(k+1,k+1) - L(k+1,k) L(k+1,k)'
+// with T' = the tile minus all EARLIER products, summed in advance by a worker task (DfJob mode 16; it lands in the
+// otherwise unused diagonal tile of the compact storage).  Nothing the chain stores is awaited where the chain would
+// notice: L^-1(k) goes out right after the factorisation and is acknowledged under the link product, L(k+1,k) is
+// acknowledged under the first panel of the next factorisation (df_potf2<true>), and the loads of T(k+1,k) and
+// T'(k+1,k+1) are issued BEFORE those stores (the memory counter of a wave retires in order).
+// No deadlock: columns are taken by ticket in task order.  A workgroup CONTINUES with column k+1 only if that column's
+// T' is there already (two bounded looks): everything else the column needs then depends on finished columns and on
+// worker tasks only.  A ticket for a column that continues a chain is passed over while the column before it may still
+// go on (giveup[k-1] != epoch); a workgroup that gives up raises giveup[k] and, if the ticket of k+1 has been passed
+// over by then (counter > pos[k+1]), takes k+1 itself as if by that ticket (claim[] arbitrates).  Whoever takes a
+// column without its link in LDS fetches the link from memory.  A chain workgroup that finds no column left becomes a
+// worker.
+struct DfChain {
+    const int *cols;     // the tile columns in ticket (= task) order
+    const int *par;      // [nT] tile row of the first tile below the diagonal of column k (the link); -1: none
+    const int *bits;     // [nT] 1: T'(k,k) leaves out the product with column k-1 (k continues a chain)  2: k+1 continues k
+    int *claim;          // [nT] == epoch: taken in this solve
+    int *dflags;         // [nT] == epoch: T'(k,k) is in the diagonal tile
+    int *giveup;         // [nT] == epoch: the workgroup that factored column k does not go on with k+1 (whoever holds k+1's ticket takes it)
+    const int *pos;      // [nT] position of column k in cols
+    int ncols, nwg, ctr_slot, role_slot;
+    int trace_potf2;     // measurement build: clocks inside df_potf2 as well (they cost about a microsecond per factorisation)
+};
+
+// T'(k,k) in the accumulator layout of mfma_tile64: element (c = 16 ty + (tx >> 4) + 4 e, r = 16 rt + (tx & 15)).
+// (Ordinary agent-scope loads throughout the chain role: the compiler counts them, so they may stay in flight across
+// whatever follows.  Registers written by inline-asm loads are only safe while the compiler neither merges nor moves
+// them before the wait -- it did, once, and a link was multiplied with whatever the registers held.)
+__device__ __forceinline__ void df_issue_acc_tile(const double *T, int64_t ld, double (&tp)[16], int tx, int ty) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tp[4 * rt + e] = ld_coh(T + (int64_t)(16 * ty + (tx >> 4) + 4 * e) * ld + 16 * rt + (tx & 15));
+}
+
+// returns false on abort (the kernel returns), true when no column is left
+__device__ __forceinline__ bool df_chain_role(double *smem, const DfView &V, int nT, const DfChain &C, int *flags, int *tflags,
+                                              int *ctl, int epoch, double *linv_all, int *info, double *ldiag,
+                                              int *s_word, long long *trace) {
+    constexpr int NB = 64, XLD = DF_LD;
+    double *Tm = smem, *Xm = smem + NB * DF_TLD;        // the augmented block of df_potf2 | L(k,k-1) as the operand [m][r] of the next update
+    const int t = threadIdx.x, tx = t & 63, ty = t >> 6;
+    int *abort_flag = ctl + 1, *counter = ctl + C.ctr_slot;
+    int *s_task = s_word, *s_ok = s_word + 1, *look = s_word + 2;      // look[3]: flags seen under the factorisation's last panels
+    int k = -1;
+    int *pub = nullptr;                                 // flag of the link tile stored last, raised once its stores are out
+    double tp[16];
+    // per-column clocks (measurement build): 0 taken / continued, 1 T' and the link are there, 2 block assembled, 3 factored,
+    // 4 flags seen, 5 operands requested, 6 link done, 7 end; 8: 1 = by ticket, 0 = continued; 9: 1 = T' of the next column
+    // was there at the first look, 2 = at the second, 0 = not / no next column; 10: 1 = T(p,k) requested under the last panel
+#define DF_CLK(slot) do { if (trace && t == 0) trace[(int64_t)k * 16 + (slot)] = wall_clock64(); } while (0)
+#define DF_VAL(slot, v) do { if (trace && t == 0) trace[(int64_t)k * 16 + (slot)] = (v); } while (0)
+    bool fresh = true;                                  // column k was taken without its link in LDS
+    for (;;) {
+        if (k < 0) {
+            for (;;) {                                  // the next column nobody has taken
+                if (t == 0) {
+                    const int tk = atomicAdd(counter, 1);
+                    int kk = tk < C.ncols ? C.cols[tk] : -1;
+                    if (kk >= 0 && (C.bits[kk] & 1) && atomicAdd(C.giveup + kk - 1, 0) != epoch) kk = -2;     // its chain may still go on
+                    if (kk >= 0 && atomicExch(C.claim + kk, epoch) == epoch) kk = -2;
+                    *s_task = kk;
+                }
+                __syncthreads();
+                k = *s_task;
+                __syncthreads();
+                if (k != -2) break;
+            }
+            if (k < 0) return true;
+            fresh = true;
+        }
+        if (fresh) {
+            fresh = false;
+            DF_CLK(0); DF_VAL(8, 1);
+            const bool cont = (C.bits[k] & 1) != 0;
+            if (t == 0) {
+                bool ok = df_spin(C.dflags + k, epoch, abort_flag);
+                if (ok && cont) ok = df_spin(flags + (int64_t)k * nT + (k - 1), epoch, abort_flag);
+                *s_ok = ok;
+            }
+            __syncthreads();
+            if (!*s_ok) { if (t == 0) *info = -1; return false; }
+            df_issue_acc_tile(V.base + V.toff[(int64_t)k * nT + k], V.ld, tp, tx, ty);
+            if (cont) df_load_tile16<XLD>(V.base + V.toff[(int64_t)k * nT + (k - 1)], V.ld, Xm, tx, ty, false);
+            __syncthreads();
+        }
+        DF_CLK(1);
+        // ---- column k: T = T' - L(k,k-1) L(k,k-1)' -> the augmented block
+        {
+            chol_d4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+            if (C.bits[k] & 1) mfma_tile64<XLD>(Xm, Xm, ty, tx, acc);
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = 16 * ty + (tx >> 4) + 4 * e, r = 16 * rt + (tx & 15);
+                    Tm[c * DF_TLD + r] = r >= c ? tp[4 * rt + e] - acc[rt][e] : 0.0;
+                }
+        }
+        DF_CLK(2);
+        const int p = C.par[k];                         // (>= 0: the right-hand-side row lies below every column)
+        const bool nxt = (C.bits[k] & 2) != 0;
+        double *Tpk = V.base + V.toff[(int64_t)p * nT + k];
+        DfHook H;
+        H.pub_flag = pub; H.epoch = epoch;
+        H.look1 = tflags + k; H.look2 = nxt ? C.dflags + k + 1 : nullptr; H.look_out = look;
+        // the operand of the link product straight into registers: thread (tx, ty) multiplies T(r = 16 ty + (tx & 15), m = 4 kk + (tx >> 4))
+        H.tsrc = Tpk + (int64_t)(tx >> 4) * V.ld + 16 * ty + (tx & 15); H.tld = V.ld;
+        df_potf2<true>(Tm, NB, NB * k, info, trace && C.trace_potf2 ? trace + (int64_t)(nT + k) * 16 : nullptr, &H);
+        DF_CLK(3);
+        pub = nullptr;
+        const double piv = ty == 0 ? Tm[tx * DF_TLD + tx] : 0.0;
+        // what the looks under the last panels saw is in LDS for everybody: no barrier on the usual path
+        bool have_t = H.tb_loaded || look[0] == epoch;
+        bool pre = nxt && look[1] == epoch;
+        if (!have_t || (nxt && !pre)) {                 // ... otherwise thread 0 looks again (T(p,k): until it is there)
+            if (t == 0) {
+                const bool ok = have_t || df_spin(tflags + k, epoch, abort_flag);
+                int pr = pre ? 1 : 0;
+                if (ok && nxt && !pre && __hip_atomic_load(C.dflags + k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) pr = 1;
+                *s_ok = ok ? 1 + pr : 0;
+            }
+            __syncthreads();
+            const int st = *s_ok;
+            if (!st) { if (t == 0) *info = -1; return false; }
+            pre = st == 2;
+        }
+        // (nobody else can take column k+1 before giveup[k] is raised: a plain store marks it)
+        if (pre && t == 0) __hip_atomic_store(C.claim + k + 1, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        DF_CLK(4); DF_VAL(9, pre ? 1 : 0); DF_VAL(10, H.tb_loaded ? 1 : 0);
+        if (!H.tb_loaded) {
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) H.tb[kk] = ld_coh(H.tsrc + (int64_t)(4 * kk) * V.ld);
+        }
+        // L^-1 -> Linv[c*64 + i] = Linv(i, c) = Tm[i][64 + c], behind the operand loads (a wave's memory counter retires in order)
+        double *Linv = linv_all + (size_t)k * NB * NB;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int c = ty + 4 * q;
+            st_coh(Linv + c * NB + tx, (c >> 4) <= (tx >> 4) ? Tm[tx * DF_TLD + 64 + c] : 0.0);
+        }
+        // T' of the next column BEHIND the stores: it is wanted after the link product, when the stores are out anyway
+        if (pre) df_issue_acc_tile(V.base + V.toff[(int64_t)(k + 1) * nT + k + 1], V.ld, tp, tx, ty);
+        DF_CLK(5);
+        // the link: X(r, c) = sum_{m <= c} T(r, m) Linv(c, m)  (see the diagonal task of k_chol_df)
+        const int nrp = p == nT ? 1 : NB;
+        {
+            chol_d4 x[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+            const double *pl = Tm + (tx & 15) * DF_TLD + 64 + (tx >> 4);
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const double b = H.tb[kk];
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+                    if (kk < 4 * (cb + 1)) {
+                        const double a = pl[16 * cb * DF_TLD + 4 * kk];
+                        x[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, x[cb], 0, 0, 0);
+                    }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // L^-1 is out (issued before the product)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = 16 * cb + (tx >> 4) + 4 * e, r = 16 * ty + (tx & 15);
+                    if (r < nrp) st_coh(Tpk + (int64_t)c * V.ld + r, x[cb][e]);
+                    Xm[c * XLD + r] = x[cb][e];
+                }
+        }
+        if (ldiag && ty == 0) { const int zn = V.iperm[NB * k + tx]; if (zn >= 0) ldiag[zn] = piv; }
+        if (t == 0 && nxt && !pre) {                    // a second, bounded look (the loads then queue behind the stores)
+            int got = 0;
+            for (int s = 0; s < 6 && !got; ++s) {
+                if (__hip_atomic_load(C.dflags + k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch)
+                    got = atomicExch(C.claim + k + 1, epoch) != epoch ? 1 : -1;
+                else __builtin_amdgcn_s_sleep(8);
+            }
+            *s_task = got > 0;
+        }
+        __syncthreads();
+        if (t == 0) __hip_atomic_store(flags + (int64_t)k * nT + k, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        DF_CLK(6);
+        if (nxt && !pre && *s_task) {
+            DF_VAL(9, 2);
+            df_issue_acc_tile(V.base + V.toff[(int64_t)(k + 1) * nT + k + 1], V.ld, tp, tx, ty);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                            // every wave's stores of L(k+1,k) are out
+            if (t == 0) __hip_atomic_store(flags + (int64_t)p * nT + k, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            DF_CLK(7);
+            k = k + 1;
+            DF_CLK(0); DF_VAL(8, 0);
+            continue;
+        }
+        if (pre) {                                      // on with column k+1; L(k+1,k)'s flag follows inside its factorisation
+            pub = flags + (int64_t)p * nT + k;
+            DF_CLK(7);
+            k = k + 1;
+            DF_CLK(0); DF_VAL(8, 0);
+            continue;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) {
+            __hip_atomic_store(flags + (int64_t)p * nT + k, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int take = 0;
+            if (nxt) {                                  // the next column: to whoever holds its ticket -- or, if that ticket was passed over, to this workgroup
+                atomicExch(C.giveup + k, epoch);
+                if (atomicAdd(counter, 0) > C.pos[k + 1] && atomicExch(C.claim + k + 1, epoch) != epoch) take = 1;
+            }
+            *s_task = take;
+        }
+        DF_CLK(7);
+        __syncthreads();
+        const int take = *s_task;
+        __syncthreads();
+        if (take) { k = k + 1; fresh = true; }
+        else k = -1;
+    }
+#undef DF_CLK
+#undef DF_VAL
+}
+
+// CHAIN (compact tiles): the diagonal tiles are factored by the workgroups of the chain role (df_chain_role); the task
+// list holds no diagonal task, the sums of the diagonal tiles are DfJob mode 16.  !CHAIN: everything is a task (the
+// in-place layout, DBAT_HIP_DF_CHAIN=0).
+template <bool CHAIN>
 __global__ __launch_bounds__(256) void k_chol_df(DfView V, int n, int nT, const DfJob *__restrict__ tasks,
                                                  int ntasks, int *__restrict__ flags, int *__restrict__ ctl, int epoch,
                                                  double *__restrict__ linv_all, int *__restrict__ info,
@@ -485,14 +758,25 @@ __global__ __launch_bounds__(256) void k_chol_df(DfView V, int n, int nT, const 
                                                  double *__restrict__ q_nat, double *__restrict__ ldiag,
                                                  const double *__restrict__ qscale, double *__restrict__ dz_out,
                                                  double *__restrict__ parts, int nparts,
-                                                 const int *__restrict__ bk_list, int nbk, int ctr_slot) {
+                                                 const int *__restrict__ bk_list, int nbk, int ctr_slot, DfChain C) {
     constexpr int NB = 64, LD = DF_LD;
-    __shared__ double smem[2 * NB * LD];                // Pm | Qm, or the augmented block of df_potf2
+    __shared__ double smem[(CHAIN ? 3 : 2) * NB * LD];  // Pm | Qm, or the augmented block of df_potf2 (chain role: and the link)
     double *Pm = smem, *Qm = smem + NB * LD;
-    __shared__ int s_task, s_ok;
+    __shared__ int s_word[8];                           // task / ok, and three words of the chain role
+    int &s_task = s_word[0], &s_ok = s_word[1];
     const int t = threadIdx.x, tx = t & 63, ty = t >> 6;
     int *counter = ctl + ctr_slot, *abort_flag = ctl + 1;     // (slot 0, or 2 for the second launch of a solve)
     const bool l2 = V.iperm != nullptr && !V.no_l2;     // compact tiles: finished tiles through the L2 (see ld_l2_16)
+    if constexpr (CHAIN) {                              // the first workgroups to arrive factor the diagonal tiles
+        if (t == 0) s_task = atomicAdd(ctl + C.role_slot, 1);
+        __syncthreads();
+        const int arrival = s_task;
+        __syncthreads();
+        if (arrival < C.nwg &&
+            !df_chain_role(smem, V, nT, C, flags, flags + (int64_t)(nT + 1) * nT + nparts, ctl, epoch, linv_all, info, ldiag, s_word,
+                           trace ? trace + (int64_t)(ntasks + nT) * 16 : nullptr))
+            return;
+    }
     for (;;) {
         if (t == 0) s_task = atomicAdd(counter, 1);
         __syncthreads();
@@ -674,7 +958,8 @@ __global__ __launch_bounds__(256) void k_chol_df(DfView V, int n, int nT, const 
             __syncthreads();
             continue;
         }
-        if (jb.mode == 1) {                             // sum only: T -> the tile; the diagonal task of the column finishes it
+        if (jb.mode == 1 || jb.mode == 16) {            // sum only: T -> the tile; the diagonal task of the column finishes it
+                                                        // (16: T' of the diagonal tile itself, for the chain role)
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
@@ -685,12 +970,12 @@ __global__ __launch_bounds__(256) void k_chol_df(DfView V, int n, int nT, const 
             if (trace && t == 0) trace[task * 16 + 3] = wall_clock64();
             __builtin_amdgcn_s_waitcnt(0);
             __syncthreads();
-            if (t == 0) __hip_atomic_store(tflags + k, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == 0) __hip_atomic_store(jb.mode == 1 ? tflags + k : C.dflags + k, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (trace && t == 0) trace[task * 16 + 4] = wall_clock64();
             continue;
         }
         double *Linv = linv_all + (size_t)k * NB * NB;
-        if (i == k) {
+        if (!CHAIN && i == k) {
             // T(r, c) = -acc -> augmented block, ragged part = identity, upper triangle = 0
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt)
@@ -801,7 +1086,7 @@ __global__ __launch_bounds__(256) void k_chol_df(DfView V, int n, int nT, const 
 // task counter / abort flag, "not solved yet" in q.
 __global__ void k_df_reset(int *__restrict__ info, int *__restrict__ ctl, unsigned long long *__restrict__ qflag, int nq) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) { *info = 0; ctl[0] = 0; ctl[1] = 0; ctl[2] = 0; }
+    if (i == 0) { *info = 0; for (int q = 0; q < 8; ++q) ctl[q] = 0; }
     if (i < nq) qflag[i] = DF_SENTINEL;
 }
 
@@ -830,6 +1115,10 @@ struct DataflowChol {
     DfTask *d_tile_ij = nullptr;
     int nparts = 0;                                     // partial-sum slots of the helper tasks
     bool env_l2 = false;                                // finished tiles through the L2: measured in round 2, no gain (kept off)
+    // the chain role (df_chain_role): the diagonal tiles of the compact layout, per task list (A: all / this rank's domain, B: top)
+    bool use_chain = false;
+    int nchain = 0, nchainB = 0, chain_wg = 0, chain_wgB = 0;
+    int *d_chain_cols = nullptr, *d_chain_colsB = nullptr, *d_chain_par = nullptr, *d_chain_bits = nullptr, *d_chain_bitsB = nullptr, *d_chain_pos = nullptr;
     double *d_parts = nullptr;
     double *d_tiles = nullptr, *d_qperm = nullptr;
     long long *d_trace = nullptr;                       // optional per-task timestamps (DBAT_HIP_DF_TRACE=file)
@@ -841,16 +1130,17 @@ struct DataflowChol {
 
     void release() {
         void *ps[] = {d_flags, d_ctl, d_bk_ptr, d_bk_idx, d_iperm, d_toff, d_rowbits, d_tasks, d_tile_ij, d_tiles, d_qperm, d_parts,
-                      d_tasksB, d_bk_list, d_rowbits_top};
+                      d_tasksB, d_bk_list, d_rowbits_top, d_chain_cols, d_chain_colsB, d_chain_par, d_chain_bits, d_chain_bitsB, d_chain_pos};
         for (void *p : ps) if (p) (void)hipFree(p);
         d_flags = d_ctl = d_bk_ptr = d_bk_idx = d_iperm = nullptr; d_toff = nullptr; d_rowbits = nullptr;
         d_tasks = nullptr; d_tile_ij = nullptr; d_tiles = d_qperm = d_parts = nullptr;
         d_tasksB = nullptr; d_bk_list = nullptr; d_rowbits_top = nullptr;
+        d_chain_cols = d_chain_colsB = d_chain_par = d_chain_bits = d_chain_bitsB = d_chain_pos = nullptr;
     }
     // per-task timestamps of the last solve (100 MHz ticks): task, i, k, t[0..15], jlo, jhi, mode per line
     void dump_trace(hipStream_t stream, const char *path) const {
         if (!d_trace) return;
-        std::vector<long long> h((size_t)(ntasks + nT) * 16);
+        std::vector<long long> h((size_t)(ntasks + 3 * nT) * 16);
         (void)hipStreamSynchronize(stream);
         (void)hipMemcpy(h.data(), d_trace, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
         FILE *f = fopen(path, "w");
@@ -862,6 +1152,16 @@ struct DataflowChol {
             for (int q = 0; q < 16; ++q) fprintf(f, ",%lld", h[(size_t)t * 16 + q]);
             fprintf(f, ",%d,%d,%d\n", t < ntasks ? h_tasks[t].jlo : 0, t < ntasks ? (h_tasks[t].np < 0 ? h_tasks[t].jhi : h_tasks[t].k) : 0,
                     t < ntasks ? h_tasks[t].mode : 0);   // its products: j in [jlo, jhi); mode (DfJob)
+        }
+        for (int k = 0; k < nT && use_chain; ++k) {      // the chain role's columns (df_chain_role): i = -3
+            fprintf(f, "%d,-3,%d", ntasks + nT + k, k);
+            for (int q = 0; q < 16; ++q) fprintf(f, ",%lld", h[(size_t)(ntasks + nT + k) * 16 + q]);
+            fprintf(f, ",0,0,0\n");
+        }
+        for (int k = 0; k < nT && use_chain; ++k) {      // ... and the clocks inside their factorisation (df_potf2): i = -4
+            fprintf(f, "%d,-4,%d", ntasks + 2 * nT + k, k);
+            for (int q = 0; q < 16; ++q) fprintf(f, ",%lld", h[(size_t)(ntasks + 2 * nT + k) * 16 + q]);
+            fprintf(f, ",0,0,0\n");
         }
         fclose(f);
     }
@@ -876,7 +1176,7 @@ struct DataflowChol {
     // One task list (see DfJob).  PHASE 0: the whole factorisation (one rank).  Several ranks (col_owner: the
     // rank whose domain a tile column belongs to, -1 = top separator / IO): PHASE 1 = the columns of this rank's
     // domain and its share of every top tile (mode 4); PHASE 2 = the top columns, products over top columns only.
-    struct JobList { std::vector<DfJob> jobs; std::vector<int> dptr, dep, own, sumjob; };
+    struct JobList { std::vector<DfJob> jobs; std::vector<int> dptr, dep, own, sumjob, presum, bits, par; };
     void build_jobs(int phase, const std::vector<uint64_t> &rowbits, const std::vector<int> &col_owner, int rank, JobList &L) {
         auto has = [&](int i, int k) { return (rowbits[(size_t)i * W + (k >> 6)] >> (k & 63)) & 1ull; };
         const int split_min = std::max(env_int("DBAT_HIP_DF_SPLIT", 96), 2);
@@ -889,6 +1189,9 @@ struct DataflowChol {
         if (dom_hi <= dom_lo) dom_lo = dom_hi = 0;
         L.jobs.clear(); L.dptr.assign(1, 0); L.dep.clear();
         L.own.assign((size_t)(nT + 1) * nT, -1); L.sumjob.assign(nT, -1);
+        L.presum.assign(nT, -1); L.bits.assign(nT, 0); L.par.assign(nT, -1);
+        const bool chain = use_chain && merge;
+        auto inphase = [&](int c) { return c < nT && (phase == 0 || (phase == 1 ? col_owner[c] == rank : col_owner[c] < 0)); };
         std::vector<int> js;
         for (int k = 0; k < nT; ++k) {
             // emit the job(s) of tile (i,k) with the products js; returns the owner job
@@ -929,6 +1232,16 @@ struct DataflowChol {
             // the sum-only task first: the diagonal task depends on it (job numbers stay topological)
             if (par >= 0) { products(par); L.sumjob[k] = emit(par, 1, -1, k); }
             products(k);
+            L.par[k] = par;
+            if (chain) {
+                // the chain role factors the tile: its sum is a task of its own (mode 16) -- without the product with
+                // column k-1 where this column continues the chain of k-1 (the link then stays in the workgroup's LDS)
+                const bool cont = k > 0 && (L.bits[k - 1] & 2) != 0;
+                if (cont) js.pop_back();                        // (has(k, k-1): the link itself)
+                L.presum[k] = emit(k, 16, -1, cont ? k - 1 : k);
+                js.clear();
+                L.bits[k] = (cont ? 1 : 0) | ((par == k + 1 && k + 1 < nT && inphase(k + 1)) ? 2 : 0);
+            }
             L.own[(size_t)k * nT + k] = emit(k, par >= 0 ? 2 : 0, par, k);
             if (par >= 0) L.own[(size_t)par * nT + k] = L.own[(size_t)k * nT + k];      // L(par,k) is published by the diagonal task
             for (int i = k + 1; i <= nT; ++i)
@@ -949,7 +1262,7 @@ struct DataflowChol {
         if (nt == 0) return;
         auto is_helper = [&](int t) { return jobs[t].np < 0; };
         auto is_share = [&](int t) { return (jobs[t].mode & 4) != 0; };
-        auto is_diag = [&](int t) { return jobs[t].np >= 0 && jobs[t].i == jobs[t].k && !is_share(t); };
+        auto is_diag = [&](int t) { return jobs[t].np >= 0 && jobs[t].i == jobs[t].k && !is_share(t) && jobs[t].mode != 16; };
         auto nprod_of = [&](int t) { return (dptr[t + 1] - dptr[t]) / 2; };
         // every dependency of job t: product tiles, its helpers (the np jobs right before it), the diagonal tile
         auto for_deps = [&](int t, const std::function<void(int)> &f) {
@@ -958,10 +1271,14 @@ struct DataflowChol {
                 for (int h = 1; h <= jobs[t].np; ++h) f(t - h);
                 if (jobs[t].mode == 0 && jobs[t].i != jobs[t].k) f(own[(size_t)jobs[t].k * nT + jobs[t].k]);
                 if (jobs[t].mode == 2) f(sumjob[jobs[t].k]);
+                if (is_diag(t) && L.presum[jobs[t].k] >= 0) {   // chain role: the tile's sum, and the column it continues
+                    f(L.presum[jobs[t].k]);
+                    if (L.bits[jobs[t].k] & 1) f(own[(size_t)(jobs[t].k - 1) * nT + jobs[t].k - 1]);
+                }
             }
         };
         const double c_prod = 2.5, c_diag = 13.5, c_off = 4.5, c_hop = 2.0, c_add = 1.5, c_help = 2.0;
-        auto tail_of = [&](int t) { return is_helper(t) || is_share(t) || jobs[t].mode == 1 ? c_help : (is_diag(t) ? c_diag + (jobs[t].mode == 2 ? 2.5 : 0.0) : c_off); };
+        auto tail_of = [&](int t) { return is_helper(t) || is_share(t) || jobs[t].mode == 1 || jobs[t].mode == 16 ? c_help : (is_diag(t) ? c_diag + (jobs[t].mode == 2 ? 2.5 : 0.0) : c_off); };
         // (1) earliest start: every input the moment it exists, unlimited workgroups
         std::vector<double> est(nt, 0.0), fin(nt, 0.0);
         for (int t = 0; t < nt; ++t) {
@@ -995,6 +1312,10 @@ struct DataflowChol {
                     for (int h = jobs[t].np; h >= 1; --h) tc = std::max(tc, done[t - h] + c_hop) + c_add;
                     if (jobs[t].mode == 0 && jobs[t].i != jobs[t].k) tc = std::max(tc, done[own[(size_t)jobs[t].k * nT + jobs[t].k]] + c_hop);
                     if (jobs[t].mode == 2) tc = std::max(tc, done[sumjob[jobs[t].k]] + c_hop - c_diag);    // T is only wanted after the factorisation
+                    if (is_diag(t) && L.presum[jobs[t].k] >= 0) {
+                        tc = std::max(tc, done[L.presum[jobs[t].k]] + c_hop);
+                        if (L.bits[jobs[t].k] & 1) tc = std::max(tc, done[own[(size_t)(jobs[t].k - 1) * nT + jobs[t].k - 1]]);
+                    }
                 }
                 tc += tail_of(t);
                 done[t] = tc; last = std::max(last, tc);
@@ -1064,6 +1385,21 @@ struct DataflowChol {
         if (const char *g = env_get("DBAT_HIP_DF_GRID")) grid = std::min(std::max(atoi(g), 1), 4096);
         nparts = 0; n_products = 0;
         two_phase = !col_owner.empty();
+        use_chain = permuted && env_int("DBAT_HIP_DF_CHAIN", 1) != 0;
+        // the diagonal tasks leave the ordered list for the chain role: their order is the order of the tickets
+        auto split_chain = [&](JobList &L, std::vector<DfJob> &tasks, std::vector<int> &cols) {
+            tasks.clear(); cols.clear();
+            for (const DfJob &j : L.jobs) {
+                if (use_chain && j.np >= 0 && j.i == j.k && (j.mode == 0 || j.mode == 2)) cols.push_back(j.k);
+                else tasks.push_back(j);
+            }
+        };
+        auto chain_width = [&](const std::vector<int> &cols, const std::vector<int> &bits) {
+            int runs = 0;
+            for (int k : cols) runs += !(bits[k] & 1);
+            return std::max(1, std::min(runs, env_int("DBAT_HIP_DF_CHAIN_WG", 32)));
+        };
+        std::vector<int> colsA, colsB;
         sim_critical_us.clear(); sim_schedule_us.clear();
         JobList L;
         std::vector<int> bkl;                                   // panels of the backward substitution, in task order
@@ -1071,17 +1407,22 @@ struct DataflowChol {
         if (!two_phase) {
             build_jobs(0, rowbits, col_owner, rank, L);
             order_jobs(L, "all");
-            h_tasks = L.jobs; ntasks = (int)L.jobs.size();
+            split_chain(L, h_tasks, colsA); ntasks = (int)h_tasks.size();
             for (int j = nT - 1; j >= 0; --j) bkl.push_back(j);
         } else {
             build_jobs(1, rowbits, col_owner, rank, L);
             order_jobs(L, "domain");
-            h_tasks = L.jobs; ntasks = (int)L.jobs.size();
+            split_chain(L, h_tasks, colsA); ntasks = (int)h_tasks.size();
             JobList B;
             build_jobs(2, rowbits, col_owner, rank, B);
             order_jobs(B, "top");
-            h_tasksB = B.jobs; ntasksB = (int)B.jobs.size();
+            split_chain(B, h_tasksB, colsB); ntasksB = (int)h_tasksB.size();
             if (!up(d_tasksB, h_tasksB)) return false;
+            if (use_chain) {
+                for (int k = 0; k < nT; ++k) if (B.par[k] >= 0) L.par[k] = B.par[k];      // (one table: a column is in one of the two lists)
+                nchainB = (int)colsB.size(); chain_wgB = chain_width(colsB, B.bits);
+                if (!up(d_chain_colsB, colsB) || !up(d_chain_bitsB, B.bits)) return false;
+            }
             // the top columns first (every rank), then this rank's domain: a dependency always has a smaller number
             for (int j = nT - 1; j >= 0; --j) if (col_owner[j] < 0) bkl.push_back(j);
             for (int j = nT - 1; j >= 0; --j) if (col_owner[j] == rank) bkl.push_back(j);
@@ -1092,7 +1433,21 @@ struct DataflowChol {
             if (!up(d_rowbits_top, rowbits_top)) return false;
         }
         nbk = (int)bkl.size();
-        if (env_on("DBAT_HIP_DF_TRACE") && !two_phase && hipMalloc(&d_trace, (size_t)(ntasks + nT) * 16 * sizeof(long long)) != hipSuccess) d_trace = nullptr;
+        if (use_chain) {
+            nchain = (int)colsA.size(); chain_wg = chain_width(colsA, L.bits);
+            std::vector<int> pos(nT, 0);                          // (one table: a column is in one of the two lists)
+            for (size_t q = 0; q < colsA.size(); ++q) pos[colsA[q]] = (int)q;
+            for (size_t q = 0; q < colsB.size(); ++q) pos[colsB[q]] = (int)q;
+            if (!up(d_chain_cols, colsA) || !up(d_chain_bits, L.bits) || !up(d_chain_par, L.par) || !up(d_chain_pos, pos)) return false;
+            if (env_on("DBAT_HIP_PLAN_STATS")) {
+                int runs = 0, longest = 0, cur = 0;
+                for (int k = 0; k < nT; ++k) { if (L.bits[k] & 1) ++cur; else { cur = 1; } longest = std::max(longest, cur); }
+                for (int k : colsA) runs += !(L.bits[k] & 1);
+                fprintf(stderr, "[chol] chain role: %d diagonal tiles in %d chains (longest %d), %d workgroups%s\n", nchain, runs, longest, chain_wg,
+                        two_phase ? " (domain)" : "");
+            }
+        }
+        if (env_on("DBAT_HIP_DF_TRACE") && !two_phase && hipMalloc(&d_trace, (size_t)(ntasks + 3 * nT) * 16 * sizeof(long long)) != hipSuccess) d_trace = nullptr;
         std::vector<int> bptr(nT + 1, 0), bidx;
         for (int j = 0; j < nT; ++j) {
             for (int i = nT - 1; i > j; --i)
@@ -1101,12 +1456,12 @@ struct DataflowChol {
         }
         if (!up(d_tasks, h_tasks) || !up(d_bk_ptr, bptr) || !up(d_bk_idx, bidx) || !up(d_rowbits, rowbits) || !up(d_toff, toff) || !up(d_bk_list, bkl))
             return false;
-        if (hipMalloc(&d_flags, ((size_t)(nT + 1) * nT + (size_t)nparts + (size_t)nT) * sizeof(int)) != hipSuccess) return false;   // tiles, helper slots, T of the sum-only tasks
+        if (hipMalloc(&d_flags, ((size_t)(nT + 1) * nT + (size_t)nparts + 4 * (size_t)nT) * sizeof(int)) != hipSuccess) return false;   // tiles, helper slots, T of the sum-only tasks, T' of the diagonal tiles, claims
         if (nparts > 0 && hipMalloc(&d_parts, (size_t)nparts * 4096 * sizeof(double)) != hipSuccess) return false;
-        if (hipMalloc(&d_ctl, 4 * sizeof(int)) != hipSuccess) return false;
-        (void)hipMemset(d_flags, 0, ((size_t)(nT + 1) * nT + (size_t)nparts + (size_t)nT) * sizeof(int));
-        (void)hipMemset(d_ctl, 0, 4 * sizeof(int));
-        env_l2 = false;
+        if (hipMalloc(&d_ctl, 8 * sizeof(int)) != hipSuccess) return false;
+        (void)hipMemset(d_flags, 0, ((size_t)(nT + 1) * nT + (size_t)nparts + 4 * (size_t)nT) * sizeof(int));
+        (void)hipMemset(d_ctl, 0, 8 * sizeof(int));
+        env_l2 = env_int("DBAT_HIP_DF_L2", 0) != 0;
         epoch = 0;
         return true;
     }
@@ -1257,7 +1612,7 @@ struct DataflowChol {
     // order), -1 dataflow abort (spin cap).
     void solve(hipStream_t stream, double *A, int64_t lda, double *q_out, double *linv_work, int *info_dev,
                double *ldiag = nullptr, const double *qscale = nullptr, double *dz_out = nullptr) {
-        if (d_trace) (void)hipMemsetAsync(d_trace, 0, (size_t)(ntasks + nT) * 16 * sizeof(long long), stream);
+        if (d_trace) (void)hipMemsetAsync(d_trace, 0, (size_t)(ntasks + 3 * nT) * 16 * sizeof(long long), stream);
         ++epoch;
         DfView V;
         V.toff = d_toff; V.rowbits = d_rowbits; V.W = W; V.no_l2 = env_l2 ? 0 : 1;     // measured: no gain from the L2 path
@@ -1271,14 +1626,33 @@ struct DataflowChol {
             V.base = d_tiles; V.ld = 64; V.iperm = d_iperm; qflag = d_qperm; V.S = A;
         } else {
             (void)hipMemsetAsync(info_dev, 0, sizeof(int), stream);
-            (void)hipMemsetAsync(d_ctl, 0, 4 * sizeof(int), stream);
+            (void)hipMemsetAsync(d_ctl, 0, 8 * sizeof(int), stream);
             V.base = A; V.ld = lda; V.iperm = nullptr; qflag = q_out;
             (void)hipMemsetAsync(q_out, 0xFF, (size_t)n * sizeof(double), stream);
         }
-        hipLaunchKernelGGL(k_chol_df, dim3(std::min(grid, ntasks + nT)), dim3(256), 0, stream, V, n, nT, d_tasks, ntasks,
-                           d_flags, d_ctl, epoch, linv_work, info_dev, d_trace, d_bk_ptr, d_bk_idx, qflag, q_out, ldiag,
-                           qscale, dz_out, d_parts, nparts, d_bk_list, nbk, 0);
+        if (permuted && use_chain)
+            hipLaunchKernelGGL(k_chol_df<true>, dim3(chain_grid(ntasks + nT, chain_wg)), dim3(256), 0, stream, V, n, nT, d_tasks, ntasks,
+                               d_flags, d_ctl, epoch, linv_work, info_dev, d_trace, d_bk_ptr, d_bk_idx, qflag, q_out, ldiag,
+                               qscale, dz_out, d_parts, nparts, d_bk_list, nbk, 0, chain_arg(0));
+        else
+            hipLaunchKernelGGL(k_chol_df<false>, dim3(std::min(grid, ntasks + nT)), dim3(256), 0, stream, V, n, nT, d_tasks, ntasks,
+                               d_flags, d_ctl, epoch, linv_work, info_dev, d_trace, d_bk_ptr, d_bk_idx, qflag, q_out, ldiag,
+                               qscale, dz_out, d_parts, nparts, d_bk_list, nbk, 0, DfChain{});
     }
+    // chain role: the argument of a launch (which = 0: the whole / the domain's list, 1: the top separators), and its grid --
+    // at least one worker beside the chain workgroups
+    DfChain chain_arg(int which) const {
+        DfChain C;
+        int *dfl = d_flags + (size_t)(nT + 1) * nT + nparts + nT;
+        C.cols = which ? d_chain_colsB : d_chain_cols; C.ncols = which ? nchainB : nchain;
+        C.par = d_chain_par; C.bits = which ? d_chain_bitsB : d_chain_bits;
+        C.dflags = dfl; C.claim = dfl + nT; C.giveup = dfl + 2 * nT; C.pos = d_chain_pos;
+        C.nwg = which ? chain_wgB : chain_wg;
+        C.ctr_slot = which ? 5 : 3; C.role_slot = which ? 6 : 4;
+        C.trace_potf2 = env_int("DBAT_HIP_DF_TRACE_POTF2", 0);
+        return C;
+    }
+    int chain_grid(int work, int wg) const { return std::max(std::min(grid, work + wg), wg + 1); }
     // ---- several ranks (two_phase), permuted layout only.  solve_domain: this rank factors the columns of its
     // own domain from ITS S (complete there: nd.hpp) and leaves its share of every top tile -- A_r minus the
     // domain's updates -- in the tile; the caller sums the top tiles over the ranks (top_tiles(), one
@@ -1290,23 +1664,32 @@ struct DataflowChol {
     void solve_domain(hipStream_t stream, double *A, int64_t lda, double *linv_work, int *info_dev, double *ldiag) {
         ++epoch;
         DfView V;
-        V.toff = d_toff; V.rowbits = d_rowbits; V.W = W; V.no_l2 = 1;
+        V.toff = d_toff; V.rowbits = d_rowbits; V.W = W; V.no_l2 = env_l2 ? 0 : 1;
         V.ldS = lda; V.n_nat = n_nat; V.base = d_tiles; V.ld = 64; V.iperm = d_iperm; V.S = A;
         hipLaunchKernelGGL(k_df_reset, dim3((nT * CHOL_NB + 255) / 256), dim3(256), 0, stream, info_dev, d_ctl,
                            reinterpret_cast<unsigned long long *>(d_qperm), nT * CHOL_NB);
-        if (ntasks > 0)
-            hipLaunchKernelGGL(k_chol_df, dim3(std::min(grid, ntasks)), dim3(256), 0, stream, V, n, nT, d_tasks, ntasks,
+        if (ntasks > 0 && use_chain)
+            hipLaunchKernelGGL(k_chol_df<true>, dim3(chain_grid(ntasks, chain_wg)), dim3(256), 0, stream, V, n, nT, d_tasks, ntasks,
                                d_flags, d_ctl, epoch, linv_work, info_dev, (long long *)nullptr, d_bk_ptr, d_bk_idx, (double *)nullptr,
-                               (double *)nullptr, ldiag, (const double *)nullptr, (double *)nullptr, d_parts, nparts, d_bk_list, 0, 0);
+                               (double *)nullptr, ldiag, (const double *)nullptr, (double *)nullptr, d_parts, nparts, d_bk_list, 0, 0, chain_arg(0));
+        else if (ntasks > 0)
+            hipLaunchKernelGGL(k_chol_df<false>, dim3(std::min(grid, ntasks)), dim3(256), 0, stream, V, n, nT, d_tasks, ntasks,
+                               d_flags, d_ctl, epoch, linv_work, info_dev, (long long *)nullptr, d_bk_ptr, d_bk_idx, (double *)nullptr,
+                               (double *)nullptr, ldiag, (const double *)nullptr, (double *)nullptr, d_parts, nparts, d_bk_list, 0, 0, DfChain{});
     }
     void solve_top(hipStream_t stream, int64_t lda, double *q_out, double *linv_work, int *info_dev, double *ldiag,
                    const double *qscale, double *dz_out) {
         DfView V;
         V.toff = d_toff; V.rowbits = d_rowbits_top; V.W = W; V.no_l2 = 1;
         V.ldS = lda; V.n_nat = n_nat; V.base = d_tiles; V.ld = 64; V.iperm = d_iperm; V.S = nullptr;   // the tiles hold the summed shares
-        hipLaunchKernelGGL(k_chol_df, dim3(std::min(grid, ntasksB + nbk)), dim3(256), 0, stream, V, n, nT, d_tasksB, ntasksB,
-                           d_flags, d_ctl, epoch, linv_work, info_dev, (long long *)nullptr, d_bk_ptr, d_bk_idx, d_qperm, q_out, ldiag,
-                           qscale, dz_out, d_parts, nparts, d_bk_list, nbk, 2);
+        if (use_chain)
+            hipLaunchKernelGGL(k_chol_df<true>, dim3(chain_grid(ntasksB + nbk, chain_wgB)), dim3(256), 0, stream, V, n, nT, d_tasksB, ntasksB,
+                               d_flags, d_ctl, epoch, linv_work, info_dev, (long long *)nullptr, d_bk_ptr, d_bk_idx, d_qperm, q_out, ldiag,
+                               qscale, dz_out, d_parts, nparts, d_bk_list, nbk, 2, chain_arg(1));
+        else
+            hipLaunchKernelGGL(k_chol_df<false>, dim3(std::min(grid, ntasksB + nbk)), dim3(256), 0, stream, V, n, nT, d_tasksB, ntasksB,
+                               d_flags, d_ctl, epoch, linv_work, info_dev, (long long *)nullptr, d_bk_ptr, d_bk_idx, d_qperm, q_out, ldiag,
+                               qscale, dz_out, d_parts, nparts, d_bk_list, nbk, 2, DfChain{});
     }
 };
 

@@ -36,6 +36,9 @@ static const EnvSwitch kEnvSwitches[] = {
     {"DBAT_HIP_ND_JOIN_SMALL", false, "separators up to that many rows join their child's last tile"},
     {"DBAT_HIP_DF_SPLIT", false, "factorisation: helper tasks for sums longer than this many products (default 96)"},
     {"DBAT_HIP_DF_CHUNK", false, "factorisation: products per helper task (default 32)"},
+    {"DBAT_HIP_DF_CHAIN", false, "factorisation: 0 = diagonal tiles as ordinary tasks (no chain role)"},
+    {"DBAT_HIP_DF_CHAIN_WG", false, "factorisation: workgroups of the chain role at most (default 32)"},
+    {"DBAT_HIP_DF_L2", false, "factorisation: 1 = finished tiles of the compact layout are read through the L2"},
     {"DBAT_HIP_SPRANK_OFF", false, "structural rank from the counting conditions only"},
     {"DBAT_HIP_PLAN_THREADS", false, "threads of the host plan (default: hardware concurrency, at most 32)"},
     {"DBAT_HIP_PLAN_GRAIN", false, "elements per thread below which a pass of the host plan is not split (tests: 1)"},
@@ -43,6 +46,7 @@ static const EnvSwitch kEnvSwitches[] = {
     {"DBAT_HIP_PIVOT_STATS", false, "print the pivot extremes and the rcond estimate of every solve"},
     {"DBAT_HIP_ABLATE", true, "k_build_sig / tile kernels: switch phases off (results are wrong), phase clocks"},
     {"DBAT_HIP_DF_TRACE", true, "per-task clocks of the factorisation, written to this file"},
+    {"DBAT_HIP_DF_TRACE_POTF2", true, "with DF_TRACE: clocks inside the chain role's factorisations as well"},
     {"DBAT_HIP_DF_ORDER", true, "one of the candidate task orders instead of the simulated best"},
     {"DBAT_HIP_DF_GRID", true, "workgroups of the factorisation"},
     {"DBAT_HIP_GRID_OBS", true, "launch size of the observation-parallel kernels"},

@@ -1384,7 +1384,8 @@ def test_cholesky_split_sums(hip, name, selfcal, monkeypatch):
 @pytest.mark.parametrize('switch,value', [('DBAT_HIP_ND_OFF', '1'), ('DBAT_HIP_ND_LEAF', '8'), ('DBAT_HIP_ND_PAD_ALL', '1'),
                                           ('DBAT_HIP_ND_JOIN_SMALL', '0'), ('DBAT_HIP_SPRANK_OFF', '1'), ('DBAT_HIP_TILE_BMIN', '1'),
                                           ('DBAT_HIP_TILE_BMIN', '6'), ('DBAT_HIP_PLAN_STATS', '2'), ('DBAT_HIP_PIVOT_STATS', '1'),
-                                          ('DBAT_HIP_PLAN_THREADS', '3')])
+                                          ('DBAT_HIP_PLAN_THREADS', '3'), ('DBAT_HIP_DF_CHAIN', '0'), ('DBAT_HIP_DF_CHAIN_WG', '1'),
+                                          ('DBAT_HIP_DF_CHAIN_WG', '3'), ('DBAT_HIP_DF_L2', '1')])
 def test_product_switches_leave_the_result_alone(hip, switch, value, monkeypatch):
     """csrc/env.hpp: a product switch selects a layout or a schedule (the dissection of the camera network, the tile
     length, the threads of the host plan) or prints statistics -- the step is the same to rounding whatever its value.
