@@ -684,6 +684,14 @@ __device__ __forceinline__ bool df_chain_role(double *smem, const DfView &V, int
                     }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // L^-1 is out (issued before the product)
+            // ... and its flag goes up with the last wave that gets here (an LDS count, no barrier): the workers' way from
+            // L^-1(k) to the sums of column k+1 is as long as the chain's own way to the end of the next factorisation
+            if (tx == 0) {
+                if (atomicAdd(s_word + 5, 1) == 3) {
+                    s_word[5] = 0;
+                    __hip_atomic_store(flags + (int64_t)k * nT + k, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
@@ -704,7 +712,6 @@ __device__ __forceinline__ bool df_chain_role(double *smem, const DfView &V, int
             *s_task = got > 0;
         }
         __syncthreads();
-        if (t == 0) __hip_atomic_store(flags + (int64_t)k * nT + k, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         DF_CLK(6);
         if (nxt && !pre && *s_task) {
             DF_VAL(9, 2);
@@ -768,7 +775,7 @@ __global__ __launch_bounds__(256) void k_chol_df(DfView V, int n, int nT, const 
     int *counter = ctl + ctr_slot, *abort_flag = ctl + 1;     // (slot 0, or 2 for the second launch of a solve)
     const bool l2 = V.iperm != nullptr && !V.no_l2;     // compact tiles: finished tiles through the L2 (see ld_l2_16)
     if constexpr (CHAIN) {                              // the first workgroups to arrive factor the diagonal tiles
-        if (t == 0) s_task = atomicAdd(ctl + C.role_slot, 1);
+        if (t == 0) { s_task = atomicAdd(ctl + C.role_slot, 1); s_word[5] = 0; }
         __syncthreads();
         const int arrival = s_task;
         __syncthreads();
@@ -1385,7 +1392,36 @@ struct DataflowChol {
         if (const char *g = env_get("DBAT_HIP_DF_GRID")) grid = std::min(std::max(atoi(g), 1), 4096);
         nparts = 0; n_products = 0;
         two_phase = !col_owner.empty();
+        // The chain role pays where the dependent chain of the separators decides the time (C1 ... C3: 0.61 -> 0.59 ms at C3);
+        // where the tile products do (C4: 116 000 of them, 3.07 -> 3.29 ms) its workgroups and the extra sum tasks cost more
+        // than the shorter links return.  Both times from the pattern: products x 2.6 us over the workgroups against the
+        // longest chain x 17 us (measured costs, MI355X).  DBAT_HIP_DF_CHAIN=0 / 1 forces it off / on.
         use_chain = permuted && env_int("DBAT_HIP_DF_CHAIN", 1) != 0;
+        if (use_chain && !two_phase && !env_get("DBAT_HIP_DF_CHAIN")) {
+            long long nprod = 0;
+            int longest = 0, cur = 0;
+            for (int k = 0; k < nT; ++k) {
+                int par = -1;
+                for (int i = k; i <= nT; ++i) {
+                    if (!has(i, k)) continue;
+                    if (i > k && par < 0) par = i;
+                    for (int w = 0; w < W; ++w) {
+                        uint64_t m = rowbits[(size_t)i * W + w] & rowbits[(size_t)k * W + w];
+                        if (w == (k >> 6)) m &= (1ull << (k & 63)) - 1;
+                        else if (w > (k >> 6)) m = 0;
+                        nprod += __builtin_popcountll(m);
+                    }
+                }
+                cur = (k > 0 && cur > 0) ? cur : 1;
+                longest = std::max(longest, cur);
+                cur = par == k + 1 ? cur + 1 : 0;
+            }
+            const double t_products = (double)nprod * 2.6 / std::min(grid, 256), t_chain = longest * 17.0;
+            use_chain = t_products < 0.6 * t_chain;
+            if (env_on("DBAT_HIP_PLAN_STATS"))
+                fprintf(stderr, "[chol] %lld tile products (%.0f us over the workgroups), longest chain %d links (%.0f us): chain role %s\n",
+                        nprod, t_products, longest, t_chain, use_chain ? "on" : "off");
+        }
         // the diagonal tasks leave the ordered list for the chain role: their order is the order of the tickets
         auto split_chain = [&](JobList &L, std::vector<DfJob> &tasks, std::vector<int> &cols) {
             tasks.clear(); cols.clear();

@@ -8,10 +8,16 @@
 // interleaved-complex API, a same-named .m stub that errors when the MEX file
 // is missing (code/test/postcov/icpc_mex.m:14).
 //
-//   [x,code,iters,sigma0,res,damp,aux,T,ru,rw,time,CEO,CIO,COP] = dbat_hip_mex(P, opt)
+//   [x,code,iters,sigma0,res,damp,aux,T,ru,rw,time,CEO,CIO,COP,Jw,Ju] = dbat_hip_mex(P, opt)
+//   id = dbat_hip_mex('commId')     128 bytes (uint8) of a fresh RCCL unique id: rank 0 of a multi-GPU run creates it
+//                                   and hands it to the other MATLAB workers (labSend / a file), who pass it as opt.commId
 //
 // P   struct with the flattened DBAT struct fields built by bundle_hip.m
-// opt struct: damping (0..3), maxIter, convTol, absTerm, singularTest, trace
+// opt struct: damping (0..3), maxIter, convTol, absTerm, singularTest, trace,
+//             wantJ (0: never, 1: always, 2: after a failed run, code -2 / -4 -- E.final.weighted.J, bundle.m:341-350,372-446),
+//             wantCov (posterior covariance blocks), deterministic (dbat_hip_set_deterministic),
+//             device (HIP device ordinal), shardRank, shardCount (this worker's share of the object points,
+//             dbat_hip.h "several GPUs"), commId (uint8 [128] from dbat_hip_mex('commId'); required when shardCount > 1)
 #include <cstring>
 #include <vector>
 
@@ -25,9 +31,33 @@ static const mxArray *field(const mxArray *s, const char *name) {
 }
 static double scalar(const mxArray *s, const char *name) { return mxGetScalar(field(s, name)); }
 
+// J (dbat_hip_jacobian_csc) as a MATLAB sparse matrix, as [r,J]=resFun(x) returns it (brown_euler_cam4.m:163-182)
+static mxArray *sparse_jacobian(dbat_hip_handle *h, const double *x, int weighted, int64_t m, int64_t n) {
+    int64_t nnz = 0;
+    if (dbat_hip_jacobian_csc(h, x, weighted, &nnz, nullptr, nullptr, nullptr) != DBAT_HIP_OK)
+        mexErrMsgIdAndTxt("DBAT:bundle:internal", "%s", dbat_hip_last_error());
+    mxArray *J = mxCreateSparse((mwSize)m, (mwSize)n, (mwSize)(nnz > 0 ? nnz : 1), mxREAL);
+    std::vector<int64_t> colptr((size_t)n + 1), rowidx((size_t)nnz);
+    if (dbat_hip_jacobian_csc(h, x, weighted, &nnz, colptr.data(), rowidx.data(), mxGetDoubles(J)) != DBAT_HIP_OK)
+        mexErrMsgIdAndTxt("DBAT:bundle:internal", "%s", dbat_hip_last_error());
+    mwIndex *jc = mxGetJc(J), *ir = mxGetIr(J);
+    for (int64_t c = 0; c <= n; ++c) jc[c] = (mwIndex)colptr[(size_t)c];
+    for (int64_t e = 0; e < nnz; ++e) ir[e] = (mwIndex)rowidx[(size_t)e];
+    return J;
+}
+
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
+    if (nrhs == 1 && mxIsChar(prhs[0])) {          // dbat_hip_mex('commId')
+        char what[16] = {0};
+        mxGetString(prhs[0], what, sizeof(what));
+        if (std::strcmp(what, "commId") != 0) mexErrMsgIdAndTxt("DBAT:dbat_hip_mex:badInput", "unknown request %s", what);
+        plhs[0] = mxCreateNumericMatrix(1, DBAT_HIP_UNIQUE_ID_BYTES, mxUINT8_CLASS, mxREAL);
+        if (dbat_hip_comm_unique_id((uint8_t *)mxGetData(plhs[0])) != DBAT_HIP_OK)
+            mexErrMsgIdAndTxt("DBAT:bundle:internal", "%s", dbat_hip_last_error());
+        return;
+    }
     if (nrhs != 2 || !mxIsStruct(prhs[0]) || !mxIsStruct(prhs[1]))
-        mexErrMsgIdAndTxt("DBAT:dbat_hip_mex:badInput", "usage: dbat_hip_mex(P, opt)");
+        mexErrMsgIdAndTxt("DBAT:dbat_hip_mex:badInput", "usage: dbat_hip_mex(P, opt) or dbat_hip_mex('commId')");
     const mxArray *P = prhs[0], *O = prhs[1];
     dbat_hip_problem pb;
     std::memset(&pb, 0, sizeof(pb));
@@ -61,11 +91,28 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     pb.prior_OP_use = (const uint8_t *)mxGetData(field(P, "useOP"));
     pb.prior_OP_val = mxGetDoubles(field(P, "priorOP"));
     pb.prior_OP_std = mxGetDoubles(field(P, "stdOP"));
-    pb.device = 0; pb.shard_rank = 0; pb.shard_count = 1;
+    pb.device = (int32_t)scalar(O, "device");
+    pb.shard_rank = (int32_t)scalar(O, "shardRank");
+    pb.shard_count = (int32_t)scalar(O, "shardCount");
+    const mxArray *cid = field(O, "commId");
+    if (pb.shard_count < 1 || pb.shard_rank < 0 || pb.shard_rank >= pb.shard_count)
+        mexErrMsgIdAndTxt("DBAT:bundle:badInput", "shardRank %d outside shardCount %d", (int)pb.shard_rank, (int)pb.shard_count);
+    if (pb.shard_count > 1 && (!mxIsUint8(cid) || mxGetNumberOfElements(cid) != DBAT_HIP_UNIQUE_ID_BYTES))
+        mexErrMsgIdAndTxt("DBAT:bundle:badInput", "shardCount > 1 needs opt.commId: the %d bytes of dbat_hip_mex('commId') from rank 0",
+                          DBAT_HIP_UNIQUE_ID_BYTES);
 
     dbat_hip_handle *h = nullptr;
     if (dbat_hip_create(&pb, &h) != DBAT_HIP_OK)
         mexErrMsgIdAndTxt("DBAT:bundle:badInput", "%s", dbat_hip_last_error());
+    // several workers, one GPU each: join the communicator (collective: every worker is here at the same time)
+    if (pb.shard_count > 1 && dbat_hip_comm_init(h, (const uint8_t *)mxGetData(cid)) != DBAT_HIP_OK) {
+        dbat_hip_destroy(h);
+        mexErrMsgIdAndTxt("DBAT:bundle:internal", "%s", dbat_hip_last_error());
+    }
+    if ((int)scalar(O, "deterministic") && dbat_hip_set_deterministic(h, 1) != DBAT_HIP_OK) {
+        dbat_hip_destroy(h);
+        mexErrMsgIdAndTxt("DBAT:bundle:badInput", "%s", dbat_hip_last_error());
+    }
     dbat_hip_options opt;
     dbat_hip_default_options((int32_t)scalar(O, "damping"), &opt);
     opt.max_iter = (int32_t)scalar(O, "maxIter");
@@ -118,12 +165,20 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
         const mwSize nIOu = (mwSize)(inf[0] - 6 * (int64_t)pb.n_images);
         plhs[11] = mxCreateNumericArray(3, dE, mxDOUBLE_CLASS, mxREAL);
         mxArray *cio = mxCreateDoubleMatrix(nIOu, nIOu, mxREAL), *cop = mxCreateNumericArray(3, dP, mxDOUBLE_CLASS, mxREAL);
-        if (r.code == 0 &&
+        if (r.code == 0 && (int)scalar(O, "wantCov") &&
             dbat_hip_posterior_cov(h, x, r.sigma0, mxGetDoubles(plhs[11]), nIOu ? mxGetDoubles(cio) : nullptr,
                                    mxGetDoubles(cop), nullptr) != DBAT_HIP_OK)
             mexWarnMsgIdAndTxt("DBAT:bundle_cov:notPD", "%s", dbat_hip_last_error());
         if (nlhs > 12) plhs[12] = cio; else mxDestroyArray(cio);
         if (nlhs > 13) plhs[13] = cop; else mxDestroyArray(cop);
+    }
+    if (nlhs > 14) {
+        // E.final.weighted.J / E.final.unweighted.J at the point the solver returned (bundle.m:341-350): on request, and
+        // for the post-mortem of a failed run (bundle.m:372-446 analyses J).  One-rank handles only (dbat_hip.h).
+        const int want = (int)scalar(O, "wantJ");
+        const bool give = pb.shard_count == 1 && (want == 1 || (want == 2 && (r.code == -2 || r.code == -4)));
+        plhs[14] = give ? sparse_jacobian(h, x, 1, m, n) : mxCreateSparse((mwSize)0, (mwSize)0, (mwSize)1, mxREAL);
+        if (nlhs > 15) plhs[15] = give ? sparse_jacobian(h, x, 0, m, n) : mxCreateSparse((mwSize)0, (mwSize)0, (mwSize)1, mxREAL);
     }
     dbat_hip_destroy(h);
 }

@@ -28,6 +28,14 @@ mxArray *mxCreateDoubleMatrix(mwSize m, mwSize n, mxComplexity flag);
 mxArray *mxCreateDoubleScalar(double value);
 mxArray *mxCreateNumericArray(mwSize ndim, const mwSize *dims, mxClassID classid, mxComplexity flag);
 void mxSetN(mxArray *pa, mwSize n);
+mxArray *mxCreateSparse(mwSize m, mwSize n, mwSize nzmax, mxComplexity flag);
+mwIndex *mxGetIr(const mxArray *pa);
+mwIndex *mxGetJc(const mxArray *pa);
+mxArray *mxCreateNumericMatrix(mwSize m, mwSize n, mxClassID classid, mxComplexity flag);
+size_t mxGetNumberOfElements(const mxArray *pa);
+bool mxIsChar(const mxArray *pa);
+bool mxIsUint8(const mxArray *pa);
+int mxGetString(const mxArray *pa, char *str, mwSize strlen);
 void mxDestroyArray(mxArray *pa);
 void mexErrMsgIdAndTxt(const char *identifier, const char *fmt, ...);
 void mexWarnMsgIdAndTxt(const char *identifier, const char *fmt, ...);

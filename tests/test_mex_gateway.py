@@ -81,3 +81,67 @@ def test_field_names_and_output_order_agree():
         guards = [int(g) for g in re.findall(r'if \(nlhs > (\d+)\)[^\n;]*plhs\[%d\]\s*=' % i, cpp)]
         outer = [int(g) for g in re.findall(r'if \(nlhs > (\d+)\) \{', cpp)]
         assert any(g == i for g in guards) or any(g <= i for g in outer), i   # nlhs > i <=> plhs[i] may be set
+
+
+def _option_cases(src):
+    """{option string: statement} of the varargin switch of a bundle()-style parser."""
+    sw = src[src.index('switch lower('):]
+    sw = sw[:sw.index('\n        end')]
+    out = {}
+    for m in re.finditer(r"^\s*case\s+(\{[^}]*\}|'[^']*')\s*,?\s*(.*)$", sw, re.M):
+        for name in re.findall(r"'([^']*)'", m.group(1)):
+            out[name] = m.group(2).strip()
+    return out
+
+
+def test_every_option_bundle_accepts_reaches_the_gateway_or_the_result():
+    """bundle.m:78-132 accepts a fixed set of option strings.  bundle_hip.m must accept the same set, and none may be
+    parsed and dropped (round 4's wrapper swallowed 'pmdof' / 'dofverb'): the variable a case sets has to be read
+    again -- in the gateway's opt struct or in the result code after the call."""
+    m = open(WRAPPER).read()
+    cases = _option_cases(m)
+    ref_opts = {'none', 'gm', 'gna', 'lm', 'lmp', 'trace', 'singulartest', 'nosingulartest', 'pmdof', 'dofverb', 'absterm'}
+    ref = '/root/reference/code/bundle/bundle.m'
+    if os.path.exists(ref):                     # (not on the GPU box; the set above is bundle.m:97-121)
+        assert set(_option_cases(open(ref).read())) == ref_opts
+    assert set(cases) == ref_opts, (sorted(set(cases) ^ ref_opts))
+    body_after_parse = m[m.index("% --- what BUNDLE has no argument for"):]
+    opt_literal = re.search(r"^opt=struct\((.*?)\);", m.replace('...\n', ' '), re.M | re.S).group(1)
+    for name, stmt in cases.items():
+        assert stmt and not stmt.startswith('%'), 'option %r is parsed and dropped' % name
+        var = re.match(r"(\w+)\s*=", stmt)
+        assert var, (name, stmt)
+        v = var.group(1)
+        uses = len(re.findall(r'\b%s\b' % v, body_after_parse))
+        assert uses >= 1, 'option %r sets %s, which nothing reads' % (name, v)
+    # what must reach the gateway does
+    for v in ('maxIter', 'convTol', 'absTerm', 'singularTest', 'dampNo'):
+        assert re.search(r'\b%s\b' % v, opt_literal), v
+    # what acts after the call does: the degrees of freedom and their report
+    tail = m[m.index('=dbat_hip_mex(P,opt);'):]
+    assert re.search(r'if pmDof\b', tail) and re.search(r'dof=lenR\+p-lenX', tail) and re.search(r'E\.redundancy=dof', tail)
+    assert re.search(r'if dofVerb\b', tail) and re.search(r'if doTrace\b', tail)
+    assert 's0=sqrt((rw\'*rw)/dof)' in tail
+
+
+def test_gpu_side_fields_reach_the_gateway():
+    """s.bundle.hip.* (device, shardRank, shardCount, commId, wantJ, wantCov, deterministic): every default field of
+    the wrapper is copied into opt, an unknown field raises, and the gateway reads each of them (the set equality of
+    test_field_names_and_output_order_agree) -- round 4's gateway hard-coded device 0 / one rank."""
+    m = open(WRAPPER).read()
+    cpp = open(GATEWAY).read()
+    hip_fields = _matlab_struct_fields(m, 'hip')
+    assert set(hip_fields) == {'device', 'shardRank', 'shardCount', 'commId', 'wantJ', 'wantCov', 'deterministic'}
+    opt_literal = re.search(r"^opt=struct\((.*?)\);", m.replace('...\n', ' '), re.M | re.S).group(1)
+    for f in hip_fields:
+        assert re.search(r'hip\.%s\b' % f, opt_literal) or (f == 'wantJ' and 'wantJ' in opt_literal), f
+    assert "error('DBAT:bundle:badInput','Unknown field s.bundle.hip.%s'" in m
+    # the gateway hands them on: no literal device / rank any more
+    assert not re.search(r'pb\.device\s*=\s*0', cpp) and not re.search(r'pb\.shard_count\s*=\s*1', cpp)
+    for call in ('dbat_hip_comm_init', 'dbat_hip_comm_unique_id', 'dbat_hip_set_deterministic', 'dbat_hip_jacobian_csc',
+                 'mxCreateSparse'):
+        assert call in cpp, call
+    # a failed run never reports "rank ok": the only unconditional rank = lenX sits in the final else of the post-mortem
+    wk = m[m.index('E.weakness=struct('):]
+    assert wk.count('E.weakness.numerical.rank=lenX') == 1
+    assert re.search(r"elseif code==-2 \|\| code==-4\s*\n[^\n]*\n\s*E\.weakness\.numerical\.rank=nan", wk)
