@@ -1179,33 +1179,59 @@ __global__ __launch_bounds__(256) void k_cam_normal(DevProblem d, const double *
     // columns that stay zero
     for (int c = NCX + 1; c < 16; ++c) { Gw[c * GLD + 2 * lane] = 0.0; Gw[c * GLD + 2 * lane + 1] = 0.0; }
     mfma_d4 acc = {0, 0, 0, 0};
-    for (int64_t base = q0 + 64 * w; base < q1; base += 256) {
-        const int64_t q = base + lane;
-        double r[2] = {0, 0}, E[2][NCX];
+    // A chunk is at most 2048 observations: eight rounds per wave.  The loads of a round are a dependent pair (point index,
+    // then the gather of the point) and only one other wave shares the SIMD to hide them (LDS: two workgroups per CU), so
+    // round 4's kernel spent 72 % of its wave cycles waiting (profiles/r04_c4_summary.md).  Now the indices and image
+    // coordinates of ALL the wave's rounds are requested up front and the point of round n+1 while round n is evaluated.
+    constexpr int NRW = 8;
+    for (int64_t wbase = q0 + 64 * w; wbase < q1; wbase += 256 * NRW) {
+        int ptv[NRW];
+        double2 uvv[NRW], wv[NRW];
 #pragma unroll
-        for (int c = 0; c < NCX; ++c) { E[0][c] = 0.0; E[1][c] = 0.0; }
-        if (q < q1) {
-            const int pt = cm_pt[q];
-            const int64_t zp = d.NS + 3 * (int64_t)pt;
-            const double Q[3] = {z[zp], z[zp + 1], z[zp + 2]};
-            const double w0 = cm_w ? cm_w[2 * q] : C.w[0], w1 = cm_w ? cm_w[2 * q + 1] : C.w[1];
-            double B[2][3];
-            eval_obs_pre<MODEL, NCX>(d, C, Q, cm_uv[2 * q], cm_uv[2 * q + 1], w0, w1, 7u, r, E, B);
+        for (int n = 0; n < NRW; ++n) {
+            const int64_t q = wbase + 256 * n + lane;
+            ptv[n] = 0; uvv[n] = double2{0, 0}; wv[n] = double2{C.w[0], C.w[1]};
+            if (q < q1) {
+                ptv[n] = cm_pt[q];
+                uvv[n] = reinterpret_cast<const double2 *>(cm_uv)[q];
+                if (cm_w) wv[n] = reinterpret_cast<const double2 *>(cm_w)[q];
+            }
         }
+        double Qn[3];
+        { const int64_t zp = d.NS + 3 * (int64_t)ptv[0]; Qn[0] = z[zp]; Qn[1] = z[zp + 1]; Qn[2] = z[zp + 2]; }
 #pragma unroll
-        for (int c = 0; c < NCX; ++c) {
-            const bool on = c < ncol;
-            Gw[c * GLD + 2 * lane] = on ? E[0][c] : 0.0;
-            Gw[c * GLD + 2 * lane + 1] = on ? E[1][c] : 0.0;
+        for (int n = 0; n < NRW; ++n) {
+            const int64_t base = wbase + 256 * n;
+            if (base >= q1) break;                       // (uniform: the rounds of a wave end together)
+            const int64_t q = base + lane;
+            const double Q[3] = {Qn[0], Qn[1], Qn[2]};
+            if (n + 1 < NRW) { const int64_t zp = d.NS + 3 * (int64_t)ptv[n + 1]; Qn[0] = z[zp]; Qn[1] = z[zp + 1]; Qn[2] = z[zp + 2]; }
+            double r[2] = {0, 0}, E[2][NCX];
+#pragma unroll
+            for (int c = 0; c < NCX; ++c) { E[0][c] = 0.0; E[1][c] = 0.0; }
+            if (q < q1) {
+                double B[2][3];
+                eval_obs_pre<MODEL, NCX>(d, C, Q, uvv[n].x, uvv[n].y, wv[n].x, wv[n].y, 7u, r, E, B);
+            }
+#pragma unroll
+            for (int c = 0; c < NCX; ++c) {
+                const bool on = c < ncol;
+                Gw[c * GLD + 2 * lane] = on ? E[0][c] : 0.0;
+                Gw[c * GLD + 2 * lane + 1] = on ? E[1][c] : 0.0;
+            }
+            Gw[NCX * GLD + 2 * lane] = r[0]; Gw[NCX * GLD + 2 * lane + 1] = r[1];
+            lds_fence();                                 // the panel is private to the wave
+            // all 32 operand fragments first, then 32 back-to-back products
+            {
+                double av[32];
+                const double *ga = Gw + (lane & 15) * GLD + (lane >> 4);
+#pragma unroll
+                for (int kk = 0; kk < 32; ++kk) av[kk] = ga[4 * kk];
+#pragma unroll
+                for (int kk = 0; kk < 32; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], av[kk], acc, 0, 0, 0);
+            }
+            lds_fence();
         }
-        Gw[NCX * GLD + 2 * lane] = r[0]; Gw[NCX * GLD + 2 * lane + 1] = r[1];
-        lds_fence();                                 // the panel is private to the wave
-#pragma unroll 8
-        for (int kk = 0; kk < 32; ++kk) {
-            const double a = Gw[(lane & 15) * GLD + 4 * kk + (lane >> 4)];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
-        }
-        lds_fence();
     }
     // G(i, j): register e of lane l holds i = (l>>4) + 4e, j = l&15.  Sum the four waves.
 #pragma unroll
