@@ -105,9 +105,31 @@ def cpu_baseline(s_main, name_main, budget_s=25.0, others=('C1', 'C2')):
     }
 
 
+def error_line(args, msg, **kw):
+    """One JSON line in the shape of a result, for a run that could not be measured."""
+    out = {'metric': 'LM iterations/sec', 'value': None, 'unit': 'it/s', 'n_gpus': args.gpus, 'steps': args.steps,
+           'warmup': args.warmup, 'higher_is_better': True, 'error': msg}
+    out.update(kw)
+    print(json.dumps(out), flush=True)
+
+
 def launch_ranks(args):
     """Start one rank per GPU (torch.distributed.run) as a child process; the
-    parent never initialises a GPU."""
+    parent never initialises a GPU.  A run that cannot work says so in one JSON line and a non-zero exit code:
+    fewer visible devices than ranks (checked here, before anything is started: counting devices does not
+    initialise the GPU), or ranks that failed / timed out (their own message is above the line)."""
+    host_ar = os.environ.get('DBAT_BENCH_HOST_ALLREDUCE') == '1'
+    try:
+        import torch
+        ndev = torch.cuda.device_count()
+    except Exception as e:                               # noqa: BLE001 (a broken torch install is an answer too)
+        error_line(args, 'torch.cuda.device_count() failed: %s' % e)
+        return 2
+    if ndev < args.gpus and not host_ar:
+        error_line(args, '--gpus %d but %d HIP device(s) visible (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?); '
+                         'DBAT_BENCH_HOST_ALLREDUCE=1 runs the ranks on the devices that exist, sums through the host '
+                         '(a functional check, not a scaling number)' % (args.gpus, ndev), visible_devices=ndev)
+        return 2
     # --standalone: the launcher picks its own rendezvous port (no bind-and-close race on a shared box)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--standalone', '--local-addr', '127.0.0.1', '--nnodes=1',
            '--nproc-per-node', str(args.gpus), os.path.abspath(__file__)] + sys.argv[1:]
@@ -115,7 +137,36 @@ def launch_ranks(args):
     # this pool's host driver supports dmabuf IPC only: without it RCCL's ncclCommInitRank across
     # processes fails in hipIpcGetMemHandle (the image exports the same value)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    return subprocess.run(cmd, env=env).returncode
+    rc = subprocess.run(cmd, env=env).returncode
+    if rc != 0:
+        error_line(args, 'the ranks exited with code %d (their messages are above this line)' % rc, visible_devices=ndev,
+                   launcher='torch.distributed.run --standalone --nproc-per-node %d' % args.gpus)
+    return rc
+
+
+class Watchdog:
+    """A phase that can hang on a dead peer (ncclCommInitRank, the first collective) runs under a timer: on expiry the
+    rank says where it was and leaves with os._exit -- torch.distributed.run then ends the other ranks and the parent
+    reports the failure.  Never an exec: a process that has touched the GPU must not be replaced (this pool)."""
+
+    def __init__(self, seconds, rank, what):
+        import threading
+        self.t = threading.Timer(seconds, self._fire)
+        self.t.daemon = True
+        self.rank, self.what, self.seconds = rank, what, seconds
+
+    def _fire(self):
+        sys.stderr.write('bench.py rank %d: no progress within %.0f s in: %s\n' % (self.rank, self.seconds, self.what))
+        sys.stderr.flush()
+        os._exit(3)
+
+    def __enter__(self):
+        self.t.start()
+        return self
+
+    def __exit__(self, *a):
+        self.t.cancel()
+        return False
 
 
 def main():
@@ -125,9 +176,11 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--config', default='C3')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-solve', action='store_true', help='skip the timed dbat_hip_solve("lm") run')
+    ap.add_argument('--no-solve', action='store_true', help='skip the timed dbat_hip_solve run (LM; LM-Powell for C1, as BASELINE.json quotes it)')
     ap.add_argument('--deterministic', action='store_true',
                     help='fixed-order sums into the reduced system (dbat_hip_set_deterministic: bit-identical runs); reports what that costs')
+    ap.add_argument('--no-one-gpu-ref', action='store_true',
+                    help='N > 1: skip rank 0\'s one-GPU run of the same scene after the timed region (multi_gpu.one_gpu)')
     ap.add_argument('--emulate-ranks', type=int, default=0, metavar='R',
                     help='one GPU plays rank 0 of R (its share of the points, its domain of the reduced system, the '
                          'collectives replaced by no-ops): per-rank phase times for the scaling estimate of DESIGN.md 6; '
@@ -143,13 +196,19 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus and world > 1:
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a GPU (the dbat_hip core has no CPU path)')
+    host_ar = os.environ.get('DBAT_BENCH_HOST_ALLREDUCE') == '1'
+    # (launched by torch.distributed.run directly -- the driver does -- there is no parent to look first)
+    ndev = torch.cuda.device_count()                     # counting does not initialise the GPU
+    if ndev < (world if not host_ar else 1):
+        if rank == 0:
+            error_line(args, '%d rank(s) but %d HIP device(s) visible: the dbat_hip core has no CPU path, and every rank '
+                             'needs its own GPU (DBAT_BENCH_HOST_ALLREDUCE=1: ranks share the devices that exist)' % (world, ndev),
+                       visible_devices=ndev)
+        raise SystemExit(2)
     # DBAT_BENCH_HOST_ALLREDUCE=1: the sums over the ranks go through host memory and the control-plane group
     # (gloo) instead of RCCL, and the ranks share the GPUs that exist -- the whole multi-process path (launcher,
     # rendezvous, one plan per rank, domain sharding, barriers, max over the ranks) on a box with fewer GPUs than
     # ranks.  A functional check: its numbers are not scaling numbers, and the JSON says so.
-    host_ar = os.environ.get('DBAT_BENCH_HOST_ALLREDUCE') == '1'
     if host_ar:
         local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
@@ -189,10 +248,12 @@ def main():
     emu = args.emulate_ranks if world == 1 and args.emulate_ranks > 1 else 0
     h = _hip.Handle(s, device=local, shard_rank=rank, shard_count=emu or world)
     t_plan = time.perf_counter() - t_plan
+    init_timeout = float(os.environ.get('DBAT_BENCH_INIT_TIMEOUT', '180'))
     if comm is not None and host_ar:
         comm.attach_host(h)
     elif comm is not None:
-        comm.attach(h)                       # ncclCommInitRank inside the library
+        with Watchdog(init_timeout, rank, 'ncclCommInitRank (dbat_hip_comm_init) of %d ranks' % world):
+            comm.attach(h)                   # ncclCommInitRank inside the library
     if emu:
         h.set_allreduce(lambda ptr, count, stream: 0)       # the sums over the ranks: not performed
     if args.deterministic:
@@ -201,7 +262,9 @@ def main():
     x0 = h.serialize()
     h.set_x(x0)
     # LM damping as bundle.m:301 / levenberg_marquardt.m:88-95: 1e-10*trace(J'J)/n
-    _, st = h.linearize_solve(x0, 0.0, False)
+    # (several ranks: the first linearisation + solve is the first time the collectives of the data path run)
+    with Watchdog(init_timeout if world > 1 else 1e9, rank, 'the first linearisation + solve (first all-reduce of the data path)'):
+        _, st = h.linearize_solve(x0, 0.0, False)
     lam = 1e-10 * st['trace'] / h.n
     h.set_x(x0)
 
@@ -236,18 +299,44 @@ def main():
         torch.distributed.all_gather(gl, tv)
         per_rank = [[float(v) for v in g] for g in gl]
 
+    # N > 1: the same scene on ONE GPU of the same box, by rank 0 while the others wait -- the N = 1 figure that this run's
+    # value is to be compared with (strong scaling), measured in the same process and minute
+    one_gpu = None
+    if world > 1 and not host_ar and not args.no_one_gpu_ref:
+        if rank == 0:
+            h1 = _hip.Handle(s, device=local)
+            try:
+                h1.set_x(x0)
+                _, st1 = h1.linearize_solve(x0, 0.0, False)
+                h1.set_x(x0)
+                for _ in range(args.warmup):
+                    h1.bench_step(lam, False)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    h1.bench_step(lam, False)
+                torch.cuda.synchronize()
+                dt1 = time.perf_counter() - t1
+                one_gpu = {'value': args.steps / dt1, 'ms_per_step': dt1 / args.steps * 1e3,
+                           'note': 'rank 0 alone, same scene, same steps, after the timed region'}
+            finally:
+                h1.close()
+        comm.barrier()
+
     # the shipped loop: a real dbat_hip_solve('lm') from x0 (host control flow, scalar
     # read-backs and all), outside the timed region above
     solve = None
+    # BASELINE.json: C1 is quoted with LM-Powell damping (levenberg_marquardt_powell.m:107-214), the others with LM
+    solve_damping = 'lmp' if args.config == 'C1' else 'lm'
     if not args.no_solve and not emu:
-        opt = _hip.default_options('lm')
+        opt = _hip.default_options(solve_damping)
         opt.store_trace = 0
         barrier()
         t1 = time.perf_counter()
         xs, res, rr, damp, aux, T = h.solve(x0, opt)
         barrier()
         t_solve = time.perf_counter() - t1
-        solve = {'code': int(res.code), 'iterations': int(res.iters), 'linearizations': int(res.n_linearizations),
+        solve = {'damping': solve_damping, 'code': int(res.code), 'iterations': int(res.iters), 'linearizations': int(res.n_linearizations),
                  'residual_evals': int(res.n_residual_evals), 'solves': int(res.n_solves),
                  'time_s': float(res.time_s), 'wall_s': t_solve, 'sigma0': float(res.sigma0),
                  'it_per_s': res.iters / res.time_s if res.time_s > 0 else None,
@@ -350,12 +439,13 @@ def main():
         flops_exec = ex_flops + flops_chol
         bytes_exec = 40.0 * no + 48.0 * npnt + 96.0 * nc + 16.0 * cs['tile_tasks'] * 64 * 64
         t_lb_exec = max(bytes_exec / (HBM_PEAK_GBS * 1e9), flops_exec / (FP64_PEAK_TFLOPS * 1e12))
-        roof_step = {'bytes_iter': bytes_iter, 'flops_iter': flops_iter, 'lower_bound_ms': t_lb * 1e3,
-                     'executed_flops_iter': flops_exec, 'executed_bytes_iter': bytes_exec,
+        roof_step = {'executed_flops_iter': flops_exec, 'executed_bytes_iter': bytes_exec,
                      'executed_lower_bound_ms': t_lb_exec * 1e3, 'executed_frac': t_lb_exec / (dt / args.steps),
-                     'frac': t_lb / (dt / args.steps), 'bound': 'mfma' if flops_iter / (FP64_PEAK_TFLOPS * 1e12) > bytes_iter / (HBM_PEAK_GBS * 1e9) else 'hbm',
-                     'note': 'SURVEY 8(d): dense NS^2 S traffic and dense NS^3/3 Cholesky flops; the sparse factorisation does '
-                             '%.3g flops (roofline_factorisation), so a fraction above 1 is possible and means structure was used' % flops_chol}
+                     'bound': 'mfma' if flops_exec / (FP64_PEAK_TFLOPS * 1e12) > bytes_exec / (HBM_PEAK_GBS * 1e9) else 'hbm',
+                     'survey_dense_counts': {'bytes_iter': bytes_iter, 'flops_iter': flops_iter, 'lower_bound_ms': t_lb * 1e3},
+                     'note': 'executed_*: the work the step really does (sparse factorisation: %.3g flops, symmetric Schur products) against '
+                             'max(bytes / 8 TB/s, flops / 78.6 TF); survey_dense_counts: SURVEY 8(d)\'s per-iteration figures with a dense '
+                             'NS^2 S and a dense NS^3/3 Cholesky, which nobody executes -- counts only, no fraction' % flops_chol}
         multi = None
         if world > 1 or emu:
             multi = {'ranks': emu or world, 'emulated_on_one_gpu': bool(emu), 'domain_sharding': bool(info['domain_sharding']),
@@ -378,6 +468,11 @@ def main():
                         'factor_domain', 'allreduce_top_tiles', 'factor_top_replicated', 'unused')
                 multi['per_rank_ms'] = [dict(zip(keys, r)) for r in per_rank]
                 multi['slowest_rank_ms'] = {k: max(r[i] for r in per_rank) for i, k in enumerate(keys)}
+            if one_gpu is not None:
+                multi['one_gpu'] = one_gpu
+                multi['speedup_vs_one_gpu'] = (args.steps / dt) / one_gpu['value']
+            multi['measured'] = ('per-rank phase times, all-reduce time and bytes (hipEvents on the handle\'s stream), one_gpu'
+                                 if not emu else 'rank 0\'s kernel times only: the collectives are no-ops in an emulated run')
         out = {
             'metric': 'LM iterations/sec', 'value': None if emu else args.steps / dt, 'unit': 'it/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -394,7 +489,7 @@ def main():
             'ms_build_schur': ms[0], 'ms_factor_solve': ms[1], 'ms_backsub': ms[2],
             'ms_trial_residual': ms[3], 'kernel_ms': k_ms,
             'roofline': roof, 'roofline_factorisation': roof_chol, 'roofline_step': roof_step, 'hbm_kernels': hbm, 'multi_gpu': multi,
-            'solve_lm': solve, 'solve_it_s': solve['it_per_s'] if solve else None, 'solve_reference_demo': solve_ref,
+            'solve': solve, 'solve_it_s': solve['it_per_s'] if solve else None, 'solve_reference_demo': solve_ref,
             'host_s': {'scene_generation': t_gen, 'library_load_and_first_use': t_first, 'plan_and_upload': t_plan},
         }
         if world == 1 and not args.no_cpu_baseline and not emu:

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -19,6 +20,9 @@ if os.environ.get('DBAT_AMD_LIB') == 'prof':
     LIB_PATH = os.path.join(_HERE, 'libdbat_hip_prof.so')
 elif os.environ.get('DBAT_AMD_LIB', '').endswith('.so'):          # (a development build to compare with)
     LIB_PATH = os.environ['DBAT_AMD_LIB']
+if LIB_PATH != os.path.join(_HERE, 'libdbat_hip.so'):
+    # never silently: a stale development build must not stand in for the product library in a test or bench run
+    sys.stderr.write('[dbat_amd] DBAT_AMD_LIB: loading %s instead of the product library\n' % LIB_PATH)
 
 ABI_VERSION = 2
 DAMP = {'none': 0, 'gm': 0, 'gna': 1, 'lm': 2, 'lmp': 3}

@@ -267,7 +267,7 @@ struct Core {
             giant_W.alloc((size_t)(P.giant_start.back() - P.giant_start.front()) * P.ncolmax * 3);
         }
         d.ngiant = (int)ngiant; d.giant_start = giant_start.p; d.giant_W = giant_W.p;
-        if (const char *e = env_get("DBAT_HIP_GIANT_THREADS")) { const int v = atoi(e); if (v == 64 || v == 128) giant_threads = v; }
+        if (const char *e = env_get("DBAT_HIP_GIANT_THREADS")) giant_threads = atoi(e);     // (64 | 128 | 256: env_validate has refused anything else)
         d.tile_batch = tile_batch.p; d.tile_cam_start = tile_cam_start.p; d.tile_cams = tile_cams.p;
         d.tile_io_start = tile_io_start.p; d.tile_iocols = tile_iocols.p; d.tile_cam_io = tile_cam_io.p;
         tile_io_simple.upload(P.tile_io_simple); d.tile_io_simple = P.tile_io_simple.empty() ? nullptr : tile_io_simple.p;
@@ -1555,6 +1555,9 @@ int dbat_hip_jacobian_sample(dbat_hip_handle *h, const double *x, int64_t n, con
             auto it = std::lower_bound(want.begin(), want.end(), std::make_pair(P.o_row[o], (int64_t)-1));
             for (; it != want.end() && it->first == P.o_row[o]; ++it) pos[it->second] = o;
         }
+        // (a one-rank plan holds every IP column; the kernel indexes the observation arrays with these positions)
+        for (int64_t i = 0; i < n; ++i)
+            if (pos[i] < 0) { g_err = "dbat_hip_jacobian_sample: IP column " + std::to_string(ip_col[i]) + " is not in this handle's plan"; return DBAT_HIP_EINVAL; }
     }
     DeviceGuard dev_guard(c.device);
     c.x_to_z(x, c.zt.p);

@@ -21,14 +21,15 @@ constexpr bool kProfilingBuild = true;
 constexpr bool kProfilingBuild = false;
 #endif
 
-struct EnvSwitch { const char *name; bool measurement; const char *what; };
+// values: nullptr = any value; otherwise the '|'-separated list of the values the library honours (anything else is refused)
+struct EnvSwitch { const char *name; bool measurement; const char *what; const char *values = nullptr; };
 static const EnvSwitch kEnvSwitches[] = {
-    {"DBAT_HIP_SIG", false, "0: signature kernels off, 2: on wherever a chunk's rows fit (default: by group length)"},
+    {"DBAT_HIP_SIG", false, "0: signature kernels off, 2: on wherever a chunk's rows fit (default: by group length)", "0|1|2"},
     {"DBAT_HIP_SIG_IOS_OFF", false, "self-calibration: IO rows by LDS atomics in every tile"},
     {"DBAT_HIP_CMAX", false, "cameras per tile (0: column-list kernel only)"},
-    {"DBAT_HIP_BT", false, "observations per batch (128 | 256)"},
+    {"DBAT_HIP_BT", false, "observations per batch (128 | 256)", "128|256"},
     {"DBAT_HIP_TILE_BMIN", false, "fewest batches a tile may be capped at (default 2)"},
-    {"DBAT_HIP_GIANT_THREADS", false, "threads of the giant-point kernels (64 | 128 | 256)"},
+    {"DBAT_HIP_GIANT_THREADS", false, "threads of the giant-point kernels (64 | 128 | 256)", "64|128|256"},
     {"DBAT_HIP_MG_REPLICATED", false, "several ranks: envelope summed, replicated factorisation"},
     {"DBAT_HIP_ND_OFF", false, "no nested dissection"},
     {"DBAT_HIP_ND_LEAF", false, "leaf size of the dissection"},
@@ -36,9 +37,9 @@ static const EnvSwitch kEnvSwitches[] = {
     {"DBAT_HIP_ND_JOIN_SMALL", false, "separators up to that many rows join their child's last tile"},
     {"DBAT_HIP_DF_SPLIT", false, "factorisation: helper tasks for sums longer than this many products (default 96)"},
     {"DBAT_HIP_DF_CHUNK", false, "factorisation: products per helper task (default 32)"},
-    {"DBAT_HIP_DF_CHAIN", false, "factorisation: 0 = diagonal tiles as ordinary tasks (no chain role)"},
+    {"DBAT_HIP_DF_CHAIN", false, "factorisation: 0 = diagonal tiles as ordinary tasks (no chain role), 1 = chain role whatever the pattern", "0|1"},
     {"DBAT_HIP_DF_CHAIN_WG", false, "factorisation: workgroups of the chain role at most (default 32)"},
-    {"DBAT_HIP_DF_L2", false, "factorisation: 1 = finished tiles of the compact layout are read through the L2"},
+    {"DBAT_HIP_DF_L2", false, "factorisation: 1 = finished tiles of the compact layout are read through the L2", "0|1"},
     {"DBAT_HIP_SPRANK_OFF", false, "structural rank from the counting conditions only"},
     {"DBAT_HIP_PLAN_THREADS", false, "threads of the host plan (default: hardware concurrency, at most 32)"},
     {"DBAT_HIP_PLAN_GRAIN", false, "elements per thread below which a pass of the host plan is not split (tests: 1)"},
@@ -73,6 +74,13 @@ inline bool env_validate(std::string &err) {
         if (hit->measurement && !kProfilingBuild) {
             err = name + " is a measurement switch (" + hit->what + "): this library was built without -DDBAT_HIP_PROFILING (make -C dbat_amd/csrc prof)";
             return false;
+        }
+        if (hit->values && eq) {                         // a value the library would silently ignore is as bad as a typo in the name
+            const std::string val(eq + 1), list = std::string("|") + hit->values + "|";
+            if (val.empty() || val.find('|') != std::string::npos || list.find("|" + val + "|") == std::string::npos) {
+                err = name + "=" + val + ": not one of " + hit->values + " (" + hit->what + ")";
+                return false;
+            }
         }
     }
     return true;

@@ -81,14 +81,27 @@ DBAT_HD double fma2(double acc, double a, double b, double c, double d) {
     return __builtin_fma(a, b, __builtin_fma(c, d, acc));
 }
 
-// 1/x: v_rcp_f64 and two Newton steps on the device (5 operations; the IEEE division sequence takes 12)
+// 1/x: a reciprocal estimate and two Newton steps r <- r + r (1 - x r), each a pair of FMAs (5 operations; the IEEE
+// division sequence takes 12).  v_rcp_f64 is good to about 2^-23, two steps give 1/x to within one unit in the last
+// place (not always correctly rounded: the residual and Jacobian entries differ from a division's by at most that).
+// x = 0, Inf, NaN give what 1.0 / x gives (Inf, 0, NaN: v_div_fixup_f64) -- the refinement alone would turn them all
+// into NaN (Inf * (1 - 0 * Inf)).  The HOST evaluates the same sequence from 1.0 / x as its estimate, so that
+// dbat_hip_debug_model_eval_host and bench/cpu_ref.cpp run the arithmetic of the kernels they check: there the steps
+// find nothing to correct beyond the rounding of x r.
 DBAT_HD double recip(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     double r = __builtin_amdgcn_rcp(x);
-    r = r * (2.0 - x * r);
-    return r * (2.0 - x * r);
 #else
-    return 1.0 / x;
+    double r = 1.0 / x;
+#endif
+    const double e1 = __builtin_fma(-x, r, 1.0);
+    const double r1 = __builtin_fma(r, e1, r);
+    const double e2 = __builtin_fma(-x, r1, 1.0);
+    const double r2 = __builtin_fma(r1, e2, r1);
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_div_fixup(r2, x, 1.0);      // v_div_fixup_f64: the special cases of 1.0 / x (x = 0, Inf, NaN), one instruction
+#else
+    return (r2 == r2 && r != 0.0 && r - r == 0.0) ? r2 : r;     // the same: a zero, infinite or NaN quotient is returned as it is
 #endif
 }
 

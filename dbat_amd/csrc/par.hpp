@@ -7,8 +7,11 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <exception>
 #include <functional>
 #include <memory>
+#include <mutex>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -27,6 +30,31 @@ struct NoInitAlloc : std::allocator<T> {
 };
 template <class T> using uvec = std::vector<T, NoInitAlloc<T>>;
 
+// Jobs 1 .. k-1 on threads of their own, job 0 on the caller.  A thread that cannot be created (std::system_error: a
+// pids limit of the container) leaves its job to the caller; an exception inside a job (bad_alloc of a per-thread
+// vector) is carried over the joins and rethrown -- a destroyed joinable std::thread or an exception escaping a thread
+// would be std::terminate where dbat_hip_create should return DBAT_HIP_ENOMEM.
+template <class Job>
+inline void par_jobs(int k, Job &&job) {
+    std::vector<std::thread> th;
+    std::vector<int> inline_jobs;
+    std::exception_ptr first;
+    std::mutex mu;
+    auto guarded = [&](int i) {
+        try { job(i); }
+        catch (...) { std::lock_guard<std::mutex> g(mu); if (!first) first = std::current_exception(); }
+    };
+    th.reserve(k > 1 ? k - 1 : 0);
+    for (int i = 1; i < k; ++i) {
+        try { th.emplace_back(guarded, i); }
+        catch (const std::system_error &) { inline_jobs.push_back(i); }
+    }
+    guarded(0);
+    for (int i : inline_jobs) guarded(i);
+    for (auto &x : th) x.join();
+    if (first) std::rethrow_exception(first);
+}
+
 struct Par {
     int nt = 1;
     // DBAT_HIP_PLAN_GRAIN=n: cut ranges down to n elements per thread (default: each pass has its own minimum, a few
@@ -43,11 +71,7 @@ struct Par {
     void run(int64_t n, F &&f, int64_t min_per_thread = 4096) const {
         const int k = ranges(n, min_per_thread);
         if (k <= 1) { f((int64_t)0, n, 0); return; }
-        std::vector<std::thread> th;
-        th.reserve(k - 1);
-        for (int t = 1; t < k; ++t) th.emplace_back([&f, n, k, t]() { f(n * t / k, n * (t + 1) / k, t); });
-        f((int64_t)0, n / k, 0);
-        for (auto &x : th) x.join();
+        par_jobs(k, [&f, n, k](int t) { f(n * t / k, n * (t + 1) / k, t); });
     }
     int ranges(int64_t n, int64_t min_per_thread = 4096) const {
         return (int)std::max<int64_t>(1, std::min<int64_t>(nt, n / std::max<int64_t>(grain(min_per_thread), 1)));
@@ -66,24 +90,16 @@ struct Par {
         if (k == 1) { std::sort(v.begin(), v.end(), less); return; }
         std::vector<int64_t> cut(k + 1);
         for (int i = 0; i <= k; ++i) cut[i] = n * i / k;
-        {
-            std::vector<std::thread> th;
-            for (int i = 1; i < k; ++i) th.emplace_back([&, i]() { std::sort(v.begin() + cut[i], v.begin() + cut[i + 1], less); });
-            std::sort(v.begin() + cut[0], v.begin() + cut[1], less);
-            for (auto &x : th) x.join();
-        }
+        par_jobs(k, [&](int i) { std::sort(v.begin() + cut[i], v.begin() + cut[i + 1], less); });
         std::vector<R> tmp(v.size());
         std::vector<R> *src = &v, *dst = &tmp;
         for (int w = 1; w < k; w *= 2) {
-            std::vector<std::thread> th;
-            for (int i = 0; i < k; i += 2 * w) {
+            const int nm = (k + 2 * w - 1) / (2 * w);          // merges of this level
+            par_jobs(nm, [&, w](int q) {
+                const int i = 2 * w * q;
                 const int64_t a = cut[i], b = cut[std::min(i + w, k)], c = cut[std::min(i + 2 * w, k)];
-                auto job = [src, dst, a, b, c, &less]() {
-                    std::merge(src->begin() + a, src->begin() + b, src->begin() + b, src->begin() + c, dst->begin() + a, less);
-                };
-                if (i + 2 * w < k) th.emplace_back(job); else job();
-            }
-            for (auto &x : th) x.join();
+                std::merge(src->begin() + a, src->begin() + b, src->begin() + b, src->begin() + c, dst->begin() + a, less);
+            });
             std::swap(src, dst);
         }
         if (src != &v) v.swap(tmp);

@@ -53,6 +53,18 @@ def test_unknown_or_measurement_environment_switch_is_refused(monkeypatch):
         monkeypatch.delenv(name)
     monkeypatch.setenv('DBAT_HIP_SIG', '0')           # a product switch
     assert _hip.plan(s)['n'] > 0
+    monkeypatch.delenv('DBAT_HIP_SIG')
+    # ... and a VALUE the library would not honour is refused like a misspelt name (GIANT_THREADS documented
+    # 64 | 128 | 256, and anything but 64 / 128 was silently ignored)
+    for name, bad, good in (('DBAT_HIP_GIANT_THREADS', '100', '256'), ('DBAT_HIP_BT', '64', '128'), ('DBAT_HIP_SIG', 'on', '2'),
+                            ('DBAT_HIP_DF_CHAIN', '2', '0')):
+        monkeypatch.setenv(name, bad)
+        with pytest.raises(_hip.DbatHipError) as e:
+            _hip.plan(s)
+        assert e.value.code == _hip.EINVAL and 'not one of' in str(e.value) and name in str(e.value)
+        monkeypatch.setenv(name, good)
+        assert _hip.plan(s)['n'] > 0
+        monkeypatch.delenv(name)
 
 
 def test_default_options_match_bundle_m():
