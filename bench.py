@@ -9,7 +9,7 @@ in HBM before the timed region.
 
     python bench.py --gpus N --steps K --warmup W [--config C3]
 
---config roma | roma-selfcal | camcal: the reference's own demo projects (bench/real_scenes.py, fixtures under
+--config roma | roma-selfcal | camcal | sxb: the reference's own demo projects (bench/real_scenes.py, fixtures under
 tests/golden) -- the scenes DBAT's only published timings are quoted on; the line then also carries the
 shipped dbat_hip_solve with the demo's damping next to the published MATLAB figure.
 
@@ -178,7 +178,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-solve', action='store_true', help='skip the timed dbat_hip_solve run (LM; LM-Powell for C1, as BASELINE.json quotes it)')
     ap.add_argument('--deterministic', action='store_true',
-                    help='fixed-order sums into the reduced system (dbat_hip_set_deterministic: bit-identical runs); reports what that costs')
+                    help='exact (order-independent) sums into the reduced system (dbat_hip_set_deterministic: bit-identical runs); reports what that costs')
     ap.add_argument('--no-one-gpu-ref', action='store_true',
                     help='N > 1: skip rank 0\'s one-GPU run of the same scene after the timed region (multi_gpu.one_gpu)')
     ap.add_argument('--emulate-ranks', type=int, default=0, metavar='R',
@@ -228,7 +228,7 @@ def main():
 
     t_gen = time.perf_counter()
     published = None
-    real = args.config in ('roma', 'roma-selfcal', 'camcal')
+    real = args.config in ('roma', 'roma-selfcal', 'camcal', 'sxb')
     if real:
         sys.path.insert(0, os.path.join(ROOT, 'bench'))
         import real_scenes

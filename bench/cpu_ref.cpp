@@ -25,7 +25,10 @@
 // The per-observation model is the closed form of dbat_amd/csrc/model.hpp (also
 // compiled for the host); unknown ordering and sharing follow
 // misc/buildserialindices.m:57,108-128,162-221 (x = [IO; EO; OP], column-major,
-// shared block parameters once).  No prior observations (the benchmark scenes have none).
+// shared block parameters once).  Prior observations (lsa/prior_obs.m:45-72: rows x(dest) - prior.val(src) with a
+// selection matrix as Jacobian, weighted by 1/std, misc/buildweightmatrix.m:25-29) are the rows of J below the image
+// rows -- one entry each, kept as (column, weight, value) triplets: [IO priors; EO priors; OP priors], as
+// buildserialindices.m:151-159 orders them.
 #include <omp.h>
 
 #include <algorithm>
@@ -54,6 +57,9 @@ struct cpuref_problem {
     const double *OP;            // 3 x np
     const uint8_t *estIO, *estEO, *estOP;
     const int32_t *IOblock;      // nIOrows x nc
+    // prior observations (all three may be null): use flags, values and standard deviations, shaped as IO / EO / OP
+    const uint8_t *useIO, *useEO, *useOP;
+    const double *priorIO, *priorEO, *priorOP, *stdIO, *stdEO, *stdOP;
 };
 }
 
@@ -81,7 +87,12 @@ struct Ref {
     std::vector<int8_t> ocnt;
     std::vector<int64_t> oslot;                 // [no][MAXC] slot of row 2o in column ocol
     std::vector<int64_t> ocol;                  // [no][MAXC] x index
-    std::vector<double> r;                      // weighted residual (2*no)
+    std::vector<double> r;                      // weighted residual (2*no image rows, then the prior rows)
+    // prior observation rows: x index, 1/std, prior value (row 2*no + k of J has the single entry pr_w[k] in column pr_col[k])
+    std::vector<int64_t> pr_col;
+    std::vector<double> pr_w, pr_val;
+    std::vector<int64_t> pr_ptr;                // per x index: its prior rows (CSR over the unknowns; empty without priors)
+    std::vector<int64_t> pr_rows;
     // elimination order: q[x index] = position; points first, then EO, then IO
     std::vector<int64_t> q, qinv;
     // N = J'J + lambda I, lower triangle in elimination order, CSC
@@ -145,8 +156,14 @@ static double residual_jacobian(Ref &R, const double *x, bool jac, std::vector<d
     std::vector<CamRec> cams((size_t)R.nc);
 #pragma omp parallel for schedule(static) num_threads(R.nthreads)
     for (int c = 0; c < R.nc; ++c) cam_record(R, IOv.data(), EOv.data(), c, cams[c]);
-    rout.resize((size_t)2 * R.no);
+    const int64_t npr = (int64_t)R.pr_col.size();
+    rout.resize((size_t)2 * R.no + npr);
     double f = 0;
+    for (int64_t k = 0; k < npr; ++k) {                      // prior_obs.m:45-72, weighted
+        const double v = R.pr_w[k] * (x[R.pr_col[k]] - R.pr_val[k]);
+        rout[(size_t)2 * R.no + k] = v;
+        f += v * v;
+    }
 #pragma omp parallel for schedule(static) reduction(+ : f) num_threads(R.nthreads)
     for (int64_t o = 0; o < R.no; ++o) {
         const int c = R.cam[o], p = R.pt[o];
@@ -202,6 +219,15 @@ static bool setup(Ref &R) {
     R.n = R.nIO + R.nEO + R.nOP;
     R.NS = R.nIO + R.nEO;
     if (R.n >= (int64_t)1 << 31) { R.err = "too many unknowns for 32-bit row indices"; return false; }
+    // ---- the unknowns with a prior observation each own one row per use of theirs
+    R.pr_ptr.assign((size_t)R.n + 1, 0);
+    for (int64_t k = 0; k < (int64_t)R.pr_col.size(); ++k) ++R.pr_ptr[R.pr_col[k] + 1];
+    for (int64_t j = 0; j < R.n; ++j) R.pr_ptr[j + 1] += R.pr_ptr[j];
+    R.pr_rows.resize(R.pr_col.size());
+    {
+        std::vector<int64_t> fill(R.pr_ptr.begin(), R.pr_ptr.end() - 1);
+        for (int64_t k = 0; k < (int64_t)R.pr_col.size(); ++k) R.pr_rows[fill[R.pr_col[k]]++] = k;
+    }
     // ---- weights (buildweightmatrix.m:20): sigma[mm] = IP.std[px] * pxSize
     // (R.w holds IP.std on entry)
     for (int64_t o = 0; o < R.no; ++o) {
@@ -380,6 +406,7 @@ static double spgemm_JtJ(Ref &R, double lambda) {
                     if (iq >= jq) acc[iq] += v0 * R.Jx[slot[k]] + v1 * R.Jx[slot[k] + 1];
                 }
             }
+            for (int64_t e = R.pr_ptr[j]; e < R.pr_ptr[j + 1]; ++e) { const double w = R.pr_w[R.pr_rows[e]]; acc[jq] += w * w; }   // single-entry rows
             trace += acc[jq];
             acc[jq] += lambda;
             for (int64_t s = R.Np[jq]; s < R.Np[jq + 1]; ++s) { R.Nx[s] = acc[R.Ni[s]]; acc[R.Ni[s]] = 0.0; }
@@ -647,6 +674,21 @@ cpuref_handle *cpuref_create(const cpuref_problem *pb, int32_t nthreads, double 
     R.estOP.assign(pb->estOP, pb->estOP + (size_t)3 * R.np);
     R.IOblock.assign(pb->IOblock, pb->IOblock + (size_t)R.nIOrows * R.nc);
     const auto t0 = clk::now();
+    {   // prior observations of estimated parameters (bundle.m:137-154 drops the others); the x index of an entry is known
+        // after the index maps exist, so they are built here first (setup() rebuilds the same maps)
+        std::vector<int64_t> io, eo, op, src;
+        const int64_t nIO = serial_indices(R.nIOrows, R.nc, R.estIO.data(), R.IOblock.data(), 0, io, &src);
+        const int64_t nEO = serial_indices(6, R.nc, R.estEO.data(), nullptr, nIO, eo, nullptr);
+        serial_indices(3, R.np, R.estOP.data(), nullptr, nIO + nEO, op, nullptr);
+        auto collect = [&](const uint8_t *use, const double *val, const double *sd, const std::vector<int64_t> &ix) {
+            if (!use || !val || !sd) return;
+            for (size_t e = 0; e < ix.size(); ++e)
+                if (use[e] && ix[e] >= 0) { R.pr_col.push_back(ix[e]); R.pr_w.push_back(1.0 / sd[e]); R.pr_val.push_back(val[e]); }
+        };
+        collect(pb->useIO, pb->priorIO, pb->stdIO, io);
+        collect(pb->useEO, pb->priorEO, pb->stdEO, eo);
+        collect(pb->useOP, pb->priorOP, pb->stdOP, op);
+    }
     if (!setup(R)) return nullptr;
     if (setup_ms) *setup_ms = ms_since(t0);
     return h.release();
@@ -658,7 +700,7 @@ int32_t cpuref_num_threads(const cpuref_handle *h) { return h ? h->R.nthreads : 
 int64_t cpuref_nnz(const cpuref_handle *h, int32_t which) {
     if (!h) return -1;
     const Ref &R = h->R;
-    return which == 0 ? (int64_t)R.Jx.size() : which == 1 ? (int64_t)R.Nx.size() : (int64_t)R.LR.size() + R.NS * (R.NS + 1) / 2;
+    return which == 0 ? (int64_t)(R.Jx.size() + R.pr_col.size()) : which == 1 ? (int64_t)R.Nx.size() : (int64_t)R.LR.size() + R.NS * (R.NS + 1) / 2;
 }
 
 // serialize.m:14-18
@@ -698,6 +740,7 @@ int32_t cpuref_lm_step(cpuref_handle *h, const double *x, double lambda, double 
     for (int64_t j = 0; j < R.n; ++j) {
         double s = 0;
         for (int64_t k = R.Jp[j]; k < R.Jp[j + 1]; ++k) s += R.Jx[k] * R.r[R.Ji[k]];
+        for (int64_t e = R.pr_ptr[j]; e < R.pr_ptr[j + 1]; ++e) s += R.pr_w[R.pr_rows[e]] * R.r[(size_t)2 * R.no + R.pr_rows[e]];
         R.b[R.q[j]] = -s;
     }
     const double ms_jtr = ms_since(t0);
@@ -726,7 +769,8 @@ int32_t cpuref_lm_step(cpuref_handle *h, const double *x, double lambda, double 
 int32_t cpuref_step_norms(const cpuref_handle *h, const double *v, double *out3) {
     if (!h || !v || !out3) return -1;
     const Ref &R = h->R;
-    std::vector<double> Jv((size_t)2 * R.no, 0.0);
+    std::vector<double> Jv((size_t)2 * R.no + R.pr_col.size(), 0.0);
+    for (size_t k = 0; k < R.pr_col.size(); ++k) Jv[(size_t)2 * R.no + k] = R.pr_w[k] * v[R.pr_col[k]];
     double vv = 0;
     for (int64_t j = 0; j < R.n; ++j) {              // column sweep (serial: columns share rows)
         vv += v[j] * v[j];

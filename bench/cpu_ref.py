@@ -14,7 +14,8 @@ _lib = None
 class _Problem(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ('nc', 'np', 'no', 'nIOrows', 'model', 'nK', 'nP', 'reserved')] + \
                [(k, C.c_void_p) for k in ('cam', 'pt', 'uv', 'std', 'px', 'IO', 'EO', 'OP',
-                                          'estIO', 'estEO', 'estOP', 'IOblock')]
+                                          'estIO', 'estEO', 'estOP', 'IOblock', 'useIO', 'useEO', 'useOP',
+                                          'priorIO', 'priorEO', 'priorOP', 'stdIO', 'stdEO', 'stdOP')]
 
 
 def load():
@@ -43,16 +44,13 @@ def load():
 
 
 class CpuRef:
-    """One problem (a DBAT struct without prior observations) on the CPU."""
+    """One problem (a DBAT struct; prior observations of estimated parameters are rows of J, lsa/prior_obs.m:45-72) on the CPU."""
 
     PHASES = ('residual_jacobian', 'JtJ', 'Jtr', 'chol_leaves', 'chol_root_update', 'chol_root', 'solve',
               'trial_residual')
 
     def __init__(self, s, threads=0):
         lib = load()
-        for nm in ('IO', 'EO', 'OP'):
-            if np.any(np.asarray(getattr(s.prior, nm).use, bool) & np.asarray(getattr(s.bundle.est, nm), bool)):
-                raise ValueError('the CPU baseline does not model prior observations')
         f64 = lambda a: np.ascontiguousarray(np.asarray(a, np.float64).flatten('F'))
         u8 = lambda a: np.ascontiguousarray(np.asarray(a, bool).flatten('F').astype(np.uint8))
         i32 = lambda a: np.ascontiguousarray(np.asarray(a).flatten('F').astype(np.int32))
@@ -60,6 +58,13 @@ class CpuRef:
                           px=f64(s.IO.sensor.pxSize[0]), IO=f64(s.IO.val), EO=f64(s.EO.val[:6]), OP=f64(s.OP.val),
                           estIO=u8(s.bundle.est.IO), estEO=u8(np.asarray(s.bundle.est.EO)[:6]),
                           estOP=u8(s.bundle.est.OP), IOblock=i32(s.IO.struct.block))
+        nz = lambda a: np.nan_to_num(np.asarray(a, np.float64))
+        for nm, rows in (('IO', slice(None)), ('EO', slice(0, 6)), ('OP', slice(None))):
+            pr = getattr(s.prior, nm)
+            use = np.asarray(pr.use, bool)[rows] & np.asarray(getattr(s.bundle.est, nm), bool)[rows]
+            self._keep['use' + nm] = u8(use)
+            self._keep['prior' + nm] = f64(nz(pr.val)[rows])
+            self._keep['std' + nm] = f64(np.where(use, nz(pr.std)[rows], 1.0))
         pb = _Problem()
         pb.nc, pb.np, pb.no = s.EO.val.shape[1], s.OP.val.shape[1], s.IP.val.shape[1]
         pb.nIOrows, pb.nK, pb.nP = s.IO.val.shape[0], int(s.IO.model.nK), int(s.IO.model.nP)

@@ -10,6 +10,10 @@ product's loaders and the device's initial-value stage only (no oracle import he
                 EO by 3-point resection, OP by forward intersection (on the device: dbat_amd.initial)
                 data/dbat/dbatexports/camcal-dbatreport.txt:23-24,39-45    GNA, 9 iterations, 1.17 s
 
+  sxb           data/script/sxb/sxb.xml             5 aerial images / 2 434 observations, fixed camera, 14 control points as
+                weighted PRIOR OBSERVATIONS (42 rows of J below the image rows, lsa/prior_obs.m:45-72), project
+                coordinates of 1e6 m; data/script/sxb/result/report.txt:20,41-45   GNA, 4 iterations, 0.07 s
+
 (host 'slartibartfast', MATLAB R2020a, CPU model and core count not recorded: SURVEY 6.)
 """
 import json
@@ -27,6 +31,8 @@ PUBLISHED = {
                      'source': 'data/dbat/dbatexports/roma-dbatreport-selfcal.txt:46 (demo/romabundledemo_selfcal.m)'},
     'camcal': {'damping': 'gna', 'iterations': 9, 'bundle_s': 1.17, 'sigma0': 1.6148,
                'source': 'data/dbat/dbatexports/camcal-dbatreport.txt:23-24,39-45 (demo/camcaldemo.m:119)'},
+    'sxb': {'damping': 'gna', 'iterations': 4, 'bundle_s': 0.07, 'sigma0': 1.1786,
+            'source': 'data/script/sxb/result/report.txt:20,41-45 (script/parseops.m:36-59 on data/script/sxb/sxb.xml)'},
 }
 
 
@@ -72,6 +78,31 @@ def _camcal():
     return I.forwintersect(s, 'all', True)                  # camcaldemo.m:107
 
 
+def _sxb():
+    """data/script/sxb/sxb.xml with the product's loaders: initial values by dbat_hip_resect / dbat_hip_forwintersect."""
+    from dbat_amd import initial as I
+    from dbat_amd import loadpm as L
+    from dbat_amd import loadtables as T
+    with open(os.path.join(GOLDEN, 'sxb_expected.json')) as fh:
+        exp = json.load(fh)
+    cam = exp['camera']
+    pts = L.loadcpt(os.path.join(GOLDEN, 'sxb-control.txt'))
+
+    def pick(keep):
+        m = np.isin(pts['id'], exp['check_ids']) == keep
+        return dict(id=pts['id'][m], name=[n for n, k in zip(pts['name'], m) if k], pos=pts['pos'][:, m], std=pts['std'][:, m])
+    io = T.camera_io(cam['cc'], cam['pp'], cam['K'], cam['P'])
+    marks = [(T.load_table(os.path.join(GOLDEN, 'sxb-%s.txt' % nm)), 'id,im,x,y', exp['sxy'][nm]) for nm in ('markpts', 'smartpts')]
+    s = T.struct_from_script(io, cam['sensor'], cam['image'], exp['images'], marks, pick(False), pick(True),
+                             distModel=cam['model'], im_names=exp['image_paths'])
+    s = T.set_script_defaults(s)
+    cp = s.OP.id[s.prior.OP.isCtrl]
+    s, rms, fail = I.resect(s, 'all', cp, 1, 0, cp)         # spatial_resection (script/parseops.m:36-43)
+    if fail:
+        raise RuntimeError('sxb: resection failed')
+    return I.forwintersect(s, 'all', True)
+
+
 def make(name):
     """(DBAT struct, published record) of one of the reference's demo projects."""
     if name == 'roma':
@@ -80,4 +111,6 @@ def make(name):
         return _roma(True), PUBLISHED[name]
     if name == 'camcal':
         return _camcal(), PUBLISHED[name]
+    if name == 'sxb':
+        return _sxb(), PUBLISHED[name]
     raise KeyError(name)

@@ -377,7 +377,8 @@ class Handle:
         return out.reshape(3, -1, order='F')
 
     def set_deterministic(self, on=True):
-        """Fixed-order sums into the reduced system (bit-identical runs); DbatHipError(EUNSUPPORTED) off the signature path."""
+        """Exact (order-independent) sums into the reduced system: bit-identical runs.  DbatHipError(EUNSUPPORTED) for
+        several ranks, shared EO blocks or more than nine IO columns per camera."""
         check(self.lib.dbat_hip_set_deterministic(self.h, int(bool(on))))
 
     def build_kernel_name(self):

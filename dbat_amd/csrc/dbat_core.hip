@@ -114,8 +114,8 @@ struct Core {
     DevBuf<double> io_fixed, px, cam_w, z_prw, z_prv, o_uv, o_w;
     // deterministic mode (dbat_hip_set_deterministic): ticket counters and the turn of every tile / chunk at them
     bool deterministic = false;
-    DevBuf<unsigned> det_ctr;           // [nc | nc | 2]
-    DevBuf<int32_t> tile_cam_seq, tile_io_seq, cm_chunk_seq;
+    DevBuf<double> det_cam_part, det_io_part, det_rr, det_u;      // kernels.hpp DevProblem::deterministic
+    DevBuf<int32_t> det_cam_chunks;
     DevBuf<double> o_rhs;               // fixed IO: the corrected image coordinates (k_uv_to_rhs), what d.o_uv points at
     bool uv_pre = false;
     DevBuf<uint8_t> z_est, z_mine, o_lc, o_pidx;
@@ -253,8 +253,7 @@ struct Core {
         d.o_cam = o_cam.p; d.o_pt = o_pt.p; d.o_uv = o_uv.p; d.o_w = P.uniform_w ? nullptr : o_w.p;
         d.o_seg = o_seg.p; d.o_row = o_row.p; d.batch_start = batch_start.p;
         d.CMAX = P.CMAX; d.ablate = env_int("DBAT_HIP_ABLATE", 0); d.trace_only = 0;
-        d.deterministic = 0; d.det_cam_turn = d.det_cm_turn = d.det_io_turn = d.det_timeouts = nullptr;
-        d.tile_cam_seq = d.tile_io_seq = d.cm_chunk_seq = nullptr;
+        d.deterministic = 0; d.det_cam_part = d.det_io_part = d.det_rr = d.det_u = nullptr; d.det_cam_chunks = nullptr;
         env_df_trace = env_get("DBAT_HIP_DF_TRACE");
         d.ntiles = (int)ntiles; d.o_lc = o_lc.p; d.o_pidx = o_pidx.p;
         tile_order.upload(P.tile_order); d.tile_order = tile_order.p;
@@ -599,49 +598,62 @@ struct Core {
         return 0.5 * s;
     }
 
-    // Deterministic mode: sums into the reduced system in a fixed order (kernels.hpp DevProblem::deterministic).
-    // Covered: the signature-group path with its camera-side kernels, the factorisation and the back-substitution
-    // (the latter two are order-fixed by construction).  Not covered: heavy / giant points and the tile kernels of
-    // irregular scenes (LDS and global atomics per observation), several ranks.
-    bool deterministic_supported() const {
-        return use_sig && ntiles > 0 && nb == P.nb_tiled && ngiant == 0 && P.nranks == 1 && tile_ncx <= 14;
-    }
+    // Deterministic mode: exact sums into the reduced system (kernels.hpp DevProblem::deterministic).  Covered: the
+    // signature-group path with its camera-side kernels (C1 ... C4); the factorisation and the back-substitution are
+    // order-fixed by construction.  Not covered yet: heavy / giant points and the tile kernels of irregular scenes
+    // (per-point sums by LDS atomics), shared EO blocks, several ranks.
+    // Every scene on one rank whose cameras have at most nine IO columns and own EO elements: the signature-group path keeps
+    // its tile kernel (C1 ... C4: + 4 % at C3); scenes with irregular visibility (the reference's own projects) run the
+    // column-list kernel k_build over ALL their batches instead of the wave-specialised tile kernels, whose per-point sums
+    // are LDS atomics from several waves.
+    int det_ncx() const { return P.ncolmax <= 6 ? 6 : (P.ncolmax <= 14 ? 14 : 15); }
+    bool deterministic_supported() const { return P.nranks == 1 && !P.shared_eo && P.ncolmax <= 15 && n_cm_chunks_all > 0; }
     void set_deterministic(bool on) {
         if (on && !deterministic_supported())
-            throw UsageError{"deterministic mode covers the signature-group path on one rank (no heavy or giant points, no irregular-visibility tile kernels)"};
-        if (on && !det_ctr.p) {
+            throw UsageError{"deterministic mode: one rank, no shared EO blocks (camera stations), at most nine estimated IO columns per camera"};
+        if (on && !det_u.p) {
             const int nc = P.nc;
-            det_ctr.alloc((size_t)2 * nc + 3);
-            std::vector<int32_t> cs(P.tile_cams.size(), 0), ios((size_t)ntiles, -1), cnt((size_t)nc, 0);
-            int32_t io_n = 0;
-            for (int64_t i = 0; i < ntiles; ++i) {              // launch order
-                const int32_t t = P.tile_order[i];
-                for (int32_t l = P.tile_cam_start[t]; l < P.tile_cam_start[t + 1]; ++l) cs[l] = cnt[P.tile_cams[l]]++;
-                if (tile_ncx > 6 && P.tile_io_start[t + 1] > P.tile_io_start[t]) ios[t] = io_n++;
-            }
-            std::vector<int32_t> qs((size_t)n_cm_chunks_all, 0);
-            if (tile_ncx > 6) { for (int64_t q = 0; q < n_cm_chunks_all; ++q) qs[q] = (int32_t)q; }   // shared IO rows: one global order
-            else {
-                int64_t first = 0;
-                for (int64_t q = 0; q < n_cm_chunks_all; ++q) {
-                    if (q > 0 && P.cm_chunk_cam[q] != P.cm_chunk_cam[q - 1]) first = q;
-                    if (q == n_cm_chunks) first = q;                        // (the untiled part starts over; it is not used here)
-                    qs[q] = (int32_t)(q - first);
+            det_cam_part.alloc((size_t)std::max<int64_t>(n_cm_chunks_all, 1) * DET_CP);
+            det_io_part.alloc((size_t)nc * DET_IOP);
+            det_rr.alloc((size_t)nc + 1);
+            det_u.alloc((size_t)P.NS + 1);
+            // chunk ranges of every camera in the camera-major copy: its tiled chunks [2c, 2c+1), then -- offset 2 nc + 1 --
+            // its untiled ones (both parts are sorted by camera)
+            std::vector<int32_t> cr((size_t)2 * (2 * nc + 1), 0);
+            for (int part = 0; part < 2; ++part) {
+                const int64_t q0 = part == 0 ? 0 : n_cm_chunks, q1 = part == 0 ? n_cm_chunks : n_cm_chunks_all;
+                int32_t *r = cr.data() + part * (2 * nc + 1);
+                for (int c = 0; c < nc; ++c) { r[2 * c] = (int32_t)q1; r[2 * c + 1] = (int32_t)q1; }
+                for (int64_t q = q0; q < q1; ++q) {
+                    const int c = P.cm_chunk_cam[q];
+                    if (r[2 * c] == (int32_t)q1) r[2 * c] = (int32_t)q;
+                    r[2 * c + 1] = (int32_t)q + 1;
                 }
+                for (int c = 0; c < nc; ++c) if (r[2 * c] == (int32_t)q1) r[2 * c + 1] = (int32_t)q1;   // (a camera without chunks: empty range)
             }
-            tile_cam_seq.upload(cs); tile_io_seq.upload(ios); cm_chunk_seq.upload(qs);
+            det_cam_chunks.upload(cr);
         }
         deterministic = on;
         d.deterministic = on ? 1 : 0;
-        d.det_cam_turn = det_ctr.p; d.det_cm_turn = det_ctr.p ? det_ctr.p + P.nc : nullptr; d.det_io_turn = det_ctr.p ? det_ctr.p + 2 * (size_t)P.nc : nullptr;
-        d.det_timeouts = det_ctr.p ? det_ctr.p + 2 * (size_t)P.nc + 2 : nullptr;
-        d.tile_cam_seq = tile_cam_seq.p; d.tile_io_seq = tile_io_seq.p; d.cm_chunk_seq = cm_chunk_seq.p;
+        d.det_cam_part = det_cam_part.p; d.det_io_part = det_io_part.p; d.det_rr = det_rr.p; d.det_u = det_u.p;
+        d.det_cam_chunks = det_cam_chunks.p;
+    }
+    // the camera side of a deterministic linearisation, after the camera-major kernel has left its chunk partials
+    void det_camera_side() {
+        const int nio = (int)P.nIOu;
+        const int ncx = det_ncx();
+#define L_DCR(NCXV) LAUNCHK((k_det_cam_reduce<NCXV>), dim3((unsigned)P.nc), dim3(256), 0, stream, d, cams.p, S, g_c, g_red, diagU)
+        if (ncx == 6) L_DCR(6); else if (ncx == 14) L_DCR(14); else L_DCR(15);
+#undef L_DCR
+        if (ncx > 6 && nio > 0) LAUNCHK((k_det_io_reduce<15>), dim3((unsigned)(nio * (nio + 1) / 2 + nio)), dim3(256), 0, stream, d, cams.p, nio, S, g_c, g_red, diagU);
+        LAUNCHK(k_det_rows, dim3((unsigned)cdiv(P.NS, 256)), dim3(256), 0, stream, d, (const double *)diagU);
+        if (ncx == 6) LAUNCHK((k_det_round_cam<6>), dim3((unsigned)P.nc), dim3(256), 0, stream, d, cams.p, 0, S, g_red);
+        else LAUNCHK((k_det_round_cam<15>), dim3((unsigned)P.nc + 1), dim3(256), 0, stream, d, cams.p, nio, S, g_red);
     }
 
     // ---- K1: linearise at zz with damping lambda; builds the reduced system.
     void build_enqueue(const double *zz, double lambda, int scale) {
         stage(0);
-        if (deterministic) HIPCHK(hipMemsetAsync(det_ctr.p, 0, ((size_t)2 * P.nc + 3) * sizeof(unsigned), stream));
         const bool fused_first = !s_dense_dirty && P.NS >= P.nc;
         if (!fused_first) prep_cams(zz);
         else cams_at_lin = false;
@@ -661,12 +673,24 @@ struct Core {
         // tiled batches through the MFMA kernel, the remaining ("heavy point") batches
         // -- or all of them when tiling is off -- through k_build
         int64_t npart = 0;
-        const int64_t nb_tiled = P.nb_tiled;
+        // deterministic mode off the signature path: no tile kernel, k_build takes every batch
+        const bool det_list = deterministic && !(use_sig && ntiles > 0 && P.nb_tiled > 0);
+        const int64_t nb_tiled = det_list ? 0 : P.nb_tiled;
+        if (deterministic) {
+            // the camera side of EVERY observation (tiled or not) from the camera-major kernels, chunk partials summed in order
+#define L_CAMN_ALL(M, NCXV) LAUNCHK((k_cam_normal<M, NCXV>), dim3((unsigned)n_cm_chunks_all), dim3(256), 0, stream, d, zz, cams.p, cm_pt.p, cm_uv.p, P.uniform_w ? (const double *)nullptr : cm_w.p, cm_chunk_cam.p, cm_chunk_start.p, S, g_c, g_red, diagU)
+#define L_CAMN6_ALL(M, dummy) LAUNCHK((k_cam_normal6<M>), dim3((unsigned)n_cm_chunks_all), dim3(256), 0, stream, d, zz, cams.p, cm_pt.p, cm_uv.p, P.uniform_w ? (const double *)nullptr : cm_w.p, cm_chunk_cam.p, cm_chunk_start.p, S, g_c, g_red, diagU)
+            const int ncx = det_ncx();
+            if (ncx == 6) { DISPATCH_MODEL(L_CAMN6_ALL, 0) } else if (ncx == 14) { DISPATCH_MODEL(L_CAMN_ALL, 14) } else { DISPATCH_MODEL(L_CAMN_ALL, 15) }
+#undef L_CAMN_ALL
+#undef L_CAMN6_ALL
+            det_camera_side();
+        }
         if (ntiles > 0 && nb_tiled > 0) {
             npart = ntiles;
 #define L_TILE2(M, NCXV) LAUNCHK((k_build_tile2<M, NCXV, TILE2_PC, TILE2_NBUF>), dim3((unsigned)ntiles), dim3(512), lds_tile2, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, partial.p, pivmm.p)
 #define L_CAMN(M, NCXV) LAUNCHK((k_cam_normal<M, NCXV>), dim3((unsigned)n_cm_chunks), dim3(256), 0, stream, d, zz, cams.p, cm_pt.p, cm_uv.p, P.uniform_w ? (const double *)nullptr : cm_w.p, cm_chunk_cam.p, cm_chunk_start.p, S, g_c, g_red, diagU)
-            if (use_tile2 && tile_ncx <= 15 && n_cm_chunks > 0) {
+            if (!deterministic && use_tile2 && tile_ncx <= 15 && n_cm_chunks > 0) {
                 // camera side of the tiled observations: J_c'J_c, J_c'r, squared column norms
 #define L_CAMN6(M, dummy) LAUNCHK((k_cam_normal6<M>), dim3((unsigned)n_cm_chunks), dim3(256), 0, stream, d, zz, cams.p, cm_pt.p, cm_uv.p, P.uniform_w ? (const double *)nullptr : cm_w.p, cm_chunk_cam.p, cm_chunk_start.p, S, g_c, g_red, diagU)
                 if (tile_ncx == 6) { DISPATCH_MODEL(L_CAMN6, 0) } else if (tile_ncx == 14) { DISPATCH_MODEL(L_CAMN, 14) } else { DISPATCH_MODEL(L_CAMN, 15) }
@@ -689,6 +713,8 @@ struct Core {
 #undef L_TILE2
         }
         const bool no_tiles = !(ntiles > 0 && nb_tiled > 0);
+        const int64_t ntiles_run = no_tiles ? 0 : ntiles;      // (deterministic mode may have left the tiles out)
+        (void)ntiles_run;
         if (no_tiles) mark(0);                       // no tile kernel: the events bracket k_build instead
         if (nb > nb_tiled) {
 #define L_BUILD(M, IO) LAUNCHK((k_build<M, IO>), dim3((unsigned)(nb - nb_tiled)), dim3(P.BT), lds_build, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, partial.p + npart, pivmm.p, (int)nb_tiled)
@@ -916,11 +942,6 @@ struct Core {
             mb_armed = true;
             sync();
             memcpy(h.data(), hpin, 8 * sizeof(double));
-        }
-        if (deterministic) {     // a ticket wait that gave up: the sums are incomplete (never seen; the cap exists so that it would be)
-            unsigned tmo = 0;
-            HIPCHK(hipMemcpy(&tmo, det_ctr.p + 2 * (size_t)P.nc + 2, sizeof(tmo), hipMemcpyDeviceToHost));
-            if (tmo) throw DeviceError{"deterministic mode: a ticket wait timed out"};
         }
         memcpy(hmm, hpin + 40, sizeof(hmm));
         memcpy(&hinfo, hpin + 44, sizeof(hinfo));

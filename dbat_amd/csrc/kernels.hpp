@@ -56,16 +56,23 @@ struct DevProblem {
     int CMAX, ntiles;
     int ablate;                     // measurement builds only (DBAT_HIP_ABLATE, read through DBAT_ABLATE): phases off, phase clocks
     int trace_only;                 // this linearisation serves trace(J'J) alone (levenberg_marquardt.m:88-95): no Schur complement
-    // deterministic mode (dbat_hip_set_deterministic): every sum into S / g_red / g_c / diagU is made in a FIXED order,
-    // so that two runs give the same bits.  Tickets: a tile waits until every one of its cameras has seen all the
-    // earlier tiles (launch order) that contain it; a camera-major chunk waits for the camera's earlier chunks;
-    // whatever touches the shared IO rows goes through one global ticket.
+    // deterministic mode (dbat_hip_set_deterministic): two runs give the same bits.  No ordering of the atomics -- the sums
+    // are made EXACT instead, and exact sums do not depend on their order:
+    //   * the camera side (J_c'J_c, J_c'r, the squared column norms) leaves one partial per camera-major chunk and is
+    //     summed camera by camera in chunk order (k_det_cam_reduce, k_det_io_reduce);
+    //   * from the column norms every row r of the reduced system gets a power of two u_r >= sqrt(U_rr), and element
+    //     (i, j) the grid q_ij = u_i u_j 2^-51.  Every contribution to the Schur complement is a piece of a Gram matrix
+    //     whose diagonal is bounded by U (W V^-1 W' <= U), so |sum of the absolute contributions to (i, j)| <= u_i u_j
+    //     (Cauchy-Schwarz): rounded to multiples of q_ij they add up without any rounding -- in LDS and in HBM, by the
+    //     same atomics as in the default mode.  The right-hand side likewise with u_i u_f, u_f^2 >= r'r.
+    //   The rounding is half a unit in the last place of the BOUND of an element, where an ordinary sum rounds to half a
+    //   unit of the running sum: the result differs from the default mode's by a few 1e-16 of sqrt(S_ii S_jj).
     int deterministic;
-    unsigned *det_cam_turn, *det_cm_turn, *det_io_turn;   // [nc], [nc], [2] counters, zero at the start of a build
-    unsigned *det_timeouts;         // waits that gave up (the host turns a non-zero count into an error)
-    const int32_t *tile_cam_seq;    // [#tile cams] what det_cam_turn must show before the tile may add
-    const int32_t *tile_io_seq;     // [ntiles]     ... det_io_turn[0] (-1: the tile has no IO rows)
-    const int32_t *cm_chunk_seq;    // [chunks]     ... det_cm_turn[camera] (fixed IO) / det_io_turn[1] (self-calibration)
+    double *det_cam_part;           // [camera-major chunks][DET_CP] the chunks' Gram matrices
+    double *det_io_part;            // [nc][DET_IOP] self-calibration: the cameras' IO x IO blocks and IO gradient entries
+    double *det_rr;                 // [nc] r'r of the cameras' observations; [nc]: their sum
+    double *det_u;                  // [NS + 1] u_r; [NS] = u_f
+    const int32_t *det_cam_chunks;  // [2 nc + 2] chunk ranges of every camera: tiled part, untiled part (camera-major copy)
     const uint8_t *o_lc, *o_pidx;
     const int32_t *tile_batch, *tile_cam_start, *tile_cams;
     const int32_t *tile_order;                      // launch index -> tile (longest first)
@@ -89,18 +96,23 @@ __device__ __forceinline__ void atomic_add_f64(double *p, double v) {
     unsafeAtomicAdd(p, v);          // global_atomic_add_f64 / ds_add_f64 on gfx950
 }
 
-// deterministic mode: wait until a ticket counter shows `want` (agent scope: the waiting and the signalling workgroup
-// may sit on different XCDs), and hand the turn on after this workgroup's atomics have been performed
-// (every spin is capped -- about a second -- like those of the factorisation: a scheduling accident must end in an error
-// code, DevProblem::det_timeouts, not in a hung GPU)
-__device__ __forceinline__ void det_wait(const unsigned *ctr, unsigned want, unsigned *timeouts) {
-    for (int spins = 0; __hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != want; ++spins) {
-        __builtin_amdgcn_s_sleep(2);
-        if (spins > (1 << 23)) { __hip_atomic_fetch_add(timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
-    }
+// deterministic mode: v rounded to a multiple of q = ui uj 2^-51 (ui, uj powers of two; |v| <= ui uj): the classic
+// (v + M) - M with M = 1.5 * 2^52 q = 3 ui uj.  (The empty asm keeps the compiler from folding the pair.)
+constexpr int DET_CP = 256;         // doubles per chunk partial (16 x 16 Gram matrix; fixed IO uses the first 28)
+constexpr int DET_IOP = 128;        // doubles per camera in det_io_part: (ncol-6)^2 <= 81 block entries, then <= 9 gradient entries
+__device__ __forceinline__ double det_round(double v, double ui, double uj) {
+    const double M = 3.0 * ui * uj;
+    double t = v + M;
+    asm volatile("" : "+v"(t));
+    return t - M;
 }
-__device__ __forceinline__ void det_pass(unsigned *ctr, unsigned next) {
-    __hip_atomic_store(ctr, next, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+// smallest power of two u with u * u >= a (a >= 0); 0 for a == 0 (a row nothing contributes to)
+__device__ __forceinline__ double det_pow2_sqrt(double a) {
+    if (!(a > 0.0)) return 0.0;
+    int e;
+    const double m = frexp(a, &e);                  // a = m 2^e, m in [0.5, 1)
+    (void)m;
+    return ldexp(1.0, (e + 1) >> 1);                // 2^ceil(e / 2) >= sqrt(a)
 }
 
 // ---------------------------------------------------------------- K0 ----
@@ -650,6 +662,11 @@ __global__ __launch_bounds__(256) void k_build(DevProblem d, const double *__res
     const int nobs = (int)(d.batch_start[batch0 + blockIdx.x + 1] - o0);
     const bool active = t < nobs;
     const int64_t o = o0 + t;
+    // deterministic mode (DevProblem::deterministic): the camera side of EVERY observation comes from the camera-major
+    // kernels (summed in chunk order); here only the Schur terms are added, each onto the grid of its element -- exact sums
+    const bool det = d.deterministic != 0;
+    const double *U = d.det_u;
+    const double uf = det ? U[d.NS] : 0.0;
 
     double r[2] = {0, 0};
     double E[2][NCX];
@@ -743,6 +760,7 @@ __global__ __launch_bounds__(256) void k_build(DevProblem d, const double *__res
                 if constexpr (!WITH_IO) { W[a][0] = w0; W[a][1] = w1; W[a][2] = w2; Y[a][0] = y0; Y[a][1] = y1; Y[a][2] = y2; }
                 if (WITH_IO && a >= 6) continue;     // IO columns: below, summed over the wave where the lanes share them
                 const int col = C->col[a];
+                if (det) { atomic_add_f64(g_red + col, det_round(-(y0 * gpt[0] + y1 * gpt[1] + y2 * gpt[2]), U[col], uf)); continue; }
                 const double ga = E[0][a] * r[0] + E[1][a] * r[1];
                 atomic_add_f64(g_c + col, ga);
                 atomic_add_f64(g_red + col, ga - (y0 * gpt[0] + y1 * gpt[1] + y2 * gpt[2]));
@@ -755,15 +773,17 @@ __global__ __launch_bounds__(256) void k_build(DevProblem d, const double *__res
     // of g_c and on the 45 of the IO x IO block (11.7 ms per linearisation in round 3, where 0.1 would do).  In
     // converged control flow the lanes compare their targets: if all of them agree, the wave adds up first
     // (DPP row sums, no LDS) and one lane issues the atomic; otherwise every lane goes its own way as before.
-    auto add_shared = [&](double *base, int64_t idx, bool valid, double val) {
+    // (ua, ub: deterministic mode -- the grid of the target; the wave's sum is formed in a fixed order and rounded once)
+    auto add_shared = [&](double *base, int64_t idx, bool valid, double val, double ua = 0.0, double ub = 0.0) {
         const unsigned long long vm = __ballot(valid);
         if (!vm) return;
         const int fl = __ffsll((long long)vm) - 1;
         const int64_t idx0 = __shfl(idx, fl, 64);
         if (__ballot(valid && idx != idx0) == 0) {
-            const double sum = wave_sum_f64(valid ? val : 0.0);
+            double sum = wave_sum_f64(valid ? val : 0.0);
+            if (det) sum = det_round(sum, __shfl(ua, fl, 64), __shfl(ub, fl, 64));
             if ((int)(threadIdx.x & 63) == fl) atomic_add_f64(base + idx0, sum);
-        } else if (valid) atomic_add_f64(base + idx, val);
+        } else if (valid) atomic_add_f64(base + idx, det ? det_round(val, ua, ub) : val);
     };
     if constexpr (WITH_IO) {
 #pragma unroll
@@ -775,11 +795,11 @@ __global__ __launch_bounds__(256) void k_build(DevProblem d, const double *__res
             for (int q = 6; q < NCX; ++q) if (q == a) { ea0 = E[0][q]; ea1 = E[1][q]; }
             const double *wl = Wl + (size_t)t * strideW;
             const int64_t col = valid ? C->col[a] : 0;
-            const double ga = valid ? ea0 * r[0] + ea1 * r[1] : 0.0;
+            const double ga = (valid && !det) ? ea0 * r[0] + ea1 * r[1] : 0.0;
             const double gr = valid ? ga - (wl[3 * a] * gpt[0] + wl[3 * a + 1] * gpt[1] + wl[3 * a + 2] * gpt[2]) : 0.0;
-            add_shared(g_c, col, valid, ga);
-            add_shared(g_red, col, valid, gr);
-            add_shared(diagU, col, valid, ea0 * ea0 + ea1 * ea1);
+            if (!det) add_shared(g_c, col, valid, ga);
+            add_shared(g_red, col, valid, gr, (det && valid) ? U[col] : 0.0, uf);
+            if (!det) add_shared(diagU, col, valid, ea0 * ea0 + ea1 * ea1);
         }
     }
     // Shared IO columns again: if every observation of a point sees the SAME IO columns (one camera, or one IO block
@@ -825,8 +845,9 @@ __global__ __launch_bounds__(256) void k_build(DevProblem d, const double *__res
                         double val = -(Y[a][0] * wb0 + Y[a][1] * wb1 + Y[a][2] * wb2);
                         if (jj == t) {
                             if (b < a) continue;
-                            val = fma2(val, E[0][a], E[0][b], E[1][a], E[1][b]);
+                            if (!det) val = fma2(val, E[0][a], E[0][b], E[1][a], E[1][b]);
                         }
+                        if (det) val = det_round(val, U[cbase + a], U[rbase + b]);
                         atomic_add_f64(S + (int64_t)(cbase + a) * d.ldS + (rbase + b), val);
                     }
                 }
@@ -845,8 +866,9 @@ __global__ __launch_bounds__(256) void k_build(DevProblem d, const double *__res
 #pragma unroll
                     for (int b = 6; b < NCX; ++b) {
                         if (b >= ncol) break;
+                        const double pz = -(y0 * zu[3 * b] + y1 * zu[3 * b + 1] + y2 * zu[3 * b + 2]);
                         atomic_add_f64(S + (int64_t)gcol * d.ldS + C->col[b],
-                                       ea0 * E[0][b] + ea1 * E[1][b] - (y0 * zu[3 * b] + y1 * zu[3 * b + 1] + y2 * zu[3 * b + 2]));
+                                       det ? det_round(pz, U[gcol], U[C->col[b]]) : ea0 * E[0][b] + ea1 * E[1][b] + pz);
                     }
                 }
                 for (int jj = seg_start; jj < seg_start + seg_len; ++jj) {
@@ -858,12 +880,13 @@ __global__ __launch_bounds__(256) void k_build(DevProblem d, const double *__res
                         const int grow = Cj->col[b];
                         if (grow < gcol) continue;
                         double val = -(y0 * wj[3 * b] + y1 * wj[3 * b + 1] + y2 * wj[3 * b + 2]);
-                        if (jj == t) {
+                        if (jj == t && !det) {
                             double eb0 = 0, eb1 = 0;
 #pragma unroll
                             for (int q = 0; q < NCX; ++q) if (q == b) { eb0 = E[0][q]; eb1 = E[1][q]; }
                             val = fma2(val, ea0, eb0, ea1, eb1);
                         }
+                        if (det) val = det_round(val, U[gcol], U[grow]);
                         atomic_add_f64(S + (int64_t)gcol * d.ldS + grow, val);
                     }
                 }
@@ -901,14 +924,14 @@ __global__ __launch_bounds__(256) void k_build(DevProblem d, const double *__res
                     double val = 0.0;
                     if (valid) {
                         val = -(y0 * wj[3 * b] + y1 * wj[3 * b + 1] + y2 * wj[3 * b + 2]);
-                        if (jj == t) {
+                        if (jj == t && !det) {
                             double eb0 = 0, eb1 = 0;
 #pragma unroll
                             for (int q = 6; q < NCX; ++q) if (q == b) { eb0 = E[0][q]; eb1 = E[1][q]; }
                             val = fma2(val, ea0, eb0, ea1, eb1);
                         }
                     }
-                    add_shared(S, gcol * d.ldS + grow, valid, val);
+                    add_shared(S, gcol * d.ldS + grow, valid, val, (det && valid) ? U[gcol] : 0.0, (det && valid) ? U[grow] : 0.0);
                 }
             }
         }
@@ -978,6 +1001,7 @@ __global__ __launch_bounds__(256) void k_build_giant(DevProblem d, const double 
             wl[3 * a] = ea0 * B[0][0] + ea1 * B[1][0];
             wl[3 * a + 1] = ea0 * B[0][1] + ea1 * B[1][1];
             wl[3 * a + 2] = ea0 * B[0][2] + ea1 * B[1][2];
+            if (d.deterministic) continue;           // (the camera side comes from the camera-major kernels, DevProblem::deterministic)
             const int gcol = C.col[a];
             const double ga = ea0 * r[0] + ea1 * r[1];
             atomic_add_f64(g_c + gcol, ga);
@@ -1050,7 +1074,9 @@ __global__ __launch_bounds__(256) void k_build_giant(DevProblem d, const double 
         for (int a = 0; a < nci; ++a) {
             const int gcol = Ci.col[a];
             const double y0 = wi[3 * a], y1 = wi[3 * a + 1], y2 = wi[3 * a + 2];
-            atomic_add_f64(g_red + gcol, -(y0 * g0 + y1 * g1 + y2 * g2));
+            const bool det = d.deterministic != 0;   // (every term onto the grid of its element: exact sums)
+            const double gy = -(y0 * g0 + y1 * g1 + y2 * g2);
+            atomic_add_f64(g_red + gcol, det ? det_round(gy, d.det_u[gcol], d.det_u[d.NS]) : gy);
             // partners: fixed IO -> cameras ascend inside a point, j >= i covers the lower triangle;
             // with IO columns every ordered pair whose row is not above the column
             for (int j = WITH_IO ? 0 : i; j < k; ++j) {
@@ -1061,8 +1087,8 @@ __global__ __launch_bounds__(256) void k_build_giant(DevProblem d, const double 
                     const int grow = Cj.col[b];
                     if (grow < gcol) continue;
                     if (!WITH_IO && j == i && b < a) continue;
-                    atomic_add_f64(S + (int64_t)gcol * d.ldS + grow,
-                                   -(y0 * wj[3 * b] + y1 * wj[3 * b + 1] + y2 * wj[3 * b + 2]));
+                    const double pz = -(y0 * wj[3 * b] + y1 * wj[3 * b + 1] + y2 * wj[3 * b + 2]);
+                    atomic_add_f64(S + (int64_t)gcol * d.ldS + grow, det ? det_round(pz, d.det_u[gcol], d.det_u[grow]) : pz);
                 }
             }
         }
@@ -1179,39 +1205,38 @@ __global__ __launch_bounds__(256) void k_cam_normal(DevProblem d, const double *
     // columns that stay zero
     for (int c = NCX + 1; c < 16; ++c) { Gw[c * GLD + 2 * lane] = 0.0; Gw[c * GLD + 2 * lane + 1] = 0.0; }
     mfma_d4 acc = {0, 0, 0, 0};
-    // A chunk is at most 2048 observations: eight rounds per wave.  The loads of a round are a dependent pair (point index,
-    // then the gather of the point) and only one other wave shares the SIMD to hide them (LDS: two workgroups per CU), so
-    // round 4's kernel spent 72 % of its wave cycles waiting (profiles/r04_c4_summary.md).  Now the indices and image
-    // coordinates of ALL the wave's rounds are requested up front and the point of round n+1 while round n is evaluated.
-    constexpr int NRW = 8;
-    for (int64_t wbase = q0 + 64 * w; wbase < q1; wbase += 256 * NRW) {
-        int ptv[NRW];
-        double2 uvv[NRW], wv[NRW];
-#pragma unroll
-        for (int n = 0; n < NRW; ++n) {
-            const int64_t q = wbase + 256 * n + lane;
-            ptv[n] = 0; uvv[n] = double2{0, 0}; wv[n] = double2{C.w[0], C.w[1]};
+    // The loads of a round are a dependent pair (point index, then the gather of the point) and only one other wave
+    // shares the SIMD to hide them (LDS: two workgroups per CU): round 4's kernel spent 72 % of its wave cycles waiting
+    // (profiles/r04_c4_summary.md).  Now the index and image coordinates travel two rounds ahead and the point one.
+    {
+        auto load_obs = [&](int64_t q, int &pt, double2 &uv, double2 &ww) {
+            pt = 0; uv = double2{0, 0}; ww = double2{C.w[0], C.w[1]};
             if (q < q1) {
-                ptv[n] = cm_pt[q];
-                uvv[n] = reinterpret_cast<const double2 *>(cm_uv)[q];
-                if (cm_w) wv[n] = reinterpret_cast<const double2 *>(cm_w)[q];
+                pt = cm_pt[q];
+                uv = reinterpret_cast<const double2 *>(cm_uv)[q];
+                if (cm_w) ww = reinterpret_cast<const double2 *>(cm_w)[q];
             }
-        }
+        };
+        const int64_t qw = q0 + 64 * w + lane;
+        int pt_a, pt_b;
+        double2 uv_a, uv_b, w_a, w_b;
+        load_obs(qw, pt_a, uv_a, w_a);
+        load_obs(qw + 256, pt_b, uv_b, w_b);
         double Qn[3];
-        { const int64_t zp = d.NS + 3 * (int64_t)ptv[0]; Qn[0] = z[zp]; Qn[1] = z[zp + 1]; Qn[2] = z[zp + 2]; }
-#pragma unroll
-        for (int n = 0; n < NRW; ++n) {
-            const int64_t base = wbase + 256 * n;
-            if (base >= q1) break;                       // (uniform: the rounds of a wave end together)
+        { const int64_t zp = d.NS + 3 * (int64_t)pt_a; Qn[0] = z[zp]; Qn[1] = z[zp + 1]; Qn[2] = z[zp + 2]; }
+        for (int64_t base = q0 + 64 * w; base < q1; base += 256) {
             const int64_t q = base + lane;
             const double Q[3] = {Qn[0], Qn[1], Qn[2]};
-            if (n + 1 < NRW) { const int64_t zp = d.NS + 3 * (int64_t)ptv[n + 1]; Qn[0] = z[zp]; Qn[1] = z[zp + 1]; Qn[2] = z[zp + 2]; }
+            const double2 uv = uv_a, ww = w_a;
+            pt_a = pt_b; uv_a = uv_b; w_a = w_b;
+            { const int64_t zp = d.NS + 3 * (int64_t)pt_a; Qn[0] = z[zp]; Qn[1] = z[zp + 1]; Qn[2] = z[zp + 2]; }   // (index 0 beyond the chunk)
+            load_obs(q + 512, pt_b, uv_b, w_b);
             double r[2] = {0, 0}, E[2][NCX];
 #pragma unroll
             for (int c = 0; c < NCX; ++c) { E[0][c] = 0.0; E[1][c] = 0.0; }
             if (q < q1) {
                 double B[2][3];
-                eval_obs_pre<MODEL, NCX>(d, C, Q, uvv[n].x, uvv[n].y, wv[n].x, wv[n].y, 7u, r, E, B);
+                eval_obs_pre<MODEL, NCX>(d, C, Q, uv.x, uv.y, ww.x, ww.y, 7u, r, E, B);
             }
 #pragma unroll
             for (int c = 0; c < NCX; ++c) {
@@ -1239,8 +1264,8 @@ __global__ __launch_bounds__(256) void k_cam_normal(DevProblem d, const double *
     __syncthreads();
     const int i = t >> 4, j = t & 15;
     const double g = (Gs[t] + Gs[256 + t]) + (Gs[512 + t] + Gs[768 + t]);
-    // deterministic mode: the IO x IO block is common to all cameras -- one global ticket orders the chunks
-    if (d.deterministic) { if (t == 0) det_wait(d.det_io_turn + 1, (unsigned)d.cm_chunk_seq[blockIdx.x], d.det_timeouts); __syncthreads(); }
+    // deterministic mode: the chunk's Gram matrix as it is; k_det_cam_reduce adds the chunks of a camera in their order
+    if (d.deterministic) { d.det_cam_part[(int64_t)blockIdx.x * DET_CP + t] = g; return; }
     if (i < ncol && g != 0.0) {
         const int64_t ri = C.col[i];
         if (j < ncol) {
@@ -1253,7 +1278,6 @@ __global__ __launch_bounds__(256) void k_cam_normal(DevProblem d, const double *
             atomic_add_f64(g_red + ri, g);
         }
     }
-    if (d.deterministic) { __threadfence(); __syncthreads(); if (t == 0) det_pass(d.det_io_turn + 1, (unsigned)d.cm_chunk_seq[blockIdx.x] + 1u); }
 }
 
 // Fixed interior orientation: the Gram matrix of [E | r] is 7 x 7 -- 27 useful sums.  On the matrix
@@ -1270,15 +1294,15 @@ __global__ __launch_bounds__(256) void k_cam_normal6(DevProblem d, const double 
                                                      const int64_t *__restrict__ chunk_start, double *__restrict__ S,
                                                      double *__restrict__ g_c, double *__restrict__ g_red,
                                                      double *__restrict__ diagU) {
-    __shared__ double Gs[4 * 27];
+    __shared__ double Gs[4 * 28];
     __shared__ double Rd[4][14 * 65];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int cam = chunk_cam[blockIdx.x];
     const int64_t q0 = chunk_start[blockIdx.x], q1 = chunk_start[blockIdx.x + 1];
     const CamRec &C = cams[cam];
-    double G[27];                                    // 21: E'E lower triangle by rows (i >= j), then 6: E'r
+    double G[28];                                    // 21: E'E lower triangle by rows (i >= j), then 6: E'r, then r'r
 #pragma unroll
-    for (int i = 0; i < 27; ++i) G[i] = 0.0;
+    for (int i = 0; i < 28; ++i) G[i] = 0.0;
     // four observations at a time: their point indices and coordinates are requested together, then the four
     // gathers of the object points (a chunk has at most eight observations per thread)
     const double2 *uvp = reinterpret_cast<const double2 *>(cm_uv), *wp = reinterpret_cast<const double2 *>(cm_w);
@@ -1326,6 +1350,7 @@ __global__ __launch_bounds__(256) void k_cam_normal6(DevProblem d, const double 
                 for (int j = 0; j <= i; ++j, ++n) G[n] = __builtin_fma(e0[i], e0[j], __builtin_fma(e1[i], e1[j], G[n]));
 #pragma unroll
             for (int i = 0; i < 6; ++i) G[21 + i] = __builtin_fma(e0[i], r0, __builtin_fma(e1[i], r1, G[21 + i]));
+            G[27] = __builtin_fma(r0, r0, __builtin_fma(r1, r1, G[27]));     // (the deterministic mode's bound of the right-hand side)
         }
     }
     // The 27 sums over the wave's lanes through LDS, 14 at a time: every lane leaves its values, lane l then adds value
@@ -1335,7 +1360,7 @@ __global__ __launch_bounds__(256) void k_cam_normal6(DevProblem d, const double 
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
         for (int v = 0; v < 14; ++v)
-            if (14 * h + v < 27) Rd[w][v * 65 + lane] = G[14 * h + v];
+            Rd[w][v * 65 + lane] = G[14 * h + v];
         lds_fence();
         __builtin_amdgcn_wave_barrier();
         const int v = lane & 15, q4 = lane >> 4;
@@ -1346,15 +1371,18 @@ __global__ __launch_bounds__(256) void k_cam_normal6(DevProblem d, const double 
         }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
-        if (lane < 14 && 14 * h + lane < 27) Gs[w * 27 + 14 * h + lane] = sum;
+        if (lane < 14) Gs[w * 28 + 14 * h + lane] = sum;
         lds_fence();
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    // deterministic mode: the chunks of one camera add to its block in their order
-    if (d.deterministic) { if (t == 0) det_wait(d.det_cm_turn + cam, (unsigned)d.cm_chunk_seq[blockIdx.x], d.det_timeouts); __syncthreads(); }
+    // deterministic mode: the chunk's 28 sums as they are; k_det_cam_reduce adds the chunks of a camera in their order
+    if (d.deterministic) {
+        if (t < 28) d.det_cam_part[(int64_t)blockIdx.x * DET_CP + t] = (Gs[t] + Gs[28 + t]) + (Gs[56 + t] + Gs[84 + t]);
+        return;
+    }
     if (t < 27) {
-        double g = (Gs[t] + Gs[27 + t]) + (Gs[54 + t] + Gs[81 + t]);
+        double g = (Gs[t] + Gs[28 + t]) + (Gs[56 + t] + Gs[84 + t]);
         int i = t - 21, j = i;
         if (t < 21) {
             i = 0;
@@ -1374,7 +1402,155 @@ __global__ __launch_bounds__(256) void k_cam_normal6(DevProblem d, const double 
             }
         }
     }
-    if (d.deterministic) { __threadfence(); __syncthreads(); if (t == 0) det_pass(d.det_cm_turn + cam, (unsigned)d.cm_chunk_seq[blockIdx.x] + 1u); }
+}
+
+// ---------------------------------------------------------------- deterministic mode, camera side
+// One workgroup per camera: the Gram matrices of its camera-major chunks (tiled part, then untiled part) are added in chunk
+// order -- one thread per element -- and go where k_cam_normal / k_cam_normal6 put them with atomics: the camera's own
+// block and its camera x IO block of S, g_c, g_red, diagU (one writer each).  What several cameras share (the IO x IO
+// block, the IO entries of the gradient and of the column norms) is left per camera in det_io_part for k_det_io_reduce.
+template <int NCX>
+__global__ __launch_bounds__(256) void k_det_cam_reduce(DevProblem d, const CamRec *__restrict__ cams, double *__restrict__ S,
+                                                        double *__restrict__ g_c, double *__restrict__ g_red,
+                                                        double *__restrict__ diagU) {
+    const int cam = blockIdx.x, t = threadIdx.x;
+    const CamRec &C = cams[cam];
+    const int nel = NCX == 6 ? 28 : 256;
+    double g = 0.0;
+    if (t < nel) {
+        for (int part = 0; part < 2; ++part) {
+            const int q0 = d.det_cam_chunks[2 * cam + part * (2 * d.nc + 1)], q1 = d.det_cam_chunks[2 * cam + 1 + part * (2 * d.nc + 1)];
+            for (int q = q0; q < q1; ++q) g += d.det_cam_part[(int64_t)q * DET_CP + t];
+        }
+    }
+    if constexpr (NCX == 6) {
+        if (t == 27) d.det_rr[cam] = g;
+        if (t < 27) {
+            int i = t - 21, j = i;
+            if (t < 21) {
+                i = 0;
+                while ((i + 1) * (i + 2) / 2 <= t) ++i;
+                j = t - i * (i + 1) / 2;
+            }
+            if (!((C.eo_est >> i) & (C.eo_est >> j) & 1u)) g = 0.0;      // a camera element that is not estimated: no row, no column
+            if (t < 21) {
+                const int64_t ri = C.col[i], rj = C.col[j];
+                if (((C.eo_est >> i) & (C.eo_est >> j) & 1u)) {
+                    S[(ri >= rj ? rj * d.ldS + ri : ri * d.ldS + rj)] = g;
+                    if (i == j) diagU[ri] = g;
+                }
+            } else if ((C.eo_est >> i) & 1u) {
+                const int64_t ri = C.col[i];
+                g_c[ri] = g; g_red[ri] = g;
+            }
+        }
+    } else {
+        const int ncol = min(C.ncol, NCX);
+        const int i = t >> 4, j = t & 15;
+        if (i == NCX && j == NCX) d.det_rr[cam] = g;
+        double *iop = d.det_io_part + (int64_t)cam * DET_IOP;
+        if (i < ncol) {
+            const int64_t ri = C.col[i];
+            if (j < ncol && i >= j) {
+                if (j >= 6) iop[(i - 6) * 9 + (j - 6)] = g;              // IO x IO: shared by the cameras of the block
+                else {
+                    const int64_t rj = C.col[j];
+                    S[(ri >= rj ? rj * d.ldS + ri : ri * d.ldS + rj)] = g;
+                    if (i == j) diagU[ri] = g;
+                }
+            } else if (j == NCX) {
+                if (i >= 6) iop[81 + (i - 6)] = g;
+                else { g_c[ri] = g; g_red[ri] = g; }
+            }
+        }
+    }
+}
+
+// The IO unknowns' block: one workgroup per element (p >= q) of the nio x nio block and per gradient entry.  Thread t adds
+// the cameras t, t + 256, ... in index order (a camera contributes where both columns are on its list), the 256 partial
+// sums are joined by a fixed tree: the same bits whatever the hardware does.
+template <int NCX>
+__global__ __launch_bounds__(256) void k_det_io_reduce(DevProblem d, const CamRec *__restrict__ cams, int nio, double *__restrict__ S,
+                                                       double *__restrict__ g_c, double *__restrict__ g_red,
+                                                       double *__restrict__ diagU) {
+    __shared__ double sh[256];
+    const int npair = nio * (nio + 1) / 2, e = blockIdx.x, t = threadIdx.x;
+    int p, q;
+    if (e < npair) { p = 0; while ((p + 1) * (p + 2) / 2 <= e) ++p; q = e - p * (p + 1) / 2; }
+    else { p = e - npair; q = -1; }
+    const int64_t rp = 6 * (int64_t)d.nc + p, rq = 6 * (int64_t)d.nc + q;
+    double s = 0.0;
+    for (int c = t; c < d.nc; c += 256) {
+        const CamRec &C = cams[c];
+        const int ncol = min(C.ncol, NCX);
+        int a = -1, b = -1;
+        for (int k = 6; k < ncol; ++k) { if (C.col[k] == rp) a = k; if (C.col[k] == rq) b = k; }
+        if (a < 0) continue;
+        const double *iop = d.det_io_part + (int64_t)c * DET_IOP;
+        if (q < 0) s += iop[81 + (a - 6)];
+        else if (b >= 0) s += iop[(max(a, b) - 6) * 9 + (min(a, b) - 6)];
+    }
+    sh[t] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) sh[t] += sh[t + w];
+        __syncthreads();
+    }
+    if (t == 0) {
+        if (q < 0) { g_c[rp] = sh[0]; g_red[rp] = sh[0]; }
+        else { S[rq * d.ldS + rp] = sh[0]; if (p == q) diagU[rp] = sh[0]; }
+    }
+}
+
+// u_r of every row of the reduced system from its squared column norm, and u_f from r'r (summed in camera order by one
+// thread: nc additions); then the camera-side entries of S and of g_red onto their grids, so that every later addition to
+// them is exact (one thread per camera element, as in k_det_cam_reduce; block nc: the IO x IO block).
+__global__ __launch_bounds__(256) void k_det_rows(DevProblem d, const double *__restrict__ diagU) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < d.NS) d.det_u[r] = det_pow2_sqrt(diagU[r]);
+    if (blockIdx.x == 0) {                          // r'r: thread t adds the cameras t, t + 256, ...; fixed tree over the threads
+        __shared__ double sh[256];
+        const int t = threadIdx.x;
+        double s = 0.0;
+        for (int c = t; c < d.nc; c += 256) s += d.det_rr[c];
+        sh[t] = s;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if (t < w) sh[t] += sh[t + w];
+            __syncthreads();
+        }
+        if (t == 0) { d.det_rr[d.nc] = sh[0]; d.det_u[d.NS] = det_pow2_sqrt(sh[0]); }
+    }
+}
+template <int NCX>
+__global__ __launch_bounds__(256) void k_det_round_cam(DevProblem d, const CamRec *__restrict__ cams, int nio, double *__restrict__ S,
+                                                       double *__restrict__ g_red) {
+    const int t = threadIdx.x;
+    const double *u = d.det_u, uf = d.det_u[d.NS];
+    if ((int)blockIdx.x == d.nc) {                   // the IO x IO block and the IO entries of the right-hand side
+        const int npair = nio * (nio + 1) / 2;
+        for (int e = t; e < npair + nio; e += blockDim.x) {
+            if (e < npair) {
+                int p = 0; while ((p + 1) * (p + 2) / 2 <= e) ++p;
+                const int q = e - p * (p + 1) / 2;
+                const int64_t rp = 6 * (int64_t)d.nc + p, rq = 6 * (int64_t)d.nc + q;
+                S[rq * d.ldS + rp] = det_round(S[rq * d.ldS + rp], u[rp], u[rq]);
+            } else {
+                const int64_t rp = 6 * (int64_t)d.nc + (e - npair);
+                g_red[rp] = det_round(g_red[rp], u[rp], uf);
+            }
+        }
+        return;
+    }
+    const CamRec &C = cams[blockIdx.x];
+    const int ncol = NCX == 6 ? 6 : min(C.ncol, NCX);
+    const int i = t >> 4, j = t & 15;
+    if (i < ncol && j < 6 && i >= j) {               // the camera's own block and its rows of the camera x IO block
+        const int64_t ri = C.col[i], rj = C.col[j];
+        double *e = S + (ri >= rj ? rj * d.ldS + ri : ri * d.ldS + rj);
+        *e = det_round(*e, u[ri], u[rj]);
+    }
+    if (i < 6 && j == 15) { const int64_t ri = C.col[i]; g_red[ri] = det_round(g_red[ri], u[ri], uf); }
 }
 
 // ---------------------------------------------------------------- K1t2 --

@@ -58,6 +58,8 @@ constexpr int SIG_STILE = 8064;      // 126*127/2 = 8001 packed lower triangle o
 struct SigLds {                      // static part
     int next_chunk, abort_;
     int flush_turn;                  // deterministic mode: the chunk (tile-local index) whose turn it is to add to the tile
+    double urow[128];                // deterministic mode: u_r of every row of the tile (DevProblem::det_u), [127 + 1]: u_f
+    double uf;
     int grow[128];                   // row of the reduced system of every row of the tile
     int lc[SIG_NW][16];              // tile-local camera of every slot of the wave's chunk
     short tmap[SIG_NW][80];          // tile row of every row of the wave's chunk
@@ -224,8 +226,12 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
         if constexpr (IO) camw[i] = reinterpret_cast<const double *>(&C)[f];
         else camw[i] = f < CAMW - 1 ? reinterpret_cast<const double *>(&C)[f] : (double)C.eo_est;
     }
-    if (t < 6 * ncam) sy.grow[t] = 6 * d.tile_cams[c0 + t / 6] + t % 6;
-    else if (t < nrows) sy.grow[t] = 6 * d.nc + d.tile_iocols[io0 + t - 6 * ncam];
+    if (t < nrows) {
+        const int gr = t < 6 * ncam ? 6 * d.tile_cams[c0 + t / 6] + t % 6 : 6 * d.nc + d.tile_iocols[io0 + t - 6 * ncam];
+        sy.grow[t] = gr;
+        if (d.deterministic) sy.urow[t] = d.det_u[gr];
+    }
+    if (t == 0 && d.deterministic) sy.uf = d.det_u[d.NS];
     if constexpr (IO) { for (int i = t; i < 16 * ncam; i += NT) sy.camio[i >> 4][i & 15] = d.tile_cam_io[(size_t)c0 * 16 + i]; }
     if (t == 0) { sy.next_chunk = ch0 + NW; sy.abort_ = 0; sy.flush_turn = 0; }
     for (int i = t; i < NW * 80; i += NT) { sy.tmap[i / 80][i % 80] = 0; sy.toff[i / 80][i % 80] = 0; }
@@ -651,12 +657,12 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
         // ------------------------------------------------------------ chunk -> tile (LDS atomics)
         // one predicated ds_add_f64 per accumulator element; vt follows stile, so the right-hand-side
         // row (6k) only changes the index and the sign
-        if (d.deterministic) {                        // the chunks add to the tile in their order (they are taken in that order)
+        // deterministic mode: the chunks add to the tile in their order (they are taken in that order; all the tile's waves
+        // are resident, so a wave only ever waits for waves that are running) -- the tile's sums are the same bits then,
+        // and they go onto the grid of S once, when the tile is flushed (one rounding per tile and element, not per chunk)
+        if (d.deterministic) {
             volatile int *turn = &sy.flush_turn;
-            for (int spins = 0; *turn != ch_cur - ch0; ++spins) {
-                __builtin_amdgcn_s_sleep(1);
-                if (spins > (1 << 23)) { if (lane == 0) __hip_atomic_fetch_add(d.det_timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            }
+            for (int spins = 0; *turn != ch_cur - ch0 && spins < (1 << 24); ++spins) __builtin_amdgcn_s_sleep(1);
         }
         {
             const int r6k = ry;                      // the row of y closes the chunk's rows
@@ -699,12 +705,6 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
     __syncthreads();
     lap(6);
     // ---------------------------------------------------------------- tile -> HBM
-    // deterministic mode: this tile's turn at every one of its cameras (and at the shared IO rows)
-    if (d.deterministic) {
-        if (t < ncam) det_wait(d.det_cam_turn + d.tile_cams[c0 + t], (unsigned)d.tile_cam_seq[c0 + t], d.det_timeouts);
-        if (IO && t == 64 && d.tile_io_seq[tile] >= 0) det_wait(d.det_io_turn, (unsigned)d.tile_io_seq[tile], d.det_timeouts);
-        __syncthreads();
-    }
     // one column per wave and trip: consecutive lanes, consecutive rows (neighbouring addresses in S).  All the
     // LDS reads of the wave's columns are issued first (the accumulators are dead: the registers are there), then the
     // atomics -- one LDS latency per tile instead of one per column
@@ -716,6 +716,13 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
             const int tc = wave + q * NW, tr = tc + lane;
             v0[q] = (tc < nrows && tr < nrows) ? stile[tr * (tr + 1) / 2 + tc] : 0.0;
             v1[q] = (tc < nrows && tr + 64 < nrows) ? stile[(tr + 64) * (tr + 65) / 2 + tc] : 0.0;
+            // deterministic mode: onto the grid of the element's place in S (kernels.hpp DevProblem::deterministic) -- the
+            // additions of the tiles are exact then, in whatever order they arrive
+            if (d.deterministic && tc < nrows) {
+                const double uc = sy.urow[tc];
+                if (tr < nrows) v0[q] = det_round(v0[q], sy.urow[tr], uc);
+                if (tr + 64 < nrows) v1[q] = det_round(v1[q], sy.urow[tr + 64], uc);
+            }
         }
         if (!DBAT_ABLATE(d, 16)) {
 #pragma unroll
@@ -729,13 +736,9 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
             }
         }
     }
-    for (int i = t; i < nrows; i += NT)
-        if (vt[i] != 0.0) atomic_add_f64(g_red + sy.grow[i], vt[i]);
-    if (d.deterministic) {
-        __threadfence();                             // this tile's atomics have been performed
-        __syncthreads();
-        if (t < ncam) det_pass(d.det_cam_turn + d.tile_cams[c0 + t], (unsigned)d.tile_cam_seq[c0 + t] + 1u);
-        if (IO && t == 64 && d.tile_io_seq[tile] >= 0) det_pass(d.det_io_turn, (unsigned)d.tile_io_seq[tile] + 1u);
+    for (int i = t; i < nrows; i += NT) {
+        const double v = d.deterministic ? det_round(vt[i], sy.urow[i], sy.uf) : vt[i];
+        if (v != 0.0) atomic_add_f64(g_red + sy.grow[i], v);
     }
     double accr[1] = {rr};
     block_sum<1>(accr, sh);

@@ -285,12 +285,17 @@ int  dbat_hip_comm_init(dbat_hip_handle *h, const uint8_t *id /*[128]*/);
  * (a barrier is a reduce of one double).  Identity without a communicator. */
 int  dbat_hip_comm_allreduce_host(dbat_hip_handle *h, double *buf, int64_t count, int32_t op);
 
-/* Deterministic mode: on != 0 makes every later linearisation of this handle add its contributions to the reduced
- * system in a FIXED order (tickets per image, per camera-major chunk and one for the shared IO rows), so that two
- * runs of the same problem give the same bits -- as the reference does by construction, where one MATLAB thread
- * forms J'J (gauss_newton_armijo.m:166-174).  The atomics of the default mode reorder f64 sums (1e-13 relative).
- * Costs time (the tile flushes of self-calibrating problems queue up on the IO rows); meant for parity runs.
- * DBAT_HIP_EUNSUPPORTED unless the handle runs the signature-group path on one rank (no heavy / giant points). */
+/* Deterministic mode: on != 0 makes every later linearisation of this handle give the same bits in every run -- as the
+ * reference does by construction, where one MATLAB thread forms J'J (gauss_newton_armijo.m:166-174).  The default
+ * mode's atomics reorder f64 sums (steps repeat to 1e-13).  The sums are not ordered but made EXACT: the camera side is
+ * summed chunk by chunk in a fixed order; from its column norms every element of the reduced system gets a power-of-two
+ * grid on which every Schur contribution is rounded (half a unit in the last place of the element's Cauchy-Schwarz bound
+ * sqrt(U_ii U_jj)), and sums of grid multiples below 2^53 grid units carry no rounding, whatever their order.
+ * Covers every build path on one rank (signature-group kernel: + 7 % at C3; scenes with irregular visibility run the
+ * column-list kernel over all their batches).  The step differs from the default mode's by cond(S) x 1e-15 (C1: 2e-10,
+ * C3: 5e-8); converged estimates and sigma0 agree to 1e-9 -- the right-hand side is rounded on the scale of its own
+ * summation error.  DBAT_HIP_EUNSUPPORTED for several ranks, shared EO blocks (camera stations), more than nine estimated
+ * IO columns per camera. */
 int  dbat_hip_set_deterministic(dbat_hip_handle *h, int32_t on);
 
 /* Test hook (gloo on CPU boxes, two shards on one GPU through the host):

@@ -26,10 +26,17 @@ def cpu_ref():
 
 
 @pytest.mark.parametrize('name,variant', [('tiny', 'plain'), ('tiny', 'selfcal'), ('tiny', 'imagevar'),
-                                          ('tiny', 'groups4'), ('small', 'plain'), ('small', 'groups4')])
+                                          ('tiny', 'groups4'), ('small', 'plain'), ('small', 'groups4'),
+                                          ('tiny', 'priors'), ('small', 'priors')])   # prior observations: rows of J (prior_obs.m:45-72)
 @pytest.mark.parametrize('threads', [1, 3])
 def test_cpu_ref_step_matches_oracle(cpu_ref, name, variant, threads):
     s, _ = synth_struct(name, variant)
+    if variant == 'priors':                       # (bundle.m:137-154: priors of parameters that are not estimated are dropped)
+        import copy
+        s = copy.deepcopy(s)
+        for nm in ('IO', 'EO', 'OP'):
+            pr = getattr(s.prior, nm)
+            pr.use = np.asarray(pr.use, bool) & np.asarray(getattr(s.bundle.est, nm), bool)
     so = o.buildserialindices(s)
     x0 = o.serialize(so)
     w = o.buildweightvector(so)
