@@ -1097,6 +1097,101 @@ __global__ void k_df_reset(int *__restrict__ info, int *__restrict__ ctl, unsign
     if (i < nq) qflag[i] = DF_SENTINEL;
 }
 
+// ---- Selected inversion: the entries of Z = inv(P S P') ON THE PATTERN OF THE FACTOR, from the compact tile factor
+// (Takahashi's recurrence by tiles -- the reference's own tool for this is code/test/sparseinv/sparseinv.c; bundle_cov.m:63-117
+// inverts blocks of a permuted Cholesky factor).  With column k of the factor, L_kk and L_Jk (J: the tile rows below the
+// diagonal), and M_Jk = L_Jk L_kk^-1:
+//     Z_Jk = - Z_JJ M_Jk,        Z_kk = L_kk^-T L_kk^-1 - M_Jk' Z_Jk,
+// from the last column to the first.  Z_JJ lies inside the pattern (it is closed under fill) and belongs to later
+// columns.  Columns whose J are all done form a LEVEL; a level is two launches (off-diagonal tiles, then the diagonal
+// ones), and the M tiles -- which overwrite L, the factor is formed anew by every solve -- one launch up front.
+// Cost: sum_k |J_k|^2 tile products, the count of the factorisation itself; memory: one more set of compact tiles
+// (C4: 0.35 GB) where the dense inverse took 7.2 GB and 9 TF (rocsolver_dpotri).
+// loaders: a 64 x 64 tile stored column-major (ld 64) into an LDS operand image
+template <int LD>
+__device__ __forceinline__ void si_load(const double *T, double *Pm, int tx, int ty, double sign = 1.0) {     // Pm[c*LD + r] = T(r, c)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { const int c = ty + 4 * q; Pm[c * LD + tx] = sign * T[c * 64 + tx]; }
+}
+template <int LD>
+__device__ __forceinline__ void si_load_T(const double *T, double *Pm, int tx, int ty, double sign = 1.0) {   // Pm[r*LD + c] = T(r, c)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { const int c = ty + 4 * q; Pm[tx * LD + c] = sign * T[c * 64 + tx]; }
+}
+struct SiTask { int i, k; };
+// M(i,k) = L(i,k) L_kk^-1, in place
+__global__ __launch_bounds__(256) void k_selinv_m(double *__restrict__ tiles, const int64_t *__restrict__ toff, int nT,
+                                                  const double *__restrict__ linv_all, const SiTask *__restrict__ tasks) {
+    constexpr int LD = DF_LD;
+    __shared__ double smem[2 * 64 * LD];
+    double *Pm = smem, *Qm = smem + 64 * LD;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const SiTask tk = tasks[blockIdx.x];
+    double *T = tiles + toff[(int64_t)tk.i * nT + tk.k];
+    si_load_T<LD>(linv_all + (size_t)tk.k * 4096, Pm, tx, ty);        // P(c, m) = Linv(m, c)
+    si_load<LD>(T, Qm, tx, ty);                                        // Q(r, m) = L(r, m)
+    __syncthreads();
+    chol_d4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    mfma_tile64<LD>(Pm, Qm, ty, tx, acc);                              // D(c, r) = sum_m Linv(m, c) L(r, m) = M(r, c)
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) T[(16 * ty + (tx >> 4) + 4 * e) * 64 + 16 * rt + (tx & 15)] = acc[rt][e];
+}
+// Z(i,k) = - sum_{j in J(k)} Z(i,j) M(j,k),  i in J(k)
+__global__ __launch_bounds__(256) void k_selinv_off(double *__restrict__ Z, const double *__restrict__ M, const int64_t *__restrict__ toff,
+                                                    int nT, const int *__restrict__ bk_ptr, const int *__restrict__ bk_idx,
+                                                    const SiTask *__restrict__ tasks) {
+    constexpr int LD = DF_LD;
+    __shared__ double smem[2 * 64 * LD];
+    double *Pm = smem, *Qm = smem + 64 * LD;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const SiTask tk = tasks[blockIdx.x];
+    const int i = tk.i, k = tk.k;
+    chol_d4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int e = bk_ptr[k]; e < bk_ptr[k + 1]; ++e) {
+        const int j = bk_idx[e];
+        __syncthreads();
+        si_load_T<LD>(M + toff[(int64_t)j * nT + k], Pm, tx, ty);                       // P(c, m) = M(j,k)(m, c)
+        if (i >= j) si_load<LD>(Z + toff[(int64_t)i * nT + j], Qm, tx, ty);             // Q(r, m) = Z(i,j)(r, m)
+        else si_load_T<LD>(Z + toff[(int64_t)j * nT + i], Qm, tx, ty);                  //         = Z(j,i)(m, r)
+        __syncthreads();
+        mfma_tile64<LD>(Pm, Qm, ty, tx, acc);
+    }
+    double *T = Z + toff[(int64_t)i * nT + k];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) T[(16 * ty + (tx >> 4) + 4 * e) * 64 + 16 * rt + (tx & 15)] = -acc[rt][e];
+}
+// Z(k,k) = L_kk^-T L_kk^-1 - sum_{j in J(k)} M(j,k)' Z(j,k)   (both triangles are stored)
+__global__ __launch_bounds__(256) void k_selinv_diag(double *__restrict__ Z, const double *__restrict__ M, const int64_t *__restrict__ toff,
+                                                     int nT, const int *__restrict__ bk_ptr, const int *__restrict__ bk_idx,
+                                                     const double *__restrict__ linv_all, const int *__restrict__ cols) {
+    constexpr int LD = DF_LD;
+    __shared__ double smem[2 * 64 * LD];
+    double *Pm = smem, *Qm = smem + 64 * LD;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int k = cols[blockIdx.x];
+    chol_d4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    si_load_T<LD>(linv_all + (size_t)k * 4096, Pm, tx, ty);            // P(c, m) = Linv(m, c)
+    __syncthreads();
+    mfma_tile64<LD>(Pm, Pm, ty, tx, acc);                              // D(c, r) = sum_m Linv(m, c) Linv(m, r)
+    for (int e = bk_ptr[k]; e < bk_ptr[k + 1]; ++e) {
+        const int j = bk_idx[e];
+        __syncthreads();
+        si_load_T<LD>(Z + toff[(int64_t)j * nT + k], Pm, tx, ty);                       // P(c, m) = Z(j,k)(m, c)
+        si_load_T<LD>(M + toff[(int64_t)j * nT + k], Qm, tx, ty, -1.0);                 // Q(r, m) = -M(j,k)(m, r)
+        __syncthreads();
+        mfma_tile64<LD>(Pm, Qm, ty, tx, acc);
+    }
+    double *T = Z + toff[(int64_t)k * nT + k];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) T[(16 * ty + (tx >> 4) + 4 * e) * 64 + 16 * rt + (tx & 15)] = acc[rt][e];
+}
+
 // Host side: schedule (tile pattern, task list, tables) and launch.
 //   setup_inplace   factor S where it lies, natural order, envelope pattern
 //   setup_permuted  nested-dissection order of the cameras + symbolic tile
@@ -1128,6 +1223,13 @@ struct DataflowChol {
     int *d_chain_cols = nullptr, *d_chain_colsB = nullptr, *d_chain_par = nullptr, *d_chain_bits = nullptr, *d_chain_bitsB = nullptr, *d_chain_pos = nullptr;
     double *d_parts = nullptr;
     double *d_tiles = nullptr, *d_qperm = nullptr;
+    // selected inversion (selected_inverse): Z on the factor's pattern, the schedule by levels
+    double *d_ztiles = nullptr;
+    SiTask *d_si_m = nullptr, *d_si_off = nullptr;
+    int *d_si_diag = nullptr, *d_perm = nullptr;
+    int n_si_m = 0;
+    std::vector<int> si_off_ptr, si_diag_ptr;           // per level: ranges into d_si_off / d_si_diag
+    std::vector<uint64_t> h_rowbits;
     long long *d_trace = nullptr;                       // optional per-task timestamps (DBAT_HIP_DF_TRACE=file)
     std::vector<DfJob> h_tasks;
     std::vector<int> perm;                              // natural -> permuted (empty: identity)
@@ -1137,12 +1239,15 @@ struct DataflowChol {
 
     void release() {
         void *ps[] = {d_flags, d_ctl, d_bk_ptr, d_bk_idx, d_iperm, d_toff, d_rowbits, d_tasks, d_tile_ij, d_tiles, d_qperm, d_parts,
-                      d_tasksB, d_bk_list, d_rowbits_top, d_chain_cols, d_chain_colsB, d_chain_par, d_chain_bits, d_chain_bitsB, d_chain_pos};
+                      d_tasksB, d_bk_list, d_rowbits_top, d_chain_cols, d_chain_colsB, d_chain_par, d_chain_bits, d_chain_bitsB, d_chain_pos,
+                      d_ztiles, d_si_m, d_si_off, d_si_diag, d_perm};
         for (void *p : ps) if (p) (void)hipFree(p);
         d_flags = d_ctl = d_bk_ptr = d_bk_idx = d_iperm = nullptr; d_toff = nullptr; d_rowbits = nullptr;
         d_tasks = nullptr; d_tile_ij = nullptr; d_tiles = d_qperm = d_parts = nullptr;
         d_tasksB = nullptr; d_bk_list = nullptr; d_rowbits_top = nullptr;
         d_chain_cols = d_chain_colsB = d_chain_par = d_chain_bits = d_chain_bitsB = d_chain_pos = nullptr;
+        d_ztiles = nullptr; d_si_m = d_si_off = nullptr; d_si_diag = d_perm = nullptr; n_si_m = 0;
+        si_off_ptr.clear(); si_diag_ptr.clear();
     }
     // per-task timestamps of the last solve (100 MHz ticks): task, i, k, t[0..15], jlo, jhi, mode per line
     void dump_trace(hipStream_t stream, const char *path) const {
@@ -1392,6 +1497,7 @@ struct DataflowChol {
         if (const char *g = env_get("DBAT_HIP_DF_GRID")) grid = std::min(std::max(atoi(g), 1), 4096);
         nparts = 0; n_products = 0;
         two_phase = !col_owner.empty();
+        h_rowbits = rowbits;
         // The chain role pays where the dependent chain of the separators decides the time (C1 ... C3: 0.61 -> 0.59 ms at C3);
         // where the tile products do (C4: 116 000 of them, 3.07 -> 3.29 ms) its workgroups and the extra sum tasks cost more
         // than the shorter links return.  Both times from the pattern: products x 2.6 us over the workgroups against the
@@ -1641,6 +1747,47 @@ struct DataflowChol {
         }
         return finish_setup(rb, toff, col_owner, rank);
     }
+    // Z = inv(P S P') on the pattern of the factor, after solve() in the compact (permuted) layout on the same stream.
+    // Overwrites the factor's off-diagonal tiles with M = L L_kk^-1.  One rank only.  false: out of device memory.
+    bool selinv_supported() const { return permuted && !two_phase; }
+    bool selected_inverse(hipStream_t stream, const double *linv_work) {
+        if (!d_ztiles) {                                // the schedule, once
+            auto has = [&](int i, int k) { return (h_rowbits[(size_t)i * W + (k >> 6)] >> (k & 63)) & 1ull; };
+            std::vector<SiTask> mt, off;
+            std::vector<int> level(nT, 0), diag;
+            int nlev = 0;
+            for (int k = nT - 1; k >= 0; --k) {
+                int lv = 0;
+                for (int i = k + 1; i < nT; ++i) if (has(i, k)) { lv = std::max(lv, level[i] + 1); mt.push_back(SiTask{i, k}); }
+                level[k] = lv; nlev = std::max(nlev, lv + 1);
+            }
+            si_off_ptr.assign(nlev + 1, 0); si_diag_ptr.assign(nlev + 1, 0);
+            for (int lv = 0; lv < nlev; ++lv) {
+                for (int k = nT - 1; k >= 0; --k) {
+                    if (level[k] != lv) continue;
+                    diag.push_back(k);
+                    for (int i = k + 1; i < nT; ++i) if (has(i, k)) off.push_back(SiTask{i, k});
+                }
+                si_off_ptr[lv + 1] = (int)off.size(); si_diag_ptr[lv + 1] = (int)diag.size();
+            }
+            n_si_m = (int)mt.size();
+            if (!up(d_si_m, mt) || !up(d_si_off, off) || !up(d_si_diag, diag) || !up(d_perm, perm)) return false;
+            if (hipMalloc(&d_ztiles, (size_t)ntiles * 4096 * sizeof(double)) != hipSuccess) { d_ztiles = nullptr; return false; }
+        }
+        if (n_si_m > 0)
+            hipLaunchKernelGGL(k_selinv_m, dim3(n_si_m), dim3(256), 0, stream, d_tiles, d_toff, nT, linv_work, d_si_m);
+        for (size_t lv = 0; lv + 1 < si_off_ptr.size(); ++lv) {
+            const int no = si_off_ptr[lv + 1] - si_off_ptr[lv], nd = si_diag_ptr[lv + 1] - si_diag_ptr[lv];
+            if (no > 0)
+                hipLaunchKernelGGL(k_selinv_off, dim3(no), dim3(256), 0, stream, d_ztiles, (const double *)d_tiles, d_toff, nT, d_bk_ptr,
+                                   d_bk_idx, d_si_off + si_off_ptr[lv]);
+            if (nd > 0)
+                hipLaunchKernelGGL(k_selinv_diag, dim3(nd), dim3(256), 0, stream, d_ztiles, (const double *)d_tiles, d_toff, nT, d_bk_ptr,
+                                   d_bk_idx, linv_work, d_si_diag + si_diag_ptr[lv]);
+        }
+        return true;
+    }
+    int selinv_levels() const { return (int)si_off_ptr.size() - 1; }
     // Factor and solve S q = b (b' in row n of S, lower triangle of S, leading dimension lda).
     // q -> q_out (natural order).  In-place mode leaves L in S; permuted mode leaves S untouched.
     // ldiag (optional, n entries): the pivots diag(L) by natural index.  linv_work as

@@ -967,26 +967,42 @@ struct Core {
     // ---- posterior covariance blocks at z (bundle_cov.m): s0^2 * blocks of inv(J'J)
     std::vector<double> cop_tmp;
     void posterior_cov(double s0, double *hCEO, double *hCIO, double *hCOP, double *hSinv) {
-        replicate_next = true;                       // (domain sharding: the whole system on every rank for this one)
+        // inv(S): on one rank, from the compact nested-dissection factor, only the entries the blocks need (selected inversion,
+        // chol_df.hpp) -- no dense inverse (C4: 7.2 GB and 9 TF of rocsolver_dpotri).  The dense inverse remains for several
+        // ranks, for problems without the compact factor (shared EO blocks, DBAT_HIP_ND_OFF) and for a caller who asks for it.
+        const bool selinv = use_perm && !multi() && !hSinv && dfchol.selinv_supported() && !env_on("DBAT_HIP_COV_DENSE");
+        replicate_next = !selinv;                    // (domain sharding: the whole system on every rank for this one)
         try { build(z.p, 0.0, 0); } catch (...) { replicate_next = false; throw; }   // unscaled, undamped reduced system + V^-1 per point
         replicate_next = false;
         s_valid = false;
-        chol_in_place = true;
-        // the in-place factorisation stores whole 64 x 64 tiles, which straddle the column envelope that the
-        // next build clears: from here on S must be cleared densely -- also when the factorisation fails
-        s_dense_dirty = true;
-        factor_solve_enqueue();                      // L in the lower triangle of S
-        chol_in_place = false;
+        SinvView SV;
         int hinfo = 0;
-        HIPCHK(hipMemcpyAsync(&hinfo, info.p, sizeof(hinfo), hipMemcpyDeviceToHost, stream));
-        sync();
-        if (hinfo != 0) throw DeviceError{"posterior covariance: the reduced normal matrix is not positive definite"};
-        if (!blas) {     // (created on first use: rocblas_create_handle costs 0.1 s, and only the posterior covariance needs it)
-            if (rocblas_create_handle(&blas) != rocblas_status_success) throw DeviceError{"rocblas_create_handle failed"};
-            rocblas_set_stream(blas, stream);
+        if (selinv) {
+            factor_solve_enqueue();                  // the compact factor (S itself is only read)
+            HIPCHK(hipMemcpyAsync(&hinfo, info.p, sizeof(hinfo), hipMemcpyDeviceToHost, stream));
+            sync();
+            if (hinfo != 0) throw DeviceError{"posterior covariance: the reduced normal matrix is not positive definite"};
+            if (!dfchol.selected_inverse(stream, linv.p)) throw DeviceError{"out of device memory (selected inverse)"};
+            HIPCHK(hipGetLastError());
+            SV.tiles = dfchol.d_ztiles; SV.toff = dfchol.d_toff; SV.perm = dfchol.d_perm; SV.nT = dfchol.nT;
+        } else {
+            chol_in_place = true;
+            // the in-place factorisation stores whole 64 x 64 tiles, which straddle the column envelope that the
+            // next build clears: from here on S must be cleared densely -- also when the factorisation fails
+            s_dense_dirty = true;
+            factor_solve_enqueue();                  // L in the lower triangle of S
+            chol_in_place = false;
+            HIPCHK(hipMemcpyAsync(&hinfo, info.p, sizeof(hinfo), hipMemcpyDeviceToHost, stream));
+            sync();
+            if (hinfo != 0) throw DeviceError{"posterior covariance: the reduced normal matrix is not positive definite"};
+            if (!blas) {     // (created on first use: rocblas_create_handle costs 0.1 s, and only the dense inverse needs it)
+                if (rocblas_create_handle(&blas) != rocblas_status_success) throw DeviceError{"rocblas_create_handle failed"};
+                rocblas_set_stream(blas, stream);
+            }
+            if (rocsolver_dpotri(blas, rocblas_fill_lower, (rocblas_int)P.NS, S, (rocblas_int)ldS, info.p) != rocblas_status_success)
+                throw DeviceError{"rocsolver_dpotri failed"};
+            SV.dense = S; SV.ld = ldS;
         }
-        if (rocsolver_dpotri(blas, rocblas_fill_lower, (rocblas_int)P.NS, S, (rocblas_int)ldS, info.p) != rocblas_status_success)
-            throw DeviceError{"rocsolver_dpotri failed"};
         have_lin = false;
         const double s02 = s0 * s0;
         prep_cams(z.p);
@@ -995,19 +1011,19 @@ struct Core {
         if (hCIO && P.nIOu > 0) dCIO.alloc((size_t)P.nIOu * P.nIOu);
         if (hCEO || (hCIO && P.nIOu > 0)) {
             const int64_t tot = 36 * (int64_t)P.nc + (int64_t)P.nIOu * P.nIOu;
-            LAUNCHK(k_cov_cam, dim3((unsigned)cdiv(tot, 256)), dim3(256), 0, stream, d, S, s02, dCEO.p, dCIO.p);
+            LAUNCHK(k_cov_cam, dim3((unsigned)cdiv(tot, 256)), dim3(256), 0, stream, d, SV, s02, dCEO.p, dCIO.p);
         }
         if (hCOP) {
             dCOP.alloc((size_t)9 * P.np);
             HIPCHK(hipMemsetAsync(dCOP.p, 0, (size_t)9 * P.np * sizeof(double), stream));
             const size_t lds_cov = ((size_t)P.BT * P.ncolmax * 3 + (size_t)P.BT * 6) * sizeof(double);
             if (nb > 0) {
-#define L_COV(M, IO) LAUNCHK((k_cov_points<M, IO>), dim3((unsigned)nb), dim3(P.BT), lds_cov, stream, d, z.p, cams.p, Vinv.p, S, s02, dCOP.p)
+#define L_COV(M, IO) LAUNCHK((k_cov_points<M, IO>), dim3((unsigned)nb), dim3(P.BT), lds_cov, stream, d, z.p, cams.p, Vinv.p, SV, s02, dCOP.p)
                 if (P.with_io) { DISPATCH_MODEL(L_COV, true) } else { DISPATCH_MODEL(L_COV, false) }
 #undef L_COV
             }
             if (ngiant > 0) {
-#define L_COVG(M, IO) LAUNCHK((k_cov_giant<M, IO>), dim3((unsigned)ngiant), dim3(giant_threads), 0, stream, d, z.p, cams.p, Vinv.p, S, s02, dCOP.p)
+#define L_COVG(M, IO) LAUNCHK((k_cov_giant<M, IO>), dim3((unsigned)ngiant), dim3(giant_threads), 0, stream, d, z.p, cams.p, Vinv.p, SV, s02, dCOP.p)
                 if (P.with_io) { DISPATCH_MODEL(L_COVG, true) } else { DISPATCH_MODEL(L_COVG, false) }
 #undef L_COVG
             }

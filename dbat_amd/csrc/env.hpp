@@ -40,6 +40,7 @@ static const EnvSwitch kEnvSwitches[] = {
     {"DBAT_HIP_DF_CHAIN", false, "factorisation: 0 = diagonal tiles as ordinary tasks (no chain role), 1 = chain role whatever the pattern", "0|1"},
     {"DBAT_HIP_DF_CHAIN_WG", false, "factorisation: workgroups of the chain role at most (default 32)"},
     {"DBAT_HIP_DF_L2", false, "factorisation: 1 = finished tiles of the compact layout are read through the L2", "0|1"},
+    {"DBAT_HIP_COV_DENSE", false, "posterior covariance: the dense inverse of the reduced system (rocsolver_dpotri) instead of the selected inversion"},
     {"DBAT_HIP_SPRANK_OFF", false, "structural rank from the counting conditions only"},
     {"DBAT_HIP_PLAN_THREADS", false, "threads of the host plan (default: hardware concurrency, at most 32)"},
     {"DBAT_HIP_PLAN_GRAIN", false, "elements per thread below which a pass of the host plan is not split (tests: 1)"},

@@ -2317,14 +2317,28 @@ __global__ __launch_bounds__(768) void k_build_tile3(DevProblem d, const double 
 // bundle_cov.m: blocks of C = s0^2 inv(J'J).  With the points eliminated,
 //   inv(J'J)[cams, cams] = inv(S)                         (CEO, CIO)
 //   inv(J'J)[p, p]       = V_p^-1 + Y_p' inv(S) Y_p,  Y_p = W_p V_p^-1  (COP)
-// Sinv holds the lower triangle of inv(S) (column-major, leading dimension ldS).
-__device__ __forceinline__ double sym_at(const double *Sinv, int64_t ldS, int r, int c) {
-    return r >= c ? Sinv[(int64_t)c * ldS + r] : Sinv[(int64_t)r * ldS + c];
+// inv(S) comes in one of two forms (SinvView):
+//   dense   the lower triangle of inv(S), column-major with leading dimension ld (rocsolver_dpotri on the in-place factor:
+//           several ranks, shared EO blocks, or a caller who wants the whole inverse);
+//   tiles   the entries of inv(S) ON THE PATTERN OF THE FACTOR only -- compact 64 x 64 tiles in the nested-dissection order
+//           of the dataflow Cholesky, from the selected inversion of chol_df.hpp (DataflowChol::selected_inverse).  Everything
+//           the covariance blocks need lies on that pattern: the cameras' own blocks, the IO block, and the blocks of camera
+//           pairs that see a common object point.
+struct SinvView {
+    const double *dense = nullptr; int64_t ld = 0;
+    const double *tiles = nullptr; const int64_t *toff = nullptr; const int *perm = nullptr; int nT = 0;
+};
+__device__ __forceinline__ double sym_at(const SinvView &V, int64_t /*unused*/, int r, int c) {
+    if (V.dense) return r >= c ? V.dense[(int64_t)c * V.ld + r] : V.dense[(int64_t)r * V.ld + c];
+    const int pr = V.perm[r], pc = V.perm[c];
+    const int i = max(pr, pc), j = min(pr, pc);
+    const int64_t off = V.toff[(int64_t)(i >> 6) * V.nT + (j >> 6)];
+    return off < 0 ? 0.0 : V.tiles[off + (int64_t)(j & 63) * 64 + (i & 63)];      // (diagonal tiles hold both triangles)
 }
 
 // CEO: 6x6 block per image (zero rows/columns for fixed elements); CIO: the
 // nIOu x nIOu block of the IO unknowns.
-__global__ void k_cov_cam(DevProblem d, const double *__restrict__ Sinv, double s02, double *__restrict__ CEO,
+__global__ void k_cov_cam(DevProblem d, const SinvView Sinv, double s02, double *__restrict__ CEO,
                           double *__restrict__ CIO) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t nE = 36 * (int64_t)d.nc, nI = (int64_t)d.nIOu * d.nIOu;
@@ -2346,7 +2360,7 @@ template <int MODEL, bool WITH_IO>
 __global__ __launch_bounds__(256) void k_cov_points(DevProblem d, const double *__restrict__ z,
                                                     const CamRec *__restrict__ cams,
                                                     const double *__restrict__ Vinv,
-                                                    const double *__restrict__ Sinv, double s02,
+                                                    const SinvView Sinv, double s02,
                                                     double *__restrict__ COP) {
     constexpr int NCX = WITH_IO ? MAXCOL : 6;
     extern __shared__ double smem[];
@@ -2429,7 +2443,7 @@ __global__ __launch_bounds__(256) void k_cov_points(DevProblem d, const double *
 template <int MODEL, bool WITH_IO>
 __global__ __launch_bounds__(256) void k_cov_giant(DevProblem d, const double *__restrict__ z,
                                                    const CamRec *__restrict__ cams,
-                                                   const double *__restrict__ Vinv, const double *__restrict__ Sinv,
+                                                   const double *__restrict__ Vinv, const SinvView Sinv,
                                                    double s02, double *__restrict__ COP) {
     constexpr int NCX = WITH_IO ? MAXCOL : 6;
     __shared__ double sh[6 * 4];

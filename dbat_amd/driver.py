@@ -210,36 +210,65 @@ def bundle(s, *args, device=None, comm=None, store_trace=True, jacobian=False, d
         h.close()
 
 
+CXX_MAX_N = 6000       # unknowns up to which bundle_cov offers the dense matrices 'CXX' / 'COPF' (288 MB)
+
+
 def bundle_cov(s, E, *names, device=0):
     """C = bundle_cov(s, E, 'CIO' | 'CEO' | 'COP' | 'CIOF' | 'CEOF', ...)
     (bundle/bundle_cov.m:1-31): sigma0^2 times blocks of inv(J'J) at the
     bundle result (s, E) as scipy sparse matrices of size numel(val) x
     numel(val), zero-padded for elements that were not estimated; 'CIO',
     'CEO', 'COP' keep the per-column diagonal blocks only (:9-16), 'CIOF' and
-    'CEOF' are the full component matrices.  'CXX' and 'COPF' (n x n resp.
-    3np x 3np dense results) are not offered by the GPU path.
-    Everything is computed on the device from the Schur blocks
-    (dbat_hip_posterior_cov); this function only scatters the blocks."""
+    'CEOF' are the full component matrices.  The blocks come from the device
+    (dbat_hip_posterior_cov: Schur pieces and a selected inversion of the compact
+    factor); this function only scatters them.
+    'CXX' (n x n, not zero-padded) and 'COPF' (3np x 3np) are dense by nature
+    ("may require a lot of memory", bundle_cov.m:24): offered up to CXX_MAX_N
+    unknowns -- the sizes the reference's own callers use them at -- from the
+    weighted Jacobian of the device (dbat_hip_jacobian_csc) by one dense
+    factorisation on the host, as bundle_cov.m:63-117 does it in MATLAB."""
     import scipy.sparse as sp
     names = [n.lower() for n in names]
     for n in names:
-        if n in ('cxx', 'copf'):
-            raise BadInput("bundle_cov: '%s' is not offered by the GPU path" % n.upper())
-        if n not in ('cio', 'ceo', 'cop', 'ciof', 'ceof'):
+        if n not in ('cio', 'ceo', 'cop', 'ciof', 'ceof', 'cxx', 'copf'):
             raise BadInput("Bad covariance string '%s'" % n)          # bundle_cov.m:53-55
     if not names:
         return None
+    dense = [n for n in names if n in ('cxx', 'copf')]
     h = _hip.Handle(s, device=device)
     try:
-        full = any(n.endswith('f') for n in names)
-        res = h.posterior_cov(np.asarray(E.x, float), float(E.s0), want_sinv=full)
-        CEOb, CIOu, COPb = res[:3]
+        if dense and h.n > CXX_MAX_N:
+            raise BadInput("bundle_cov: '%s' is an n x n dense matrix and n = %d (offered up to %d unknowns; "
+                           "'CIO', 'CEO', 'COP' give the blocks at any size)" % (dense[0].upper(), h.n, CXX_MAX_N))
+        CXX = None
+        if dense:
+            J = h.jacobian_csc(np.asarray(E.x, float), True)
+            N = (J.T @ J).toarray()
+            import scipy.linalg as sla
+            c, low = sla.cho_factor(N, lower=True)           # (fails loudly if J'J is not positive definite)
+            CXX = float(E.s0) ** 2 * sla.cho_solve((c, low), np.eye(N.shape[0]))
+        blocks = [n for n in names if n not in dense]
+        res = None
+        if blocks:
+            full = any(n.endswith('f') for n in blocks)
+            res = h.posterior_cov(np.asarray(E.x, float), float(E.s0), want_sinv=full)
+            CEOb, CIOu, COPb = res[:3]
         ixIO, ixEO, ixOP = h.index_maps()                   # x index of every array entry, -1 = no unknown
         nc = s.EO.val.shape[1]
     finally:
         h.close()
     out = []
     for n in names:
+        if n == 'cxx':
+            out.append(CXX)
+            continue
+        if n == 'copf':                                      # zero-padded: rows / columns of coordinates that are not estimated
+            ix = ixOP.flatten('F')
+            est = np.flatnonzero(ix >= 0)
+            D = np.zeros((ix.size, ix.size))
+            D[np.ix_(est, est)] = CXX[np.ix_(ix[est], ix[est])]
+            out.append(sp.csc_matrix(D))
+            continue
         comp = n[1:3].upper()
         val = getattr(s, comp).val
         m, ncol = val.shape

@@ -312,3 +312,35 @@ def test_deterministic_mode_at_bench_size(hip, name):
         assert t_det < 2.0 * t_def, (t_det, t_def)
     finally:
         h.close()
+
+
+@pytest.mark.parametrize('name', ['C2', 'C3'])
+def test_posterior_covariance_selected_inverse_at_bench_size(hip, name, monkeypatch):
+    """the covariance blocks with inv(S) from the SELECTED INVERSION of the compact nested-dissection
+    factor (chol_df.hpp; Takahashi's recurrence over the tile pattern, the algorithm of the reference's
+    code/test/sparseinv/sparseinv.c) against the same blocks from the dense inverse of the reduced system
+    (rocsolver_dpotri on the in-place factor) -- two independent routes to bundle_cov.m:63-117's 'CEO' / 'CIO' / 'COP'."""
+    import time
+    from dbat_amd import synth
+    s, _ = synth.make_scene(name)
+    h = hip.Handle(s)
+    try:
+        x0 = h.serialize()
+        opt = hip.default_options('gna')
+        opt.store_trace = 0
+        x, res, rr, damp, aux, T = h.solve(x0, opt)
+        assert res.code == 0
+        t0 = time.perf_counter()
+        a = h.posterior_cov(x, float(res.sigma0))
+        t_sel = time.perf_counter() - t0
+        monkeypatch.setenv('DBAT_HIP_COV_DENSE', '1')
+        t0 = time.perf_counter()
+        b = h.posterior_cov(x, float(res.sigma0))
+        t_dense = time.perf_counter() - t0
+        print('%s posterior covariance: selected inversion %.1f ms, dense inverse %.1f ms' % (name, t_sel * 1e3, t_dense * 1e3))
+        for A, B in zip(a[:3], b[:3]):
+            if B is None or np.size(B) == 0:
+                continue
+            assert np.abs(np.asarray(A) - np.asarray(B)).max() <= 1e-8 * np.abs(np.asarray(B)).max()
+    finally:
+        h.close()

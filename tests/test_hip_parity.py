@@ -818,6 +818,13 @@ def test_posterior_covariance_camcal_known_answer(hip, model):
         assert abs(A - B).max() <= 1e-6 * abs(B).max()
     CEOF = bundle_cov(res, E, 'CEOF')
     assert abs(CEOF - o.bundle_cov(ro, Eo, 'CEOF')).max() <= 1e-6 * abs(CEOo).max()
+    # 'CXX' and 'COPF' (bundle_cov.m:18-24), offered at the sizes the reference's callers use them at
+    CXX, COPF = bundle_cov(res, E, 'CXX', 'COPF')
+    CXXo, COPFo = o.bundle_cov(ro, Eo, 'CXX', 'COPF')
+    assert CXX.shape == CXXo.shape and abs(CXX - CXXo).max() <= 1e-6 * abs(CXXo).max()
+    assert abs(COPF - COPFo).max() <= 1e-6 * abs(COPFo).max()
+    # ... and the diagonal blocks of the full matrix are the blocks the device computes by selected inversion
+    assert abs(COPF.multiply(COP != 0) - COP).max() <= 1e-8 * abs(COP).max()
 
 
 @pytest.mark.parametrize('variant', ['plain', 'selfcal', 'imagevar', 'priors', 'groups4'])
@@ -837,12 +844,16 @@ def test_posterior_covariance_synthetic(hip, variant):
             assert abs(A).max() == 0
 
 
-def test_posterior_covariance_C1_sampled(hip):
+@pytest.mark.parametrize('dense', [False, True])
+def test_posterior_covariance_C1_sampled(hip, dense, monkeypatch):
     """100 cams / 10k pts: blocks of inv(J'J) for a sample of points and images
     from sparse direct solves with unit vectors (the oracle's dense inverse
-    would need 7.5 GB) against the device's Schur-block formulation."""
+    would need 7.5 GB) against the device's Schur-block formulation -- with inv(S) from the selected inversion of the
+    compact nested-dissection factor (the default on one rank) and from the dense inverse (DBAT_HIP_COV_DENSE)."""
     import scipy.sparse.linalg as spl
     from dbat_amd import bundle, bundle_cov
+    if dense:
+        monkeypatch.setenv('DBAT_HIP_COV_DENSE', '1')
     s, truth = synth_struct('C1', 'plain')
     res, ok, iters, s0, E = bundle(s, 'gna')
     assert ok
