@@ -108,6 +108,7 @@ SYMBOLS = {
     'dbat_hip_gradient': (C.c_int, [_H, _dp]),
     'dbat_hip_colnorms': (C.c_int, [_H, _dp]),
     'dbat_hip_jtimes_sqnorm': (C.c_int, [_H, _dp, _dp]),
+    'dbat_hip_jtimes': (C.c_int, [_H, _dp, _dp]),
     'dbat_hip_solve': (C.c_int, [_H, C.POINTER(Options), _dp, C.POINTER(Result), _dp, _dp, _dp, _dp]),
     'dbat_hip_final_residuals': (C.c_int, [_H, _dp, _dp]),
     'dbat_hip_comm_unique_id': (C.c_int, [_bp]),
@@ -347,6 +348,13 @@ class Handle:
         out = C.c_double(0)
         check(self.lib.dbat_hip_jtimes_sqnorm(self.h, dptr(v), C.byref(out)))
         return out.value
+
+    def jtimes(self, v):
+        """J v at the last linearisation point: m weighted rows in the reference's row order."""
+        v = np.ascontiguousarray(v, float)
+        out = np.zeros(self.m)
+        check(self.lib.dbat_hip_jtimes(self.h, dptr(v), dptr(out)))
+        return out
 
     def solve(self, x0, opt):
         x = np.ascontiguousarray(x0, float).copy()

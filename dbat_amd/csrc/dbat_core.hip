@@ -1758,6 +1758,37 @@ int dbat_hip_jtimes_sqnorm(dbat_hip_handle *h, const double *v, double *sqnorm) 
     API_CATCH
 }
 
+int dbat_hip_jtimes(dbat_hip_handle *h, const double *v, double *Jv) {
+    API_TRY
+    if (!h || !v || !Jv || !h->core->have_lin) { g_err = "no linearisation"; return DBAT_HIP_EINVAL; }
+    Core &c = *h->core;
+    const Plan &P = c.P;
+    if (P.nranks > 1) { g_err = "dbat_hip_jtimes: one-rank handles only"; return DBAT_HIP_EUNSUPPORTED; }
+    DeviceGuard dev_guard(c.device);
+    c.ensure_build();                                 // (a linearisation the damping loop left to whoever needs it)
+    HIPCHK(hipMemsetAsync(c.vtmp.p, 0, P.NZ * 8, c.stream));
+    if (P.n) {
+        HIPCHK(hipMemcpyAsync(c.xbuf.p, v, P.n * 8, hipMemcpyHostToDevice, c.stream));
+        LAUNCHK(k_scatter_x, dim3((unsigned)cdiv(P.n, 256)), dim3(256), 0, c.stream, P.n, c.x2z.p, c.xbuf.p, c.vtmp.p);
+    }
+    if (!c.cams_at_lin) { c.prep_cams(c.zlin.p); c.cams_at_lin = true; }
+    DevBuf<double> out;
+    out.alloc(2 * std::max<int64_t>(P.no, 1));
+    if (c.nobs > 0) {
+#define L_JTV(M, NCXV) LAUNCHK((k_jtimes_vec<M, NCXV>), dim3((unsigned)cdiv(c.nobs, 256)), dim3(256), 0, c.stream, c.d, c.zlin.p, c.cams.p, (const double *)c.vtmp.p, out.p)
+        if (c.tile_ncx == 6) { DISPATCH_MODEL(L_JTV, 6) } else if (c.tile_ncx == 14) { DISPATCH_MODEL(L_JTV, 14) } else if (c.tile_ncx == 15) { DISPATCH_MODEL(L_JTV, 15) } else { DISPATCH_MODEL(L_JTV, MAXCOL) }
+#undef L_JTV
+    }
+    std::vector<double> vz(P.NZ);
+    HIPCHK(hipMemcpyAsync(Jv, out.p, 2 * P.no * 8, hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipMemcpyAsync(vz.data(), c.vtmp.p, P.NZ * 8, hipMemcpyDeviceToHost, c.stream));
+    c.sync();
+    int64_t row = 2 * P.no;                                  // prior rows: selection rows of I, weighted (prior_obs.m:45-72)
+    for (int64_t zi : P.prior_z) Jv[row++] = vz[zi] * std::sqrt(P.z_prw[zi]);
+    return DBAT_HIP_OK;
+    API_CATCH
+}
+
 int dbat_hip_solve(dbat_hip_handle *h, const dbat_hip_options *opt, double *x, dbat_hip_result *result,
                    double *res, double *damp, double *aux, double *trace) {
     API_TRY

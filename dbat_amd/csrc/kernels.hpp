@@ -2827,6 +2827,31 @@ __global__ __launch_bounds__(256) void k_jtimes(DevProblem d, const double *__re
     if (threadIdx.x == 0) { partial[2 * blockIdx.x] = acc[0]; partial[2 * blockIdx.x + 1] = acc[1]; }
 }
 
+// J v of the image rows as a VECTOR (weighted, chol(W) J as the solvers see it), in the reference's row order
+// (multi_res.m:143-144,297: image-major, ascending object point, x / y interleaved): what termFun(Jp, r) of
+// bundle.m:186-192 / gauss_newton_armijo.m:187 receives.
+template <int MODEL, int NCXT>
+__global__ __launch_bounds__(256) void k_jtimes_vec(DevProblem d, const double *__restrict__ z, const CamRec *__restrict__ cams,
+                                                    const double *__restrict__ v, double *__restrict__ Jv) {
+    constexpr int NCX = NCXT;
+    constexpr bool WITH_IO = NCXT > 6;
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= d.nobs) return;
+    const int cam = d.o_cam[o], pt = d.o_pt[o];
+    const CamRec &C = cams[cam];
+    const int ncol = WITH_IO ? min(C.ncol, NCX) : 6;
+    double r[2], E[2][NCX], B[2][3];
+    eval_obs_cols_n<MODEL, NCX>(d, C, z, o, pt, r, E, B);
+    const double *vp = v + d.NS + 3 * (int64_t)pt;
+    double j0 = B[0][0] * vp[0] + B[0][1] * vp[1] + B[0][2] * vp[2];
+    double j1 = B[1][0] * vp[0] + B[1][1] * vp[1] + B[1][2] * vp[2];
+#pragma unroll
+    for (int a = 0; a < NCX; ++a)
+        if (a < ncol) { const double vc = v[C.col[a]]; j0 += E[0][a] * vc; j1 += E[1][a] * vc; }
+    const int64_t row = d.o_row[o];
+    Jv[2 * row] = j0; Jv[2 * row + 1] = j1;
+}
+
 // {prior rows' share of ||Jv||^2, r'Jv of ALL rows, ||v||^2 (owned)}: out[3] per block.
 // r'Jv = (J'r)'v = g'v with the gradient of the last linearisation (g_c incl. the camera/IO
 // priors, g_p incl. the point priors): no pass over the observations, no stored residual.

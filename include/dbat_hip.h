@@ -222,6 +222,11 @@ int  dbat_hip_gradient(dbat_hip_handle *h, double *g);
 int  dbat_hip_colnorms(dbat_hip_handle *h, double *Jn);
 /* ||J*v||^2 at the last linearisation point (Jp, dog-leg g'J'Jg: lmp.m:304-311) */
 int  dbat_hip_jtimes_sqnorm(dbat_hip_handle *h, const double *v, double *sqnorm);
+/* J*v itself at the last linearisation point: n_residuals weighted rows in the reference's row order (image rows, then the
+ * prior rows) -- the vector termFun(Jp, r) of bundle.m:186-192 / gauss_newton_armijo.m:187 receives; a caller with a
+ * termination test of its own runs the loop through dbat_hip_linearize_solve and evaluates it on this (the built-in loops
+ * only need ||Jp||: dbat_hip_jtimes_sqnorm).  One-rank handles only. */
+int  dbat_hip_jtimes(dbat_hip_handle *h, const double *v, double *Jv);
 
 /* The same for a SAMPLE of the image observations -- n IP columns ip_col[i] (0-based, reference order) -- so that
  * the model of a problem with 10^7 ... 10^8 observations can be checked without exporting 12 doubles for each:

@@ -168,6 +168,7 @@ def test_step_parity(hip, name, make):
         v = np.random.default_rng(2).standard_normal(len(x0))
         Jv = J @ v
         assert abs(h.jtimes_sqnorm(v) - Jv @ Jv) <= 1e-10 * (Jv @ Jv)
+        assert relerr(h.jtimes(v), Jv) < 1e-10           # J v itself, in the reference's row order (termFun's first argument)
         # damped, unscaled step (levenberg_marquardt.m:119)
         JTJ = (J.T @ J).tocsc()
         lam = 1e-4 * JTJ.diagonal().sum() / J.shape[1]
