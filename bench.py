@@ -204,6 +204,8 @@ def main():
             error_line(args, '%d rank(s) but %d HIP device(s) visible: the dbat_hip core has no CPU path, and every rank '
                              'needs its own GPU (DBAT_BENCH_HOST_ALLREDUCE=1: ranks share the devices that exist)' % (world, ndev),
                        visible_devices=ndev)
+        else:
+            time.sleep(3.0)          # the launcher ends every rank at the first exit: let rank 0's line out first
         raise SystemExit(2)
     # DBAT_BENCH_HOST_ALLREDUCE=1: the sums over the ranks go through host memory and the control-plane group
     # (gloo) instead of RCCL, and the ranks share the GPUs that exist -- the whole multi-process path (launcher,

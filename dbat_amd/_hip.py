@@ -24,7 +24,7 @@ if LIB_PATH != os.path.join(_HERE, 'libdbat_hip.so'):
     # never silently: a stale development build must not stand in for the product library in a test or bench run
     sys.stderr.write('[dbat_amd] DBAT_AMD_LIB: loading %s instead of the product library\n' % LIB_PATH)
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 DAMP = {'none': 0, 'gm': 0, 'gna': 1, 'lm': 2, 'lmp': 3}
 
 OK, EINVAL, EUNSUPPORTED, EDEVICE, ENOMEM = 0, -101, -102, -103, -104
@@ -67,7 +67,12 @@ class Options(C.Structure):
         ('mu', C.c_double), ('alpha_min', C.c_double), ('lambda0', C.c_double),
         ('lambda_min', C.c_double), ('rho_bad', C.c_double), ('rho_good', C.c_double),
         ('delta0', C.c_double),
+        ('term_fun', C.c_void_p), ('term_user', C.c_void_p), ('veto_fun', C.c_void_p), ('veto_user', C.c_void_p),
     ]
+
+
+TERM_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, _dp, _dp, C.c_int64)   # dbat_hip_term_fn
+VETO_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, _dp, C.c_int64)        # dbat_hip_veto_fn
 
 
 class Result(C.Structure):
@@ -356,8 +361,37 @@ class Handle:
         check(self.lib.dbat_hip_jtimes(self.h, dptr(v), dptr(out)))
         return out
 
-    def solve(self, x0, opt):
+    def solve(self, x0, opt, term_fun=None, veto_fun=None):
+        """term_fun(Jp, r) -> bool and veto_fun(x) -> bool: the caller's own tests (bundle.m:168-192), called from the
+        damping loop with numpy views of the library's vectors; an exception inside one ends the run and is re-raised."""
         x = np.ascontiguousarray(x0, float).copy()
+        raised = []
+
+        def guarded(fn, *views):
+            if raised:
+                return 1
+            try:
+                return int(bool(fn(*views)))
+            except BaseException as e:          # (never unwind through the C frames)
+                raised.append(e)
+                return 1
+        keep = []
+        if term_fun is not None:
+            keep.append(TERM_FN(lambda _u, Jp, r, m: guarded(term_fun, np.ctypeslib.as_array(Jp, (m,)).copy(),
+                                                             np.ctypeslib.as_array(r, (m,)).copy())))
+            opt.term_fun = C.cast(keep[-1], C.c_void_p)
+        if veto_fun is not None:
+            keep.append(VETO_FN(lambda _u, xx, n: guarded(veto_fun, np.ctypeslib.as_array(xx, (n,)).copy())))
+            opt.veto_fun = C.cast(keep[-1], C.c_void_p)
+        try:
+            return self._solve(x, opt, raised)
+        finally:
+            if term_fun is not None:
+                opt.term_fun = None
+            if veto_fun is not None:
+                opt.veto_fun = None
+
+    def _solve(self, x, opt, raised):
         res = Result()
         mi = opt.max_iter
         rr = np.full(mi + 3, np.nan)
@@ -366,6 +400,8 @@ class Handle:
         trace = np.full(self.n * (mi + 2), np.nan) if opt.store_trace else None
         check(self.lib.dbat_hip_solve(self.h, C.byref(opt), dptr(x), C.byref(res), dptr(rr),
                                       dptr(damp), dptr(aux), dptr(trace)))
+        if raised:
+            raise raised[0]
         T = (trace[:self.n * res.n_trace].reshape(self.n, res.n_trace, order='F')
              if trace is not None else None)
         return x, res, rr[:res.n_res], damp[:res.n_damp], aux, T

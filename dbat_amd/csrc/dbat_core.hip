@@ -1086,11 +1086,33 @@ struct LoopOut {
     double f_final = 0;
 };
 
-static bool term_fun(const dbat_hip_options &o, double JpJp, double f) {
+static void export_residuals(Core &c, const double *zdev, double *r_unw, double *r_wgt, double *f);
+static void jtimes_rows(Core &c, const double *v_dev, double *Jv);
+
+// J*p as a host vector for a caller-supplied termFun: taken right after the solve, at the linearisation that produced p
+// (levenberg_marquardt.m:217 tests the OLD Jp against the NEW r)
+static void keep_Jp(Core &c, const dbat_hip_options &o, const double *p_dev, std::vector<double> &Jp) {
+    if (!o.term_fun) return;
+    Jp.resize((size_t)c.P.m);
+    jtimes_rows(c, p_dev, Jp.data());
+}
+static bool term_fun(Core &c, const dbat_hip_options &o, double JpJp, double f, const std::vector<double> &Jp) {
+    if (o.term_fun) {                                // termFun(Jp, r), r = the weighted residual at the current point
+        std::vector<double> r((size_t)c.P.m);
+        export_residuals(c, c.z.p, nullptr, r.data(), nullptr);
+        return o.term_fun(o.term_user, Jp.data(), r.data(), c.P.m) != 0;
+    }
     // bundle.m:186-192: relative  norm(Jp)<=tol*norm(r) ; absolute norm(r)<=tol
     const double nr = std::sqrt(2 * f);
     if (o.abs_term) return nr <= o.conv_tol;
     return std::sqrt(JpJp) <= o.conv_tol * nr;
+}
+// vetoFun(t) at the trial point c.zt
+static bool vetoed(Core &c, const dbat_hip_options &o) {
+    if (!o.veto_fun) return false;
+    std::vector<double> x((size_t)c.P.n);
+    c.z_to_x(c.zt.p, x.data());
+    return o.veto_fun(o.veto_user, x.data(), c.P.n) != 0;
 }
 
 static void push_trace(Core &c, const dbat_hip_options &o, LoopOut &out) {
@@ -1109,6 +1131,7 @@ static void push_trace(Core &c, const dbat_hip_options &o, LoopOut &out) {
 // lsa/gauss_newton_armijo.m:86-245, linesearch :249-290
 static void loop_gna(Core &c, const dbat_hip_options &o, LoopOut &out) {
     int n = 0;
+    std::vector<double> Jp_host;
     push_trace(c, o, out);
     double f = c.eval_f(c.z.p, nullptr, nullptr);
     while (true) {
@@ -1118,7 +1141,8 @@ static void loop_gna(Core &c, const dbat_hip_options &o, LoopOut &out) {
         double JpJp, rJp, pp;
         const bool failed = c.solve(JpJp, rJp, pp);               // :172-174
         if (failed || (o.singular_test && c.near_singular)) { out.code = -2; break; }  // :176-184
-        if (term_fun(o, JpJp, f)) break;                          // :191
+        keep_Jp(c, o, c.dz.p, Jp_host);
+        if (term_fun(c, o, JpJp, f, Jp_host)) break;              // :191
         ++n;
         // linesearch
         const double f0 = f, fp0 = rJp;
@@ -1126,7 +1150,7 @@ static void loop_gna(Core &c, const dbat_hip_options &o, LoopOut &out) {
         bool found = false;
         while (alpha >= o.alpha_min) {
             const double ft = c.eval_f_step(c.z.p, alpha, c.dz.p, c.zt.p);
-            if (ft < f0 + o.mu * alpha * fp0) { found = true; f = ft; break; }
+            if (ft < f0 + o.mu * alpha * fp0 && !vetoed(c, o)) { found = true; f = ft; break; }     // :265-281
             alpha /= 2;
         }
         if (!found) alpha = 0.0;
@@ -1143,6 +1167,7 @@ static void loop_gna(Core &c, const dbat_hip_options &o, LoopOut &out) {
 // lsa/gauss_markov.m:52-129 with the documented semantics
 static void loop_gm(Core &c, const dbat_hip_options &o, LoopOut &out) {
     int n = 0;
+    std::vector<double> Jp_host;
     push_trace(c, o, out);
     double f = 0;
     while (true) {
@@ -1152,7 +1177,8 @@ static void loop_gm(Core &c, const dbat_hip_options &o, LoopOut &out) {
         double JpJp, rJp, pp;
         const bool failed = c.solve(JpJp, rJp, pp);               // :79
         if (failed || (o.singular_test && c.near_singular)) { out.code = -2; break; }
-        if (term_fun(o, JpJp, f)) break;                          // :94
+        keep_Jp(c, o, c.dz.p, Jp_host);
+        if (term_fun(c, o, JpJp, f, Jp_host)) break;              // :94
         ++n;
         c.axpby(1.0, c.z.p, 1.0, c.dz.p, c.z.p);
         push_trace(c, o, out);
@@ -1185,10 +1211,12 @@ static void loop_lm(Core &c, const dbat_hip_options &o, LoopOut &out) {
     double prevLambda = NAN;
     double JpJp = 0, rJp = 0, pp = 0;
     std::vector<std::vector<double>> T;
+    std::vector<double> Jp_host;
     while (true) {
         while (n <= o.max_iter) {
             if (c.lambda_lin != lambda) c.build(c.z.p, lambda, 0, true);      // (JTJ+lambda*I), :119
             const bool failed = c.solve(JpJp, rJp, pp);
+            if (!failed) keep_Jp(c, o, c.dz.p, Jp_host);                      // :162 (Jp = J*p, before the trial point)
             out.res.push_back(std::sqrt(2 * f));
             if (n == 0 && !c.P.rank_ok) { out.code = -4; break; }             // :126-135
             if (failed) { out.code = -2; break; }   // the reference has no test here; MATLAB would continue on Inf/NaN
@@ -1196,7 +1224,7 @@ static void loop_lm(Core &c, const dbat_hip_options &o, LoopOut &out) {
             if (o.store_trace) { std::vector<double> x(c.P.n); c.z_to_x(c.z.p, x.data()); if ((int)T.size() <= n) T.resize(n + 1); T[n] = std::move(x); }
             ++n;
             const double fNew = c.eval_f_step(c.z.p, 1.0, c.dz.p, c.zt.p);                 // t = x+p
-            if (fNew < f) {
+            if (fNew < f && !vetoed(c, o)) {                                  // :170-177
                 c.accept_trial();
                 lambda = lambda / 10;
                 if (lambda < lambdaMin) lambda = 0;
@@ -1208,7 +1236,7 @@ static void loop_lm(Core &c, const dbat_hip_options &o, LoopOut &out) {
             }
         }
         if (out.code != 0) break;
-        if (prevLambda == 0 && term_fun(o, JpJp, f)) break;                   // :217 (old Jp, new r)
+        if (prevLambda == 0 && term_fun(c, o, JpJp, f, Jp_host)) break;       // :217 (old Jp, new r)
         prevLambda = lambda;
         if (n > o.max_iter) { out.code = -1; break; }
     }
@@ -1234,6 +1262,7 @@ static void loop_lmp(Core &c, const dbat_hip_options &o, double delta0, LoopOut 
     double f = c.eval_f(c.z.p, nullptr, nullptr);
     c.build(c.z.p, 0.0, 1);
     bool have_gn = false;
+    std::vector<double> Jp_host;
     double gnJpJp = 0, gnrJp = 0, gnpp = 0;
     double *pGN = c.vtmp.p, *g = c.vtmp2.p;
     while (true) {
@@ -1277,13 +1306,17 @@ static void loop_lmp(Core &c, const dbat_hip_options &o, double delta0, LoopOut 
         }
         out.damp.push_back(delta);
         steps.push_back(step);
-        if (step == 0 && term_fun(o, gnJpJp, f)) break;            // :134-140
+        if (step == 0) {
+            keep_Jp(c, o, c.dz.p, Jp_host);
+            if (term_fun(c, o, gnJpJp, f, Jp_host)) break;         // :134-140
+        }
         const double ft = c.eval_f_step(c.z.p, 1.0, c.dz.p, c.zt.p);
+        const bool veto = vetoed(c, o);                            // :146-150
         const double predicted = -rJp - 0.5 * JpJp;                // :153
         const double actual = f - ft;
         const double rho = actual / predicted;
         rhos.push_back(rho);
-        if (rho <= o.rho_bad) {                                    // :166-179
+        if (veto || rho <= o.rho_bad) {                            // :166-179
             delta = delta / 2;
             if (delta > npGN) delta = delta / std::exp2(std::ceil(std::log2(delta / npGN)));
         } else {
@@ -1338,6 +1371,7 @@ int dbat_hip_abi_version(void) { return DBAT_HIP_ABI_VERSION; }
 
 int dbat_hip_default_options(int32_t damping, dbat_hip_options *opt) {
     if (!opt || damping < 0 || damping > 3) { g_err = "bad damping"; return DBAT_HIP_EINVAL; }
+    opt->term_fun = nullptr; opt->term_user = nullptr; opt->veto_fun = nullptr; opt->veto_user = nullptr;
     opt->damping = damping; opt->max_iter = 20; opt->conv_tol = 1e-6; opt->abs_term = 0;
     opt->singular_test = 1; opt->store_trace = 1; opt->mu = 0.1; opt->alpha_min = 1e-9;
     opt->lambda0 = -1e-10; opt->lambda_min = -1e-10; opt->rho_bad = 0.25; opt->rho_good = 0.75;
@@ -1495,6 +1529,7 @@ int dbat_hip_structural_rank_ok(const dbat_hip_handle *h, int32_t *ok) {
     return DBAT_HIP_OK;
 }
 
+namespace dbat {
 static void export_residuals(Core &c, const double *zdev, double *r_unw, double *r_wgt, double *f) {
     // image rows via k_residual (reference row order), prior rows on the host
     DevBuf<double> tmp;
@@ -1532,6 +1567,7 @@ static void export_residuals(Core &c, const double *zdev, double *r_unw, double 
         ++row;
     }
 }
+}  // namespace dbat
 
 int dbat_hip_residual(dbat_hip_handle *h, const double *x, double *r_unweighted, double *f) {
     API_TRY
@@ -1758,6 +1794,28 @@ int dbat_hip_jtimes_sqnorm(dbat_hip_handle *h, const double *v, double *sqnorm) 
     API_CATCH
 }
 
+namespace dbat {
+// J v (v in z layout on the device) as host rows: image rows in the reference's order, then the prior rows -- at the
+// linearisation the handle holds (zlin)
+static void jtimes_rows(Core &c, const double *v_dev, double *Jv) {
+    const Plan &P = c.P;
+    if (!c.cams_at_lin) { c.prep_cams(c.zlin.p); c.cams_at_lin = true; }
+    DevBuf<double> out;
+    out.alloc(2 * std::max<int64_t>(P.no, 1));
+    if (c.nobs > 0) {
+#define L_JTV(M, NCXV) LAUNCHK((k_jtimes_vec<M, NCXV>), dim3((unsigned)cdiv(c.nobs, 256)), dim3(256), 0, c.stream, c.d, c.zlin.p, c.cams.p, v_dev, out.p)
+        if (c.tile_ncx == 6) { DISPATCH_MODEL(L_JTV, 6) } else if (c.tile_ncx == 14) { DISPATCH_MODEL(L_JTV, 14) } else if (c.tile_ncx == 15) { DISPATCH_MODEL(L_JTV, 15) } else { DISPATCH_MODEL(L_JTV, MAXCOL) }
+#undef L_JTV
+    }
+    std::vector<double> vz(P.NZ);
+    HIPCHK(hipMemcpyAsync(Jv, out.p, 2 * P.no * 8, hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipMemcpyAsync(vz.data(), v_dev, P.NZ * 8, hipMemcpyDeviceToHost, c.stream));
+    c.sync();
+    int64_t row = 2 * P.no;                                  // prior rows: selection rows of I, weighted (prior_obs.m:45-72)
+    for (int64_t zi : P.prior_z) Jv[row++] = vz[zi] * std::sqrt(P.z_prw[zi]);
+}
+}  // namespace dbat
+
 int dbat_hip_jtimes(dbat_hip_handle *h, const double *v, double *Jv) {
     API_TRY
     if (!h || !v || !Jv || !h->core->have_lin) { g_err = "no linearisation"; return DBAT_HIP_EINVAL; }
@@ -1771,20 +1829,7 @@ int dbat_hip_jtimes(dbat_hip_handle *h, const double *v, double *Jv) {
         HIPCHK(hipMemcpyAsync(c.xbuf.p, v, P.n * 8, hipMemcpyHostToDevice, c.stream));
         LAUNCHK(k_scatter_x, dim3((unsigned)cdiv(P.n, 256)), dim3(256), 0, c.stream, P.n, c.x2z.p, c.xbuf.p, c.vtmp.p);
     }
-    if (!c.cams_at_lin) { c.prep_cams(c.zlin.p); c.cams_at_lin = true; }
-    DevBuf<double> out;
-    out.alloc(2 * std::max<int64_t>(P.no, 1));
-    if (c.nobs > 0) {
-#define L_JTV(M, NCXV) LAUNCHK((k_jtimes_vec<M, NCXV>), dim3((unsigned)cdiv(c.nobs, 256)), dim3(256), 0, c.stream, c.d, c.zlin.p, c.cams.p, (const double *)c.vtmp.p, out.p)
-        if (c.tile_ncx == 6) { DISPATCH_MODEL(L_JTV, 6) } else if (c.tile_ncx == 14) { DISPATCH_MODEL(L_JTV, 14) } else if (c.tile_ncx == 15) { DISPATCH_MODEL(L_JTV, 15) } else { DISPATCH_MODEL(L_JTV, MAXCOL) }
-#undef L_JTV
-    }
-    std::vector<double> vz(P.NZ);
-    HIPCHK(hipMemcpyAsync(Jv, out.p, 2 * P.no * 8, hipMemcpyDeviceToHost, c.stream));
-    HIPCHK(hipMemcpyAsync(vz.data(), c.vtmp.p, P.NZ * 8, hipMemcpyDeviceToHost, c.stream));
-    c.sync();
-    int64_t row = 2 * P.no;                                  // prior rows: selection rows of I, weighted (prior_obs.m:45-72)
-    for (int64_t zi : P.prior_z) Jv[row++] = vz[zi] * std::sqrt(P.z_prw[zi]);
+    jtimes_rows(c, c.vtmp.p, Jv);
     return DBAT_HIP_OK;
     API_CATCH
 }
@@ -1795,6 +1840,7 @@ int dbat_hip_solve(dbat_hip_handle *h, const dbat_hip_options *opt, double *x, d
     if (!h || !opt || !x || !result) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
     if (opt->damping < 0 || opt->damping > 3) { g_err = "Unknown damping"; return DBAT_HIP_EINVAL; }
     if (opt->store_trace && !trace) { g_err = "store_trace without a trace buffer"; return DBAT_HIP_EINVAL; }
+    if (opt->term_fun && h->core->P.nranks > 1) { g_err = "term_fun: one-rank handles only (J*p rows stay with their shard)"; return DBAT_HIP_EUNSUPPORTED; }
     Core &c = *h->core;
     DeviceGuard dev_guard(c.device);
     c.n_res_evals = c.n_lin = c.n_solves = c.n_trace_only = 0;

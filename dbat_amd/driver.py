@@ -60,7 +60,8 @@ def _parse_args(args):
     return o
 
 
-def bundle(s, *args, device=None, comm=None, store_trace=True, jacobian=False, deterministic=False):
+def bundle(s, *args, device=None, comm=None, store_trace=True, jacobian=False, deterministic=False,
+           term_fun=None, veto_fun=None):
     """[s,ok,iters,s0,E] = bundle(s[,maxIter][,damping][,'trace'][,tol]
     [,'absterm'][,'singulartest'|'nosingulartest'][,veto][,'pmdof'][,'dofverb'])
 
@@ -70,6 +71,9 @@ def bundle(s, *args, device=None, comm=None, store_trace=True, jacobian=False, d
     problems.  `deterministic=True` sums the reduced system in a fixed order (dbat_hip_set_deterministic:
     two runs give the same bits; slower; signature-group path only).  `jacobian=True` also returns E.final.weighted.J and E.final.unweighted.J
     (scipy CSC, bundle.m:341-350) -- on request only, the solver never forms J.
+    `term_fun(Jp, r) -> bool` replaces the termination test bundle() builds (bundle.m:186-192) and `veto_fun(x) -> bool`
+    is the veto the lsa solvers call at every trial point (bundle.m:168-172 only ever passes the undefined `chirality`):
+    the two function handles of the reference's solver interface, for callers that used the solvers directly.
     """
     o = _parse_args(args)
     if o['veto']:
@@ -109,7 +113,7 @@ def bundle(s, *args, device=None, comm=None, store_trace=True, jacobian=False, d
         opt.abs_term = int(o['absTerm'])
         opt.singular_test = int(o['singularTest'])
         opt.store_trace = int(bool(store_trace))
-        x, res, rr, damp, aux, T = h.solve(x0, opt)      # complete on every rank of a sharded run
+        x, res, rr, damp, aux, T = h.solve(x0, opt, term_fun=term_fun, veto_fun=veto_fun)   # complete on every rank of a sharded run
         E = NS(maxIter=o['maxIter'], convTol=o['convTol'], absTerm=o['absTerm'],
                singularTest=o['singularTest'], chirality=False)
         name = 'gm' if o['damping'] in ('none', 'gm') else o['damping']

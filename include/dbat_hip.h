@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DBAT_HIP_ABI_VERSION 2   /* 2: dbat_hip_result grew (stage_s, n_trace_only); dbat_hip_info [16]; dbat_hip_bench_step ms[12] */
+#define DBAT_HIP_ABI_VERSION 3   /* 3: dbat_hip_options grew (term_fun, veto_fun); 2: dbat_hip_result grew (stage_s, n_trace_only); dbat_hip_info [16]; dbat_hip_bench_step ms[12] */
 
 /* error returns */
 #define DBAT_HIP_OK            0
@@ -93,6 +93,16 @@ typedef struct dbat_hip_problem {
 
 /* options = the varargin of bundle() (bundle.m:78-132) plus the constants
  * bundle.m hard-codes for each damping scheme (:281-283, :301-304, :321-325). */
+/* The caller's own tests, as bundle() hands them to the lsa solvers (bundle.m:168-192):
+ *   termFun(Jp, r) -> logical  (gauss_newton_armijo.m:187-191, levenberg_marquardt.m:217, levenberg_marquardt_powell.m:134-140):
+ *       Jp = J*p and r, both weighted, n_residuals rows in the reference's row order; != 0 ends the iteration (code 0);
+ *   vetoFun(x) -> logical  (gauss_newton_armijo.m:268-271, levenberg_marquardt.m:170-173, levenberg_marquardt_powell.m:146-166):
+ *       x = the trial point (n_params, reference order); != 0 rejects it.
+ * NULL (the default): the built-in tests of bundle.m:186-192 on ||Jp|| and ||r|| -- no vectors leave the device -- and no veto.
+ * With a termFun every termination test costs one pass for J*p, one for r and their copies to the host. */
+typedef int32_t (*dbat_hip_term_fn)(void *user, const double *Jp, const double *r, int64_t n_residuals);
+typedef int32_t (*dbat_hip_veto_fn)(void *user, const double *x, int64_t n_params);
+
 typedef struct dbat_hip_options {
     int32_t damping;        /* DBAT_HIP_DAMP_* ; default GNA (bundle.m:79) */
     int32_t max_iter;       /* 20   (bundle.m:78) */
@@ -107,6 +117,10 @@ typedef struct dbat_hip_options {
     double  rho_bad;        /* LMP 0.25 (bundle.m:321) */
     double  rho_good;       /* LMP 0.75 (bundle.m:322) */
     double  delta0;         /* LMP: <=0 => norm(x0) (bundle.m:325) */
+    dbat_hip_term_fn term_fun;  /* NULL: bundle.m:186-192 */
+    void   *term_user;
+    dbat_hip_veto_fn veto_fun;  /* NULL: no veto (bundle.m:168-172; the reference's own 'chirality' is undefined) */
+    void   *veto_user;
 } dbat_hip_options;
 
 /* what the lsa solvers return: [x,code,n,final,T,rr,extra...]

@@ -39,8 +39,11 @@ end
 %                 BUNDLE_COV 'CXX' / 'COPF' read them); default: only after a failed run, for the post-mortem
 %   wantCov       false: no posterior covariance blocks in s.post.cov (default true)
 %   deterministic true: fixed-order sums on the device (bit-identical runs)
+%   termFun       @(Jp,r) -> logical: replaces the termination test of bundle.m:186-192 (default [])
+%   vetoFun       @(x) -> logical: the veto the LSA functions call at each trial point (default []: none;
+%                 bundle.m:169 only knows the undefined CHIRALITY)
 hip=struct('device',0,'shardRank',0,'shardCount',1,'commId',uint8([]),'wantJ',false,'wantCov',true,...
-           'deterministic',false);
+           'deterministic',false,'termFun',[],'vetoFun',[]);
 if isfield(s.bundle,'hip') && ~isempty(s.bundle.hip)
     fn=fieldnames(s.bundle.hip);
     for i=1:length(fn)
@@ -75,7 +78,8 @@ wantJ=2; if hip.wantJ, wantJ=1; end   % 2: the gateway ships J only after code -
 opt=struct('damping',dampNo,'maxIter',maxIter,'convTol',convTol,'absTerm',absTerm,...
            'singularTest',singularTest,'trace',true,'wantJ',wantJ,'wantCov',logical(hip.wantCov),...
            'deterministic',logical(hip.deterministic),'device',hip.device,...
-           'shardRank',hip.shardRank,'shardCount',hip.shardCount,'commId',uint8(hip.commId));
+           'shardRank',hip.shardRank,'shardCount',hip.shardCount,'commId',uint8(hip.commId),...
+           'termFun',hip.termFun,'vetoFun',hip.vetoFun);
 [x,code,iters,s0,res,damp,aux,T,ru,rw,time,CEOb,CIOu,COPb,Jw,Ju]=dbat_hip_mex(P,opt);
 if doTrace   % the iteration trace the LSA functions print with 'trace'
     for i=1:length(res), fprintf('%s: iteration %d, residual norm %g\n',mfilename,i-1,res(i)); end

@@ -46,6 +46,34 @@ static mxArray *sparse_jacobian(dbat_hip_handle *h, const double *x, int weighte
     return J;
 }
 
+// A MATLAB function handle as a dbat_hip_term_fn / dbat_hip_veto_fn: feval(fh, args...) with errors trapped, so that
+// the handle is released before MATLAB unwinds.
+struct MatlabFn { const mxArray *fh; mxArray *error; };
+static int32_t call_handle(MatlabFn *f, int nargs, mxArray **args) {
+    if (f->error) return 1;
+    mxArray *in[3] = {const_cast<mxArray *>(f->fh), args[0], nargs > 1 ? args[1] : nullptr};
+    mxArray *out = nullptr;
+    f->error = mexCallMATLABWithTrap(1, &out, nargs + 1, in, "feval");
+    for (int i = 0; i < nargs; ++i) mxDestroyArray(args[i]);
+    if (f->error) return 1;                            // stop (termFun) / reject (vetoFun); rethrown after the solve
+    const int32_t v = out && !mxIsEmpty(out) && mxGetScalar(out) != 0;
+    if (out) mxDestroyArray(out);
+    return v;
+}
+static mxArray *column(const double *p, int64_t k) {
+    mxArray *a = mxCreateDoubleMatrix((mwSize)k, 1, mxREAL);
+    std::memcpy(mxGetDoubles(a), p, sizeof(double) * (size_t)k);
+    return a;
+}
+static int32_t call_term(void *user, const double *Jp, const double *r, int64_t m) {
+    mxArray *args[2] = {column(Jp, m), column(r, m)};
+    return call_handle(static_cast<MatlabFn *>(user), 2, args);
+}
+static int32_t call_veto(void *user, const double *x, int64_t n) {
+    mxArray *args[1] = {column(x, n)};
+    return call_handle(static_cast<MatlabFn *>(user), 1, args);
+}
+
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     if (nrhs == 1 && mxIsChar(prhs[0])) {          // dbat_hip_mex('commId')
         char what[16] = {0};
@@ -120,6 +148,16 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     opt.abs_term = (int32_t)scalar(O, "absTerm");
     opt.singular_test = (int32_t)scalar(O, "singularTest");
     opt.store_trace = (int32_t)scalar(O, "trace");
+    // the caller's own termFun(Jp,r) / vetoFun(x) (function handles; [] = the tests bundle.m:168-192 builds): called back on
+    // this thread, from inside dbat_hip_solve
+    MatlabFn term_cb{field(O, "termFun"), nullptr}, veto_cb{field(O, "vetoFun"), nullptr};
+    if (!mxIsEmpty(term_cb.fh)) { opt.term_fun = call_term; opt.term_user = &term_cb; }
+    if (!mxIsEmpty(veto_cb.fh)) { opt.veto_fun = call_veto; opt.veto_user = &veto_cb; }
+    for (const MatlabFn *f : {&term_cb, &veto_cb})
+        if (!mxIsEmpty(f->fh) && !mxIsClass(f->fh, "function_handle")) {
+            dbat_hip_destroy(h);
+            mexErrMsgIdAndTxt("DBAT:bundle:badInput", "opt.termFun / opt.vetoFun: a function handle or []");
+        }
     const int64_t n = dbat_hip_num_params(h), m = dbat_hip_num_residuals(h);
     const int mi = opt.max_iter;
     plhs[0] = mxCreateDoubleMatrix(n, 1, mxREAL);
@@ -134,6 +172,12 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
         dbat_hip_destroy(h);
         mexErrMsgIdAndTxt("DBAT:bundle:internal", "%s", dbat_hip_last_error());
     }
+    for (MatlabFn *f : {&term_cb, &veto_cb})
+        if (f->error) {                                // an error inside a callback ended the run: hand it on
+            dbat_hip_destroy(h);
+            mxArray *rethrow_in[1] = {f->error};
+            mexCallMATLAB(0, nullptr, 1, rethrow_in, "rethrow");
+        }
     auto vec = [](const double *p, int k) {
         mxArray *a = mxCreateDoubleMatrix(1, k, mxREAL);
         std::memcpy(mxGetDoubles(a), p, sizeof(double) * k);

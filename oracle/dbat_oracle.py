@@ -846,8 +846,8 @@ def _scaled_gn(J, r):
 
 
 def gauss_newton_armijo(resFun, x0, wdiag, maxIter, termFun, sTest=True,
-                        mu=0.1, alphaMin=1e-9, trace=False):
-    """bundle/lsa/gauss_newton_armijo.m:86-245 (+ linesearch :249-290)."""
+                        mu=0.1, alphaMin=1e-9, trace=False, vetoFun=None):
+    """bundle/lsa/gauss_newton_armijo.m:86-245 (+ linesearch :249-290; veto :268-283)."""
     x = x0.copy()
     T = [x0.copy()]
     n = 0
@@ -885,7 +885,7 @@ def gauss_newton_armijo(resFun, x0, wdiag, maxIter, termFun, sTest=True,
             t = x + alpha * p
             rt = wres(t)
             f = 0.5 * (rt @ rt)
-            if f < f0 + mu * alpha * fp0:
+            if f < f0 + mu * alpha * fp0 and not (vetoFun is not None and vetoFun(t)):   # :266-276
                 xNew, rNew = t, rt
                 found = True
                 break
@@ -908,7 +908,7 @@ def gauss_newton_armijo(resFun, x0, wdiag, maxIter, termFun, sTest=True,
 
 
 def levenberg_marquardt(resFun, x0, wdiag, maxIter, termFun, lambda0, lambdaMin,
-                        trace=False):
+                        trace=False, vetoFun=None):
     """bundle/lsa/levenberg_marquardt.m:52-250."""
     x = x0.copy()
     T = {}
@@ -954,7 +954,7 @@ def levenberg_marquardt(resFun, x0, wdiag, maxIter, termFun, lambda0, lambdaMin,
             t = x + p
             rNew = wres(t)
             fNew = 0.5 * (rNew @ rNew)
-            if fNew < f:
+            if fNew < f and not (vetoFun is not None and vetoFun(t)):      # :170-177
                 x = t
                 lam = lam / 10
                 if lam < lambdaMin:
@@ -1008,7 +1008,7 @@ def dogleg(r, J, delta):
 
 
 def levenberg_marquardt_powell(resFun, x0, wdiag, maxIter, termFun, delta0, mu,
-                               eta, trace=False):
+                               eta, trace=False, vetoFun=None):
     """bundle/lsa/levenberg_marquardt_powell.m:60-230."""
     x = x0.copy()
     T = {0: x0.copy()}
@@ -1038,6 +1038,7 @@ def levenberg_marquardt_powell(resFun, x0, wdiag, maxIter, termFun, delta0, mu,
         t = x + p
         rt = wres(t)
         ft = 0.5 * (rt @ rt)
+        veto = vetoFun is not None and bool(vetoFun(t))          # :146-150
         predicted = -(r @ Jp) - 0.5 * (Jp @ Jp)
         actual = f - ft
         rho = actual / predicted
@@ -1045,7 +1046,7 @@ def levenberg_marquardt_powell(resFun, x0, wdiag, maxIter, termFun, delta0, mu,
         if trace:
             print('Levenberg-Marquardt-Powell: iteration %d, residual norm=%.6g, '
                   'delta=%.3g, step=%d, rho=%.2f' % (n, rr[-1], delta, step, rho))
-        if rho <= mu:
+        if veto or rho <= mu:                                    # :166
             delta = delta / 2
             npgn = np.linalg.norm(pGN)
             if delta > npgn:
@@ -1111,9 +1112,12 @@ def gauss_markov(resFun, x0, wdiag, maxIter, termFun, sTest=True, trace=False):
 # F1: bundle driver
 # ----------------------------------------------------------------------------
 
-def bundle(s, *args):
+def bundle(s, *args, termFun=None, vetoFun=None):
     """bundle/bundle.m:1-132 (args), :156-192 (setup), :267-358 (dispatch),
     :449-491 (residual scatter, sigma0).
+
+    termFun / vetoFun: the two function handles bundle.m:168-192 builds and hands to the lsa solvers, replaceable here
+    so that the solvers' callback interface can be checked (the reference's own vetoFun, @chirality, is undefined).
 
     Returns (s, ok, iters, s0, E) like the reference.  `s` is a deep-ish copy
     with IO/EO/OP.val updated only when code==0 (bundle.m:356-358).
@@ -1159,7 +1163,8 @@ def bundle(s, *args):
     x0 = serialize(s)                                            # :162
     resFun = lambda x, jac: brown_euler_cam4(x, s, jac)          # :165
     wdiag = buildweightvector(s)                                 # :175
-    termFun = term_absolute(convTol) if absTerm else term_relative(convTol)
+    if termFun is None:
+        termFun = term_absolute(convTol) if absTerm else term_relative(convTol)
     E = NS(maxIter=maxIter, convTol=convTol, absTerm=absTerm,
            singularTest=singularTest)
     if damping in ('none', 'gm'):
@@ -1168,16 +1173,16 @@ def bundle(s, *args):
         E.damping = NS(name='gm')
     elif damping == 'gna':
         x, code, iters, final, X, res, alpha = gauss_newton_armijo(
-            resFun, x0, wdiag, maxIter, termFun, singularTest, 0.1, 1e-9, doTrace)
+            resFun, x0, wdiag, maxIter, termFun, singularTest, 0.1, 1e-9, doTrace, vetoFun)
         E.damping = NS(name='gna', alpha=alpha, mu=0.1, alphaMin=1e-9)
     elif damping == 'lm':
         x, code, iters, final, X, res, lam = levenberg_marquardt(
-            resFun, x0, wdiag, maxIter, termFun, -1e-10, -1e-10, doTrace)
+            resFun, x0, wdiag, maxIter, termFun, -1e-10, -1e-10, doTrace, vetoFun)
         E.damping = NS(name='lm', **{'lambda': lam}, lambda0=lam[0], lambdaMin=lam[0])
     elif damping == 'lmp':
         delta0 = np.linalg.norm(x0)                              # :325
         x, code, iters, final, X, res, delta, rho, step = levenberg_marquardt_powell(
-            resFun, x0, wdiag, maxIter, termFun, delta0, 0.25, 0.75, doTrace)
+            resFun, x0, wdiag, maxIter, termFun, delta0, 0.25, 0.75, doTrace, vetoFun)
         E.damping = NS(name='lmp', delta=delta, rho=rho, delta0=delta0,
                        rhoBad=0.25, rhoGood=0.75, step=step)
     E.res, E.trace, E.code, E.usedIters, E.final = res, X, code, iters, final

@@ -43,6 +43,8 @@ static void layout(void) {
     FIELD(dbat_hip_options, mu); FIELD(dbat_hip_options, alpha_min); FIELD(dbat_hip_options, lambda0);
     FIELD(dbat_hip_options, lambda_min); FIELD(dbat_hip_options, rho_bad); FIELD(dbat_hip_options, rho_good);
     FIELD(dbat_hip_options, delta0);
+    FIELD(dbat_hip_options, term_fun); FIELD(dbat_hip_options, term_user);
+    FIELD(dbat_hip_options, veto_fun); FIELD(dbat_hip_options, veto_user);
     first = 0;
     printf("}}, \"dbat_hip_result\": {\"sizeof\": %zu, \"offsets\": {", sizeof(dbat_hip_result));
     FIELD(dbat_hip_result, code); FIELD(dbat_hip_result, iters); FIELD(dbat_hip_result, n_res);

@@ -37,6 +37,10 @@ bool mxIsChar(const mxArray *pa);
 bool mxIsUint8(const mxArray *pa);
 int mxGetString(const mxArray *pa, char *str, mwSize strlen);
 void mxDestroyArray(mxArray *pa);
+bool mxIsEmpty(const mxArray *pa);
+bool mxIsClass(const mxArray *pa, const char *classname);
+int mexCallMATLAB(int nlhs, mxArray *plhs[], int nrhs, mxArray *prhs[], const char *functionName);
+mxArray *mexCallMATLABWithTrap(int nlhs, mxArray *plhs[], int nrhs, mxArray *prhs[], const char *functionName);
 void mexErrMsgIdAndTxt(const char *identifier, const char *fmt, ...);
 void mexWarnMsgIdAndTxt(const char *identifier, const char *fmt, ...);
 

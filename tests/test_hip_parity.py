@@ -257,6 +257,71 @@ def test_lm_iteration_count_where_it_is_a_property_of_the_problem(hip, name):
     assert np.abs(np.asarray(E.res) - np.asarray(Eo.res)).max() <= 1e-11 * np.asarray(Eo.res).max()
 
 
+@pytest.mark.parametrize('damping', ['gm', 'gna', 'lm', 'lmp'])
+@pytest.mark.parametrize('name', ['tiny-priors', 'camcal3', 'small-plain'])
+def test_caller_supplied_term_and_veto_functions(hip, name, damping):
+    """The solvers' two function handles (bundle.m:168-192; gauss_newton_armijo.m:187-191,265-281,
+    levenberg_marquardt.m:170-177,217, levenberg_marquardt_powell.m:134-150,166) through dbat_hip_options.term_fun /
+    veto_fun.  termFun here needs the VECTORS (max norms), vetoFun rejects the first trial point it is shown: every call
+    must arrive with the oracle's arguments -- Jp and r weighted, in the reference's row order, x the trial point -- the
+    same number of times, and the run must take the oracle's course (step halved / lambda raised / delta halved once)."""
+    from dbat_amd import bundle
+    s = dict(cases())[name]()
+
+    def recorder():
+        log = {'term': [], 'veto': []}
+
+        def term(Jp, r):
+            log['term'].append((np.array(Jp), np.array(r)))
+            return np.abs(Jp).max() <= 1e-3 * np.abs(r).max()
+
+        def veto(x):
+            log['veto'].append(np.array(x))
+            return len(log['veto']) == 1
+        return log, term, veto
+    lg, term, veto = recorder()
+    lo, termo, vetoo = recorder()
+    res, ok, iters, s0, E = bundle(s, damping, term_fun=term, veto_fun=veto)
+    ro, oko, ito, s0o, Eo = o.bundle(s, damping, termFun=termo, vetoFun=vetoo)
+    assert ok == oko and E.code == Eo.code == 0
+    assert iters == ito and len(lg['term']) == len(lo['term']) and len(lg['veto']) == len(lo['veto'])
+    assert len(lg['term']) >= 1 and (damping == 'gm' or len(lg['veto']) >= 2)
+    for (Jp, r), (Jpo, ro_) in zip(lg['term'], lo['term']):
+        assert Jp.shape == Jpo.shape == r.shape == ro_.shape == (E.numObs,)
+        assert np.abs(r - ro_).max() <= 1e-9 * np.abs(ro_).max()
+        assert np.abs(Jp - Jpo).max() <= 1e-6 * np.abs(Jpo).max() + 1e-9 * np.abs(ro_).max()
+    for x, xo in zip(lg['veto'], lo['veto']):
+        assert x.shape == xo.shape == (E.numParams,) and relerr(x, xo) < 1e-8
+    assert len(E.res) == len(Eo.res) and relerr(E.res, Eo.res) < 1e-8 and relerr(E.x, Eo.x) < 1e-6
+    if damping == 'gna':
+        assert E.damping.alpha[0] == Eo.damping.alpha[0] == 0.5          # the vetoed full step
+        assert np.array_equal(E.damping.alpha, Eo.damping.alpha)
+    elif damping == 'lm':
+        lam, lamo = E.damping.__dict__['lambda'], Eo.damping.__dict__['lambda']
+        assert len(lam) == len(lamo) and relerr(lam, lamo) < 1e-8 and lam[2] > lam[1]   # raised after the veto
+    elif damping == 'lmp':
+        assert np.array_equal(E.damping.step[:len(Eo.damping.step)], Eo.damping.step)
+        assert relerr(E.damping.delta[:iters + 1], Eo.damping.delta[:ito + 1]) < 1e-8
+
+
+def test_callbacks_fail_loudly(hip):
+    """An exception inside a callback ends the run and comes back to the caller unchanged; a veto that never accepts
+    is the reference's code -3 (gauss_newton_armijo.m:218-224)."""
+    from dbat_amd import bundle
+    s = dict(cases())['tiny-plain']()
+
+    class Boom(Exception):
+        pass
+
+    def bad(Jp, r):
+        raise Boom('in termFun')
+    with pytest.raises(Boom):
+        bundle(s, 'gna', term_fun=bad)
+    res, ok, iters, s0, E = bundle(s, 'gna', veto_fun=lambda x: True)
+    ro, oko, ito, s0o, Eo = o.bundle(s, 'gna', vetoFun=lambda x: True)
+    assert not ok and not oko and E.code == Eo.code == -3 and iters == ito
+
+
 def test_roma_script_known_answer_hip(hip):
     """The reference's roma script result (79 321 unknowns, real data, 5 IO
     estimated) reproduced by bundle() on the GPU: first/last error, iteration

@@ -131,7 +131,8 @@ def test_gpu_side_fields_reach_the_gateway():
     m = open(WRAPPER).read()
     cpp = open(GATEWAY).read()
     hip_fields = _matlab_struct_fields(m, 'hip')
-    assert set(hip_fields) == {'device', 'shardRank', 'shardCount', 'commId', 'wantJ', 'wantCov', 'deterministic'}
+    assert set(hip_fields) == {'device', 'shardRank', 'shardCount', 'commId', 'wantJ', 'wantCov', 'deterministic',
+                               'termFun', 'vetoFun'}
     opt_literal = re.search(r"^opt=struct\((.*?)\);", m.replace('...\n', ' '), re.M | re.S).group(1)
     for f in hip_fields:
         assert re.search(r'hip\.%s\b' % f, opt_literal) or (f == 'wantJ' and 'wantJ' in opt_literal), f
@@ -139,7 +140,7 @@ def test_gpu_side_fields_reach_the_gateway():
     # the gateway hands them on: no literal device / rank any more
     assert not re.search(r'pb\.device\s*=\s*0', cpp) and not re.search(r'pb\.shard_count\s*=\s*1', cpp)
     for call in ('dbat_hip_comm_init', 'dbat_hip_comm_unique_id', 'dbat_hip_set_deterministic', 'dbat_hip_jacobian_csc',
-                 'mxCreateSparse'):
+                 'mxCreateSparse', 'opt.term_fun = call_term', 'opt.veto_fun = call_veto', 'mexCallMATLABWithTrap'):
         assert call in cpp, call
     # a failed run never reports "rank ok": the only unconditional rank = lenX sits in the final else of the post-mortem
     wk = m[m.index('E.weakness=struct('):]
