@@ -267,6 +267,9 @@ def test_caller_supplied_term_and_veto_functions(hip, name, damping):
     same number of times, and the run must take the oracle's course (step halved / lambda raised / delta halved once)."""
     from dbat_amd import bundle
     s = dict(cases())[name]()
+    # LM: the SECOND point shown (lambda is 0 there: 0 -> lambdaMin -> 0, levenberg_marquardt.m:177-205).  Rejecting the
+    # first one leaves (10*lambda0)/10 < lambdaMin = lambda0 to the last bit of trace(J'J): not a property of the problem
+    nth = 2 if damping == 'lm' else 1
 
     def recorder():
         log = {'term': [], 'veto': []}
@@ -277,7 +280,7 @@ def test_caller_supplied_term_and_veto_functions(hip, name, damping):
 
         def veto(x):
             log['veto'].append(np.array(x))
-            return len(log['veto']) == 1
+            return len(log['veto']) == nth
         return log, term, veto
     lg, term, veto = recorder()
     lo, termo, vetoo = recorder()
@@ -298,7 +301,7 @@ def test_caller_supplied_term_and_veto_functions(hip, name, damping):
         assert np.array_equal(E.damping.alpha, Eo.damping.alpha)
     elif damping == 'lm':
         lam, lamo = E.damping.__dict__['lambda'], Eo.damping.__dict__['lambda']
-        assert len(lam) == len(lamo) and relerr(lam, lamo) < 1e-8 and lam[2] > lam[1]   # raised after the veto
+        assert len(lam) == len(lamo) and relerr(lam, lamo) < 1e-8 and lam[2] == 0 and lam[3] > 0   # raised after the veto
     elif damping == 'lmp':
         assert np.array_equal(E.damping.step[:len(Eo.damping.step)], Eo.damping.step)
         assert relerr(E.damping.delta[:iters + 1], Eo.damping.delta[:ito + 1]) < 1e-8
