@@ -1184,18 +1184,23 @@ __device__ __forceinline__ void lds_fence() {           // all LDS traffic of th
 // with a handful of atomics per chunk -- instead of ~40 (fixed IO) to ~150
 // (self-calibration) LDS atomics per observation in the tile kernel.
 template <int MODEL, int NCX>
-__global__ __launch_bounds__(256) void k_cam_normal(DevProblem d, const double *__restrict__ z,
-                                                    const CamRec *__restrict__ cams,
-                                                    const int32_t *__restrict__ cm_pt, const double *__restrict__ cm_uv,
-                                                    const double *__restrict__ cm_w,
-                                                    const int32_t *__restrict__ chunk_cam,
-                                                    const int64_t *__restrict__ chunk_start, double *__restrict__ S,
-                                                    double *__restrict__ g_c, double *__restrict__ g_red,
-                                                    double *__restrict__ diagU) {
+__global__ __launch_bounds__(256, 3) void k_cam_normal(DevProblem d, const double *__restrict__ z,
+                                                       const CamRec *__restrict__ cams,
+                                                       const int32_t *__restrict__ cm_pt, const double *__restrict__ cm_uv,
+                                                       const double *__restrict__ cm_w,
+                                                       const int32_t *__restrict__ chunk_cam,
+                                                       const int64_t *__restrict__ chunk_start, double *__restrict__ S,
+                                                       double *__restrict__ g_c, double *__restrict__ g_red,
+                                                       double *__restrict__ diagU) {
     constexpr bool IO = NCX > 6;
-    constexpr int GLD = 130;                         // panel [16 columns][128 rows], column stride 130
-    __shared__ double Gl[4 * 16 * GLD];
-    __shared__ double Gs[4 * 256];
+    // Round 5: the wave's panel holds the rows of 32 observations, [16 columns][64 rows], column stride 66 doubles;
+    // the two halves of the wave take turns.  34 KB per workgroup instead of 75: three workgroups per CU (three waves per
+    // SIMD, 168 registers) where two stood -- the kernel spent a quarter of its wave cycles waiting for the gathers with
+    // nobody to take the SIMD (profiles/r05_c4_summary.md).  Row h of lane l's observation is panel row 32 h + (l & 31):
+    // consecutive lanes write consecutive doubles (the 2 l + h of round 4 put lanes l and l + 16 on one bank: 34 % of the
+    // LDS cycles were conflicts); the Gram matrix does not care about the order of the rows.
+    constexpr int GLD = 66;
+    __shared__ double Gl[4 * 16 * GLD];              // (the four partial Gram matrices at the end go here as well)
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int cam = chunk_cam[blockIdx.x];
     const int64_t q0 = chunk_start[blockIdx.x], q1 = chunk_start[blockIdx.x + 1];
@@ -1203,11 +1208,10 @@ __global__ __launch_bounds__(256) void k_cam_normal(DevProblem d, const double *
     const int ncol = IO ? min(C.ncol, NCX) : 6;
     double *Gw = Gl + w * 16 * GLD;
     // columns that stay zero
-    for (int c = NCX + 1; c < 16; ++c) { Gw[c * GLD + 2 * lane] = 0.0; Gw[c * GLD + 2 * lane + 1] = 0.0; }
+    for (int c = NCX + 1; c < 16; ++c) Gw[c * GLD + lane] = 0.0;
     mfma_d4 acc = {0, 0, 0, 0};
-    // The loads of a round are a dependent pair (point index, then the gather of the point) and only one other wave
-    // shares the SIMD to hide them (LDS: two workgroups per CU): round 4's kernel spent 72 % of its wave cycles waiting
-    // (profiles/r04_c4_summary.md).  Now the index and image coordinates travel two rounds ahead and the point one.
+    // The loads of a round are a dependent pair (point index, then the gather of the point): the index and image
+    // coordinates travel two rounds ahead and the point one.
     {
         auto load_obs = [&](int64_t q, int &pt, double2 &uv, double2 &ww) {
             pt = 0; uv = double2{0, 0}; ww = double2{C.w[0], C.w[1]};
@@ -1224,6 +1228,8 @@ __global__ __launch_bounds__(256) void k_cam_normal(DevProblem d, const double *
         load_obs(qw + 256, pt_b, uv_b, w_b);
         double Qn[3];
         { const int64_t zp = d.NS + 3 * (int64_t)pt_a; Qn[0] = z[zp]; Qn[1] = z[zp + 1]; Qn[2] = z[zp + 2]; }
+        const int prow = lane & 31;
+        const double *ga = Gw + (lane & 15) * GLD + (lane >> 4);
         for (int64_t base = q0 + 64 * w; base < q1; base += 256) {
             const int64_t q = base + lane;
             const double Q[3] = {Qn[0], Qn[1], Qn[2]};
@@ -1239,25 +1245,35 @@ __global__ __launch_bounds__(256) void k_cam_normal(DevProblem d, const double *
                 eval_obs_pre<MODEL, NCX>(d, C, Q, uv.x, uv.y, ww.x, ww.y, 7u, r, E, B);
             }
 #pragma unroll
-            for (int c = 0; c < NCX; ++c) {
-                const bool on = c < ncol;
-                Gw[c * GLD + 2 * lane] = on ? E[0][c] : 0.0;
-                Gw[c * GLD + 2 * lane + 1] = on ? E[1][c] : 0.0;
-            }
-            Gw[NCX * GLD + 2 * lane] = r[0]; Gw[NCX * GLD + 2 * lane + 1] = r[1];
-            lds_fence();                                 // the panel is private to the wave
-            // all 32 operand fragments first, then 32 back-to-back products
-            {
-                double av[32];
-                const double *ga = Gw + (lane & 15) * GLD + (lane >> 4);
+            for (int half = 0; half < 2; ++half) {
+                if ((lane >> 5) == half) {
+                    if (ncol == NCX) {                   // (uniform; the usual case: no selects)
 #pragma unroll
-                for (int kk = 0; kk < 32; ++kk) av[kk] = ga[4 * kk];
+                        for (int c = 0; c < NCX; ++c) { Gw[c * GLD + prow] = E[0][c]; Gw[c * GLD + 32 + prow] = E[1][c]; }
+                    } else {
 #pragma unroll
-                for (int kk = 0; kk < 32; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], av[kk], acc, 0, 0, 0);
+                        for (int c = 0; c < NCX; ++c) {
+                            const bool on = c < ncol;
+                            Gw[c * GLD + prow] = on ? E[0][c] : 0.0;
+                            Gw[c * GLD + 32 + prow] = on ? E[1][c] : 0.0;
+                        }
+                    }
+                    Gw[NCX * GLD + prow] = r[0]; Gw[NCX * GLD + 32 + prow] = r[1];
+                }
+                lds_fence();                             // the panel is private to the wave
+                if (base + 32 * half < q1) {             // (wave-uniform: the second half of a chunk's last round may be empty)
+                    double av[16];                       // all operand fragments first, then the products back to back
+#pragma unroll
+                    for (int kk = 0; kk < 16; ++kk) av[kk] = ga[4 * kk];
+#pragma unroll
+                    for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], av[kk], acc, 0, 0, 0);
+                }
+                lds_fence();
             }
-            lds_fence();
         }
     }
+    double *Gs = Gl;
+    __syncthreads();                                 // every wave is done with its panel
     // G(i, j): register e of lane l holds i = (l>>4) + 4e, j = l&15.  Sum the four waves.
 #pragma unroll
     for (int e = 0; e < 4; ++e) Gs[w * 256 + ((lane >> 4) + 4 * e) * 16 + (lane & 15)] = acc[e];
