@@ -49,7 +49,7 @@ def irregular_scene(sd):
     if rng.integers(0, 2): env['DBAT_HIP_SIG'] = str(rng.choice(['0', '2']))
     if rng.integers(0, 2): env['DBAT_HIP_CMAX'] = str(rng.choice(['0', '4', '6', '10']))
     if rng.integers(0, 2):
-        env['DBAT_HIP_BT'] = str(rng.choice(['64', '128']))
+        env['DBAT_HIP_BT'] = str(rng.choice(['128', '256']))
         env['DBAT_HIP_GIANT_THREADS'] = str(rng.choice(['64', '128', '256']))
     desc = '%3d cams %4d pts %2d rays, %d obs (max %3d per point), selfcal=%d groups=%d, drop %.1f, %s' % (
         cams, points, rays, len(cam), int(np.bincount(pt).max()), selfcal, groups, drop, ' '.join('%s=%s' % (k[9:], v) for k, v in env.items()) or 'defaults')
