@@ -455,7 +455,7 @@ __device__ __forceinline__ bool df_backward(double *smem, const DfView &V, int n
     if (!df_spin_wave(flags + (int64_t)j * nT + j, epoch, abort_flag)) return false;
     if (!df_spin_wave(flags + (int64_t)nT * nT + j, epoch, abort_flag)) return false;
     double lv[16];                                      // Linv(k = ty + 4q, c = tx)
-    const bool l2 = V.iperm != nullptr && !V.no_l2;     // compact tiles: finished tiles through the L2 (see ld_l2_16)
+    const bool l2 = V.iperm != nullptr && !(V.no_l2 & 1);     // compact tiles: finished tiles through the L2 (see ld_l2_16)
 #pragma unroll
     for (int q = 0; q < 16; ++q) lv[q] = ld_tile(linv_all + (size_t)j * NB * NB + tx * NB + ty + 4 * q, l2);
     const double yv = tx < nc ? ld_coh(V.base + V.toff[(int64_t)nT * nT + j] + (int64_t)tx * V.ld) : 0.0;   // y_j(tx)
@@ -773,7 +773,7 @@ __global__ __launch_bounds__(256) void k_chol_df(DfView V, int n, int nT, const 
     int &s_task = s_word[0], &s_ok = s_word[1];
     const int t = threadIdx.x, tx = t & 63, ty = t >> 6;
     int *counter = ctl + ctr_slot, *abort_flag = ctl + 1;     // (slot 0, or 2 for the second launch of a solve)
-    const bool l2 = V.iperm != nullptr && !V.no_l2;     // compact tiles: finished tiles through the L2 (see ld_l2_16)
+    const bool l2 = V.iperm != nullptr && !(V.no_l2 & 1);     // compact tiles: finished tiles through the L2 (see ld_l2_16)
     if constexpr (CHAIN) {                              // the first workgroups to arrive factor the diagonal tiles
         if (t == 0) { s_task = atomicAdd(ctl + C.role_slot, 1); s_word[5] = 0; }
         __syncthreads();
@@ -865,42 +865,79 @@ __global__ __launch_bounds__(256) void k_chol_df(DfView V, int n, int nT, const 
             // Otherwise the workgroup finishes product n first and then waits.  2.0 instead of 3.7 us per
             // product for a task whose inputs exist (the long sums of the dense IO / right-hand-side rows).
             df_d2 rp[8], rq[8];
-            int jn = next_j();
-            if (jn >= 0) {
-                if (t == 0) s_ok = spin_both(jn);
+#ifdef DBAT_HIP_PROFILING
+            const bool abl_f = (V.no_l2 & 6) == 6;                               // 3: ... and no look at the next product's flags either
+            const bool abl_q = (V.no_l2 & 6) != 0, abl_p = (V.no_l2 & 4) != 0;   // DBAT_HIP_DF_ABLATE: operand tiles not fetched (timing only)
+            if (abl_q) for (int q = 0; q < 8; ++q) { rq[q].x = 1e-3 * tx; rq[q].y = 1e-3 * ty; }
+            if (abl_p) for (int q = 0; q < 8; ++q) { rp[q].x = 1e-3 * tx; rp[q].y = 1e-3 * ty; }
+#else
+            constexpr bool abl_q = false, abl_p = false, abl_f = false;
+#endif
+            // jc: the product whose tiles are on their way; jn: the one after it.  Thread 0 looks at jn's flags ONE
+            // PRODUCT AHEAD -- the look is issued before the MFMA pass of the product before jc and read after jc's tiles
+            // have arrived, so its latency (an agent-scope load: 1.5 us) hides under that pass.  Round 4 looked at the top
+            // of jc's own round and paid the latency in every product (C4: 10 % of the factorisation).  A look that found
+            // the flags down is repeated at the top of the round (fresh), as before.
+            int jc = next_j(), jn = -1;
+            int f1 = 0, f2 = 0;
+            auto look = [&](int j) {
+                f1 = f2 = epoch;
+                if (t == 0 && j >= 0 && !abl_f) {
+                    f1 = __hip_atomic_load(flags + (int64_t)k * nT + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (i != k) f2 = __hip_atomic_load(flags + (int64_t)i * nT + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            };
+            // The tile offsets are a table in memory (V.toff) and the compiler reads it with VECTOR loads followed by
+            // s_waitcnt vmcnt(0) -- placed between the requests of L(k,j) and L(i,j) that wait also drained the first tile
+            // before the second was even requested, in every product (found in the ISA in round 5: 5.2 us per product
+            // where the MFMA pass takes 2.4).  The offsets of a product are read ONE ROUND BEFORE its tiles are requested,
+            // where nothing is in flight behind them.
+            int64_t ok_n = 0, oi_n = 0;              // offsets of jn's tiles
+            auto offsets = [&](int j, int64_t &ok_, int64_t &oi_) {
+                ok_ = j >= 0 ? V.toff[(int64_t)k * nT + j] : 0;
+                oi_ = j >= 0 && i != k ? V.toff[(int64_t)i * nT + j] : 0;
+            };
+            auto issue = [&](int64_t ok_, int64_t oi_) {
+                if (!abl_p) df_tile16_issue(V.base + ok_, V.ld, rp, tx, ty, l2);
+                if (i != k && !abl_q) df_tile16_issue(V.base + oi_, V.ld, rq, tx, ty, l2);
+            };
+            if (jc >= 0) {
+                int64_t ok_c, oi_c;
+                offsets(jc, ok_c, oi_c);
+                jn = next_j();
+                offsets(jn, ok_n, oi_n);
+                if (t == 0) s_ok = spin_both(jc);
                 __syncthreads();
                 if (!s_ok) alive = false;
                 else {
-                    df_tile16_issue(V.base + V.toff[(int64_t)k * nT + jn], V.ld, rp, tx, ty, l2);
-                    if (i != k) df_tile16_issue(V.base + V.toff[(int64_t)i * nT + jn], V.ld, rq, tx, ty, l2);
+                    issue(ok_c, oi_c);
+                    look(jn);
                 }
             }
-            while (alive && jn >= 0) {
-                jn = next_j();
-                int f1 = epoch, f2 = epoch;
-                if (t == 0 && jn >= 0) {                // the look at the next product's flags
-                    f1 = __hip_atomic_load(flags + (int64_t)k * nT + jn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (i != k) f2 = __hip_atomic_load(flags + (int64_t)i * nT + jn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+            while (alive && jc >= 0) {
+                // (the row words next_j reads and the offsets are vector loads: taken here, where nothing is in flight
+                // behind them)
+                const int jnn = jn >= 0 ? next_j() : -1;
+                int64_t ok_nn, oi_nn;
+                offsets(jnn, ok_nn, oi_nn);
+                if (t == 0 && jn >= 0 && (f1 != epoch || f2 != epoch)) look(jn);      // down a product ago: look again
                 __syncthreads();                        // the previous MFMA pass has read Pm/Qm
                 df_tile16_commit<LD>(rp, Pm, tx, ty);
                 if (i != k) df_tile16_commit<LD>(rq, Qm, tx, ty);
                 if (t == 0) s_ok = jn >= 0 && f1 == epoch && f2 == epoch;
                 __syncthreads();
                 const bool early = s_ok;
-                if (early) {
-                    df_tile16_issue(V.base + V.toff[(int64_t)k * nT + jn], V.ld, rp, tx, ty, l2);
-                    if (i != k) df_tile16_issue(V.base + V.toff[(int64_t)i * nT + jn], V.ld, rq, tx, ty, l2);
-                }
+                if (early) { issue(ok_n, oi_n); look(jnn); }     // (the look's answer is read after the next round's tiles have arrived)
                 mfma_tile64<LD>(Pm, i == k ? Pm : Qm, ty, tx, acc);
                 if (jn >= 0 && !early) {
                     __syncthreads();                    // s_ok has been read by everybody
                     if (t == 0) s_ok = spin_both(jn);
                     __syncthreads();
                     if (!s_ok) { alive = false; break; }
-                    df_tile16_issue(V.base + V.toff[(int64_t)k * nT + jn], V.ld, rp, tx, ty, l2);
-                    if (i != k) df_tile16_issue(V.base + V.toff[(int64_t)i * nT + jn], V.ld, rq, tx, ty, l2);
+                    issue(ok_n, oi_n);
+                    look(jnn);
                 }
+                jc = jn; jn = jnn; ok_n = ok_nn; oi_n = oi_nn;
             }
         } else {
             for (int j = next_j(); j >= 0; j = next_j()) {
@@ -1217,6 +1254,7 @@ struct DataflowChol {
     DfTask *d_tile_ij = nullptr;
     int nparts = 0;                                     // partial-sum slots of the helper tasks
     bool env_l2 = false;                                // finished tiles through the L2: measured in round 2, no gain (kept off)
+    int env_df_ablate = 0;                              // measurement build (DBAT_HIP_DF_ABLATE): operand fetches of the tile products off
     // the chain role (df_chain_role): the diagonal tiles of the compact layout, per task list (A: all / this rank's domain, B: top)
     bool use_chain = false;
     int nchain = 0, nchainB = 0, chain_wg = 0, chain_wgB = 0;
@@ -1604,6 +1642,7 @@ struct DataflowChol {
         (void)hipMemset(d_flags, 0, ((size_t)(nT + 1) * nT + (size_t)nparts + 4 * (size_t)nT) * sizeof(int));
         (void)hipMemset(d_ctl, 0, 8 * sizeof(int));
         env_l2 = env_int("DBAT_HIP_DF_L2", 0) != 0;
+        env_df_ablate = 2 * (env_int("DBAT_HIP_DF_ABLATE", 0) & 3);     // measurement build: 1 = L(i,j) not fetched, 2 = neither tile
         epoch = 0;
         return true;
     }
@@ -1798,7 +1837,7 @@ struct DataflowChol {
         if (d_trace) (void)hipMemsetAsync(d_trace, 0, (size_t)(ntasks + 3 * nT) * 16 * sizeof(long long), stream);
         ++epoch;
         DfView V;
-        V.toff = d_toff; V.rowbits = d_rowbits; V.W = W; V.no_l2 = env_l2 ? 0 : 1;     // measured: no gain from the L2 path
+        V.toff = d_toff; V.rowbits = d_rowbits; V.W = W; V.no_l2 = (env_l2 ? 0 : 1) | env_df_ablate;     // measured: no gain from the L2 path
         double *qflag;
         V.S = nullptr; V.ldS = lda; V.n_nat = n_nat;
         if (permuted) {
@@ -1847,7 +1886,7 @@ struct DataflowChol {
     void solve_domain(hipStream_t stream, double *A, int64_t lda, double *linv_work, int *info_dev, double *ldiag) {
         ++epoch;
         DfView V;
-        V.toff = d_toff; V.rowbits = d_rowbits; V.W = W; V.no_l2 = env_l2 ? 0 : 1;
+        V.toff = d_toff; V.rowbits = d_rowbits; V.W = W; V.no_l2 = (env_l2 ? 0 : 1) | env_df_ablate;
         V.ldS = lda; V.n_nat = n_nat; V.base = d_tiles; V.ld = 64; V.iperm = d_iperm; V.S = A;
         hipLaunchKernelGGL(k_df_reset, dim3((nT * CHOL_NB + 255) / 256), dim3(256), 0, stream, info_dev, d_ctl,
                            reinterpret_cast<unsigned long long *>(d_qperm), nT * CHOL_NB);

@@ -49,6 +49,7 @@ static const EnvSwitch kEnvSwitches[] = {
     {"DBAT_HIP_ABLATE", true, "k_build_sig / tile kernels: switch phases off (results are wrong), phase clocks"},
     {"DBAT_HIP_DF_TRACE", true, "per-task clocks of the factorisation, written to this file"},
     {"DBAT_HIP_DF_TRACE_POTF2", true, "with DF_TRACE: clocks inside the chain role's factorisations as well"},
+    {"DBAT_HIP_DF_ABLATE", true, "factorisation: operand tiles of the products not fetched (1: L(i,j), 2: both, 3: and no flag looks) -- timing only, wrong results", "0|1|2|3"},
     {"DBAT_HIP_DF_ORDER", true, "one of the candidate task orders instead of the simulated best"},
     {"DBAT_HIP_DF_GRID", true, "workgroups of the factorisation"},
     {"DBAT_HIP_GRID_OBS", true, "launch size of the observation-parallel kernels"},
