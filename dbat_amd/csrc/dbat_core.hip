@@ -395,9 +395,10 @@ struct Core {
         // cap is 48); self-calibration: k_build_tile2
         use_tile3 = use_tile2 && !P.with_io;
         if (use_sig) {
-#define SET_SIG(M) SET_LDS((k_build_sig<M, 4, 6>), sig_lds_bytes(4, false)); SET_LDS((k_build_sig<M, 5, 6>), sig_lds_bytes(5, false)); \
-                   SET_LDS((k_build_sig<M, 4, 14>), sig_lds_bytes(4, true)); SET_LDS((k_build_sig<M, 5, 14>), sig_lds_bytes(5, true));
-            SET_SIG(2); SET_SIG(3); SET_SIG(4); SET_SIG(5);
+#define SET_SIG(M, PW) SET_LDS((k_build_sig<M, 4, 6, PW>), sig_lds_bytes(4, false)); SET_LDS((k_build_sig<M, 5, 6, PW>), sig_lds_bytes(5, false)); \
+                       SET_LDS((k_build_sig<M, 4, 14, PW>), sig_lds_bytes(4, true)); SET_LDS((k_build_sig<M, 5, 14, PW>), sig_lds_bytes(5, true));
+            if (P.uniform_w) { SET_SIG(2, false); SET_SIG(3, false); SET_SIG(4, false); SET_SIG(5, false); }
+            else { SET_SIG(2, true); SET_SIG(3, true); SET_SIG(4, true); SET_SIG(5, true); }
 #undef SET_SIG
         }
         if (use_tile3) {
@@ -699,7 +700,8 @@ struct Core {
 #undef L_CAMN
             mark(0);                                 // events around the tile kernel alone (bench roofline)
 #define L_TILE3(M, DUMMY) LAUNCHK((k_build_tile3<M, TILE3_PC, TILE3_NBUF>), dim3((unsigned)ntiles), dim3(768), lds_tile3, stream, d, zz, cams.p, lambda, scale, S, g_red, Vinv.p, gp.p, jn2p.p, partial.p, pivmm.p)
-#define L_SIG(M, RBV) LAUNCHK((k_build_sig<M, (RBV) % 8, (RBV) / 8>), dim3((unsigned)std::min<int64_t>(ntiles, n_cu)), dim3(64 * sig_waves((RBV) % 8, (RBV) / 8 > 6)), sig_lds_bytes((RBV) % 8, (RBV) / 8 > 6), stream, d, zz, cams.p, lambda, scale, S, g_red, Vinv.p, gp.p, jn2p.p, partial.p, pivmm.p, sg_chunk.p, sg_tile_chunk0.p, sg_lc.p, sg_uv.p, P.uniform_w ? (const double *)nullptr : sg_w.p, gctr.p + 5)
+#define L_SIGW(M, RBV, PW) LAUNCHK((k_build_sig<M, (RBV) % 8, (RBV) / 8, PW>), dim3((unsigned)std::min<int64_t>(ntiles, n_cu)), dim3(64 * sig_waves((RBV) % 8, (RBV) / 8 > 6)), sig_lds_bytes((RBV) % 8, (RBV) / 8 > 6), stream, d, zz, cams.p, lambda, scale, S, g_red, Vinv.p, gp.p, jn2p.p, partial.p, pivmm.p, sg_chunk.p, sg_tile_chunk0.p, sg_lc.p, sg_uv.p, PW ? sg_w.p : (const double *)nullptr, gctr.p + 5)
+#define L_SIG(M, RBV) do { if (P.uniform_w) L_SIGW(M, RBV, false); else L_SIGW(M, RBV, true); } while (0)
             // (row blocks, camera-side columns) packed into one macro argument: RB + 8 * NCX
             if (use_sig && tile_ncx == 6 && sig_rb == 4) { DISPATCH_MODEL(L_SIG, 4 + 8 * 6) }
             else if (use_sig && tile_ncx == 6) { DISPATCH_MODEL(L_SIG, 5 + 8 * 6) }

@@ -176,7 +176,10 @@ __device__ __forceinline__ void sig_step_dot6(const CamRec &C, const double (&Q)
 // IOS = 1, 2: self-calibration, tiles whose cameras belong to one or two IO blocks with the identity row
 // map inside each block: the IO rows of a point are summed in pass 1 (see below).  One launch serves both kinds of tiles
 // (k_build_sig branches per workgroup on the plan's flag), so they share the longest-first order.
-template <int MODEL, int RB, int NCX, int IOS>
+// PW: observations with their own weights (sg_w; else the camera's two weights from its record in LDS).  A template
+// parameter since round 5: as a run-time test the compiler turned "LDS value or global value" into a select of ADDRESSES and
+// read the weights of pass 1 with flat loads, each trip waiting for vmcnt(0) lgkmcnt(0) right behind them.
+template <int MODEL, int RB, int NCX, int IOS, bool PW>
 __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int tile, const int part_slot, const double *__restrict__ z,
                                                const CamRec *__restrict__ cams, double lambda, int scale,
                                                double *__restrict__ S, double *__restrict__ g_red,
@@ -348,7 +351,7 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
                         const CamRec &CB = *reinterpret_cast<const CamRec *>(camw + sy.lc[wave][j2] * CAMW);
                         const double2 ca = uvl[2 * tq], cb = vb ? uvl[2 * tq + 1] : uvl[2 * tq];
                         double wa0 = CA.w[0], wa1 = CA.w[1], wb0 = CB.w[0], wb1 = CB.w[1];
-                        if (sg_w) {                  // (observations with their own standard deviations: the rare case)
+                        if constexpr (PW) {           // (observations with their own standard deviations: the rare case)
                             const double2 cwa = wp[q0 + (int64_t)j * gm], cwb = wp[q0 + (int64_t)j2 * gm];
                             wa0 = cwa.x; wa1 = cwa.y; wb0 = cwb.x; wb1 = cwb.y;
                         }
@@ -364,16 +367,16 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
                 }
             } else {
             double2 uv_n = double2{0, 0}, w_n = double2{0, 0};
-            if (jh < k) { uv_n = uvp[q0 + (int64_t)jh * gm]; if (sg_w) w_n = wp[q0 + (int64_t)jh * gm]; }
+            if (jh < k) { uv_n = uvp[q0 + (int64_t)jh * gm]; if constexpr (PW) w_n = wp[q0 + (int64_t)jh * gm]; }
             for (int j = jh; j < kk; j += jstep) {
                 const int lc = sy.lc[wave][j];
                 const CamRec &C = *reinterpret_cast<const CamRec *>(camw + lc * CAMW);
                 const int64_t q = q0 + (int64_t)j * gm;
                 const double uu = uv_n.x, vv = uv_n.y;
-                const double w0 = sg_w ? w_n.x : C.w[0], w1 = sg_w ? w_n.y : C.w[1];
+                const double w0 = PW ? w_n.x : C.w[0], w1 = PW ? w_n.y : C.w[1];
                 if (j + jstep < k) {                  // next slot's image coordinates, one slot ahead
                     uv_n = uvp[q + (int64_t)jstep * gm];
-                    if (sg_w) w_n = wp[q + (int64_t)jstep * gm];
+                    if constexpr (PW) w_n = wp[q + (int64_t)jstep * gm];
                 }
                 double r[2], A[2][6], B[2][3], Cf[2][MAXIO];
                 obs_eval<MODEL, true, io_simple>(C, d.nK, d.nP, Q, uu, vv, r, A, B, Cf);    // A is dead code here
@@ -508,12 +511,12 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
         const double2 *uvp2 = reinterpret_cast<const double2 *>(sg_uv), *wp2 = reinterpret_cast<const double2 *>(sg_w);
         const int64_t qj = uv0 + (int64_t)j * gm + gi0;
         double2 uv2 = double2{0, 0}, w2 = double2{0, 0};
-        if (lane_on && ir < npts) { uv2 = uvp2[qj + ir]; if (sg_w) w2 = wp2[qj + ir]; }
+        if (lane_on && ir < npts) { uv2 = uvp2[qj + ir]; if constexpr (PW) w2 = wp2[qj + ir]; }
         for (int p0 = 0; p0 < npts; p0 += ppr) {
             const int i = p0 + ir;
             const bool on = lane_on && i < npts;
             const double2 uv_c = uv2, w_c = w2;
-            if (lane_on && i + ppr < npts) { uv2 = uvp2[qj + i + ppr]; if (sg_w) w2 = wp2[qj + i + ppr]; }   // next round's
+            if (lane_on && i + ppr < npts) { uv2 = uvp2[qj + i + ppr]; if constexpr (PW) w2 = wp2[qj + i + ppr]; }   // next round's
             double Zr[6][3];
 #pragma unroll
             for (int a = 0; a < 6; ++a) Zr[a][0] = Zr[a][1] = Zr[a][2] = 0.0;
@@ -560,7 +563,7 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
             if constexpr (!IO || io_simple) {
                 if (on && !DBAT_ABLATE(d, 2)) {
                     const double Q[3] = {gQ[0], gQ[1], gQ[2]};
-                    const double w0 = sg_w ? w_c.x : C.w[0], w1 = sg_w ? w_c.y : C.w[1];
+                    const double w0 = PW ? w_c.x : C.w[0], w1 = PW ? w_c.y : C.w[1];
                     sig_eval_Z(C, Q, w0, w1, gR, Zr);
                     if ((eo_est & 63u) != 63u) {
 #pragma unroll
@@ -573,7 +576,7 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
             if (on && !DBAT_ABLATE(d, 2)) {
                 const double Q[3] = {gQ[0], gQ[1], gQ[2]};
                 const double uu = uv_c.x, vv = uv_c.y;
-                const double w0 = sg_w ? w_c.x : C.w[0], w1 = sg_w ? w_c.y : C.w[1];
+                const double w0 = PW ? w_c.x : C.w[0], w1 = PW ? w_c.y : C.w[1];
                 double r[2], A[2][6], B[2][3], Cf[2][MAXIO];
                 obs_eval<MODEL, true, (IO && !io_simple)>(C, d.nK, d.nP, Q, uu, vv, r, A, B, Cf);
 #pragma unroll
@@ -762,7 +765,7 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
 // dispatched for one tile only pays the dispatch and the release of 150 KB of LDS every time (round 4: about 14 us
 // per tile between the end of one workgroup and the first instruction of the next).  Every workgroup draws exactly one
 // ticket beyond the last tile; the one that draws the very last ticket of the launch puts the counter back to zero.
-template <int MODEL, int RB, int NCX>
+template <int MODEL, int RB, int NCX, bool PW>
 __global__ __launch_bounds__(64 * sig_waves(RB, (NCX > 6))) void k_build_sig(DevProblem d, const double *__restrict__ z,
                                                    const CamRec *__restrict__ cams, double lambda, int scale,
                                                    double *__restrict__ S, double *__restrict__ g_red,
@@ -787,11 +790,11 @@ __global__ __launch_bounds__(64 * sig_waves(RB, (NCX > 6))) void k_build_sig(Dev
         int ios = 0;
         if constexpr (NCX > 6) ios = d.tile_io_simple ? d.tile_io_simple[tile] : 0;       // IO blocks of the tile, if it qualifies
         if (NCX > 6 && ios == 1)
-            build_sig_tile<MODEL, RB, NCX, (NCX > 6 ? 1 : 0)>(d, tile, (int)ti, z, cams, lambda, scale, S, g_red, Vinv, gp, jn2p, partial, pivmm, sg_chunk, sg_tile_chunk0, sg_lc, sg_uv, sg_w);
+            build_sig_tile<MODEL, RB, NCX, (NCX > 6 ? 1 : 0), PW>(d, tile, (int)ti, z, cams, lambda, scale, S, g_red, Vinv, gp, jn2p, partial, pivmm, sg_chunk, sg_tile_chunk0, sg_lc, sg_uv, sg_w);
         else if (NCX > 6 && ios == 2)
-            build_sig_tile<MODEL, RB, NCX, (NCX > 6 ? 2 : 0)>(d, tile, (int)ti, z, cams, lambda, scale, S, g_red, Vinv, gp, jn2p, partial, pivmm, sg_chunk, sg_tile_chunk0, sg_lc, sg_uv, sg_w);
+            build_sig_tile<MODEL, RB, NCX, (NCX > 6 ? 2 : 0), PW>(d, tile, (int)ti, z, cams, lambda, scale, S, g_red, Vinv, gp, jn2p, partial, pivmm, sg_chunk, sg_tile_chunk0, sg_lc, sg_uv, sg_w);
         else
-            build_sig_tile<MODEL, RB, NCX, 0>(d, tile, (int)ti, z, cams, lambda, scale, S, g_red, Vinv, gp, jn2p, partial, pivmm, sg_chunk, sg_tile_chunk0, sg_lc, sg_uv, sg_w);
+            build_sig_tile<MODEL, RB, NCX, 0, PW>(d, tile, (int)ti, z, cams, lambda, scale, S, g_red, Vinv, gp, jn2p, partial, pivmm, sg_chunk, sg_tile_chunk0, sg_lc, sg_uv, sg_w);
         __syncthreads();                             // the tile's LDS is free again (and s_ticket may be redrawn)
     }
 }
