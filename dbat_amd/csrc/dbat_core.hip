@@ -253,6 +253,8 @@ struct Core {
         d.o_cam = o_cam.p; d.o_pt = o_pt.p; d.o_uv = o_uv.p; d.o_w = P.uniform_w ? nullptr : o_w.p;
         d.o_seg = o_seg.p; d.o_row = o_row.p; d.batch_start = batch_start.p;
         d.CMAX = P.CMAX; d.ablate = env_int("DBAT_HIP_ABLATE", 0); d.trace_only = 0;
+        d.any_prior = 0;
+        for (double w : P.z_prw) if (w > 0) { d.any_prior = 1; break; }
         d.deterministic = 0; d.det_cam_part = d.det_io_part = d.det_rr = d.det_u = nullptr; d.det_cam_chunks = nullptr;
         env_df_trace = env_get("DBAT_HIP_DF_TRACE");
         d.ntiles = (int)ntiles; d.o_lc = o_lc.p; d.o_pidx = o_pidx.p;

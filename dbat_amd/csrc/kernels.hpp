@@ -68,6 +68,7 @@ struct DevProblem {
     //   The rounding is half a unit in the last place of the BOUND of an element, where an ordinary sum rounds to half a
     //   unit of the running sum: the result differs from the default mode's by a few 1e-16 of sqrt(S_ii S_jj).
     int deterministic;
+    int any_prior;                  // 0: no prior observation anywhere (z_prw is all zero): the sums over the unknowns skip that array
     double *det_cam_part;           // [camera-major chunks][DET_CP] the chunks' Gram matrices
     double *det_io_part;            // [nc][DET_IOP] self-calibration: the cameras' IO x IO blocks and IO gradient entries
     double *det_rr;                 // [nc] r'r of the cameras' observations; [nc]: their sum
@@ -371,10 +372,11 @@ __global__ __launch_bounds__(1024) void k_prior_sq(DevProblem d, const double *_
     __shared__ double sh[16];
     double acc[1] = {0.0};
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.NZ; i += stride) {
-        const double w = d.z_prw[i];
-        if (w > 0 && d.z_mine[i]) { const double e = z[i] - d.z_prv[i]; acc[0] += w * e * e; }
-    }
+    if (d.any_prior)
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.NZ; i += stride) {
+            const double w = d.z_prw[i];
+            if (w > 0 && d.z_mine[i]) { const double e = z[i] - d.z_prv[i]; acc[0] += w * e * e; }
+        }
     if (grid_sum<1, 1>(acc, sh, partial, ctr, res_partial, n_res) && threadIdx.x == 0) {
         out[0] = acc[0];
         if (mailbox) { mailbox[0] = acc[0]; mailbox_done(mailbox, seq); }
@@ -441,7 +443,7 @@ __global__ __launch_bounds__(1024) void k_build_tail(DevProblem d, const double 
     double acc[2] = {0.0, 0.0};
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.NZ; i += stride) {
-        const double w = d.z_prw[i];
+        const double w = d.any_prior ? d.z_prw[i] : 0.0;
         const bool mine = d.z_mine[i] != 0;
         const double zi = z[i];
         if (zcopy) zcopy[i] = zi;
@@ -2895,7 +2897,7 @@ __global__ __launch_bounds__(1024) void k_prior_jv(DevProblem d, const double *_
             pmin = fmin(pmin, p); pmax = fmax(pmax, p);
         }
         if (!d.z_mine[i]) continue;
-        const double w = d.z_prw[i], vi = d.z_est[i] ? v[i] : 0.0;
+        const double w = d.any_prior ? d.z_prw[i] : 0.0, vi = d.z_est[i] ? v[i] : 0.0;
         if (w > 0) acc[0] += w * vi * vi;
         acc[1] += (i < d.NS ? g_c[i] : gp[i - d.NS]) * vi;
         acc[2] += vi * vi;
