@@ -236,6 +236,22 @@ def test_shard_without_communicator_is_a_usage_error(hip):
         h.close()
 
 
+def test_caller_term_function_is_refused_on_a_shard(hip):
+    """dbat_hip_options.term_fun needs J*p and r as whole vectors on the host; a shard holds the rows of its own
+    observations only: DBAT_HIP_EUNSUPPORTED before anything is launched (include/dbat_hip.h), not a half vector."""
+    from dbat_amd import synth
+    s, _ = synth.make_scene('C1')
+    h = hip.Handle(s, shard_rank=0, shard_count=2)
+    try:
+        opt = hip.default_options('gna')
+        calls = []
+        with pytest.raises(hip.DbatHipError) as e:
+            h.solve(h.serialize(), opt, term_fun=lambda Jp, r: calls.append(1) or False)
+        assert e.value.code == hip.EUNSUPPORTED and 'term_fun' in str(e.value) and not calls
+    finally:
+        h.close()
+
+
 @pytest.mark.parametrize('env', ['DBAT_HIP_MG_REPLICATED=1', 'DBAT_HIP_SIG=2', 'DBAT_HIP_SIG=0'])
 def test_domain_shards_variants(hip, env, monkeypatch):
     """The replicated fall-back (contiguous point ranges, envelope of the whole system summed, every rank factors
