@@ -386,6 +386,12 @@ __global__ __launch_bounds__(1024) void k_prior_sq(DevProblem d, const double *_
 // trace(J'J) and nothing else -- levenberg_marquardt.m:76-95 linearises at x0 only to set lambda0 = c trace(J'J) / n.
 // One streaming pass over the camera-major copy: the squared weighted, masked Jacobian columns of every observation
 // (partial[chunk]); k_trace_tail adds the prior weights of the estimated unknowns and hands the total to the mailbox.
+// (defined with the other evaluation wrappers below)
+template <int MODEL, int NCX>
+__device__ __forceinline__ void eval_obs_pre(const DevProblem &d, const CamRec &C, const double Q[3], double u,
+                                             double v, double w0, double w1, unsigned est, double r[2],
+                                             double E[2][NCX], double B[2][3]);
+
 template <int MODEL, int NCX>
 __global__ __launch_bounds__(256) void k_trace_cm(DevProblem d, const double *__restrict__ z,
                                                   const CamRec *__restrict__ cams,
