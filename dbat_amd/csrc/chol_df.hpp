@@ -1239,6 +1239,14 @@ __global__ __launch_bounds__(256) void k_selinv_diag(double *__restrict__ Z, con
 struct DataflowChol {
     int n = 0, n_nat = 0, nT = 0, W = 0, ntasks = 0, ntiles = 0, epoch = 0, grid = 512;   // n: order of the factorised system (padded)
     bool permuted = false;
+    // The caller's last kernel before solve() has done what k_df_reset does (k_finish takes it along: reset_args);
+    // consumed by the next solve().
+    bool reset_done = false;
+    bool reset_args(int *&ctl, unsigned long long *&q, int &nq) const {
+        if (!permuted || !d_ctl || !d_qperm) return false;
+        ctl = d_ctl; q = reinterpret_cast<unsigned long long *>(d_qperm); nq = nT * CHOL_NB;
+        return true;
+    }
     long long n_products = 0;                           // 64x64x64 tile products of the update phase (schedule statistic)
     int *d_flags = nullptr, *d_ctl = nullptr, *d_bk_ptr = nullptr, *d_bk_idx = nullptr, *d_iperm = nullptr;
     int64_t *d_toff = nullptr;
@@ -1843,8 +1851,10 @@ struct DataflowChol {
         if (permuted) {
             // every task fetches its own tile of P S P' from S (the rows of the right-hand-side tiles below
             // the first stay zero from the set-up): a small reset instead of the gather launch
-            hipLaunchKernelGGL(k_df_reset, dim3((nT * CHOL_NB + 255) / 256), dim3(256), 0, stream, info_dev, d_ctl,
-                               reinterpret_cast<unsigned long long *>(d_qperm), nT * CHOL_NB);
+            if (!reset_done)
+                hipLaunchKernelGGL(k_df_reset, dim3((nT * CHOL_NB + 255) / 256), dim3(256), 0, stream, info_dev, d_ctl,
+                                   reinterpret_cast<unsigned long long *>(d_qperm), nT * CHOL_NB);
+            reset_done = false;
             V.base = d_tiles; V.ld = 64; V.iperm = d_iperm; qflag = d_qperm; V.S = A;
         } else {
             (void)hipMemsetAsync(info_dev, 0, sizeof(int), stream);

@@ -845,8 +845,13 @@ struct Core {
         LAUNCHK(k_pack_envelope, dim3((unsigned)P.NS), dim3(256), 0, stream, S, ldS, (int)P.NS, env_tail0, col_bend.p, col_off.p, pk.p, 0);
     }
     void finish_enqueue(const double *zz, double lambda, int scale) {
+        // one rank, compact tiles: the factorisation's reset rides along (DfChol::reset_args)
+        int *df_ctl = nullptr; unsigned long long *df_q = nullptr; int df_nq = 0;
+        const bool ride = use_perm && !chol_in_place && !(mg_subtree && multi()) && dfchol.reset_args(df_ctl, df_q, df_nq);
         LAUNCHK(k_finish, dim3((unsigned)cdiv(P.NS, 256)), dim3(256), 0, stream, d, zz, lambda, scale, S, g_c, g_red, diagU, jn2c.p, dscale.p,
-                gpart.p, gctr.p + 3, (const double *)red_scal, scal.p, hpin, mg_subtree && multi() ? (const uint8_t *)z_mine.p : (const uint8_t *)nullptr);
+                gpart.p, gctr.p + 3, (const double *)red_scal, scal.p, hpin, mg_subtree && multi() ? (const uint8_t *)z_mine.p : (const uint8_t *)nullptr,
+                ride ? info.p : (int *)nullptr, ride ? df_ctl : (int *)nullptr, ride ? df_q : (unsigned long long *)nullptr, ride ? df_nq : 0);
+        if (ride) dfchol.reset_done = true;
         if (scale)      // D S D on the envelope
             LAUNCHK(k_envelope_op, dim3((unsigned)P.NS), dim3(256), 0, stream, S, ldS, (int)P.NS, env_tail0, col_bend.p, (const double *)dscale.p);
     }
