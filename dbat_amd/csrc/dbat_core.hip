@@ -581,8 +581,11 @@ struct Core {
         // every value the damping loops compare); the point-major one only when residuals are exported.
         // Both kernels finish their grid sums themselves; the second one adds the prior rows and hands
         // the total to the pinned mailbox (one rank) or to scal[0] for the all-reduce.
+        // small projects without prior observations: the residual kernel's last block sums up and tells the host itself
+        const bool res_tail = n_cm_chunks_all > 0 && n_cm_chunks_all <= 512 && !d.any_prior && !multi() && !r_w_out && !r_unw_out;
         if (n_cm_chunks_all > 0) {
-#define L_RESCM(M, PRE) LAUNCHK((k_residual_cm<M, PRE>), dim3((unsigned)n_cm_chunks_all), dim3(256), 0, stream, d, zz, cams_f.p, cm_pt.p, cm_uv.p, P.uniform_w ? (const double *)nullptr : cm_w.p, cm_chunk_cam.p, cm_chunk_start.p, partial.p)
+#define L_RESCM(M, PRE) LAUNCHK((k_residual_cm<M, PRE>), dim3((unsigned)n_cm_chunks_all), dim3(256), 0, stream, d, zz, cams_f.p, cm_pt.p, cm_uv.p, P.uniform_w ? (const double *)nullptr : cm_w.p, cm_chunk_cam.p, cm_chunk_start.p, partial.p, \
+                                res_tail ? gctr.p + 1 : (unsigned *)nullptr, scal.p, hpin, res_tail ? ++mb_seq : 0ull)
             if (uv_pre) { DISPATCH_MODEL(L_RESCM, true) } else { DISPATCH_MODEL(L_RESCM, false) }
 #undef L_RESCM
         }
@@ -592,8 +595,9 @@ struct Core {
             if (uv_pre) { DISPATCH_MODEL(L_RES, true) } else { DISPATCH_MODEL(L_RES, false) }
 #undef L_RES
         }
-        LAUNCHK(k_prior_sq, dim3(grid_zs), dim3(1024), 0, stream, d, zz, gpart.p, gctr.p + 1, (const double *)partial.p, n_cm_chunks_all,
-                scal.p, multi() ? (double *)nullptr : hpin, ++mb_seq);
+        if (!res_tail)
+            LAUNCHK(k_prior_sq, dim3(grid_zs), dim3(1024), 0, stream, d, zz, gpart.p, gctr.p + 1, (const double *)partial.p, n_cm_chunks_all,
+                    scal.p, multi() ? (double *)nullptr : hpin, ++mb_seq);
         double s;
         if (multi()) { do_allreduce(scal.p, 1); read_scal(&s, 1); }
         else { mb_armed = true; sync(); s = hpin[0]; }
