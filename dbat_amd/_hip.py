@@ -24,7 +24,7 @@ if LIB_PATH != os.path.join(_HERE, 'libdbat_hip.so'):
     # never silently: a stale development build must not stand in for the product library in a test or bench run
     sys.stderr.write('[dbat_amd] DBAT_AMD_LIB: loading %s instead of the product library\n' % LIB_PATH)
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 DAMP = {'none': 0, 'gm': 0, 'gna': 1, 'lm': 2, 'lmp': 3}
 
 OK, EINVAL, EUNSUPPORTED, EDEVICE, ENOMEM = 0, -101, -102, -103, -104
@@ -133,6 +133,7 @@ SYMBOLS = {
 }
 DEBUG_SYMBOLS = {
     'dbat_hip_debug_plan_digest': (C.c_int, [C.POINTER(Problem), C.POINTER(C.c_uint64), C.c_int32, C.c_char_p, C.c_int32]),
+    'dbat_hip_debug_heavy_plan_selftest': (C.c_int, [C.POINTER(Problem), _dp]),
     'dbat_hip_debug_model_eval_host': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, C.c_double,
                                                  _dp, _dp, _dp, _dp, _dp, _dp]),
 }
@@ -492,7 +493,7 @@ class Handle:
         check(self.lib.dbat_hip_set_x(self.h, dptr(x)))
 
     def bench_step(self, lam=0.0, scale=False):
-        ms = np.zeros(12)
+        ms = np.zeros(16)
         check(self.lib.dbat_hip_bench_step(self.h, float(lam), int(bool(scale)), dptr(ms)))
         return ms
 
@@ -503,11 +504,13 @@ class Handle:
         return dict(zip(keys, [int(v) for v in a]))
 
     def info(self):
-        a = (C.c_int64 * 16)()
+        a = (C.c_int64 * 24)()
         check(self.lib.dbat_hip_info(self.h, a))
         keys = ('NS', 'n_batches', 'max_k', 'n_obs_shard', 'n_pts_shard', 'BT', 'ncolmax', 'n_tiles',
                 'domain_sharding', 'reduced_doubles_per_factorisation', 'vector_doubles_per_linearisation',
-                'n_top_cams', 'factor_tile_rows', 'tasks_domain', 'tasks_top', 'tile_kernel_mfma')
+                'n_top_cams', 'factor_tile_rows', 'tasks_domain', 'tasks_top', 'tile_kernel_mfma',
+                'heavy_tasks', 'heavy_mfma', 'heavy_row_groups', 'heavy_scratch_bytes', 'heavy_points', 'heavy_obs',
+                'heavy_ksteps_per_task', 'heavy_algorithmic_flops')
         return dict(zip(keys, [int(v) for v in a]))
 
 
@@ -570,7 +573,7 @@ def plan_layout_stats(s, shard_rank=0, shard_count=1):
     v = [int(x) for x in a]
     return dict(n_tiles=v[0], n_batches=v[1], n_batches_tiled=v[2], n_groups=v[3], n_group_points=v[4], n_chunks=v[5],
                 chunks_by_length={'1-8': v[6], '9-16': v[7], '17-32': v[8], '33-64': v[9]}, chunks_multi_round=v[10],
-                k_max=v[11], rows_max=v[12], build_sig=bool(v[13]), backsub_sig=bool(v[14]))
+                k_max=v[11], rows_max=v[12], build_sig=bool(v[13]), backsub_sig=bool(v[14]), heavy_tasks=v[15])
 
 
 def plan_digest(s, shard_rank=0, shard_count=1):
@@ -583,6 +586,17 @@ def plan_digest(s, shard_rank=0, shard_count=1):
     if n < 0:
         check(n)
     return dict(zip(names.value.decode().split(','), [int(v) for v in out[:n]]))
+
+
+def heavy_plan_selftest(s, shard_rank=0, shard_count=1):
+    """Host-only (debug): the row groups / slots / pair tasks of the heavy and giant points (csrc/heavy.hpp) replayed on
+    the host against the plain sum of z_p z_p' -- see dbat_hip_debug_heavy_plan_selftest."""
+    lib = load()
+    p, keep = problem_from_struct(s, 0, shard_rank, shard_count)
+    out = np.zeros(8)
+    check(lib.dbat_hip_debug_heavy_plan_selftest(C.byref(p), dptr(out)))
+    return dict(on=bool(out[0]), points=int(out[1]), row_groups=int(out[2]), tasks=int(out[3]), ksteps=int(out[4]),
+                max_diff=float(out[5]), max_abs=float(out[6]), entries=int(out[7]))
 
 
 def plan_domain_map(s, shard_count):

@@ -19,6 +19,7 @@
 #include "chol_df.hpp"
 #include "kernels.hpp"
 #include "sig.hpp"
+#include "heavy.hpp"
 #include "plan.hpp"
 #include "resect.hpp"
 
@@ -106,7 +107,7 @@ struct Core {
     // build sums, [40..47] pivots / info, [48..51] the pivot reset pattern
     double *hpin = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t kev[10] = {};     // per-kernel brackets, recorded only while timing is on ([8], [9]: the all-reduce of the top tiles)
+    hipEvent_t kev[13] = {};     // per-kernel brackets, recorded only while timing is on ([8], [9]: the all-reduce of the top tiles; [10 .. 12]: the kernels of the heavy / giant points)
     bool timing = false;
     // static problem data
     DevBuf<int32_t> cam_ncol, cam_col, cam_iorow, io_src, o_cam, o_pt;
@@ -140,6 +141,12 @@ struct Core {
     int64_t n_cm_chunks = 0, n_cm_chunks_all = 0;
     DevBuf<double> giant_W;
     int64_t ngiant = 0;
+    // heavy / giant points on the matrix cores (heavy.hpp; Plan::hv_*)
+    bool use_heavy = false;
+    HeavyDev hv{};
+    DevBuf<int32_t> hv_obs_dst, hv_pt_io0, hv_io_dst, hv_io_pt, hv_pt_y, hv_grp_nb, hv_grp_row, hv_task, hv_ops;
+    DevBuf<uint8_t> hv_obs_ld, hv_obs_ioloc, hv_io_ld;
+    DevBuf<double> hv_Z;
     int giant_threads = 256;            // DBAT_HIP_GIANT_THREADS (64/128/256): tests force several chunks per point
     // state
     DevBuf<CamRec> cams, cams_f;                     // camera records at the linearisation point / at the last objective evaluation
@@ -268,6 +275,20 @@ struct Core {
             giant_W.alloc((size_t)(P.giant_start.back() - P.giant_start.front()) * P.ncolmax * 3);
         }
         d.ngiant = (int)ngiant; d.giant_start = giant_start.p; d.giant_W = giant_W.p;
+        use_heavy = P.hv_ok;
+        if (use_heavy) {
+            hv_obs_dst.upload(P.hv_obs_dst); hv_obs_ld.upload(P.hv_obs_ld); hv_obs_ioloc.upload(P.hv_obs_ioloc);
+            hv_pt_io0.upload(P.hv_pt_io0); hv_io_dst.upload(P.hv_io_dst); hv_io_ld.upload(P.hv_io_ld); hv_io_pt.upload(P.hv_io_pt);
+            hv_pt_y.upload(P.hv_pt_y); hv_grp_nb.upload(P.hv_grp_nb); hv_grp_row.upload(P.hv_grp_row);
+            hv_task.upload(P.hv_task); hv_ops.upload(P.hv_ops);
+            // rows of a slot that its point does not touch are never written: zero once, for good
+            hv_Z.alloc((size_t)P.hv_z_doubles);
+            HIPCHK(hipMemset(hv_Z.p, 0, (size_t)P.hv_z_doubles * sizeof(double)));
+            hv.obs_dst = hv_obs_dst.p; hv.obs_ld = hv_obs_ld.p; hv.obs_ioloc = hv_obs_ioloc.p; hv.pt_io0 = hv_pt_io0.p;
+            hv.io_dst = hv_io_dst.p; hv.io_ld = hv_io_ld.p; hv.io_pt = hv_io_pt.p; hv.pt_y = hv_pt_y.p;
+            hv.grp_nb = hv_grp_nb.p; hv.grp_row = hv_grp_row.p; hv.task = hv_task.p; hv.ops = hv_ops.p;
+            hv.obs0 = P.hv_obs0; hv.pt0 = P.hv_pt0; hv.ntasks = P.hv_ntasks;
+        }
         if (const char *e = env_get("DBAT_HIP_GIANT_THREADS")) giant_threads = atoi(e);     // (64 | 128 | 256: env_validate has refused anything else)
         d.tile_batch = tile_batch.p; d.tile_cam_start = tile_cam_start.p; d.tile_cams = tile_cams.p;
         d.tile_io_start = tile_io_start.p; d.tile_iocols = tile_iocols.p; d.tile_cam_io = tile_cam_io.p;
@@ -413,6 +434,11 @@ struct Core {
             SET_LDS((k_cov_points<4, false>), lds_cov); SET_LDS((k_cov_points<5, false>), lds_cov);
             SET_LDS((k_cov_points<2, true>), lds_cov); SET_LDS((k_cov_points<3, true>), lds_cov);
             SET_LDS((k_cov_points<4, true>), lds_cov); SET_LDS((k_cov_points<5, true>), lds_cov);
+        }
+        if (use_heavy) {
+#define SET_HVZ(M) SET_LDS((k_heavy_z<M, 6>), heavy_z_lds_bytes(6)); SET_LDS((k_heavy_z<M, 14>), heavy_z_lds_bytes(14)); SET_LDS((k_heavy_z<M, 15>), heavy_z_lds_bytes(15))
+            SET_HVZ(2); SET_HVZ(3); SET_HVZ(4); SET_HVZ(5);
+#undef SET_HVZ
         }
         SET_LDS((k_build<2, false>), lds_build); SET_LDS((k_build<3, false>), lds_build);
         SET_LDS((k_build<4, false>), lds_build); SET_LDS((k_build<5, false>), lds_build);
@@ -721,17 +747,45 @@ struct Core {
 #undef L_TILE2
         }
         const bool no_tiles = !(ntiles > 0 && nb_tiled > 0);
-        const int64_t ntiles_run = no_tiles ? 0 : ntiles;      // (deterministic mode may have left the tiles out)
-        (void)ntiles_run;
-        if (no_tiles) mark(0);                       // no tile kernel: the events bracket k_build instead
-        if (nb > nb_tiled) {
-#define L_BUILD(M, IO) LAUNCHK((k_build<M, IO>), dim3((unsigned)(nb - nb_tiled)), dim3(P.BT), lds_build, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, partial.p + npart, pivmm.p, (int)nb_tiled)
+        if (no_tiles) mark(0);                       // no tile kernel: the events bracket the kernels of the untiled points instead
+        // heavy.hpp: the untiled points -- batches [P.nb_tiled, nb) and the giant points -- on the matrix cores; the
+        // tiled batches that the deterministic mode keeps off the tile kernels stay with the column lists
+        const int64_t nb_lists = use_heavy ? P.nb_tiled : nb;      // batches [nb_tiled, nb_lists) go through k_build
+        if (nb_lists > nb_tiled) {
+#define L_BUILD(M, IO) LAUNCHK((k_build<M, IO>), dim3((unsigned)(nb_lists - nb_tiled)), dim3(P.BT), lds_build, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, partial.p + npart, pivmm.p, (int)nb_tiled)
             if (P.with_io) { DISPATCH_MODEL(L_BUILD, true) } else { DISPATCH_MODEL(L_BUILD, false) }
 #undef L_BUILD
-            npart += nb - nb_tiled;
+            npart += nb_lists - nb_tiled;
+        }
+        if (use_heavy) {
+            mark(10);
+            if (!deterministic && n_cm_chunks_all > n_cm_chunks) {
+                // camera side of the untiled observations (deterministic mode: every chunk has been through it above)
+                const unsigned nch = (unsigned)(n_cm_chunks_all - n_cm_chunks);
+#define L_CAMNU(M, NCXV) LAUNCHK((k_cam_normal<M, NCXV>), dim3(nch), dim3(256), 0, stream, d, zz, cams.p, cm_pt.p, cm_uv.p, P.uniform_w ? (const double *)nullptr : cm_w.p, cm_chunk_cam.p + n_cm_chunks, cm_chunk_start.p + n_cm_chunks, S, g_c, g_red, diagU)
+#define L_CAMN6U(M, dummy) LAUNCHK((k_cam_normal6<M>), dim3(nch), dim3(256), 0, stream, d, zz, cams.p, cm_pt.p, cm_uv.p, P.uniform_w ? (const double *)nullptr : cm_w.p, cm_chunk_cam.p + n_cm_chunks, cm_chunk_start.p + n_cm_chunks, S, g_c, g_red, diagU)
+                if (tile_ncx == 6) { DISPATCH_MODEL(L_CAMN6U, 0) } else if (tile_ncx == 14) { DISPATCH_MODEL(L_CAMNU, 14) } else { DISPATCH_MODEL(L_CAMNU, 15) }
+#undef L_CAMNU
+#undef L_CAMN6U
+            }
+            if (nb > P.nb_tiled) {
+#define L_HVZ(M, NCXV) LAUNCHK((k_heavy_z<M, NCXV>), dim3((unsigned)(nb - P.nb_tiled)), dim3(256), heavy_z_lds_bytes(NCXV), stream, d, hv, zz, cams.p, lambda, scale, hv_Z.p, Vinv.p, gp.p, jn2p.p, partial.p + npart, pivmm.p, (int)P.nb_tiled)
+                if (tile_ncx == 6) { DISPATCH_MODEL(L_HVZ, 6) } else if (tile_ncx == 14) { DISPATCH_MODEL(L_HVZ, 14) } else { DISPATCH_MODEL(L_HVZ, 15) }
+#undef L_HVZ
+                npart += nb - P.nb_tiled;
+            }
+            if (ngiant > 0) {
+#define L_HVG(M, NCXV) LAUNCHK((k_heavy_z_giant<M, NCXV>), dim3((unsigned)ngiant), dim3(giant_threads), 0, stream, d, hv, zz, cams.p, lambda, scale, hv_Z.p, Vinv.p, gp.p, jn2p.p, partial.p + npart, pivmm.p)
+                if (tile_ncx == 6) { DISPATCH_MODEL(L_HVG, 6) } else if (tile_ncx == 14) { DISPATCH_MODEL(L_HVG, 14) } else { DISPATCH_MODEL(L_HVG, 15) }
+#undef L_HVG
+                npart += ngiant;
+            }
+            mark(11);
+            LAUNCHK(k_heavy_syrk, dim3((unsigned)cdiv(hv.ntasks, 4)), dim3(256), 0, stream, d, hv, (const double *)hv_Z.p, S, g_red);
+            mark(12);
         }
         if (no_tiles) mark(1);
-        if (ngiant > 0) {                            // points with more observations than a batch holds
+        if (ngiant > 0 && !use_heavy) {               // points with more observations than a batch holds
 #define L_GIANT(M, IO) LAUNCHK((k_build_giant<M, IO>), dim3((unsigned)ngiant), dim3(giant_threads), 0, stream, d, zz, cams.p, lambda, scale, S, g_c, g_red, diagU, Vinv.p, gp.p, jn2p.p, partial.p + npart, pivmm.p)
             if (P.with_io) { DISPATCH_MODEL(L_GIANT, true) } else { DISPATCH_MODEL(L_GIANT, false) }
 #undef L_GIANT
@@ -1459,7 +1513,7 @@ int dbat_hip_plan_layout_stats(const dbat_hip_problem *prob, int64_t *st) {
         st[6 + (npts > 32 ? 3 : (npts > 16 ? 2 : (npts > 8 ? 1 : 0)))]++;
         if (npts > std::min(6, 64 / std::max(k, 1))) st[10]++;      // SIG_PPR points per round of pass 2
     }
-    st[11] = P.sg_kmax; st[12] = P.sg_rows_max; st[13] = P.sg_ok ? 1 : 0; st[14] = P.sg_backsub_ok ? 1 : 0;
+    st[11] = P.sg_kmax; st[12] = P.sg_rows_max; st[13] = P.sg_ok ? 1 : 0; st[14] = P.sg_backsub_ok ? 1 : 0; st[15] = P.hv_ok ? P.hv_ntasks : 0;
     return DBAT_HIP_OK;
     API_CATCH
 }
@@ -2025,7 +2079,12 @@ int dbat_hip_bench_step(dbat_hip_handle *h, double lambda, int32_t scale_columns
             HIPCHK(hipEventElapsedTime(&t, c.kev[2 * i], c.kev[2 * i + 1]));
             ms[4 + i] = t;
         }
-        ms[8] = ms[9] = ms[10] = ms[11] = 0.0;
+        for (int i = 8; i < 16; ++i) ms[i] = 0.0;
+        if (c.use_heavy) {                                   // heavy / giant points: camera side + Z rows, then the products
+            float t = 0;
+            HIPCHK(hipEventElapsedTime(&t, c.kev[10], c.kev[11])); ms[12] = t;
+            HIPCHK(hipEventElapsedTime(&t, c.kev[11], c.kev[12])); ms[13] = t;
+        }
         if (c.mg_subtree && c.multi() && c.use_perm) {      // domain sharding: the three parts of the factorisation
             float t = 0;
             HIPCHK(hipEventElapsedTime(&t, c.kev[2], c.kev[8])); ms[8] = t;       // own domain + shares of the top tiles
@@ -2145,6 +2204,11 @@ int dbat_hip_info(const dbat_hip_handle *h, int64_t *info) {
     info[12] = c.use_perm ? c.dfchol.nT : 0;
     info[13] = c.mg_subtree ? c.dfchol.ntasks : 0; info[14] = c.mg_subtree ? c.dfchol.ntasksB : 0;
     info[15] = c.tile_kernel_mfma();
+    for (int i = 16; i < 24; ++i) info[i] = 0;
+    if (c.use_heavy) {
+        info[16] = c.P.hv_ntasks; info[17] = c.P.hv_mfma; info[18] = c.P.hv_ngroups; info[19] = c.P.hv_z_doubles * 8;
+        info[20] = c.P.hv_npts; info[21] = c.nobs - c.P.hv_obs0; info[22] = c.P.hv_ks_per_task; info[23] = c.P.hv_alg_flops;
+    }
     return DBAT_HIP_OK;
 }
 
@@ -2185,6 +2249,107 @@ int dbat_hip_debug_plan_digest(const dbat_hip_problem *prob, uint64_t *out, int3
     for (int i = (int)hs.size(); i < n_out; ++i) out[i] = 0;
     if (names && names_len > 0) snprintf(names, (size_t)names_len, "%s", nm.c_str());
     return (int)hs.size();
+    API_CATCH
+}
+
+/* Host only (debug / CPU unit tests; never used by the product path): the index structures of the heavy / giant points
+ * (Plan::hv_*, csrc/heavy.hpp) checked against their definition.  Every row of Z that k_heavy_z would write gets a
+ * pseudo-random value (a hash of its point, its row of the reduced system and its k-column) at the place the plan gives
+ * it; the tasks of k_heavy_syrk are then replayed on the host (same operand places, same flush rules) and compared with
+ * the plain sum over the points of z_p z_p' over ALL their rows.  out[8]: { 1 if the plan takes the path, untiled points,
+ * row groups, tasks, k-steps, largest absolute difference, largest absolute entry, number of compared entries }. */
+int dbat_hip_debug_heavy_plan_selftest(const dbat_hip_problem *prob, double *out) {
+    API_TRY
+    if (!prob || !out) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
+    Plan P;
+    if (!build_plan(*prob, P, true)) { g_err = P.err; return DBAT_HIP_EINVAL; }
+    for (int i = 0; i < 8; ++i) out[i] = 0.0;
+    if (!P.hv_ok) return DBAT_HIP_OK;
+    const int64_t NS = P.NS;
+    if (NS > 4000) { g_err = "selftest: reduced system too large for the dense host check"; return DBAT_HIP_EINVAL; }
+    auto val = [](int64_t pt, int64_t row, int c) {
+        uint64_t h = (uint64_t)pt * 0x9E3779B97F4A7C15ull ^ (uint64_t)(row + 1) * 0xC2B2AE3D27D4EB4Full ^ (uint64_t)(c + 1) * 0x165667B19E3779F9ull;
+        h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+        return (double)(int64_t)(h % 2001) / 1000.0 - 1.0;
+    };
+    std::vector<double> Zs((size_t)P.hv_z_doubles, 0.0);
+    std::vector<double> ref((size_t)(NS + 1) * (NS + 1), 0.0), got((size_t)(NS + 1) * (NS + 1), 0.0);
+    const int64_t ho0 = P.hv_obs0, ho1 = (int64_t)P.o_cam.size();
+    // rows of every point: (row of the reduced system, values of the three k-columns)
+    std::vector<int64_t> prow; std::vector<double> pval;
+    int64_t o = ho0;
+    while (o < ho1) {
+        const int32_t pt = P.o_pt[o];
+        const int32_t hp = pt - P.hv_pt0;
+        prow.clear(); pval.clear();
+        std::vector<int32_t> slot_row((size_t)(P.hv_pt_io0[hp + 1] - P.hv_pt_io0[hp]), -1);
+        int64_t oe = o;
+        for (; oe < ho1 && P.o_pt[oe] == pt; ++oe) {
+            const int32_t c = P.o_cam[oe];
+            const int32_t dst = P.hv_obs_dst[oe - ho0];
+            const int ld = P.hv_obs_ld[oe - ho0];
+            for (int a = 0; a < 6; ++a) {
+                const int64_t row = P.cam_col[(size_t)c * MAXCOL + a];
+                prow.push_back(row);
+                for (int k = 0; k < 3; ++k) { const double v = val(pt, row, k); pval.push_back(v); Zs[(size_t)dst + (size_t)k * ld + a] = v; }
+            }
+            for (int q = 6; q < P.cam_ncol[c]; ++q) {
+                const int sl = P.hv_obs_ioloc[(size_t)(oe - ho0) * Plan::HV_NIOC + (q - 6)];
+                if (sl >= (int)slot_row.size()) { g_err = "selftest: IO slot out of range"; return DBAT_HIP_EINVAL; }
+                const int32_t row = P.cam_col[(size_t)c * MAXCOL + q];
+                if (slot_row[sl] >= 0 && slot_row[sl] != row) { g_err = "selftest: two IO columns in one slot"; return DBAT_HIP_EINVAL; }
+                slot_row[sl] = row;
+            }
+        }
+        for (size_t sl = 0; sl < slot_row.size(); ++sl) {
+            if (slot_row[sl] < 0) { g_err = "selftest: IO slot without a column"; return DBAT_HIP_EINVAL; }
+            const int gs = P.hv_pt_io0[hp] + (int)sl;
+            if (P.hv_io_pt[gs] != hp) { g_err = "selftest: IO slot of another point"; return DBAT_HIP_EINVAL; }
+            prow.push_back(slot_row[sl]);
+            for (int k = 0; k < 3; ++k) { const double v = val(pt, slot_row[sl], k); pval.push_back(v); Zs[(size_t)P.hv_io_dst[gs] + (size_t)k * P.hv_io_ld[gs]] = v; }
+        }
+        prow.push_back(NS);
+        for (int k = 0; k < 3; ++k) { const double v = val(pt, NS, k); pval.push_back(v); Zs[(size_t)P.hv_pt_y[2 * hp] + (size_t)k * P.hv_pt_y[2 * hp + 1]] = v; }
+        for (size_t a = 0; a < prow.size(); ++a)
+            for (size_t b = 0; b < prow.size(); ++b) {
+                const int64_t ri = prow[a], rj = prow[b];
+                if (ri < rj || (ri == NS && rj == NS)) continue;
+                ref[(size_t)rj * (NS + 1) + ri] -= pval[3 * a] * pval[3 * b] + pval[3 * a + 1] * pval[3 * b + 1] + pval[3 * a + 2] * pval[3 * b + 2];
+            }
+        o = oe;
+    }
+    // the tasks, as k_heavy_syrk runs them
+    int64_t nks_all = 0;
+    for (int t = 0; t < P.hv_ntasks; ++t) {
+        const int gi = P.hv_task[4 * t], gj = P.hv_task[4 * t + 1], ks0 = P.hv_task[4 * t + 2], nks = P.hv_task[4 * t + 3];
+        const int nbi = P.hv_grp_nb[gi], nbj = P.hv_grp_nb[gj];
+        nks_all += nks;
+        std::vector<double> acc((size_t)48 * 48, 0.0);
+        for (int ks = 0; ks < nks; ++ks)
+            for (int kk = 0; kk < 4; ++kk) {
+                const int32_t *op = P.hv_ops.data() + ((size_t)(ks0 + ks) * 4 + kk) * 2;
+                if ((op[0] < 0) != (op[1] < 0)) { g_err = "selftest: half an operand"; return DBAT_HIP_EINVAL; }
+                if (op[0] < 0) continue;
+                for (int i = 0; i < 16 * nbi; ++i)
+                    for (int j = 0; j < 16 * nbj; ++j) acc[(size_t)i * 48 + j] += Zs[(size_t)op[0] + i] * Zs[(size_t)op[1] + j];
+            }
+        for (int i = 0; i < 16 * nbi; ++i)
+            for (int j = 0; j < 16 * nbj; ++j) {
+                if (gi == gj && i < j) continue;
+                const int32_t ri = P.hv_grp_row[(size_t)gi * 48 + i], cj = P.hv_grp_row[(size_t)gj * 48 + j];
+                if (ri < 0 || cj < 0 || cj == NS) continue;
+                if (ri < cj) { g_err = "selftest: rows of the groups are not ascending"; return DBAT_HIP_EINVAL; }
+                got[(size_t)cj * (NS + 1) + ri] -= acc[(size_t)i * 48 + j];
+            }
+    }
+    double dmax = 0, vmax = 0; int64_t ncmp = 0;
+    for (size_t i = 0; i < ref.size(); ++i) {
+        dmax = std::max(dmax, std::fabs(ref[i] - got[i])); vmax = std::max(vmax, std::fabs(ref[i]));
+        ncmp += ref[i] != 0.0;
+    }
+    out[0] = 1; out[1] = P.hv_npts; out[2] = P.hv_ngroups; out[3] = P.hv_ntasks; out[4] = (double)nks_all;
+    out[5] = dmax; out[6] = vmax; out[7] = (double)ncmp;
+    return DBAT_HIP_OK;
     API_CATCH
 }
 

@@ -29,6 +29,8 @@ static const EnvSwitch kEnvSwitches[] = {
     {"DBAT_HIP_CMAX", false, "cameras per tile (0: column-list kernel only)"},
     {"DBAT_HIP_BT", false, "observations per batch (128 | 256)", "128|256"},
     {"DBAT_HIP_TILE_BMIN", false, "fewest batches a tile may be capped at (default 2)"},
+    {"DBAT_HIP_HEAVY", false, "0: heavy / giant points by the column-list kernels (pair terms by global atomics) instead of the matrix-core path", "0|1"},
+    {"DBAT_HIP_HEAVY_KS", false, "heavy / giant points: k-steps per task of k_heavy_syrk at most (default: by the amount of work, 12 ... 96)"},
     {"DBAT_HIP_GIANT_THREADS", false, "threads of the giant-point kernels (64 | 128 | 256)", "64|128|256"},
     {"DBAT_HIP_MG_REPLICATED", false, "several ranks: envelope summed, replicated factorisation"},
     {"DBAT_HIP_ND_OFF", false, "no nested dissection"},

@@ -131,6 +131,36 @@ struct Plan {
                                                    // every shared element is ONE unknown in the slot of its leading
                                                    // entry (cam_col), the other entries' slots are inert
     bool rank_ok = true;                           // structural rank test
+    // Heavy and giant points on the matrix cores (heavy.hpp).  The rows of the reduced system that these points touch
+    // -- the EO rows of their cameras, the IO columns those cameras estimate, and one row for the right-hand side --
+    // are cut into ROW GROUPS of at most 48 rows (eight cameras; three 16-row blocks of v_mfma_f64_16x16x4_f64).  A
+    // point has a SLOT in every group it touches: 3 k-columns x (16 x row blocks) doubles of the scratch array Zs, which
+    // k_heavy_z fills with the point's rows of Z = W R (V^-1 = R R').  The Schur complement of these points is then the
+    // block-sparse product  S(Gi, Gj) -= sum over the points p in both groups  Z_p(Gi) Z_p(Gj)'  -- one list of slot
+    // pairs per pair of groups, cut into tasks of at most hv_ks_per_task k-steps (k_heavy_syrk: one wave per task,
+    // accumulators in registers, ONE flush per task).
+    bool hv_ok = false;
+    int64_t hv_obs0 = 0;                           // first observation (processing order) of the untiled points
+    int32_t hv_pt0 = 0, hv_npts = 0;               // their range in the processing order
+    int32_t hv_ngroups = 0, hv_ntasks = 0, hv_ks_per_task = 0;
+    int64_t hv_z_doubles = 0;                      // size of Zs
+    int64_t hv_mfma = 0;                           // v_mfma_f64_16x16x4_f64 instructions of one launch of k_heavy_syrk
+    int64_t hv_alg_flops = 0;                      // sum over these points of 108 k + 216 k^2 (the full product Y W')
+    int hv_max_io_slots = 0;                       // most IO columns of one point
+    std::vector<int32_t> hv_grp_nb;                // [groups] 16-row blocks of the group (1 .. 3)
+    std::vector<int32_t> hv_grp_row;               // [groups][48] row of the reduced system (-1: padding, NS: right-hand side)
+    std::vector<int32_t> hv_obs_dst;               // [untiled observations] Zs index of (slot, k-column 0, first EO row of the camera)
+    std::vector<uint8_t> hv_obs_ld;                // ... and the stride between the k-columns of that group (16 x row blocks)
+    std::vector<uint8_t> hv_obs_ioloc;             // [untiled observations][HV_NIOC] slot of the camera's j-th IO column in the point's IO list
+    std::vector<int32_t> hv_pt_io0;                // [points + 1] first IO slot of every point
+    std::vector<int32_t> hv_io_dst;                // [IO slots] Zs index of (slot, k-column 0, row of the IO column)
+    std::vector<uint8_t> hv_io_ld;
+    std::vector<int32_t> hv_io_pt;                 // [IO slots] the point (index from hv_pt0)
+    std::vector<int32_t> hv_pt_y;                  // [points][2] Zs index and stride of the point's right-hand-side row
+    std::vector<int32_t> hv_task;                  // [tasks][4] group i, group j <= i, first k-step, k-steps
+    std::vector<int32_t> hv_ops;                   // [k-steps][4][2] Zs index of the k-column lane group kk reads, in Gi and in Gj (-1: zero)
+    static constexpr int HV_NIOC = 9;              // IO columns per camera at most (ncolmax <= 15)
+    static constexpr int HV_MAXSLOTS = 48;         // IO columns per point at most
     int order_dims = 3;                            // dimensions of the point-ordering curve (2 = flat cloud)
     std::string err;
 };
@@ -174,6 +204,193 @@ inline void serialize_block(int rows, int cols, const int32_t *block, const uint
             }
         }
     }
+}
+
+// Row groups, slots and pair tasks of the heavy / giant points (Plan::hv_*; kernels in heavy.hpp).  One thread: the
+// lists are proportional to the observations of these points only, and every thread count must give the same plan.
+inline void build_heavy_plan(Plan &P) {
+    P.hv_ok = false; P.hv_ntasks = 0; P.hv_ngroups = 0; P.hv_z_doubles = 0; P.hv_mfma = 0;
+    if (!P.CMAX || P.BT != 256 || P.shared_eo || P.ncolmax > 6 + Plan::HV_NIOC) return;
+    if (env_int("DBAT_HIP_HEAVY", 1) == 0) return;
+    const int64_t nb = (int64_t)P.batch_start.size() - 1;
+    if (P.nb_tiled > nb) return;
+    const int64_t ho0 = P.batch_start[P.nb_tiled], ho1 = (int64_t)P.o_cam.size();
+    if (ho1 <= ho0) return;
+    const int nc = P.nc;
+    const int32_t hp0 = P.o_pt[ho0], hp1 = P.o_pt[ho1 - 1] + 1;
+    const int32_t nhp = hp1 - hp0;
+    // observation range of every point (a point's observations are contiguous, the points consecutive)
+    std::vector<int64_t> pobs((size_t)nhp + 1, ho1);
+    for (int64_t o = ho1 - 1; o >= ho0; --o) pobs[P.o_pt[o] - hp0] = o;
+    for (int32_t i = nhp - 1; i >= 0; --i) if (pobs[i] > pobs[i + 1]) pobs[i] = pobs[i + 1];     // (a point without observations: empty range)
+    // cameras and IO columns these points touch, ascending
+    std::vector<int32_t> cam_idx((size_t)nc, -1), hcams;
+    for (int64_t o = ho0; o < ho1; ++o) cam_idx[P.o_cam[o]] = 0;
+    for (int c = 0; c < nc; ++c) if (cam_idx[c] == 0) { cam_idx[c] = (int32_t)hcams.size(); hcams.push_back(c); }
+    std::vector<int32_t> io_idx((size_t)std::max(1, P.nIOu), -1), hio;
+    for (int32_t c : hcams)
+        for (int q = 6; q < P.cam_ncol[c]; ++q) io_idx[P.cam_col[(size_t)c * MAXCOL + q] - 6 * nc] = 0;
+    for (int k = 0; k < P.nIOu; ++k) if (io_idx[k] == 0) { io_idx[k] = (int32_t)hio.size(); hio.push_back(k); }
+    // groups: eight cameras each; then the IO columns and the row of the right-hand side, 48 rows each
+    const int ngc = ((int)hcams.size() + 7) / 8;
+    const int nior = (int)hio.size() + 1;            // IO rows + the right-hand side
+    const int ngi = (nior + 47) / 48;
+    const int ng = ngc + ngi;
+    P.hv_ngroups = ng;
+    P.hv_grp_nb.assign(ng, 0); P.hv_grp_row.assign((size_t)ng * 48, -1);
+    for (size_t i = 0; i < hcams.size(); ++i)
+        for (int a = 0; a < 6; ++a) P.hv_grp_row[(i / 8) * 48 + 6 * (i % 8) + a] = 6 * hcams[i] + a;
+    for (int i = 0; i < nior; ++i)
+        P.hv_grp_row[(size_t)(ngc + i / 48) * 48 + i % 48] = i < (int)hio.size() ? 6 * nc + hio[i] : (int32_t)P.NS;
+    for (int g = 0; g < ng; ++g) {
+        int rows = 0;
+        for (int r = 0; r < 48; ++r) if (P.hv_grp_row[(size_t)g * 48 + r] >= 0) rows = r + 1;
+        P.hv_grp_nb[g] = (rows + 15) / 16;
+    }
+    const int yg = ngc + (nior - 1) / 48, yrow = (nior - 1) % 48;
+    // the groups of every point (ascending) with its slot in each; IO slots
+    std::vector<int32_t> cnt((size_t)ng, 0);         // slots handed out per group
+    std::vector<int64_t> pg0((size_t)nhp + 1, 0);    // prefix of the points' group lists
+    std::vector<int32_t> pg_g, pg_slot;
+    const int64_t nho = ho1 - ho0;
+    P.hv_obs_dst.assign((size_t)nho, 0); P.hv_obs_ld.assign((size_t)nho, 16);
+    P.hv_obs_ioloc.assign((size_t)nho * Plan::HV_NIOC, 255);
+    P.hv_pt_io0.assign((size_t)nhp + 1, 0); P.hv_io_dst.clear(); P.hv_io_ld.clear(); P.hv_io_pt.clear();
+    P.hv_pt_y.assign((size_t)2 * nhp, 0);
+    P.hv_max_io_slots = 0;
+    std::vector<int32_t> pio;                        // IO columns (indices into hio) of the current point, ascending
+    std::vector<int32_t> grp_slot((size_t)ng, -1);   // slot of the current point in a group (-1: not touched)
+    std::vector<int32_t> touched;
+    std::vector<int32_t> io_slot_grp;               // group of every IO slot
+    for (int32_t i = 0; i < nhp; ++i) {
+        pio.clear(); touched.clear();
+        for (int64_t o = pobs[i]; o < pobs[i + 1]; ++o) {
+            const int32_t c = P.o_cam[o];
+            const int g = cam_idx[c] / 8;
+            if (grp_slot[g] < 0) { grp_slot[g] = cnt[g]++; touched.push_back(g); }
+            for (int q = 6; q < P.cam_ncol[c]; ++q) pio.push_back(io_idx[P.cam_col[(size_t)c * MAXCOL + q] - 6 * nc]);
+        }
+        std::sort(pio.begin(), pio.end());
+        pio.erase(std::unique(pio.begin(), pio.end()), pio.end());
+        if ((int)pio.size() > Plan::HV_MAXSLOTS) return;          // (hv_ok stays false: the column-list kernels take these points)
+        P.hv_max_io_slots = std::max(P.hv_max_io_slots, (int)pio.size());
+        for (int32_t q : pio) { const int g = ngc + q / 48; if (grp_slot[g] < 0) { grp_slot[g] = cnt[g]++; touched.push_back(g); } }
+        if (pobs[i + 1] > pobs[i] && grp_slot[yg] < 0) { grp_slot[yg] = cnt[yg]++; touched.push_back(yg); }
+        std::sort(touched.begin(), touched.end());
+        for (int32_t g : touched) { pg_g.push_back(g); pg_slot.push_back(grp_slot[g]); }
+        pg0[i + 1] = (int64_t)pg_g.size();
+        // (the Zs indices need the groups' offsets, which need the final slot counts: second pass below; here the
+        // group-local parts)
+        for (int64_t o = pobs[i]; o < pobs[i + 1]; ++o) {
+            const int32_t c = P.o_cam[o];
+            const int g = cam_idx[c] / 8, ld = 16 * P.hv_grp_nb[g];
+            P.hv_obs_dst[o - ho0] = grp_slot[g] * 3 * ld + 6 * (cam_idx[c] % 8);
+            P.hv_obs_ld[o - ho0] = (uint8_t)ld;
+            for (int q = 6; q < P.cam_ncol[c]; ++q) {
+                const int32_t io = io_idx[P.cam_col[(size_t)c * MAXCOL + q] - 6 * nc];
+                P.hv_obs_ioloc[(size_t)(o - ho0) * Plan::HV_NIOC + (q - 6)] = (uint8_t)(std::lower_bound(pio.begin(), pio.end(), io) - pio.begin());
+            }
+        }
+        for (int32_t q : pio) {
+            const int g = ngc + q / 48, ld = 16 * P.hv_grp_nb[g];
+            P.hv_io_dst.push_back(grp_slot[g] * 3 * ld + q % 48);
+            P.hv_io_ld.push_back((uint8_t)ld); P.hv_io_pt.push_back(i); io_slot_grp.push_back(g);
+        }
+        P.hv_pt_io0[i + 1] = (int32_t)P.hv_io_dst.size();
+        if (pobs[i + 1] > pobs[i]) { const int ld = 16 * P.hv_grp_nb[yg]; P.hv_pt_y[2 * i] = grp_slot[yg] * 3 * ld + yrow; P.hv_pt_y[2 * i + 1] = ld; }
+        for (int32_t g : touched) grp_slot[g] = -1;
+    }
+    // offsets of the groups in Zs
+    std::vector<int64_t> zoff((size_t)ng + 1, 0);
+    for (int g = 0; g < ng; ++g) zoff[g + 1] = zoff[g] + (int64_t)cnt[g] * 3 * 16 * P.hv_grp_nb[g];
+    if (zoff[ng] >= (int64_t)1 << 31) return;          // (32-bit indices)
+    P.hv_z_doubles = zoff[ng];
+    for (int32_t i = 0; i < nhp; ++i) {
+        for (int64_t o = pobs[i]; o < pobs[i + 1]; ++o) P.hv_obs_dst[o - ho0] += (int32_t)zoff[cam_idx[P.o_cam[o]] / 8];
+        if (pobs[i + 1] > pobs[i]) P.hv_pt_y[2 * i] += (int32_t)zoff[yg];
+    }
+    for (size_t q = 0; q < P.hv_io_dst.size(); ++q) P.hv_io_dst[q] += (int32_t)zoff[io_slot_grp[q]];
+    // pair lists: every point contributes (slot_i, slot_j) to every pair of its groups, i >= j
+    std::unordered_map<uint64_t, int32_t> pair_id;
+    std::vector<int32_t> pair_g;                      // [pairs][2]
+    std::vector<int64_t> pair_n;
+    for (int32_t i = 0; i < nhp; ++i)
+        for (int64_t a = pg0[i]; a < pg0[i + 1]; ++a)
+            for (int64_t b = pg0[i]; b <= a; ++b) {
+                const uint64_t key = (uint64_t)pg_g[a] * (uint64_t)ng + (uint64_t)pg_g[b];
+                auto it = pair_id.find(key);
+                if (it == pair_id.end()) { it = pair_id.emplace(key, (int32_t)pair_n.size()).first; pair_g.push_back(pg_g[a]); pair_g.push_back(pg_g[b]); pair_n.push_back(0); }
+                ++pair_n[it->second];
+            }
+    const size_t npairs = pair_n.size();
+    // a fixed order of the pairs (the hash map's is not one): by (group i, group j)
+    std::vector<int32_t> pord(npairs);
+    std::iota(pord.begin(), pord.end(), 0);
+    std::sort(pord.begin(), pord.end(), [&](int32_t a, int32_t b) {
+        return pair_g[2 * a] != pair_g[2 * b] ? pair_g[2 * a] < pair_g[2 * b] : pair_g[2 * a + 1] < pair_g[2 * b + 1];
+    });
+    std::vector<int32_t> prank(npairs);
+    for (size_t r = 0; r < npairs; ++r) prank[pord[r]] = (int32_t)r;
+    std::vector<int64_t> pk0(npairs + 1, 0);          // first k-step of every pair (in the fixed order)
+    for (size_t r = 0; r < npairs; ++r) pk0[r + 1] = pk0[r] + (3 * pair_n[pord[r]] + 3) / 4;
+    const int64_t total_ks = pk0[npairs];
+    if (total_ks * 8 >= (int64_t)1 << 31) return;
+    P.hv_ops.assign((size_t)total_ks * 8, -1);
+    std::vector<int64_t> fill(npairs, 0);             // points placed so far
+    for (int32_t i = 0; i < nhp; ++i)
+        for (int64_t a = pg0[i]; a < pg0[i + 1]; ++a)
+            for (int64_t b = pg0[i]; b <= a; ++b) {
+                const int32_t r = prank[pair_id[(uint64_t)pg_g[a] * (uint64_t)ng + (uint64_t)pg_g[b]]];
+                const int64_t e = fill[r]++;
+                const int gi = pg_g[a], gj = pg_g[b];
+                const int ldi = 16 * P.hv_grp_nb[gi], ldj = 16 * P.hv_grp_nb[gj];
+                for (int c = 0; c < 3; ++c) {
+                    const int64_t q = 3 * e + c;      // k-column of the pair: k-step q / 4, lane group q % 4
+                    int32_t *op = P.hv_ops.data() + ((pk0[r] + q / 4) * 4 + q % 4) * 2;
+                    op[0] = (int32_t)(zoff[gi] + ((int64_t)pg_slot[a] * 3 + c) * ldi);
+                    op[1] = (int32_t)(zoff[gj] + ((int64_t)pg_slot[b] * 3 + c) * ldj);
+                }
+            }
+    // tasks: the pairs' k-steps in pieces of about equal length.  Enough of them to occupy the chip, long enough to
+    // pay for the flush (one atomic per element of the pair's blocks)
+    int ksmax = env_int("DBAT_HIP_HEAVY_KS", 0);
+    if (ksmax <= 0) ksmax = (int)std::min<int64_t>(96, std::max<int64_t>(12, (total_ks + 4095) / 4096));
+    P.hv_ks_per_task = ksmax;
+    P.hv_task.clear(); P.hv_mfma = 0;
+    for (size_t r = 0; r < npairs; ++r) {
+        const int gi = pair_g[2 * pord[r]], gj = pair_g[2 * pord[r] + 1];
+        const int64_t nks = pk0[r + 1] - pk0[r];
+        const int64_t nt = (nks + ksmax - 1) / ksmax;
+        const int nbi = P.hv_grp_nb[gi], nbj = P.hv_grp_nb[gj];
+        P.hv_mfma += nks * (gi == gj ? nbi * (nbi + 1) / 2 : nbi * nbj);
+        for (int64_t q = 0; q < nt; ++q) {
+            const int64_t k0 = q * nks / nt, k1 = (q + 1) * nks / nt;
+            const int32_t tk[4] = {gi, gj, (int32_t)(pk0[r] + k0), (int32_t)(k1 - k0)};
+            P.hv_task.insert(P.hv_task.end(), tk, tk + 4);
+        }
+    }
+    {   // longest tasks first
+        const size_t nt = P.hv_task.size() / 4;
+        std::vector<int32_t> ord(nt);
+        std::iota(ord.begin(), ord.end(), 0);
+        auto work = [&](int32_t t) {
+            const int gi = P.hv_task[4 * t], gj = P.hv_task[4 * t + 1];
+            return (int64_t)P.hv_task[4 * t + 3] * (gi == gj ? P.hv_grp_nb[gi] * (P.hv_grp_nb[gi] + 1) / 2 : P.hv_grp_nb[gi] * P.hv_grp_nb[gj]);
+        };
+        std::stable_sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) { return work(a) > work(b); });
+        std::vector<int32_t> tk(P.hv_task.size());
+        for (size_t a = 0; a < nt; ++a) std::copy(P.hv_task.begin() + 4 * ord[a], P.hv_task.begin() + 4 * ord[a] + 4, tk.begin() + 4 * a);
+        P.hv_task.swap(tk);
+    }
+    P.hv_ntasks = (int32_t)(P.hv_task.size() / 4);
+    P.hv_obs0 = ho0; P.hv_pt0 = hp0; P.hv_npts = nhp;
+    P.hv_alg_flops = 0;
+    for (int32_t i = 0; i < nhp; ++i) { const int64_t k = pobs[i + 1] - pobs[i]; P.hv_alg_flops += 108 * k + 216 * k * k; }
+    P.hv_ok = P.hv_ntasks > 0;
+    if (env_on("DBAT_HIP_PLAN_STATS"))
+        fprintf(stderr, "[plan] heavy / giant points on the matrix cores: %d points, %lld observations, %d row groups (%zu cameras, %zu IO columns), "
+                        "%zu group pairs, %lld k-steps in %d tasks (<= %d each), Zs %.2f MB\n",
+                nhp, (long long)nho, ng, hcams.size(), hio.size(), npairs, (long long)total_ks, P.hv_ntasks, ksmax, P.hv_z_doubles * 8e-6);
 }
 
 inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
@@ -636,6 +853,15 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
         }
     }
     });
+    {   // A tile kernel launched for a handful of points costs its fixed 40 ... 50 us whatever it does (the four control
+        // points of the camcal demo beside 96 points that every image sees): where heavy points exist anyway and the others
+        // are few, they all take the matrix-core path of the heavy points (heavy.hpp), whose cost per point is small.
+        int64_t n_heavy = 0, n_tiled = 0;
+        for (int p = 0; p < np; ++p) { if (giant[p]) continue; if (heavy[p]) n_heavy += k_pt[p]; else n_tiled += k_pt[p]; }
+        const bool hv_can = P.CMAX && P.BT == 256 && !P.shared_eo && P.ncolmax <= 6 + Plan::HV_NIOC && env_int("DBAT_HIP_HEAVY", 1) != 0;
+        if (hv_can && n_heavy > 0 && n_tiled <= 2048)
+            for (int p = 0; p < np; ++p) if (k_pt[p] > 0 && !giant[p]) heavy[p] = 1;
+    }
     lapt("tile-fit classification of the points");
     // Key = Morton code of the point's initial coordinates in the principal axes of the
     // point cloud: points that are close in object space are seen by the same cameras, so
@@ -1220,6 +1446,8 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
                 nbt[nbt.size() * 99 / 100], nbt.back(), (double)P.tile_cams.size() / nbt.size());
     }
     lapt("kernel choice");
+    build_heavy_plan(P);
+    lapt("heavy / giant points: row groups, slots, pair tasks");
     return true;
 }
 

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DBAT_HIP_ABI_VERSION 3   /* 3: dbat_hip_options grew (term_fun, veto_fun); 2: dbat_hip_result grew (stage_s, n_trace_only); dbat_hip_info [16]; dbat_hip_bench_step ms[12] */
+#define DBAT_HIP_ABI_VERSION 4   /* 4: dbat_hip_bench_step ms[16], dbat_hip_info [24]; 3: dbat_hip_options grew (term_fun, veto_fun); 2: dbat_hip_result grew (stage_s, n_trace_only); dbat_hip_info [16]; dbat_hip_bench_step ms[12] */
 
 /* error returns */
 #define DBAT_HIP_OK            0
@@ -376,7 +376,8 @@ int  dbat_hip_resect(int32_t device, int32_t n_images, const int64_t *pt_start, 
  * k_chol_df incl. its flag reset, the back-substitution kernels, k_residual_cm },
  * then (several ranks, domain sharding; else 0) { factorisation of the rank's own domain
  * + its shares of the top tiles, the all-reduce of the top tiles as the stream sees it,
- * top separators + backward substitution, 0 }.  ms[12]. */
+ * top separators + backward substitution, 0 }, then (heavy / giant points on the matrix cores, csrc/heavy.hpp;
+ * else 0) { camera side of their observations + k_heavy_z / k_heavy_z_giant, k_heavy_syrk, 0, 0 }.  ms[16]. */
 int  dbat_hip_bench_step(dbat_hip_handle *h, double lambda, int32_t scale_columns, double *ms);
 /* load x into the handle (device resident) before bench steps */
 int  dbat_hip_set_x(dbat_hip_handle *h, const double *x);
@@ -389,15 +390,20 @@ int  dbat_hip_set_x(dbat_hip_handle *h, const double *x);
  * linearisation info[11]=images in the top separators info[12]=tile rows of the factor
  * info[13], info[14]=tasks of the two launches of the factorisation
  * info[15]=v_mfma_f64_16x16x4_f64 instructions (2048 flops each) one launch of the tile kernel executes (its symmetric
- * products; the algorithmic count of the roofline is the full product) */
-int  dbat_hip_info(const dbat_hip_handle *h, int64_t *info /*[16]*/);
+ * products; the algorithmic count of the roofline is the full product)
+ * heavy / giant points on the matrix cores (csrc/heavy.hpp; all 0 when the column-list kernels take them):
+ * info[16]=tasks of k_heavy_syrk info[17]=its v_mfma_f64_16x16x4_f64 instructions per launch info[18]=row groups
+ * info[19]=bytes of the scratch array Zs info[20]=points info[21]=observations info[22]=k-steps per task at most
+ * info[23]=algorithmic flops of their Schur terms, sum of 108 k + 216 k^2 */
+int  dbat_hip_info(const dbat_hip_handle *h, int64_t *info /*[24]*/);
 
 /* Host only (no GPU): statistics of the layout the plan gives this problem (this shard), so that a test
  * can tell which code path of the signature kernel a scene exercises.  st[16]:
  * [0] tiles [1] batches [2] tiled batches [3] signature groups [4] their points [5] chunks
  * [6..9] chunks of 1-8 / 9-16 / 17-32 / 33-64 points (8, 4, 2, 1 lanes per point in pass 1)
  * [10] chunks that need more than one round of pass 2 [11] most cameras per chunk
- * [12] most rows of a chunk [13] 1 = k_build_sig selected [14] 1 = k_backsub_sig selected [15] 0 */
+ * [12] most rows of a chunk [13] 1 = k_build_sig selected [14] 1 = k_backsub_sig selected
+ * [15] tasks of k_heavy_syrk (0: heavy / giant points, if any, take the column-list kernels) */
 int  dbat_hip_plan_layout_stats(const dbat_hip_problem *prob, int64_t *st /*[16]*/);
 
 /* name of the kernel that builds the Schur complement of the tiled points in this handle
