@@ -1,6 +1,6 @@
 """Randomised sweep of the paths that regular synthetic scenes never reach, outside the test-suite: irregular
 visibility (random observations dropped, down to two rays per point), control points seen in many or all images
-(heavy points through the column-list kernel, giant points through k_build_giant / k_backsub_giant), cameras per
+(heavy and giant points: k_heavy_z / k_heavy_z_giant / k_heavy_syrk of csrc/heavy.hpp, or the column-list kernels), cameras per
 tile, batch length and giant-kernel width forced small, signature kernels on / off -- the device's Gauss-Newton and
 damped steps, step scalars, gradient and (small scenes) the posterior covariance blocks against the oracle.
     python bench/fuzz_irregular.py [n_scenes] [first_seed]"""
@@ -13,7 +13,7 @@ from dbat_amd import synth, _hip
 from test_hip_parity import oracle_setup
 
 relerr = lambda a, b: float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
-KNOBS = ('DBAT_HIP_SIG', 'DBAT_HIP_CMAX', 'DBAT_HIP_BT', 'DBAT_HIP_GIANT_THREADS')
+KNOBS = ('DBAT_HIP_SIG', 'DBAT_HIP_CMAX', 'DBAT_HIP_BT', 'DBAT_HIP_GIANT_THREADS', 'DBAT_HIP_HEAVY', 'DBAT_HIP_HEAVY_KS')
 
 
 def irregular_scene(sd):
@@ -51,6 +51,11 @@ def irregular_scene(sd):
     if rng.integers(0, 2):
         env['DBAT_HIP_BT'] = str(rng.choice(['128', '256']))
         env['DBAT_HIP_GIANT_THREADS'] = str(rng.choice(['64', '128', '256']))
+    # heavy / giant points: the matrix-core path of csrc/heavy.hpp (default) with tasks of a few k-steps now and then, or
+    # the column-list kernels it replaces
+    hk = int(rng.integers(0, 4))
+    if hk == 0: env['DBAT_HIP_HEAVY'] = '0'
+    elif hk == 1: env['DBAT_HIP_HEAVY_KS'] = str(rng.choice(['1', '3', '7']))
     desc = '%3d cams %4d pts %2d rays, %d obs (max %3d per point), selfcal=%d groups=%d, drop %.1f, %s' % (
         cams, points, rays, len(cam), int(np.bincount(pt).max()), selfcal, groups, drop, ' '.join('%s=%s' % (k[9:], v) for k, v in env.items()) or 'defaults')
     return s, env, desc

@@ -68,11 +68,31 @@ class Options(C.Structure):
         ('lambda_min', C.c_double), ('rho_bad', C.c_double), ('rho_good', C.c_double),
         ('delta0', C.c_double),
         ('term_fun', C.c_void_p), ('term_user', C.c_void_p), ('veto_fun', C.c_void_p), ('veto_user', C.c_void_p),
+        ('trace_fun', C.c_void_p), ('trace_user', C.c_void_p),
     ]
 
 
 TERM_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, _dp, _dp, C.c_int64)   # dbat_hip_term_fn
 VETO_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, _dp, C.c_int64)        # dbat_hip_veto_fn
+TRACE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_double)   # dbat_hip_trace_fn
+
+
+def trace_text(damping, n, res, damp, step, rho):
+    """The line the reference's lsa solver prints with 'trace' (gauss_newton_armijo.m:119-128, gauss_markov.m:74-76,
+    levenberg_marquardt.m:138-147, levenberg_marquardt_powell.m:160-164), from the arguments of a dbat_hip_trace_fn."""
+    from fractions import Fraction
+    if damping == DAMP['gna']:
+        if damp != damp:
+            return 'Gauss-Newton-Armijo: iteration %d, residual norm=%.2g' % (n, res)
+        return 'Gauss-Newton-Armijo: iteration %d, residual norm=%.2g, last alpha=%s' % (n, res, Fraction(damp).limit_denominator(1 << 40))   # strtrim(rats(alpha)): alpha = 2^-k
+    if damping == DAMP['lm']:
+        if damp != damp:
+            return 'Levenberg-Marquardt: iteration %d, residual norm=%.2g' % (n, res)
+        return 'Levenberg-Marquardt: iteration %d, residual norm=%.2g, lambda=%.2g' % (n, res, damp)
+    if damping == DAMP['lmp']:
+        return 'Levenberg-Marquardt-Powell: iteration %d, residual norm=%.2g, delta=%.2g, step=%s, rho=%.1f' % (
+            n, res, damp, ('GN', 'IP', 'CP')[step] if 0 <= step < 3 else '?', rho)
+    return 'Gauss-Markov: iteration %d, residual norm=%.2g' % (n, res)
 
 
 class Result(C.Structure):
@@ -125,6 +145,9 @@ SYMBOLS = {
     'dbat_hip_forwintersect': (C.c_int, [_H, _dp, _bp, _dp]),
     'dbat_hip_resect': (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_int64), _dp, _dp, C.POINTER(C.c_int64), _ip, _dp, _dp]),
     'dbat_hip_bench_step': (C.c_int, [_H, C.c_double, C.c_int32, _dp]),
+    'dbat_hip_structure_key': (C.c_int, [C.POINTER(Problem), C.POINTER(C.c_uint64)]),
+    'dbat_hip_handle_key': (C.c_int, [_H, C.POINTER(C.c_uint64)]),
+    'dbat_hip_set_values': (C.c_int, [_H, C.POINTER(Problem)]),
     'dbat_hip_set_x': (C.c_int, [_H, _dp]),
     'dbat_hip_info': (C.c_int, [_H, C.POINTER(C.c_int64)]),
     'dbat_hip_build_kernel_name': (C.c_int, [_H, C.c_char_p, C.c_int32]),
@@ -197,16 +220,33 @@ def dptr(a):
     return a.ctypes.data_as(_dp) if a is not None else None
 
 
+def _flat(a, dtype):
+    """a as a flat column-major array of dtype -- WITHOUT a copy when it already is one (a Fortran-ordered or
+    one-dimensional array of that type: what dbat_amd.dbatstruct builds), so that marshalling a 10 M observation struct
+    for a cached handle costs microseconds, not a pass over 500 MB."""
+    a = np.asarray(a)
+    if a.dtype != dtype:
+        a = a.astype(dtype)
+    if a.ndim <= 1:
+        return np.ascontiguousarray(a)
+    if a.flags.f_contiguous:
+        return a.reshape(-1, order='F')
+    return a.flatten('F')
+
+
 def _f64(a):
-    return np.ascontiguousarray(np.asarray(a, dtype=np.float64).flatten('F'))
+    return _flat(a, np.float64)
 
 
 def _u8(a):
-    return np.ascontiguousarray(np.asarray(a, dtype=bool).flatten('F').astype(np.uint8))
+    a = np.asarray(a)
+    if a.dtype != np.bool_:
+        a = a.astype(bool)
+    return _flat(a, np.bool_).view(np.uint8)
 
 
 def _i32(a):
-    return np.ascontiguousarray(np.asarray(a).flatten('F').astype(np.int32))
+    return _flat(a, np.int32)
 
 
 def problem_from_struct(s, device=0, shard_rank=0, shard_count=1):
@@ -238,9 +278,14 @@ def problem_from_struct(s, device=0, shard_rank=0, shard_count=1):
     for nm in ('IO', 'EO', 'OP'):
         pr = getattr(s.prior, nm)
         rows = slice(0, 6) if nm == 'EO' else slice(None)
-        keep['prior_%s_use' % nm] = _u8(np.asarray(pr.use)[rows])
-        keep['prior_%s_val' % nm] = _f64(np.nan_to_num(np.asarray(pr.val, float)[rows]))
-        keep['prior_%s_std' % nm] = _f64(np.nan_to_num(np.asarray(pr.std, float)[rows], nan=1.0))
+        use = np.asarray(pr.use)[rows]
+        keep['prior_%s_use' % nm] = _u8(use)
+        if use.any():
+            keep['prior_%s_val' % nm] = _f64(np.nan_to_num(np.asarray(pr.val, float)[rows]))
+            keep['prior_%s_std' % nm] = _f64(np.nan_to_num(np.asarray(pr.std, float)[rows], nan=1.0))
+        else:                   # (the library reads value and standard deviation only where `use` is set: no pass over the arrays)
+            keep['prior_%s_val' % nm] = _f64(np.asarray(pr.val, float)[rows])
+            keep['prior_%s_std' % nm] = _f64(np.asarray(pr.std, float)[rows])
     p = Problem()
     p.abi_version = ABI_VERSION
     p.n_images, p.n_points, p.n_obs = nc, npnt, no
@@ -255,9 +300,9 @@ def problem_from_struct(s, device=0, shard_rank=0, shard_count=1):
 class Handle:
     """RAII wrapper of dbat_hip_handle."""
 
-    def __init__(self, s, device=0, shard_rank=0, shard_count=1):
+    def __init__(self, s, device=0, shard_rank=0, shard_count=1, _problem=None):
         self.lib = load()
-        self.prob, self._keep = problem_from_struct(s, device, shard_rank, shard_count)
+        self.prob, self._keep = _problem if _problem is not None else problem_from_struct(s, device, shard_rank, shard_count)
         h = _H()
         check(self.lib.dbat_hip_create(C.byref(self.prob), C.byref(h)))
         self.h = h
@@ -271,6 +316,20 @@ class Handle:
             self.h = None
 
     __del__ = close
+
+    def key(self):
+        """The structure key of the problem this handle was created from (dbat_hip_handle_key)."""
+        k = (C.c_uint64 * 2)()
+        check(self.lib.dbat_hip_handle_key(self.h, k))
+        return (int(k[0]), int(k[1]))
+
+    def set_values(self, s=None, _problem=None):
+        """New IO / EO / OP values and prior observations of a struct with the same structure (dbat_hip_set_values);
+        DbatHipError if the structure differs."""
+        prob, keep = _problem if _problem is not None else problem_from_struct(
+            s, self.prob.device, self.prob.shard_rank, self.prob.shard_count)
+        check(self.lib.dbat_hip_set_values(self.h, C.byref(prob)))
+        self.prob, self._keep = prob, keep
 
     def serialize(self):
         x = np.empty(self.n)
@@ -362,9 +421,11 @@ class Handle:
         check(self.lib.dbat_hip_jtimes(self.h, dptr(v), dptr(out)))
         return out
 
-    def solve(self, x0, opt, term_fun=None, veto_fun=None):
+    def solve(self, x0, opt, term_fun=None, veto_fun=None, trace_fun=None):
         """term_fun(Jp, r) -> bool and veto_fun(x) -> bool: the caller's own tests (bundle.m:168-192), called from the
-        damping loop with numpy views of the library's vectors; an exception inside one ends the run and is re-raised."""
+        damping loop with numpy views of the library's vectors; an exception inside one ends the run and is re-raised.
+        trace_fun(damping, n, res_norm, damp, step_type, rho): called where the reference's solver prints its 'trace' line
+        (trace_text formats it)."""
         x = np.ascontiguousarray(x0, float).copy()
         raised = []
 
@@ -384,9 +445,20 @@ class Handle:
         if veto_fun is not None:
             keep.append(VETO_FN(lambda _u, xx, n: guarded(veto_fun, np.ctypeslib.as_array(xx, (n,)).copy())))
             opt.veto_fun = C.cast(keep[-1], C.c_void_p)
+        if trace_fun is not None:
+            def traced(_u, damping, n, res, damp, step, rho):
+                if not raised:
+                    try:
+                        trace_fun(damping, n, res, damp, step, rho)
+                    except BaseException as e:
+                        raised.append(e)
+            keep.append(TRACE_FN(traced))
+            opt.trace_fun = C.cast(keep[-1], C.c_void_p)
         try:
             return self._solve(x, opt, raised)
         finally:
+            if trace_fun is not None:
+                opt.trace_fun = None
             if term_fun is not None:
                 opt.term_fun = None
             if veto_fun is not None:
@@ -512,6 +584,66 @@ class Handle:
                 'heavy_tasks', 'heavy_mfma', 'heavy_row_groups', 'heavy_scratch_bytes', 'heavy_points', 'heavy_obs',
                 'heavy_ksteps_per_task', 'heavy_algorithmic_flops')
         return dict(zip(keys, [int(v) for v in a]))
+
+
+def structure_key(s, device=0, shard_rank=0, shard_count=1, _problem=None):
+    """Host-only: the 128-bit key of everything a plan depends on (dbat_hip_structure_key) -- equal keys: one handle
+    serves both structs through Handle.set_values."""
+    prob, keep = _problem if _problem is not None else problem_from_struct(s, device, shard_rank, shard_count)
+    k = (C.c_uint64 * 2)()
+    check(load().dbat_hip_structure_key(C.byref(prob), k))
+    return (int(k[0]), int(k[1]))
+
+
+# ---- handle cache: bundle() -> bundle() -> bundle_cov() on one structure build ONE plan (the reference keeps its index
+# structures in s.bundle.serial / deserial, bundle.m:156-159).  One handle (it owns device memory in proportion to the
+# problem), one-rank handles only; a struct whose structure key differs -- a changed mask, block, observation -- gets a
+# new handle and the cached one is destroyed.
+_cached = None
+cache_stats = {'hits': 0, 'misses': 0}
+
+
+def acquire(s, device=0):
+    """A one-rank handle for s: the cached one with s's values (dbat_hip_set_values) when the structure key matches, a
+    new one otherwise.  Give it back with release()."""
+    global _cached
+    problem = problem_from_struct(s, device)
+    h, _cached = _cached, None
+    if h is not None and h.h:
+        if h.key() == structure_key(None, _problem=problem):
+            try:
+                h.set_values(_problem=problem)
+                cache_stats['hits'] += 1
+                cache_stats['last'] = 'hit'
+                return h
+            except DbatHipError:
+                pass
+        h.close()
+    cache_stats['misses'] += 1
+    cache_stats['last'] = 'miss'
+    return Handle(None, _problem=problem)
+
+
+def release(h, keep=True):
+    """Return a handle of acquire(): kept for the next acquire() of the same structure (keep=False, or an older cached
+    handle: closed)."""
+    global _cached
+    if not keep or h is None or not h.h:
+        if h is not None:
+            h.close()
+        return
+    if _cached is not None and _cached is not h:
+        _cached.close()
+    h.set_deterministic(False)
+    _cached = h
+
+
+def clear_cache():
+    """Destroy the cached handle (frees its device memory)."""
+    global _cached
+    if _cached is not None:
+        _cached.close()
+    _cached = None
 
 
 def default_options(damping='gna'):

@@ -389,7 +389,7 @@ struct Core {
         d.o_uv_raw = o_uv.p; d.uv_pre = uv_pre ? 1 : 0;
         if (!uv_pre || nobs == 0) return;
         prep_cams(z.p, cams_f.p);                    // interior orientation: the fixed values
-        o_rhs.alloc((size_t)2 * nobs);
+        if (!o_rhs.p) o_rhs.alloc((size_t)2 * nobs);
 #define L_RHS(M, dummy)                                                                                              \
         LAUNCHK((k_uv_to_rhs<M>), dim3((unsigned)cdiv(nobs, 256)), dim3(256), 0, stream, d.nK, d.nP, cams_f.p, nobs, o_cam.p, o_uv.p, o_rhs.p); \
         if (n_cm_chunks_all > 0) LAUNCHK((k_uv_to_rhs_cm<M>), dim3((unsigned)n_cm_chunks_all), dim3(256), 0, stream, d.nK, d.nP, cams_f.p, cm_chunk_cam.p, cm_chunk_start.p, cm_uv.p); \
@@ -397,6 +397,30 @@ struct Core {
         DISPATCH_MODEL(L_RHS, 0)
 #undef L_RHS
         d.o_uv = o_rhs.p;
+    }
+
+    // dbat_hip_set_values: new parameter values / prior observations for the same structure.  The host plan has them
+    // already (plan_set_values); here the device copies, and everything a previous solve left behind is forgotten.
+    void set_values(bool io_changed) {
+        HIPCHK(hipMemcpyAsync(z.p, P.z0.data(), P.NZ * 8, hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(io_fixed.p, P.io_fixed.data(), P.io_fixed.size() * 8, hipMemcpyHostToDevice, stream));
+        if (d.any_prior) {
+            HIPCHK(hipMemcpyAsync(z_prw.p, P.z_prw.data(), P.NZ * 8, hipMemcpyHostToDevice, stream));
+            HIPCHK(hipMemcpyAsync(z_prv.p, P.z_prv.data(), P.NZ * 8, hipMemcpyHostToDevice, stream));
+        }
+        HIPCHK(hipStreamSynchronize(stream));
+        if (uv_pre && io_changed && nobs > 0) {
+            // fixed interior orientation with other values: the corrected image coordinates again, from the measured ones
+            // (the camera-major and slot-major copies were converted in place)
+            HIPCHK(hipMemcpy(cm_uv.p, P.cm_uv.data(), P.cm_uv.size() * 8, hipMemcpyHostToDevice));
+            if (use_sig && sg_nchunks > 0) HIPCHK(hipMemcpy(sg_uv.p, P.sg_uv.data(), P.sg_uv.size() * 8, hipMemcpyHostToDevice));
+            d.o_uv = o_uv.p;
+            precompute_image_side();
+            HIPCHK(hipStreamSynchronize(stream));
+        }
+        cams_at_lin = false; have_lin = false; s_valid = false; pend_build = false; lin_pending = false;
+        lambda_lin = 0; scale_lin = 0; f_lin = 0; trace_jtj = 0; near_singular = false; chol_in_place = false; replicate_next = false;
+        n_res_evals = n_lin = n_solves = n_trace_only = 0;
     }
 
     // grid of the grid-stride observation kernels: one resident round (k_residual: 6 waves/SIMD
@@ -1182,6 +1206,11 @@ static bool vetoed(Core &c, const dbat_hip_options &o) {
     return o.veto_fun(o.veto_user, x.data(), c.P.n) != 0;
 }
 
+// the line the lsa solver prints with 'trace', handed to the caller while the loop runs (dbat_hip_trace_fn)
+static inline void trace_line(const dbat_hip_options &o, int n, double res, double damp, int step = -1, double rho = NAN) {
+    if (o.trace_fun) o.trace_fun(o.trace_user, o.damping, n, res, damp, step, rho);
+}
+
 static void push_trace(Core &c, const dbat_hip_options &o, LoopOut &out) {
     if (!o.store_trace) return;
     std::vector<double> x(c.P.n);
@@ -1204,6 +1233,7 @@ static void loop_gna(Core &c, const dbat_hip_options &o, LoopOut &out) {
     while (true) {
         c.build(c.z.p, 0.0, 1, true);                             // :112-116, :166-170 (scalars: with the solve's sync)
         out.res.push_back(std::sqrt(2 * f));
+        trace_line(o, n, out.res.back(), out.damp.empty() ? NAN : out.damp.back());   // :119-128
         if (n == 0 && !c.P.rank_ok) { out.code = -4; break; }     // :132-142
         double JpJp, rJp, pp;
         const bool failed = c.solve(JpJp, rJp, pp);               // :172-174
@@ -1241,6 +1271,7 @@ static void loop_gm(Core &c, const dbat_hip_options &o, LoopOut &out) {
         f = c.eval_f(c.z.p, nullptr, nullptr);
         c.build(c.z.p, 0.0, 0, true);
         out.res.push_back(std::sqrt(2 * f));
+        trace_line(o, n, out.res.back(), NAN);                    // :74-76
         double JpJp, rJp, pp;
         const bool failed = c.solve(JpJp, rJp, pp);               // :79
         if (failed || (o.singular_test && c.near_singular)) { out.code = -2; break; }
@@ -1288,6 +1319,7 @@ static void loop_lm(Core &c, const dbat_hip_options &o, LoopOut &out) {
             if (n == 0 && !c.P.rank_ok) { out.code = -4; break; }             // :126-135
             if (failed) { out.code = -2; break; }   // the reference has no test here; MATLAB would continue on Inf/NaN
             out.damp.push_back(lambda);
+            trace_line(o, n, out.res.back(), n == 0 ? NAN : lambda);              // :138-147
             if (o.store_trace) { std::vector<double> x(c.P.n); c.z_to_x(c.z.p, x.data()); if ((int)T.size() <= n) T.resize(n + 1); T[n] = std::move(x); }
             ++n;
             const double fNew = c.eval_f_step(c.z.p, 1.0, c.dz.p, c.zt.p);                 // t = x+p
@@ -1383,6 +1415,7 @@ static void loop_lmp(Core &c, const dbat_hip_options &o, double delta0, LoopOut 
         const double actual = f - ft;
         const double rho = actual / predicted;
         rhos.push_back(rho);
+        trace_line(o, n, out.res.back(), delta, step, rho);        // :160-164
         if (veto || rho <= o.rho_bad) {                            // :166-179
             delta = delta / 2;
             if (delta > npGN) delta = delta / std::exp2(std::ceil(std::log2(delta / npGN)));
@@ -1439,6 +1472,7 @@ int dbat_hip_abi_version(void) { return DBAT_HIP_ABI_VERSION; }
 int dbat_hip_default_options(int32_t damping, dbat_hip_options *opt) {
     if (!opt || damping < 0 || damping > 3) { g_err = "bad damping"; return DBAT_HIP_EINVAL; }
     opt->term_fun = nullptr; opt->term_user = nullptr; opt->veto_fun = nullptr; opt->veto_user = nullptr;
+    opt->trace_fun = nullptr; opt->trace_user = nullptr;
     opt->damping = damping; opt->max_iter = 20; opt->conv_tol = 1e-6; opt->abs_term = 0;
     opt->singular_test = 1; opt->store_trace = 1; opt->mu = 0.1; opt->alpha_min = 1e-9;
     opt->lambda0 = -1e-10; opt->lambda_min = -1e-10; opt->rho_bad = 0.25; opt->rho_good = 0.75;
@@ -1562,6 +1596,42 @@ int dbat_hip_create(const dbat_hip_problem *prob, dbat_hip_handle **out) {
 }
 
 void dbat_hip_destroy(dbat_hip_handle *h) { delete h; }
+
+int dbat_hip_structure_key(const dbat_hip_problem *prob, uint64_t *key) {
+    API_TRY
+    if (!prob || !key) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
+    if (prob->abi_version != DBAT_HIP_ABI_VERSION) { g_err = "ABI version mismatch"; return DBAT_HIP_EINVAL; }
+    structure_key(*prob, key);
+    return DBAT_HIP_OK;
+    API_CATCH
+}
+
+int dbat_hip_handle_key(const dbat_hip_handle *h, uint64_t *key) {
+    if (!h || !key) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
+    key[0] = h->core->P.key[0]; key[1] = h->core->P.key[1];
+    return DBAT_HIP_OK;
+}
+
+int dbat_hip_set_values(dbat_hip_handle *h, const dbat_hip_problem *prob) {
+    API_TRY
+    if (!h || !prob) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
+    Core &c = *h->core;
+    uint64_t key[2];
+    if (prob->abi_version != DBAT_HIP_ABI_VERSION) { g_err = "ABI version mismatch"; return DBAT_HIP_EINVAL; }
+    structure_key(*prob, key);
+    if (key[0] != c.P.key[0] || key[1] != c.P.key[1]) {
+        g_err = "dbat_hip_set_values: the problem's structure (sizes, visibility, image observations, masks, blocks, prior pattern, "
+                "shard, device, DBAT_HIP_* environment) differs from the one this handle was created for: create a new handle";
+        return DBAT_HIP_EINVAL;
+    }
+    DeviceGuard dev_guard(c.device);
+    const size_t nio = (size_t)c.P.nIOrows * c.P.nc;
+    const bool io_changed = memcmp(c.P.io_fixed.data(), prob->IO_val, nio * sizeof(double)) != 0;
+    if (!plan_set_values(*prob, c.P)) { g_err = c.P.err; return DBAT_HIP_EINVAL; }
+    c.set_values(io_changed);
+    return DBAT_HIP_OK;
+    API_CATCH
+}
 
 int64_t dbat_hip_num_params(const dbat_hip_handle *h) { return h ? h->core->P.n : -1; }
 int64_t dbat_hip_num_residuals(const dbat_hip_handle *h) { return h ? h->core->P.m : -1; }

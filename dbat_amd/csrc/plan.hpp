@@ -39,6 +39,8 @@ struct Plan {
     int64_t NS = 0, NZ = 0;
     int nIOu = 0;
     std::vector<int64_t> x2z;                      // [n] z index of every x entry
+    std::vector<int64_t> lead_io;                  // [nIOu] entry of IO.val (column-major) that leads every IO unknown
+    uint64_t key[2] = {0, 0};                      // structure_key of the problem the plan was built from
     std::vector<int32_t> io_src;                   // [nIOrows*nc] IOu index or -1 (fixed)
     std::vector<double> io_fixed;                  // [nIOrows*nc] IO.val (used where io_src<0)
     std::vector<uint8_t> z_est;                    // [NZ]
@@ -393,6 +395,103 @@ inline void build_heavy_plan(Plan &P) {
                 nhp, (long long)nho, ng, hcams.size(), hio.size(), npairs, (long long)total_ks, P.hv_ntasks, ksmax, P.hv_z_doubles * 8e-6);
 }
 
+// ---- plan reuse (dbat_hip_structure_key / dbat_hip_set_values) --------------------------------------------------------
+// What a plan depends on -- everything of the problem but the parameter VALUES (IO, EO, OP) and the values / standard
+// deviations of the prior observations: sizes, lens model, visibility (ip_cam, ip_pt), the image observations and their
+// standard deviations, pixel sizes, the estimation masks, the block structure, which parameters have prior observations,
+// the shard, the device, and the DBAT_HIP_* switches of the environment.  Two problems with the same key differ at most in
+// those values: the reference re-enters bundle() from any s at no set-up cost (misc/deserialize.m:31-46); here a handle is
+// re-used through dbat_hip_set_values.  128 bits, the same for any number of threads (fixed blocks, combined in order).
+inline void hash_words(const void *data, size_t bytes, uint64_t &h0, uint64_t &h1) {
+    const unsigned char *p = static_cast<const unsigned char *>(data);
+    uint64_t a = h0 ^ 0x9E3779B97F4A7C15ull, b = h1 ^ 0xC2B2AE3D27D4EB4Full, c = h0 + 0x165667B19E3779F9ull, d = h1 + 0x27D4EB2F165667C5ull;
+    auto mix = [](uint64_t h, uint64_t w, uint64_t k) { h ^= w * k; h = ((h << 31) | (h >> 33)) * 0x9FB21C651E98DF25ull; return h; };
+    size_t i = 0;
+    for (; i + 16 <= bytes; i += 16) {
+        uint64_t w0, w1;
+        memcpy(&w0, p + i, 8); memcpy(&w1, p + i + 8, 8);
+        a = mix(a, w0, 0xA0761D6478BD642Full); b = mix(b, w0, 0xE7037ED1A0B428DBull);
+        c = mix(c, w1, 0x8EBC6AF09C88C6E3ull); d = mix(d, w1, 0x589965CC75374CC3ull);
+    }
+    uint64_t tail[2] = {0, 0};
+    if (i < bytes) memcpy(tail, p + i, bytes - i);
+    a = mix(a, tail[0] ^ (uint64_t)bytes, 0xA0761D6478BD642Full); b = mix(b, tail[1] + (uint64_t)bytes, 0xE7037ED1A0B428DBull);
+    h0 = mix(a, c, 0x1D8E4E27C47D124Full); h1 = mix(b, d, 0xEB44ACCAB455D165ull);
+    h0 ^= h0 >> 29; h1 ^= h1 >> 32;
+}
+inline void structure_key(const dbat_hip_problem &pb, uint64_t key[2]) {
+    uint64_t h0 = 0x0123456789ABCDEFull, h1 = 0xFEDCBA9876543210ull;
+    const Par par{Par::default_threads()};
+    auto field = [&](const void *data, size_t bytes, uint64_t tag) {
+        const uint64_t hdr[3] = {tag, (uint64_t)bytes, data ? 1ull : 0ull};
+        hash_words(hdr, sizeof(hdr), h0, h1);
+        if (!data || !bytes) return;
+        constexpr size_t BLK = (size_t)1 << 20;
+        const int64_t nblk = (int64_t)((bytes + BLK - 1) / BLK);
+        if (nblk <= 1) { hash_words(data, bytes, h0, h1); return; }
+        std::vector<uint64_t> bh((size_t)2 * nblk);
+        par.run(nblk, [&](int64_t lo, int64_t hi, int) {
+            for (int64_t q = lo; q < hi; ++q) {
+                uint64_t a = (uint64_t)q, b = ~(uint64_t)q;
+                hash_words(static_cast<const unsigned char *>(data) + (size_t)q * BLK, std::min(BLK, bytes - (size_t)q * BLK), a, b);
+                bh[2 * q] = a; bh[2 * q + 1] = b;
+            }
+        }, 1);
+        hash_words(bh.data(), bh.size() * 8, h0, h1);
+    };
+    const int64_t nc = pb.n_images, np = pb.n_points, no = pb.n_obs, R = 5 + (int64_t)pb.nK + pb.nP;
+    const int64_t hdr[10] = {pb.abi_version, nc, np, no, pb.dist_model, pb.nK, pb.nP, pb.device, pb.shard_rank, pb.shard_count};
+    field(hdr, sizeof(hdr), 1);
+    if (nc > 0 && np > 0 && no >= 0 && R >= 5 && R <= MAXIO) {
+        field(pb.ip_cam, (size_t)no * 4, 2); field(pb.ip_pt, (size_t)no * 4, 3);
+        field(pb.ip_val, (size_t)no * 16, 4); field(pb.ip_std, (size_t)no * 16, 5);
+        field(pb.px_size, (size_t)nc * 16, 6);
+        field(pb.est_IO, (size_t)(R * nc), 7); field(pb.est_EO, (size_t)(6 * nc), 8); field(pb.est_OP, (size_t)(3 * np), 9);
+        field(pb.IO_block, (size_t)(R * nc) * 4, 10); field(pb.EO_block, (size_t)(6 * nc) * 4, 11);
+        field(pb.prior_IO_use, (size_t)(R * nc), 12); field(pb.prior_EO_use, (size_t)(6 * nc), 13); field(pb.prior_OP_use, (size_t)(3 * np), 14);
+    }
+    // the switches of the environment select layouts and kernels: part of the structure
+    std::vector<std::string> envs;
+    for (char **e = environ; e && *e; ++e) if (strncmp(*e, "DBAT_HIP_", 9) == 0) envs.emplace_back(*e);
+    std::sort(envs.begin(), envs.end());
+    for (const std::string &e : envs) field(e.data(), e.size(), 15);
+    key[0] = h0; key[1] = h1;
+}
+
+// New parameter values and prior observations for a plan of the same structure: z0, the fixed IO values, the prior
+// weights and values -- exactly what build_plan derives from IO_val, EO_val, OP_val and prior_*_val / prior_*_std.
+inline bool plan_set_values(const dbat_hip_problem &pb, Plan &P) {
+    const int nc = P.nc, np = P.np, R = P.nIOrows;
+    const Par par{Par::default_threads()};
+    for (size_t e = 0; e < (size_t)6 * nc; ++e) P.z0[e] = pb.EO_val[e];
+    for (int k = 0; k < P.nIOu; ++k) P.z0[6 * (int64_t)nc + k] = pb.IO_val[P.lead_io[k]];
+    par.run(np, [&](int64_t plo, int64_t phi, int) {
+        for (int64_t p = plo; p < phi; ++p)
+            for (int d = 0; d < 3; ++d) P.z0[P.NS + 3 * (int64_t)P.pt_rank[p] + d] = pb.OP_val[3 * p + d];
+    });
+    P.io_fixed.assign(pb.IO_val, pb.IO_val + (size_t)R * nc);
+    bool bad = false;
+    auto prior = [&](int64_t z, double val, double std_) {
+        const double w = 1.0 / (std_ * std_);
+        if (!(w > 0) || !std::isfinite(w)) bad = true;
+        P.z_prw[z] = w; P.z_prv[z] = val;
+    };
+    // (which entries have prior observations is structure: z_prw > 0 marks them)
+    for (int k = 0; k < P.nIOu; ++k) {
+        const int64_t e = P.lead_io[k], z = 6 * (int64_t)nc + k;
+        if (P.z_prw[z] > 0) prior(z, pb.prior_IO_val[e], pb.prior_IO_std[e]);
+    }
+    for (size_t e = 0; e < (size_t)6 * nc; ++e) if (P.z_prw[e] > 0) prior((int64_t)e, pb.prior_EO_val[e], pb.prior_EO_std[e]);
+    if (P.n_prior[2] > 0)
+        for (int64_t p = 0; p < np; ++p)
+            for (int d = 0; d < 3; ++d) {
+                const int64_t z = P.NS + 3 * (int64_t)P.pt_rank[p] + d;
+                if (P.z_prw[z] > 0) prior(z, pb.prior_OP_val[3 * p + d], pb.prior_OP_std[3 * p + d]);
+            }
+    if (bad) return fail(P, "prior observation with zero/invalid std");
+    return true;
+}
+
 inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     // DBAT_HIP_PLAN_STATS=2: wall time of every section of the plan (stderr)
     const bool plan_clock = env_int("DBAT_HIP_PLAN_STATS", 0) >= 2;
@@ -406,6 +505,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     if (pb.abi_version != DBAT_HIP_ABI_VERSION) return fail(P, "ABI version mismatch");
     { std::string env_err; if (!env_validate(env_err)) return fail(P, env_err.c_str()); }
     if (pb.n_images <= 0 || pb.n_points <= 0 || pb.n_obs < 0) return fail(P, "empty problem");
+    if (with_obs) structure_key(pb, P.key);
     if (pb.dist_model < 2 || pb.dist_model > 5)
         return fail(P, "lens distortion model must be 2..5 (brown_euler_cam4.m:122-130)");
     if (pb.nK < 0 || pb.nK > MAXK || pb.nP < 0 || pb.nP > MAXP || pb.nP == 1)
@@ -452,6 +552,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     for (size_t e = 0; e < estIO.size(); ++e)
         if (estIO[e] && pb.IO_block[e] == 0) return fail(P, "estimated IO element with block id 0");
     P.nIOu = (int)leadIO.size();
+    P.lead_io = leadIO;
     P.nIO = P.nIOu; P.nEO = (int64_t)leadEO.size();
     P.NS = (int64_t)6 * nc + P.nIOu;
     P.NZ = P.NS + (int64_t)3 * np;

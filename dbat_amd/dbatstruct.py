@@ -81,8 +81,8 @@ def make_struct(IO, EO, OP, ip_val, ip_cam, ip_pt, pxSize, *, ip_std=None,
                                if EOblock is None else np.array(EOblock, np.int64))))
     s.OP = NS(val=OP, id=np.arange(1, OP.shape[1] + 1))      # prob2dbatstruct.m: OP.id
     s.IP = NS(val=ip_val, std=np.array(std, float, order='F'),
-              cam=np.asarray(ip_cam, np.int64).copy(),
-              pt=np.asarray(ip_pt, np.int64).copy(),
+              cam=np.array(ip_cam, np.int32),              # (int32: what the C ABI takes -- no conversion per bundle() call)
+              pt=np.array(ip_pt, np.int32),
               sigmas=sigmas)
     s.bundle = NS(est=NS(
         IO=np.zeros(IO.shape, bool) if estIO is None else np.array(estIO, bool),
@@ -110,7 +110,7 @@ def validate(s):
     if cam.size:
         if cam.min() < 0 or cam.max() >= nc or pt.min() < 0 or pt.max() >= npnt:
             raise ValueError('IP.cam/IP.pt out of range')
-        key = cam * np.int64(npnt) + pt
+        key = cam.astype(np.int64) * np.int64(npnt) + pt
         if np.any(np.diff(key) <= 0):
             raise ValueError('IP columns must be image-major with strictly '
                              'ascending OP index within each image')
@@ -122,6 +122,16 @@ def validate(s):
 
 def copy_struct(s):
     return copy.deepcopy(s)
+
+
+def share_struct(s):
+    """A new struct whose namespaces are copies and whose ARRAYS are shared with s: what bundle() works on.  bundle() never
+    writes into an array of its input -- it replaces IO.val / EO.val / OP.val / prior.*.use by new arrays and adds s.post
+    -- so the caller's struct stays as it was (MATLAB's value semantics, bundle.m:1) without a pass over the 10 M
+    observations of a large project; the result shares its untouched arrays (IP.*, masks, blocks) with the input."""
+    if isinstance(s, NS):
+        return NS(**{k: share_struct(v) for k, v in vars(s).items()})
+    return s
 
 
 def seteoest_depend(s, camNo=0):

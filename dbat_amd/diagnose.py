@@ -19,69 +19,146 @@ import numpy as np
 import scipy.sparse as sp
 
 
-def buildparamtypes(s):
-    """Names of every IO / EO / OP entry (misc/buildparamtypes.m:46-136):
+class _Namer:
+    """Names of the IO / EO / OP entries (misc/buildparamtypes.m:46-136), one at a time:
     'cc', 'px', .. 'K1', 'P1' (with '-<col>' for image-variant cameras and
     '-<col>(<block>)' for mixed ones); 'EX-<n>' .. 'ka-<n>'; 'OX-<n>[/<id>]',
     control points 'CX..', check points 'HX..'."""
-    nK, nP = int(s.IO.model.nK), int(s.IO.model.nP)
-    base = ['cc', 'px', 'py', 'as', 'sk'] + ['K%d' % (k + 1) for k in range(nK)] + ['P%d' % (k + 1) for k in range(nP)]
-    nc = s.IO.val.shape[1]
-    IO = np.empty((len(base), nc), object)
-    blk = np.asarray(s.IO.struct.block)
-    one_block = len(np.unique(blk)) == 1
-    # isSimple: every parameter of the column belongs to the column's own block
-    simple = np.all(blk == blk[0:1], axis=0)
-    for j in range(nc):
-        for i, b in enumerate(base):
-            if nc == 1 or one_block:
-                IO[i, j] = b
-            elif simple.all():
-                IO[i, j] = '%s-%d' % (b, j + 1)
-            else:
-                IO[i, j] = '%s-%d(%d)' % (b, j + 1, blk[i, j])
-    ne = s.EO.val.shape[1]
-    EO = np.empty((6, ne), object)
-    eid = np.asarray(getattr(s.EO, 'id', np.arange(1, ne + 1)))
-    use_ids = bool(np.any(eid != np.arange(1, ne + 1)))
-    for j in range(ne):
-        tail = '' if ne == 1 else ('-%d(%d)' % (j + 1, eid[j]) if use_ids else '-%d' % (j + 1))
-        for i, b in enumerate(['EX', 'EY', 'EZ', 'om', 'ph', 'ka']):
-            EO[i, j] = b + tail
-    npnt = s.OP.val.shape[1]
-    OP = np.empty((3, npnt), object)
-    oid = np.asarray(getattr(s.OP, 'id', np.arange(1, npnt + 1)))
-    raw = np.asarray(getattr(s.OP, 'rawId', oid))
-    label = getattr(s.OP, 'label', None)
-    ctrl = np.asarray(getattr(s.prior.OP, 'isCtrl', np.zeros(npnt, bool)), bool)
-    chk = np.asarray(getattr(s.prior.OP, 'isCheck', np.zeros(npnt, bool)), bool)
-    for j in range(npnt):
-        pre = 'H' if chk[j] else ('C' if ctrl[j] else 'O')
+
+    def __init__(self, s):
+        nK, nP = int(s.IO.model.nK), int(s.IO.model.nP)
+        self.base = ['cc', 'px', 'py', 'as', 'sk'] + ['K%d' % (k + 1) for k in range(nK)] + ['P%d' % (k + 1) for k in range(nP)]
+        self.nc = s.IO.val.shape[1]
+        self.blk = np.asarray(s.IO.struct.block)
+        self.one_block = len(np.unique(self.blk)) == 1
+        # isSimple: every parameter of the column belongs to the column's own block
+        self.simple = bool(np.all(self.blk == self.blk[0:1]))
+        self.ne = s.EO.val.shape[1]
+        self.eid = np.asarray(getattr(s.EO, 'id', np.arange(1, self.ne + 1)))
+        self.use_ids = bool(np.any(self.eid != np.arange(1, self.ne + 1)))
+        self.npnt = s.OP.val.shape[1]
+        self.oid = np.asarray(getattr(s.OP, 'id', np.arange(1, self.npnt + 1)))
+        self.raw = np.asarray(getattr(s.OP, 'rawId', self.oid))
+        self.label = getattr(s.OP, 'label', None)
+        self.ctrl = np.asarray(getattr(s.prior.OP, 'isCtrl', np.zeros(self.npnt, bool)), bool)
+        self.chk = np.asarray(getattr(s.prior.OP, 'isCheck', np.zeros(self.npnt, bool)), bool)
+        self.shapes = ((len(self.base), self.nc), (6, self.ne), (3, self.npnt))
+
+    def io(self, i, j):
+        b = self.base[i]
+        if self.nc == 1 or self.one_block:
+            return b
+        if self.simple:
+            return '%s-%d' % (b, j + 1)
+        return '%s-%d(%d)' % (b, j + 1, self.blk[i, j])
+
+    def eo(self, i, j):
+        tail = '' if self.ne == 1 else ('-%d(%d)' % (j + 1, self.eid[j]) if self.use_ids else '-%d' % (j + 1))
+        return ('EX', 'EY', 'EZ', 'om', 'ph', 'ka')[i] + tail
+
+    def op(self, i, j):
+        pre = 'H' if self.chk[j] else ('C' if self.ctrl[j] else 'O')
         tail = ''
-        if npnt > 1:
+        if self.npnt > 1:
             tail = '-%d' % (j + 1)
-            if oid[j] != j + 1:
-                tail += '/%d' % oid[j]
-            if raw[j] != oid[j]:
-                tail += '/%d' % raw[j]
-            if label is not None and label[j]:
-                tail += '-' + label[j]
-        for i, c in enumerate('XYZ'):
-            OP[i, j] = pre + c + tail
-    return IO, EO, OP
+            if self.oid[j] != j + 1:
+                tail += '/%d' % self.oid[j]
+            if self.raw[j] != self.oid[j]:
+                tail += '/%d' % self.raw[j]
+            if self.label is not None and self.label[j]:
+                tail += '-' + self.label[j]
+        return pre + 'XYZ'[i] + tail
+
+    def name(self, section, i, j):
+        return (self.io, self.eo, self.op)[section](i, j)
+
+
+def buildparamtypes(s):
+    """Names of every IO / EO / OP entry (misc/buildparamtypes.m:46-136) as three object arrays."""
+    nm = _Namer(s)
+    out = []
+    for sec, (r, c) in enumerate(nm.shapes):
+        A = np.empty((r, c), object)
+        for j in range(c):
+            for i in range(r):
+                A[i, j] = nm.name(sec, i, j)
+        out.append(A)
+    return tuple(out)
+
+
+class ParamTypes:
+    """Name of every element of x (serialize.m:20-25; E.paramTypes of bundle.m:162,368) as a read-only sequence that
+    builds a name when it is asked for -- a project with three million unknowns has three million names, and the result
+    file and the post-mortem read a few dozen of them (building them all took a second per bundle() at C3, 50 times the
+    solve).  maps = Handle.index_maps(): position in x of every IO / EO / OP entry, -1 when fixed; the leading entry
+    of a block names it.  Indexing with an integer gives a str, with a slice / index array / boolean mask an object array;
+    list(E.paramTypes) gives them all."""
+
+    def __init__(self, s, maps, n):
+        self._namer = _Namer(s)
+        self._n = int(n)
+        self._maps = maps
+        self._sec = self._ent = None
+
+    def _index(self):
+        if self._sec is None:                            # x position -> (section, column-major entry): the first (leading) entry wins
+            sec = np.full(self._n, -1, np.int8)
+            ent = np.zeros(self._n, np.int64)
+            for k, ix in enumerate(self._maps):
+                flat = ix.flatten('F')
+                e = np.flatnonzero(flat >= 0)[::-1]
+                sec[flat[e]] = k
+                ent[flat[e]] = e
+            self._sec, self._ent = sec, ent
+        return self._sec, self._ent
+
+    def _one(self, k):
+        sec, ent = self._index()
+        if sec[k] < 0:
+            return None
+        rows = self._maps[sec[k]].shape[0]
+        return self._namer.name(int(sec[k]), int(ent[k] % rows), int(ent[k] // rows))
+
+    def __len__(self):
+        return self._n
+
+    @property
+    def shape(self):
+        return (self._n,)
+
+    def __getitem__(self, key):
+        if isinstance(key, (int, np.integer)):
+            k = int(key)
+            if k < 0:
+                k += self._n
+            if not 0 <= k < self._n:
+                raise IndexError(key)
+            return self._one(k)
+        idx = np.arange(self._n)[key]
+        out = np.empty(idx.shape, object)
+        for q, k in enumerate(idx.ravel()):
+            out.ravel()[q] = self._one(int(k))
+        return out
+
+    def __iter__(self):
+        return (self._one(k) for k in range(self._n))
+
+    def __array__(self, dtype=None, copy=None):
+        return self[:]
+
+    def __eq__(self, other):
+        try:
+            return len(other) == self._n and all(a == b for a, b in zip(self, other))
+        except TypeError:
+            return NotImplemented
+
+    def __repr__(self):
+        return 'ParamTypes(%d names%s)' % (self._n, '' if not self._n else ': %s ... %s' % (self[0], self[self._n - 1]))
 
 
 def param_types(s, maps, n):
-    """Name of every element of x (serialize.m:20-25).  maps = Handle.index_maps():
-    position in x of every IO / EO / OP entry, -1 when fixed; the leading
-    entry of a block names it."""
-    t = np.empty(n, object)
-    for names, ix in zip(buildparamtypes(s), maps):
-        names = names[:ix.shape[0]]
-        flat_ix, flat_nm = ix.flatten('F'), names.flatten('F')
-        for k in np.flatnonzero(flat_ix >= 0)[::-1]:           # first (leading) entry wins
-            t[flat_ix[k]] = flat_nm[k]
-    return t
+    """Name of every element of x (serialize.m:20-25), built on demand: ParamTypes."""
+    return ParamTypes(s, maps, n)
 
 
 def _prior_rows(s, maps):

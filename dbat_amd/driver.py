@@ -11,11 +11,13 @@ computes them on the CPU.
 from __future__ import annotations
 
 import copy
+import time
 import types
 
 import numpy as np
 
 from . import _hip, diagnose
+from .dbatstruct import share_struct
 
 NS = types.SimpleNamespace
 
@@ -61,7 +63,7 @@ def _parse_args(args):
 
 
 def bundle(s, *args, device=None, comm=None, store_trace=True, jacobian=False, deterministic=False,
-           term_fun=None, veto_fun=None):
+           term_fun=None, veto_fun=None, reuse_handle=True):
     """[s,ok,iters,s0,E] = bundle(s[,maxIter][,damping][,'trace'][,tol]
     [,'absterm'][,'singulartest'|'nosingulartest'][,veto][,'pmdof'][,'dofverb'])
 
@@ -74,13 +76,15 @@ def bundle(s, *args, device=None, comm=None, store_trace=True, jacobian=False, d
     `term_fun(Jp, r) -> bool` replaces the termination test bundle() builds (bundle.m:186-192) and `veto_fun(x) -> bool`
     is the veto the lsa solvers call at every trial point (bundle.m:168-172 only ever passes the undefined `chirality`):
     the two function handles of the reference's solver interface, for callers that used the solvers directly.
+    `reuse_handle=False` builds (and destroys) a handle of its own instead of using the cached one (_hip.acquire).
+    The returned struct shares the arrays bundle() does not change (IP.*, masks, blocks) with its input.
     """
     o = _parse_args(args)
     if o['veto']:
         # bundle.m:169 references an undefined function `chirality`
         # (SURVEY Appendix B item 2): the reference errors at this point too.
         raise BadInput("chirality veto is not defined in the reference (bundle.m:169)")
-    s = copy.deepcopy(s)
+    s = share_struct(s)          # (namespaces copied, arrays shared: nothing below writes into an array of the input)
     # bundle.m:137-154: a fixed parameter cannot be used as a prior observation
     for nm in ('IO', 'EO', 'OP'):
         pr = getattr(s.prior, nm)
@@ -97,7 +101,14 @@ def bundle(s, *args, device=None, comm=None, store_trace=True, jacobian=False, d
         # a rank of a multi-GPU run works on the device its process selected
         device = getattr(comm, 'device', None) if comm is not None else 0
         device = 0 if device is None else device
-    h = _hip.Handle(s, device=device, shard_rank=rank, shard_count=world)
+    # Plan reuse (bundle.m:156-159 keeps s.bundle.serial / deserial between calls): one-rank runs take the cached handle
+    # when the structure of s -- everything but the parameter and prior values -- is the one it was built for
+    # (_hip.acquire: dbat_hip_structure_key + dbat_hip_set_values); a changed mask, block or observation builds a new plan.
+    cached = world == 1 and reuse_handle
+    t_host = [time.perf_counter()]
+    h = _hip.acquire(s, device) if cached else _hip.Handle(s, device=device, shard_rank=rank, shard_count=world)
+    t_host.append(time.perf_counter())
+    done = False
     try:
         if deterministic:                                            # fixed-order sums: bit-identical runs (parity mode)
             h.set_deterministic(True)
@@ -113,7 +124,10 @@ def bundle(s, *args, device=None, comm=None, store_trace=True, jacobian=False, d
         opt.abs_term = int(o['absTerm'])
         opt.singular_test = int(o['singularTest'])
         opt.store_trace = int(bool(store_trace))
-        x, res, rr, damp, aux, T = h.solve(x0, opt, term_fun=term_fun, veto_fun=veto_fun)   # complete on every rank of a sharded run
+        # 'trace': the solver's own line per iteration, printed while the loop runs (gauss_newton_armijo.m:119-128 ...)
+        live = (lambda *a: print(_hip.trace_text(*a), flush=True)) if o['doTrace'] and rank == 0 else None
+        x, res, rr, damp, aux, T = h.solve(x0, opt, term_fun=term_fun, veto_fun=veto_fun, trace_fun=live)   # complete on every rank of a sharded run
+        t_host.append(time.perf_counter())
         E = NS(maxIter=o['maxIter'], convTol=o['convTol'], absTerm=o['absTerm'],
                singularTest=o['singularTest'], chirality=False)
         name = 'gm' if o['damping'] in ('none', 'gm') else o['damping']
@@ -206,12 +220,17 @@ def bundle(s, *args, device=None, comm=None, store_trace=True, jacobian=False, d
         elif E.code == -4:
             E.weakness.structural = diagnose.structural_weakness(s, maps, h.n, E.paramTypes)
             E.weakness.numerical = NS(rank=float('nan'), deficiency=float('nan'))
-        if o['doTrace']:
-            for k, v in enumerate(rr):
-                print('%s: iteration %d, residual norm=%.6g' % (name, k, v))
+        done = True
+        # where the wall time of this call went on the host: the handle (a plan and its uploads, or -- a cached handle of
+        # the same structure -- the key and the new values), the solve (E.time of it inside the damping loop), the result
+        E.timeHost = dict(handle=t_host[1] - t_host[0], solve=t_host[2] - t_host[1], result=time.perf_counter() - t_host[2],
+                          handle_reused=bool(cached and _hip.cache_stats.get('last') == 'hit'))
         return s, ok, E.usedIters, s0, E
     finally:
-        h.close()
+        if cached:
+            _hip.release(h, keep=done)                               # (after an exception: destroyed, not kept)
+        else:
+            h.close()
 
 
 CXX_MAX_N = 6000       # unknowns up to which bundle_cov offers the dense matrices 'CXX' / 'COPF' (288 MB)
@@ -239,7 +258,8 @@ def bundle_cov(s, E, *names, device=0):
     if not names:
         return None
     dense = [n for n in names if n in ('cxx', 'copf')]
-    h = _hip.Handle(s, device=device)
+    h = _hip.acquire(s, device)          # the handle bundle() left behind, with the values of its result: one plan for both
+    done = False
     try:
         if dense and h.n > CXX_MAX_N:
             raise BadInput("bundle_cov: '%s' is an n x n dense matrix and n = %d (offered up to %d unknowns; "
@@ -259,8 +279,9 @@ def bundle_cov(s, E, *names, device=0):
             CEOb, CIOu, COPb = res[:3]
         ixIO, ixEO, ixOP = h.index_maps()                   # x index of every array entry, -1 = no unknown
         nc = s.EO.val.shape[1]
+        done = True
     finally:
-        h.close()
+        _hip.release(h, keep=done)
     out = []
     for n in names:
         if n == 'cxx':

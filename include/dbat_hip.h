@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DBAT_HIP_ABI_VERSION 4   /* 4: dbat_hip_bench_step ms[16], dbat_hip_info [24]; 3: dbat_hip_options grew (term_fun, veto_fun); 2: dbat_hip_result grew (stage_s, n_trace_only); dbat_hip_info [16]; dbat_hip_bench_step ms[12] */
+#define DBAT_HIP_ABI_VERSION 4   /* 4: dbat_hip_options grew (trace_fun); dbat_hip_structure_key / dbat_hip_handle_key / dbat_hip_set_values; dbat_hip_bench_step ms[16], dbat_hip_info [24]; 3: dbat_hip_options grew (term_fun, veto_fun); 2: dbat_hip_result grew (stage_s, n_trace_only); dbat_hip_info [16]; dbat_hip_bench_step ms[12] */
 
 /* error returns */
 #define DBAT_HIP_OK            0
@@ -79,7 +79,7 @@ typedef struct dbat_hip_problem {
     const uint8_t *est_EO;      /* s.bundle.est.EO 6 x n_images */
     const uint8_t *est_OP;      /* s.bundle.est.OP 3 x n_points */
     const int32_t *IO_block;    /* s.IO.struct.block nIOrows x n_images */
-    const int32_t *EO_block;    /* s.EO.struct.block 6 x n_images (must be simple: distinct per image) */
+    const int32_t *EO_block;    /* s.EO.struct.block 6 x n_images (shared elements -- camera stations -- take the column-list kernels) */
 
     /* prior observations (lsa/prior_obs.m:26-72; buildweightmatrix.m:25-29) */
     const uint8_t *prior_IO_use; const double *prior_IO_val; const double *prior_IO_std;
@@ -102,6 +102,12 @@ typedef struct dbat_hip_problem {
  * With a termFun every termination test costs one pass for J*p, one for r and their copies to the host. */
 typedef int32_t (*dbat_hip_term_fn)(void *user, const double *Jp, const double *r, int64_t n_residuals);
 typedef int32_t (*dbat_hip_veto_fn)(void *user, const double *x, int64_t n_params);
+/* 'trace' (bundle.m:82): called INSIDE the damping loop, at the statement where the lsa solver prints its line
+ * (gauss_newton_armijo.m:119-128, gauss_markov.m:74-76, levenberg_marquardt.m:138-147, levenberg_marquardt_powell.m:160-164):
+ * iteration n, residual norm rr(end), the damping quantity the line shows (GNA: the last alpha, LM: lambda, LMP: delta;
+ * NaN where the reference prints none: GNA's and LM's iteration 0, Gauss-Markov), and for LMP the step type
+ * (0 GN, 1 IP, 2 CP; -1 otherwise) and the gain ratio rho (NaN otherwise).  NULL: nothing is reported before the loop returns. */
+typedef void (*dbat_hip_trace_fn)(void *user, int32_t damping, int32_t iter, double res_norm, double damp, int32_t step_type, double rho);
 
 typedef struct dbat_hip_options {
     int32_t damping;        /* DBAT_HIP_DAMP_* ; default GNA (bundle.m:79) */
@@ -121,6 +127,8 @@ typedef struct dbat_hip_options {
     void   *term_user;
     dbat_hip_veto_fn veto_fun;  /* NULL: no veto (bundle.m:168-172; the reference's own 'chirality' is undefined) */
     void   *veto_user;
+    dbat_hip_trace_fn trace_fun; /* NULL: no live trace lines */
+    void   *trace_user;
 } dbat_hip_options;
 
 /* what the lsa solvers return: [x,code,n,final,T,rr,extra...]
@@ -184,6 +192,25 @@ int  dbat_hip_plan_serialize(const dbat_hip_problem *prob, double *x0);
  * Replaces bundle.m:156-175. */
 int  dbat_hip_create(const dbat_hip_problem *prob, dbat_hip_handle **out);
 void dbat_hip_destroy(dbat_hip_handle *h);
+
+/* Plan reuse.  The reference re-enters bundle() from any s at no set-up cost: the indices of
+ * buildserialindices.m are kept in s.bundle.serial / deserial and only rebuilt when missing (bundle.m:156-159),
+ * deserialize.m:31-46 puts any x back into the same struct.  Here the set-up is the plan and its uploads
+ * (dbat_hip_create); a handle is re-used for another problem of the SAME STRUCTURE:
+ *   dbat_hip_structure_key   host only: 128 bits over everything a plan depends on -- sizes, lens model, ip_cam, ip_pt,
+ *                            ip_val, ip_std, px_size, the est_* masks, IO_block / EO_block, the prior_*_use masks, shard_rank /
+ *                            shard_count, device and the DBAT_HIP_* switches of the environment.  NOT part of it: IO_val,
+ *                            EO_val, OP_val, prior_*_val, prior_*_std.
+ *   dbat_hip_handle_key      the key of the problem a handle was created from.
+ *   dbat_hip_set_values      new IO_val / EO_val / OP_val and prior values / standard deviations into the handle (its
+ *                            serialize() then returns the new x0; a fixed interior orientation with new values has its
+ *                            corrected image coordinates recomputed); every state of an earlier solve is dropped.
+ *                            DBAT_HIP_EINVAL, and the handle untouched, if the key of prob differs from the handle's:
+ *                            a changed mask, block, visibility or observation needs a new handle.
+ * One-rank handles and the handles of a sharded run alike (the communicator stays attached). */
+int  dbat_hip_structure_key(const dbat_hip_problem *prob, uint64_t *key /*[2]*/);
+int  dbat_hip_handle_key(const dbat_hip_handle *h, uint64_t *key /*[2]*/);
+int  dbat_hip_set_values(dbat_hip_handle *h, const dbat_hip_problem *prob);
 
 int64_t dbat_hip_num_params(const dbat_hip_handle *h);      /* s.bundle.serial.n */
 int64_t dbat_hip_num_residuals(const dbat_hip_handle *h);   /* s.post.res.ix.n */

@@ -77,13 +77,13 @@ if strcmp(damping,'none'), dampNo=0; end
 wantJ=2; if hip.wantJ, wantJ=1; end   % 2: the gateway ships J only after code -2 / -4
 opt=struct('damping',dampNo,'maxIter',maxIter,'convTol',convTol,'absTerm',absTerm,...
            'singularTest',singularTest,'trace',true,'wantJ',wantJ,'wantCov',logical(hip.wantCov),...
-           'deterministic',logical(hip.deterministic),'device',hip.device,...
+           'liveTrace',doTrace,'deterministic',logical(hip.deterministic),'device',hip.device,...
            'shardRank',hip.shardRank,'shardCount',hip.shardCount,'commId',uint8(hip.commId),...
            'termFun',hip.termFun,'vetoFun',hip.vetoFun);
+% (with 'trace' the gateway prints the LSA function's line per iteration while the loop runs: opt.liveTrace)
 [x,code,iters,s0,res,damp,aux,T,ru,rw,time,CEOb,CIOu,COPb,Jw,Ju]=dbat_hip_mex(P,opt);
-if doTrace   % the iteration trace the LSA functions print with 'trace'
-    for i=1:length(res), fprintf('%s: iteration %d, residual norm %g\n',mfilename,i-1,res(i)); end
-end
+s0gw=s0;     % the gateway's sigma0 (dof = m-n): what its covariance blocks are scaled with
+if doTrace, fprintf('%s: %d iterations, code %d.\n',mfilename,iters,code); end
 % --- result packaging, bundle.m:341-358,449-491
 if isempty(s.bundle.serial) || isempty(s.bundle.deserial), s=buildserialindices(s); end
 E=struct('maxIter',maxIter,'convTol',convTol,'absTerm',absTerm,'singularTest',singularTest,...
@@ -136,6 +136,11 @@ E.s0=s0; E.sigmas=s.post.sigmas;
 % --- posterior covariance blocks from the device (bundle_cov.m:193-210 reads
 % s.post.cov.CEO / COP when they are present)
 if ok && hip.wantCov
+    % the gateway scaled the blocks with ITS sigma0; with 'pmdof' the degrees of freedom differ (bundle.m:466-483), and
+    % BUNDLE_COV scales with E.s0 (bundle_cov.m:63-70): same blocks, E.s0's scale
+    if s0~=s0gw && isfinite(s0gw) && s0gw>0
+        sc=(s0/s0gw)^2; CEOb=CEOb*sc; CIOu=CIOu*sc; COPb=COPb*sc;
+    end
     % block diagonals from (i,j,v) triplets: no dense intermediate (roma: 78 963^2 doubles)
     m=size(s.EO.val,1); nI=size(s.EO.val,2);
     [bi,bj]=ndgrid(1:6,1:6); ofs=reshape(m*(0:nI-1),1,1,[]);

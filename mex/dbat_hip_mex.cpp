@@ -11,10 +11,18 @@
 //   [x,code,iters,sigma0,res,damp,aux,T,ru,rw,time,CEO,CIO,COP,Jw,Ju] = dbat_hip_mex(P, opt)
 //   id = dbat_hip_mex('commId')     128 bytes (uint8) of a fresh RCCL unique id: rank 0 of a multi-GPU run creates it
 //                                   and hands it to the other MATLAB workers (labSend / a file), who pass it as opt.commId
+//   dbat_hip_mex('clear')           destroy the handle the gateway keeps between calls (below) and unlock the MEX file
+//
+// PLAN REUSE.  BUNDLE re-enters from any s at no set-up cost (the serial indices stay in s.bundle.serial / deserial,
+// bundle.m:156-159).  The gateway keeps the handle of its last one-rank call (mexLock; destroyed by mexAtExit, by
+// 'clear', or when a problem of another structure arrives): a call whose structure key (dbat_hip_structure_key: sizes,
+// visibility, observations, masks, blocks, prior pattern) equals the kept handle's only sends the new parameter values
+// (dbat_hip_set_values) -- the second bundle_hip on a project, and every later one, skips the host plan and its uploads.
 //
 // P   struct with the flattened DBAT struct fields built by bundle_hip.m
 // opt struct: damping (0..3), maxIter, convTol, absTerm, singularTest, trace,
 //             wantJ (0: never, 1: always, 2: after a failed run, code -2 / -4 -- E.final.weighted.J, bundle.m:341-350,372-446),
+//             liveTrace (print the LSA function's line per iteration while the loop runs: gauss_newton_armijo.m:119-128),
 //             wantCov (posterior covariance blocks), deterministic (dbat_hip_set_deterministic),
 //             device (HIP device ordinal), shardRank, shardCount (this worker's share of the object points,
 //             dbat_hip.h "several GPUs"), commId (uint8 [128] from dbat_hip_mex('commId'); required when shardCount > 1)
@@ -32,14 +40,17 @@ static const mxArray *field(const mxArray *s, const char *name) {
 static double scalar(const mxArray *s, const char *name) { return mxGetScalar(field(s, name)); }
 
 // J (dbat_hip_jacobian_csc) as a MATLAB sparse matrix, as [r,J]=resFun(x) returns it (brown_euler_cam4.m:163-182)
+// nullptr on failure (dbat_hip_last_error says why): the caller releases the handle BEFORE it raises -- mexErrMsgIdAndTxt
+// does not return, and a handle that is still alive then would leak its device memory inside the MATLAB process.
 static mxArray *sparse_jacobian(dbat_hip_handle *h, const double *x, int weighted, int64_t m, int64_t n) {
     int64_t nnz = 0;
-    if (dbat_hip_jacobian_csc(h, x, weighted, &nnz, nullptr, nullptr, nullptr) != DBAT_HIP_OK)
-        mexErrMsgIdAndTxt("DBAT:bundle:internal", "%s", dbat_hip_last_error());
+    if (dbat_hip_jacobian_csc(h, x, weighted, &nnz, nullptr, nullptr, nullptr) != DBAT_HIP_OK) return nullptr;
     mxArray *J = mxCreateSparse((mwSize)m, (mwSize)n, (mwSize)(nnz > 0 ? nnz : 1), mxREAL);
     std::vector<int64_t> colptr((size_t)n + 1), rowidx((size_t)nnz);
-    if (dbat_hip_jacobian_csc(h, x, weighted, &nnz, colptr.data(), rowidx.data(), mxGetDoubles(J)) != DBAT_HIP_OK)
-        mexErrMsgIdAndTxt("DBAT:bundle:internal", "%s", dbat_hip_last_error());
+    if (dbat_hip_jacobian_csc(h, x, weighted, &nnz, colptr.data(), rowidx.data(), mxGetDoubles(J)) != DBAT_HIP_OK) {
+        mxDestroyArray(J);
+        return nullptr;
+    }
     mwIndex *jc = mxGetJc(J), *ir = mxGetIr(J);
     for (int64_t c = 0; c <= n; ++c) jc[c] = (mwIndex)colptr[(size_t)c];
     for (int64_t e = 0; e < nnz; ++e) ir[e] = (mwIndex)rowidx[(size_t)e];
@@ -74,10 +85,58 @@ static int32_t call_veto(void *user, const double *x, int64_t n) {
     return call_handle(static_cast<MatlabFn *>(user), 1, args);
 }
 
+// 'trace': the line the LSA function prints, while the loop runs (gauss_newton_armijo.m:119-128, gauss_markov.m:74-76,
+// levenberg_marquardt.m:138-147, levenberg_marquardt_powell.m:160-164)
+static void print_trace(void *, int32_t damping, int32_t n, double res, double damp, int32_t step, double rho) {
+    static const char *step_str[3] = {"GN", "IP", "CP"};
+    if (damping == DBAT_HIP_DAMP_GNA) {
+        if (damp != damp) mexPrintf("Gauss-Newton-Armijo: iteration %d, residual norm=%.2g\n", (int)n, res);
+        else if (damp == 1.0) mexPrintf("Gauss-Newton-Armijo: iteration %d, residual norm=%.2g, last alpha=1\n", (int)n, res);
+        else mexPrintf("Gauss-Newton-Armijo: iteration %d, residual norm=%.2g, last alpha=1/%.0f\n", (int)n, res, 1.0 / damp);   // rats(2^-k)
+    } else if (damping == DBAT_HIP_DAMP_LM) {
+        if (damp != damp) mexPrintf("Levenberg-Marquardt: iteration %d, residual norm=%.2g\n", (int)n, res);
+        else mexPrintf("Levenberg-Marquardt: iteration %d, residual norm=%.2g, lambda=%.2g\n", (int)n, res, damp);
+    } else if (damping == DBAT_HIP_DAMP_LMP) {
+        mexPrintf("Levenberg-Marquardt-Powell: iteration %d, residual norm=%.2g, delta=%.2g, step=%s, rho=%.1f\n", (int)n, res, damp,
+                  step >= 0 && step < 3 ? step_str[step] : "?", rho);
+    } else mexPrintf("Gauss-Markov: iteration %d, residual norm=%.2g\n", (int)n, res);
+}
+
+// the handle kept between calls (one-rank problems; see PLAN REUSE above)
+static dbat_hip_handle *g_kept = nullptr;
+static void drop_kept() {
+    if (g_kept) { dbat_hip_destroy(g_kept); g_kept = nullptr; }
+}
+// the handle for pb: the kept one with pb's values if the structure is the same, else a new one (nullptr: dbat_hip_last_error)
+static dbat_hip_handle *acquire(const dbat_hip_problem &pb) {
+    dbat_hip_handle *h = g_kept;
+    g_kept = nullptr;                              // (in use: an error path destroys it instead of keeping a half-used handle)
+    if (h && pb.shard_count == 1) {
+        uint64_t kp[2], kh[2];
+        if (dbat_hip_structure_key(&pb, kp) == DBAT_HIP_OK && dbat_hip_handle_key(h, kh) == DBAT_HIP_OK &&
+            kp[0] == kh[0] && kp[1] == kh[1] && dbat_hip_set_values(h, &pb) == DBAT_HIP_OK)
+            return h;
+    }
+    if (h) dbat_hip_destroy(h);
+    h = nullptr;
+    return dbat_hip_create(&pb, &h) == DBAT_HIP_OK ? h : nullptr;
+}
+static void release(dbat_hip_handle *h, bool one_rank) {
+    if (!one_rank) { dbat_hip_destroy(h); return; }          // (a sharded handle owns a communicator: its life is the call's)
+    dbat_hip_set_deterministic(h, 0);
+    g_kept = h;
+    if (!mexIsLocked()) { mexLock(); mexAtExit(drop_kept); }
+}
+
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
-    if (nrhs == 1 && mxIsChar(prhs[0])) {          // dbat_hip_mex('commId')
+    if (nrhs == 1 && mxIsChar(prhs[0])) {          // dbat_hip_mex('commId') / dbat_hip_mex('clear')
         char what[16] = {0};
         mxGetString(prhs[0], what, sizeof(what));
+        if (std::strcmp(what, "clear") == 0) {
+            drop_kept();
+            if (mexIsLocked()) mexUnlock();
+            return;
+        }
         if (std::strcmp(what, "commId") != 0) mexErrMsgIdAndTxt("DBAT:dbat_hip_mex:badInput", "unknown request %s", what);
         plhs[0] = mxCreateNumericMatrix(1, DBAT_HIP_UNIQUE_ID_BYTES, mxUINT8_CLASS, mxREAL);
         if (dbat_hip_comm_unique_id((uint8_t *)mxGetData(plhs[0])) != DBAT_HIP_OK)
@@ -129,9 +188,9 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
         mexErrMsgIdAndTxt("DBAT:bundle:badInput", "shardCount > 1 needs opt.commId: the %d bytes of dbat_hip_mex('commId') from rank 0",
                           DBAT_HIP_UNIQUE_ID_BYTES);
 
-    dbat_hip_handle *h = nullptr;
-    if (dbat_hip_create(&pb, &h) != DBAT_HIP_OK)
-        mexErrMsgIdAndTxt("DBAT:bundle:badInput", "%s", dbat_hip_last_error());
+    const bool one_rank = pb.shard_count == 1;
+    dbat_hip_handle *h = acquire(pb);
+    if (!h) mexErrMsgIdAndTxt("DBAT:bundle:badInput", "%s", dbat_hip_last_error());
     // several workers, one GPU each: join the communicator (collective: every worker is here at the same time)
     if (pb.shard_count > 1 && dbat_hip_comm_init(h, (const uint8_t *)mxGetData(cid)) != DBAT_HIP_OK) {
         dbat_hip_destroy(h);
@@ -153,6 +212,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     MatlabFn term_cb{field(O, "termFun"), nullptr}, veto_cb{field(O, "vetoFun"), nullptr};
     if (!mxIsEmpty(term_cb.fh)) { opt.term_fun = call_term; opt.term_user = &term_cb; }
     if (!mxIsEmpty(veto_cb.fh)) { opt.veto_fun = call_veto; opt.veto_user = &veto_cb; }
+    if ((int)scalar(O, "liveTrace") && pb.shard_rank == 0) opt.trace_fun = print_trace;
     for (const MatlabFn *f : {&term_cb, &veto_cb})
         if (!mxIsEmpty(f->fh) && !mxIsClass(f->fh, "function_handle")) {
             dbat_hip_destroy(h);
@@ -204,7 +264,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
         // posterior covariance blocks (bundle_cov.m 'CEO','CIO','COP') at the result:
         // plhs[11] 6 x 6 x nImages, plhs[12] nIOu x nIOu (IO unknowns in x order), plhs[13] 3 x 3 x nOP
         const mwSize dE[3] = {6, 6, (mwSize)pb.n_images}, dP[3] = {3, 3, (mwSize)pb.n_points};
-        int64_t inf[16];
+        int64_t inf[24];
         dbat_hip_info(h, inf);
         const mwSize nIOu = (mwSize)(inf[0] - 6 * (int64_t)pb.n_images);
         plhs[11] = mxCreateNumericArray(3, dE, mxDOUBLE_CLASS, mxREAL);
@@ -223,6 +283,10 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
         const bool give = pb.shard_count == 1 && (want == 1 || (want == 2 && (r.code == -2 || r.code == -4)));
         plhs[14] = give ? sparse_jacobian(h, x, 1, m, n) : mxCreateSparse((mwSize)0, (mwSize)0, (mwSize)1, mxREAL);
         if (nlhs > 15) plhs[15] = give ? sparse_jacobian(h, x, 0, m, n) : mxCreateSparse((mwSize)0, (mwSize)0, (mwSize)1, mxREAL);
+        if (!plhs[14] || (nlhs > 15 && !plhs[15])) {
+            dbat_hip_destroy(h);
+            mexErrMsgIdAndTxt("DBAT:bundle:internal", "%s", dbat_hip_last_error());
+        }
     }
-    dbat_hip_destroy(h);
+    release(h, one_rank);
 }

@@ -45,6 +45,7 @@ static void layout(void) {
     FIELD(dbat_hip_options, delta0);
     FIELD(dbat_hip_options, term_fun); FIELD(dbat_hip_options, term_user);
     FIELD(dbat_hip_options, veto_fun); FIELD(dbat_hip_options, veto_user);
+    FIELD(dbat_hip_options, trace_fun); FIELD(dbat_hip_options, trace_user);
     first = 0;
     printf("}}, \"dbat_hip_result\": {\"sizeof\": %zu, \"offsets\": {", sizeof(dbat_hip_result));
     FIELD(dbat_hip_result, code); FIELD(dbat_hip_result, iters); FIELD(dbat_hip_result, n_res);

@@ -42,6 +42,11 @@ bool mxIsClass(const mxArray *pa, const char *classname);
 int mexCallMATLAB(int nlhs, mxArray *plhs[], int nrhs, mxArray *prhs[], const char *functionName);
 mxArray *mexCallMATLABWithTrap(int nlhs, mxArray *plhs[], int nrhs, mxArray *prhs[], const char *functionName);
 void mexErrMsgIdAndTxt(const char *identifier, const char *fmt, ...);
+int mexPrintf(const char *fmt, ...);
+void mexLock(void);
+void mexUnlock(void);
+bool mexIsLocked(void);
+int mexAtExit(void (*exit_fcn)(void));
 void mexWarnMsgIdAndTxt(const char *identifier, const char *fmt, ...);
 
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]);

@@ -801,14 +801,17 @@ def test_mixed_tiled_and_heavy_points(hip, variant, monkeypatch):
     r_o, K = o.brown_euler_cam4(x0, so, jac=True)
     J = (sp.diags(R) @ K).tocsc()
     p_o, *_ = o._scaled_gn(J, R * r_o)
-    h = hip.Handle(s)
-    try:
-        info = h.info()
-        assert 0 < info['n_tiles'] and info['n_batches'] > 0
-        p_h, st = h.linearize_solve(x0, 0.0, True)
-        assert relerr(p_h, p_o) < TOL_STEP
-    finally:
-        h.close()
+    for heavy in ('1', '0'):                            # the matrix-core path of csrc/heavy.hpp, and the column lists it replaces
+        monkeypatch.setenv('DBAT_HIP_HEAVY', heavy)
+        h = hip.Handle(s)
+        try:
+            info = h.info()
+            assert 0 < info['n_tiles'] and info['n_batches'] > 0 and (info['heavy_tasks'] > 0) == (heavy == '1')
+            p_h, st = h.linearize_solve(x0, 0.0, True)
+            assert relerr(p_h, p_o) < TOL_STEP
+        finally:
+            h.close()
+    monkeypatch.delenv('DBAT_HIP_HEAVY')
     res, ok, iters, s0, E = bundle(s, 'gna')
     monkeypatch.delenv('DBAT_HIP_CMAX')
     ro, oko, ito, s0o, Eo = o.bundle(s, 'gna')
@@ -867,6 +870,208 @@ def test_giant_points(hip, variant, monkeypatch):
     res, ok, iters, s0, E = bundle(s, 'gna')
     ro, oko, ito, s0o, Eo = o.bundle(s, 'gna')
     assert ok and oko and iters == ito and relerr(E.x, Eo.x) < TOL_X
+
+
+def _all_see_all_scene(cams, points, selfcal, groups=1, seed=3):
+    """Every point in every image (the geometry of the reference's calibration demo, demo/camcaldemo.m:56-119):
+    cameras on a ring look at a point cloud in the middle.  Distortion-free lens, so that every projection is defined."""
+    from dbat_amd import synth
+    s, truth = synth.make_scene('small', cams=cams, points=points, rays=6, seed=seed)
+    s.IO.val[5:10] = 0.0
+    truth['IO'][5:10] = 0.0
+    nc = s.EO.val.shape[1]
+    px = float(np.ravel(s.IO.sensor.pxSize)[0])
+    cam = np.repeat(np.arange(nc), points); pt = np.tile(np.arange(points), nc)
+    uv, depth = synth.project(truth['IO'], truth['EO'], truth['OP'], cam, pt, px, nK=3, nP=2)
+    assert np.all(depth < 0)
+    rng = np.random.default_rng(seed)
+    s.IP.val = uv + rng.normal(0, 0.5, uv.shape)
+    s.IP.std = np.ones_like(uv)
+    s.IP.cam, s.IP.pt = cam, pt
+    if selfcal:
+        s.bundle.est.IO[[0, 1, 2, 5, 6]] = True
+        if groups > 1:                                  # independent IO blocks for runs of cameras
+            blk = 1 + (np.arange(nc) * groups) // nc
+            s.IO.struct.block[:] = blk[None, :]
+    return s, truth
+
+
+@pytest.mark.parametrize('variant', ['plain', 'selfcal', 'selfcal-groups3'])
+def test_giant_points_on_the_matrix_cores(hip, variant, monkeypatch):
+    """csrc/heavy.hpp: points seen in all 300 images (more than a 256-observation batch holds: k_heavy_z_giant, three
+    rounds of 128 threads) beside ordinary tiled points, their Schur terms by k_heavy_syrk over 38 camera groups.  Step,
+    ||J p||^2 and gradient against the oracle, the bundle against the oracle's, the deterministic mode bit for bit."""
+    from dbat_amd import bundle, synth
+    s, truth = synth.make_scene('small', cams=300, points=400, rays=6)
+    s.IO.val[5:10] = 0.0
+    truth['IO'][5:10] = 0.0
+    nc = s.EO.val.shape[1]
+    if variant != 'plain':
+        s.bundle.est.IO[[0, 1, 2, 5, 6]] = True
+        if variant == 'selfcal-groups3':
+            s.IO.struct.block[:] = (1 + (np.arange(nc) * 3) // nc)[None, :]
+    px = float(np.ravel(s.IO.sensor.pxSize)[0])
+    rng = np.random.default_rng(5)
+    add_cam, add_pt = [], []
+    for p in (3, 77, 250):
+        have = set(s.IP.cam[s.IP.pt == p].tolist())
+        for c in range(nc):
+            if c not in have:
+                add_cam.append(c); add_pt.append(p)
+    cam = np.r_[s.IP.cam, np.array(add_cam)]; pt = np.r_[s.IP.pt, np.array(add_pt)]
+    order = np.lexsort((pt, cam))
+    cam, pt = cam[order], pt[order]
+    uv, depth = synth.project(truth['IO'], truth['EO'], truth['OP'], cam, pt, px, nK=3, nP=2)
+    assert np.all(depth < 0)
+    s.IP.val = uv + rng.normal(0, 0.5, uv.shape)
+    s.IP.std = np.ones_like(uv)
+    s.IP.cam, s.IP.pt = cam, pt
+    monkeypatch.setenv('DBAT_HIP_GIANT_THREADS', '128')
+    so, x0, w = oracle_setup(s)
+    R = np.sqrt(w)
+    r_o, K = o.brown_euler_cam4(x0, so, jac=True)
+    J = (sp.diags(R) @ K).tocsc()
+    p_o, *_ = o._scaled_gn(J, R * r_o)
+    h = hip.Handle(s)
+    try:
+        info = h.info()
+        assert info['heavy_tasks'] > 0 and info['heavy_points'] == 3 and info['n_tiles'] > 0
+        p_h, st = h.linearize_solve(x0, 0.0, True)
+        assert not st['singular']
+        assert relerr(p_h, p_o) < TOL_STEP
+        Jp = J @ p_o
+        assert abs(st['JpJp'] - Jp @ Jp) <= 1e-7 * (Jp @ Jp)
+        assert relerr(h.gradient(), J.T @ (R * r_o)) < 1e-10
+        h.set_deterministic(True)
+        pd = [h.linearize_solve(x0, 0.0, True)[0] for _ in range(4)]
+        assert all(np.array_equal(pd[0], q) for q in pd[1:]) and relerr(pd[0], p_h) < 1e-8
+    finally:
+        h.close()
+    res, ok, iters, s0, E = bundle(s, 'gna')
+    ro, oko, ito, s0o, Eo = o.bundle(s, 'gna')
+    assert ok and oko and iters == ito and relerr(E.x, Eo.x) < TOL_X
+
+
+@pytest.mark.parametrize('cams,selfcal,groups', [(21, True, 1), (30, False, 1), (40, True, 3), (9, True, 2)])
+@pytest.mark.parametrize('ks', [None, '2'])
+def test_every_point_in_every_image(hip, cams, selfcal, groups, ks, monkeypatch):
+    """The visibility of the reference's flagship project (demo/camcaldemo.m:56-119): every point is heavy.  Against the
+    oracle: the step through the row groups of csrc/heavy.hpp (3 ... 5 camera groups + the IO / right-hand-side group,
+    several independent IO blocks, two k-steps per task: many tasks per pair of groups), and against the column-list
+    kernels it replaces (DBAT_HIP_HEAVY=0)."""
+    from dbat_amd import bundle
+    if ks:
+        monkeypatch.setenv('DBAT_HIP_HEAVY_KS', ks)
+    monkeypatch.setenv('DBAT_HIP_CMAX', '8')            # (nine cameras: heavy because a tile holds eight)
+    s, _ = _all_see_all_scene(cams, 150, selfcal, groups)
+    so, x0, w = oracle_setup(s)
+    R = np.sqrt(w)
+    r_o, K = o.brown_euler_cam4(x0, so, jac=True)
+    J = (sp.diags(R) @ K).tocsc()
+    p_o, *_ = o._scaled_gn(J, R * r_o)
+    h = hip.Handle(s)
+    try:
+        info = h.info()
+        assert info['heavy_points'] == 150 and info['n_tiles'] == 0 and info['heavy_row_groups'] >= (cams + 7) // 8 + 1
+        p_h, st = h.linearize_solve(x0, 0.0, True)
+        assert not st['singular'] and relerr(p_h, p_o) < TOL_STEP
+        assert relerr(h.gradient(), J.T @ (R * r_o)) < 1e-10
+        p_lm, _ = h.linearize_solve(x0, 1e-3, False)     # damped, unscaled (levenberg_marquardt.m:119)
+        JTJ = (J.T @ J).toarray()
+        p_lmo = np.linalg.solve(JTJ + 1e-3 * np.eye(JTJ.shape[0]), -(J.T @ (R * r_o)))
+        assert relerr(p_lm, p_lmo) < TOL_STEP
+    finally:
+        h.close()
+    monkeypatch.setenv('DBAT_HIP_HEAVY', '0')
+    h = hip.Handle(s)
+    try:
+        assert h.info()['heavy_tasks'] == 0
+        p_l, _ = h.linearize_solve(x0, 0.0, True)
+        assert relerr(p_l, p_h) < 1e-9
+    finally:
+        h.close()
+    monkeypatch.delenv('DBAT_HIP_HEAVY')
+    res, ok, iters, s0, E = bundle(s, 'gna')
+    ro, oko, ito, s0o, Eo = o.bundle(s, 'gna')
+    assert ok and oko and iters == ito and relerr(E.x, Eo.x) < TOL_X
+
+
+@pytest.mark.parametrize('variant', ['plain', 'selfcal', 'priors'])
+def test_plan_reuse_set_values(hip, variant):
+    """dbat_hip_set_values: a handle re-used for other parameter values of the same structure (bundle.m:156-159 keeps the
+    serial indices; deserialize.m:31-46) gives the step, the objective value and the bundle of a handle built for those
+    values -- also where a FIXED interior orientation changes (the corrected image coordinates are computed again) and
+    where the values and standard deviations of the prior observations change.  A different structure is refused and
+    leaves the handle as it was."""
+    s, truth = synth_struct('small', variant)
+    rng = np.random.default_rng(9)
+    t = copy.deepcopy(s)
+    t.EO.val = t.EO.val + rng.normal(0, 0.01, t.EO.val.shape) * np.asarray(t.bundle.est.EO, float)
+    t.OP.val = t.OP.val + rng.normal(0, 0.02, t.OP.val.shape)
+    t.IO.val = t.IO.val.copy(); t.IO.val[0] *= 1.002; t.IO.val[5] *= 0.9          # cc, K1: fixed (plain / priors) or start values
+    if variant == 'priors':
+        t.prior.EO.val = t.prior.EO.val + 0.01; t.prior.OP.std = t.prior.OP.std * 1.5
+    h = hip.Handle(s)
+    fresh = hip.Handle(t)
+    try:
+        x_s = h.serialize()
+        p_s, _ = h.linearize_solve(x_s, 0.0, True)
+        h.set_values(t)
+        x_t = h.serialize()
+        assert np.array_equal(x_t, fresh.serialize()) and not np.array_equal(x_t, x_s)
+        p_r, st_r = h.linearize_solve(x_t, 0.0, True)
+        p_f, st_f = fresh.linearize_solve(x_t, 0.0, True)
+        assert relerr(p_r, p_f) < 1e-10 and abs(st_r['f'] - st_f['f']) <= 1e-12 * st_f['f'] and relerr(p_r, p_s) > 1e-6
+        assert np.allclose(h.residual(x_t)[0], fresh.residual(x_t)[0], rtol=0, atol=1e-12)
+        opt = hip.default_options('gna')
+        xr, res_r, *_ = h.solve(x_t, opt)
+        xf, res_f, *_ = fresh.solve(x_t, opt)
+        assert res_r.code == 0 and res_r.iters == res_f.iters and relerr(xr, xf) < 1e-9
+        h.set_values(s)                                               # ... and back
+        assert np.array_equal(h.serialize(), x_s)
+        p_b, _ = h.linearize_solve(x_s, 0.0, True)
+        assert relerr(p_b, p_s) < 1e-10
+        u = copy.deepcopy(s)
+        u.bundle.est.OP[0, 6] = False                                 # another structure
+        with pytest.raises(hip.DbatHipError, match='structure'):
+            h.set_values(u)
+        assert np.array_equal(h.serialize(), x_s)
+    finally:
+        h.close(); fresh.close()
+
+
+def test_bundle_reuses_the_cached_handle(hip, capsys):
+    """bundle() -> bundle() -> bundle_cov() on one structure build ONE plan; a changed mask builds a
+    new one; results are those of runs with handles of their own.  'trace' prints the solver's line per iteration."""
+    from dbat_amd import bundle, bundle_cov
+    s, _ = synth_struct('small', 'selfcal')
+    hip.clear_cache()
+    st = dict(hip.cache_stats)
+    r1 = bundle(s, 'gna', 'trace')
+    out = capsys.readouterr().out
+    lines = [ln for ln in out.splitlines() if ln.startswith('Gauss-Newton-Armijo: iteration')]
+    assert len(lines) == r1[2] + 1 and lines[0].endswith('residual norm=%.2g' % r1[4].res[0]) and 'last alpha=1' in lines[1]
+    assert hip.cache_stats['misses'] == st['misses'] + 1 and hip.cache_stats['hits'] == st['hits']
+    r2 = bundle(r1[0], 'lm')                                          # from the result: same structure, other values
+    assert hip.cache_stats['hits'] == st['hits'] + 1 and hip.cache_stats['misses'] == st['misses'] + 1
+    C1 = bundle_cov(r2[0], r2[4], 'CEO')
+    assert hip.cache_stats['hits'] == st['hits'] + 2 and hip.cache_stats['misses'] == st['misses'] + 1
+    # the same calls with handles of their own
+    q1 = bundle(s, 'gna', reuse_handle=False)
+    q2 = bundle(q1[0], 'lm', reuse_handle=False)
+    assert r1[2] == q1[2] and relerr(r1[4].x, q1[4].x) < 1e-9 and r2[1] and relerr(r2[4].x, q2[4].x) < 1e-9
+    hip.clear_cache()
+    C2 = bundle_cov(q2[0], q2[4], 'CEO')
+    assert abs(C1 - C2).max() <= 1e-8 * abs(C2).max()
+    # a changed mask: new plan, and the result of the changed problem
+    u = copy.deepcopy(s)
+    u.bundle.est.OP[:, 11] = False
+    m0 = hip.cache_stats['misses']
+    r3 = bundle(u, 'gna')
+    assert hip.cache_stats['misses'] == m0 + 1
+    q3 = bundle(u, 'gna', reuse_handle=False)
+    assert r3[1] and relerr(r3[4].x, q3[4].x) < 1e-9 and r3[4].numParams == r1[4].numParams - 3
+    hip.clear_cache()
 
 
 @pytest.mark.parametrize('model', [3, 5])

@@ -146,3 +146,25 @@ def test_gpu_side_fields_reach_the_gateway():
     wk = m[m.index('E.weakness=struct('):]
     assert wk.count('E.weakness.numerical.rank=lenX') == 1
     assert re.search(r"elseif code==-2 \|\| code==-4\s*\n[^\n]*\n\s*E\.weakness\.numerical\.rank=nan", wk)
+
+
+def test_plan_reuse_pmdof_and_live_trace_in_the_gateway():
+    """Round 6: the gateway keeps its one-rank handle between calls (mexLock / mexAtExit; structure key + dbat_hip_set_values:
+    bundle.m:156-159 keeps the serial indices), never raises with a live handle, prints the LSA function's 'trace' line
+    from inside the loop, and bundle_hip.m puts the covariance blocks on E.s0's scale when 'pmdof' changes the degrees of
+    freedom (the gateway scales with its own sigma0)."""
+    cpp = open(GATEWAY).read()
+    m = open(WRAPPER).read()
+    for call in ('dbat_hip_structure_key', 'dbat_hip_handle_key', 'dbat_hip_set_values', 'mexLock()', 'mexAtExit(drop_kept)',
+                 'opt.trace_fun = print_trace', "\"clear\""):
+        assert call in cpp, call
+    # every mexErrMsgIdAndTxt after the handle exists is preceded by its destruction (or the handle is not alive yet)
+    body = cpp[cpp.index('dbat_hip_handle *h = acquire(pb);'):]
+    for mt in re.finditer(r'mexErrMsgIdAndTxt\(', body):
+        before = body[:mt.start()].rstrip()
+        ok = before.endswith('if (!h)') or re.search(r'dbat_hip_destroy\(h\);\s*$', before)
+        assert ok, body[max(0, mt.start() - 160):mt.start() + 60]
+    assert 'return nullptr' in cpp[cpp.index('static mxArray *sparse_jacobian'):cpp.index('struct MatlabFn')]
+    assert "sc=(s0/s0gw)^2" in m and 's0gw=s0;' in m and "'liveTrace',doTrace" in m
+    tail = m[m.index('=dbat_hip_mex(P,opt);'):]
+    assert tail.index('s0=sqrt(') < tail.index('sc=(s0/s0gw)^2')      # the rescaling uses the pmdof sigma0
