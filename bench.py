@@ -74,7 +74,9 @@ def cpu_baseline(s_main, name_main, budget_s=25.0, others=('C1', 'C2')):
                     x = x + p
                 n_it += 1
             t_it.sort()
-            return {'it_per_s': n_it / t_all, 'iterations': n_it, 'threads': c.threads, 'n_params': c.n,
+            # the MEDIAN iteration (a 128-thread OpenMP run on a shared box has outliers both ways: C1 measured 2.0 / 10.2 /
+            # 106.9 it/s slowest / median / fastest in round 5, and its mean 7.4 was noise -- VERDICT r05)
+            return {'it_per_s': 1.0 / t_it[len(t_it) // 2], 'it_per_s_mean': n_it / t_all, 'iterations': n_it, 'threads': c.threads, 'n_params': c.n,
                     'it_per_s_slowest_median_fastest': [1.0 / t_it[-1], 1.0 / t_it[len(t_it) // 2], 1.0 / t_it[0]],
                     'setup_s': c.setup_ms * 1e-3, 'nnz': c.nnz,
                     'ms_per_phase': {k: v / n_it for k, v in ms.items()}}
@@ -94,7 +96,7 @@ def cpu_baseline(s_main, name_main, budget_s=25.0, others=('C1', 'C2')):
     return {
         'value': main['it_per_s'], 'unit': 'it/s', 'cores': main['threads'], 'kind': 'port',
         'cpu': cpu_model(), 'nproc': os.cpu_count(),
-        'sample': '%d LM iterations of bench/cpu_ref.cpp (C++17/OpenMP: explicit CSC Jacobian, J\'J by sparse '
+        'sample': 'median of %d LM iterations of bench/cpu_ref.cpp (C++17/OpenMP: explicit CSC Jacobian, J\'J by sparse '
                   'product, supernodal Cholesky of the full %d x %d normal matrix, trial residual) on the '
                   'bench scene %s itself (%d obs), %d threads'
                   % (main['iterations'], main['n_params'], main['n_params'], name_main, no, main['threads']),
@@ -115,15 +117,17 @@ def error_line(args, msg, **kw):
 
 def launch_ranks(args):
     """Start one rank per GPU (torch.distributed.run) as a child process; the
-    parent never initialises a GPU.  A run that cannot work says so in one JSON line and a non-zero exit code:
-    fewer visible devices than ranks (checked here, before anything is started: counting devices does not
-    initialise the GPU), or ranks that failed / timed out (their own message is above the line)."""
+    parent never initialises a GPU -- not even to count the devices: torch.cuda.device_count() goes through the HIP
+    runtime on ROCm builds without amdsmi, so the count is taken by a short-lived child of its own.  A run
+    that cannot work says so in one JSON line and a non-zero exit code: fewer visible devices than ranks (checked here,
+    before any rank is started), or ranks that failed / timed out (their own message is above the line)."""
     host_ar = os.environ.get('DBAT_BENCH_HOST_ALLREDUCE') == '1'
     try:
-        import torch
-        ndev = torch.cuda.device_count()
+        r = subprocess.run([sys.executable, '-c', 'import torch; print(torch.cuda.device_count())'],
+                           capture_output=True, text=True, timeout=600)
+        ndev = int(r.stdout.strip().splitlines()[-1])
     except Exception as e:                               # noqa: BLE001 (a broken torch install is an answer too)
-        error_line(args, 'torch.cuda.device_count() failed: %s' % e)
+        error_line(args, 'counting the HIP devices (torch.cuda.device_count() in a child process) failed: %s' % e)
         return 2
     if ndev < args.gpus and not host_ar:
         error_line(args, '--gpus %d but %d HIP device(s) visible (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?); '
@@ -198,7 +202,7 @@ def main():
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     host_ar = os.environ.get('DBAT_BENCH_HOST_ALLREDUCE') == '1'
     # (launched by torch.distributed.run directly -- the driver does -- there is no parent to look first)
-    ndev = torch.cuda.device_count()                     # counting does not initialise the GPU
+    ndev = torch.cuda.device_count()                     # (a rank: it is about to use its GPU anyway)
     if ndev < (world if not host_ar else 1):
         if rank == 0:
             error_line(args, '%d rank(s) but %d HIP device(s) visible: the dbat_hip core has no CPU path, and every rank '
@@ -377,7 +381,10 @@ def main():
         no_s, np_s = info['n_obs_shard'], info['n_pts_shard']
         kp = np.bincount(s.IP.pt, minlength=npnt).astype(np.float64)
         flops_schur = float(np.sum(108.0 * kp + 216.0 * kp * kp)) * (no_s / max(no, 1))
-        bytes_build = 40 * no_s + 24 * np_s + 48 * nc + 8 * NS * NS
+        # S is written inside its sparsity pattern only: the 64 x 64 tiles of the factor's pattern bound it from above (a dense
+        # 8 NS^2, SURVEY 8(d)'s count, is 289 MB at C2 that no kernel moves -- it made the C2 line read 'hbm')
+        s_pattern_bytes = 8 * h.chol_stats()['tile_tasks'] * 64 * 64
+        bytes_build = 40 * no_s + 24 * np_s + 48 * nc + min(8 * NS * NS, s_pattern_bytes)
         # ms[4]: the tile kernel alone (k_cam_normal and the heavy-point kernels are outside its events); ms[12], ms[13]:
         # the kernels of the heavy / giant points (csrc/heavy.hpp): camera side + k_heavy_z, then k_heavy_syrk
         heavy = info['heavy_tasks'] > 0
@@ -391,7 +398,7 @@ def main():
         if heavy_dominates:
             kname = 'k_heavy_syrk'
             flops_schur = float(info['heavy_algorithmic_flops'])
-            bytes_build = 40 * info['heavy_obs'] + 24 * info['heavy_points'] + 48 * nc + 8 * NS * NS
+            bytes_build = 40 * info['heavy_obs'] + 24 * info['heavy_points'] + 48 * nc + min(8 * NS * NS, s_pattern_bytes)
         # HBM traffic of the dominant kernel: PMC counters cannot be read inside this run
         # (rocprofv3 --pmc is its own pass); the figure of the committed profile of the same
         # command is attached with its source, or null when there is none for this kernel

@@ -737,7 +737,13 @@ __device__ __forceinline__ bool df_chain_role(double *smem, const DfView &V, int
             __hip_atomic_store(flags + (int64_t)p * nT + k, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int take = 0;
             if (nxt) {                                  // the next column: to whoever holds its ticket -- or, if that ticket was passed over, to this workgroup
-                atomicExch(C.giveup + k, epoch);
+                // Store-buffering pair: a ticket holder adds to the counter and THEN reads giveup[k] (its second
+                // atomic depends on the first's result); this side raises giveup[k] and THEN reads the counter.  Both may
+                // not see the old value, or column k+1 is never taken: the exchange must have been performed at the L2
+                // before the counter is read -- its result is consumed here, so the wave waits for it (a non-returning
+                // exchange could still be in flight while the counter, in another L2 channel, is read).
+                const int was = atomicExch(C.giveup + k, epoch);
+                asm volatile("" ::"v"(was) : "memory");
                 if (atomicAdd(counter, 0) > C.pos[k + 1] && atomicExch(C.claim + k + 1, epoch) != epoch) take = 1;
             }
             *s_task = take;

@@ -499,6 +499,7 @@ struct Core {
 
     // ---- helpers
     bool lin_pending = false;                        // k_finish's scalars are in the mailbox (or on their way), not read yet
+    bool det_timeout_pending = false;                // ... and the timeout count of the deterministic signature kernel
     unsigned long long mb_seq = 0;                   // ticket of the last kernel that reports through mailbox slot 63
     bool mb_armed = false;                           // ... and such a kernel is the last one enqueued
     void sync() {
@@ -522,6 +523,16 @@ struct Core {
             mb_armed = false;
         }
         if (!done) HIPCHK(hipStreamSynchronize(stream));
+        if (det_timeout_pending) {
+            det_timeout_pending = false;
+            unsigned n_to = 0;
+            memcpy(&n_to, hpin + 60, sizeof(unsigned));
+            if (n_to) {
+                HIPCHK(hipMemsetAsync(gctr.p + 7, 0, sizeof(unsigned), stream));
+                throw DeviceError{"deterministic mode: " + std::to_string(n_to) + " chunk(s) of the signature kernel gave up waiting for their turn at "
+                                  "the tile (spin cap): the sums of this linearisation are not order-fixed"};
+            }
+        }
         if (lin_pending) {      // trace(J'J): camera part from jn2c (estimated), point part from red_scal[1]
             f_lin = 0.5 * hpin[32];
             trace_jtj = hpin[34] + hpin[33];
@@ -672,7 +683,7 @@ struct Core {
             const int nc = P.nc;
             det_cam_part.alloc((size_t)std::max<int64_t>(n_cm_chunks_all, 1) * DET_CP);
             det_io_part.alloc((size_t)nc * DET_IOP);
-            det_rr.alloc((size_t)nc + 1);
+            det_rr.alloc((size_t)nc + 1 + DET_PRIOR_PARTS);
             det_u.alloc((size_t)P.NS + 1);
             // chunk ranges of every camera in the camera-major copy: its tiled chunks [2c, 2c+1), then -- offset 2 nc + 1 --
             // its untiled ones (both parts are sorted by camera)
@@ -696,6 +707,7 @@ struct Core {
         d.det_cam_chunks = det_cam_chunks.p;
     }
     // the camera side of a deterministic linearisation, after the camera-major kernel has left its chunk partials
+    const double *det_z = nullptr;      // the point of the deterministic linearisation in progress
     void det_camera_side() {
         const int nio = (int)P.nIOu;
         const int ncx = det_ncx();
@@ -703,6 +715,7 @@ struct Core {
         if (ncx == 6) L_DCR(6); else if (ncx == 14) L_DCR(14); else L_DCR(15);
 #undef L_DCR
         if (ncx > 6 && nio > 0) LAUNCHK((k_det_io_reduce<15>), dim3((unsigned)(nio * (nio + 1) / 2 + nio)), dim3(256), 0, stream, d, cams.p, nio, S, g_c, g_red, diagU);
+        if (d.any_prior) LAUNCHK(k_det_prior_sq, dim3(DET_PRIOR_PARTS), dim3(256), 0, stream, d, det_z);
         LAUNCHK(k_det_rows, dim3((unsigned)cdiv(P.NS, 256)), dim3(256), 0, stream, d, (const double *)diagU);
         if (ncx == 6) LAUNCHK((k_det_round_cam<6>), dim3((unsigned)P.nc), dim3(256), 0, stream, d, cams.p, 0, S, g_red);
         else LAUNCHK((k_det_round_cam<15>), dim3((unsigned)P.nc + 1), dim3(256), 0, stream, d, cams.p, nio, S, g_red);
@@ -741,6 +754,7 @@ struct Core {
             if (ncx == 6) { DISPATCH_MODEL(L_CAMN6_ALL, 0) } else if (ncx == 14) { DISPATCH_MODEL(L_CAMN_ALL, 14) } else { DISPATCH_MODEL(L_CAMN_ALL, 15) }
 #undef L_CAMN_ALL
 #undef L_CAMN6_ALL
+            det_z = zz;
             det_camera_side();
         }
         if (ntiles > 0 && nb_tiled > 0) {
@@ -814,6 +828,11 @@ struct Core {
             if (P.with_io) { DISPATCH_MODEL(L_GIANT, true) } else { DISPATCH_MODEL(L_GIANT, false) }
 #undef L_GIANT
             npart += ngiant;
+        }
+        if (deterministic && use_sig && !no_tiles) {
+            // deterministic mode: chunks whose turn at the tile never came (sig.hpp, spin cap) -- read with the scalars
+            HIPCHK(hipMemcpyAsync(hpin + 60, gctr.p + 7, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+            det_timeout_pending = true;
         }
         if ((d.ablate & 32) && use_sig) {            // phase profile of the signature kernel (wave 0 of every tile)
             unsigned long long h[16];

@@ -1557,13 +1557,37 @@ __global__ __launch_bounds__(256) void k_det_io_reduce(DevProblem d, const CamRe
 // u_r of every row of the reduced system from its squared column norm, and u_f from r'r (summed in camera order by one
 // thread: nc additions); then the camera-side entries of S and of g_red onto their grids, so that every later addition to
 // them is exact (one thread per camera element, as in k_det_cam_reduce; block nc: the IO x IO block).
+// Deterministic mode, the bound of the right-hand side: the gradient that enters -(W V^-1) g_p carries the weighted
+// residuals of the PRIOR observations beside those of the image observations (g_p += pw (z - prior)), so
+// u_f^2 >= r'r + sum pw (z - prior)^2 (with r'r of the image rows alone, prior offsets a few times the image
+// residual norm broke |sum| <= u_i u_f and with it the exactness of the sums).  Block b sums its slice of z in a fixed
+// order into det_rr[nc + 1 + b]; k_det_rows adds the DET_PRIOR_PARTS slices.
+constexpr int DET_PRIOR_PARTS = 256;
+__global__ __launch_bounds__(256) void k_det_prior_sq(DevProblem d, const double *__restrict__ z) {
+    __shared__ double sh[256];
+    const int t = threadIdx.x;
+    const int64_t per = (d.NZ + DET_PRIOR_PARTS - 1) / DET_PRIOR_PARTS;
+    const int64_t lo = per * blockIdx.x, hi = lo + per < d.NZ ? lo + per : d.NZ;
+    double s = 0.0;
+    for (int64_t i = lo + t; i < hi; i += 256) {
+        const double pw = d.z_prw[i];
+        if (pw > 0) { const double e = z[i] - d.z_prv[i]; s += pw * e * e; }
+    }
+    sh[t] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) sh[t] += sh[t + w];
+        __syncthreads();
+    }
+    if (t == 0) d.det_rr[d.nc + 1 + blockIdx.x] = sh[0];
+}
 __global__ __launch_bounds__(256) void k_det_rows(DevProblem d, const double *__restrict__ diagU) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r < d.NS) d.det_u[r] = det_pow2_sqrt(diagU[r]);
     if (blockIdx.x == 0) {                          // r'r: thread t adds the cameras t, t + 256, ...; fixed tree over the threads
         __shared__ double sh[256];
         const int t = threadIdx.x;
-        double s = 0.0;
+        double s = d.any_prior ? d.det_rr[d.nc + 1 + t] : 0.0;      // (+ the prior rows' squares: k_det_prior_sq)
         for (int c = t; c < d.nc; c += 256) s += d.det_rr[c];
         sh[t] = s;
         __syncthreads();

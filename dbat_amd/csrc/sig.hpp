@@ -38,7 +38,8 @@
 //     block E, W = E'B, Z = W R into the wave's operand panel [rows][18 k-columns],
 //     then ceil(3 n/4) k-steps of the block products (operands of the next k-step are read
 //     while one multiplies).
-// LDS reads of the operands are conflict free (row stride 18 doubles = 2 mod 4).
+// (row stride of the operand panel: 18 doubles; the reads of a k-step still conflict -- SQ_LDS_BANK_CONFLICT is 17 ... 23 %
+// of SQ_LDS_IDX_ACTIVE at C3 / C4, profiles/r05_c{3,4}_summary.md -- see DESIGN.md 4)
 #pragma once
 #include <cstddef>
 #include <type_traits>
@@ -189,7 +190,7 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
                                                const int32_t *__restrict__ sg_chunk,
                                                const int32_t *__restrict__ sg_tile_chunk0,
                                                const uint8_t *__restrict__ sg_lc, const double *__restrict__ sg_uv,
-                                               const double *__restrict__ sg_w) {
+                                               const double *__restrict__ sg_w, unsigned *__restrict__ det_timeouts) {
     constexpr bool IO = NCX > 6;
     constexpr bool io_simple = IO && IOS != 0;
     constexpr int NBLK = RB * (RB + 1) / 2, PROWS = RB * 16, LDK = SIG_LDK, NW = sig_waves(RB, IO), NT = 64 * NW;
@@ -665,7 +666,11 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
         // and they go onto the grid of S once, when the tile is flushed (one rounding per tile and element, not per chunk)
         if (d.deterministic) {
             volatile int *turn = &sy.flush_turn;
-            for (int spins = 0; *turn != ch_cur - ch0 && spins < (1 << 24); ++spins) __builtin_amdgcn_s_sleep(1);
+            int spins = 0;
+            for (; *turn != ch_cur - ch0 && spins < (1 << 24); ++spins) __builtin_amdgcn_s_sleep(1);
+            // the cap is there for the case that the argument above fails: the chunks would then add out of order and the
+            // run would lose its determinism without a word -- the host turns this count into an error (Core::sync)
+            if (spins >= (1 << 24) && lane == 0) atomicAdd(det_timeouts, 1u);
         }
         {
             const int r6k = ry;                      // the row of y closes the chunk's rows
@@ -790,11 +795,11 @@ __global__ __launch_bounds__(64 * sig_waves(RB, (NCX > 6))) void k_build_sig(Dev
         int ios = 0;
         if constexpr (NCX > 6) ios = d.tile_io_simple ? d.tile_io_simple[tile] : 0;       // IO blocks of the tile, if it qualifies
         if (NCX > 6 && ios == 1)
-            build_sig_tile<MODEL, RB, NCX, (NCX > 6 ? 1 : 0), PW>(d, tile, (int)ti, z, cams, lambda, scale, S, g_red, Vinv, gp, jn2p, partial, pivmm, sg_chunk, sg_tile_chunk0, sg_lc, sg_uv, sg_w);
+            build_sig_tile<MODEL, RB, NCX, (NCX > 6 ? 1 : 0), PW>(d, tile, (int)ti, z, cams, lambda, scale, S, g_red, Vinv, gp, jn2p, partial, pivmm, sg_chunk, sg_tile_chunk0, sg_lc, sg_uv, sg_w, tile_ctr + 2);
         else if (NCX > 6 && ios == 2)
-            build_sig_tile<MODEL, RB, NCX, (NCX > 6 ? 2 : 0), PW>(d, tile, (int)ti, z, cams, lambda, scale, S, g_red, Vinv, gp, jn2p, partial, pivmm, sg_chunk, sg_tile_chunk0, sg_lc, sg_uv, sg_w);
+            build_sig_tile<MODEL, RB, NCX, (NCX > 6 ? 2 : 0), PW>(d, tile, (int)ti, z, cams, lambda, scale, S, g_red, Vinv, gp, jn2p, partial, pivmm, sg_chunk, sg_tile_chunk0, sg_lc, sg_uv, sg_w, tile_ctr + 2);
         else
-            build_sig_tile<MODEL, RB, NCX, 0, PW>(d, tile, (int)ti, z, cams, lambda, scale, S, g_red, Vinv, gp, jn2p, partial, pivmm, sg_chunk, sg_tile_chunk0, sg_lc, sg_uv, sg_w);
+            build_sig_tile<MODEL, RB, NCX, 0, PW>(d, tile, (int)ti, z, cams, lambda, scale, S, g_red, Vinv, gp, jn2p, partial, pivmm, sg_chunk, sg_tile_chunk0, sg_lc, sg_uv, sg_w, tile_ctr + 2);
         __syncthreads();                             // the tile's LDS is free again (and s_ticket may be redrawn)
     }
 }

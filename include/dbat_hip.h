@@ -310,11 +310,19 @@ int  dbat_hip_final_residuals(dbat_hip_handle *h, double *r_unweighted, double *
 /* The reference is one MATLAB thread; the sharded path has no
  * counterpart there.  One handle per rank (prob->shard_rank of
  * prob->shard_count, one GPU each); object points and their observations are
- * sharded, cameras/IO replicated.  Per linearisation the ranks sum the envelope
- * of the reduced camera system [S | J_c'r | diag] with ONE RCCL all-reduce on
- * the handle's stream (ncclAllReduce = reduce-scatter + all-gather over xGMI);
- * per solve one all-reduce of 8 + 2*shard_count doubles carries the scalar
- * sums and the pivot extremes; per objective value one double.  With a
+ * sharded.  DOMAIN SHARDING (the default): the first levels of the nested
+ * dissection of the camera network give every rank a domain of images; an object point
+ * goes to the rank whose domain holds its interior images, so a rank builds AND factors
+ * its domain of the reduced camera system alone.  What crosses xGMI, all as RCCL
+ * all-reduces on the handle's stream: per linearisation the vectors [J_c'r | diag | sums]
+ * (2 NS + 8 doubles); per factorisation the ranks' shares of the TOP-SEPARATOR tiles of
+ * the factor, one contiguous buffer (16 MB at 1000 images / 8 ranks, where a
+ * reduce-scatter of the whole reduced system would carry 288 MB), after which every rank
+ * factors the top separators and substitutes back; per solve 8 + 4*shard_count doubles
+ * of scalar sums and pivot extremes; per objective value one double.
+ * DBAT_HIP_MG_REPLICATED (or a problem without a usable dissection: shared EO blocks):
+ * the envelope of the reduced system [S | J_c'r | diag] is summed per linearisation
+ * instead and every rank factors all of it.  With a
  * communicator every entry point below "the damping loops", dbat_hip_residual,
  * dbat_hip_final_residuals, dbat_hip_gradient/_colnorms and
  * dbat_hip_posterior_cov is COLLECTIVE: all ranks call it with the same
@@ -395,7 +403,7 @@ int  dbat_hip_resect(int32_t device, int32_t n_images, const int64_t *pt_start, 
 /* One benchmark step = one Levenberg-Marquardt iteration's device work at
  * the current point: J'J build + Schur solve (+ back-substitution) and one
  * residual-only evaluation at the trial point.  x is not advanced, so every
- * step does identical work.  ms[8], from HIP events on the handle's stream:
+ * step does identical work.  From HIP events on the handle's stream, ms[16]:
  * phases { linearize+Schur build, factor+solve, back-substitution, trial
  * residual } then single kernels { the Schur kernel alone (k_build_sig, or the
  * tile kernel k_build_tile3 / k_build_tile2 where the signature groups are too

@@ -1389,6 +1389,11 @@ def test_signature_group_kernel(hip, name, variant, monkeypatch):
     test runs it.)"""
     from dbat_amd import bundle
     s, truth = synth_struct(name, variant)
+    if (name, variant) == ('tiny', 'groups4'):
+        # 7 of its 9 batches hold points whose cameras span more than 16 IO columns: the plan would send ALL points down the
+        # matrix-core path of the heavy points (plan.hpp: a tile kernel for two batches is not worth its launch) and no
+        # tile would be left to test -- the column lists keep the two tiles ('small' / groups4 runs both paths together)
+        monkeypatch.setenv('DBAT_HIP_HEAVY', '0')
     so, x0, w = oracle_setup(s)
     R = np.sqrt(w)
     r_o, K = o.brown_euler_cam4(x0, so, jac=True)
