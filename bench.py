@@ -300,7 +300,10 @@ def main():
     # them with the bytes each all-reduce carried and the rate that implies
     per_rank = None
     if comm is not None and world > 1:
-        tv = torch.tensor(ms, dtype=torch.float64)
+        # ... with the sizes of every rank's shard behind them (its observations, points, matrix-core instructions of its
+        # tile kernel), so that rank 0 can print north_star's table -- HBM GB/s and MFMA % of peak per rank -- itself
+        tv = torch.tensor(list(ms) + [float(info['n_obs_shard']), float(info['n_pts_shard']),
+                                      float(info['tile_kernel_mfma'] + info['heavy_mfma'])], dtype=torch.float64)
         gl = [torch.zeros_like(tv) for _ in range(world)]
         torch.distributed.all_gather(gl, tv)
         per_rank = [[float(v) for v in g] for g in gl]
@@ -484,11 +487,37 @@ def main():
                 alg = multi['allreduce_bytes_reduced_system'] / (multi['ms_allreduce'] * 1e-3) / 1e9
                 multi['allreduce_algbw_GBs'] = alg
                 multi['allreduce_busbw_GBs'] = alg * 2.0 * (R_ - 1) / R_
+            keys = ('build', 'factor_solve', 'backsub', 'trial_residual', 'tile_kernel', 'k_chol_df', 'k_backsub', 'k_residual_cm',
+                    'factor_domain', 'allreduce_top_tiles', 'factor_top_replicated', 'unused', 'heavy_z', 'heavy_syrk', 'unused2', 'unused3')
             if per_rank is not None:
-                keys = ('build', 'factor_solve', 'backsub', 'trial_residual', 'tile_kernel', 'k_chol_df', 'k_backsub', 'k_residual_cm',
-                        'factor_domain', 'allreduce_top_tiles', 'factor_top_replicated', 'unused', 'heavy_z', 'heavy_syrk', 'unused2', 'unused3')
-                multi['per_rank_ms'] = [dict(zip(keys, r)) for r in per_rank]
+                multi['per_rank_ms'] = [dict(zip(keys, r[:16])) for r in per_rank]
                 multi['slowest_rank_ms'] = {k: max(r[i] for r in per_rank) for i, k in enumerate(keys)}
+            # north_star's table, one row per rank: achieved HBM GB/s of the streaming kernels on their algorithmic bytes
+            # and MFMA % of the FP64 matrix peak of the Schur kernel (algorithmic flops of the rank's points; executed:
+            # the matrix-core instructions it issues x 2048).  An emulated run has rank 0's row only.
+            rows_in = per_rank if per_rank is not None else [list(ms) + [float(no_s), float(np_s),
+                                                                          float(info['tile_kernel_mfma'] + info['heavy_mfma'])]]
+            flops_all = float(np.sum(108.0 * kp + 216.0 * kp * kp))
+            table = []
+            for rk, r in enumerate(rows_in):
+                o_r, p_r, mf_r = r[16], r[17], r[18]
+                t_tile = (r[4] + r[13]) * 1e-3
+                row = {'rank': rk, 'obs': int(o_r), 'points': int(p_r), 'ms_step_device': r[0] + r[1] + r[2] + r[3]}
+                if t_tile > 0:
+                    fl = flops_all * o_r / max(no, 1)
+                    row['schur_TFLOPs_algorithmic'] = fl / t_tile / 1e12
+                    row['schur_mfma_pct_of_fp64_peak_algorithmic'] = 100.0 * fl / t_tile / 1e12 / FP64_PEAK_TFLOPS
+                    row['schur_mfma_pct_of_fp64_peak_executed'] = 100.0 * 2048.0 * mf_r / t_tile / 1e12 / FP64_PEAK_TFLOPS
+                if r[7] > 0:
+                    row['residual_HBM_GBs'] = (20 * o_r + 24 * p_r + 48 * nc) / (r[7] * 1e-3) / 1e9
+                    row['residual_pct_of_8TBs'] = 100.0 * row['residual_HBM_GBs'] / HBM_PEAK_GBS
+                if r[6] > 0:
+                    row['backsub_HBM_GBs'] = (40 * o_r + 48 * p_r + 48 * nc) / (r[6] * 1e-3) / 1e9
+                    row['backsub_pct_of_8TBs'] = 100.0 * row['backsub_HBM_GBs'] / HBM_PEAK_GBS
+                if r[1] > 0:
+                    row['factor_solve_ms'] = r[1]
+                table.append(row)
+            multi['per_rank_roofline'] = table
             if one_gpu is not None:
                 multi['one_gpu'] = one_gpu
                 multi['speedup_vs_one_gpu'] = (args.steps / dt) / one_gpu['value']

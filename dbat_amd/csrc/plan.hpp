@@ -99,6 +99,10 @@ struct Plan {
     // observation (point-major arrays), #points of the whole group, index of the chunk's first
     // point in the group, first observation of the group (slot-major copy), offset into sg_lc}.
     static constexpr int SG_KMAX = 13;             // 6*13 + 1 rows fit five 16-row blocks
+#ifndef DBAT_SIG_IO_WAVES
+#define DBAT_SIG_IO_WAVES 4
+#endif
+    static constexpr int SIG_IO_CMAX = DBAT_SIG_IO_WAVES == 8 ? 16 : 18;    // cameras per tile, self-calibration (sig.hpp SIG_IO_CAMS)
     static constexpr int SG_CHUNK = 64;
     std::vector<int32_t> sg_chunk;                 // [nchunks][8]
     std::vector<int32_t> sg_tile_chunk0;           // [ntiles+1]
@@ -923,7 +927,7 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     // Points that fit a tile of the MFMA Schur kernel (at most CMAX cameras and
     // IOT estimated IO columns) are processed first; "heavy" points (e.g. control
     // points seen in very many images) follow and go through k_build.
-    P.CMAX = env_int("DBAT_HIP_CMAX", P.with_io ? 18 : 21);
+    P.CMAX = env_int("DBAT_HIP_CMAX", P.with_io ? Plan::SIG_IO_CMAX : 21);
     if (P.shared_eo) P.CMAX = 0;                    // the tile kernels address camera rows as 6*camera + k
     if (P.CMAX < 0 || P.CMAX > (P.with_io ? 18 : 21)) P.CMAX = P.with_io ? 18 : 21;   // 6*CMAX (+IOT) <= 128 rows of the MFMA tile
     if (P.ncolmax > 15) P.CMAX = 0;                  // the tile kernels hold at most 9 IO columns per camera (DBAT's usual self-calibration:

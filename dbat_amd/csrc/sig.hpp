@@ -55,6 +55,14 @@ constexpr int SIG_NW = 8;            // waves per workgroup (two per SIMD: one e
 constexpr int SIG_CAMW = (int)(offsetof(CamRec, ncol) / 8) + 1;   // doubles of a CamRec that the fixed-IO evaluation reads (.. w[2]) + eo_est
 constexpr int SIG_CAMW_IO = (int)((sizeof(CamRec) + 7) / 8);   // self-calibration: the whole record (column lists)
 constexpr int SIG_STILE = 8064;      // 126*127/2 = 8001 packed lower triangle of the tile, padded
+// Self-calibration at EIGHT waves per workgroup (two per SIMD; DBAT_SIG_IO_WAVES=8): the eight operand panels (92 KB) leave
+// room for a tile of 16 cameras + 16 IO columns = 112 rows (the plan's DBAT_HIP_CMAX default follows: Plan::SIG_IO_CMAX)
+#ifndef DBAT_SIG_IO_WAVES
+#define DBAT_SIG_IO_WAVES 4
+#endif
+constexpr int SIG_IO_CAMS = DBAT_SIG_IO_WAVES == 8 ? 16 : 21;
+__host__ __device__ constexpr int sig_stile(bool io) { return io && DBAT_SIG_IO_WAVES == 8 ? 6336 : SIG_STILE; }      // 112*113/2 = 6328
+__host__ __device__ constexpr int sig_cams(bool io) { return io ? SIG_IO_CAMS : 21; }
 
 struct SigLds {                      // static part
     int next_chunk, abort_;
@@ -70,9 +78,9 @@ struct SigLds {                      // static part
 
 // eight waves (two per SIMD, 256 registers each) where the kernel fits them; the variants with five row
 // blocks or with the IO Jacobian need more registers: four waves with 512 each
-__host__ __device__ constexpr int sig_waves(int RB, bool io) { return RB <= 4 && !io ? SIG_NW : 4; }
+__host__ __device__ constexpr int sig_waves(int RB, bool io) { return RB <= 4 && !io ? SIG_NW : (io ? DBAT_SIG_IO_WAVES : 4); }
 __host__ __device__ constexpr size_t sig_lds_bytes(int RB, bool io) {
-    return ((size_t)SIG_STILE + 128 + 21 * (io ? SIG_CAMW_IO : SIG_CAMW) + sig_waves(RB, io) * ((size_t)RB * 16 * SIG_LDK)) * sizeof(double);
+    return ((size_t)sig_stile(io) + 128 + sig_cams(io) * (io ? SIG_CAMW_IO : SIG_CAMW) + sig_waves(RB, io) * ((size_t)RB * 16 * SIG_LDK)) * sizeof(double);
 }
 
 // value of x in lane `src` (ds_bpermute_b32 on both halves)
@@ -190,18 +198,18 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
                                                const int32_t *__restrict__ sg_chunk,
                                                const int32_t *__restrict__ sg_tile_chunk0,
                                                const uint8_t *__restrict__ sg_lc, const double *__restrict__ sg_uv,
-                                               const double *__restrict__ sg_w, unsigned *__restrict__ det_timeouts) {
+                                               const double *__restrict__ sg_w, unsigned *__restrict__ det_timeouts,
+                                               SigLds &sy, double *sh) {
     constexpr bool IO = NCX > 6;
     constexpr bool io_simple = IO && IOS != 0;
     constexpr int NBLK = RB * (RB + 1) / 2, PROWS = RB * 16, LDK = SIG_LDK, NW = sig_waves(RB, IO), NT = 64 * NW;
     constexpr int CAMW = IO ? SIG_CAMW_IO : SIG_CAMW;
     extern __shared__ double smem[];
     double *stile = smem;                            // packed lower triangle of the tile's block of S (negated sum)
-    double *vt = stile + SIG_STILE;                  // [128] -(W V^-1 g) by tile row
+    constexpr int STILE = sig_stile(IO);
+    double *vt = stile + STILE;                      // [128] -(W V^-1 g) by tile row
     double *camw = vt + 128;                         // [21][SIG_CAMW]
-    double *wave_base = camw + 21 * CAMW;
-    __shared__ SigLds sy;
-    __shared__ double sh[16];
+    double *wave_base = camw + sig_cams(IO) * CAMW;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     // DBAT_HIP_ABLATE & 32 (measurement build): phase clocks of wave 0 (100 MHz ticks), summed over the tiles into g_tile2_prof
@@ -222,7 +230,7 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
         if (lane < 8) nd = sg_chunk[8 * (int64_t)ch + lane];
         if (lane < 16) nlc = sg_lc[16 * (int64_t)ch + lane];
     }
-    for (int i = t; i < SIG_STILE + 128; i += NT) stile[i] = 0.0;
+    for (int i = t; i < STILE + 128; i += NT) stile[i] = 0.0;
     for (int i = t; i < NW * (PROWS * LDK); i += NT) wave_base[i] = 0.0;
     for (int i = t; i < ncam * CAMW; i += NT) {
         const int c = i / CAMW, f = i - c * CAMW;
@@ -688,7 +696,7 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
                 for (int e = 0; e < 4; ++e) {
                     const int lr = 16 * r1 + (lane >> 4) + 4 * e;
                     const bool yrow = lr == r6k;
-                    double *row = stile + (yrow ? SIG_STILE : sy.toff[wave][min(lr, 79)]);
+                    double *row = stile + (yrow ? STILE : sy.toff[wave][min(lr, 79)]);
                     if (!DBAT_ABLATE(d, 8)) {
 #pragma unroll
                         for (int r2 = 0; r2 < r1; ++r2) {
@@ -782,6 +790,8 @@ __global__ __launch_bounds__(64 * sig_waves(RB, (NCX > 6))) void k_build_sig(Dev
                                                    const uint8_t *__restrict__ sg_lc, const double *__restrict__ sg_uv,
                                                    const double *__restrict__ sg_w, unsigned *__restrict__ tile_ctr) {
     __shared__ unsigned s_ticket;
+    __shared__ SigLds sy;                            // (one copy for the three instantiations of build_sig_tile)
+    __shared__ double sh[16];
     for (;;) {
         if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(tile_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
@@ -794,12 +804,15 @@ __global__ __launch_bounds__(64 * sig_waves(RB, (NCX > 6))) void k_build_sig(Dev
         const int tile = d.tile_order[ti];
         int ios = 0;
         if constexpr (NCX > 6) ios = d.tile_io_simple ? d.tile_io_simple[tile] : 0;       // IO blocks of the tile, if it qualifies
+#ifdef DBAT_SIG_ONLY_IOS
+        ios = DBAT_SIG_ONLY_IOS;     // (register experiments: one instantiation per kernel)
+#endif
         if (NCX > 6 && ios == 1)
-            build_sig_tile<MODEL, RB, NCX, (NCX > 6 ? 1 : 0), PW>(d, tile, (int)ti, z, cams, lambda, scale, S, g_red, Vinv, gp, jn2p, partial, pivmm, sg_chunk, sg_tile_chunk0, sg_lc, sg_uv, sg_w, tile_ctr + 2);
+            build_sig_tile<MODEL, RB, NCX, (NCX > 6 ? 1 : 0), PW>(d, tile, (int)ti, z, cams, lambda, scale, S, g_red, Vinv, gp, jn2p, partial, pivmm, sg_chunk, sg_tile_chunk0, sg_lc, sg_uv, sg_w, tile_ctr + 2, sy, sh);
         else if (NCX > 6 && ios == 2)
-            build_sig_tile<MODEL, RB, NCX, (NCX > 6 ? 2 : 0), PW>(d, tile, (int)ti, z, cams, lambda, scale, S, g_red, Vinv, gp, jn2p, partial, pivmm, sg_chunk, sg_tile_chunk0, sg_lc, sg_uv, sg_w, tile_ctr + 2);
+            build_sig_tile<MODEL, RB, NCX, (NCX > 6 ? 2 : 0), PW>(d, tile, (int)ti, z, cams, lambda, scale, S, g_red, Vinv, gp, jn2p, partial, pivmm, sg_chunk, sg_tile_chunk0, sg_lc, sg_uv, sg_w, tile_ctr + 2, sy, sh);
         else
-            build_sig_tile<MODEL, RB, NCX, 0, PW>(d, tile, (int)ti, z, cams, lambda, scale, S, g_red, Vinv, gp, jn2p, partial, pivmm, sg_chunk, sg_tile_chunk0, sg_lc, sg_uv, sg_w, tile_ctr + 2);
+            build_sig_tile<MODEL, RB, NCX, 0, PW>(d, tile, (int)ti, z, cams, lambda, scale, S, g_red, Vinv, gp, jn2p, partial, pivmm, sg_chunk, sg_tile_chunk0, sg_lc, sg_uv, sg_w, tile_ctr + 2, sy, sh);
         __syncthreads();                             // the tile's LDS is free again (and s_ticket may be redrawn)
     }
 }

@@ -62,32 +62,34 @@ def make_struct(IO, EO, OP, ip_val, ip_cam, ip_pt, pxSize, *, ip_std=None,
     # IP.sigmas = the distinct standard deviations (one sort of 2*no values unless they are all equal)
     sigmas = np.array([std.flat[0]]) if std.size and std.min() == std.max() else np.unique(std)
 
+    # (every array column-major, as MATLAB holds it and as the C ABI takes it: marshalling a struct is then a matter of
+    # views -- dbat_amd._hip._flat -- and a second bundle() on a 10 M observation project finds its cached handle in
+    # milliseconds)
     def prior(p, val):
         if p is None:
-            return NS(use=np.zeros(val.shape, bool),
-                      val=np.full(val.shape, np.nan),
-                      std=np.full(val.shape, np.nan))
-        return NS(use=np.array(p[0], bool), val=np.array(p[1], float),
-                  std=np.array(p[2], float))
+            return NS(use=np.zeros(val.shape, bool, order='F'),
+                      val=np.full(val.shape, np.nan, order='F'),
+                      std=np.full(val.shape, np.nan, order='F'))
+        return NS(use=np.array(p[0], bool, order='F'), val=np.array(p[1], float, order='F'),
+                  std=np.array(p[2], float, order='F'))
 
     s = NS()
     s.IO = NS(val=IO,
               model=NS(distModel=np.full(nc, int(distModel)), nK=int(nK), nP=int(nP)),
-              sensor=NS(pxSize=np.array(px, float)),
-              struct=NS(block=(np.ones(IO.shape, np.int64) if IOblock is None
-                               else np.array(IOblock, np.int64))))
+              sensor=NS(pxSize=np.array(px, float, order='F')),
+              struct=NS(block=(np.ones(IO.shape, np.int32, order='F') if IOblock is None
+                               else np.array(IOblock, np.int32, order='F'))))
     s.EO = NS(val=EO,
-              struct=NS(block=(np.tile(np.arange(1, nc + 1), (6, 1))
-                               if EOblock is None else np.array(EOblock, np.int64))))
+              struct=NS(block=np.array(np.tile(np.arange(1, nc + 1), (6, 1)) if EOblock is None else EOblock, np.int32, order='F')))
     s.OP = NS(val=OP, id=np.arange(1, OP.shape[1] + 1))      # prob2dbatstruct.m: OP.id
     s.IP = NS(val=ip_val, std=np.array(std, float, order='F'),
               cam=np.array(ip_cam, np.int32),              # (int32: what the C ABI takes -- no conversion per bundle() call)
               pt=np.array(ip_pt, np.int32),
               sigmas=sigmas)
     s.bundle = NS(est=NS(
-        IO=np.zeros(IO.shape, bool) if estIO is None else np.array(estIO, bool),
-        EO=np.ones(EO.shape, bool) if estEO is None else np.array(estEO, bool),
-        OP=np.ones(OP.shape, bool) if estOP is None else np.array(estOP, bool)),
+        IO=np.zeros(IO.shape, bool, order='F') if estIO is None else np.array(estIO, bool, order='F'),
+        EO=np.ones(EO.shape, bool, order='F') if estEO is None else np.array(estEO, bool, order='F'),
+        OP=np.ones(OP.shape, bool, order='F') if estOP is None else np.array(estOP, bool, order='F')),
         serial=None, deserial=None)
     s.prior = NS(IO=prior(priorIO, IO), EO=prior(priorEO, EO), OP=prior(priorOP, OP))
     s.post = NS()

@@ -693,6 +693,12 @@ def test_bench_two_processes_on_one_gpu(hip):
     assert 'host memory' in j2['config']['collective']
     assert j2['solve']['code'] == 0 and j1['solve']['code'] == 0
     assert abs(j2['solve']['sigma0'] - j1['solve']['sigma0']) < 1e-8 * j1['solve']['sigma0']
+    # north_star's table: one row per rank with its shard, the HBM rate of the streaming kernels and the MFMA share of the
+    # Schur kernel (round 6: printed by rank 0 so that the first real N > 1 run yields it)
+    rows = j2['multi_gpu']['per_rank_roofline']
+    assert [r['rank'] for r in rows] == [0, 1] and sum(r['obs'] for r in rows) == 100000
+    for r in rows:
+        assert r['schur_mfma_pct_of_fp64_peak_algorithmic'] > 0 and r['residual_HBM_GBs'] > 0 and r['backsub_HBM_GBs'] > 0
 
 
 def test_rccl_allreduce_on_raw_device_pointer(hip):
