@@ -20,6 +20,14 @@ for sd in range(seed0, seed0 + n_scenes):
     sig = str(rng.choice(['0', '2', '']))
     if sig: os.environ['DBAT_HIP_SIG'] = sig
     else: os.environ.pop('DBAT_HIP_SIG', None)
+    if os.environ.get('FUZZ_IRREGULAR'):     # bench/fuzz_irregular.py's family: thinned visibility, heavy / giant points (csrc/heavy.hpp), forced kernel paths
+        sys.path.insert(0, os.path.join(R_, 'oracle')); sys.path.insert(0, os.path.join(R_, 'tests')); sys.path.insert(0, os.path.join(R_, 'bench'))
+        from fuzz_irregular import irregular_scene, KNOBS
+        s, env, desc = irregular_scene(sd)
+        for k in KNOBS: os.environ.pop(k, None)
+        env.pop('DBAT_HIP_BT', None)         # (128-observation batches: no tiles, the deterministic column lists -- covered by the suite)
+        os.environ.update(env)
+        cams, points, rays, sig = s.EO.val.shape[1], s.OP.val.shape[1], 0, env.get('DBAT_HIP_SIG', '') + ' ' + ' '.join('%s=%s' % (k[9:], v) for k, v in env.items())
     lam = float(rng.choice([0.0, 1e-3]))
     h = _hip.Handle(s)
     try:

@@ -55,8 +55,11 @@ constexpr int SIG_NW = 8;            // waves per workgroup (two per SIMD: one e
 constexpr int SIG_CAMW = (int)(offsetof(CamRec, ncol) / 8) + 1;   // doubles of a CamRec that the fixed-IO evaluation reads (.. w[2]) + eo_est
 constexpr int SIG_CAMW_IO = (int)((sizeof(CamRec) + 7) / 8);   // self-calibration: the whole record (column lists)
 constexpr int SIG_STILE = 8064;      // 126*127/2 = 8001 packed lower triangle of the tile, padded
-// Self-calibration at EIGHT waves per workgroup (two per SIMD; DBAT_SIG_IO_WAVES=8): the eight operand panels (92 KB) leave
-// room for a tile of 16 cameras + 16 IO columns = 112 rows (the plan's DBAT_HIP_CMAX default follows: Plan::SIG_IO_CMAX)
+// Self-calibration at EIGHT waves per workgroup (two per SIMD; -DDBAT_SIG_IO_WAVES=8, a compile-time experiment): the eight
+// operand panels (92 KB) leave room for a tile of 16 cameras + 16 IO columns = 112 rows (the plan's DBAT_HIP_CMAX default
+// follows: Plan::SIG_IO_CMAX).  Measured in round 6 (profiles/r06_selfcal_sig.md): under the 256-register cap the kernel
+// spills 364 ... 888 bytes per lane and takes 15 % (C4) to 39 % (C2) LONGER than the four-wave kernel (and 16-camera tiles
+// alone cost 6 ... 10 %): the default stays four waves, one per SIMD.
 #ifndef DBAT_SIG_IO_WAVES
 #define DBAT_SIG_IO_WAVES 4
 #endif
