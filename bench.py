@@ -235,7 +235,11 @@ def main():
     t_gen = time.perf_counter()
     published = None
     real = args.config in ('roma', 'roma-selfcal', 'camcal', 'sxb')
-    if real:
+    dense = args.config.startswith('dense')      # 'dense' or 'dense:<cams>x<points>': every point in every image (heavy points only)
+    if dense:
+        nc_d, np_d = (int(v) for v in args.config.split(':')[1].split('x')) if ':' in args.config else (48, 16384)
+        s, _ = synth.make_dense_scene(nc_d, np_d)
+    elif real:
         sys.path.insert(0, os.path.join(ROOT, 'bench'))
         import real_scenes
         s, published = real_scenes.make(args.config)       # (initial values on the device: needs the GPU)
@@ -544,7 +548,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and not emu:
             try:
-                out['cpu_baseline'] = cpu_baseline(s, args.config, others=() if real else ('C1', 'C2'))
+                out['cpu_baseline'] = cpu_baseline(s, args.config, others=() if (real or dense) else ('C1', 'C2'))
             except ValueError as e:                          # (a scene the C++ port does not model)
                 out['cpu_baseline'] = {'value': None, 'kind': 'port', 'note': str(e)}
         else:

@@ -38,7 +38,7 @@ for sd in range(seed0, seed0 + n_scenes):
         for i in range(5):
             p, st2 = h.linearize_solve(x0, lam, True)
             if ref is None: ref = p.copy()
-            bad += not np.array_equal(p, ref)
+            bad += not np.array_equal(p, ref, equal_nan=True)     # (a singular scene: NaN steps, in every repeat)
         e = float(np.linalg.norm(ref - p_def) / np.linalg.norm(p_def))
         worst = max(worst, e)
         print('seed %d: %d cams %d pts %d rays selfcal %d groups %d SIG=%s lambda %g: %d of 5 repeats differ, vs default %.1e%s'

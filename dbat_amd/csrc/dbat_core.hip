@@ -287,7 +287,7 @@ struct Core {
             hv.obs_dst = hv_obs_dst.p; hv.obs_ld = hv_obs_ld.p; hv.obs_ioloc = hv_obs_ioloc.p; hv.pt_io0 = hv_pt_io0.p;
             hv.io_dst = hv_io_dst.p; hv.io_ld = hv_io_ld.p; hv.io_pt = hv_io_pt.p; hv.pt_y = hv_pt_y.p;
             hv.grp_nb = hv_grp_nb.p; hv.grp_row = hv_grp_row.p; hv.task = hv_task.p; hv.ops = hv_ops.p;
-            hv.obs0 = P.hv_obs0; hv.pt0 = P.hv_pt0; hv.ntasks = P.hv_ntasks;
+            hv.obs0 = P.hv_obs0; hv.pt0 = P.hv_pt0; hv.ntasks = P.hv_ntasks; hv.max_batch_slots = P.hv_max_batch_slots;
         }
         if (const char *e = env_get("DBAT_HIP_GIANT_THREADS")) giant_threads = atoi(e);     // (64 | 128 | 256: env_validate has refused anything else)
         d.tile_batch = tile_batch.p; d.tile_cam_start = tile_cam_start.p; d.tile_cams = tile_cams.p;
@@ -460,7 +460,7 @@ struct Core {
             SET_LDS((k_cov_points<4, true>), lds_cov); SET_LDS((k_cov_points<5, true>), lds_cov);
         }
         if (use_heavy) {
-#define SET_HVZ(M) SET_LDS((k_heavy_z<M, 6>), heavy_z_lds_bytes(6)); SET_LDS((k_heavy_z<M, 14>), heavy_z_lds_bytes(14)); SET_LDS((k_heavy_z<M, 15>), heavy_z_lds_bytes(15))
+#define SET_HVZ(M) SET_LDS((k_heavy_z<M, 6>), heavy_z_lds_bytes(6, 0, true)); SET_LDS((k_heavy_z<M, 14>), heavy_z_lds_bytes(14, P.hv_max_batch_slots, true)); SET_LDS((k_heavy_z<M, 15>), heavy_z_lds_bytes(15, P.hv_max_batch_slots, true))
             SET_HVZ(2); SET_HVZ(3); SET_HVZ(4); SET_HVZ(5);
 #undef SET_HVZ
         }
@@ -807,7 +807,7 @@ struct Core {
 #undef L_CAMN6U
             }
             if (nb > P.nb_tiled) {
-#define L_HVZ(M, NCXV) LAUNCHK((k_heavy_z<M, NCXV>), dim3((unsigned)(nb - P.nb_tiled)), dim3(256), heavy_z_lds_bytes(NCXV), stream, d, hv, zz, cams.p, lambda, scale, hv_Z.p, Vinv.p, gp.p, jn2p.p, partial.p + npart, pivmm.p, (int)P.nb_tiled)
+#define L_HVZ(M, NCXV) LAUNCHK((k_heavy_z<M, NCXV>), dim3((unsigned)(nb - P.nb_tiled)), dim3(256), heavy_z_lds_bytes(NCXV, P.hv_max_batch_slots, deterministic), stream, d, hv, zz, cams.p, lambda, scale, hv_Z.p, Vinv.p, gp.p, jn2p.p, partial.p + npart, pivmm.p, (int)P.nb_tiled)
                 if (tile_ncx == 6) { DISPATCH_MODEL(L_HVZ, 6) } else if (tile_ncx == 14) { DISPATCH_MODEL(L_HVZ, 14) } else { DISPATCH_MODEL(L_HVZ, 15) }
 #undef L_HVZ
                 npart += nb - P.nb_tiled;
@@ -833,6 +833,17 @@ struct Core {
             // deterministic mode: chunks whose turn at the tile never came (sig.hpp, spin cap) -- read with the scalars
             HIPCHK(hipMemcpyAsync(hpin + 60, gctr.p + 7, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
             det_timeout_pending = true;
+        }
+        if ((d.ablate & 32) && use_heavy && nb > P.nb_tiled) {      // phase profile of k_heavy_z (thread 0 of every batch)
+            unsigned long long h[16];
+            HIPCHK(hipStreamSynchronize(stream));
+            HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tile2_prof), sizeof(h)));
+            static const char *nm[6] = {"evaluate", "V, g sums", "point blocks", "EO rows of Z", "IO rows of Z", "tail"};
+            fprintf(stderr, "[heavy_z prof, us per batch (thread 0) avg over %d batches]", (int)(nb - P.nb_tiled));
+            for (int i = 0; i < 6; ++i) fprintf(stderr, " %s=%.2f", nm[i], h[8 + i] * 0.01 / (double)std::max<int64_t>(nb - P.nb_tiled, 1));
+            fprintf(stderr, "\n");
+            for (int i = 8; i < 16; ++i) h[i] = 0;
+            HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_tile2_prof), h, sizeof(h)));
         }
         if ((d.ablate & 32) && use_sig) {            // phase profile of the signature kernel (wave 0 of every tile)
             unsigned long long h[16];
@@ -2270,7 +2281,7 @@ int dbat_hip_chol_stats(const dbat_hip_handle *h, int64_t *st) {
 int dbat_hip_build_kernel_name(const dbat_hip_handle *h, char *buf, int32_t buf_len) {
     if (!h || !buf || buf_len < 2) { g_err = "null argument"; return DBAT_HIP_EINVAL; }
     const Core &c = *h->core;
-    const char *nm = "k_build";
+    const char *nm = c.use_heavy ? "k_heavy_z + k_heavy_syrk" : "k_build";      // (nothing tiled: the kernels of the untiled points)
     if (c.ntiles > 0 && c.P.nb_tiled > 0) {
         if (c.use_sig) nm = "k_build_sig";
         else if (c.use_tile3 && c.tile_ncx == 6) nm = "k_build_tile3";

@@ -39,12 +39,14 @@ struct HeavyDev {
     const int32_t *task;             // [tasks][4]
     const int32_t *ops;              // [k-steps][4][2]
     int64_t obs0;
-    int32_t pt0, ntasks;
+    int32_t pt0, ntasks, max_batch_slots;
 };
 constexpr int HV_NIOC = 9;
 
-__host__ __device__ constexpr size_t heavy_z_lds_bytes(int ncx) {
-    return ((size_t)256 * 9 + (size_t)128 * 9 + (size_t)256 * 3 * (ncx > 6 ? ncx - 6 : 0)) * sizeof(double);
+// dynamic LDS of k_heavy_z: [256][9] per-observation terms | [128][9] per-point blocks | the IO rows of the batch's points
+// (slots x 3, self-calibration) | deterministic mode: [256][3 (NCX - 6)] the observations' shares of the IO rows
+__host__ __device__ constexpr size_t heavy_z_lds_bytes(int ncx, int max_batch_slots, bool deterministic) {
+    return ((size_t)256 * 9 + (size_t)128 * 9 + (ncx > 6 ? (size_t)3 * max_batch_slots + (deterministic ? (size_t)256 * 3 * (ncx - 6) : 0) : 0)) * sizeof(double);
 }
 
 // The point's block: priors, squared column norms, damping, R (V^-1 = R R'), pivots, y = R'g -- as k_build.
@@ -56,13 +58,19 @@ __device__ __forceinline__ void heavy_point_block(const DevProblem &d, const dou
     const int64_t zp = d.NS + 3 * (int64_t)pt;
     const int dix[3] = {0, 3, 5};
     double jn[3];
+    // (everything the block needs from memory is requested at once: a handful of lanes do this while the workgroup
+    // waits, and three dependent round trips per coordinate -- weight, then value and prior -- were 6 of its 8 us)
+    double pwv[3], zv[3], pvv[3];
+    bool estv[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { pwv[k] = d.any_prior ? d.z_prw[zp + k] : 0.0; zv[k] = z[zp + k]; pvv[k] = d.any_prior ? d.z_prv[zp + k] : 0.0; estv[k] = d.z_est[zp + k] != 0; }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const double pw = d.z_prw[zp + k];
-        if (pw > 0) { V[dix[k]] += pw; g[k] += pw * (z[zp + k] - d.z_prv[zp + k]); }
+        const double pw = pwv[k];
+        if (pw > 0) { V[dix[k]] += pw; g[k] += pw * (zv[k] - pvv[k]); }
         jn[k] = V[dix[k]];
         jn2p[3 * (int64_t)pt + k] = jn[k];
-        if (d.z_est[zp + k]) V[dix[k]] += lambda; else V[dix[k]] = 1.0;
+        if (estv[k]) V[dix[k]] += lambda; else V[dix[k]] = 1.0;
     }
     double inv[6], R[6];
     point_block_factor(V, R, inv);
@@ -73,7 +81,7 @@ __device__ __forceinline__ void heavy_point_block(const DevProblem &d, const dou
         const double dd[3] = {d0, d1, d2};
 #pragma unroll
         for (int k = 0; k < 3; ++k)
-            if (d.z_est[zp + k]) {
+            if (estv[k]) {
                 double v = scale ? dd[k] / sqrt(jn[k]) : dd[k];
                 v = v == v ? v : 0.0;
                 pmin = fmin(pmin, v); pmax = fmax(pmax, v);
@@ -96,11 +104,11 @@ __global__ __launch_bounds__(256) void k_heavy_z(DevProblem d, HeavyDev hv, cons
                                                  double *__restrict__ jn2p, double *__restrict__ partial,
                                                  unsigned long long *__restrict__ pivmm, int batch0) {
     constexpr int NQ = NCX - 6;                      // IO columns of one camera at most
-    constexpr int WS = 3 * (NQ > 0 ? NQ : 1);
     extern __shared__ double smem[];
     double *red = smem;                              // [256][9]  B'B (6) | B'r (3) of every observation
     double *pinfo = red + 256 * 9;                   // [128][9]  per point: V | g, then R | y
-    double *wio = pinfo + 128 * 9;                   // [256][3 NQ]  the observation's share of its point's IO rows of Z
+    double *zsum = pinfo + 128 * 9;                  // [IO slots of the batch][3]  the IO rows of Z
+    constexpr int WS = 3 * (NQ > 0 ? NQ : 1);
     __shared__ int pseg[128];                        // per point of the batch: first lane | observations << 16
     __shared__ unsigned char lio[256][NQ > 0 ? NQ : 1];
     __shared__ double sh[8];
@@ -110,8 +118,13 @@ __global__ __launch_bounds__(256) void k_heavy_z(DevProblem d, HeavyDev hv, cons
     const bool active = t < nobs;
     const int64_t o = o0 + t;
     const int npb = nobs > 0 ? (int)d.o_pidx[o0 + nobs - 1] + 1 : 0;      // points of the batch
+    // DBAT_HIP_ABLATE & 32 (measurement build): phase clocks of thread 0 (100 MHz ticks), summed over the batches into g_tile2_prof[8 ..]
+    const bool prof = DBAT_ABLATE(d, 32) && t == 0;
+    long long tlast = prof ? wall_clock64() : 0;
+    auto lap = [&](int i) { if (prof) { const long long now = wall_clock64(); atomicAdd(&g_tile2_prof[8 + i], (unsigned long long)(now - tlast)); tlast = now; } };
     double r[2] = {0, 0}, E[2][NCX], B[2][3];
-    int pt = 0, seg_start = 0, pidx = 0, ncol = 6;
+    int pt = 0, seg_start = 0, pidx = -1, ncol = 6;
+    int32_t zdst = 0; int zld = 16, ioslot0 = 0;
     if (active) {
         const int cam = d.o_cam[o];
         pt = d.o_pt[o];
@@ -132,13 +145,16 @@ __global__ __launch_bounds__(256) void k_heavy_z(DevProblem d, HeavyDev hv, cons
         rd[7] = B[0][1] * r[0] + B[1][1] * r[1];
         rd[8] = B[0][2] * r[0] + B[1][2] * r[1];
         if (t == seg_start) pseg[pidx] = (int)sg;
+        zdst = hv.obs_dst[o - hv.obs0]; zld = hv.obs_ld[o - hv.obs0];
         if constexpr (NQ > 0) {
             const uint8_t *il = hv.obs_ioloc + (size_t)(o - hv.obs0) * HV_NIOC;
 #pragma unroll
             for (int j = 0; j < NQ; ++j) lio[t][j] = il[j];
+            ioslot0 = hv.pt_io0[pt - hv.pt0];
         }
     }
     __syncthreads();
+    lap(0);
     // V and g of every point: its observations' terms added in their order (one thread per point and element)
     for (int idx = t; idx < npb * 9; idx += 256) {
         const int pi = idx / 9, v = idx - 9 * pi;
@@ -148,6 +164,7 @@ __global__ __launch_bounds__(256) void k_heavy_z(DevProblem d, HeavyDev hv, cons
         pinfo[pi * 9 + v] = sum;
     }
     __syncthreads();
+    lap(1);
     double pmin = 1e300, pmax = 0.0;
     if (active && t == seg_start) {
         double Vg[9];
@@ -160,50 +177,91 @@ __global__ __launch_bounds__(256) void k_heavy_z(DevProblem d, HeavyDev hv, cons
         Zs[py[0]] = Vg[6]; Zs[py[0] + py[1]] = Vg[7]; Zs[py[0] + 2 * py[1]] = Vg[8];
     }
     __syncthreads();
-    // the observation's rows of Z = (E'B) R: the six EO rows into its camera's slot, the IO rows to LDS
+    lap(2);
+    // the observation's rows of Z = (E'B) R: the six EO rows into its camera's slot
+    double r00 = 0, r10 = 0, r20 = 0, r11 = 0, r21 = 0, r22 = 0;
     if (active) {
         const double *pi = pinfo + pidx * 9;
-        const double r00 = pi[0], r10 = pi[1], r20 = pi[2], r11 = pi[3], r21 = pi[4], r22 = pi[5];
-        const int32_t dst = hv.obs_dst[o - hv.obs0];
-        const int ld = hv.obs_ld[o - hv.obs0];
+        r00 = pi[0]; r10 = pi[1]; r20 = pi[2]; r11 = pi[3]; r21 = pi[4]; r22 = pi[5];
+        const int32_t dst = zdst;
+        const int ld = zld;
 #pragma unroll
-        for (int a = 0; a < NCX; ++a) {
-            if (a < ncol) {
-                const double w0 = E[0][a] * B[0][0] + E[1][a] * B[1][0];
-                const double w1 = E[0][a] * B[0][1] + E[1][a] * B[1][1];
-                const double w2 = E[0][a] * B[0][2] + E[1][a] * B[1][2];
-                const double z0 = w0 * r00 + w1 * r10 + w2 * r20, z1 = w1 * r11 + w2 * r21, z2 = w2 * r22;
-                if (a < 6) { Zs[dst + a] = z0; Zs[dst + ld + a] = z1; Zs[dst + 2 * ld + a] = z2; }
-                else { double *wl = wio + (size_t)t * WS + 3 * (a - 6); wl[0] = z0; wl[1] = z1; wl[2] = z2; }
-            }
+        for (int a = 0; a < 6; ++a) {
+            const double w0 = E[0][a] * B[0][0] + E[1][a] * B[1][0];
+            const double w1 = E[0][a] * B[0][1] + E[1][a] * B[1][1];
+            const double w2 = E[0][a] * B[0][2] + E[1][a] * B[1][2];
+            Zs[dst + a] = w0 * r00 + w1 * r10 + w2 * r20; Zs[dst + ld + a] = w1 * r11 + w2 * r21; Zs[dst + 2 * ld + a] = w2 * r22;
         }
     }
+    lap(3);
     if constexpr (NQ > 0) {
-        __syncthreads();
-        // IO rows: one thread per (IO slot of a point, k-column), the point's observations in their order
+        // IO rows: sums over a point's observations, Z_io(slot) = sum_j (E_io,j' B_j) R.
+        //   default: every observation adds its terms to the point's slots in LDS (ds_add_f64; the lanes of a point hit the
+        //     same addresses, which the LDS serialises) -- no staging array, 30 KB of LDS per workgroup where the ordered sums
+        //     need 85, and every lane works.  (Adding up inside the wave first -- segmented sums by lane shuffles -- took
+        //     as long as the contended atomics: 12.4 against 11.0 us per batch of the dense scene; not kept.);
+        //   deterministic mode: the terms are staged per observation and one thread per (slot, k-column) adds the point's
+        //     observations in their order (the same bits every run; the launch asks for the staging array).
         const int hp_first = d.o_pt[o0] - hv.pt0;
         const int gs0 = hv.pt_io0[hp_first], gs1 = hv.pt_io0[hp_first + npb];
-        for (int idx = t; idx < (gs1 - gs0) * 3; idx += 256) {
-            const int gs = gs0 + idx / 3, c = idx % 3;
-            const int hp = hv.io_pt[gs], pi = hp - hp_first, s = gs - hv.pt_io0[hp];
-            const int s0 = pseg[pi] & 0xFFFF, len = (unsigned)pseg[pi] >> 16;
-            double sum = 0.0;
-            for (int j = 0; j < len; ++j) {
-                const int l = s0 + j;
-                int jj = -1;
-                if (s < NQ && lio[l][s < NQ ? s : 0] == s) jj = s;      // (the usual case: every camera of the point has the same IO columns)
-                else {
+        const int nout = (gs1 - gs0) * 3;
+        const bool det = d.deterministic != 0;
+        double *wio = zsum + 3 * (size_t)hv.max_batch_slots;      // [256][3 NQ], deterministic mode only
+        if (!det) {
+            for (int idx = t; idx < nout; idx += 256) zsum[idx] = 0.0;
+            __syncthreads();
+        }
+        if (det) {
+            if (active) {
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) if (lio[l][q] == s) jj = q;
+                for (int a = 6; a < NCX; ++a)
+                    if (a < ncol) {
+                        const double w0 = E[0][a] * B[0][0] + E[1][a] * B[1][0];
+                        const double w1 = E[0][a] * B[0][1] + E[1][a] * B[1][1];
+                        const double w2 = E[0][a] * B[0][2] + E[1][a] * B[1][2];
+                        double *wl = wio + (size_t)t * WS + 3 * (a - 6);
+                        wl[0] = w0 * r00 + w1 * r10 + w2 * r20; wl[1] = w1 * r11 + w2 * r21; wl[2] = w2 * r22;
+                    }
+            }
+        } else if (active) {
+#pragma unroll
+            for (int a = 6; a < NCX; ++a)
+                if (a < ncol) {
+                    const double w0 = E[0][a] * B[0][0] + E[1][a] * B[1][0];
+                    const double w1 = E[0][a] * B[0][1] + E[1][a] * B[1][1];
+                    const double w2 = E[0][a] * B[0][2] + E[1][a] * B[1][2];
+                    double *zs = zsum + 3 * (ioslot0 - gs0 + (int)lio[t][a - 6]);
+                    atomic_add_f64(zs, w0 * r00 + w1 * r10 + w2 * r20); atomic_add_f64(zs + 1, w1 * r11 + w2 * r21); atomic_add_f64(zs + 2, w2 * r22);
                 }
-                if (jj >= 0) sum += wio[(size_t)l * WS + 3 * jj + c];
+        }
+        __syncthreads();
+        for (int idx = t; idx < nout; idx += 256) {
+            const int gs = gs0 + idx / 3, c = idx % 3;
+            double sum;
+            if (!det) sum = zsum[idx];
+            else {
+                const int hp = hv.io_pt[gs], pi = hp - hp_first, s = gs - hv.pt_io0[hp];
+                const int s0 = pseg[pi] & 0xFFFF, len = (unsigned)pseg[pi] >> 16;
+                sum = 0.0;
+                for (int j = 0; j < len; ++j) {
+                    const int l = s0 + j;
+                    int jj = -1;
+                    if (s < NQ && lio[l][s < NQ ? s : 0] == s) jj = s;      // (the usual case: every camera of the point has the same IO columns)
+                    else {
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) if (lio[l][q] == s) jj = q;
+                    }
+                    if (jj >= 0) sum += wio[(size_t)l * WS + 3 * jj + c];
+                }
             }
             Zs[hv.io_dst[gs] + c * (int)hv.io_ld[gs]] = sum;
         }
     }
+    lap(4);
     double acc[1] = {r[0] * r[0] + r[1] * r[1]};
     block_sum<1>(acc, sh);
     if (t == 0) partial[blockIdx.x] = acc[0];
+    lap(5);
     for (int off = 32; off > 0; off >>= 1) {
         pmin = fmin(pmin, __shfl_down(pmin, off, 64));
         pmax = fmax(pmax, __shfl_down(pmax, off, 64));
@@ -321,7 +379,12 @@ __global__ __launch_bounds__(256) void k_heavy_z_giant(DevProblem d, HeavyDev hv
 __global__ __launch_bounds__(256) void k_heavy_syrk(DevProblem d, HeavyDev hv, const double *__restrict__ Zs,
                                                     double *__restrict__ S, double *__restrict__ g_red) {
     const int lane = threadIdx.x & 63;
-    const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    // Workgroups are dealt round-robin over the eight XCDs (b and b + 8 share one: observed, for speed only).  The task
+    // list is ordered so that neighbours read the same slots (plan.hpp): XCD x takes a CONTIGUOUS run of it, and a slot
+    // comes into that XCD's L2 once for all its partner groups.
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7;
+    const int wg = xcd * (nwg >> 3) + min(xcd, nwg & 7) + (blockIdx.x >> 3);
+    const int task = __builtin_amdgcn_readfirstlane(wg * 4 + (threadIdx.x >> 6));
     if (task >= hv.ntasks) return;
     const int gi = hv.task[4 * task], gj = hv.task[4 * task + 1];
     const int ks0 = hv.task[4 * task + 2], nks = hv.task[4 * task + 3];

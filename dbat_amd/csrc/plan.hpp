@@ -153,6 +153,7 @@ struct Plan {
     int64_t hv_mfma = 0;                           // v_mfma_f64_16x16x4_f64 instructions of one launch of k_heavy_syrk
     int64_t hv_alg_flops = 0;                      // sum over these points of 108 k + 216 k^2 (the full product Y W')
     int hv_max_io_slots = 0;                       // most IO columns of one point
+    int hv_max_batch_slots = 0;                    // most IO slots of the points of one batch (k_heavy_z sums them in LDS)
     std::vector<int32_t> hv_grp_nb;                // [groups] 16-row blocks of the group (1 .. 3)
     std::vector<int32_t> hv_grp_row;               // [groups][48] row of the reduced system (-1: padding, NS: right-hand side)
     std::vector<int32_t> hv_obs_dst;               // [untiled observations] Zs index of (slot, k-column 0, first EO row of the camera)
@@ -343,11 +344,14 @@ inline void build_heavy_plan(Plan &P) {
     if (total_ks * 8 >= (int64_t)1 << 31) return;
     P.hv_ops.assign((size_t)total_ks * 8, -1);
     std::vector<int64_t> fill(npairs, 0);             // points placed so far
+    std::vector<std::vector<int32_t>> pair_first(npairs);      // the point of every entry of a pair's list (ascending)
+    for (size_t r = 0; r < npairs; ++r) pair_first[r].reserve((size_t)pair_n[pord[r]]);
     for (int32_t i = 0; i < nhp; ++i)
         for (int64_t a = pg0[i]; a < pg0[i + 1]; ++a)
             for (int64_t b = pg0[i]; b <= a; ++b) {
                 const int32_t r = prank[pair_id[(uint64_t)pg_g[a] * (uint64_t)ng + (uint64_t)pg_g[b]]];
                 const int64_t e = fill[r]++;
+                pair_first[r].push_back(i);
                 const int gi = pg_g[a], gj = pg_g[b];
                 const int ldi = 16 * P.hv_grp_nb[gi], ldj = 16 * P.hv_grp_nb[gj];
                 for (int c = 0; c < 3; ++c) {
@@ -363,6 +367,7 @@ inline void build_heavy_plan(Plan &P) {
     if (ksmax <= 0) ksmax = (int)std::min<int64_t>(96, std::max<int64_t>(12, (total_ks + 4095) / 4096));
     P.hv_ks_per_task = ksmax;
     P.hv_task.clear(); P.hv_mfma = 0;
+    std::vector<int64_t> task_key;                    // position of the task's first k-step in its pair's list, as a fraction of the point range
     for (size_t r = 0; r < npairs; ++r) {
         const int gi = pair_g[2 * pord[r]], gj = pair_g[2 * pord[r] + 1];
         const int64_t nks = pk0[r + 1] - pk0[r];
@@ -373,23 +378,37 @@ inline void build_heavy_plan(Plan &P) {
             const int64_t k0 = q * nks / nt, k1 = (q + 1) * nks / nt;
             const int32_t tk[4] = {gi, gj, (int32_t)(pk0[r] + k0), (int32_t)(k1 - k0)};
             P.hv_task.insert(P.hv_task.end(), tk, tk + 4);
+            task_key.push_back(pair_first[r][(size_t)std::min<int64_t>(4 * k0 / 3, (int64_t)pair_first[r].size() - 1)]);
         }
     }
-    {   // longest tasks first
+    {   // Task order: by the first point of the task, then by group pair -- tasks that read the same slots (one run of points,
+        // every pair of its groups) are neighbours.  k_heavy_syrk maps consecutive workgroups onto ONE XCD (its blockIdx
+        // remap), so a slot is fetched into that XCD's L2 once and read from there by its other partner groups (dense
+        // scene, 48 images x 16 384 points: every slot has seven partners; without the order the kernel pulled 784 MB
+        // per launch through the fabric, bound by that and not by the matrix pipe).  The tasks are about equal in length
+        // (hv_ks_per_task), so nothing is lost by giving up "longest first".
         const size_t nt = P.hv_task.size() / 4;
         std::vector<int32_t> ord(nt);
         std::iota(ord.begin(), ord.end(), 0);
-        auto work = [&](int32_t t) {
-            const int gi = P.hv_task[4 * t], gj = P.hv_task[4 * t + 1];
-            return (int64_t)P.hv_task[4 * t + 3] * (gi == gj ? P.hv_grp_nb[gi] * (P.hv_grp_nb[gi] + 1) / 2 : P.hv_grp_nb[gi] * P.hv_grp_nb[gj]);
-        };
-        std::stable_sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) { return work(a) > work(b); });
+        std::stable_sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) {
+            if (task_key[a] != task_key[b]) return task_key[a] < task_key[b];
+            if (P.hv_task[4 * a] != P.hv_task[4 * b]) return P.hv_task[4 * a] < P.hv_task[4 * b];
+            return P.hv_task[4 * a + 1] < P.hv_task[4 * b + 1];
+        });
         std::vector<int32_t> tk(P.hv_task.size());
         for (size_t a = 0; a < nt; ++a) std::copy(P.hv_task.begin() + 4 * ord[a], P.hv_task.begin() + 4 * ord[a] + 4, tk.begin() + 4 * a);
         P.hv_task.swap(tk);
     }
     P.hv_ntasks = (int32_t)(P.hv_task.size() / 4);
     P.hv_obs0 = ho0; P.hv_pt0 = hp0; P.hv_npts = nhp;
+    P.hv_max_batch_slots = 0;
+    for (int64_t b = P.nb_tiled; b < nb; ++b) {
+        const int64_t b0 = P.batch_start[b], b1 = P.batch_start[b + 1];
+        if (b1 <= b0) continue;
+        const int32_t p0 = P.o_pt[b0] - hp0, p1 = P.o_pt[b1 - 1] - hp0 + 1;
+        P.hv_max_batch_slots = std::max(P.hv_max_batch_slots, P.hv_pt_io0[p1] - P.hv_pt_io0[p0]);
+    }
+    if (P.hv_max_batch_slots > 2048) { P.hv_ok = false; return; }      // (48 KB of LDS for the sums: beyond that the column lists)
     P.hv_alg_flops = 0;
     for (int32_t i = 0; i < nhp; ++i) { const int64_t k = pobs[i + 1] - pobs[i]; P.hv_alg_flops += 108 * k + 216 * k * k; }
     P.hv_ok = P.hv_ntasks > 0;

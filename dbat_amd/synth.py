@@ -246,3 +246,30 @@ def make_scene(name='C1', seed=None, cams=None, points=None, rays=None, selfcal=
     s = seteoest_depend(s, 0)
     s.damping = damping
     return s, truth
+
+
+def make_dense_scene(cams=48, points=16384, selfcal=True, groups=1, seed=3, noise_px=0.5):
+    """Every point in every image -- the visibility of the reference's camera-calibration demo
+    (demo/camcaldemo.m:56-119: 21 images, every target in all of them) at a size of one's choosing: the cameras and
+    points of make_scene('small', cams, points), then every point projected into every camera.  Distortion-free lens, so
+    that projections far outside the image format stay defined.  selfcal: cc, px, py, K1, K2 estimated (groups > 1:
+    independent IO blocks for runs of cameras).  Returns (s, truth)."""
+    s, truth = make_scene('small', cams=cams, points=points, rays=6, seed=seed)
+    s.IO.val[5:10] = 0.0
+    truth['IO'][5:10] = 0.0
+    nc = s.EO.val.shape[1]
+    px = float(np.ravel(s.IO.sensor.pxSize)[0])
+    cam = np.repeat(np.arange(nc, dtype=np.int32), points)
+    pt = np.tile(np.arange(points, dtype=np.int32), nc)
+    uv, depth = project(truth['IO'], truth['EO'], truth['OP'], cam, pt, px, nK=3, nP=2)
+    if not np.all(depth < 0):
+        raise RuntimeError('a point behind a camera')
+    rng = np.random.default_rng(seed)
+    s.IP.val = np.asfortranarray(uv + rng.normal(0, noise_px, uv.shape))
+    s.IP.std = np.ones(uv.shape, order='F')
+    s.IP.cam, s.IP.pt = cam, pt
+    if selfcal:
+        s.bundle.est.IO[[0, 1, 2, 5, 6]] = True
+        if groups > 1:
+            s.IO.struct.block[:] = (1 + (np.arange(nc) * groups) // nc)[None, :]
+    return s, truth

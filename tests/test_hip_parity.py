@@ -879,27 +879,9 @@ def test_giant_points(hip, variant, monkeypatch):
 
 
 def _all_see_all_scene(cams, points, selfcal, groups=1, seed=3):
-    """Every point in every image (the geometry of the reference's calibration demo, demo/camcaldemo.m:56-119):
-    cameras on a ring look at a point cloud in the middle.  Distortion-free lens, so that every projection is defined."""
+    """Every point in every image (the geometry of the reference's calibration demo, demo/camcaldemo.m:56-119)."""
     from dbat_amd import synth
-    s, truth = synth.make_scene('small', cams=cams, points=points, rays=6, seed=seed)
-    s.IO.val[5:10] = 0.0
-    truth['IO'][5:10] = 0.0
-    nc = s.EO.val.shape[1]
-    px = float(np.ravel(s.IO.sensor.pxSize)[0])
-    cam = np.repeat(np.arange(nc), points); pt = np.tile(np.arange(points), nc)
-    uv, depth = synth.project(truth['IO'], truth['EO'], truth['OP'], cam, pt, px, nK=3, nP=2)
-    assert np.all(depth < 0)
-    rng = np.random.default_rng(seed)
-    s.IP.val = uv + rng.normal(0, 0.5, uv.shape)
-    s.IP.std = np.ones_like(uv)
-    s.IP.cam, s.IP.pt = cam, pt
-    if selfcal:
-        s.bundle.est.IO[[0, 1, 2, 5, 6]] = True
-        if groups > 1:                                  # independent IO blocks for runs of cameras
-            blk = 1 + (np.arange(nc) * groups) // nc
-            s.IO.struct.block[:] = blk[None, :]
-    return s, truth
+    return synth.make_dense_scene(cams, points, selfcal, groups, seed)
 
 
 @pytest.mark.parametrize('variant', ['plain', 'selfcal', 'selfcal-groups3'])
