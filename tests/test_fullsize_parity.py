@@ -152,6 +152,39 @@ LONG = {
 }
 
 
+def test_C2_step_against_the_oracles_full_sparse_solve(hip):
+    """Round 6: ONE independent check at bench size.  The oracle (NumPy / SciPy restatement of the
+    reference, nothing of the product) evaluated the C2 scene -- 1 000 000 image points, self-calibration -- and solved the
+    scaled normal equations of gauss_newton_armijo.m:166-174 by a sparse direct factorisation of the FULL normal matrix;
+    that took three minutes on the build container and travels as data (tests/golden/c2_oracle_step.npz, written by
+    tests/golden/make_c2_oracle_step.py: every 16th entry of x0, gradient, column norms and step, and their norms).  The
+    device's objective, gradient and column norms (the model, the weights, the serialisation: 1e-11) and its step (1e-8)
+    against them -- no bench/cpu_ref.cpp, no csrc/model.hpp on the checking side."""
+    from dbat_amd import synth
+    gold = np.load(os.path.join(ROOT, 'tests', 'golden', 'c2_oracle_step.npz'))
+    s, _ = synth.make_scene('C2')
+    import hashlib
+    vis = np.frombuffer(hashlib.sha1(np.ascontiguousarray(s.IP.cam).tobytes() + np.ascontiguousarray(s.IP.pt).tobytes()).digest(), np.uint8)
+    if not np.array_equal(vis, gold['vis_sha1']) or abs(float(np.sum(s.IP.val)) - float(gold['ip_sum'])) > 1e-6 * abs(float(gold['ip_sum'])):
+        pytest.skip('this host generates another C2 scene than the one the fixture was made from (NumPy build / CPU dispatch): '
+                    'rerun tests/golden/make_c2_oracle_step.py here')
+    h = hip.Handle(s)
+    try:
+        x0 = h.serialize()
+        ev = slice(None, None, 16)
+        assert len(x0) == int(gold['n']) and np.array_equal(x0[ev], gold['x0_every']) and abs(np.linalg.norm(x0) - float(gold['x0_norm'])) <= 1e-14 * float(gold['x0_norm'])
+        p, st = h.linearize_solve(x0, 0.0, True)
+        assert not st['singular']
+        assert abs(st['f'] - float(gold['f'])) <= 1e-11 * float(gold['f'])
+        g, cn = h.gradient(), h.colnorms()
+        assert relerr(g[ev], gold['g_every']) < 1e-10 and abs(np.linalg.norm(g) - float(gold['g_norm'])) <= 1e-10 * float(gold['g_norm'])
+        assert relerr(cn[ev], gold['colnorm_every']) < 1e-11 and abs(np.linalg.norm(cn) - float(gold['colnorm_norm'])) <= 1e-11 * float(gold['colnorm_norm'])
+        assert relerr(p[ev], gold['p_every']) < TOL_STEP
+        assert abs(np.linalg.norm(p) - float(gold['p_norm'])) <= TOL_STEP * float(gold['p_norm'])
+    finally:
+        h.close()
+
+
 @pytest.mark.parametrize('kind', list(LONG))
 def test_long_signature_groups_vs_oracle(hip, kind):
     """The chunk lengths of the benchmark scenes at oracle size: twelve cameras, ten of them per

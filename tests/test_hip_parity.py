@@ -1714,7 +1714,7 @@ def test_product_switches_leave_the_result_alone(hip, switch, value, monkeypatch
     """csrc/env.hpp: a product switch selects a layout or a schedule (the dissection of the camera network, the tile
     length, the threads of the host plan) or prints statistics -- the step is the same to rounding whatever its value.
     (The switches that select kernels have their own tests: SIG, SIG_IOS_OFF, CMAX, BT, GIANT_THREADS, MG_REPLICATED,
-    DF_SPLIT / DF_CHUNK.)  Fixed IO and self-calibration, 'small' (several tiles, a dissection with separators)."""
+    DF_SPLIT / DF_CHUNK, HEAVY / HEAVY_KS: test_every_point_in_every_image, test_mixed_tiled_and_heavy_points.)  Fixed IO and self-calibration, 'small' (several tiles, a dissection with separators)."""
     from dbat_amd import synth
     for selfcal in (False, True):
         s, _ = synth.make_scene('small', selfcal=selfcal) if selfcal else synth.make_scene('small')
