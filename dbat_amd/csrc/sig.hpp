@@ -313,14 +313,14 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
             const int pi = lane & (G - 1);
             const int jh = lane / G, jstep = 64 / G;
             const bool act = pi < npts;
-            const int pt = pt0 + (act ? pi : 0);
+            const int pt = DBAT_ABLATE(d, 1024) ? (pi & 31) : pt0 + (act ? pi : 0);      // (1024, measurement build: every load of pass 1 from the cache)
             const int64_t zp = d.NS + 3 * (int64_t)pt;
             double Q[3] = {z[zp], z[zp + 1], z[zp + 2]};
             const unsigned est = (d.z_est[zp] ? 1u : 0u) | (d.z_est[zp + 1] ? 2u : 0u) | (d.z_est[zp + 2] ? 4u : 0u);
             const double prw[3] = {d.z_prw[zp], d.z_prw[zp + 1], d.z_prw[zp + 2]};     // (used after the sums: requested with the point)
             const double prv[3] = {d.z_prv[zp], d.z_prv[zp + 1], d.z_prv[zp + 2]};
             double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
-            const int64_t q0 = uv0 + gi0 + (act ? pi : 0);
+            const int64_t q0 = DBAT_ABLATE(d, 1024) ? (int64_t)(pi & 31) : uv0 + gi0 + (act ? pi : 0);
             const double2 *uvp = reinterpret_cast<const double2 *>(sg_uv), *wp = reinterpret_cast<const double2 *>(sg_w);
             // V += B'B, g += B'r of one observation (weighted, fixed coordinates masked)
             auto accumulate = [&](const double (&r)[2], const double (&B)[2][3]) {
@@ -335,7 +335,7 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
                 g[1] = fma2(g[1], B[0][1], r[0], B[1][1], r[1]);
                 g[2] = fma2(g[2], B[0][2], r[0], B[1][2], r[1]);
             };
-            const int kk = DBAT_ABLATE(d, 4) ? 1 : k;
+            const int kk = DBAT_ABLATE(d, 128) ? 0 : (DBAT_ABLATE(d, 4) ? 1 : k);      // (128: no camera at all in pass 1)
             if constexpr (!IO) {
                 // Fixed IO: TWO cameras per trip.  One evaluation is a dependent chain of ~120 f64 operations and the
                 // SIMD holds two waves, so a single chain leaves the issue slots half empty (r03a_c3_summary.md: 40 %
@@ -351,7 +351,7 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
                 for (int tq = 0; tq < 2 * NT1; ++tq) {
                     const int jj = jh + tq * jstep;
                     uvl[tq] = double2{0, 0};
-                    if (jj < k) uvl[tq] = uvp[q0 + (int64_t)jj * gm];
+                    if (jj < k) uvl[tq] = uvp[q0 + (int64_t)jj * (DBAT_ABLATE(d, 1024) ? 32 : gm)];
                 }
 #pragma unroll
                 for (int tq = 0; tq < NT1; ++tq) {
@@ -506,7 +506,7 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
         lap(2);
         // trace(J'J) only (the first linearisation of levenberg_marquardt.m:76-95 serves lambda0 = c trace / n and
         // nothing else): the squared column norms of the points are out, the Schur complement is not wanted
-        if (d.trace_only) continue;
+        if (d.trace_only || DBAT_ABLATE(d, 64)) continue;      // (64, measurement build: no pass 2 at all)
         // ------------------------------------------------------------ pass 2: lane = observation
         mfma_d4 acc[NBLK];
 #pragma unroll
@@ -564,10 +564,17 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
             // R | y | Q | est of this lane's point, from the lane that holds it
             const int src = on ? i : lane;
             double gR[6], gY[3], gQ[3];
+            if (!DBAT_ABLATE(d, 256)) {              // (256, measurement build: no gathers)
 #pragma unroll
             for (int c = 0; c < 6; ++c) gR[c] = lane_get(pR[c], src);
 #pragma unroll
             for (int c = 0; c < 3; ++c) { gY[c] = lane_get(pY[c], src); gQ[c] = lane_get(pQ[c], src); }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) gR[c] = pR[c];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { gY[c] = pY[c]; gQ[c] = pQ[c]; }
+            }
             unsigned est = 7u;
             if constexpr (IO && !io_simple) est = (unsigned)__builtin_amdgcn_ds_bpermute(4 * src, (int)pEst);
             // fixed IO, and self-calibrating tiles whose IO rows were summed in pass 1: the camera rows of Z need the
@@ -628,7 +635,7 @@ __device__ __forceinline__ void build_sig_tile(const DevProblem &d, const int ti
                 }
                 y3[0] = gY[0]; y3[1] = gY[1]; y3[2] = gY[2];
             }
-            if (lane_on) {                           // lanes of missing points overwrite the previous round with zeros
+            if (lane_on && !DBAT_ABLATE(d, 512)) {   // lanes of missing points overwrite the previous round with zeros  (512, measurement build: no panel writes)
                 double *pr = pan + (6 * j) * LDK + 3 * ir;
 #pragma unroll
                 for (int a = 0; a < 6; ++a) { pr[a * LDK] = Zr[a][0]; pr[a * LDK + 1] = Zr[a][1]; pr[a * LDK + 2] = Zr[a][2]; }
