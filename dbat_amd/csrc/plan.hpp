@@ -1545,12 +1545,14 @@ inline bool build_plan(const dbat_hip_problem &pb, Plan &P, bool with_obs) {
     // interior orientation is fixed and the groups are long enough to fill a wave's lanes
     // every chunk's rows (6k + the IO columns of its tile + the right-hand-side row) fit five 16-row blocks
     const bool sg_can = P.CMAX > 0 && P.nb_tiled > 0 && P.sg_kmax > 0 && P.sg_rows_max <= 80 && P.ncolmax <= 14 && P.BT == 256;
-    // the build kernel pays from about four points per group on, the back-substitution (one lane per
-    // point, one wave per chunk) from about eight (C1 / C2: 6 ... 7 points per group)
+    // the build kernel pays from about four points per group on; so does the back-substitution since round 6 (several
+    // lanes per point of a short chunk; until then from about eight: C1 / C2 have 6 ... 7 points per group)
     P.sg_ok = sg_can && P.sg_npoints >= 4 * P.sg_ngroups;
     // (self-calibration: k_backsub_sig knows the usual eight IO columns only)
     const bool bs_can = sg_can && (P.ncolmax <= 6 || P.all_std8);
-    P.sg_backsub_ok = bs_can && P.sg_npoints >= 8 * P.sg_ngroups;
+    // (round 6: short chunks take several lanes per point.  Self-calibration: from four points per group on -- C2: k_backsub
+    // 0.066 -> k_backsub_sig 0.049 ms; fixed IO: the column-list kernel stays ahead below eight -- C1: 0.009 against 0.012 ms)
+    P.sg_backsub_ok = bs_can && P.sg_npoints >= (P.ncolmax > 6 ? 4 : 8) * P.sg_ngroups;
     if (const char *e = env_get("DBAT_HIP_SIG")) {     // 0 off, 2 whenever possible
         P.sg_ok = atoi(e) == 0 ? false : (atoi(e) >= 2 ? sg_can : P.sg_ok);
         P.sg_backsub_ok = atoi(e) == 0 ? false : (atoi(e) >= 2 ? bs_can : P.sg_backsub_ok);

@@ -866,13 +866,19 @@ __global__ __launch_bounds__(256) void k_backsub_sig(DevProblem d, const double 
             dcs[wv][c][a] = on ? dz[C.col[a]] : 0.0;
         }
         __builtin_amdgcn_wave_barrier();
-        const bool act = lane < npts;
-        const int pt = pt0 + (act ? lane : 0);
+        // A short chunk takes several lanes per point, as pass 1 of k_build_sig does: with G = 32, 16 or 8 point slots (the
+        // smallest that holds the chunk) the lanes l, l + G, ... share the point's cameras and add their sums up afterwards
+        // (round 6: a chunk of C2 / C4 has seven points -- 57 of a wave's 64 lanes did nothing while seven ran ten
+        // evaluations one after the other).
+        const int G = npts > 32 ? 64 : (npts > 16 ? 32 : (npts > 8 ? 16 : 8));
+        const int pi = lane & (G - 1), jh = lane / G, jstep = 64 / G;
+        const bool act = pi < npts;
+        const int pt = pt0 + (act ? pi : 0);
         const int64_t zp = d.NS + 3 * (int64_t)pt;
         const double Q[3] = {z[zp], z[zp + 1], z[zp + 2]};
         const unsigned est = (d.z_est[zp] ? 1u : 0u) | (d.z_est[zp + 1] ? 2u : 0u) | (d.z_est[zp + 2] ? 4u : 0u);
         const double2 *uvp = reinterpret_cast<const double2 *>(sg_uv), *wp = reinterpret_cast<const double2 *>(sg_w);
-        const int64_t q0 = uv0 + gi0 + (act ? lane : 0);
+        const int64_t q0 = uv0 + gi0 + (act ? pi : 0);
         // one sweep over the cameras: with t_j = E_j dc_j (2-vector of observation j),
         //   dp = -V^-1 (g_p + sum_j B_j' t_j)
         //   sum_j |t_j + B_j dp|^2 = sum |t_j|^2 + 2 dp' (sum B_j' t_j) + dp' (sum B_j' B_j) dp
@@ -881,7 +887,7 @@ __global__ __launch_bounds__(256) void k_backsub_sig(DevProblem d, const double 
         // (two copies of the sweep, with the weights of the observations or of the camera: a select between a
         // global and an LDS address inside the loop becomes a flat load)
         auto sweep = [&](auto per_obs_w) {
-        for (int j = 0; j < k; ++j) {
+        for (int j = jh; j < k; j += jstep) {
             const CamRec &C = *reinterpret_cast<const CamRec *>(crec[wv][j]);
             double2 uv = {0, 0};
             if constexpr (NCX > 6) uv = uvp[q0 + (int64_t)j * gm];        // (fixed IO: E and B do not depend on the image point)
@@ -913,12 +919,19 @@ __global__ __launch_bounds__(256) void k_backsub_sig(DevProblem d, const double 
         }
         };
         if (sg_w) sweep(std::true_type{}); else sweep(std::false_type{});
+        for (int m = G; m < 64; m <<= 1) {           // the other lanes of the point (uniform loop: butterfly over the slices)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) sB[c] += lane_get(sB[c], lane ^ m);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) V0[c] += lane_get(V0[c], lane ^ m);
+            tt2 += lane_get(tt2, lane ^ m);
+        }
         {
             const double s0 = gp[3 * (int64_t)pt] + sB[0], s1 = gp[3 * (int64_t)pt + 1] + sB[1], s2 = gp[3 * (int64_t)pt + 2] + sB[2];
             double p0, p1, p2;
             point_block_solve_neg(Vinv + 6 * (int64_t)pt, s0, s1, s2, p0, p1, p2);
             const double d0 = (est & 1u) ? p0 : 0.0, d1 = (est & 2u) ? p1 : 0.0, d2 = (est & 4u) ? p2 : 0.0;
-            if (act) {
+            if (act && lane == pi) {                 // one lane per point writes and counts
                 dz[zp] = d0; dz[zp + 1] = d1; dz[zp + 2] = d2;
                 acc[0] = tt2 + 2.0 * (d0 * sB[0] + d1 * sB[1] + d2 * sB[2])
                        + d0 * (V0[0] * d0 + V0[1] * d1 + V0[2] * d2) + d1 * (V0[1] * d0 + V0[3] * d1 + V0[4] * d2)
