@@ -1062,6 +1062,57 @@ def test_bundle_reuses_the_cached_handle(hip, capsys):
     hip.clear_cache()
 
 
+@pytest.mark.parametrize('selfcal', [False, True])
+def test_heavy_points_with_priors_weights_and_fixed_coordinates(hip, selfcal):
+    """The matrix-core path of the heavy points (csrc/heavy.hpp) with everything a project can hang on a point: image
+    observations with their own standard deviations (no per-camera weight), prior observations of object points and of
+    camera positions, fixed control points (rows and columns masked), a camera with fixed elements -- every point in
+    every one of 24 images.  Step, gradient, column norms, the bundle and the posterior covariance blocks against the oracle."""
+    from dbat_amd import bundle, bundle_cov
+    s, truth = _all_see_all_scene(24, 120, selfcal)
+    nc, npnt = s.EO.val.shape[1], s.OP.val.shape[1]
+    rng = np.random.default_rng(21)
+    s.IP.std = np.asfortranarray(s.IP.std * (1 + (np.arange(s.IP.std.shape[1]) % 3)[None, :] * 0.5))
+    s.IP.sigmas = np.unique(s.IP.std)
+    cps = np.arange(0, npnt, 17)
+    s.prior.OP.use[:, cps] = True
+    s.prior.OP.val[:, cps] = truth['OP'][:, cps] + rng.normal(0, 0.01, (3, len(cps)))
+    s.prior.OP.std[:, cps] = np.array([[0.01], [0.01], [0.02]])
+    fixed = np.arange(5, npnt, 23)
+    s.OP.val[:, fixed] = truth['OP'][:, fixed]
+    s.bundle.est.OP[:, fixed] = False
+    s.bundle.est.OP[2, 9] = False                                   # one coordinate of a point
+    cams = np.arange(1, nc, 5)
+    s.prior.EO.use[0:3, cams] = True
+    s.prior.EO.val[0:3, cams] = truth['EO'][0:3, cams] + rng.normal(0, 0.02, (3, len(cams)))
+    s.prior.EO.std[0:3, cams] = 0.02
+    so, x0, w = oracle_setup(s)
+    R = np.sqrt(w)
+    r_o, K = o.brown_euler_cam4(x0, so, jac=True)
+    J = (sp.diags(R) @ K).tocsc()
+    p_o, *_ = o._scaled_gn(J, R * r_o)
+    h = hip.Handle(s)
+    try:
+        info = h.info()
+        assert info['heavy_points'] == npnt and info['n_tiles'] == 0
+        p_h, st = h.linearize_solve(x0, 0.0, True)
+        assert not st['singular'] and relerr(p_h, p_o) < TOL_STEP
+        assert abs(st['f'] - 0.5 * (R * r_o) @ (R * r_o)) <= 1e-11 * st['f']
+        assert relerr(h.gradient(), J.T @ (R * r_o)) < 1e-10
+        assert relerr(h.colnorms(), np.sqrt(np.asarray(J.multiply(J).sum(0)).ravel())) < 1e-10
+        h.set_deterministic(True)
+        pd = [h.linearize_solve(x0, 0.0, True)[0] for _ in range(3)]
+        assert all(np.array_equal(pd[0], q) for q in pd[1:]) and relerr(pd[0], p_h) < 1e-8
+    finally:
+        h.close()
+    res, ok, iters, s0, E = bundle(s, 'gna')
+    ro, oko, ito, s0o, Eo = o.bundle(s, 'gna')
+    assert ok and oko and iters == ito and relerr(E.x, Eo.x) < TOL_X and abs(s0 - s0o) < 1e-8 * s0o
+    CEO, COP = bundle_cov(res, E, 'CEO', 'COP')
+    CEOo, COPo = o.bundle_cov(ro, Eo, 'CEO', 'COP')
+    assert abs(CEO - CEOo).max() <= 1e-6 * abs(CEOo).max() and abs(COP - COPo).max() <= 1e-6 * abs(COPo).max()
+
+
 @pytest.mark.parametrize('model', [3, 5])
 def test_posterior_covariance_camcal_known_answer(hip, model):
     """bundle_cov on the GPU (inv(S) and the per-point blocks from the Schur
