@@ -40,6 +40,9 @@ if len(pf) == len(ch) and used.any() and (pf[:, 3 + 6] > 0).any():
     dd = np.diff(seq, axis=1)[used]
     print('inside df_potf2 (median us): ' + '  '.join('%s %.2f' % (n, v) for n, v in zip(
         ['panel0', 'trail0', 'panel1', 'trail1', 'panel2', 'trail2', 'panel3', 'exit'], np.median(dd, axis=0))))
+    el = (P[:, 13] - P[:, 5])[used & (P[:, 13] > 0)]
+    if len(el):
+        print('   panel 1: loads of the rows done -> elimination done (median us): %.2f' % np.median(el))
 if len(sys.argv) > 2:
     for i in order:
         if T[i, 3] > 0:
