@@ -70,11 +70,6 @@ struct DfTask { int i, k; };
 // ranks before the top separators are factored (phase B, every rank).  | 8: no identity on the padding rows
 // (they are contributed by rank 0 only).
 struct DfJob { int i, k, jlo, jhi, part, np, mode, p; };
-// One product of a task's sum, T -= L(i,j) L(k,j)': where the two tiles lie (doubles from DfView::base) and their flags.
-// The lists are a table of the plan (the pattern is fixed): a task copies its own into LDS and the pipelined sum reads
-// offsets and flag numbers from there -- nothing in its loop is a vector load that would drain the tiles in flight.
-struct DfProd { int64_t ok, oi; int fk, fi; };
-constexpr int DF_MAXP = 128;                            // products per task at most (build_jobs cuts longer sums into helpers)
 
 // Tiles that one workgroup writes and others read inside the same launch move
 // with agent-scope relaxed atomics (sc1 loads/stores that bypass the per-XCD
@@ -106,22 +101,6 @@ __device__ __forceinline__ df_d2 ld_l2_16(const double *p) {
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
     return v;
 }
-// 16-byte agent-scope loads the COMPILER counts (buffer_load_dwordx4 ... sc1): with two tile pairs in flight the waits
-// must be partial (s_waitcnt vmcnt(16): the older pair has arrived, the younger may still travel), and registers that
-// in-flight loads write live across barriers and loop edges -- the compiler's bookkeeping does both, inline asm neither.
-// One descriptor per tile (uniform base: two v_readfirstlane), the lane's place in the tile as the offset; a
-// descriptor of zero records answers every load with zeros and fetches nothing (measurement build: DBAT_HIP_DF_ABLATE).
-typedef int df_i4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t df_tile_rsrc(const double *p, bool fetch) {
-    const unsigned long long v = (unsigned long long)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, fetch ? 0x7fffffff : 0, 0x00020000);
-}
-__device__ __forceinline__ df_d2 df_bload16(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    return __builtin_bit_cast(df_d2, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 16 /* sc1 */));
-}
-struct DfPair { df_d2 p[8], q[8]; };                    // one product's two tiles on their way: thread (tx, ty) holds the row pair
-                                                        // 2 (tx & 31) of the columns 2 (ty + 4 q) + (tx >> 5) of both
 __device__ __forceinline__ double ld_tile(const double *p, bool l2) {
     return l2 ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
               : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -478,8 +457,6 @@ struct DfView {
     int64_t ldS;                //   (natural order, lower triangle, right-hand side in row n_nat) instead of a gather launch
     int n_nat;
     int no_l2;                  // 1: tiles with agent-scope loads everywhere (0 would read finished tiles through the L2: no gain measured)
-    const int *prod_ptr;        // [ntasks + 1] the products of task t: prod[prod_ptr[t] .. prod_ptr[t+1])
-    const DfProd *prod;
 };
 
 // Backward substitution task of panel j:  q_j = Linv_j' (y_j - sum_{i>j} L(i,j)' q_i).
@@ -811,12 +788,8 @@ __device__ __forceinline__ bool df_chain_role(double *smem, const DfView &V, int
 // CHAIN (compact tiles): the diagonal tiles are factored by the workgroups of the chain role (df_chain_role); the task
 // list holds no diagonal task, the sums of the diagonal tiles are DfJob mode 16.  !CHAIN: everything is a task (the
 // in-place layout, DBAT_HIP_DF_CHAIN=0).
-#ifndef DBAT_DF_OCC2
-#define DBAT_DF_OCC2 0
-#endif
-#define DBAT_DF_WAVES(chain) ((DBAT_DF_OCC2 && !(chain)) ? 2 : 1)
 template <bool CHAIN>
-__global__ __launch_bounds__(256, DBAT_DF_WAVES(CHAIN)) void k_chol_df(DfView V, int n, int nT, const DfJob *__restrict__ tasks,
+__global__ __launch_bounds__(256) void k_chol_df(DfView V, int n, int nT, const DfJob *__restrict__ tasks,
                                                  int ntasks, int *__restrict__ flags, int *__restrict__ ctl, int epoch,
                                                  double *__restrict__ linv_all, int *__restrict__ info,
                                                  long long *__restrict__ trace, const int *__restrict__ bk_ptr,
@@ -829,7 +802,6 @@ __global__ __launch_bounds__(256, DBAT_DF_WAVES(CHAIN)) void k_chol_df(DfView V,
     __shared__ double smem[(CHAIN ? 3 : 2) * NB * LD];  // Pm | Qm, or the augmented block of df_potf2 (chain role: and the link)
     double *Pm = smem, *Qm = smem + NB * LD;
     __shared__ int s_word[8];                           // task / ok, and three words of the chain role
-    __shared__ DfProd s_prod[DF_MAXP];                  // the products of the task at hand (pipelined sum)
     int &s_task = s_word[0], &s_ok = s_word[1];
     const int t = threadIdx.x, tx = t & 63, ty = t >> 6;
     int *counter = ctl + ctr_slot, *abort_flag = ctl + 1;     // (slot 0, or 2 for the second launch of a solve)
@@ -919,104 +891,85 @@ __global__ __launch_bounds__(256, DBAT_DF_WAVES(CHAIN)) void k_chol_df(DfView V,
         };
         // whole tiles (in the compact storage the right-hand-side row is a whole tile too, zero below its row)
         if (nc == NB && (nr == NB || i == k || (V.iperm && i == nT)) && !(V.ld & 1)) {
-            // Software pipeline, TWO products deep (round 6; round 5 kept one pair in flight, requested one MFMA pass
-            // = 2.4 us ahead of its use where a pair needs 3.7 us to arrive: 1.3 us of every product was waiting).
-            // While the matrix cores work on product n, the tiles of n+1 AND n+2 are on their way into two register
-            // sets; a set is requested right after its previous content went to LDS.  The tiles of n+2 are requested
-            // only if thread 0 found their flags up -- one non-blocking look, issued a round earlier BEFORE the
-            // request of n+1 (loads return in order: the answer is there when the tiles of n have arrived).  Flags
-            // down: the run ends -- the two products in flight are finished, the workgroup spins on the next product
-            // and starts a new run from there.  The offsets and flag numbers come from the task's product list
-            // in LDS (DfProd), the loads are buffer loads the compiler counts (df_bload16).
-            const int p0 = V.prod_ptr[task], np_ = V.prod_ptr[task + 1] - p0;
-            for (int e = t; e < np_ && e < DF_MAXP; e += 256) s_prod[e] = V.prod[p0 + e];
+            // Software pipeline: while the matrix cores work on product n, the tiles of product n+1 are
+            // on their way into registers -- if its flags were up when thread 0 looked (one non-blocking
+            // look, issued before the wait for the tiles of product n, so its latency hides there).
+            // Otherwise the workgroup finishes product n first and then waits.  2.0 instead of 3.7 us per
+            // product for a task whose inputs exist (the long sums of the dense IO / right-hand-side rows).
+            df_d2 rp[8], rq[8];
 #ifdef DBAT_HIP_PROFILING
             const bool abl_f = (V.no_l2 & 6) == 6;                               // 3: ... and no look at the next product's flags either
             const bool abl_q = (V.no_l2 & 6) != 0, abl_p = (V.no_l2 & 4) != 0;   // DBAT_HIP_DF_ABLATE: operand tiles not fetched (timing only)
+            if (abl_q) for (int q = 0; q < 8; ++q) { rq[q].x = 1e-3 * tx; rq[q].y = 1e-3 * ty; }
+            if (abl_p) for (int q = 0; q < 8; ++q) { rp[q].x = 1e-3 * tx; rp[q].y = 1e-3 * ty; }
 #else
             constexpr bool abl_q = false, abl_p = false, abl_f = false;
 #endif
-            const int vo0 = (int)(((int64_t)(2 * ty + (tx >> 5)) * V.ld + 2 * (tx & 31)) * 8);   // this thread's first pair in a tile (bytes)
-            const int vstep = (int)(V.ld * 64);                                  // eight columns on
-            // One loop, no prologue (a separate first request of a set costs phi copies of registers that loads are still
-            // writing, each with its wait): every half step sends what its set holds to LDS (if it holds a product),
-            // decides whether the next product's tiles may be requested (flags seen up by the look of the step before;
-            // with nothing in flight and nothing to multiply thread 0 spins), requests them into the set just freed --
-            // or "requests" through a descriptor of zero records (no fetch; the number of loads in flight stays what the
-            // compiler counted) -- and multiplies what it sent.
-            DfPair SA, SB;
-            int tagA = -1, tagB = -1, nx = 0;           // the product a set holds (-1: none); the next product to request
-            int f1 = epoch - 1, f2 = epoch - 1;         // thread 0: the flags of product nx as the last look saw them
-            auto look = [&](int e) {                    // thread 0, non-blocking; beyond the list: "down"
-                if (t == 0) {
-                    f1 = f2 = epoch - 1;
-                    if (e < np_) {
-                        f1 = f2 = epoch;
-                        if (!abl_f) {
-                            f1 = __hip_atomic_load(flags + s_prod[e].fk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            f2 = __hip_atomic_load(flags + s_prod[e].fi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                    }
+            // jc: the product whose tiles are on their way; jn: the one after it.  Thread 0 looks at jn's flags ONE
+            // PRODUCT AHEAD -- the look is issued before the MFMA pass of the product before jc and read after jc's tiles
+            // have arrived, so its latency (an agent-scope load: 1.5 us) hides under that pass.  Round 4 looked at the top
+            // of jc's own round and paid the latency in every product (C4: 10 % of the factorisation).  A look that found
+            // the flags down is repeated at the top of the round (fresh), as before.
+            int jc = next_j(), jn = -1;
+            int f1 = 0, f2 = 0;
+            auto look = [&](int j) {
+                f1 = f2 = epoch;
+                if (t == 0 && j >= 0 && !abl_f) {
+                    f1 = __hip_atomic_load(flags + (int64_t)k * nT + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (i != k) f2 = __hip_atomic_load(flags + (int64_t)i * nT + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             };
-            auto issue = [&](int e, DfPair &S, bool fetch) {
-                const __amdgpu_buffer_rsrc_t rk = df_tile_rsrc(V.base + s_prod[e].ok, fetch && !abl_p), ri = df_tile_rsrc(V.base + s_prod[e].oi, fetch && !abl_q);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) S.p[q] = df_bload16(rk, vo0, q * vstep);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) S.q[q] = df_bload16(ri, vo0, q * vstep);
+            // The tile offsets are a table in memory (V.toff) and the compiler reads it with VECTOR loads followed by
+            // s_waitcnt vmcnt(0) -- placed between the requests of L(k,j) and L(i,j) that wait also drained the first tile
+            // before the second was even requested, in every product (found in the ISA in round 5: 5.2 us per product
+            // where the MFMA pass takes 2.4).  The offsets of a product are read ONE ROUND BEFORE its tiles are requested,
+            // where nothing is in flight behind them.
+            int64_t ok_n = 0, oi_n = 0;              // offsets of jn's tiles
+            auto offsets = [&](int j, int64_t &ok_, int64_t &oi_) {
+                ok_ = j >= 0 ? V.toff[(int64_t)k * nT + j] : 0;
+                oi_ = j >= 0 && i != k ? V.toff[(int64_t)i * nT + j] : 0;
             };
-            auto commit = [&](const DfPair &S) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int o = (2 * (ty + 4 * q) + (tx >> 5)) * LD + 2 * (tx & 31);
-                    Pm[o] = S.p[q].x; Pm[o + 1] = S.p[q].y;
-                    Qm[o] = S.q[q].x; Qm[o + 1] = S.q[q].y;
-                }
+            auto issue = [&](int64_t ok_, int64_t oi_) {
+                if (!abl_p) df_tile16_issue(V.base + ok_, V.ld, rp, tx, ty, l2);
+                if (i != k && !abl_q) df_tile16_issue(V.base + oi_, V.ld, rq, tx, ty, l2);
             };
-            auto half = [&](DfPair &X, int &tagX, const int &tagY) {
-                __syncthreads();                        // the previous MFMA pass has read Pm/Qm; s_ok has been read
-                const int cX = tagX;
-                if (cX >= 0) commit(X);
-                if (t == 0) {
-                    int go = 0;
-                    if (alive && nx < np_) {
-                        go = f1 == epoch && f2 == epoch;
-                        if (!go && cX < 0 && tagY < 0)   // nothing on its way, nothing to multiply: wait for the product
-                            go = df_spin(flags + s_prod[nx].fk, epoch, abort_flag) && df_spin(flags + s_prod[nx].fi, epoch, abort_flag) ? 1 : -1;
-                    }
-                    s_ok = go;
-                }
+            if (jc >= 0) {
+                int64_t ok_c, oi_c;
+                offsets(jc, ok_c, oi_c);
+                jn = next_j();
+                offsets(jn, ok_n, oi_n);
+                if (t == 0) s_ok = spin_both(jc);
                 __syncthreads();
-                int go = s_ok;
-                if (go < 0) { alive = false; go = 0; }  // abort: the steps that follow request and multiply nothing
-                const int ei = min(nx, np_ - 1);
-                tagX = go ? nx : -1;
-                nx += go;
-                look(nx);
-                issue(ei, X, go != 0);
-                if (cX >= 0) mfma_tile64<LD>(Pm, Qm, ty, tx, acc);
-            };
-            __syncthreads();                            // the list is in LDS
-            // (Nothing may be in flight when the loop is entered as far as the compiler's wait-count bookkeeping can see:
-            // a store possibly pending on one way into the loop -- a trace clock, say -- makes the counter "out of order"
-            // for the whole loop, and every wait in it a full one.)
-            __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0)
-            if (np_ > 0) {
-                // The loop is entered with the same loads "in flight" -- in the same order -- as its back edge carries
-                // (requests of zero records: nothing is fetched), and it has ONE exit, behind the second half step: the
-                // compiler's wait counts are computed over all ways through the code, feasible or not, register by
-                // register towards the most recent request.  A look or a set that is the LAST thing requested on some
-                // way to the loop's top -- the way in, or an exit test after the first half step that shares its block
-                // with the back edge -- turns the partial waits of every round into full ones.
-                issue(0, SA, false);
-                look(0);
-                issue(0, SB, false);
-                for (;;) {
-                    half(SA, tagA, tagB);
-                    half(SB, tagB, tagA);
-                    if (!alive || (nx == np_ && tagA < 0 && tagB < 0)) break;
+                if (!s_ok) alive = false;
+                else {
+                    issue(ok_c, oi_c);
+                    look(jn);
                 }
+            }
+            while (alive && jc >= 0) {
+                // (the row words next_j reads and the offsets are vector loads: taken here, where nothing is in flight
+                // behind them)
+                const int jnn = jn >= 0 ? next_j() : -1;
+                int64_t ok_nn, oi_nn;
+                offsets(jnn, ok_nn, oi_nn);
+                if (t == 0 && jn >= 0 && (f1 != epoch || f2 != epoch)) look(jn);      // down a product ago: look again
+                __syncthreads();                        // the previous MFMA pass has read Pm/Qm
+                df_tile16_commit<LD>(rp, Pm, tx, ty);
+                if (i != k) df_tile16_commit<LD>(rq, Qm, tx, ty);
+                if (t == 0) s_ok = jn >= 0 && f1 == epoch && f2 == epoch;
+                __syncthreads();
+                const bool early = s_ok;
+                if (early) { issue(ok_n, oi_n); look(jnn); }     // (the look's answer is read after the next round's tiles have arrived)
+                mfma_tile64<LD>(Pm, i == k ? Pm : Qm, ty, tx, acc);
+                if (jn >= 0 && !early) {
+                    __syncthreads();                    // s_ok has been read by everybody
+                    if (t == 0) s_ok = spin_both(jn);
+                    __syncthreads();
+                    if (!s_ok) { alive = false; break; }
+                    issue(ok_n, oi_n);
+                    look(jnn);
+                }
+                jc = jn; jn = jnn; ok_n = ok_nn; oi_n = oi_nn;
             }
         } else {
             for (int j = next_j(); j >= 0; j = next_j()) {
@@ -1331,8 +1284,6 @@ struct DataflowChol {
     int64_t *d_toff = nullptr;
     uint64_t *d_rowbits = nullptr;
     DfJob *d_tasks = nullptr, *d_tasksB = nullptr;      // task list (one rank: everything; several: this rank's domain) / the top separators
-    int *d_prod_ptr = nullptr, *d_prod_ptrB = nullptr;  // per task list: the products of every task (DfProd; see k_chol_df's pipelined sum)
-    DfProd *d_prod = nullptr, *d_prodB = nullptr;
     int ntasksB = 0, nbk = 0;
     int *d_bk_list = nullptr;                           // panels of the backward substitution in task order
     uint64_t *d_rowbits_top = nullptr;                  // rowbits restricted to the top columns (second launch)
@@ -1367,14 +1318,13 @@ struct DataflowChol {
     void release() {
         void *ps[] = {d_flags, d_ctl, d_bk_ptr, d_bk_idx, d_iperm, d_toff, d_rowbits, d_tasks, d_tile_ij, d_tiles, d_qperm, d_parts,
                       d_tasksB, d_bk_list, d_rowbits_top, d_chain_cols, d_chain_colsB, d_chain_par, d_chain_bits, d_chain_bitsB, d_chain_pos,
-                      d_ztiles, d_si_m, d_si_off, d_si_diag, d_perm, d_prod_ptr, d_prod_ptrB, d_prod, d_prodB};
+                      d_ztiles, d_si_m, d_si_off, d_si_diag, d_perm};
         for (void *p : ps) if (p) (void)hipFree(p);
         d_flags = d_ctl = d_bk_ptr = d_bk_idx = d_iperm = nullptr; d_toff = nullptr; d_rowbits = nullptr;
         d_tasks = nullptr; d_tile_ij = nullptr; d_tiles = d_qperm = d_parts = nullptr;
         d_tasksB = nullptr; d_bk_list = nullptr; d_rowbits_top = nullptr;
         d_chain_cols = d_chain_colsB = d_chain_par = d_chain_bits = d_chain_bitsB = d_chain_pos = nullptr;
         d_ztiles = nullptr; d_si_m = d_si_off = nullptr; d_si_diag = d_perm = nullptr; n_si_m = 0;
-        d_prod_ptr = d_prod_ptrB = nullptr; d_prod = d_prodB = nullptr;
         si_off_ptr.clear(); si_diag_ptr.clear();
     }
     // per-task timestamps of the last solve (100 MHz ticks): task, i, k, t[0..15], jlo, jhi, mode per line
@@ -1419,8 +1369,8 @@ struct DataflowChol {
     struct JobList { std::vector<DfJob> jobs; std::vector<int> dptr, dep, own, sumjob, presum, bits, par; };
     void build_jobs(int phase, const std::vector<uint64_t> &rowbits, const std::vector<int> &col_owner, int rank, JobList &L) {
         auto has = [&](int i, int k) { return (rowbits[(size_t)i * W + (k >> 6)] >> (k & 63)) & 1ull; };
-        const int split_min = std::min(std::max(env_int("DBAT_HIP_DF_SPLIT", 96), 2), DF_MAXP);       // (a task's product list lives in LDS)
-        const int chunk = std::min(std::max(env_int("DBAT_HIP_DF_CHUNK", 32), 1), DF_MAXP);
+        const int split_min = std::max(env_int("DBAT_HIP_DF_SPLIT", 96), 2);
+        const int chunk = std::max(env_int("DBAT_HIP_DF_CHUNK", 32), 1);
         const bool merge = permuted;                            // compact tiles only (see k_chol_df)
         auto top = [&](int k) { return phase != 0 && col_owner[k] < 0; };
         auto mine = [&](int k) { return phase == 0 || col_owner[k] == rank; };
@@ -1535,7 +1485,7 @@ struct DataflowChol {
         }
         // The kernel as a list schedule: `workers` resident workgroups take the tasks in order; a
         // workgroup consumes its inputs in its fixed order, every product after both tiles exist.
-        const int workers = std::max(1, std::min(grid, DBAT_DF_OCC2 ? 512 : 256));      // 400 registers per lane: one workgroup per CU
+        const int workers = std::max(1, std::min(grid, 256));      // 400 registers per lane: one workgroup per CU
         auto simulate = [&](const std::vector<int> &ord) {
             std::vector<double> done(nt, 0.0);
             std::priority_queue<double, std::vector<double>, std::greater<double>> freeat;
@@ -1616,29 +1566,6 @@ struct DataflowChol {
         std::vector<DfJob> sorted(nt);
         for (int t = 0; t < nt; ++t) sorted[t] = jobs[best_ord[t]];
         jobs.swap(sorted);
-    }
-    // The products of every task of a list, in the order the kernel multiplies them: the columns j in [jlo, jhi) whose
-    // tiles exist in both tile rows (rb: the row bitsets the list was built from) -- offsets and flag numbers (DfProd).
-    bool upload_products(const std::vector<DfJob> &jobs, const std::vector<uint64_t> &rb, const std::vector<int64_t> &toff,
-                         int *&d_ptr, DfProd *&d_pr) {
-        std::vector<int> ptr(jobs.size() + 1, 0);
-        std::vector<DfProd> pr;
-        for (size_t t = 0; t < jobs.size(); ++t) {
-            const DfJob &jb = jobs[t];
-            for (int j = jb.jlo; j < jb.jhi; ++j) {
-                if (!((rb[(size_t)jb.i * W + (j >> 6)] & rb[(size_t)jb.k * W + (j >> 6)]) >> (j & 63) & 1ull)) continue;
-                DfProd q;
-                q.ok = toff[(size_t)jb.k * nT + j]; q.oi = toff[(size_t)jb.i * nT + j];
-                q.fk = jb.k * nT + j; q.fi = jb.i * nT + j;
-                pr.push_back(q);
-            }
-            ptr[t + 1] = (int)pr.size();
-            if (ptr[t + 1] - ptr[t] > DF_MAXP) {
-                fprintf(stderr, "[chol] task %zu has %d products (at most %d)\n", t, ptr[t + 1] - ptr[t], DF_MAXP);
-                return false;
-            }
-        }
-        return up(d_ptr, ptr) && up(d_pr, pr);
     }
     // common part: nz[i] = bitset of columns k <= i with a structurally non-zero tile (i, k), i = 0..nT
     // (row nT = right-hand side, all columns), fill included.  col_owner (empty: one rank): see build_jobs.
@@ -1724,7 +1651,6 @@ struct DataflowChol {
                 for (int k = 0; k < nT; ++k)
                     if (col_owner[k] >= 0) rowbits_top[(size_t)i * W + (k >> 6)] &= ~(1ull << (k & 63));
             if (!up(d_rowbits_top, rowbits_top)) return false;
-            if (!upload_products(h_tasksB, rowbits_top, toff, d_prod_ptrB, d_prodB)) return false;
         }
         nbk = (int)bkl.size();
         if (use_chain) {
@@ -1748,7 +1674,6 @@ struct DataflowChol {
                 if (has(i, j)) bidx.push_back(i);
             bptr[j + 1] = (int)bidx.size();
         }
-        if (!upload_products(h_tasks, rowbits, toff, d_prod_ptr, d_prod)) return false;
         if (!up(d_tasks, h_tasks) || !up(d_bk_ptr, bptr) || !up(d_bk_idx, bidx) || !up(d_rowbits, rowbits) || !up(d_toff, toff) || !up(d_bk_list, bkl))
             return false;
         if (hipMalloc(&d_flags, ((size_t)(nT + 1) * nT + (size_t)nparts + 4 * (size_t)nT) * sizeof(int)) != hipSuccess) return false;   // tiles, helper slots, T of the sum-only tasks, T' of the diagonal tiles, claims
@@ -1953,7 +1878,6 @@ struct DataflowChol {
         ++epoch;
         DfView V;
         V.toff = d_toff; V.rowbits = d_rowbits; V.W = W; V.no_l2 = (env_l2 ? 0 : 1) | env_df_ablate;     // measured: no gain from the L2 path
-        V.prod_ptr = d_prod_ptr; V.prod = d_prod;
         double *qflag;
         V.S = nullptr; V.ldS = lda; V.n_nat = n_nat;
         if (permuted) {
@@ -2006,7 +1930,6 @@ struct DataflowChol {
         DfView V;
         V.toff = d_toff; V.rowbits = d_rowbits; V.W = W; V.no_l2 = (env_l2 ? 0 : 1) | env_df_ablate;
         V.ldS = lda; V.n_nat = n_nat; V.base = d_tiles; V.ld = 64; V.iperm = d_iperm; V.S = A;
-        V.prod_ptr = d_prod_ptr; V.prod = d_prod;
         hipLaunchKernelGGL(k_df_reset, dim3((nT * CHOL_NB + 255) / 256), dim3(256), 0, stream, info_dev, d_ctl,
                            reinterpret_cast<unsigned long long *>(d_qperm), nT * CHOL_NB);
         if (ntasks > 0 && use_chain)
@@ -2022,7 +1945,6 @@ struct DataflowChol {
                    const double *qscale, double *dz_out) {
         DfView V;
         V.toff = d_toff; V.rowbits = d_rowbits_top; V.W = W; V.no_l2 = 1;
-        V.prod_ptr = d_prod_ptrB; V.prod = d_prodB;
         V.ldS = lda; V.n_nat = n_nat; V.base = d_tiles; V.ld = 64; V.iperm = d_iperm; V.S = nullptr;   // the tiles hold the summed shares
         if (use_chain)
             hipLaunchKernelGGL(k_chol_df<true>, dim3(chain_grid(ntasksB + nbk, chain_wgB)), dim3(256), 0, stream, V, n, nT, d_tasksB, ntasksB,
