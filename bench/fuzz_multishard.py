@@ -89,10 +89,15 @@ def main():
         bad = False
         e = [0.0, 0.0, 0.0]
         for p, st, q, stq, xs, code, iters, s0 in out:
-            e[0] = max(e[0], relerr(p, p1)); e[1] = max(e[1], relerr(q, q1)); e[2] = max(e[2], relerr(xs, xs1))
+            ep, eq = relerr(p, p1), relerr(q, q1)
+            e[0] = max(e[0], ep); e[1] = max(e[1], eq); e[2] = max(e[2], relerr(xs, xs1))
             for k in ('f', 'JpJp', 'rJp', 'pp', 'trace'):
                 if res1.code == -4 and k != 'f': continue       # structurally singular (sprank(J) < n): the solve refuses, the steps mean nothing
-                if not abs(st[k] - st1[k]) <= 1e-8 * abs(st1[k]) or not abs(stq[k] - st2[k]) <= 1e-8 * abs(st2[k]): bad = True
+                # the scalars of a step are quadratic in it: on a weak network (an undamped step that the two summation
+                # orders move by 1e-7) they follow the step, not the 1e-8 of a well-conditioned one
+                tp = 1e-8 if k in ('f', 'trace') else max(1e-8, 4 * ep)
+                tq = 1e-8 if k in ('f', 'trace') else max(1e-8, 4 * eq)
+                if not abs(st[k] - st1[k]) <= tp * abs(st1[k]) or not abs(stq[k] - st2[k]) <= tq * abs(st2[k]): bad = True
             if code != res1.code or (st['singular'] != st1['singular']): bad = True
             if code == 0 and abs(s0 - res1.sigma0) > 1e-7 * res1.sigma0: bad = True
         line += ' GN %.1e LM %.1e solve %.1e (code %d, %d/%d its)' % (e[0], e[1], e[2], out[0][5], out[0][6], res1.iters)
