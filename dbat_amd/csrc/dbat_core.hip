@@ -625,6 +625,43 @@ struct Core {
         sync();
     }
 
+    // ---- The parameter trace of a damping loop (bundle.m's T: x of every iteration), kept ON THE DEVICE while the loop
+    // runs -- one gather kernel per column, no copy and no wait -- and brought down once at the end.  (Round 5 fetched
+    // every column when it was made: a 24 MB copy into pageable memory and a synchronisation per iteration at C3, then a
+    // second copy into the caller's array.)  Columns a loop never wrote come back as NaN.
+    DevBuf<double> trace_dev;
+    int trace_cap = 0, trace_n = 0;
+    std::vector<uint8_t> trace_have;
+    void trace_begin() { trace_n = 0; trace_have.clear(); }
+    void trace_put(int k, const double *z_dev) {       // column k <- x(z_dev); collective on a sharded handle
+        if (!P.n || k < 0) return;
+        if (k >= trace_cap) {
+            const int cap = std::max(8, std::max(2 * trace_cap, k + 1));
+            DevBuf<double> nb;
+            nb.alloc((size_t)P.n * cap);
+            if (trace_cap > 0) HIPCHK(hipMemcpyAsync(nb.p, trace_dev.p, (size_t)P.n * trace_cap * 8, hipMemcpyDeviceToDevice, stream));
+            HIPCHK(hipStreamSynchronize(stream));      // (the old buffer is freed with the swap)
+            std::swap(trace_dev.p, nb.p);
+            trace_cap = cap;
+        }
+        stage(4);
+        z_dev = gathered(z_dev);
+        LAUNCHK(k_gather_x, dim3((unsigned)cdiv(P.n, 256)), dim3(256), 0, stream, P.n, x2z.p, z_dev, trace_dev.p + (size_t)P.n * k);
+        if ((int)trace_have.size() <= k) trace_have.resize((size_t)k + 1, 0);
+        trace_have[k] = 1;
+        trace_n = std::max(trace_n, k + 1);
+    }
+    void trace_truncate(int n) { trace_n = std::min(trace_n, std::max(n, 0)); }
+    int trace_download(double *host, int cap_cols) {    // -> number of columns
+        const int nt = std::min(trace_n, cap_cols);
+        if (!P.n || nt <= 0) return std::max(nt, 0);
+        HIPCHK(hipMemcpyAsync(host, trace_dev.p, (size_t)P.n * nt * 8, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        for (int k = 0; k < nt; ++k)
+            if (!trace_have[k]) std::fill(host + (size_t)P.n * k, host + (size_t)P.n * (k + 1), NAN);
+        return nt;
+    }
+
     // ---- K2: f = 0.5 r'r at zz (all ranks' sum).  Optionally store r.
     // f at x + alpha p (x, p as given; the point goes to out): the trial point and its camera records in one launch
     double eval_f_step(const double *x, double alpha, const double *pdir, double *out) {
@@ -1202,7 +1239,6 @@ struct Core {
 
 struct LoopOut {
     std::vector<double> res, damp, aux;
-    std::vector<std::vector<double>> trace;
     int code = 0, iters = 0;
     double f_final = 0;
 };
@@ -1241,11 +1277,9 @@ static inline void trace_line(const dbat_hip_options &o, int n, double res, doub
     if (o.trace_fun) o.trace_fun(o.trace_user, o.damping, n, res, damp, step, rho);
 }
 
-static void push_trace(Core &c, const dbat_hip_options &o, LoopOut &out) {
+static void push_trace(Core &c, const dbat_hip_options &o, LoopOut &) {
     if (!o.store_trace) return;
-    std::vector<double> x(c.P.n);
-    c.z_to_x(c.z.p, x.data());
-    out.trace.push_back(std::move(x));
+    c.trace_put(c.trace_n, c.z.p);
 }
 
 // Objective values: every f = 0.5*r'r the loops compare comes from the same
@@ -1338,7 +1372,6 @@ static void loop_lm(Core &c, const dbat_hip_options &o, LoopOut &out) {
     out.damp.push_back(lambda);
     double prevLambda = NAN;
     double JpJp = 0, rJp = 0, pp = 0;
-    std::vector<std::vector<double>> T;
     std::vector<double> Jp_host;
     while (true) {
         while (n <= o.max_iter) {
@@ -1350,7 +1383,7 @@ static void loop_lm(Core &c, const dbat_hip_options &o, LoopOut &out) {
             if (failed) { out.code = -2; break; }   // the reference has no test here; MATLAB would continue on Inf/NaN
             out.damp.push_back(lambda);
             trace_line(o, n, out.res.back(), n == 0 ? NAN : lambda);              // :138-147
-            if (o.store_trace) { std::vector<double> x(c.P.n); c.z_to_x(c.z.p, x.data()); if ((int)T.size() <= n) T.resize(n + 1); T[n] = std::move(x); }
+            if (o.store_trace) c.trace_put(n, c.z.p);
             ++n;
             const double fNew = c.eval_f_step(c.z.p, 1.0, c.dz.p, c.zt.p);                 // t = x+p
             if (fNew < f && !vetoed(c, o)) {                                  // :170-177
@@ -1369,12 +1402,7 @@ static void loop_lm(Core &c, const dbat_hip_options &o, LoopOut &out) {
         prevLambda = lambda;
         if (n > o.max_iter) { out.code = -1; break; }
     }
-    if (o.store_trace) {
-        std::vector<double> x(c.P.n); c.z_to_x(c.z.p, x.data());
-        if ((int)T.size() <= n) T.resize(n + 1);
-        T[n] = std::move(x);
-        out.trace = std::move(T);
-    }
+    if (o.store_trace) c.trace_put(n, c.z.p);
     out.res.push_back(std::sqrt(2 * f));                                      // :242
     out.iters = n;
     out.f_final = f;
@@ -1386,8 +1414,7 @@ static void loop_lmp(Core &c, const dbat_hip_options &o, double delta0, LoopOut 
     int n = 0;
     double delta = delta0;
     std::vector<double> rhos, steps;
-    std::vector<std::vector<double>> T;
-    if (o.store_trace) { std::vector<double> x(c.P.n); c.z_to_x(c.z.p, x.data()); T.push_back(std::move(x)); }
+    if (o.store_trace) c.trace_put(0, c.z.p);
     double f = c.eval_f(c.z.p, nullptr, nullptr);
     c.build(c.z.p, 0.0, 1);
     bool have_gn = false;
@@ -1456,16 +1483,13 @@ static void loop_lmp(Core &c, const dbat_hip_options &o, double delta0, LoopOut 
             have_gn = false;
             if (rho >= o.rho_good) delta = delta * 2;
         }
-        if (o.store_trace) { std::vector<double> x(c.P.n); c.z_to_x(c.z.p, x.data()); if ((int)T.size() <= n) T.resize(n + 1); T[n] = std::move(x); }
+        if (o.store_trace) c.trace_put(n, c.z.p);
         ++n;
         if (n > o.max_iter) { out.code = -1; break; }
     }
     if (o.store_trace) {
-        std::vector<double> x(c.P.n); c.z_to_x(c.z.p, x.data());
-        if ((int)T.size() <= n) T.resize(n + 1);
-        T[n] = std::move(x);
-        T.resize(std::max(n, 1));                                  // :229 trims to 1:n
-        out.trace = std::move(T);
+        c.trace_put(n, c.z.p);
+        c.trace_truncate(std::max(n, 1));                          // :229 trims to 1:n
     }
     out.aux = rhos;
     out.aux.resize((size_t)o.max_iter + 2, NAN);
@@ -2011,6 +2035,7 @@ int dbat_hip_solve(dbat_hip_handle *h, const dbat_hip_options *opt, double *x, d
     Core &c = *h->core;
     DeviceGuard dev_guard(c.device);
     c.n_res_evals = c.n_lin = c.n_solves = c.n_trace_only = 0;
+    c.trace_begin();
     c.x_to_z(x, c.z.p);
     c.lambda_lin = NAN;
     LoopOut out;
@@ -2045,10 +2070,7 @@ int dbat_hip_solve(dbat_hip_handle *h, const dbat_hip_options *opt, double *x, d
     result->n_trace = 0;
     if (opt->store_trace && trace) {
         const int cap_t = opt->max_iter + 2;
-        result->n_trace = (int)std::min<size_t>(out.trace.size(), cap_t);
-        for (int k = 0; k < result->n_trace; ++k)
-            for (int64_t i = 0; i < c.P.n; ++i)
-                trace[(int64_t)k * c.P.n + i] = out.trace[k].empty() ? NAN : out.trace[k][i];
+        result->n_trace = c.trace_download(trace, cap_t);
     }
     const double dof = (double)(c.P.m - c.P.n);
     result->sigma0 = std::sqrt(2 * out.f_final / dof);            // bundle.m:476-483

@@ -165,7 +165,11 @@ def bundle(s, *args, device=None, comm=None, store_trace=True, jacobian=False, d
         no = s.IP.val.shape[1]
         s.post = getattr(s, 'post', NS())
         s.post.res = NS()
-        s.post.res.IP = ru[:2 * no].reshape(2, no, order='F') / s.IO.sensor.pxSize[:, s.IP.cam]
+        px = np.asarray(s.IO.sensor.pxSize)
+        if px.shape[1] == 1 or not (px != px[:, :1]).any():          # one pixel size for every camera: no 2 x nObs gather
+            s.post.res.IP = ru[:2 * no].reshape(2, no, order='F') / px[:, :1]
+        else:
+            s.post.res.IP = ru[:2 * no].reshape(2, no, order='F') / px[:, s.IP.cam]
         IOix, EOix, OPix = h.index_maps()
         ofs = 2 * no
         for nm, ixmap in (('IO', IOix), ('EO', EOix), ('OP', OPix)):
@@ -173,6 +177,9 @@ def bundle(s, *args, device=None, comm=None, store_trace=True, jacobian=False, d
             rows = slice(0, 6) if nm == 'EO' else slice(None)
             use = np.asarray(getattr(s.prior, nm).use, bool)[rows]
             arr = np.full(val[rows].shape, np.nan)
+            if not use.any():                                        # no prior observation of this kind: nothing to place
+                setattr(s.post.res, nm, arr)                         # (the leading-element map below sorts 3 x points entries)
+                continue
             # prior rows = column-major order of use & leading (buildserialindices.m:138-139,200)
             flatmap = ixmap.flatten('F')
             lead = np.zeros(flatmap.shape, bool)
