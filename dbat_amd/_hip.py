@@ -536,10 +536,15 @@ class Handle:
     def index_maps(self):
         """x index of every IO/EO/OP array entry (-1 = not an unknown); the
         deserial maps of misc/buildserialindices.m:204-221."""
-        big = 1e15
-        IO, EO, OP = self.deserialize(big + np.arange(self.n, dtype=float))
-        f = lambda a: np.where(a >= big / 2, np.rint(a - big), -1).astype(np.int64)
-        return f(IO), f(EO), f(OP)
+        if getattr(self, '_index_maps', None) is None:     # a matter of the structure: once per handle (read-only arrays)
+            big = 1e15
+            IO, EO, OP = self.deserialize(big + np.arange(self.n, dtype=float))
+            f = lambda a: np.where(a >= big / 2, np.rint(a - big), -1).astype(np.int64)
+            maps = f(IO), f(EO), f(OP)
+            for a in maps:
+                a.setflags(write=False)
+            self._index_maps = maps
+        return self._index_maps
 
     def posterior_cov(self, x, sigma0, want_sinv=False):
         """sigma0^2 * blocks of inv(J'J) at x (bundle_cov.m): CEO (nc,6,6), CIOu
