@@ -1046,13 +1046,19 @@ def test_bundle_reuses_the_cached_handle(hip, capsys):
     lines = [ln for ln in out.splitlines() if ln.startswith('Gauss-Newton-Armijo: iteration')]
     assert len(lines) == r1[2] + 1 and lines[0].endswith('residual norm=%.2g' % r1[4].res[0]) and 'last alpha=1' in lines[1]
     assert hip.cache_stats['misses'] == st['misses'] + 1 and hip.cache_stats['hits'] == st['hits']
-    r2 = bundle(r1[0], 'lm')                                          # from the result: same structure, other values
+    # from the result, pushed a little away from it: same structure, other values.  (LM started AT a converged point accepts or
+    # rejects its first steps by the last bits of f -- with the default mode's atomic sums a coin that fell on 'iteration cap'
+    # in one run of the suite out of six.)
+    t = copy.deepcopy(r1[0])
+    t.OP.val = t.OP.val + 1e-3 * np.cos(np.arange(t.OP.val.size, dtype=float)).reshape(t.OP.val.shape)
+    t.OP.val[~np.asarray(t.bundle.est.OP, bool)] = r1[0].OP.val[~np.asarray(t.bundle.est.OP, bool)]
+    r2 = bundle(t, 'lm')
     assert hip.cache_stats['hits'] == st['hits'] + 1 and hip.cache_stats['misses'] == st['misses'] + 1
     C1 = bundle_cov(r2[0], r2[4], 'CEO')
     assert hip.cache_stats['hits'] == st['hits'] + 2 and hip.cache_stats['misses'] == st['misses'] + 1
     # the same calls with handles of their own
     q1 = bundle(s, 'gna', reuse_handle=False)
-    q2 = bundle(q1[0], 'lm', reuse_handle=False)
+    q2 = bundle(copy.deepcopy(t), 'lm', reuse_handle=False)
     assert r1[2] == q1[2] and relerr(r1[4].x, q1[4].x) < 1e-9 and r2[1] and relerr(r2[4].x, q2[4].x) < 1e-9
     hip.clear_cache()
     C2 = bundle_cov(q2[0], q2[4], 'CEO')
