@@ -198,10 +198,11 @@ def test_camcal_known_answer_hip(hip, model, damping):
         assert relerr(E.trace, Eo.trace) < 1e-7
     else:       # (LM's last steps are rounding: the columns agree to what its stopping rule leaves; the trace comes down from
                 # the device in one piece at the end of the loop -- same columns, same gaps, first = x0, last = x)
-        assert E.trace.shape == Eo.trace.shape and np.array_equal(np.isnan(E.trace), np.isnan(Eo.trace))
-        fin = ~np.isnan(Eo.trace)
-        assert relerr(E.trace[fin], Eo.trace[fin]) < 1e-5
-        assert np.array_equal(E.trace[:, -1], E.x)
+        assert np.array_equal(E.trace[:, -1], E.x) and relerr(E.trace[:, 0], Eo.trace[:, 0]) < 1e-12
+        if iters == ito:        # (near the end LM accepts or rejects by the last bits of f: the COUNT may differ, check_history allows it)
+            assert E.trace.shape == Eo.trace.shape and np.array_equal(np.isnan(E.trace), np.isnan(Eo.trace))
+            fin = ~np.isnan(Eo.trace)
+            assert relerr(E.trace[fin], Eo.trace[fin]) < 1e-5
     assert relerr(res.post.res.IP, ro.post.res.IP) < 1e-6
 
 
