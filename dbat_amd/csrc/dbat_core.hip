@@ -659,6 +659,11 @@ struct Core {
         HIPCHK(hipStreamSynchronize(stream));
         for (int k = 0; k < nt; ++k)
             if (!trace_have[k]) std::fill(host + (size_t)P.n * k, host + (size_t)P.n * (k + 1), NAN);
+        if ((size_t)P.n * trace_cap * 8 > ((size_t)256 << 20)) {      // a kept handle does not sit on a large trace buffer
+            DevBuf<double> old;
+            std::swap(old.p, trace_dev.p);
+            trace_cap = 0;
+        }
         return nt;
     }
 
